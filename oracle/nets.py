@@ -1,0 +1,199 @@
+"""Generator / Discriminator of the three north-star scripts, restated on the oracle ops.
+
+Test infrastructure only.  Every random draw the reference makes inside these functions
+(tf.random_normal noise, tf.nn.dropout masks) is an explicit argument.
+  resnet : TF/CT_gan_cifar_resnet.py:67-186
+  cifar  : TF/CT_gan_cifar.py:47-100     (DCGAN, MODE 'wgan-CT')
+  mnist  : TF/CT_gan_mnist.py:39-108     (DCGAN, MODE 'wgan-CT')
+"""
+import functools
+
+import torch
+
+from . import tf_ops
+from . import tflib_ref as ops
+
+
+# ----------------------------------------------------------------------------- ResNet (CIFAR)
+class ResnetCfg:
+    """UPPERCASE globals of TF/CT_gan_cifar_resnet.py:33-56 that shape the nets."""
+    def __init__(self, DIM_G=128, DIM_D=128, OUTPUT_DIM=3072, CONDITIONAL=True, ACGAN=True,
+                 NORMALIZATION_G=True, NORMALIZATION_D=False):
+        self.DIM_G, self.DIM_D, self.OUTPUT_DIM = DIM_G, DIM_D, OUTPUT_DIM
+        self.CONDITIONAL, self.ACGAN = CONDITIONAL, ACGAN
+        self.NORMALIZATION_G, self.NORMALIZATION_D = NORMALIZATION_G, NORMALIZATION_D
+
+
+def Normalize(reg, cfg, name, inputs, labels=None):
+    """TF/CT_gan_cifar_resnet.py:70-87."""
+    if not cfg.CONDITIONAL:
+        labels = None
+    if cfg.CONDITIONAL and cfg.ACGAN and ('Discriminator' in name):
+        labels = None
+    if ('Discriminator' in name) and cfg.NORMALIZATION_D:
+        return ops.Layernorm(reg, name, [1, 2, 3], inputs)
+    elif ('Generator' in name) and cfg.NORMALIZATION_G:
+        if labels is not None:
+            return ops.CondBatchnorm(reg, name, [0, 2, 3], inputs, labels=labels, n_labels=10)
+        return ops.Batchnorm(reg, name, [0, 2, 3], inputs, fused=True)
+    return inputs
+
+
+def ConvMeanPool(reg, name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True):
+    """:89-92"""
+    out = ops.Conv2D(reg, name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases)
+    return tf_ops.mean_pool2(out)
+
+
+def MeanPoolConv(reg, name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True):
+    """:94-98"""
+    out = tf_ops.mean_pool2(inputs)
+    return ops.Conv2D(reg, name, input_dim, output_dim, filter_size, out, he_init=he_init, biases=biases)
+
+
+def UpsampleConv(reg, name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True):
+    """:100-107"""
+    out = tf_ops.upsample2(inputs)
+    return ops.Conv2D(reg, name, input_dim, output_dim, filter_size, out, he_init=he_init, biases=biases)
+
+
+def ResidualBlock(reg, cfg, name, input_dim, output_dim, filter_size, inputs, resample=None, labels=None):
+    """:109-141"""
+    if resample == 'down':
+        conv_1 = functools.partial(ops.Conv2D, reg, input_dim=input_dim, output_dim=input_dim)
+        conv_2 = functools.partial(ConvMeanPool, reg, input_dim=input_dim, output_dim=output_dim)
+        conv_shortcut = functools.partial(ConvMeanPool, reg)
+    elif resample == 'up':
+        conv_1 = functools.partial(UpsampleConv, reg, input_dim=input_dim, output_dim=output_dim)
+        conv_shortcut = functools.partial(UpsampleConv, reg)
+        conv_2 = functools.partial(ops.Conv2D, reg, input_dim=output_dim, output_dim=output_dim)
+    elif resample is None:
+        conv_shortcut = functools.partial(ops.Conv2D, reg)
+        conv_1 = functools.partial(ops.Conv2D, reg, input_dim=input_dim, output_dim=output_dim)
+        conv_2 = functools.partial(ops.Conv2D, reg, input_dim=output_dim, output_dim=output_dim)
+    else:
+        raise Exception('invalid resample value')
+
+    if output_dim == input_dim and resample is None:
+        shortcut = inputs
+    else:
+        shortcut = conv_shortcut(name + '.Shortcut', input_dim=input_dim, output_dim=output_dim,
+                                 filter_size=1, he_init=False, biases=True, inputs=inputs)
+    out = inputs
+    out = Normalize(reg, cfg, name + '.N1', out, labels=labels)
+    out = torch.relu(out)
+    out = conv_1(name + '.Conv1', filter_size=filter_size, inputs=out)
+    out = Normalize(reg, cfg, name + '.N2', out, labels=labels)
+    out = torch.relu(out)
+    out = conv_2(name + '.Conv2', filter_size=filter_size, inputs=out)
+    return shortcut + out
+
+
+def OptimizedResBlockDisc1(reg, cfg, inputs):
+    """:143-153"""
+    D = cfg.DIM_D
+    shortcut = MeanPoolConv(reg, 'Discriminator.1.Shortcut', input_dim=3, output_dim=D, filter_size=1,
+                            he_init=False, biases=True, inputs=inputs)
+    out = ops.Conv2D(reg, 'Discriminator.1.Conv1', 3, D, 3, inputs)
+    out = torch.relu(out)
+    out = ConvMeanPool(reg, 'Discriminator.1.Conv2', D, D, 3, out)
+    return shortcut + out
+
+
+def resnet_generator(reg, cfg, n_samples, labels, noise):
+    """Generator(n_samples, labels, noise) :155-167.  `noise` [n,128] is required (explicit draw)."""
+    G = cfg.DIM_G
+    out = ops.Linear(reg, 'Generator.Input', 128, 4 * 4 * G, noise)
+    out = out.reshape(-1, G, 4, 4)
+    out = ResidualBlock(reg, cfg, 'Generator.1', G, G, 3, out, resample='up', labels=labels)
+    out = ResidualBlock(reg, cfg, 'Generator.2', G, G, 3, out, resample='up', labels=labels)
+    out = ResidualBlock(reg, cfg, 'Generator.3', G, G, 3, out, resample='up', labels=labels)
+    out = Normalize(reg, cfg, 'Generator.OutputN', out)
+    out = torch.relu(out)
+    out = ops.Conv2D(reg, 'Generator.Output', G, 3, 3, out, he_init=False)
+    out = torch.tanh(out)
+    return out.reshape(-1, cfg.OUTPUT_DIM)
+
+
+def resnet_discriminator(reg, cfg, inputs, labels, kp1, kp2, kp3, u=None):
+    """Discriminator(inputs, labels, kp1, kp2, kp3) :169-186.
+    `u` = (u1,u2,u3): the three dropout uniforms, each [n,DIM_D,8,8]; may be None iff all kp == 1."""
+    D = cfg.DIM_D
+    u1, u2, u3 = u if u is not None else (None, None, None)
+    out = inputs.reshape(-1, 3, 32, 32)
+    out = OptimizedResBlockDisc1(reg, cfg, out)
+    out = ResidualBlock(reg, cfg, 'Discriminator.2', D, D, 3, out, resample='down', labels=labels)
+    out = tf_ops.dropout(out, kp1, u1)
+    out = ResidualBlock(reg, cfg, 'Discriminator.3', D, D, 3, out, resample=None, labels=labels)
+    out = tf_ops.dropout(out, kp2, u2)
+    out = ResidualBlock(reg, cfg, 'Discriminator.4', D, D, 3, out, resample=None, labels=labels)
+    out = tf_ops.dropout(out, kp3, u3)
+    out = torch.relu(out)
+    output2 = out.mean(dim=[2, 3])
+    output_wgan = ops.Linear(reg, 'Discriminator.Output', D, 1, output2).reshape(-1)
+    if cfg.CONDITIONAL and cfg.ACGAN:
+        output_acgan = ops.Linear(reg, 'Discriminator.ACGANOutput', D, 10, output2)
+        return output_wgan, output2, output_acgan
+    return output_wgan, output2, None
+
+
+# ----------------------------------------------------------------------------- DCGAN (CIFAR)
+def cifar_generator(reg, n_samples, noise, DIM=128, OUTPUT_DIM=3072):
+    """TF/CT_gan_cifar.py:58-79."""
+    out = ops.Linear(reg, 'Generator.Input', 128, 4 * 4 * 4 * DIM, noise)
+    out = ops.Batchnorm(reg, 'Generator.BN1', [0], out)
+    out = torch.relu(out)
+    out = out.reshape(-1, 4 * DIM, 4, 4)
+    out = ops.Deconv2D(reg, 'Generator.2', 4 * DIM, 2 * DIM, 5, out)
+    out = ops.Batchnorm(reg, 'Generator.BN2', [0, 2, 3], out)
+    out = torch.relu(out)
+    out = ops.Deconv2D(reg, 'Generator.3', 2 * DIM, DIM, 5, out)
+    out = ops.Batchnorm(reg, 'Generator.BN3', [0, 2, 3], out)
+    out = torch.relu(out)
+    out = ops.Deconv2D(reg, 'Generator.5', DIM, 3, 5, out)
+    out = torch.tanh(out)
+    return out.reshape(-1, OUTPUT_DIM)
+
+
+def cifar_discriminator(reg, inputs, u, DIM=128):
+    """TF/CT_gan_cifar.py:81-100 (MODE 'wgan-CT': no BN).  u = 3 dropout uniforms (keep 0.5)."""
+    out = inputs.reshape(-1, 3, 32, 32)
+    out = ops.Conv2D(reg, 'Discriminator.1', 3, DIM, 5, out, stride=2)
+    out = tf_ops.dropout(tf_ops.leaky_relu(out), 0.5, u[0])
+    out = ops.Conv2D(reg, 'Discriminator.2', DIM, 2 * DIM, 5, out, stride=2)
+    out = tf_ops.dropout(tf_ops.leaky_relu(out), 0.5, u[1])
+    out = ops.Conv2D(reg, 'Discriminator.3', 2 * DIM, 4 * DIM, 5, out, stride=2)
+    out = tf_ops.dropout(tf_ops.leaky_relu(out), 0.5, u[2])
+    output2 = out.reshape(-1, 4 * 4 * 4 * DIM)
+    out = ops.Linear(reg, 'Discriminator.Output', 4 * 4 * 4 * DIM, 1, output2)
+    return out.reshape(-1), output2
+
+
+# ----------------------------------------------------------------------------- DCGAN (MNIST)
+def mnist_generator(reg, n_samples, noise, DIM=64, OUTPUT_DIM=784):
+    """TF/CT_gan_mnist.py:62-87 (MODE 'wgan-CT': no BN)."""
+    out = ops.Linear(reg, 'Generator.Input', 128, 4 * 4 * 4 * DIM, noise)
+    out = torch.relu(out)
+    out = out.reshape(-1, 4 * DIM, 4, 4)
+    out = ops.Deconv2D(reg, 'Generator.2', 4 * DIM, 2 * DIM, 5, out)
+    out = torch.relu(out)
+    out = out[:, :, :7, :7]
+    out = ops.Deconv2D(reg, 'Generator.3', 2 * DIM, DIM, 5, out)
+    out = torch.relu(out)
+    out = ops.Deconv2D(reg, 'Generator.5', DIM, 1, 5, out)
+    out = torch.sigmoid(out)
+    return out.reshape(-1, OUTPUT_DIM)
+
+
+def mnist_discriminator(reg, inputs, u, DIM=64):
+    """TF/CT_gan_mnist.py:89-108."""
+    out = inputs.reshape(-1, 1, 28, 28)
+    out = ops.Conv2D(reg, 'Discriminator.1', 1, DIM, 5, out, stride=2)
+    out = tf_ops.dropout(tf_ops.leaky_relu(out), 0.5, u[0])
+    out = ops.Conv2D(reg, 'Discriminator.2', DIM, 2 * DIM, 5, out, stride=2)
+    out = tf_ops.dropout(tf_ops.leaky_relu(out), 0.5, u[1])
+    out = ops.Conv2D(reg, 'Discriminator.3', 2 * DIM, 4 * DIM, 5, out, stride=2)
+    out = tf_ops.dropout(tf_ops.leaky_relu(out), 0.5, u[2])
+    output2 = out.reshape(-1, 4 * 4 * 4 * DIM)
+    out = ops.Linear(reg, 'Discriminator.Output', 4 * 4 * 4 * DIM, 1, output2)
+    return out.reshape(-1), output2
