@@ -1,0 +1,110 @@
+"""ctypes binding of libctgan_hip.so (the C-ABI declared in include/ctgan_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or an entry point is
+absent this module raises at import, and every wrapper in `kernels.py` raises on non-HIP tensors.
+Build with `python __graft_entry__.py` (or `make -C ctgan_amd/csrc`).
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libctgan_hip.so')
+
+
+class ConvDesc(ctypes.Structure):
+    """struct ctgan_conv_desc (include/ctgan_hip.h)."""
+    _fields_ = [
+        ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32),
+        ('K', c_int32), ('R', c_int32), ('S', c_int32),
+        ('P', c_int32), ('Q', c_int32),
+        ('stride', c_int32), ('pad_t', c_int32), ('pad_l', c_int32),
+        ('x_up', c_int32), ('reserved', c_int32),
+        ('xs', c_int64 * 4), ('ys', c_int64 * 4),
+    ]
+
+
+I64x4 = c_int64 * 4
+I32x4 = c_int32 * 4
+_p = c_void_p          # device pointers and the stream travel as void*
+_D = POINTER(ConvDesc)
+
+# name -> (restype, argtypes); the single source the symbol-export test checks against the header
+SIGNATURES = {
+    'ctgan_version': (c_int, []),
+    'ctgan_last_error': (c_char_p, []),
+    'ctgan_last_kernel': (c_char_p, []),
+    'ctgan_conv2d_workspace_bytes': (c_size_t, [_D, c_int]),
+    'ctgan_conv2d_fwd': (c_int, [_D, _p, _p, _p, _p, _p, c_int, _p]),
+    'ctgan_conv2d_dgrad': (c_int, [_D, _p, _p, _p, _p, _p, c_size_t, _p]),
+    'ctgan_conv2d_wgrad': (c_int, [_D, _p, _p, _p, _p, c_size_t, _p]),
+    'ctgan_colsum': (c_int, [_p, c_int64, c_int32, c_int64, _p, _p, c_size_t, _p]),
+    'ctgan_colsum_workspace_bytes': (c_size_t, [c_int64, c_int32]),
+    'ctgan_lrelu_fwd': (c_int, [_p, _p, c_int64, c_float, _p]),
+    'ctgan_lrelu_bwd': (c_int, [_p, _p, _p, c_int64, c_float, _p]),
+    'ctgan_dropout': (c_int, [_p, _p, _p, c_int64, c_float, _p]),
+    'ctgan_tanh_fwd': (c_int, [_p, _p, c_int64, _p]),
+    'ctgan_tanh_bwd': (c_int, [_p, _p, _p, c_int64, _p]),
+    'ctgan_sigmoid_fwd': (c_int, [_p, _p, c_int64, _p]),
+    'ctgan_sigmoid_bwd': (c_int, [_p, _p, _p, c_int64, _p]),
+    'ctgan_axpby': (c_int, [_p, _p, _p, c_int64, c_float, c_float, _p]),
+    'ctgan_copy4d': (c_int, [_p, POINTER(c_int64), _p, POINTER(c_int64), POINTER(c_int32), _p]),
+    'ctgan_pool2': (c_int, [_p, POINTER(c_int64), _p, POINTER(c_int64), POINTER(c_int32), c_float, _p]),
+    'ctgan_upsample2': (c_int, [_p, POINTER(c_int64), _p, POINTER(c_int64), POINTER(c_int32), c_float, _p]),
+    'ctgan_spatial_sum': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
+    'ctgan_spatial_bcast': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
+    'ctgan_real_prep': (c_int, [_p, _p, _p, c_int64, c_float, _p]),
+    'ctgan_interpolate': (c_int, [_p, _p, _p, _p, c_int32, c_int32, _p]),
+    'ctgan_bn_stats': (c_int, [_p, c_int32, c_int32, c_int32, c_int32, c_float, _p, _p, _p, c_size_t, _p]),
+    'ctgan_bn_apply': (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32, _p]),
+    'ctgan_bn_bwd': (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                             c_int32, _p, c_size_t, _p]),
+    'ctgan_bn_workspace_bytes': (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    'ctgan_gp_fwd': (c_int, [_p, c_int32, c_int32, c_float, _p, _p, _p]),
+    'ctgan_gp_bwd': (c_int, [_p, _p, _p, c_int32, c_int32, c_float, _p, _p]),
+    'ctgan_ct_fwd': (c_int, [_p, _p, _p, _p, c_int32, c_int32, c_float, c_float, _p, _p, _p]),
+    'ctgan_ct_bwd': (c_int, [_p, _p, _p, _p, _p, _p, c_int32, c_int32, c_float, c_float, _p, _p, _p, _p, _p]),
+    'ctgan_softmax_ce_fwd': (c_int, [_p, _p, c_int32, c_int32, _p, _p, _p, _p]),
+    'ctgan_softmax_ce_bwd': (c_int, [_p, _p, _p, c_int32, c_int32, _p, _p]),
+    'ctgan_mean_diff_fwd': (c_int, [_p, c_int32, c_int32, c_float, c_float, _p, _p]),
+    'ctgan_mean_diff_bwd': (c_int, [_p, c_int32, c_int32, c_float, c_float, _p, _p]),
+    'ctgan_adam_step': (c_int, [_p, _p, _p, _p, c_int64, _p, c_float, c_float, c_float, c_float, _p]),
+    'ctgan_adam_advance': (c_int, [_p, c_float, c_float, _p]),
+    'ctgan_rng_uniform': (c_int, [_p, c_int64, c_uint64, c_uint64, _p, c_float, c_float, _p]),
+    'ctgan_rng_normal': (c_int, [_p, c_int64, c_uint64, c_uint64, _p, _p]),
+    'ctgan_rng_labels': (c_int, [_p, c_int64, c_int32, c_uint64, c_uint64, _p, _p]),
+    'ctgan_rng_advance': (c_int, [_p, c_uint64, _p]),
+}
+
+
+class CtganError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'ctgan_amd: %s is missing - build the HIP extension first (python __graft_entry__.py, or '
+            'make -C ctgan_amd/csrc).  There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError('ctgan_amd: %s does not export %s (stale build?)' % (LIB_PATH, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib.ctgan_last_error().decode(errors='replace')
+        if rc == -2:
+            raise NotImplementedError('%s: %s' % (what, msg))
+        if rc == -1:
+            raise ValueError('%s: %s' % (what, msg))
+        raise CtganError('%s failed (%d): %s' % (what, rc, msg))

@@ -1,0 +1,258 @@
+// bn.hip - training-mode batch normalisation for the generator.
+//   cond_batchnorm.Batchnorm (TF/tflib/ops/cond_batchnorm.py:10-16): moments over (n,h,w),
+//     per-sample scale/offset gathered by label from [n_labels, C]
+//   batchnorm.Batchnorm fused path (TF/tflib/ops/batchnorm.py:29-30) and axes=[0] path (:77-84)
+// x is channels-last [n, hw, c].  `groups` splits the batch into independent statistic groups
+// (the reference evaluates one generator tower per device, each with its own batch statistics).
+// Reductions are two-stage and fixed-order (deterministic); sums are carried in fp64 because
+// E[x^2]-E[x]^2 cancels catastrophically in fp32 for |mean| >> std.
+#include "common.h"
+
+namespace {
+
+constexpr int CB = 64;      // channels per workgroup (one 256-byte row segment per wave load)
+constexpr int RL = 4;       // row lanes per workgroup
+constexpr int POS = 64;     // spatial positions per workgroup
+
+struct BnShape { int n, hw, c, groups, hc; };
+
+__device__ __forceinline__ int chunk_count(int hw) { return (hw + POS - 1) / POS; }
+
+// part[(sample*hc + chunk)][2][c] (double): sum x, sum x^2 over the chunk's positions
+__global__ __launch_bounds__(CB * RL) void bn_stats_partial_kernel(const float* __restrict__ x, BnShape s,
+                                                                  double* __restrict__ part) {
+    __shared__ double red[2][RL][CB];
+    const int cl = threadIdx.x % CB, rl = threadIdx.x / CB;
+    const int c = blockIdx.y * CB + cl;
+    const int sample = blockIdx.x / s.hc, chunk = blockIdx.x - sample * s.hc;
+    const int p0 = chunk * POS, p1 = min(s.hw, p0 + POS);
+    double a = 0., b = 0.;
+    if (c < s.c) {
+        const float* base = x + ((long long)sample * s.hw) * s.c + c;
+        for (int p = p0 + rl; p < p1; p += RL) {
+            const double v = base[(long long)p * s.c];
+            a += v; b += v * v;
+        }
+    }
+    red[0][rl][cl] = a; red[1][rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < s.c) {
+        double sa = 0., sb = 0.;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) { sa += red[0][r][cl]; sb += red[1][r][cl]; }
+        double* o = part + (long long)blockIdx.x * 2 * s.c;
+        o[c] = sa; o[s.c + c] = sb;
+    }
+}
+
+__global__ void bn_stats_final_kernel(const double* __restrict__ part, BnShape s, float eps, float* __restrict__ mean,
+                                      float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (c >= s.c) return;
+    const int per = s.n / s.groups;
+    double a = 0., b = 0.;
+    for (int i = g * per * s.hc; i < (g + 1) * per * s.hc; ++i) {
+        a += part[(long long)i * 2 * s.c + c];
+        b += part[(long long)i * 2 * s.c + s.c + c];
+    }
+    const double cnt = (double)per * s.hw;
+    const double m = a / cnt;
+    double var = b / cnt - m * m;
+    if (var < 0.) var = 0.;
+    mean[g * s.c + c] = (float)m;
+    rstd[g * s.c + c] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ scale, const float* __restrict__ offset,
+                                const int32_t* __restrict__ labels, float* __restrict__ y, BnShape s, int relu) {
+    const long long total = (long long)s.n * s.hw * s.c;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int per = s.n / s.groups;
+    const long long hwc = (long long)s.hw * s.c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = i % s.c;
+        const int sample = i / hwc;
+        const int g = sample / per;
+        const int lab = labels ? labels[sample] : 0;
+        float v = (x[i] - mean[g * s.c + c]) * rstd[g * s.c + c] * scale[lab * s.c + c] + offset[lab * s.c + c];
+        if (relu) v = fmaxf(v, 0.f);
+        y[i] = v;
+    }
+}
+
+// part[(sample*hc+chunk)][2][c] (double): sum g, sum g*xhat, with g = relu-masked gy
+__global__ __launch_bounds__(CB * RL) void bn_bwd_partial_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ offset,
+    const int32_t* __restrict__ labels, BnShape s, int relu, double* __restrict__ part) {
+    __shared__ double red[2][RL][CB];
+    const int cl = threadIdx.x % CB, rl = threadIdx.x / CB;
+    const int c = blockIdx.y * CB + cl;
+    const int sample = blockIdx.x / s.hc, chunk = blockIdx.x - sample * s.hc;
+    const int p0 = chunk * POS, p1 = min(s.hw, p0 + POS);
+    double a = 0., b = 0.;
+    if (c < s.c) {
+        const int g = sample / (s.n / s.groups);
+        const int lab = labels ? labels[sample] : 0;
+        const float mu = mean[g * s.c + c], rs = rstd[g * s.c + c];
+        const float ga = scale[lab * s.c + c], be = offset[lab * s.c + c];
+        const long long base = ((long long)sample * s.hw) * s.c + c;
+        for (int p = p0 + rl; p < p1; p += RL) {
+            const long long o = base + (long long)p * s.c;
+            const float xh = (x[o] - mu) * rs;
+            float gg = gy[o];
+            if (relu && !(xh * ga + be > 0.f)) gg = 0.f;
+            a += gg; b += (double)gg * xh;
+        }
+    }
+    red[0][rl][cl] = a; red[1][rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < s.c) {
+        double sa = 0., sb = 0.;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) { sa += red[0][r][cl]; sb += red[1][r][cl]; }
+        double* o = part + (long long)blockIdx.x * 2 * s.c;
+        o[c] = sa; o[s.c + c] = sb;
+    }
+}
+
+// one thread per channel: walks the samples in order (deterministic), fills the label bins of
+// gscale/goffset and the per-group sums s12[g][2][c] = { sum dxhat, sum dxhat*xhat } / count
+__global__ void bn_bwd_final_kernel(const double* __restrict__ part, const float* __restrict__ scale,
+                                    const int32_t* __restrict__ labels, BnShape s, int n_labels,
+                                    float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ s12) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= s.c) return;
+    const int per = s.n / s.groups;
+    for (int l = 0; l < n_labels; ++l) { gscale[l * s.c + c] = 0.f; goffset[l * s.c + c] = 0.f; }
+    // label bins in fp64 registers are not indexable without scratch; accumulate through a second
+    // pass per label instead (n_labels <= 10, n <= a few hundred: negligible work)
+    for (int l = 0; l < n_labels; ++l) {
+        double da = 0., db = 0.;
+        for (int sample = 0; sample < s.n; ++sample) {
+            const int lab = labels ? labels[sample] : 0;
+            if (lab != l) continue;
+            for (int k = 0; k < s.hc; ++k) {
+                const long long i = (long long)(sample * s.hc + k) * 2 * s.c;
+                da += part[i + c]; db += part[i + s.c + c];
+            }
+        }
+        goffset[l * s.c + c] = (float)da;
+        gscale[l * s.c + c] = (float)db;
+    }
+    const double cnt = (double)per * s.hw;
+    for (int g = 0; g < s.groups; ++g) {
+        double s1 = 0., s2 = 0.;
+        for (int sample = g * per; sample < (g + 1) * per; ++sample) {
+            const int lab = labels ? labels[sample] : 0;
+            const double ga = scale[lab * s.c + c];
+            for (int k = 0; k < s.hc; ++k) {
+                const long long i = (long long)(sample * s.hc + k) * 2 * s.c;
+                s1 += part[i + c] * ga; s2 += part[i + s.c + c] * ga;
+            }
+        }
+        s12[(g * 2 + 0) * s.c + c] = (float)(s1 / cnt);
+        s12[(g * 2 + 1) * s.c + c] = (float)(s2 / cnt);
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ scale, const float* __restrict__ offset,
+                                    const int32_t* __restrict__ labels, const float* __restrict__ s12,
+                                    float* __restrict__ gx, BnShape s, int relu) {
+    const long long total = (long long)s.n * s.hw * s.c;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int per = s.n / s.groups;
+    const long long hwc = (long long)s.hw * s.c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = i % s.c;
+        const int sample = i / hwc;
+        const int g = sample / per;
+        const int lab = labels ? labels[sample] : 0;
+        const float rs = rstd[g * s.c + c];
+        const float xh = (x[i] - mean[g * s.c + c]) * rs;
+        const float ga = scale[lab * s.c + c];
+        float gg = gy[i];
+        if (relu && !(xh * ga + offset[lab * s.c + c] > 0.f)) gg = 0.f;
+        gx[i] = rs * (gg * ga - s12[(g * 2 + 0) * s.c + c] - xh * s12[(g * 2 + 1) * s.c + c]);
+    }
+}
+
+int check_shape(int n, int hw, int c, int groups, const char* who) {
+    if (n <= 0 || hw <= 0 || c <= 0 || groups <= 0 || n % groups) return ctgan_fail(CTGAN_E_BADARG, "%s: bad shape", who);
+    return 0;
+}
+BnShape mk(int n, int hw, int c, int groups) { return BnShape{n, hw, c, groups, (hw + POS - 1) / POS}; }
+size_t part_bytes(const BnShape& s) { return (size_t)s.n * s.hc * 2 * s.c * sizeof(double); }
+
+}  // namespace
+
+extern "C" {
+
+size_t ctgan_bn_workspace_bytes(int32_t n, int32_t hw, int32_t c, int32_t groups, int32_t n_labels) {
+    (void)n_labels;
+    if (n <= 0 || hw <= 0 || c <= 0 || groups <= 0) return 0;
+    const BnShape s = mk(n, hw, c, groups);
+    return part_bytes(s) + (size_t)groups * 2 * c * sizeof(float);
+}
+
+int ctgan_bn_stats(const float* x, int32_t n, int32_t hw, int32_t c, int32_t groups, float eps, float* mean, float* rstd,
+                   void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+    int rc = check_shape(n, hw, c, groups, "bn_stats");
+    if (rc) return rc;
+    if (!x || !mean || !rstd || !ws) return ctgan_fail(CTGAN_E_BADARG, "bn_stats: null");
+    const BnShape s = mk(n, hw, c, groups);
+    if (ws_bytes < part_bytes(s)) return ctgan_fail(CTGAN_E_BADARG, "bn_stats: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(n * s.hc, (c + CB - 1) / CB), dim3(CB * RL), 0, st, x, s,
+                       static_cast<double*>(ws));
+    rc = ctgan_check_launch("bn_stats_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 127) / 128, groups), dim3(128), 0, st,
+                       static_cast<const double*>(ws), s, eps, mean, rstd);
+    return ctgan_check_launch("bn_stats_final");
+}
+
+int ctgan_bn_apply(const float* x, const float* mean, const float* rstd, const float* scale, const float* offset,
+                   const int32_t* labels, float* y, int32_t n, int32_t hw, int32_t c, int32_t groups, int32_t relu,
+                   ctgan_stream_t stream) {
+    int rc = check_shape(n, hw, c, groups, "bn_apply");
+    if (rc) return rc;
+    if (!x || !mean || !rstd || !scale || !offset || !y) return ctgan_fail(CTGAN_E_BADARG, "bn_apply: null");
+    const BnShape s = mk(n, hw, c, groups);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ctgan_blocks((long long)n * hw * c, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, mean, rstd, scale, offset, labels, y, s, relu);
+    return ctgan_check_launch("bn_apply");
+}
+
+int ctgan_bn_bwd(const float* gy, const float* x, const float* mean, const float* rstd, const float* scale,
+                 const float* offset, const int32_t* labels, float* gx, float* gscale, float* goffset, int32_t n,
+                 int32_t hw, int32_t c, int32_t groups, int32_t n_labels, int32_t relu, void* ws, size_t ws_bytes,
+                 ctgan_stream_t stream) {
+    int rc = check_shape(n, hw, c, groups, "bn_bwd");
+    if (rc) return rc;
+    if (!gy || !x || !mean || !rstd || !scale || !offset || !gx || !gscale || !goffset || !ws || n_labels <= 0)
+        return ctgan_fail(CTGAN_E_BADARG, "bn_bwd: bad argument");
+    const BnShape s = mk(n, hw, c, groups);
+    if (ws_bytes < part_bytes(s) + (size_t)groups * 2 * c * sizeof(float))
+        return ctgan_fail(CTGAN_E_BADARG, "bn_bwd: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(ws);
+    float* s12 = reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(s));
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(n * s.hc, (c + CB - 1) / CB), dim3(CB * RL), 0, st, gy, x, mean, rstd,
+                       scale, offset, labels, s, relu, part);
+    rc = ctgan_check_launch("bn_bwd_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 63) / 64), dim3(64), 0, st, part, scale, labels, s, n_labels, gscale,
+                       goffset, s12);
+    rc = ctgan_check_launch("bn_bwd_final");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ctgan_blocks((long long)n * hw * c, 256)), dim3(256), 0, st, gy, x, mean,
+                       rstd, scale, offset, labels, s12, gx, s, relu);
+    return ctgan_check_launch("bn_bwd_apply");
+}
+
+}  // extern "C"

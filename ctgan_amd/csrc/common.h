@@ -1,0 +1,21 @@
+// common.h - shared host-side helpers of libctgan_hip.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/ctgan_hip.h"
+
+// thread-local last-error message (no exception crosses the C ABI)
+int ctgan_fail(int code, const char* fmt, ...);
+// hipGetLastError() after a launch -> CTGAN_E_LAUNCH with the HIP error string
+int ctgan_check_launch(const char* what);
+// split-K plan of the weight-gradient GEMM (shared by the launcher and the workspace query)
+void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk);
+
+static inline unsigned ctgan_blocks(long long n, int per_block, int cap = 4096) {
+    long long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}

@@ -1,0 +1,309 @@
+// elementwise.hip - HBM-bound helpers of the CT-WGAN step.
+// All are grid-stride kernels; contiguous fp32 streams use 16-byte accesses when aligned.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+template <typename F>
+__global__ void map1_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, F f) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n4 = n >> 2;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+        for (long long v = i; v < n4; v += stride) {
+            float4 a = reinterpret_cast<const float4*>(x)[v];
+            a.x = f(a.x); a.y = f(a.y); a.z = f(a.z); a.w = f(a.w);
+            reinterpret_cast<float4*>(y)[v] = a;
+        }
+        for (long long t = (n4 << 2) + i; t < n; t += stride) y[t] = f(x[t]);
+    } else {
+        for (; i < n; i += stride) y[i] = f(x[i]);
+    }
+}
+
+template <typename F>
+__global__ void map2_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y,
+                            long long n, F f) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n4 = n >> 2;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z)) & 15) == 0) {
+        for (long long v = i; v < n4; v += stride) {
+            float4 a = reinterpret_cast<const float4*>(x)[v];
+            const float4 b = reinterpret_cast<const float4*>(z)[v];
+            a.x = f(a.x, b.x); a.y = f(a.y, b.y); a.z = f(a.z, b.z); a.w = f(a.w, b.w);
+            reinterpret_cast<float4*>(y)[v] = a;
+        }
+        for (long long t = (n4 << 2) + i; t < n; t += stride) y[t] = f(x[t], z[t]);
+    } else {
+        for (; i < n; i += stride) y[i] = f(x[i], z[i]);
+    }
+}
+
+template <typename F>
+int launch1(const float* x, float* y, long long n, F f, ctgan_stream_t s, const char* who) {
+    if (n < 0 || (n > 0 && (!x || !y))) return ctgan_fail(CTGAN_E_BADARG, "%s: bad argument", who);
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(map1_kernel<F>, dim3(ctgan_blocks((n + 3) / 4, TPB, 2048)), dim3(TPB), 0,
+                       static_cast<hipStream_t>(s), x, y, n, f);
+    return ctgan_check_launch(who);
+}
+template <typename F>
+int launch2(const float* x, const float* z, float* y, long long n, F f, ctgan_stream_t s, const char* who) {
+    if (n < 0 || (n > 0 && (!x || !y || !z))) return ctgan_fail(CTGAN_E_BADARG, "%s: bad argument", who);
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(map2_kernel<F>, dim3(ctgan_blocks((n + 3) / 4, TPB, 2048)), dim3(TPB), 0,
+                       static_cast<hipStream_t>(s), x, z, y, n, f);
+    return ctgan_check_launch(who);
+}
+
+struct LReluF { float a; __device__ float operator()(float x) const { return x > 0.f ? x : a * x; } };
+struct LReluB { float a; __device__ float operator()(float g, float r) const { return r > 0.f ? g : a * g; } };
+struct DropF { float keep, inv; __device__ float operator()(float x, float u) const { return x * inv * floorf(keep + u); } };
+struct TanhF { __device__ float operator()(float x) const { return tanhf(x); } };
+struct TanhB { __device__ float operator()(float g, float y) const { return g * (1.f - y * y); } };
+struct SigF { __device__ float operator()(float x) const { return 1.f / (1.f + expf(-x)); } };
+struct SigB { __device__ float operator()(float g, float y) const { return g * y * (1.f - y); } };
+struct ScaleF { float a; __device__ float operator()(float x) const { return a * x; } };
+struct AxpbyF { float a, b; __device__ float operator()(float x, float y) const { return a * x + b * y; } };
+
+struct Dims4 { int d[4]; long long xs[4], ys[4]; };
+
+__global__ void copy4d_kernel(const float* __restrict__ x, float* __restrict__ y, Dims4 p, long long n) {
+    // iterate in the OUTPUT's fastest-varying order so writes coalesce: order[] sorts dims by ys
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long t = i;
+        const int i3 = t % p.d[3]; t /= p.d[3];
+        const int i2 = t % p.d[2]; t /= p.d[2];
+        const int i1 = t % p.d[1]; const int i0 = t / p.d[1];
+        y[i0 * p.ys[0] + i1 * p.ys[1] + i2 * p.ys[2] + i3 * p.ys[3]] =
+            x[i0 * p.xs[0] + i1 * p.xs[1] + i2 * p.xs[2] + i3 * p.xs[3]];
+    }
+}
+
+// y[n,c,p,q] = scale * (x[n,c,2p,2q] + x[n,c,2p+1,2q] + x[n,c,2p,2q+1] + x[n,c,2p+1,2q+1])
+// iteration order (n,p,q,c): c fastest, matching channels-last tensors
+__global__ void pool2_kernel(const float* __restrict__ x, float* __restrict__ y, Dims4 p, float scale, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int N = p.d[0], C = p.d[1], P = p.d[2], Q = p.d[3];
+    (void)N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long t = i;
+        const int c = t % C; t /= C;
+        const int q = t % Q; t /= Q;
+        const int pp = t % P; const int nn = t / P;
+        const float* b = x + nn * p.xs[0] + c * p.xs[1] + (2 * pp) * p.xs[2] + (2 * q) * p.xs[3];
+        const float v = (b[0] + b[p.xs[2]]) + (b[p.xs[3]] + b[p.xs[2] + p.xs[3]]);
+        y[nn * p.ys[0] + c * p.ys[1] + pp * p.ys[2] + q * p.ys[3]] = scale * v;
+    }
+}
+
+__global__ void upsample2_kernel(const float* __restrict__ x, float* __restrict__ y, Dims4 p, float scale, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int C = p.d[1], H = p.d[2], W = p.d[3];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        long long t = i;
+        const int c = t % C; t /= C;
+        const int w = t % W; t /= W;
+        const int h = t % H; const int nn = t / H;
+        y[nn * p.ys[0] + c * p.ys[1] + h * p.ys[2] + w * p.ys[3]] =
+            scale * x[nn * p.xs[0] + c * p.xs[1] + (h >> 1) * p.xs[2] + (w >> 1) * p.xs[3]];
+    }
+}
+
+// x [n, hw, c] channels-last -> y[n,c] = scale * sum_hw ; one thread per (n,c), coalesced over c
+__global__ void spatial_sum_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int hw, int c, float scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * c) return;
+    const int nn = i / c, cc = i - (long long)nn * c;
+    const float* b = x + (long long)nn * hw * c + cc;
+    float s = 0.f;
+    for (int k = 0; k < hw; ++k) s += b[(long long)k * c];
+    y[i] = scale * s;
+}
+
+__global__ void spatial_bcast_kernel(const float* __restrict__ g, float* __restrict__ y, int n, int hw, int c, float scale) {
+    const long long total = (long long)n * hw * c;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int cc = i % c; const long long nn = i / ((long long)hw * c);
+        y[i] = scale * g[nn * c + cc];
+    }
+}
+
+__global__ void real_prep_kernel(const int32_t* __restrict__ xi, const float* __restrict__ noise, float* __restrict__ y,
+                                 long long n, float denom) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = 2.f * (((float)xi[i] / denom) - .5f);
+        if (noise) v += noise[i];
+        y[i] = v;
+    }
+}
+
+__global__ void interpolate_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                   const float* __restrict__ alpha, float* __restrict__ out, int b, int d) {
+    const long long total = (long long)b * d;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float r = real[i];
+        out[i] = r + alpha[i / d] * (fake[i] - r);
+    }
+}
+
+// column sums: stage 1 - each block sums a row range for all columns; stage 2 - sum partials
+__global__ void colsum_partial_kernel(const float* __restrict__ x, long long rows, int cols, long long ld,
+                                      float* __restrict__ part, int rows_per_block) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+        float s = 0.f;
+        for (long long r = r0; r < r1; ++r) s += x[r * ld + j];
+        part[(long long)blockIdx.x * cols + j] = s;
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long long)b * cols + j];
+    out[j] = s;
+}
+
+int colsum_plan(long long rows, int* rows_per_block) {
+    int nblk = (int)((rows + 63) / 64);
+    if (nblk > 1024) nblk = 1024;
+    if (nblk < 1) nblk = 1;
+    *rows_per_block = (int)((rows + nblk - 1) / nblk);
+    return (int)((rows + *rows_per_block - 1) / *rows_per_block);
+}
+
+Dims4 mk(const int32_t dims[4], const int64_t xs[4], const int64_t ys[4]) {
+    Dims4 p;
+    for (int i = 0; i < 4; ++i) { p.d[i] = dims[i]; p.xs[i] = xs[i]; p.ys[i] = ys[i]; }
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctgan_lrelu_fwd(const float* x, float* y, int64_t n, float alpha, ctgan_stream_t s) {
+    return launch1(x, y, n, LReluF{alpha}, s, "lrelu_fwd");
+}
+int ctgan_lrelu_bwd(const float* gy, const float* ref, float* gx, int64_t n, float alpha, ctgan_stream_t s) {
+    return launch2(gy, ref, gx, n, LReluB{alpha}, s, "lrelu_bwd");
+}
+int ctgan_dropout(const float* x, const float* u, float* y, int64_t n, float keep, ctgan_stream_t s) {
+    if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "dropout: keep=%g not in (0,1]", keep);
+    return launch2(x, u, y, n, DropF{keep, 1.f / keep}, s, "dropout");
+}
+int ctgan_tanh_fwd(const float* x, float* y, int64_t n, ctgan_stream_t s) { return launch1(x, y, n, TanhF{}, s, "tanh_fwd"); }
+int ctgan_tanh_bwd(const float* gy, const float* y, float* gx, int64_t n, ctgan_stream_t s) {
+    return launch2(gy, y, gx, n, TanhB{}, s, "tanh_bwd");
+}
+int ctgan_sigmoid_fwd(const float* x, float* y, int64_t n, ctgan_stream_t s) { return launch1(x, y, n, SigF{}, s, "sigmoid_fwd"); }
+int ctgan_sigmoid_bwd(const float* gy, const float* y, float* gx, int64_t n, ctgan_stream_t s) {
+    return launch2(gy, y, gx, n, SigB{}, s, "sigmoid_bwd");
+}
+int ctgan_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, ctgan_stream_t s) {
+    if (!y) return launch1(x, out, n, ScaleF{a}, s, "axpby");
+    return launch2(x, y, out, n, AxpbyF{a, b}, s, "axpby");
+}
+
+int ctgan_copy4d(const float* x, const int64_t xs[4], float* y, const int64_t ys[4], const int32_t dims[4],
+                 ctgan_stream_t s) {
+    if (!x || !y || !xs || !ys || !dims) return ctgan_fail(CTGAN_E_BADARG, "copy4d: null");
+    // walk in the order that makes the output's unit-stride dim fastest
+    int order[4] = {0, 1, 2, 3};
+    for (int a = 0; a < 4; ++a)
+        for (int b = a + 1; b < 4; ++b)
+            if (ys[order[b]] > ys[order[a]]) { int t = order[a]; order[a] = order[b]; order[b] = t; }
+    int32_t d2[4]; int64_t xs2[4], ys2[4];
+    long long n = 1;
+    for (int i = 0; i < 4; ++i) { d2[i] = dims[order[i]]; xs2[i] = xs[order[i]]; ys2[i] = ys[order[i]]; n *= dims[i]; }
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(copy4d_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), x, y,
+                       mk(d2, xs2, ys2), n);
+    return ctgan_check_launch("copy4d");
+}
+
+int ctgan_pool2(const float* x, const int64_t xs[4], float* y, const int64_t ys[4], const int32_t ydims[4], float scale,
+                ctgan_stream_t s) {
+    if (!x || !y) return ctgan_fail(CTGAN_E_BADARG, "pool2: null");
+    long long n = 1;
+    for (int i = 0; i < 4; ++i) n *= ydims[i];
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(pool2_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), x, y,
+                       mk(ydims, xs, ys), scale, n);
+    return ctgan_check_launch("pool2");
+}
+
+int ctgan_upsample2(const float* x, const int64_t xs[4], float* y, const int64_t ys[4], const int32_t ydims[4],
+                    float scale, ctgan_stream_t s) {
+    if (!x || !y) return ctgan_fail(CTGAN_E_BADARG, "upsample2: null");
+    if (ydims[2] % 2 || ydims[3] % 2) return ctgan_fail(CTGAN_E_BADARG, "upsample2: odd output size");
+    long long n = 1;
+    for (int i = 0; i < 4; ++i) n *= ydims[i];
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(upsample2_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), x, y,
+                       mk(ydims, xs, ys), scale, n);
+    return ctgan_check_launch("upsample2");
+}
+
+int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale, ctgan_stream_t s) {
+    if (!x || !y || n <= 0 || hw <= 0 || c <= 0) return ctgan_fail(CTGAN_E_BADARG, "spatial_sum: bad argument");
+    const long long t = (long long)n * c;
+    hipLaunchKernelGGL(spatial_sum_kernel, dim3((unsigned)((t + TPB - 1) / TPB)), dim3(TPB), 0,
+                       static_cast<hipStream_t>(s), x, y, n, hw, c, scale);
+    return ctgan_check_launch("spatial_sum");
+}
+int ctgan_spatial_bcast(const float* g, float* y, int32_t n, int32_t hw, int32_t c, float scale, ctgan_stream_t s) {
+    if (!g || !y || n <= 0 || hw <= 0 || c <= 0) return ctgan_fail(CTGAN_E_BADARG, "spatial_bcast: bad argument");
+    hipLaunchKernelGGL(spatial_bcast_kernel, dim3(ctgan_blocks((long long)n * hw * c, TPB)), dim3(TPB), 0,
+                       static_cast<hipStream_t>(s), g, y, n, hw, c, scale);
+    return ctgan_check_launch("spatial_bcast");
+}
+
+int ctgan_real_prep(const int32_t* x_int, const float* noise, float* y, int64_t n, float denom, ctgan_stream_t s) {
+    if (!x_int || !y || n < 0 || denom == 0.f) return ctgan_fail(CTGAN_E_BADARG, "real_prep: bad argument");
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(real_prep_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), x_int,
+                       noise, y, (long long)n, denom);
+    return ctgan_check_launch("real_prep");
+}
+
+int ctgan_interpolate(const float* real, const float* fake, const float* alpha, float* out, int32_t b, int32_t d,
+                      ctgan_stream_t s) {
+    if (!real || !fake || !alpha || !out || b <= 0 || d <= 0) return ctgan_fail(CTGAN_E_BADARG, "interpolate: bad argument");
+    hipLaunchKernelGGL(interpolate_kernel, dim3(ctgan_blocks((long long)b * d, TPB)), dim3(TPB), 0,
+                       static_cast<hipStream_t>(s), real, fake, alpha, out, b, d);
+    return ctgan_check_launch("interpolate");
+}
+
+size_t ctgan_colsum_workspace_bytes(int64_t rows, int32_t cols) {
+    int rpb;
+    const int nblk = colsum_plan(rows, &rpb);
+    return (size_t)nblk * cols * sizeof(float);
+}
+
+int ctgan_colsum(const float* x, int64_t rows, int32_t cols, int64_t ld, float* out, void* ws, size_t ws_bytes,
+                 ctgan_stream_t s) {
+    if (!x || !out || rows <= 0 || cols <= 0) return ctgan_fail(CTGAN_E_BADARG, "colsum: bad argument");
+    int rpb;
+    const int nblk = colsum_plan(rows, &rpb);
+    if (!ws || ws_bytes < (size_t)nblk * cols * sizeof(float)) return ctgan_fail(CTGAN_E_BADARG, "colsum: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(cols >= 256 ? 256 : (cols + 63) / 64 * 64), 0, st, x,
+                       (long long)rows, cols, (long long)ld, static_cast<float*>(ws), rpb);
+    int rc = ctgan_check_launch("colsum_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws),
+                       nblk, cols, out);
+    return ctgan_check_launch("colsum_final");
+}
+
+}  // extern "C"

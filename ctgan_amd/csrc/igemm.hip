@@ -1,0 +1,737 @@
+// igemm.hip - implicit-GEMM convolution family on gfx950 fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// One gather-GEMM template serves every conv-shaped op of the CT-WGAN step:
+//   FWD   : D[m=(n,p,q)][j=k]     = sum_{(r,s,c)} X(n, p*st-pt+r, q*st-pl+s, c) * Wt(r,s,c,k)
+//   DGRAD : the same kernel on dy with flipped / transposed filter taps and an input dilation
+//           (dx = conv of the stride-dilated dy with the 180-degree-rotated filter)
+//   WGRAD : D[m=(r,s,c)][j=k]     = sum_{(n,p,q)} X(n, p*st-pt+r, q*st-pl+s, c) * dy[n,p,q,k]
+//           split over the pixel axis into per-block partial slabs + a fixed-order reduction
+//           (deterministic: no float atomics).
+// X() applies zero padding, the stride dilation of a transposed conv and the nearest-2x upsample
+// of UpsampleConv on the fly, so none of those tensors is ever materialised.
+//
+// Tiling (MI355X: 256 CUs, 4 SIMDs, 64-wide waves): a workgroup is 4 waves; a wave owns TM x TN
+// 32x32 MFMA accumulators; the K loop walks 32-deep slices staged through LDS with register
+// prefetch of the next slice (global -> VGPR before the MFMAs, VGPR -> LDS after the barrier).
+// Within a slice lane-half h=lane>>5 consumes k = 16h..16h+15, so the A fragment of a pixel row
+// is 16 contiguous floats (4 x ds_read_b128, row stride 36 floats = conflict-free) and the B
+// fragment is one ds_read_b32 per MFMA.  fp32 MFMA is exact fp32 (fmaf chain), 64 cycles per
+// instruction, so 4 waves x 4 accumulators already saturate the matrix pipe; everything else
+// hides behind it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDA 36  // k-contiguous A tile row stride (floats): 16-B aligned, ds_read_b128 conflict-free
+
+namespace {
+
+struct Geom {               // how the pixel-indexed operand is gathered
+    int H, W;               // physical source height/width
+    int P, Q;               // pixel grid the GEMM rows (FWD) or K axis (WGRAD) enumerate
+    int R, S, C;            // taps and channels per tap
+    int stride, pad_t, pad_l;
+    int shift, mask;        // logical index i is valid iff i>=0 && !(i&mask) && (i>>shift) < H
+    long long s_n, s_h, s_w, s_c;
+};
+
+struct FwdParams {
+    Geom g;
+    const float* A;
+    const float* B;
+    const float* bias;
+    const float* resid;
+    float* D;
+    int M, Ng, Kg;
+    long long b_off, bs_r, bs_s, bs_c, bs_k;   // Wt(r,s,c,k) = B[b_off + r*bs_r + s*bs_s + c*bs_c + k*bs_k]
+    long long ds_n, ds_p, ds_q, ds_k;          // D strides over (n,p,q,k)
+    int relu;
+};
+
+struct WgradParams {
+    Geom g;
+    const float* X;
+    const float* DY;
+    float* OUT;              // [splits][Mtot][Ng] partial slabs (or the final dw when splits==1)
+    int Mtot, Ng, Kg;        // R*S*C, K, N*P*Q
+    long long dy_n, dy_p, dy_q, dy_k;
+    int chunk;               // pixels per split (multiple of BK)
+};
+
+__device__ __forceinline__ bool src_index(int i, int shift, int mask, int lim, int& o) {
+    o = i >> shift;
+    return (i >= 0) && !(i & mask) && (o < lim);
+}
+
+// ------------------------------------------------------------------------------------------
+// MFMA over one 32-deep slice.  A tile k-contiguous [BM][LDA]; B tile [BK][BN].
+template <int TM, int TN, int BN>
+__device__ __forceinline__ void mma_slice_krow(const float* As, const float* Bs, int a_row0, int b_col0,
+                                               int lane, f32x16 (&acc)[TM][TN]) {
+    const int h = lane >> 5, l31 = lane & 31;
+    float4 a[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            a[i][v] = *reinterpret_cast<const float4*>(&As[(a_row0 + i * 32 + l31) * LDA + h * 16 + v * 4]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        float b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[(h * 16 + s) * BN + b_col0 + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float4 av = a[i][s >> 2];
+            const float ae = (s & 3) == 0 ? av.x : (s & 3) == 1 ? av.y : (s & 3) == 2 ? av.z : av.w;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// A tile m-contiguous [BK][BM] (WGRAD)
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void mma_slice_mrow(const float* As, const float* Bs, int a_row0, int b_col0,
+                                               int lane, f32x16 (&acc)[TM][TN]) {
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[(h * 16 + s) * BM + a_row0 + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[(h * 16 + s) * BN + b_col0 + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// FWD / DGRAD kernel
+template <bool AVEC, bool BVEC, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const FwdParams p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int A_VEC_PER = (BM * 8) / NT;       // float4 per thread (AVEC)
+    constexpr int A_SCL_PER = (BM * BK) / NT;      // floats per thread (generic)
+    constexpr int B_VEC_PER = (BK * BN / 4) / NT;
+    constexpr int B_SCL_PER = (BK * BN) / NT;
+    static_assert((BM * 8) % NT == 0 && (BK * BN / 4) % NT == 0, "tile/threads mismatch");
+
+    __shared__ __attribute__((aligned(16))) float smem[BM * LDA + BK * BN];
+    __shared__ long long row_off[BM];
+    __shared__ int row_ih0[BM], row_iw0[BM];
+    __shared__ long long ka_coff[2][BK], kb_off[2][BK];
+    __shared__ int ka_r[2][BK], ka_s[2][BK];
+    float* As = smem;
+    float* Bs = smem + BM * LDA;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.Ng + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = (p.Kg + BK - 1) / BK;
+    const int PQ = g.P * g.Q;
+
+    for (int i = tid; i < BM; i += NT) {
+        const int m = m0 + i;
+        if (m < p.M) {
+            const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+            row_off[i] = (long long)n * g.s_n;
+            row_ih0[i] = pp * g.stride - g.pad_t;
+            row_iw0[i] = qq * g.stride - g.pad_l;
+        } else {
+            row_off[i] = -1; row_ih0[i] = 0; row_iw0[i] = 0;
+        }
+    }
+    auto fill_ktab = [&](int kt) {
+        if (tid < BK) {
+            const int gk = kt * BK + tid, buf = kt & 1;
+            if (gk < p.Kg) {
+                const int tap = gk / g.C, c = gk - tap * g.C, r = tap / g.S, s = tap - r * g.S;
+                ka_r[buf][tid] = r; ka_s[buf][tid] = s;
+                ka_coff[buf][tid] = (long long)c * g.s_c;
+                kb_off[buf][tid] = p.b_off + r * p.bs_r + s * p.bs_s + c * p.bs_c;
+            } else {
+                ka_r[buf][tid] = 0; ka_s[buf][tid] = 0; ka_coff[buf][tid] = -1; kb_off[buf][tid] = -1;
+            }
+        }
+    };
+    fill_ktab(0);
+    __syncthreads();
+
+    // per-thread A row cache (AVEC)
+    long long a_off[AVEC ? A_VEC_PER : 1];
+    int a_ih0[AVEC ? A_VEC_PER : 1], a_iw0[AVEC ? A_VEC_PER : 1];
+    if constexpr (AVEC) {
+#pragma unroll
+        for (int i = 0; i < A_VEC_PER; ++i) {
+            const int row = (tid >> 3) + i * (NT / 8);
+            a_off[i] = row_off[row]; a_ih0[i] = row_ih0[row]; a_iw0[i] = row_iw0[row];
+        }
+    }
+
+    float4 ra4[AVEC ? A_VEC_PER : 1];
+    float ras[AVEC ? 1 : A_SCL_PER];
+    float4 rb4[BVEC ? B_VEC_PER : 1];
+    float rbs[BVEC ? 1 : B_SCL_PER];
+
+    auto load_tile = [&](int kt) {
+        const int buf = kt & 1;
+        if constexpr (AVEC) {
+            const int kk0 = kt * BK;               // C % 32 == 0: the slice lies inside one tap
+            const int tap = kk0 / g.C, c0 = kk0 - tap * g.C, r = tap / g.S, s = tap - r * g.S;
+            const int chunk = tid & 7;
+#pragma unroll
+            for (int i = 0; i < A_VEC_PER; ++i) {
+                int ih, iw;
+                const bool ok = (a_off[i] >= 0) & src_index(a_ih0[i] + r, g.shift, g.mask, g.H, ih) &
+                                src_index(a_iw0[i] + s, g.shift, g.mask, g.W, iw);
+                if (ok) ra4[i] = *reinterpret_cast<const float4*>(
+                            p.A + a_off[i] + (long long)ih * g.s_h + (long long)iw * g.s_w + c0 + chunk * 4);
+                else ra4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int kk = tid & 31;
+            const int r = ka_r[buf][kk], s = ka_s[buf][kk];
+            const long long coff = ka_coff[buf][kk];
+#pragma unroll
+            for (int i = 0; i < A_SCL_PER; ++i) {
+                const int row = (tid >> 5) + i * (NT / 32);
+                const long long ro = row_off[row];
+                int ih, iw;
+                const bool ok = (ro >= 0) & (coff >= 0) & src_index(row_ih0[row] + r, g.shift, g.mask, g.H, ih) &
+                                src_index(row_iw0[row] + s, g.shift, g.mask, g.W, iw);
+                ras[i] = ok ? p.A[ro + (long long)ih * g.s_h + (long long)iw * g.s_w + coff] : 0.f;
+            }
+        }
+        if constexpr (BVEC) {
+            constexpr int J4 = BN / 4;
+            const int j4 = tid % J4;
+#pragma unroll
+            for (int i = 0; i < B_VEC_PER; ++i) {
+                const int kk = tid / J4 + i * (NT / J4);
+                const long long bo = kb_off[buf][kk];
+                const int col = n0 + j4 * 4;
+                if (bo >= 0 && col < p.Ng) rb4[i] = *reinterpret_cast<const float4*>(p.B + bo + col);
+                else rb4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int j = tid % BN;
+#pragma unroll
+            for (int i = 0; i < B_SCL_PER; ++i) {
+                const int kk = tid / BN + i * (NT / BN);
+                const long long bo = kb_off[buf][kk];
+                const int col = n0 + j;
+                rbs[i] = (bo >= 0 && col < p.Ng) ? p.B[bo + (long long)col * p.bs_k] : 0.f;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        if constexpr (AVEC) {
+            const int chunk = tid & 7;
+#pragma unroll
+            for (int i = 0; i < A_VEC_PER; ++i) {
+                const int row = (tid >> 3) + i * (NT / 8);
+                *reinterpret_cast<float4*>(&As[row * LDA + chunk * 4]) = ra4[i];
+            }
+        } else {
+            const int kk = tid & 31;
+#pragma unroll
+            for (int i = 0; i < A_SCL_PER; ++i) As[((tid >> 5) + i * (NT / 32)) * LDA + kk] = ras[i];
+        }
+        if constexpr (BVEC) {
+            constexpr int J4 = BN / 4;
+            const int j4 = tid % J4;
+#pragma unroll
+            for (int i = 0; i < B_VEC_PER; ++i)
+                *reinterpret_cast<float4*>(&Bs[(tid / J4 + i * (NT / J4)) * BN + j4 * 4]) = rb4[i];
+        } else {
+            const int j = tid % BN;
+#pragma unroll
+            for (int i = 0; i < B_SCL_PER; ++i) Bs[(tid / BN + i * (NT / BN)) * BN + j] = rbs[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tile(0);
+    store_tile();
+    if (nk > 1) fill_ktab(1);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+        mma_slice_krow<TM, TN, BN>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+        __syncthreads();
+        if (kt + 1 < nk) store_tile();
+        if (kt + 2 < nk) fill_ktab(kt + 2);
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][e] -> row = (e&3) + 8*(e>>2) + 4*(lane>>5), col = lane&31
+    const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        if (col >= p.Ng) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = m0 + row;
+                if (m >= p.M) continue;
+                const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+                const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
+                float v = acc[i][j][e] + bv;
+                if (p.resid) v += p.resid[off];
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.D[off] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// WGRAD kernel: grid = (tiles_m * tiles_n, splits)
+template <bool AVEC, bool BVEC, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_kernel(const WgradParams p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int A_VEC_PER = (BK * BM / 4) / NT, A_SCL_PER = (BK * BM) / NT;
+    constexpr int B_VEC_PER = (BK * BN / 4) / NT, B_SCL_PER = (BK * BN) / NT;
+
+    __shared__ __attribute__((aligned(16))) float smem[BK * BM + BK * BN];
+    __shared__ long long px_xoff[2][BK], px_yoff[2][BK];
+    __shared__ int px_ih0[2][BK], px_iw0[2][BK];
+    float* As = smem;
+    float* Bs = smem + BK * BM;
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.Ng + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int k_begin = blockIdx.y * p.chunk;
+    const int k_end = min(p.Kg, k_begin + p.chunk);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    const int PQ = g.P * g.Q;
+
+    auto fill_ptab = [&](int kt) {
+        if (tid < BK) {
+            const int buf = kt & 1, px = k_begin + kt * BK + tid;
+            if (px < k_end) {
+                const int n = px / PQ, rem = px - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+                px_xoff[buf][tid] = (long long)n * g.s_n;
+                px_ih0[buf][tid] = pp * g.stride - g.pad_t;
+                px_iw0[buf][tid] = qq * g.stride - g.pad_l;
+                px_yoff[buf][tid] = n * p.dy_n + pp * p.dy_p + qq * p.dy_q;
+            } else {
+                px_xoff[buf][tid] = -1; px_yoff[buf][tid] = -1; px_ih0[buf][tid] = 0; px_iw0[buf][tid] = 0;
+            }
+        }
+    };
+
+    // A-side row (= filter element) decode
+    int ar = 0, as_ = 0;                   // AVEC: block-uniform tap
+    long long acoff = 0;                   // AVEC: channel offset of this thread's float4
+    int gr = 0, gs = 0; long long gcoff = -1;   // generic: this thread's fixed filter element
+    if constexpr (AVEC) {
+        const int tap = m0 / g.C, c0 = m0 - tap * g.C;   // C % BM == 0
+        ar = tap / g.S; as_ = tap - ar * g.S;
+        acoff = c0 + (tid % (BM / 4)) * 4;
+    } else {
+        const int m = m0 + tid % BM;
+        if (m < p.Mtot) {
+            const int tap = m / g.C, c = m - tap * g.C;
+            gr = tap / g.S; gs = tap - gr * g.S; gcoff = (long long)c * g.s_c;
+        }
+    }
+
+    float4 ra4[AVEC ? A_VEC_PER : 1];
+    float ras[AVEC ? 1 : A_SCL_PER];
+    float4 rb4[BVEC ? B_VEC_PER : 1];
+    float rbs[BVEC ? 1 : B_SCL_PER];
+
+    auto load_tile = [&](int kt) {
+        const int buf = kt & 1;
+        if constexpr (AVEC) {
+            constexpr int M4 = BM / 4;
+#pragma unroll
+            for (int i = 0; i < A_VEC_PER; ++i) {
+                const int kk = tid / M4 + i * (NT / M4);
+                const long long xo = px_xoff[buf][kk];
+                int ih, iw;
+                const bool ok = (xo >= 0) & src_index(px_ih0[buf][kk] + ar, g.shift, g.mask, g.H, ih) &
+                                src_index(px_iw0[buf][kk] + as_, g.shift, g.mask, g.W, iw);
+                if (ok) ra4[i] = *reinterpret_cast<const float4*>(
+                            p.X + xo + (long long)ih * g.s_h + (long long)iw * g.s_w + acoff);
+                else ra4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_SCL_PER; ++i) {
+                const int kk = tid / BM + i * (NT / BM);
+                const long long xo = px_xoff[buf][kk];
+                int ih, iw;
+                const bool ok = (xo >= 0) & (gcoff >= 0) & src_index(px_ih0[buf][kk] + gr, g.shift, g.mask, g.H, ih) &
+                                src_index(px_iw0[buf][kk] + gs, g.shift, g.mask, g.W, iw);
+                ras[i] = ok ? p.X[xo + (long long)ih * g.s_h + (long long)iw * g.s_w + gcoff] : 0.f;
+            }
+        }
+        if constexpr (BVEC) {
+            constexpr int J4 = BN / 4;
+            const int j4 = tid % J4;
+#pragma unroll
+            for (int i = 0; i < B_VEC_PER; ++i) {
+                const int kk = tid / J4 + i * (NT / J4);
+                const long long yo = px_yoff[buf][kk];
+                const int col = n0 + j4 * 4;
+                if (yo >= 0 && col < p.Ng) rb4[i] = *reinterpret_cast<const float4*>(p.DY + yo + col);
+                else rb4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int j = tid % BN;
+#pragma unroll
+            for (int i = 0; i < B_SCL_PER; ++i) {
+                const int kk = tid / BN + i * (NT / BN);
+                const long long yo = px_yoff[buf][kk];
+                const int col = n0 + j;
+                rbs[i] = (yo >= 0 && col < p.Ng) ? p.DY[yo + (long long)col * p.dy_k] : 0.f;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        if constexpr (AVEC) {
+            constexpr int M4 = BM / 4;
+#pragma unroll
+            for (int i = 0; i < A_VEC_PER; ++i)
+                *reinterpret_cast<float4*>(&As[(tid / M4 + i * (NT / M4)) * BM + (tid % M4) * 4]) = ra4[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_SCL_PER; ++i) As[(tid / BM + i * (NT / BM)) * BM + tid % BM] = ras[i];
+        }
+        if constexpr (BVEC) {
+            constexpr int J4 = BN / 4;
+#pragma unroll
+            for (int i = 0; i < B_VEC_PER; ++i)
+                *reinterpret_cast<float4*>(&Bs[(tid / J4 + i * (NT / J4)) * BN + (tid % J4) * 4]) = rb4[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_SCL_PER; ++i) Bs[(tid / BN + i * (NT / BN)) * BN + tid % BN] = rbs[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nk > 0) {
+        fill_ptab(0);
+        __syncthreads();
+        load_tile(0);
+        store_tile();
+        if (nk > 1) fill_ptab(1);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile(kt + 1);
+            mma_slice_mrow<TM, TN, BM, BN>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+            __syncthreads();
+            if (kt + 1 < nk) store_tile();
+            if (kt + 2 < nk) fill_ptab(kt + 2);
+            __syncthreads();
+        }
+    }
+
+    const int h = lane >> 5, l31 = lane & 31;
+    float* out = p.OUT + (long long)blockIdx.y * p.Mtot * p.Ng;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        if (col >= p.Ng) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < p.Mtot) out[(long long)m * p.Ng + col] = acc[i][j][e];
+            }
+    }
+}
+
+// out[i] = sum_s part[s][i]   (fixed order => deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int splits) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(long long)k * n + i];
+    out[i] = s;
+}
+
+// wT[r',s',k,c] = w[R-1-r', S-1-s', c, k]   (dgrad filter: rotate 180 degrees, swap I/O)
+__global__ void repack_dgrad_filter_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int S, int C, int K) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)R * S * C * K;
+    if (i >= n) return;
+    const int c = i % C; long long t = i / C;
+    const int k = t % K; t /= K;
+    const int s = t % S; const int r = t / S;
+    wt[i] = w[(((long long)(R - 1 - r) * S + (S - 1 - s)) * C + c) * K + k];
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+thread_local char g_last_kernel[128] = "";
+
+template <bool AVEC, bool BVEC, int WM, int WN, int TM, int TN>
+int launch_fwd(const FwdParams& p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd<%s,%s,%dx%d>", AVEC ? "avec" : "agen",
+             BVEC ? "bvec" : "bgen", BM, BN);
+    hipLaunchKernelGGL((igemm_fwd_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(tiles), dim3(64 * WM * WN), 0, st, p);
+    return ctgan_check_launch("igemm_fwd");
+}
+
+template <bool AVEC, bool BVEC>
+int dispatch_fwd_tile(const FwdParams& p, hipStream_t st) {
+    // pick the largest tile that still yields >= ~2 workgroups per CU; N tile by Ng
+    const long long M = p.M;
+    if (p.Ng > 64) {
+        if (M >= 128LL * 512) return launch_fwd<AVEC, BVEC, 2, 2, 2, 2>(p, st);   // 128x128
+        if (M >= 64LL * 384) return launch_fwd<AVEC, BVEC, 1, 4, 2, 1>(p, st);    // 64x128
+        return launch_fwd<AVEC, BVEC, 1, 4, 1, 1>(p, st);                         // 32x128
+    }
+    if (p.Ng > 32) return launch_fwd<AVEC, BVEC, 2, 2, 1, 1>(p, st);              // 64x64
+    return launch_fwd<AVEC, BVEC, 4, 1, 1, 1>(p, st);                             // 128x32
+}
+
+int run_fwd(const FwdParams& p, hipStream_t st) {
+    const Geom& g = p.g;
+    const bool avec = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
+    const bool bvec = p.bs_k == 1 && (p.Ng % 4 == 0) && (p.b_off % 4 == 0) && (p.bs_r % 4 == 0) && (p.bs_s % 4 == 0) &&
+                      (p.bs_c % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+    if (avec && bvec) return dispatch_fwd_tile<true, true>(p, st);
+    if (avec) return dispatch_fwd_tile<true, false>(p, st);
+    if (bvec) return dispatch_fwd_tile<false, true>(p, st);
+    return dispatch_fwd_tile<false, false>(p, st);
+}
+
+template <bool AVEC, bool BVEC, int WM, int WN, int TM, int TN>
+int launch_wgrad(WgradParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int tiles = ((p.Mtot + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
+    int splits, chunk;
+    ctgan_wgrad_split(tiles, p.Kg, &splits, &chunk);
+    const size_t need = splits > 1 ? (size_t)splits * p.Mtot * p.Ng * sizeof(float) : 0;
+    if (need > ws_bytes) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    p.chunk = chunk;
+    p.OUT = splits > 1 ? static_cast<float*>(ws) : dw;
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad<%s,%s,%dx%d,split%d>", AVEC ? "avec" : "agen",
+             BVEC ? "bvec" : "bgen", BM, BN, splits);
+    hipLaunchKernelGGL((igemm_wgrad_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(tiles, splits), dim3(64 * WM * WN), 0, st, p);
+    int rc = ctgan_check_launch("igemm_wgrad");
+    if (rc) return rc;
+    if (splits > 1) {
+        const long long n = (long long)p.Mtot * p.Ng;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.OUT, dw, n, splits);
+        rc = ctgan_check_launch("splitk_reduce");
+    }
+    return rc;
+}
+
+// tile choice depends only on (C, Mtot, Ng) so that the workspace query can reproduce it
+enum WTile { W128x128, W64x128, W32x128, W64x64, W128x32 };
+WTile wgrad_tile_choice(int C, int Mtot, int Ng, int* bm, int* bn) {
+    WTile t;
+    if (C % 32 == 0) {           // AVEC-capable: the M tile must lie inside one filter tap
+        if (Ng > 64) t = (C % 128 == 0) ? W128x128 : (C % 64 == 0) ? W64x128 : W32x128;
+        else if (Ng > 32) t = (C % 64 == 0) ? W64x64 : W32x128;
+        else t = (C % 128 == 0) ? W128x32 : W32x128;
+    } else {                     // generic gather: any M tile
+        if (Ng > 64) t = Mtot > 64 ? W128x128 : Mtot > 32 ? W64x128 : W32x128;
+        else if (Ng > 32) t = Mtot > 32 ? W64x64 : W32x128;
+        else t = Mtot > 32 ? W128x32 : W32x128;
+    }
+    static const int dims[5][2] = {{128, 128}, {64, 128}, {32, 128}, {64, 64}, {128, 32}};
+    *bm = dims[t][0]; *bn = dims[t][1];
+    return t;
+}
+
+template <bool AVEC, bool BVEC>
+int dispatch_wgrad_tile(const WgradParams& p, float* dw, void* ws, size_t wsb, hipStream_t st) {
+    int bm, bn;
+    switch (wgrad_tile_choice(p.g.C, p.Mtot, p.Ng, &bm, &bn)) {
+        case W128x128: return launch_wgrad<AVEC, BVEC, 2, 2, 2, 2>(p, dw, ws, wsb, st);
+        case W64x128: return launch_wgrad<AVEC, BVEC, 1, 4, 2, 1>(p, dw, ws, wsb, st);
+        case W32x128: return launch_wgrad<AVEC, BVEC, 1, 4, 1, 1>(p, dw, ws, wsb, st);
+        case W64x64: return launch_wgrad<AVEC, BVEC, 2, 2, 1, 1>(p, dw, ws, wsb, st);
+        default: return launch_wgrad<AVEC, BVEC, 4, 1, 1, 1>(p, dw, ws, wsb, st);
+    }
+}
+
+int run_wgrad(const WgradParams& p, float* dw, void* ws, size_t wsb, hipStream_t st) {
+    const Geom& g = p.g;
+    const bool avec = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+    const bool bvec = p.dy_k == 1 && (p.Ng % 4 == 0) && (p.dy_n % 4 == 0) && (p.dy_p % 4 == 0) && (p.dy_q % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.DY) & 15) == 0);
+    if (avec && bvec) return dispatch_wgrad_tile<true, true>(p, dw, ws, wsb, st);
+    if (avec) return dispatch_wgrad_tile<true, false>(p, dw, ws, wsb, st);
+    if (bvec) return dispatch_wgrad_tile<false, true>(p, dw, ws, wsb, st);
+    return dispatch_wgrad_tile<false, false>(p, dw, ws, wsb, st);
+}
+
+int check_desc(const ctgan_conv_desc* d, const char* who) {
+    if (!d) return ctgan_fail(CTGAN_E_BADARG, "%s: null descriptor", who);
+    if (d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0 || d->P <= 0 || d->Q <= 0)
+        return ctgan_fail(CTGAN_E_BADARG, "%s: non-positive dimension", who);
+    if (d->stride != 1 && d->stride != 2) return ctgan_fail(CTGAN_E_UNSUPPORTED, "%s: stride %d (1 or 2)", who, d->stride);
+    if (d->x_up && (d->H % 2 || d->W % 2)) return ctgan_fail(CTGAN_E_BADARG, "%s: x_up needs even H,W", who);
+    if ((long long)d->N * d->P * d->Q >= (1LL << 31) || (long long)d->R * d->S * d->C >= (1LL << 31))
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "%s: GEMM extent exceeds int32", who);
+    return 0;
+}
+
+Geom geom_from_x(const ctgan_conv_desc* d) {   // gather from x (FWD / WGRAD)
+    Geom g;
+    g.H = d->x_up ? d->H / 2 : d->H; g.W = d->x_up ? d->W / 2 : d->W;
+    g.P = d->P; g.Q = d->Q; g.R = d->R; g.S = d->S; g.C = d->C;
+    g.stride = d->stride; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
+    g.shift = d->x_up ? 1 : 0; g.mask = 0;
+    g.s_n = d->xs[0]; g.s_c = d->xs[1]; g.s_h = d->xs[2]; g.s_w = d->xs[3];
+    return g;
+}
+
+}  // namespace
+
+void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
+    // choose splits so that tiles*splits ~ k*256 workgroups (k small) with >= 4 slices per split
+    const int max_splits = (Kg + 4 * BK - 1) / (4 * BK);
+    int best = 1;
+    for (int k = 1; k <= 4; ++k) {
+        int s = (256 * k) / tiles;
+        if (s < 1) s = 1;
+        if (s > max_splits) s = max_splits;
+        best = s;
+        if ((double)tiles * s >= 0.9 * 256 * k || s == max_splits) break;
+    }
+    if (best < 1) best = 1;
+    int ch = (Kg + best - 1) / best;
+    ch = ((ch + BK - 1) / BK) * BK;
+    *splits = (Kg + ch - 1) / ch;
+    *chunk = ch;
+}
+
+extern "C" {
+
+const char* ctgan_last_kernel(void) { return g_last_kernel; }
+
+size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
+    if (!d) return 0;
+    if (op == CTGAN_CONV_DGRAD) return (size_t)d->R * d->S * d->C * d->K * sizeof(float);
+    if (op == CTGAN_CONV_WGRAD) {
+        const int mt = d->R * d->S * d->C, Kg = d->N * d->P * d->Q;
+        int bm, bn, splits, chunk;
+        wgrad_tile_choice(d->C, mt, d->K, &bm, &bn);
+        const int tiles = ((mt + bm - 1) / bm) * ((d->K + bn - 1) / bn);
+        ctgan_wgrad_split(tiles, Kg, &splits, &chunk);
+        return splits > 1 ? (size_t)splits * mt * d->K * sizeof(float) : 0;
+    }
+    return 0;
+}
+
+int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
+                     float* y, int flags, ctgan_stream_t stream) {
+    int rc = check_desc(d, "conv2d_fwd");
+    if (rc) return rc;
+    if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
+    FwdParams p;
+    p.g = geom_from_x(d);
+    p.A = x; p.B = w; p.bias = bias; p.resid = resid; p.D = y;
+    p.M = d->N * d->P * d->Q; p.Ng = d->K; p.Kg = d->R * d->S * d->C;
+    p.b_off = 0; p.bs_r = (long long)d->S * d->C * d->K; p.bs_s = (long long)d->C * d->K; p.bs_c = d->K; p.bs_k = 1;
+    p.ds_n = d->ys[0]; p.ds_k = d->ys[1]; p.ds_p = d->ys[2]; p.ds_q = d->ys[3];
+    p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0;
+    return run_fwd(p, static_cast<hipStream_t>(stream));
+}
+
+int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+                       size_t ws_bytes, ctgan_stream_t stream) {
+    int rc = check_desc(d, "conv2d_dgrad");
+    if (rc) return rc;
+    if (!dy || !w || !dx) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: null pointer");
+    if (d->x_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: x_up (pool the result instead)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    FwdParams p;
+    Geom& g = p.g;
+    g.H = d->P; g.W = d->Q;                 // physical source = dy
+    g.P = d->H; g.Q = d->W;                 // rows enumerate dx pixels
+    g.R = d->R; g.S = d->S; g.C = d->K;     // channels per tap = dy channels
+    g.stride = 1; g.pad_t = d->R - 1 - d->pad_t; g.pad_l = d->S - 1 - d->pad_l;
+    g.shift = d->stride == 2 ? 1 : 0; g.mask = d->stride == 2 ? 1 : 0;
+    g.s_n = d->ys[0]; g.s_c = d->ys[1]; g.s_h = d->ys[2]; g.s_w = d->ys[3];
+    p.A = dy; p.bias = bias; p.resid = nullptr; p.D = dx;
+    p.M = d->N * d->H * d->W; p.Ng = d->C; p.Kg = d->R * d->S * d->K;
+    p.ds_n = d->xs[0]; p.ds_k = d->xs[1]; p.ds_p = d->xs[2]; p.ds_q = d->xs[3];
+    p.relu = 0;
+    const size_t need = (size_t)d->R * d->S * d->C * d->K * sizeof(float);
+    const bool repack = ws && ws_bytes >= need && (d->C % 4 == 0) && (d->K % 32 == 0);
+    if (repack) {
+        const long long n = (long long)d->R * d->S * d->C * d->K;
+        hipLaunchKernelGGL(repack_dgrad_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w,
+                           static_cast<float*>(ws), d->R, d->S, d->C, d->K);
+        rc = ctgan_check_launch("repack_dgrad_filter");
+        if (rc) return rc;
+        p.B = static_cast<const float*>(ws);
+        p.b_off = 0; p.bs_r = (long long)d->S * d->K * d->C; p.bs_s = (long long)d->K * d->C; p.bs_c = d->C; p.bs_k = 1;
+    } else {
+        p.B = w;   // strided view of the original HWIO filter: rotate via negative tap strides
+        p.b_off = ((long long)(d->R - 1) * d->S + (d->S - 1)) * d->C * d->K;
+        p.bs_r = -(long long)d->S * d->C * d->K; p.bs_s = -(long long)d->C * d->K; p.bs_c = 1; p.bs_k = d->K;
+    }
+    return run_fwd(p, st);
+}
+
+int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                       ctgan_stream_t stream) {
+    int rc = check_desc(d, "conv2d_wgrad");
+    if (rc) return rc;
+    if (!x || !dy || !dw) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: null pointer");
+    WgradParams p;
+    p.g = geom_from_x(d);
+    p.X = x; p.DY = dy; p.OUT = dw;
+    p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
+    p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
+    p.chunk = 0;
+    return run_wgrad(p, dw, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

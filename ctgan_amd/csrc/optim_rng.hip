@@ -1,0 +1,156 @@
+// optim_rng.hip - TF-form Adam on flat buffers (K21) and Philox4x32-10 random streams (K12/K19).
+#include "common.h"
+
+namespace {
+
+// tf.train.AdamOptimizer:  lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1 m+(1-b1) g; v=b2 v+(1-b2) g^2;
+// theta -= lr_t*m/(sqrt(v)+eps)    (eps outside the bias correction, unlike torch.optim.Adam)
+__global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, const float* __restrict__ state, float b1, float b2,
+                            float eps, float gscale) {
+    const float lr = state[0], b1p = state[1], b2p = state[2];
+    const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        th[i] = th[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+__global__ void adam_advance_kernel(float* state, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] *= b1; state[2] *= b2; }
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11); constants of the Random123 reference
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// counter layout: { element-block index, stream id, step lo, step hi }, key = seed
+__device__ __forceinline__ void draw4(uint64_t seed, uint32_t sid, uint64_t step, uint32_t blk, uint32_t (&c)[4]) {
+    c[0] = blk; c[1] = sid; c[2] = (uint32_t)step; c[3] = (uint32_t)(step >> 32);
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0,1), 24 bits
+
+__global__ void rng_uniform_kernel(float* __restrict__ out, long long n, uint64_t seed, uint32_t sid,
+                                   const uint64_t* __restrict__ ctr, float lo, float hi) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long nblk = (n + 3) >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        uint32_t c[4];
+        draw4(seed, sid, step, (uint32_t)b, c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = b * 4 + k;
+            if (i < n) out[i] = lo + (hi - lo) * u01(c[k]);
+        }
+    }
+}
+__global__ void rng_normal_kernel(float* __restrict__ out, long long n, uint64_t seed, uint32_t sid,
+                                  const uint64_t* __restrict__ ctr) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long nblk = (n + 3) >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        uint32_t c[4];
+        draw4(seed, sid, step, (uint32_t)b, c);
+        float z[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {   // Box-Muller on (c[2k], c[2k+1])
+            const float u1 = ((float)(c[2 * k] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+            const float u2 = u01(c[2 * k + 1]);
+            const float r = sqrtf(-2.f * logf(u1));
+            float sn, cs;
+            sincosf(6.283185307179586f * u2, &sn, &cs);
+            z[2 * k] = r * cs; z[2 * k + 1] = r * sn;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = b * 4 + k;
+            if (i < n) out[i] = z[k];
+        }
+    }
+}
+__global__ void rng_labels_kernel(int32_t* __restrict__ out, long long n, int nlab, uint64_t seed, uint32_t sid,
+                                  const uint64_t* __restrict__ ctr) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long nblk = (n + 3) >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        uint32_t c[4];
+        draw4(seed, sid, step, (uint32_t)b, c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long i = b * 4 + k;
+            if (i < n) out[i] = (int32_t)(u01(c[k]) * (float)nlab);   // tf.cast(float->int32) truncates
+        }
+    }
+}
+__global__ void rng_advance_kernel(uint64_t* ctr, uint64_t by) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += by;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, const float* state, float beta1,
+                    float beta2, float eps, float grad_scale, ctgan_stream_t s) {
+    if (!theta || !g || !m || !v || !state || n < 0) return ctgan_fail(CTGAN_E_BADARG, "adam_step: bad argument");
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(ctgan_blocks(n, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), theta, g, m,
+                       v, (long long)n, state, beta1, beta2, eps, grad_scale);
+    return ctgan_check_launch("adam_step");
+}
+int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t s) {
+    if (!state) return ctgan_fail(CTGAN_E_BADARG, "adam_advance: null");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(s), state, beta1, beta2);
+    return ctgan_check_launch("adam_advance");
+}
+
+int ctgan_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr, float lo, float hi,
+                      ctgan_stream_t s) {
+    if (!out || n < 0 || n >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "rng_uniform: bad argument");
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(rng_uniform_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(s), out, (long long)n, seed, (uint32_t)stream_id, ctr, lo, hi);
+    return ctgan_check_launch("rng_uniform");
+}
+int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t s) {
+    if (!out || n < 0 || n >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "rng_normal: bad argument");
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(rng_normal_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(s), out, (long long)n, seed, (uint32_t)stream_id, ctr);
+    return ctgan_check_launch("rng_normal");
+}
+int ctgan_rng_labels(int32_t* out, int64_t n, int32_t nlab, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
+                     ctgan_stream_t s) {
+    if (!out || n < 0 || nlab <= 0) return ctgan_fail(CTGAN_E_BADARG, "rng_labels: bad argument");
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(rng_labels_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0,
+                       static_cast<hipStream_t>(s), out, (long long)n, nlab, seed, (uint32_t)stream_id, ctr);
+    return ctgan_check_launch("rng_labels");
+}
+int ctgan_rng_advance(uint64_t* ctr, uint64_t by, ctgan_stream_t s) {
+    if (!ctr) return ctgan_fail(CTGAN_E_BADARG, "rng_advance: null");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(s), ctr, by);
+    return ctgan_check_launch("rng_advance");
+}
+
+}  // extern "C"

@@ -1,0 +1,493 @@
+"""Differentiable operators built on the HIP kernels (autograd wiring only - no arithmetic here).
+
+The gradient penalty needs the gradient of a gradient (`tf.gradients` inside the loss,
+TF/CT_gan_cifar_resnet.py:284-286), so every op on the critic path has a backward that is itself
+made of differentiable ops: conv / conv-dgrad / conv-wgrad form a closed family, the mask ops
+(ReLU, dropout), pool/upsample and spatial mean/broadcast are linear maps whose adjoints are
+again members of the set.
+
+`weight_grads(False)` marks a forward whose parameter gradients are not wanted (the critic inside
+the generator step; the critic pass that only feeds the gradient penalty, where the critic is
+piecewise linear so the penalty reaches the weights through the backward ops alone).
+"""
+import contextlib
+
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from .kernels import ConvGeom
+
+_WEIGHT_GRADS = True
+
+
+@contextlib.contextmanager
+def weight_grads(enabled):
+    """Forward passes inside this context record (enabled) or skip (not enabled) parameter grads."""
+    global _WEIGHT_GRADS
+    old = _WEIGHT_GRADS
+    _WEIGHT_GRADS = enabled
+    try:
+        yield
+    finally:
+        _WEIGHT_GRADS = old
+
+
+# --------------------------------------------------------------------------------- conv family
+class ConvFn(Function):
+    """y = conv(x, w) [+ b] [+ resid]   (SAME conv described by geometry g)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, resid, g, out_strides):
+        ctx.g = g
+        ctx.N = x.shape[0]
+        ctx.x_strides = x.stride()
+        ctx.want_w = _WEIGHT_GRADS
+        ctx.has_b = b is not None
+        ctx.has_resid = resid is not None
+        ctx.save_for_backward(x, w)
+        return K.conv_fwd(x, w, b, g, resid=resid, out_strides=out_strides)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        g = ctx.g
+        gx = gw = gb = gr = None
+        if ctx.needs_input_grad[0]:
+            if g.x_up:
+                gfull = ConvDgradFn.apply(gy, w, None, _no_up(g), ctx.N, None)
+                gx = Pool2Fn.apply(gfull, 1.0)
+            else:
+                keep = ctx.x_strides if _is_plain_nchw(x) else None
+                gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep)
+        if ctx.needs_input_grad[1] and ctx.want_w:
+            gw = ConvWgradFn.apply(x, gy, g)
+        if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
+            gb = ChannelSumFn.apply(gy)
+        if ctx.has_resid and ctx.needs_input_grad[3]:
+            gr = gy
+        return gx, gw, gb, gr, None, None
+
+
+class ConvDgradFn(Function):
+    """gx = conv^T(gy, w) [+ b]   (with b: Deconv2D's forward)"""
+
+    @staticmethod
+    def forward(ctx, gy, w, b, g, N, out_strides):
+        ctx.g = g
+        ctx.want_w = _WEIGHT_GRADS
+        ctx.has_b = b is not None
+        ctx.save_for_backward(gy, w)
+        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g = ctx.g
+        g_gy = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_gy = ConvFn.apply(ggx, w, None, None, g, None)
+        if ctx.needs_input_grad[1] and ctx.want_w:
+            g_w = ConvWgradFn.apply(ggx, gy, g)
+        if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
+            g_b = ChannelSumFn.apply(ggx)
+        return g_gy, g_w, g_b, None, None, None
+
+
+class ConvWgradFn(Function):
+    """gw = sum_pixels x (x) gy"""
+
+    @staticmethod
+    def forward(ctx, x, gy, g):
+        ctx.g = g
+        ctx.N = x.shape[0]
+        ctx.save_for_backward(x, gy)
+        return K.conv_wgrad(x, gy, g)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        g = ctx.g
+        g_x = g_gy = None
+        ggw = ggw.contiguous()
+        if ctx.needs_input_grad[0]:
+            if g.x_up:
+                g_x = Pool2Fn.apply(ConvDgradFn.apply(gy, ggw, None, _no_up(g), ctx.N, None), 1.0)
+            else:
+                g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None)
+        if ctx.needs_input_grad[1]:
+            g_gy = ConvFn.apply(x, ggw, None, None, g, None)
+        return g_x, g_gy, None
+
+
+class ChannelSumFn(Function):
+    """[N,K,P,Q] -> [K] (bias gradient); its adjoint broadcasts (only reached by 3rd-order use)."""
+
+    @staticmethod
+    def forward(ctx, gy):
+        ctx.shape = gy.shape
+        return K.colsum_channels(gy)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.view(1, -1, 1, 1).expand(ctx.shape)
+
+
+def _no_up(g):
+    return ConvGeom(g.C, g.H, g.W, g.K, g.R, g.S, g.stride, False)
+
+
+def _is_plain_nchw(x):
+    return x.dim() == 4 and x.is_contiguous() and not x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False):
+    """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`."""
+    R, S, C, Kout = w.shape
+    N, Cx, H, W = x.shape
+    assert Cx == C, 'channel mismatch: x has %d, filter expects %d' % (Cx, C)
+    if x_up:
+        H, W = 2 * H, 2 * W
+    g = ConvGeom(C, H, W, Kout, R, S, stride, x_up)
+    out_strides = None
+    if out_nchw:
+        out_strides = (Kout * g.P * g.Q, g.P * g.Q, g.Q, 1)
+    return ConvFn.apply(x, w, b, resid, g, out_strides)
+
+
+def conv2d_transpose(x, w_hwoi, b=None, stride=2):
+    """tf.nn.conv2d_transpose 'SAME' with filter [k,k,out,in]: the dgrad of the strided conv whose
+    HWIO filter is `w_hwoi` (I = out, O = in)."""
+    R, S, Cout, Cin = w_hwoi.shape
+    N, Cx, H, W = x.shape
+    assert Cx == Cin
+    g = ConvGeom(Cout, H * stride, W * stride, Cin, R, S, stride, False)
+    assert (g.P, g.Q) == (H, W)
+    return ConvDgradFn.apply(x, w_hwoi, b, g, N, None)
+
+
+def linear(x, w, b=None):
+    """x [n,in] @ w [in,out] + b, as a 1x1 conv on a 1x1 image."""
+    n, cin = x.shape
+    cout = w.shape[1]
+    x4 = x.reshape(n, cin, 1, 1)
+    y = conv2d(x4, w.view(1, 1, cin, cout), b)
+    return y.reshape(n, cout)
+
+
+# --------------------------------------------------------------------------------- mask ops
+class LReluFn(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        y = K.lrelu_fwd(x, alpha)
+        ctx.alpha = alpha
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return LReluBwdFn.apply(gy, y, ctx.alpha), None
+
+
+class LReluBwdFn(Function):
+    @staticmethod
+    def forward(ctx, gy, ref, alpha):
+        ctx.alpha = alpha
+        ctx.save_for_backward(ref)
+        return K.lrelu_bwd(gy, ref, alpha)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        (ref,) = ctx.saved_tensors
+        return LReluBwdFn.apply(ggx, ref, ctx.alpha), None, None
+
+
+def relu(x):
+    return LReluFn.apply(x, 0.0)
+
+
+def leaky_relu(x, alpha=0.2):
+    return LReluFn.apply(x, alpha)
+
+
+class DropoutFn(Function):
+    """tf.nn.dropout with the uniform draw `u` explicit; linear in x, self-adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, u, keep):
+        ctx.keep = keep
+        u = K.match_layout(u, x)
+        ctx.save_for_backward(u)
+        return K.dropout(x, u, keep)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (u,) = ctx.saved_tensors
+        return DropoutFn.apply(gy, u, ctx.keep), None, None
+
+
+def dropout(x, keep_prob, u):
+    if keep_prob == 1.0:
+        return x
+    return DropoutFn.apply(x, u, float(keep_prob))
+
+
+# --------------------------------------------------------------------------------- resampling
+class Pool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return K.pool2(x, scale)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return Upsample2Fn.apply(gy, ctx.scale), None
+
+
+class Upsample2Fn(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return K.upsample2(x, scale)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return Pool2Fn.apply(gy, ctx.scale), None
+
+
+def mean_pool2(x):
+    return Pool2Fn.apply(x, 0.25)
+
+
+def upsample2(x):
+    return Upsample2Fn.apply(x, 1.0)
+
+
+class SpatialMeanFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[2], x.shape[3])
+        return K.spatial_sum(x, 1.0 / (x.shape[2] * x.shape[3]))
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.hw
+        return SpatialBcastFn.apply(g, H, W, 1.0 / (H * W))
+
+
+class SpatialBcastFn(Function):
+    @staticmethod
+    def forward(ctx, g, H, W, scale):
+        ctx.scale = scale
+        return K.spatial_bcast(g, H, W, scale)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _SpatialSumScaled.apply(gy, ctx.scale), None, None, None
+
+
+class _SpatialSumScaled(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        ctx.hw = (x.shape[2], x.shape[3])
+        return K.spatial_sum(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.hw
+        return SpatialBcastFn.apply(g, H, W, ctx.scale), None
+
+
+def spatial_mean(x):
+    return SpatialMeanFn.apply(x)
+
+
+class Copy4dFn(Function):
+    """Layout change (NCHW <-> channels-last); values unchanged, adjoint = copy back."""
+
+    @staticmethod
+    def forward(ctx, x, to_cl):
+        ctx.to_cl = to_cl
+        return K.to_channels_last(x) if to_cl else K.to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return Copy4dFn.apply(g, not ctx.to_cl), None
+
+
+def to_channels_last(x):
+    return Copy4dFn.apply(x, True)
+
+
+def to_nchw(x):
+    return Copy4dFn.apply(x, False)
+
+
+class AddFn(Function):
+    """a*x + b*y through the axpby kernel (used where the add cannot ride a conv epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        ctx.a, ctx.b = a, b
+        return K.axpby(x, y, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = g if ctx.a == 1.0 else ScaleFn.apply(g, ctx.a)
+        gb = g if ctx.b == 1.0 else ScaleFn.apply(g, ctx.b)
+        return ga, gb, None, None
+
+
+class ScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, a):
+        ctx.a = a
+        return K.axpby(x, None, a, 0.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ScaleFn.apply(g, ctx.a), None
+
+
+def add(x, y):
+    return AddFn.apply(x, y, 1.0, 1.0)
+
+
+# --------------------------------------------------------------------------------- activations (G)
+class TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = K.tanh_fwd(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return K.tanh_bwd(gy.contiguous() if not K.is_dense(gy) else gy, y)
+
+
+class SigmoidFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = K.sigmoid_fwd(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return K.sigmoid_bwd(gy.contiguous() if not K.is_dense(gy) else gy, y)
+
+
+def tanh(x):
+    return TanhFn.apply(x)
+
+
+def sigmoid(x):
+    return SigmoidFn.apply(x)
+
+
+# --------------------------------------------------------------------------------- batch norm (G)
+class BatchNormFn(Function):
+    """Training-mode BN (+ optional per-label scale/offset, + optional fused ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, labels, groups, relu):
+        y, mean, rstd, x4 = K.bn_fwd(x, scale, offset, labels, groups, relu)
+        ctx.groups, ctx.relu = groups, relu
+        ctx.labels = labels
+        ctx.in_shape = x.shape
+        ctx.save_for_backward(x4, mean, rstd, scale, offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x4, mean, rstd, scale, offset = ctx.saved_tensors
+        gx, gs, go = K.bn_bwd(gy, x4, mean, rstd, scale, offset, ctx.labels, ctx.groups, ctx.relu)
+        if len(ctx.in_shape) == 2:
+            gx = gx.reshape(ctx.in_shape)
+        return gx, gs.view(scale.shape), go.view(offset.shape), None, None, None
+
+
+def batch_norm(x, scale, offset, labels=None, groups=1, relu=False):
+    return BatchNormFn.apply(x, scale, offset, labels, groups, relu)
+
+
+# --------------------------------------------------------------------------------- loss heads
+class GradPenaltyFn(Function):
+    """lambda * mean((||g_b|| - 1)^2)"""
+
+    @staticmethod
+    def forward(ctx, g, lam):
+        gp, slopes = K.gp_fwd(g, lam)
+        ctx.lam = lam
+        ctx.save_for_backward(g, slopes)
+        ctx.mark_non_differentiable(slopes)
+        return gp, slopes
+
+    @staticmethod
+    def backward(ctx, gout, _):
+        g, slopes = ctx.saved_tensors
+        return K.gp_bwd(g, slopes, gout, ctx.lam), None
+
+
+class ConsistencyFn(Function):
+    @staticmethod
+    def forward(ctx, d, d_, f, f_, lam2, M):
+        ct, ct_i = K.ct_fwd(d, d_, f, f_, lam2, M)
+        ctx.lam2, ctx.M = lam2, M
+        ctx.save_for_backward(d, d_, f, f_, ct_i)
+        return ct
+
+    @staticmethod
+    def backward(ctx, gout):
+        d, d_, f, f_, ct_i = ctx.saved_tensors
+        gd, gd_, gf, gf_ = K.ct_bwd(d, d_, f, f_, ct_i, gout, ctx.lam2, ctx.M)
+        return gd, gd_, gf, gf_, None, None
+
+
+class SoftmaxCEFn(Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, probs, ncorrect = K.softmax_ce_fwd(logits, labels)
+        ctx.save_for_backward(probs, labels)
+        ctx.mark_non_differentiable(ncorrect)
+        return loss, ncorrect
+
+    @staticmethod
+    def backward(ctx, gout, _):
+        probs, labels = ctx.saved_tensors
+        return K.softmax_ce_bwd(probs, labels, gout), None
+
+
+class MeanDiffFn(Function):
+    """sa*mean(x[:na]) + sb*mean(x[na:])"""
+
+    @staticmethod
+    def forward(ctx, x, na, nb, sa, sb):
+        ctx.cfg = (na, nb, sa, sb)
+        return K.mean_diff_fwd(x, na, nb, sa, sb)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return K.mean_diff_bwd(gout, *ctx.cfg), None, None, None, None
+
+
+def gradient_penalty(g, lam):
+    return GradPenaltyFn.apply(g, float(lam))
+
+
+def consistency_term(d, d_, f, f_, lam2=2.0, M=0.0):
+    return ConsistencyFn.apply(d, d_, f, f_, float(lam2), float(M))
+
+
+def softmax_cross_entropy(logits, labels):
+    """mean sparse softmax CE and the number of argmax hits."""
+    return SoftmaxCEFn.apply(logits, labels)
+
+
+def mean_diff(x, na, nb, sa, sb):
+    return MeanDiffFn.apply(x, int(na), int(nb), float(sa), float(sb))

@@ -1,0 +1,359 @@
+"""CT-WGAN ResNet for CIFAR-10 on MI355X: the hot path of TF/CT_gan_cifar_resnet.py.
+
+Same call surface as the reference script - `Generator(n_samples, labels, noise=None)`,
+`Discriminator(inputs, labels, kp1, kp2, kp3)`, the UPPERCASE hyper-parameters - built on the
+drop-in `tflib.ops` (HIP kernels).  The loss graph of `:190-338` is restated imperatively in
+`Trainer.d_step` / `Trainer.g_step`; the loop of `:393-434` in `Trainer.train_iteration`.
+
+Exact restructurings relative to the reference graph (same outputs, less work):
+  * the two generator towers of one step are one batch with two BatchNorm statistic groups;
+  * the critic trunk (blocks 1-2, before the first dropout) is evaluated once per input and
+    shared by the two dropout passes and the clean accuracy pass;
+  * pass 2 is evaluated on the real half only (its fake half reaches no loss term);
+  * 1x1 shortcut convs commute with mean-pool / nearest-upsample and run on the small side;
+  * residual adds ride the conv epilogue; UpsampleConv never materialises the upsampled tensor.
+"""
+import functools
+
+import torch
+
+from . import functional as F
+from . import kernels as K
+from . import tflib as lib
+from .optim import FlatAdam
+from .rng import DeviceRNG
+from .tflib.ops import batchnorm as _bn
+from .tflib.ops import cond_batchnorm as _cbn
+from .tflib.ops import conv2d as _conv2d
+from .tflib.ops import linear as _linear
+
+
+class Config:
+    """UPPERCASE globals of TF/CT_gan_cifar_resnet.py:33-56."""
+    LAMBDA_2 = 2.0
+    Factor_M = 0.0
+    BATCH_SIZE = 64
+    GEN_BS_MULTIPLE = 2
+    ITERS = 100000
+    DIM_G = 128
+    DIM_D = 128
+    NORMALIZATION_G = True
+    NORMALIZATION_D = False
+    OUTPUT_DIM = 3072
+    LR = 2e-4
+    DECAY = True
+    N_CRITIC = 5
+    CONDITIONAL = True
+    ACGAN = True
+    ACGAN_SCALE = 1.
+    ACGAN_SCALE_G = 0.1
+    GP_LAMBDA = 10.0          # the literal 10.0 of :286
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(Config, k):
+                raise AttributeError('unknown hyper-parameter %s' % k)
+            setattr(self, k, v)
+
+
+cfg = Config()
+
+
+def configure(**kw):
+    global cfg
+    cfg = Config(**kw)
+    return cfg
+
+
+def nonlinearity(x):
+    return F.relu(x)
+
+
+def Normalize(name, inputs, labels=None, groups=1, relu=False):
+    """TF/CT_gan_cifar_resnet.py:70-87 (+ build-only `groups`, fused `relu`)."""
+    if not cfg.CONDITIONAL:
+        labels = None
+    if cfg.CONDITIONAL and cfg.ACGAN and ('Discriminator' in name):
+        labels = None
+    if ('Discriminator' in name) and cfg.NORMALIZATION_D:
+        raise NotImplementedError('NORMALIZATION_D (Layernorm critic) is not built yet')
+    elif ('Generator' in name) and cfg.NORMALIZATION_G:
+        if labels is not None:
+            return _cbn.Batchnorm(name, [0, 2, 3], inputs, labels=labels, n_labels=10, groups=groups, relu=relu)
+        return _bn.Batchnorm(name, [0, 2, 3], inputs, fused=True, groups=groups, relu=relu)
+    return F.relu(inputs) if relu else inputs
+
+
+def ConvMeanPool(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None):
+    """:89-92.  A 1x1 conv commutes with the mean pool: pool first (4x fewer MACs)."""
+    if filter_size == 1:
+        return _conv2d.Conv2D(name, input_dim, output_dim, 1, F.mean_pool2(inputs), he_init=he_init, biases=biases,
+                              resid=resid)
+    out = _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases)
+    out = F.mean_pool2(out)
+    return out if resid is None else F.add(out, resid)
+
+
+def MeanPoolConv(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None):
+    """:94-98"""
+    out = F.mean_pool2(inputs)
+    return _conv2d.Conv2D(name, input_dim, output_dim, filter_size, out, he_init=he_init, biases=biases, resid=resid)
+
+
+def UpsampleConv(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None):
+    """:100-107.  The nearest-2x upsample is folded into the conv's input gather (x_up); a 1x1
+    conv commutes with it and runs on the small side."""
+    if filter_size == 1:
+        out = _conv2d.Conv2D(name, input_dim, output_dim, 1, inputs, he_init=he_init, biases=biases)
+        out = F.upsample2(out)
+        return out if resid is None else F.add(out, resid)
+    return _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases,
+                          x_up=True, resid=resid)
+
+
+def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=None, no_dropout=False, labels=None,
+                  groups=1):
+    """:109-141  (resample: None, 'down', or 'up')"""
+    if resample not in (None, 'down', 'up'):
+        raise Exception('invalid resample value')
+    out = Normalize(name + '.N1', inputs, labels=labels, groups=groups, relu=True)
+    if resample == 'down':
+        out = _conv2d.Conv2D(name + '.Conv1', input_dim, input_dim, filter_size, out)
+        out = Normalize(name + '.N2', out, labels=labels, groups=groups, relu=True)
+        out = ConvMeanPool(name + '.Conv2', input_dim, output_dim, filter_size, out)
+        # shortcut = ConvMeanPool 1x1 (he_init=False); the residual add rides its epilogue
+        return ConvMeanPool(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True, resid=out)
+    if resample == 'up':
+        shortcut = UpsampleConv(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
+        out = UpsampleConv(name + '.Conv1', input_dim, output_dim, filter_size, out)
+        out = Normalize(name + '.N2', out, labels=labels, groups=groups, relu=True)
+        return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut)
+    # resample None
+    if output_dim == input_dim:
+        shortcut = inputs
+    else:
+        shortcut = _conv2d.Conv2D(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
+    out = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out)
+    out = Normalize(name + '.N2', out, labels=labels, groups=groups, relu=True)
+    return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut)
+
+
+def OptimizedResBlockDisc1(inputs):
+    """:143-153"""
+    D = cfg.DIM_D
+    out = _conv2d.Conv2D('Discriminator.1.Conv1', 3, D, 3, inputs)
+    out = nonlinearity(out)
+    out = ConvMeanPool('Discriminator.1.Conv2', D, D, 3, out)
+    return MeanPoolConv('Discriminator.1.Shortcut', 3, D, 1, inputs, he_init=False, biases=True, resid=out)
+
+
+def Generator(n_samples, labels, noise=None, groups=1, rng=None):
+    """:155-167.  `groups` > 1 evaluates that many reference towers (separate BN statistics) at once."""
+    G = cfg.DIM_G
+    if noise is None:
+        noise = rng.normal(n_samples, 128)
+    out = _linear.Linear('Generator.Input', 128, 4 * 4 * G, noise)
+    out = F.to_channels_last(out.reshape(-1, G, 4, 4))
+    out = ResidualBlock('Generator.1', G, G, 3, out, resample='up', labels=labels, groups=groups)
+    out = ResidualBlock('Generator.2', G, G, 3, out, resample='up', labels=labels, groups=groups)
+    out = ResidualBlock('Generator.3', G, G, 3, out, resample='up', labels=labels, groups=groups)
+    out = Normalize('Generator.OutputN', out, groups=groups, relu=True)
+    out = _conv2d.Conv2D('Generator.Output', G, 3, 3, out, he_init=False, out_nchw=True)
+    out = F.tanh(out)
+    return out.reshape(-1, cfg.OUTPUT_DIM)
+
+
+def DiscriminatorTrunk(inputs):
+    """Blocks 1-2 of the critic: everything before the first dropout (:170-172)."""
+    D = cfg.DIM_D
+    out = inputs.reshape(-1, 3, 32, 32)
+    out = OptimizedResBlockDisc1(out)
+    return ResidualBlock('Discriminator.2', D, D, 3, out, resample='down')
+
+
+def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None):
+    """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186)."""
+    D = cfg.DIM_D
+
+    def draw(i, like):
+        if u is not None:
+            return u[i]
+        return rng.uniform(*like.shape, channels_last=True)
+
+    out = F.dropout(h, kp1, None if kp1 == 1.0 else draw(0, h))
+    out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None)
+    out = F.dropout(out, kp2, None if kp2 == 1.0 else draw(1, out))
+    out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None)
+    out = F.dropout(out, kp3, None if kp3 == 1.0 else draw(2, out))
+    out = nonlinearity(out)
+    output2 = F.spatial_mean(out)
+    output_wgan = _linear.Linear('Discriminator.Output', D, 1, output2).reshape(-1)
+    if cfg.CONDITIONAL and cfg.ACGAN:
+        output_acgan = _linear.Linear('Discriminator.ACGANOutput', D, 10, output2)
+        return output_wgan, output2, output_acgan
+    return output_wgan, output2, None
+
+
+def Discriminator(inputs, labels, kp1, kp2, kp3, u=None, rng=None):
+    """:169-186 - returns (D [n], D_ [n,DIM_D], acgan logits [n,10] or None).
+    `u` = the three dropout uniforms [n,DIM_D,8,8] (explicit draws); else drawn from `rng`."""
+    return DiscriminatorTail(DiscriminatorTrunk(inputs), kp1, kp2, kp3, u=u, rng=rng)
+
+
+def build_params(device=None):
+    """Instantiate every parameter once (the reference does this while building its graph)."""
+    if device is not None:
+        lib.set_device(device)
+    dev = lib._dev()
+    lab = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.no_grad():
+        x = Generator(2, lab, noise=torch.zeros(2, 128, device=dev))
+        Discriminator(x, lab, 1.0, 1.0, 1.0)
+
+
+def _cat_rows(a, b):
+    return torch.cat([a, b], dim=0)
+
+
+class Trainer:
+    """Owns the optimizers, the random streams and the D/G step (the session of the reference)."""
+
+    def __init__(self, seed=2024, rank=0, world_size=1, allreduce=None):
+        self.dev = lib._dev()
+        self.rank, self.world = rank, world_size
+        self.allreduce = allreduce            # callable(flat_tensor) -> None, sums across ranks (ddp.py)
+        self.rng = DeviceRNG(seed, rank, self.dev)
+        self.d_named = lib.named_params_with_name('Discriminator.', trainable_only=True)
+        self.g_named = lib.named_params_with_name('Generator', trainable_only=True)
+        self.d_opt = FlatAdam(self.d_named, 0.0, 0.9)
+        self.g_opt = FlatAdam(self.g_named, 0.0, 0.9)
+        self.d_params = [p for _, p in self.d_named]
+        self.g_params = [p for _, p in self.g_named]
+
+    # ------------------------------------------------------------------ losses
+    def d_losses(self, real_int, labels, rnd=None):
+        """Critic loss graph :194-305.  `rnd` (parity mode) injects every random draw; see
+        oracle/steps.make_rnd_resnet_d for the keys and shapes."""
+        B = cfg.BATCH_SIZE
+        rng = self.rng
+        with torch.no_grad():
+            z = torch.cat(rnd['z'], 0) if rnd is not None else None
+            fake = Generator(B, labels, noise=z, groups=2, rng=rng)
+            deq = rnd['dequant'] if rnd is not None else rng.uniform(B, cfg.OUTPUT_DIM, lo=0.0, hi=1. / 128)
+            real = K.real_prep(real_int, deq, 256.0)
+            alpha = rnd['alpha'] if rnd is not None else rng.uniform(B, 1)
+            interp = K.interpolate(real, fake, alpha)
+            rf = _cat_rows(real, fake)
+
+        # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
+        h = DiscriminatorTrunk(rf)
+        if rnd is not None:
+            u = [_cat_rows(a, b[:B]) for a, b in zip(rnd['u_pass1'], rnd['u_pass2'])]
+        else:
+            u = None
+        tail_in = _cat_rows(h, h[:B])
+        d_all, f_all, a_all = DiscriminatorTail(tail_in, 0.8, 0.5, 0.5, u=u, rng=rng)
+        d1, d2_real = d_all[:2 * B], d_all[2 * B:]
+        f1_real, f2_real = f_all[:B], f_all[2 * B:]
+
+        out = {}
+        wgan = F.mean_diff(d1, B, B, -1.0, 1.0)                              # mean(fake) - mean(real)  :244
+        ct = F.consistency_term(d1[:B], d2_real, f1_real, f2_real, cfg.LAMBDA_2, cfg.Factor_M)
+        if cfg.CONDITIONAL and cfg.ACGAN:
+            acgan, _ = F.softmax_cross_entropy(a_all[:B], labels)           # pass-1 logits, real half :246-248
+            with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
+                _, _, a_clean = DiscriminatorTail(h.detach(), 1.0, 1.0, 1.0)
+                _, hit_r = F.softmax_cross_entropy(a_clean[:B], labels)
+                _, hit_f = F.softmax_cross_entropy(a_clean[B:], labels)
+            out['acc_real'], out['acc_fake'] = hit_r / B, hit_f / B
+        else:
+            acgan = None
+
+        # gradient penalty :277-286 - the critic is piecewise linear (no normalisation in D), so the
+        # penalty reaches the weights only through the backward ops: skip the forward's own wgrads
+        interp.requires_grad_(True)
+        with F.weight_grads(not _critic_piecewise_linear()):
+            u_gp = rnd['u_gp'] if rnd is not None else None
+            d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng)[0]
+        ones = torch.ones_like(d_gp)
+        (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
+        gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
+
+        disc_wgan = wgan + ct + gp
+        cost = disc_wgan + cfg.ACGAN_SCALE * acgan if acgan is not None else disc_wgan
+        out.update(cost=cost, wgan=disc_wgan, acgan=acgan, wgan_only=wgan, ct=ct, gp=gp, slopes=slopes, fake=fake,
+                   real=real, d_real=d1[:B], d_fake=d1[B:], gp_grads=grads)
+        return out
+
+    def g_losses(self, rnd=None):
+        """Generator loss graph :314-330: two towers of GEN_BS_MULTIPLE*B/2 samples."""
+        n = cfg.GEN_BS_MULTIPLE * cfg.BATCH_SIZE
+        rng = self.rng
+        if rnd is not None:
+            fake_labels = torch.cat([(lu * 10).to(torch.int32) for lu in rnd['label_u']], 0)
+            z = torch.cat(rnd['z'], 0)
+            u = [torch.cat([rnd['u'][0][i], rnd['u'][1][i]], 0) for i in range(3)]
+        else:
+            fake_labels = rng.labels(n, 10)
+            z, u = None, None
+        x = Generator(n, fake_labels, noise=z, groups=2, rng=rng)
+        with F.weight_grads(False):                      # only dD/dx is needed from the critic
+            d, _, a = Discriminator(x, fake_labels, 0.8, 0.5, 0.5, u=u, rng=rng)
+        cost = F.mean_diff(d, n, 0, -1.0, 0.0)
+        if cfg.CONDITIONAL and cfg.ACGAN:
+            ce, _ = F.softmax_cross_entropy(a, fake_labels)
+            cost = cost + cfg.ACGAN_SCALE_G * ce
+        return {'cost': cost, 'samples': x}
+
+    # ------------------------------------------------------------------ steps
+    def lr(self, iteration):
+        decay = max(0., 1. - float(iteration) / cfg.ITERS) if cfg.DECAY else 1.
+        return cfg.LR * decay
+
+    def d_step(self, real_int, labels, rnd=None, iteration=0, set_lr=True):
+        """session.run([..., disc_train_op]) :402"""
+        self.rng.begin_step()
+        out = self.d_losses(real_int, labels, rnd)
+        grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
+        self._apply(self.d_opt, grads, iteration, set_lr)
+        self.rng.end_step()
+        out['grads'] = dict(zip([n for n, _ in self.d_named], grads))
+        return out
+
+    def g_step(self, rnd=None, iteration=0, set_lr=True):
+        """session.run([gen_train_op]) :397"""
+        self.rng.begin_step()
+        out = self.g_losses(rnd)
+        grads = torch.autograd.grad(out['cost'], self.g_params, allow_unused=True)
+        self._apply(self.g_opt, grads, iteration, set_lr)
+        self.rng.end_step()
+        out['grads'] = dict(zip([n for n, _ in self.g_named], grads))
+        return out
+
+    def _apply(self, opt, grads, iteration, set_lr):
+        if set_lr:
+            opt.set_lr(self.lr(iteration))
+        flat = opt.gather_grads(grads)
+        if self.allreduce is not None and self.world > 1:
+            self.allreduce(flat)
+        opt.step(grad_scale=1.0 / self.world)
+
+    def train_iteration(self, iteration, next_batch):
+        """One pass of the loop body :393-404: [G step if it>0] then N_CRITIC x (batch, D step)."""
+        if iteration > 0:
+            self.g_step(iteration=iteration)
+        out = None
+        for _ in range(cfg.N_CRITIC):
+            data, labels = next_batch()
+            out = self.d_step(data, labels, iteration=iteration)
+        return out
+
+    def generate_samples(self, noise, labels):
+        """fixed_noise_samples / generate_image :341-348: int pixels = ((s+1)*255/2) truncated."""
+        with torch.no_grad():
+            s = Generator(noise.shape[0], labels, noise=noise)
+        return s, ((s + 1.) * (255. / 2)).to(torch.int32)
+
+
+def _critic_piecewise_linear():
+    return not cfg.NORMALIZATION_D

@@ -1,0 +1,505 @@
+"""Tensor-level wrappers over the C-ABI (one function per entry point family).
+
+PyTorch is used for device memory and the current HIP stream only; all arithmetic happens in
+libctgan_hip.so.  Activations are logical NCHW `torch.Tensor`s like the reference's tensors; the
+preferred physical layout is channels-last (NHWC), but every conv entry point takes explicit
+strides, so NCHW images / sample tensors are consumed and produced in place.
+
+No CPU fallback: every wrapper raises on a non-HIP tensor.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, I32x4, I64x4, check, lib
+
+_ws_cache = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('ctgan_amd kernels need HIP device tensors (got %s); there is no CPU fallback'
+                               % t.device)
+        if t.dtype not in (torch.float32, torch.int32):
+            raise TypeError('ctgan_amd kernels are fp32/int32 (got %s)' % t.dtype)
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (stream-ordered reuse)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def empty_cl(n, c, h, w, device, dtype=torch.float32):
+    """Logical [n,c,h,w] tensor with NHWC physical layout (explicit, also for degenerate dims)."""
+    return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def is_dense_like(a, b):
+    return a.shape == b.shape and a.stride() == b.stride()
+
+
+def is_dense(t):
+    """True if t's elements occupy one gap-free block (any dim permutation)."""
+    if t.numel() == 0:
+        return True
+    dims = sorted([(st, sz) for sz, st in zip(t.shape, t.stride()) if sz > 1])
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def empty_like_dense(t):
+    """New tensor with the same shape AND strides as the dense tensor t."""
+    assert is_dense(t)
+    return torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
+
+
+def same_pads(in_size, k, stride):
+    """TF 'SAME': out = ceil(in/s); total = max((out-1)*s+k-in, 0); leading pad = total//2."""
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + k - in_size, 0)
+    return out, total // 2
+
+
+class ConvGeom:
+    """Static geometry of one SAME conv (hashable; shared by fwd/dgrad/wgrad)."""
+    __slots__ = ('C', 'H', 'W', 'K', 'R', 'S', 'stride', 'P', 'Q', 'pad_t', 'pad_l', 'x_up')
+
+    def __init__(self, C, H, W, K, R, S, stride=1, x_up=False):
+        self.C, self.H, self.W, self.K, self.R, self.S, self.stride, self.x_up = C, H, W, K, R, S, stride, bool(x_up)
+        self.P, self.pad_t = same_pads(H, R, stride)
+        self.Q, self.pad_l = same_pads(W, S, stride)
+
+    def desc(self, N, xs, ys):
+        d = ConvDesc()
+        d.N, d.C, d.H, d.W, d.K, d.R, d.S = N, self.C, self.H, self.W, self.K, self.R, self.S
+        d.P, d.Q, d.stride, d.pad_t, d.pad_l = self.P, self.Q, self.stride, self.pad_t, self.pad_l
+        d.x_up = 1 if self.x_up else 0
+        xs, ys = list(xs), list(ys)
+        hp, wp = (self.H // 2, self.W // 2) if self.x_up else (self.H, self.W)
+        # strides of size-1 dims are never used for addressing: zero them so that degenerate
+        # layouts (Linear as a 1x1 conv on a 1x1 image) still qualify for the vector loaders
+        if hp == 1: xs[2] = 0
+        if wp == 1: xs[3] = 0
+        if self.P == 1: ys[2] = 0
+        if self.Q == 1: ys[3] = 0
+        d.xs = I64x4(*xs)
+        d.ys = I64x4(*ys)
+        return d
+
+
+def _x_phys_shape(g, N):
+    return (N, g.C, g.H // 2, g.W // 2) if g.x_up else (N, g.C, g.H, g.W)
+
+
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None):
+    """y = conv(x,w) [+bias] [+resid] [relu].  x logical [N,C,H(/2),W(/2)], w HWIO contiguous."""
+    _need_dev(x, w, bias, resid)
+    N = x.shape[0]
+    assert tuple(x.shape) == _x_phys_shape(g, N), (tuple(x.shape), _x_phys_shape(g, N))
+    assert tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
+    if out_strides is None:
+        y = empty_cl(N, g.K, g.P, g.Q, x.device)
+    else:
+        y = torch.empty_strided((N, g.K, g.P, g.Q), out_strides, dtype=torch.float32, device=x.device)
+    if resid is not None:
+        assert is_dense_like(resid, y)
+    d = g.desc(N, x.stride(), y.stride())
+    check(lib.ctgan_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y),
+                               1 if relu else 0, _stream()), 'conv2d_fwd')
+    return y
+
+
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None):
+    """dx = conv^T(gy, w) [+ bias]; dx logical [N,C,H,W] (channels-last unless out_strides given)."""
+    _need_dev(gy, w, bias)
+    assert not g.x_up
+    assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
+    assert tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
+    if out_strides is None:
+        dx = empty_cl(N, g.C, g.H, g.W, gy.device)
+    else:
+        dx = torch.empty_strided((N, g.C, g.H, g.W), out_strides, dtype=torch.float32, device=gy.device)
+    d = g.desc(N, dx.stride(), gy.stride())
+    nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)
+    ws = workspace(nb, gy.device)
+    check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
+          'conv2d_dgrad')
+    return dx
+
+
+def conv_wgrad(x, gy, g):
+    """dw[R,S,C,K] = sum over pixels of x (gathered) * gy."""
+    _need_dev(x, gy)
+    N = x.shape[0]
+    assert tuple(x.shape) == _x_phys_shape(g, N)
+    assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
+    dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+    d = g.desc(N, x.stride(), gy.stride())
+    nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 2)
+    ws = workspace(nb, x.device)
+    check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(ws), ws.numel(), _stream()),
+          'conv2d_wgrad')
+    return dw
+
+
+def last_kernel():
+    return lib.ctgan_last_kernel().decode()
+
+
+def colsum_channels(gy):
+    """sum over (n,h,w) of a channels-last [N,K,P,Q] tensor -> [K] (bias gradient)."""
+    _need_dev(gy)
+    N, K, P, Q = gy.shape
+    if not gy.permute(0, 2, 3, 1).is_contiguous():
+        gy = to_channels_last(gy)
+    out = torch.empty(K, dtype=torch.float32, device=gy.device)
+    rows = N * P * Q
+    nb = lib.ctgan_colsum_workspace_bytes(rows, K)
+    ws = workspace(nb, gy.device)
+    check(lib.ctgan_colsum(_ptr(gy), rows, K, K, _ptr(out), _ptr(ws), ws.numel(), _stream()), 'colsum')
+    return out
+
+
+# ------------------------------------------------------------------------------- elementwise
+def _ew_out(x):
+    if not is_dense(x):
+        raise ValueError('elementwise kernels need dense tensors')
+    return empty_like_dense(x)
+
+
+def lrelu_fwd(x, alpha):
+    _need_dev(x)
+    y = _ew_out(x)
+    check(lib.ctgan_lrelu_fwd(_ptr(x), _ptr(y), x.numel(), alpha, _stream()), 'lrelu_fwd')
+    return y
+
+
+def lrelu_bwd(gy, ref, alpha):
+    _need_dev(gy, ref)
+    gy = match_layout(gy, ref)
+    gx = _ew_out(ref)
+    check(lib.ctgan_lrelu_bwd(_ptr(gy), _ptr(ref), _ptr(gx), ref.numel(), alpha, _stream()), 'lrelu_bwd')
+    return gx
+
+
+def dropout(x, u, keep):
+    _need_dev(x, u)
+    u = match_layout(u, x)
+    y = _ew_out(x)
+    check(lib.ctgan_dropout(_ptr(x), _ptr(u), _ptr(y), x.numel(), keep, _stream()), 'dropout')
+    return y
+
+
+def tanh_fwd(x):
+    _need_dev(x)
+    y = _ew_out(x)
+    check(lib.ctgan_tanh_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), 'tanh_fwd')
+    return y
+
+
+def tanh_bwd(gy, y):
+    _need_dev(gy, y)
+    gy = match_layout(gy, y)
+    gx = _ew_out(y)
+    check(lib.ctgan_tanh_bwd(_ptr(gy), _ptr(y), _ptr(gx), y.numel(), _stream()), 'tanh_bwd')
+    return gx
+
+
+def sigmoid_fwd(x):
+    _need_dev(x)
+    y = _ew_out(x)
+    check(lib.ctgan_sigmoid_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), 'sigmoid_fwd')
+    return y
+
+
+def sigmoid_bwd(gy, y):
+    _need_dev(gy, y)
+    gy = match_layout(gy, y)
+    gx = _ew_out(y)
+    check(lib.ctgan_sigmoid_bwd(_ptr(gy), _ptr(y), _ptr(gx), y.numel(), _stream()), 'sigmoid_bwd')
+    return gx
+
+
+def axpby(x, y, a, b):
+    """a*x + b*y (y may be None)."""
+    _need_dev(x, y)
+    if y is not None:
+        y = match_layout(y, x)
+    out = _ew_out(x)
+    check(lib.ctgan_axpby(_ptr(x), _ptr(y), _ptr(out), x.numel(), a, b, _stream()), 'axpby')
+    return out
+
+
+def copy4d(x, out):
+    """out[...] = x[...] for two logical-4D tensors of equal shape and arbitrary strides."""
+    _need_dev(x, out)
+    assert x.shape == out.shape and x.dim() == 4
+    check(lib.ctgan_copy4d(_ptr(x), I64x4(*x.stride()), _ptr(out), I64x4(*out.stride()), I32x4(*x.shape), _stream()),
+          'copy4d')
+    return out
+
+
+def to_channels_last(x):
+    if x.permute(0, 2, 3, 1).is_contiguous():
+        return x
+    return copy4d(x, empty_cl(*x.shape, device=x.device))
+
+
+def to_nchw(x):
+    if x.is_contiguous():
+        return x
+    return copy4d(x, torch.empty(x.shape, dtype=x.dtype, device=x.device))
+
+
+def match_layout(t, ref):
+    """Return t with exactly ref's strides (repacking through copy4d if needed)."""
+    if t.shape != ref.shape:
+        raise ValueError('shape mismatch %s vs %s' % (tuple(t.shape), tuple(ref.shape)))
+    if t.stride() == ref.stride():
+        return t
+    if t.dim() != 4:
+        raise ValueError('layout mismatch on a non-4D tensor')
+    return copy4d(t, empty_like_dense(ref))
+
+
+def pool2(x, scale):
+    """y[n,c,p,q] = scale * (sum of the 2x2 window of x)."""
+    _need_dev(x)
+    N, C, H, W = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    y = empty_cl(N, C, H // 2, W // 2, x.device)
+    check(lib.ctgan_pool2(_ptr(x), I64x4(*x.stride()), _ptr(y), I64x4(*y.stride()), I32x4(*y.shape), scale, _stream()),
+          'pool2')
+    return y
+
+
+def upsample2(x, scale):
+    """y[n,c,h,w] = scale * x[n,c,h//2,w//2]."""
+    _need_dev(x)
+    N, C, H, W = x.shape
+    y = empty_cl(N, C, 2 * H, 2 * W, x.device)
+    check(lib.ctgan_upsample2(_ptr(x), I64x4(*x.stride()), _ptr(y), I64x4(*y.stride()), I32x4(*y.shape), scale,
+                              _stream()), 'upsample2')
+    return y
+
+
+def spatial_sum(x, scale):
+    """[N,C,H,W] channels-last -> [N,C], scale * sum over (h,w)."""
+    _need_dev(x)
+    x = to_channels_last(x)
+    N, C, H, W = x.shape
+    y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    check(lib.ctgan_spatial_sum(_ptr(x), _ptr(y), N, H * W, C, scale, _stream()), 'spatial_sum')
+    return y
+
+
+def spatial_bcast(g, H, W, scale):
+    """[N,C] -> channels-last [N,C,H,W] = scale * g[n,c]."""
+    _need_dev(g)
+    g = g.contiguous()
+    N, C = g.shape
+    y = empty_cl(N, C, H, W, g.device)
+    check(lib.ctgan_spatial_bcast(_ptr(g), _ptr(y), N, H * W, C, scale, _stream()), 'spatial_bcast')
+    return y
+
+
+def real_prep(x_int, noise, denom):
+    _need_dev(x_int, noise)
+    assert x_int.dtype == torch.int32 and x_int.is_contiguous()
+    y = torch.empty(x_int.shape, dtype=torch.float32, device=x_int.device)
+    if noise is not None:
+        assert noise.is_contiguous() and noise.shape == x_int.shape
+    check(lib.ctgan_real_prep(_ptr(x_int), _ptr(noise), _ptr(y), x_int.numel(), denom, _stream()), 'real_prep')
+    return y
+
+
+def interpolate(real, fake, alpha):
+    _need_dev(real, fake, alpha)
+    B, D = real.shape
+    assert real.is_contiguous() and fake.is_contiguous() and fake.shape == real.shape and alpha.numel() == B
+    out = torch.empty_like(real)
+    check(lib.ctgan_interpolate(_ptr(real), _ptr(fake), _ptr(alpha.contiguous()), _ptr(out), B, D, _stream()),
+          'interpolate')
+    return out
+
+
+# ------------------------------------------------------------------------------- batch norm
+def bn_fwd(x, scale, offset, labels, groups, relu, eps=1e-5):
+    """x channels-last [N,C,H,W] (or [N,C]); returns y, mean[groups,C], rstd[groups,C]."""
+    _need_dev(x, scale, offset, labels)
+    x4 = x if x.dim() == 4 else x.view(x.shape[0], x.shape[1], 1, 1)
+    x4 = to_channels_last(x4)
+    N, C, H, W = x4.shape
+    hw = H * W
+    mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+    nb = lib.ctgan_bn_workspace_bytes(N, hw, C, groups, 1)
+    ws = workspace(nb, x.device)
+    check(lib.ctgan_bn_stats(_ptr(x4), N, hw, C, groups, eps, _ptr(mean), _ptr(rstd), _ptr(ws), ws.numel(), _stream()),
+          'bn_stats')
+    y = empty_cl(N, C, H, W, x.device)
+    check(lib.ctgan_bn_apply(_ptr(x4), _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(offset), _ptr(labels), _ptr(y), N, hw,
+                             C, groups, 1 if relu else 0, _stream()), 'bn_apply')
+    if x.dim() == 2:
+        y = y.view(N, C)
+    return y, mean, rstd, x4
+
+
+def bn_bwd(gy, x4, mean, rstd, scale, offset, labels, groups, relu):
+    _need_dev(gy, x4, mean, rstd, scale, offset, labels)
+    N, C, H, W = x4.shape
+    hw = H * W
+    gy4 = gy if gy.dim() == 4 else gy.reshape(N, C, 1, 1)
+    gy4 = to_channels_last(gy4)
+    n_labels = scale.shape[0] if labels is not None else 1
+    gx = empty_cl(N, C, H, W, gy.device)
+    gscale = torch.empty((n_labels, C), dtype=torch.float32, device=gy.device)
+    goffset = torch.empty((n_labels, C), dtype=torch.float32, device=gy.device)
+    nb = lib.ctgan_bn_workspace_bytes(N, hw, C, groups, n_labels)
+    ws = workspace(nb, gy.device)
+    check(lib.ctgan_bn_bwd(_ptr(gy4), _ptr(x4), _ptr(mean), _ptr(rstd), _ptr(scale), _ptr(offset), _ptr(labels),
+                           _ptr(gx), _ptr(gscale), _ptr(goffset), N, hw, C, groups, n_labels, 1 if relu else 0,
+                           _ptr(ws), ws.numel(), _stream()), 'bn_bwd')
+    return gx, gscale, goffset
+
+
+# ------------------------------------------------------------------------------- loss heads
+def gp_fwd(g, lam):
+    _need_dev(g)
+    g = g.contiguous()
+    B, D = g.shape
+    slopes = torch.empty(B, dtype=torch.float32, device=g.device)
+    gp = torch.empty((), dtype=torch.float32, device=g.device)
+    check(lib.ctgan_gp_fwd(_ptr(g), B, D, lam, _ptr(slopes), _ptr(gp), _stream()), 'gp_fwd')
+    return gp, slopes
+
+
+def gp_bwd(g, slopes, gout, lam):
+    _need_dev(g, slopes, gout)
+    g = g.contiguous()
+    B, D = g.shape
+    gg = torch.empty_like(g)
+    check(lib.ctgan_gp_bwd(_ptr(g), _ptr(slopes), _ptr(gout.contiguous()), B, D, lam, _ptr(gg), _stream()), 'gp_bwd')
+    return gg
+
+
+def ct_fwd(d, d_, f, f_, lam2, M):
+    _need_dev(d, d_, f, f_)
+    d, d_, f, f_ = d.contiguous(), d_.contiguous(), f.contiguous(), f_.contiguous()
+    B, NF = f.shape
+    ct_i = torch.empty(B, dtype=torch.float32, device=d.device)
+    ct = torch.empty((), dtype=torch.float32, device=d.device)
+    check(lib.ctgan_ct_fwd(_ptr(d), _ptr(d_), _ptr(f), _ptr(f_), B, NF, lam2, M, _ptr(ct_i), _ptr(ct), _stream()),
+          'ct_fwd')
+    return ct, ct_i
+
+
+def ct_bwd(d, d_, f, f_, ct_i, gout, lam2, M):
+    _need_dev(d, d_, f, f_, ct_i, gout)
+    d, d_, f, f_ = d.contiguous(), d_.contiguous(), f.contiguous(), f_.contiguous()
+    B, NF = f.shape
+    gd, gd_ = torch.empty_like(d), torch.empty_like(d_)
+    gf, gf_ = torch.empty_like(f), torch.empty_like(f_)
+    check(lib.ctgan_ct_bwd(_ptr(d), _ptr(d_), _ptr(f), _ptr(f_), _ptr(ct_i), _ptr(gout.contiguous()), B, NF, lam2, M,
+                           _ptr(gd), _ptr(gd_), _ptr(gf), _ptr(gf_), _stream()), 'ct_bwd')
+    return gd, gd_, gf, gf_
+
+
+def softmax_ce_fwd(logits, labels):
+    _need_dev(logits, labels)
+    logits = logits.contiguous()
+    B, NC = logits.shape
+    assert labels.dtype == torch.int32 and labels.numel() == B
+    probs = torch.empty_like(logits)
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    ncorrect = torch.empty((), dtype=torch.float32, device=logits.device)
+    check(lib.ctgan_softmax_ce_fwd(_ptr(logits), _ptr(labels.contiguous()), B, NC, _ptr(probs), _ptr(loss),
+                                   _ptr(ncorrect), _stream()), 'softmax_ce_fwd')
+    return loss, probs, ncorrect
+
+
+def softmax_ce_bwd(probs, labels, gout):
+    _need_dev(probs, labels, gout)
+    B, NC = probs.shape
+    gl = torch.empty_like(probs)
+    check(lib.ctgan_softmax_ce_bwd(_ptr(probs), _ptr(labels.contiguous()), _ptr(gout.contiguous()), B, NC, _ptr(gl),
+                                   _stream()), 'softmax_ce_bwd')
+    return gl
+
+
+def mean_diff_fwd(x, na, nb, sa, sb):
+    _need_dev(x)
+    x = x.contiguous()
+    assert x.numel() == na + nb
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    check(lib.ctgan_mean_diff_fwd(_ptr(x), na, nb, sa, sb, _ptr(out), _stream()), 'mean_diff_fwd')
+    return out
+
+
+def mean_diff_bwd(gout, na, nb, sa, sb):
+    _need_dev(gout)
+    gx = torch.empty(na + nb, dtype=torch.float32, device=gout.device)
+    check(lib.ctgan_mean_diff_bwd(_ptr(gout.contiguous()), na, nb, sa, sb, _ptr(gx), _stream()), 'mean_diff_bwd')
+    return gx
+
+
+# ------------------------------------------------------------------------------- optimizer / rng
+def adam_step(theta, g, m, v, state, beta1, beta2, eps=1e-8, grad_scale=1.0):
+    """In-place TF-Adam on flat fp32 buffers; `state` = device float[4] {lr, beta1^t, beta2^t, -}."""
+    _need_dev(theta, g, m, v, state)
+    for t in (theta, g, m, v):
+        assert t.is_contiguous() and t.numel() == theta.numel()
+    check(lib.ctgan_adam_step(_ptr(theta), _ptr(g), _ptr(m), _ptr(v), theta.numel(), _ptr(state), beta1, beta2, eps,
+                              grad_scale, _stream()), 'adam_step')
+
+
+def adam_advance(state, beta1, beta2):
+    _need_dev(state)
+    check(lib.ctgan_adam_advance(_ptr(state), beta1, beta2, _stream()), 'adam_advance')
+
+
+def rng_uniform(out, seed, stream_id, ctr, lo=0.0, hi=1.0):
+    _need_dev(out)
+    assert is_dense(out) and out.dtype == torch.float32
+    check(lib.ctgan_rng_uniform(_ptr(out), out.numel(), seed, stream_id, _ptr(ctr), lo, hi, _stream()), 'rng_uniform')
+    return out
+
+
+def rng_normal(out, seed, stream_id, ctr):
+    _need_dev(out)
+    assert is_dense(out) and out.dtype == torch.float32
+    check(lib.ctgan_rng_normal(_ptr(out), out.numel(), seed, stream_id, _ptr(ctr), _stream()), 'rng_normal')
+    return out
+
+
+def rng_labels(out, nlab, seed, stream_id, ctr):
+    assert out.is_cuda and out.dtype == torch.int32 and out.is_contiguous()
+    check(lib.ctgan_rng_labels(_ptr(out), out.numel(), nlab, seed, stream_id, _ptr(ctr), _stream()), 'rng_labels')
+    return out
+
+
+def rng_advance(ctr, by=1):
+    assert ctr.is_cuda and ctr.dtype == torch.int64
+    check(lib.ctgan_rng_advance(_ptr(ctr), by, _stream()), 'rng_advance')

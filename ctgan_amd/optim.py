@@ -1,0 +1,65 @@
+"""TF-form Adam over one flat fp32 buffer per network (csrc/optim_rng.hip: adam_kernel).
+
+Mirrors `tf.train.AdamOptimizer(learning_rate=LR*decay, beta1, beta2)` + compute_gradients /
+apply_gradients (TF/CT_gan_cifar_resnet.py:333-338; TF/CT_gan_cifar.py:153-154).  The flat
+parameter / gradient buffers double as the all-reduce buckets of the batch-sharded step (ddp.py).
+"""
+import torch
+
+from . import kernels as K
+
+
+class FlatAdam:
+    def __init__(self, named_params, beta1, beta2, eps=1e-8):
+        """named_params: [(name, Parameter)] - the trainable variable list, in registry order."""
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        if not self.params:
+            raise ValueError('empty parameter list')
+        dev = self.params[0].device
+        self.beta1, self.beta2, self.eps = float(beta1), float(beta2), float(eps)
+        self.sizes = [p.numel() for p in self.params]
+        total = sum(self.sizes)
+        self.theta = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        # re-home every parameter inside the flat buffer (same values, same shapes)
+        off = 0
+        with torch.no_grad():
+            for p, n in zip(self.params, self.sizes):
+                self.theta[off:off + n].copy_(p.reshape(-1))
+                p.data = self.theta[off:off + n].view(p.shape)
+                off += n
+        # {lr, beta1^t, beta2^t, unused}; TF initialises the power accumulators to beta (t = 1)
+        self.state = torch.tensor([0.0, self.beta1, self.beta2, 0.0], dtype=torch.float32, device=dev)
+        self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == 'cuda' else torch.zeros(1)
+        self.t = 0
+
+    def set_lr(self, lr):
+        """Host -> device copy of the scalar learning rate (outside any captured graph)."""
+        self._lr_host[0] = float(lr)
+        self.state[0:1].copy_(self._lr_host, non_blocking=True)
+
+    def gather_grads(self, grads):
+        """Pack per-parameter gradients (None = zero) into the flat bucket."""
+        off = 0
+        for g, n in zip(grads, self.sizes):
+            if g is None:
+                self.grad[off:off + n].zero_()
+            else:
+                self.grad[off:off + n].copy_(g.reshape(-1))
+            off += n
+        return self.grad
+
+    def step(self, grad_scale=1.0):
+        """theta <- Adam(theta, grad); advances the beta-power accumulators."""
+        K.adam_step(self.theta, self.grad, self.m, self.v, self.state, self.beta1, self.beta2, self.eps, grad_scale)
+        K.adam_advance(self.state, self.beta1, self.beta2)
+        self.t += 1
+
+    def state_dict(self):
+        return {'m': self.m.cpu().clone(), 'v': self.v.cpu().clone(), 'state': self.state.cpu().clone(), 't': self.t}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.state.copy_(sd['state']); self.t = int(sd['t'])

@@ -1,0 +1,194 @@
+/* ctgan_hip.h - C-ABI of libctgan_hip.so: the MI355X (gfx950) kernels behind the CT-WGAN
+ * adversarial step of biuyq/CT-GAN.
+ *
+ * The reference has no native code and no FFI: its operator library (the tflib/ops modules) bottoms out
+ * in TensorFlow-1.2.1 graph nodes.  Each entry point below replaces one of those TF call sites
+ * (cited per function; TF/ = CT-GANs/tensorflow_generative_model/).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - All tensors are fp32 unless stated; activations are logically NCHW like the reference but
+ *    described with explicit element strides, so the physical layout may be NHWC (channels-last,
+ *    what the fast kernels want) or NCHW (image inputs / sample outputs).
+ *  - The library never allocates or frees caller-visible memory; workspaces are caller-provided
+ *    (size from ctgan_conv2d_workspace_bytes).
+ *  - Every call is asynchronous on the caller's hipStream_t (`stream`, passed as void*); no
+ *    internal device synchronisation; safe under hipGraph stream capture.
+ *  - Return 0 on success, negative CTGAN_E_* on failure; ctgan_last_error() gives a thread-local
+ *    message.  No C++ exception crosses the ABI.
+ */
+#ifndef CTGAN_HIP_H
+#define CTGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTGAN_OK 0
+#define CTGAN_E_BADARG (-1)
+#define CTGAN_E_UNSUPPORTED (-2)
+#define CTGAN_E_LAUNCH (-3)
+
+#define CTGAN_ABI_VERSION 1
+
+typedef void* ctgan_stream_t; /* hipStream_t */
+
+/* Geometry of one TF 'SAME' convolution  y[n,k,p,q] = sum_{r,s,c} x[n,c,p*stride-pad_t+r,
+ * q*stride-pad_l+s] * w[r,s,c,k]  (w is HWIO, contiguous: tflib `name.Filters`).
+ * The same descriptor drives the forward op, its data gradient and its weight gradient.
+ * A Deconv2D is described by the descriptor of the strided conv it is the adjoint of
+ * (x side = the large / output side of the deconv). */
+typedef struct ctgan_conv_desc {
+    int32_t N, C, H, W;   /* x: batch, channels, height, width                                */
+    int32_t K, R, S;      /* y channels, filter height, filter width                           */
+    int32_t P, Q;         /* y height, width ( = ceil(H/stride), ceil(W/stride) under SAME )   */
+    int32_t stride;       /* 1 or 2                                                            */
+    int32_t pad_t, pad_l; /* leading SAME pads (trailing pads are implied by P,Q)              */
+    int32_t x_up;         /* 1: x is read through a nearest-neighbour 2x upsample (H,W are the */
+                          /*    upsampled sizes; the physical tensor is H/2 x W/2)  (K10)      */
+    int32_t reserved;
+    int64_t xs[4];        /* x element strides for (n, c, h, w)                                */
+    int64_t ys[4];        /* y element strides for (n, k, p, q)                                */
+} ctgan_conv_desc;
+
+enum { CTGAN_CONV_FWD = 0, CTGAN_CONV_DGRAD = 1, CTGAN_CONV_WGRAD = 2 };
+enum { CTGAN_EPI_RELU = 1 };
+
+/* ---- library ------------------------------------------------------------------------------ */
+int ctgan_version(void);
+const char* ctgan_last_error(void);
+/* which kernel variant the last conv call on this thread dispatched to (for tests/profiles)   */
+const char* ctgan_last_kernel(void);
+
+/* ---- convolution family  (replaces tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112,
+ *      tf.nn.conv2d_transpose TF/tflib/ops/deconv2d.py:97-103, tf.matmul
+ *      TF/tflib/ops/linear.py:132-137 (as 1x1 conv on a 1x1 image), and the conv gradient nodes
+ *      tf.gradients / compute_gradients generate, TF/CT_gan_cifar_resnet.py:284,335-336) ------- */
+size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op);
+/* y = conv(x,w) [+ bias[k]] [+ resid (same strides as y)] [relu if flags&CTGAN_EPI_RELU]       */
+int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias,
+                     const float* resid, float* y, int flags, ctgan_stream_t stream);
+/* dx = adjoint of conv w.r.t. x, applied to dy [+ bias[c]] (dx has the strides d->xs; x_up must
+ * be 0).  With bias this is Deconv2D's forward (TF/tflib/ops/deconv2d.py:97-110).               */
+int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias,
+                       float* dx, void* ws, size_t ws_bytes, ctgan_stream_t stream);
+/* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K)   */
+int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw,
+                       void* ws, size_t ws_bytes, ctgan_stream_t stream);
+/* out[j] = sum_i x[i*ld + j], i<rows, j<cols (bias gradient; tf.nn.bias_add grad)             */
+int ctgan_colsum(const float* x, int64_t rows, int32_t cols, int64_t ld, float* out,
+                 void* ws, size_t ws_bytes, ctgan_stream_t stream);
+size_t ctgan_colsum_workspace_bytes(int64_t rows, int32_t cols);
+
+/* ---- elementwise / layout (K9-K12, K19 of SURVEY 2.1) -------------------------------------- */
+/* y = x>0 ? x : alpha*x   (tf.nn.relu alpha=0; LeakyReLU tf.maximum(alpha*x,x) alpha=0.2)     */
+int ctgan_lrelu_fwd(const float* x, float* y, int64_t n, float alpha, ctgan_stream_t stream);
+/* gx = ref>0 ? gy : alpha*gy  (ref = forward input or output; same sign)                      */
+int ctgan_lrelu_bwd(const float* gy, const float* ref, float* gx, int64_t n, float alpha,
+                    ctgan_stream_t stream);
+/* tf.nn.dropout: y = x/keep * floor(keep + u)  (TF/CT_gan_cifar_resnet.py:173-177); the
+ * backward is the same call on the gradient.                                                  */
+int ctgan_dropout(const float* x, const float* u, float* y, int64_t n, float keep,
+                  ctgan_stream_t stream);
+int ctgan_tanh_fwd(const float* x, float* y, int64_t n, ctgan_stream_t stream);
+int ctgan_tanh_bwd(const float* gy, const float* y, float* gx, int64_t n, ctgan_stream_t stream);
+int ctgan_sigmoid_fwd(const float* x, float* y, int64_t n, ctgan_stream_t stream);
+int ctgan_sigmoid_bwd(const float* gy, const float* y, float* gx, int64_t n, ctgan_stream_t stream);
+/* out = a*x + b*y  (residual add; y may be NULL => out = a*x)                                  */
+int ctgan_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b,
+                ctgan_stream_t stream);
+/* generic 4-D strided copy (NCHW <-> NHWC repack): y[i0,i1,i2,i3] = x[i0,i1,i2,i3]            */
+int ctgan_copy4d(const float* x, const int64_t xs[4], float* y, const int64_t ys[4],
+                 const int32_t dims[4], ctgan_stream_t stream);
+/* y[n,c,p,q] = scale * sum of the 2x2 window of x  (mean-pool: scale=.25,
+ * TF/CT_gan_cifar_resnet.py:91,96; also the adjoint of upsample2 with scale=1)                 */
+int ctgan_pool2(const float* x, const int64_t xs[4], float* y, const int64_t ys[4],
+                const int32_t ydims[4] /* n,c,p,q */, float scale, ctgan_stream_t stream);
+/* y[n,c,h,w] = scale * x[n,c,h/2,w/2]  (nearest 2x upsample, TF/CT_gan_cifar_resnet.py:102-105;
+ * also the adjoint of pool2)                                                                   */
+int ctgan_upsample2(const float* x, const int64_t xs[4], float* y, const int64_t ys[4],
+                    const int32_t ydims[4] /* n,c,h,w */, float scale, ctgan_stream_t stream);
+/* y[n,c] = scale * sum_{hw} x[n,hw,c]  (tf.reduce_mean(axis=[2,3]) :179) on channels-last x    */
+int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale,
+                      ctgan_stream_t stream);
+/* y[n,hw,c] = scale * g[n,c]  (its adjoint)                                                    */
+int ctgan_spatial_bcast(const float* g, float* y, int32_t n, int32_t hw, int32_t c, float scale,
+                        ctgan_stream_t stream);
+/* real = 2*((int/denom)-.5) + noise   (TF/CT_gan_cifar_resnet.py:201-202; noise may be NULL:
+ * TF/CT_gan_cifar.py:103 with denom 255)                                                       */
+int ctgan_real_prep(const int32_t* x_int, const float* noise, float* y, int64_t n, float denom,
+                    ctgan_stream_t stream);
+/* out[b,:] = real[b,:] + alpha[b]*(fake[b,:]-real[b,:])   (:282-283)                           */
+int ctgan_interpolate(const float* real, const float* fake, const float* alpha, float* out,
+                      int32_t b, int32_t d, ctgan_stream_t stream);
+
+/* ---- batch norm (K13/K14): training-mode statistics over (n,h,w) per channel, biased variance,
+ *      eps added inside rsqrt; `groups` independent row groups of n/groups samples each model the
+ *      reference's per-tower statistics (TF/CT_gan_cifar_resnet.py:196-199,316-321).
+ *      x is channels-last [n, hw, c].  scale/offset are [n_labels, c] gathered by labels[n]
+ *      (cond_batchnorm.py:12-16) or [c] when labels == NULL (batchnorm.py:23-30).  ---------- */
+int ctgan_bn_stats(const float* x, int32_t n, int32_t hw, int32_t c, int32_t groups, float eps,
+                   float* mean /*[groups,c]*/, float* rstd /*[groups,c]*/,
+                   void* ws, size_t ws_bytes, ctgan_stream_t stream);
+int ctgan_bn_apply(const float* x, const float* mean, const float* rstd, const float* scale,
+                   const float* offset, const int32_t* labels, float* y, int32_t n, int32_t hw,
+                   int32_t c, int32_t groups, int32_t relu, ctgan_stream_t stream);
+/* backward of y = [relu]( xhat*scale + offset ): gy -> gx, gscale, goffset                     */
+int ctgan_bn_bwd(const float* gy, const float* x, const float* mean, const float* rstd,
+                 const float* scale, const float* offset, const int32_t* labels,
+                 float* gx, float* gscale, float* goffset, int32_t n, int32_t hw, int32_t c,
+                 int32_t groups, int32_t n_labels, int32_t relu, void* ws, size_t ws_bytes,
+                 ctgan_stream_t stream);
+size_t ctgan_bn_workspace_bytes(int32_t n, int32_t hw, int32_t c, int32_t groups, int32_t n_labels);
+
+/* ---- fused loss heads (K16-K20) ------------------------------------------------------------- */
+/* slopes[b] = ||g[b,:]||_2 ; gp = lambda*mean((slopes-1)^2)   (TF/CT_gan_cifar_resnet.py:285-286) */
+int ctgan_gp_fwd(const float* g, int32_t b, int32_t d, float lambda, float* slopes, float* gp,
+                 ctgan_stream_t stream);
+/* gg[b,:] = gout * lambda*2*(s-1)/(s*B) * g[b,:]                                               */
+int ctgan_gp_bwd(const float* g, const float* slopes, const float* gout, int32_t b, int32_t d,
+                 float lambda, float* gg, ctgan_stream_t stream);
+/* CT_i = l2*(d-d_)^2 + l2*0.1*mean_j (f-f_)^2 ; ct = mean_i max(CT_i - M, 0)   (:288-291)      */
+int ctgan_ct_fwd(const float* d, const float* d_, const float* f, const float* f_, int32_t b,
+                 int32_t nf, float lambda2, float M, float* ct_i, float* ct, ctgan_stream_t stream);
+int ctgan_ct_bwd(const float* d, const float* d_, const float* f, const float* f_,
+                 const float* ct_i, const float* gout, int32_t b, int32_t nf, float lambda2, float M,
+                 float* gd, float* gd_, float* gf, float* gf_, ctgan_stream_t stream);
+/* loss = mean_i CE(logits[i,:], labels[i]); probs saved for backward; correct = #argmax==label  */
+int ctgan_softmax_ce_fwd(const float* logits, const int32_t* labels, int32_t b, int32_t ncls,
+                         float* probs, float* loss, float* n_correct, ctgan_stream_t stream);
+int ctgan_softmax_ce_bwd(const float* probs, const int32_t* labels, const float* gout, int32_t b,
+                         int32_t ncls, float* glogits, ctgan_stream_t stream);
+/* out = sign_a*mean(x[0:na]) + sign_b*mean(x[na:na+nb])  (WGAN critic / generator cost :244,322) */
+int ctgan_mean_diff_fwd(const float* x, int32_t na, int32_t nb, float sa, float sb, float* out,
+                        ctgan_stream_t stream);
+int ctgan_mean_diff_bwd(const float* gout, int32_t na, int32_t nb, float sa, float sb, float* gx,
+                        ctgan_stream_t stream);
+
+/* ---- optimizer (K21): tf.train.AdamOptimizer on a flat buffer
+ *      (TF/CT_gan_cifar_resnet.py:333-338).  `state` = device float[4]: {lr, beta1^t, beta2^t, _};
+ *      the kernel reads lr and the running beta powers from it (graph-replay safe) and
+ *      ctgan_adam_advance multiplies the powers after all buckets of a step are applied. ------ */
+int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, const float* state,
+                    float beta1, float beta2, float eps, float grad_scale, ctgan_stream_t stream);
+int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t stream);
+
+/* ---- RNG: Philox4x32-10 counter-based streams (tf.random_uniform / tf.random_normal /
+ *      dropout masks :157,202,277,319).  counter base is read from device memory
+ *      (`ctr[0]`, advanced by ctgan_rng_advance) so captured graphs draw fresh numbers. -------- */
+int ctgan_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
+                      float lo, float hi, ctgan_stream_t stream);
+int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
+                     ctgan_stream_t stream);
+/* labels = (int32)(u*nlab), u~U[0,1)   (tf.cast(tf.random_uniform*10, int32) :319)             */
+int ctgan_rng_labels(int32_t* out, int64_t n, int32_t nlab, uint64_t seed, uint64_t stream_id,
+                     const uint64_t* ctr, ctgan_stream_t stream);
+int ctgan_rng_advance(uint64_t* ctr, uint64_t by, ctgan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTGAN_HIP_H */

@@ -25,3 +25,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    """Swap the HIP kernel wrappers for torch-CPU stand-ins (tests/cpu_kernels.py) so that the
+    host logic can be exercised without a GPU.  Test infrastructure; the product has no CPU path."""
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from tests import cpu_kernels as M
+    for name in M.__all__:
+        monkeypatch.setattr(K, name, getattr(M, name))
+    lib.delete_all_params()
+    lib.set_device('cpu')
+    yield M
+    lib.delete_all_params()
+    lib.set_device(None)

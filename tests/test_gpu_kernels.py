@@ -1,0 +1,307 @@
+"""Parity of every HIP kernel family against the CPU oracle (fp64 truth), through the C-ABI.
+Runs on the MI355X box only (`-m gpu`)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tf_ops  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def K():
+    import ctgan_amd.kernels as K
+    return K
+
+
+def dev(t):
+    return t.to('cuda')
+
+
+def cl(t):
+    """channels-last copy on device"""
+    d = t.to('cuda')
+    out = torch.empty((d.shape[0], d.shape[2], d.shape[3], d.shape[1]), device='cuda', dtype=d.dtype).permute(0, 3, 1, 2)
+    out.copy_(d)
+    return out
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+# (N, C, H, W, K, k, stride, x_layout, up)   -- covers vector + generic loaders, every tile shape
+CONV_CASES = [
+    (4, 128, 8, 8, 128, 3, 1, 'cl', False),      # hot 3x3, 32x128 tile
+    (16, 128, 16, 16, 128, 3, 1, 'cl', False),    # 64x128
+    (64, 128, 32, 32, 128, 3, 1, 'cl', False),    # 128x128 tile (M=65536)
+    (3, 3, 32, 32, 128, 3, 1, 'nchw', False),     # first critic conv: generic A from NCHW image
+    (3, 3, 16, 16, 128, 1, 1, 'cl', False),       # 1x1 shortcut from pooled image
+    (5, 128, 16, 16, 128, 1, 1, 'cl', False),     # 1x1 shortcut
+    (3, 128, 32, 32, 3, 3, 1, 'cl', False),       # generator output conv (K=3: generic B)
+    (4, 128, 8, 8, 128, 3, 1, 'cl', True),        # UpsampleConv: x_up gather, physical 4x4
+    (2, 3, 32, 32, 128, 5, 2, 'nchw', False),     # DCGAN critic layer 1 (stride 2, asymmetric pad)
+    (2, 128, 16, 16, 256, 5, 2, 'cl', False),     # DCGAN critic layer 2
+    (3, 64, 7, 7, 96, 5, 2, 'cl', False),         # odd size, pad (2,2); K=96 -> partial N tile
+    (2, 1, 28, 28, 64, 5, 2, 'cl', False),        # MNIST layer 1
+    (7, 40, 6, 5, 24, 3, 1, 'cl', False),         # nothing aligned: fully generic
+    (130, 128, 1, 1, 2048, 1, 1, 'cl', False),    # Linear 128->2048 as a 1x1 conv
+    (64, 8192, 1, 1, 1, 1, 1, 'cl', False),       # DCGAN critic head (GEMV)
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d_%s%s' % (c[:8] + ('_up' if c[8] else '',)))
+def test_conv_fwd_dgrad_wgrad(K, case):
+    N, C, H, W, Ko, k, st, layout, up = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    Hp, Wp = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(N, C, Hp, Wp, generator=g)
+    w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
+    b = torch.randn(Ko, generator=g)
+    xin = tf_ops.upsample2(x.double()) if up else x.double()
+    ref = tf_ops.bias_add_nchw(tf_ops.conv2d_same(xin, w.double(), st), b.double())
+    geom = K.ConvGeom(C, H, W, Ko, k, k, st, up)
+    xd = cl(x) if layout == 'cl' else dev(x)
+    y = K.conv_fwd(xd, dev(w), dev(b), geom)
+    name_fwd = K.last_kernel()
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert relerr(y, ref) < 2e-5, name_fwd
+    # fused epilogue: + resid, relu ; NCHW output
+    r = torch.randn(ref.shape, generator=g)
+    y2 = K.conv_fwd(xd, dev(w), dev(b), geom, resid=cl(r), relu=True)
+    assert relerr(y2, torch.relu(ref + r.double())) < 2e-5
+    y3 = K.conv_fwd(xd, dev(w), None, geom, out_strides=tuple(torch.empty(ref.shape).stride()))
+    assert y3.is_contiguous() and relerr(y3, ref - b.double().view(1, -1, 1, 1)) < 2e-5
+
+    # dgrad / wgrad against autograd of the oracle
+    gy = torch.randn(ref.shape, generator=g)
+    xin_ = xin.clone().requires_grad_(True)
+    w_ = w.double().clone().requires_grad_(True)
+    out = tf_ops.conv2d_same(xin_, w_, st)
+    gx_ref, gw_ref = torch.autograd.grad(out, [xin_, w_], gy.double())
+    gw = K.conv_wgrad(xd, cl(gy), geom)
+    assert relerr(gw, gw_ref) < 3e-5, K.last_kernel()
+    gw_b = K.conv_wgrad(xd, dev(gy), geom)                     # NCHW-strided dy
+    assert relerr(gw_b, gw_ref) < 3e-5, K.last_kernel()
+    if not up:
+        gx = K.conv_dgrad(cl(gy), dev(w), geom, N)
+        assert relerr(gx, gx_ref) < 2e-5, K.last_kernel()
+        gx2 = K.conv_dgrad(dev(gy), dev(w), geom, N, out_strides=tuple(x.stride()), bias=None)
+        assert gx2.is_contiguous() and relerr(gx2, gx_ref) < 2e-5
+
+
+def test_conv_vector_and_generic_paths_agree_bitwise(K):
+    """The vector loaders only change how tiles reach LDS: same MFMA order => identical bits.
+    A misaligned (offset-by-one-element) view forces the generic path on the same values."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 128, 8, 8, generator=g)
+    w = torch.randn(3, 3, 128, 128, generator=g) * 0.03
+    geom = K.ConvGeom(128, 8, 8, 128, 3, 3, 1, False)
+    xa = cl(x)
+    y_vec = K.conv_fwd(xa, dev(w), None, geom)
+    k_vec = K.last_kernel()
+    buf = torch.empty(xa.numel() + 1, device='cuda')
+    xb = buf[1:].view(4, 8, 8, 128).permute(0, 3, 1, 2)
+    xb.copy_(xa)
+    wbuf = torch.empty(w.numel() + 1, device='cuda')
+    wb = wbuf[1:].view(3, 3, 128, 128)
+    wb.copy_(dev(w))
+    y_gen = K.conv_fwd(xb, wb, None, geom)
+    k_gen = K.last_kernel()
+    assert 'avec,bvec' in k_vec and 'agen,bgen' in k_gen, (k_vec, k_gen)
+    assert torch.equal(y_vec, y_gen)
+
+
+def test_conv_is_deterministic(K):
+    g = torch.Generator().manual_seed(8)
+    x = cl(torch.randn(32, 128, 16, 16, generator=g)); gy = cl(torch.randn(32, 128, 16, 16, generator=g))
+    w = dev(torch.randn(3, 3, 128, 128, generator=g))
+    geom = K.ConvGeom(128, 16, 16, 128, 3, 3, 1, False)
+    a = K.conv_wgrad(x, gy, geom).clone(); b = K.conv_wgrad(x, gy, geom)
+    assert 'split' in K.last_kernel() and torch.equal(a, b)
+    assert torch.equal(K.conv_fwd(x, w, None, geom), K.conv_fwd(x, w, None, geom))
+
+
+def test_deconv_matches_tf_conv2d_transpose(K):
+    import ctgan_amd.functional as F
+    g = torch.Generator().manual_seed(9)
+    for (n, ci, co, h, w_) in [(2, 256, 128, 4, 4), (3, 128, 64, 7, 7), (2, 64, 3, 16, 16), (2, 64, 1, 14, 14)]:
+        x = torch.randn(n, ci, h, w_, generator=g)
+        w = torch.randn(5, 5, co, ci, generator=g) / np.sqrt(25 * ci / 4)
+        b = torch.randn(co, generator=g)
+        ref = tf_ops.bias_add_nchw(tf_ops.conv2d_transpose_same(x.double(), w.double(), 2), b.double())
+        xd = cl(x).requires_grad_(True); wd = dev(w).requires_grad_(True); bd = dev(b).requires_grad_(True)
+        y = F.conv2d_transpose(xd, wd, bd)
+        assert tuple(y.shape) == (n, co, 2 * h, 2 * w_) and relerr(y, ref) < 2e-5
+        gy = torch.randn(ref.shape, generator=g)
+        x_ = x.double().requires_grad_(True); w_r = w.double().requires_grad_(True); b_ = b.double().requires_grad_(True)
+        r = tf_ops.bias_add_nchw(tf_ops.conv2d_transpose_same(x_, w_r, 2), b_)
+        gr = torch.autograd.grad(r, [x_, w_r, b_], gy.double())
+        gp = torch.autograd.grad(y, [xd, wd, bd], cl(gy))
+        for a, c in zip(gp, gr):
+            assert relerr(a, c) < 3e-5
+
+
+def test_elementwise(K):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 12, 6, 6, generator=g); u = torch.rand(5, 12, 6, 6, generator=g)
+    xd, ud = cl(x), cl(u)
+    assert torch.equal(K.lrelu_fwd(xd, 0.0).cpu(), torch.relu(x))
+    assert relerr(K.lrelu_fwd(xd, 0.2), tf_ops.leaky_relu(x.double())) < 1e-7
+    assert relerr(K.lrelu_bwd(ud, xd, 0.2), torch.where(x > 0, u, 0.2 * u)) < 1e-7
+    for keep in (0.8, 0.5):
+        assert relerr(K.dropout(xd, ud, keep), tf_ops.dropout(x, keep, u)) < 1e-6
+        assert relerr(K.dropout(xd, dev(u), keep), tf_ops.dropout(x, keep, u)) < 1e-6       # layout repack of u
+    assert relerr(K.tanh_fwd(xd), torch.tanh(x.double())) < 1e-6
+    assert relerr(K.sigmoid_fwd(xd), torch.sigmoid(x.double())) < 1e-6
+    y = torch.tanh(x)
+    assert relerr(K.tanh_bwd(ud, cl(y)), u.double() * (1 - y.double() ** 2)) < 1e-6
+    assert relerr(K.axpby(xd, ud, 2.0, -0.5), 2 * x.double() - 0.5 * u.double()) < 1e-6
+    assert relerr(K.axpby(xd, None, 3.0, 0.0), 3 * x.double()) < 1e-7
+    assert torch.equal(K.to_nchw(xd).cpu(), x) and K.to_nchw(xd).is_contiguous()
+    assert torch.equal(K.to_channels_last(dev(x)).cpu(), x)
+    xe = torch.randn(3, 5, 8, 10, generator=g)
+    assert relerr(K.pool2(cl(xe), 0.25), tf_ops.mean_pool2(xe.double())) < 1e-6
+    assert relerr(K.pool2(dev(xe), 0.25), tf_ops.mean_pool2(xe.double())) < 1e-6          # NCHW input
+    assert torch.equal(K.upsample2(cl(xe), 1.0).cpu(), tf_ops.upsample2(xe))
+    assert relerr(K.spatial_sum(cl(xe), 1.0 / 80), xe.double().mean(dim=(2, 3))) < 1e-6
+    gg = torch.randn(3, 5, generator=g)
+    assert relerr(K.spatial_bcast(dev(gg), 8, 10, 0.5), (0.5 * gg)[:, :, None, None].expand(3, 5, 8, 10)) < 1e-7
+    xi = torch.randint(0, 256, (6, 3072), generator=g, dtype=torch.int32)
+    nz = torch.rand(6, 3072, generator=g) / 128
+    assert relerr(K.real_prep(dev(xi), dev(nz), 256.0), 2 * (xi.double() / 256. - .5) + nz.double()) < 1e-6
+    assert relerr(K.real_prep(dev(xi), None, 255.0), 2 * (xi.double() / 255. - .5)) < 1e-6
+    a = torch.rand(6, 1, generator=g); f = torch.randn(6, 3072, generator=g); r = torch.randn(6, 3072, generator=g)
+    assert relerr(K.interpolate(dev(r), dev(f), dev(a)), r.double() + a.double() * (f.double() - r.double())) < 1e-6
+    big = torch.randn(1000, 130, generator=g)
+    assert relerr(K.colsum_channels(cl(big.view(10, 100, 130).permute(0, 2, 1).unsqueeze(3).contiguous())),
+                  big.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('n,c,h,groups,cond,relu', [(8, 128, 4, 1, True, True), (6, 16, 8, 2, True, True),
+                                                     (4, 128, 32, 1, False, True), (8, 200, 1, 1, False, False),
+                                                     (64, 128, 16, 2, True, True)])
+def test_batchnorm(K, n, c, h, groups, cond, relu):
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, h, h, generator=g) * 2 + 3.0             # |mean| >> 0: exercises the fp64 stats
+    nl = 10 if cond else 1
+    scale = torch.rand(nl, c, generator=g) + 0.5; offset = torch.randn(nl, c, generator=g)
+    labels = torch.randint(0, 10, (n,), generator=g, dtype=torch.int32) if cond else None
+    gy = torch.randn(n, c, h, h, generator=g)
+    xr = x.double().requires_grad_(True); sr = scale.double().requires_grad_(True); orr = offset.double().requires_grad_(True)
+    per = n // groups
+    outs = []
+    for gi in range(groups):
+        xs = xr[gi * per:(gi + 1) * per]
+        mean, var = tf_ops.moments(xs, [0, 2, 3])
+        lab = labels[gi * per:(gi + 1) * per].long() if cond else torch.zeros(per, dtype=torch.long)
+        outs.append(tf_ops.batch_normalization(xs, mean, var, orr[lab][:, :, None, None], sr[lab][:, :, None, None], 1e-5))
+    ref = torch.cat(outs)
+    if relu:
+        ref = torch.relu(ref)
+    gr = torch.autograd.grad(ref, [xr, sr, orr], gy.double())
+    y, mean, rstd, x4 = K.bn_fwd(cl(x), dev(scale), dev(offset), dev(labels) if cond else None, groups, relu)
+    assert relerr(y, ref) < 2e-5
+    gx, gs, go = K.bn_bwd(cl(gy), x4, mean, rstd, dev(scale), dev(offset), dev(labels) if cond else None, groups, relu)
+    assert relerr(gx, gr[0]) < 1e-4 and relerr(gs, gr[1]) < 1e-4 and relerr(go, gr[2]) < 1e-4
+
+
+def test_loss_heads(K):
+    g = torch.Generator().manual_seed(5)
+    gr = torch.randn(64, 3072, generator=g) * 0.02
+    s = gr.double().norm(dim=1)
+    gp, slopes = K.gp_fwd(dev(gr), 10.0)
+    assert relerr(slopes, s) < 1e-6 and relerr(gp, 10 * ((s - 1) ** 2).mean()) < 1e-6
+    grd = gr.double().requires_grad_(True)
+    ref = torch.autograd.grad(10 * ((grd.norm(dim=1) - 1) ** 2).mean() * 0.7, grd)[0]
+    assert relerr(K.gp_bwd(dev(gr), slopes, dev(torch.tensor(0.7)), 10.0), ref) < 1e-5
+    d, d_ = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    f, f_ = torch.randn(64, 128, generator=g), torch.randn(64, 128, generator=g)
+    from oracle import steps
+    for M in (0.0, 3.0):
+        leaves = [t.double().requires_grad_(True) for t in (d, d_, f, f_)]
+        ref = steps.ct_term(*leaves, 2.0, M)
+        refg = torch.autograd.grad(ref * 1.3, leaves)
+        ct, ct_i = K.ct_fwd(dev(d), dev(d_), dev(f), dev(f_), 2.0, M)
+        assert relerr(ct, ref) < 1e-6
+        got = K.ct_bwd(dev(d), dev(d_), dev(f), dev(f_), ct_i, dev(torch.tensor(1.3)), 2.0, M)
+        for a, b in zip(got, refg):
+            assert relerr(a, b) < 1e-5
+    logits = torch.randn(64, 10, generator=g) * 3
+    labels = torch.randint(0, 10, (64,), generator=g, dtype=torch.int32)
+    lr = logits.double().requires_grad_(True)
+    ref = tf_ops.sparse_softmax_ce(lr, labels).mean()
+    loss, probs, nc = K.softmax_ce_fwd(dev(logits), dev(labels))
+    assert relerr(loss, ref) < 1e-6 and nc.item() == (logits.argmax(1) == labels.long()).sum().item()
+    assert relerr(K.softmax_ce_bwd(probs, dev(labels), dev(torch.tensor(2.0))), torch.autograd.grad(ref * 2, lr)[0]) < 1e-5
+    x = torch.randn(128, generator=g)
+    assert relerr(K.mean_diff_fwd(dev(x), 64, 64, -1.0, 1.0), x[64:].double().mean() - x[:64].double().mean()) < 1e-5
+    assert relerr(K.mean_diff_fwd(dev(x), 128, 0, -1.0, 0.0), -x.double().mean()) < 1e-5
+    gx = K.mean_diff_bwd(dev(torch.tensor(2.0)), 64, 64, -1.0, 1.0).cpu()
+    assert torch.allclose(gx[:64], torch.full((64,), -2.0 / 64)) and torch.allclose(gx[64:], torch.full((64,), 2.0 / 64))
+
+
+def test_tf_adam_kernel(K):
+    g = torch.Generator().manual_seed(6)
+    n = 100003
+    th = torch.randn(n, generator=g); m = torch.zeros(n); v = torch.zeros(n)
+    thd, md, vd = dev(th).clone(), dev(m).clone(), dev(v).clone()
+    state = torch.tensor([1e-3, 0.5, 0.9, 0.0], device='cuda')
+    ref_t, ref_m, ref_v = th.double(), m.double(), v.double()
+    for t in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        ref_t, ref_m, ref_v = tf_ops.tf_adam_step(ref_t, gr.double(), ref_m, ref_v, t, 1e-3, 0.5, 0.9)
+        K.adam_step(thd, dev(gr), md, vd, state, 0.5, 0.9)
+        K.adam_advance(state, 0.5, 0.9)
+        assert relerr(thd, ref_t) < 1e-6 and relerr(md, ref_m) < 1e-6 and relerr(vd, ref_v) < 1e-6
+    assert abs(state[1].item() - 0.5 ** 4) < 1e-7
+
+
+def _philox_np(seed, sid, step, nblk):
+    """numpy Philox4x32-10 with the kernel's counter layout (known-answer checked below)."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = np.zeros((nblk, 4), dtype=np.uint64)
+    c[:, 0] = np.arange(nblk); c[:, 1] = sid; c[:, 2] = step & 0xffffffff; c[:, 3] = step >> 32
+    k0, k1 = seed & 0xffffffff, seed >> 32
+    for _ in range(10):
+        p0 = M0 * c[:, 0]; p1 = M1 * c[:, 2]
+        n0 = (p1 >> 32) ^ c[:, 1] ^ k0; n1 = p1 & 0xffffffff
+        n2 = (p0 >> 32) ^ c[:, 3] ^ k1; n3 = p0 & 0xffffffff
+        c = np.stack([n0, n1, n2, n3], 1) & 0xffffffff
+        k0 = (k0 + W0) & 0xffffffff; k1 = (k1 + W1) & 0xffffffff
+    return c.astype(np.uint32)
+
+
+def test_philox_known_answer_and_streams(K):
+    # Random123 known-answer vector: counter=0, key=0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8
+    assert [hex(v) for v in _philox_np(0, 0, 0, 1)[0]] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+    out = torch.empty(1001, device='cuda')
+    K.rng_uniform(out, 2024, 5, ctr, 0.0, 1.0)
+    exp = (_philox_np(2024, 5, 0, 251).reshape(-1)[:1001] >> 8).astype(np.float32) / np.float32(16777216.0)
+    assert np.array_equal(out.cpu().numpy(), exp)                                  # bit-exact
+    a = out.clone()
+    K.rng_advance(ctr, 1)
+    K.rng_uniform(out, 2024, 5, ctr, 0.0, 1.0)
+    assert not torch.equal(a, out) and ctr.item() == 1
+    exp1 = (_philox_np(2024, 5, 1, 251).reshape(-1)[:1001] >> 8).astype(np.float32) / np.float32(16777216.0)
+    assert np.array_equal(out.cpu().numpy(), exp1)
+    big = torch.empty(1 << 20, device='cuda')
+    K.rng_uniform(big, 1, 2, ctr, 0.0, 1.0)
+    assert 0 <= big.min() and big.max() < 1 and abs(big.mean().item() - 0.5) < 2e-3
+    K.rng_normal(big, 1, 3, ctr)
+    assert abs(big.mean().item()) < 5e-3 and abs(big.std().item() - 1) < 5e-3
+    lab = torch.empty(100000, dtype=torch.int32, device='cuda')
+    K.rng_labels(lab, 10, 1, 4, ctr)
+    assert lab.min() == 0 and lab.max() == 9
+    assert np.allclose(np.bincount(lab.cpu().numpy(), minlength=10) / 1e5, 0.1, atol=0.01)
+
+
+def test_errors_surface_as_python_exceptions(K):
+    with pytest.raises(RuntimeError):
+        K.lrelu_fwd(torch.zeros(4), 0.0)                   # CPU tensor: no fallback
+    x = torch.zeros(4, device='cuda')
+    with pytest.raises(ValueError):
+        K.dropout(x, x, 0.0)                               # keep must be in (0,1]

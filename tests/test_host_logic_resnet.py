@@ -1,0 +1,144 @@
+"""Host logic of the ResNet CT-WGAN step (autograd wiring incl. the GP double backward, registry,
+restructured loss graph, flat TF-Adam) checked against the CPU oracle - with the HIP kernel
+wrappers swapped for torch-CPU stand-ins (fixture cpu_kernels).  The kernels themselves are
+checked on the GPU box by tests/test_gpu_*.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets, steps as osteps, tflib_ref as oref
+
+
+def _oracle_from_product(lib, dtype=torch.float64):
+    reg = oref.Registry(dtype=dtype)
+    for n, p in lib._params.items():
+        t = p.detach().clone().to(dtype)
+        trainable = n not in lib._non_trainable
+        t.requires_grad_(trainable)
+        reg[n] = t
+        if not trainable:
+            reg.non_trainable.add(n)
+    return reg
+
+
+def _cmp(a, b, tol, what, atol=1e-7):
+    """max-norm relative check.  `atol` absorbs quantities that are analytically zero (e.g. the
+    gradient of a bias that feeds a batch norm), where fp32 leaves O(1e-9) noise; for parameters
+    Adam turns that noise into O(0.1*lr) steps on weights the network is invariant to."""
+    a = a.detach().double().reshape(-1)
+    b = b.detach().double().reshape(-1)
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item()
+    assert err <= tol * scale + atol, '%s: max err %.3e vs scale %.3e' % (what, err, scale)
+
+
+@pytest.fixture
+def small(cpu_kernels):
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    lib.set_seed(5)
+    R.configure(DIM_G=8, DIM_D=8, BATCH_SIZE=4)
+    R.build_params('cpu')
+    yield R, lib
+    R.configure()
+
+
+def test_param_names_shapes_and_counts_full_width(cpu_kernels):
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    R.configure()
+    R.build_params('cpu')
+    nD = sum(p.numel() for _, p in lib.named_params_with_name('Discriminator.', True))
+    nG = sum(p.numel() for _, p in lib.named_params_with_name('Generator', True))
+    assert nD == 1055115 and nG == 1218307
+    oreg = oref.Registry(dtype=torch.float32)
+    cfg = onets.ResnetCfg()
+    lab = torch.zeros(2, dtype=torch.int32)
+    x = onets.resnet_generator(oreg, cfg, 2, lab, torch.zeros(2, 128))
+    onets.resnet_discriminator(oreg, cfg, x, lab, 1., 1., 1.)
+    assert {n: tuple(p.shape) for n, p in lib._params.items()} == {n: tuple(p.shape) for n, p in oreg.items()}
+    assert lib._non_trainable == oreg.non_trainable
+    # same init scheme (per-name streams): identical values for the same seed
+    lib.delete_all_params(); lib.set_seed(0)
+    R.build_params('cpu')
+    for n in ('Discriminator.2.Conv1.Filters', 'Generator.Input.W', 'Generator.1.Shortcut.Filters'):
+        assert torch.equal(lib._params[n].detach(), oreg[n].detach()), n
+
+
+def test_forward_matches_oracle(small):
+    R, lib = small
+    reg = _oracle_from_product(lib)
+    cfg = onets.ResnetCfg(DIM_G=8, DIM_D=8)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(6, 128, generator=g)
+    lab = torch.randint(0, 10, (6,), generator=g, dtype=torch.int32)
+    x = R.Generator(6, lab, noise=z)
+    xo = onets.resnet_generator(reg, cfg, 6, lab, z.double())
+    _cmp(x, xo, 2e-5, 'generator')
+    u = [torch.rand(6, 8, 8, 8, generator=g) for _ in range(3)]
+    d, f, a = R.Discriminator(x, lab, 0.8, 0.5, 0.5, u=u)
+    do, fo, ao = onets.resnet_discriminator(reg, cfg, xo, lab, 0.8, 0.5, 0.5, [t.double() for t in u])
+    _cmp(d, do, 5e-5, 'D'); _cmp(f, fo, 5e-5, 'D_'); _cmp(a, ao, 5e-5, 'acgan')
+    # groups=2 == two separate towers
+    x2 = R.Generator(6, lab, noise=z, groups=2)
+    xa = onets.resnet_generator(reg, cfg, 3, lab[:3], z[:3].double())
+    xb = onets.resnet_generator(reg, cfg, 3, lab[3:], z[3:].double())
+    _cmp(x2, torch.cat([xa, xb]), 2e-5, 'generator groups=2')
+
+
+def test_d_step_and_g_step_match_oracle(small):
+    R, lib = small
+    B = 4
+    reg = _oracle_from_product(lib)
+    cfg = onets.ResnetCfg(DIM_G=8, DIM_D=8)
+    g = torch.Generator().manual_seed(1)
+    real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+    labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+    rnd64 = osteps.make_rnd_resnet_d(B, 8, g)
+    rnd32 = {k: ([t.float() for t in v] if isinstance(v, list) else v.float()) for k, v in rnd64.items()}
+    tr = R.Trainer(seed=1)
+    optD = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+    optG = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Generator')], 0.0, 0.9)
+
+    for it in range(2):                                   # two D steps: checks Adam slot/beta-power carry-over
+        out = tr.d_step(real, labels, rnd32, iteration=it)
+        ref = osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd64, iteration=it, B=B)
+        for k in ('cost', 'wgan', 'acgan', 'ct', 'gp', 'wgan_only', 'acc_real', 'acc_fake'):
+            _cmp(out[k], ref[k], 2e-4, 'd_step[%d].%s' % (it, k))
+        _cmp(out['gp_grads'], ref['gp_grads'], 2e-4, 'gp grads')
+        assert set(out['grads']) == set(ref['grads'])
+        for n in ref['grads']:
+            _cmp(out['grads'][n], ref['grads'][n], 5e-4, 'dgrad ' + n)
+        for n, _ in reg.trainable_with_name('Discriminator.'):
+            _cmp(lib._params[n], reg[n], 5e-4, 'theta ' + n, atol=2e-5)
+
+    rg64 = osteps.make_rnd_resnet_g(B, 8, g)
+    rg32 = {'z': [t.float() for t in rg64['z']], 'label_u': [t.float() for t in rg64['label_u']],
+            'u': [[t.float() for t in tw] for tw in rg64['u']]}
+    out = tr.g_step(rg32, iteration=1)
+    ref = osteps.resnet_g_step(reg, cfg, optG, rg64, iteration=1, B=B)
+    _cmp(out['cost'], ref['cost'], 2e-4, 'g cost')
+    assert set(out['grads']) == set(ref['grads'])
+    for n in ref['grads']:
+        _cmp(out['grads'][n], ref['grads'][n], 1e-3, 'ggrad ' + n)
+    for n, _ in reg.trainable_with_name('Generator'):
+        if ref['grads'][n].abs().max() < 1e-12:
+            continue     # bias feeding a batch norm: analytically zero gradient, Adam amplifies fp32 noise
+        _cmp(lib._params[n], reg[n], 1e-3, 'theta ' + n, atol=2e-5)
+    # the critic received no update from the G step
+    assert tr.d_opt.t == 2 and tr.g_opt.t == 1
+
+
+def test_eager_rng_path_runs(small):
+    """No injected randomness: draws come from DeviceRNG (mocked here) - finite losses, params move."""
+    R, lib = small
+    tr = R.Trainer(seed=3)
+    g = torch.Generator().manual_seed(2)
+    real = torch.randint(0, 256, (4, 3072), generator=g, dtype=torch.int32)
+    labels = torch.randint(0, 10, (4,), generator=g, dtype=torch.int32)
+    before = tr.d_opt.theta.clone()
+    it = iter(lambda: (real, labels), None)
+    out = tr.train_iteration(1, lambda: next(it))
+    assert torch.isfinite(out['cost']) and not torch.equal(before, tr.d_opt.theta)
+    s, px = tr.generate_samples(torch.zeros(10, 128), torch.arange(10, dtype=torch.int32))
+    assert s.shape == (10, 3072) and px.dtype == torch.int32 and px.min() >= 0 and px.max() <= 255
