@@ -6,6 +6,11 @@ Build with `python __graft_entry__.py` (or `make -C ctgan_amd/csrc`).
 """
 import ctypes
 import os
+
+# torch must be imported BEFORE the library is loaded: torch ships its own HIP runtime and places it
+# in the global symbol scope; loading ours first would bind the kernels to the system runtime and
+# leave the process with two HIP runtimes (streams / allocations of one are invalid in the other).
+import torch  # noqa: F401  (also the device-memory / stream provider of every wrapper)
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

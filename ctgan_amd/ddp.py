@@ -1,0 +1,79 @@
+"""Batch-sharded adversarial step: one process per GPU, gradients averaged over RCCL / xGMI.
+
+The reference has no collective (its "multi-GPU" is in-graph device placement of roles,
+TF/CT_gan_cifar_resnet.py:205-213); this is new design.  Every rank runs the
+full D/G step on its own batch of BATCH_SIZE reals; after each backward the flat gradient bucket of
+the network being updated (critic 1,055,115 floats = 4.2 MB, generator 1,218,307 = 4.9 MB) is
+summed with ONE all-reduce and the 1/world average is folded into the Adam kernel (`grad_scale`).
+The messages are latency-bound on xGMI (7 point-to-point links), hence one flat bucket per network
+instead of per-layer buckets.  The reference averages tower costs (`/ len(DEVICES)`, :295,328), so
+averaging is the faithful generalisation; generator BatchNorm statistics stay per rank, like the
+reference's per-tower statistics (no SyncBN).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatAllReduce:
+    """Sum a flat fp32 bucket across ranks, on a side stream when one is given.
+
+    With `side_stream`, the collective is enqueued on that stream after the producer's work
+    (event wait) and the caller's stream waits for its completion only at `wait()` - the Adam
+    kernel - so independent work (the next step's generator forward) can overlap it."""
+
+    def __init__(self, group=None, side_stream=None):
+        self.group = group
+        self.side = side_stream
+        self._pending = None
+
+    def __call__(self, flat):
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return
+        if self.side is None or not flat.is_cuda:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self._pending = done
+        self.wait()
+
+    def wait(self):
+        if self._pending is not None:
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
+
+
+def broadcast_params(flat_buffers, src=0, group=None):
+    """Make every rank start from rank `src`'s weights (the reference has a single copy)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for b in flat_buffers:
+            dist.broadcast(b, src=src, group=group)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -58,6 +58,17 @@ class FlatAdam:
         K.adam_advance(self.state, self.beta1, self.beta2)
         self.t += 1
 
+    def load_named_slots(self, m_by_name, v_by_name, t):
+        """Overwrite the Adam slots from per-parameter tensors (teacher-forced parity tests, resume)."""
+        off = 0
+        for name, n in zip(self.names, self.sizes):
+            self.m[off:off + n].copy_(m_by_name[name].reshape(-1).to(self.m.device, torch.float32))
+            self.v[off:off + n].copy_(v_by_name[name].reshape(-1).to(self.v.device, torch.float32))
+            off += n
+        self.t = int(t)
+        self.state[1] = self.beta1 ** (self.t + 1)
+        self.state[2] = self.beta2 ** (self.t + 1)
+
     def state_dict(self):
         return {'m': self.m.cpu().clone(), 'v': self.v.cpu().clone(), 'state': self.state.cpu().clone(), 't': self.t}
 
