@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py - img/s of the CT-WGAN adversarial iteration (N_CRITIC critic steps + 1 generator step)
+of CT_gan_cifar_resnet.py on MI355X, synthetic 32x32x3 data, fp32 (the reference's dtype).
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL).  A "step" here is one full
+iteration of the reference loop body (TF/CT_gan_cifar_resnet.py:393-404): 1 G step + 5 x (batch,
+D step) at BATCH_SIZE=64 per GPU = 320 real images per GPU.  Inputs are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line including
+  roofline     : the dominant kernel (by GPU time) of the iteration, its algorithmic FLOPs per
+                 launch / average launch duration, measured with HIP events on the launch stream
+                 in an instrumented eager iteration, against the fp32 MFMA peak (157.3 TFLOP/s)
+  cpu_baseline : the CPU oracle (PyTorch-CPU fp32 restatement of the reference graph AS WRITTEN;
+                 TF1 cannot be installed here) timed on the host cores - 1 D step + 1 G step,
+                 extrapolated to an iteration (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+ITER_GFLOP = 2990.5                   # algorithmic GFLOP per GPU per iteration
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ctgan_amd import ddp
+    rank, world, local = ddp.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.engine import GraphedTrainer
+
+    lib.delete_all_params()
+    lib.set_seed(0)
+    R.configure()                                      # full-width reference hyper-parameters
+    R.build_params(dev)
+    side = torch.cuda.Stream() if world > 1 else None
+    trainer = R.Trainer(seed=2024, rank=rank, world_size=world, allreduce=ddp.FlatAllReduce(side_stream=side))
+    ddp.broadcast_params([trainer.d_opt.theta, trainer.g_opt.theta])
+
+    B = R.cfg.BATCH_SIZE
+    nrng = np.random.default_rng(1234 + rank)          # 16 distinct synthetic batches, cycled
+    batches = [(torch.from_numpy(nrng.integers(0, 256, (B, 3072), dtype=np.int32)).to(dev),
+                torch.from_numpy(nrng.integers(0, 10, (B,), dtype=np.int32)).to(dev)) for _ in range(16)]
+    cursor = [0]
+
+    def next_batch():
+        cursor[0] = (cursor[0] + 1) % len(batches)
+        return batches[cursor[0]]
+
+    eng = GraphedTrainer(trainer, use_graphs=not args.no_graph)
+    if eng.graph_error and rank == 0:
+        print('hipGraph capture failed, running eager: ' + eng.graph_error, file=sys.stderr)
+
+    it = 1
+    for _ in range(args.warmup):
+        eng.train_iteration(it, next_batch); it += 1
+    ddp.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.train_iteration(it, next_batch); it += 1
+    torch.cuda.synchronize(); ddp.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    last_cost = float(out['cost'].item())
+    ms_per_step = 1e3 * dt / args.steps
+    imgs = R.cfg.N_CRITIC * B * world * args.steps
+    value = imgs / dt
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        roofline = measure_roofline(trainer, next_batch, K, torch)
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(lib, torch)
+
+    if rank == 0:
+        rec = {
+            'metric': 'img/s per (n_critic D + 1 G) step, CIFAR-10 ResNet',
+            'value': round(value, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'CT_gan_cifar_resnet.py ResNet G/D 32x32 CT-WGAN (GP+CT+ACGAN), batch 64/GPU, '
+                                   'N_CRITIC=5 + 1 G step (128 samples) per step', 'global_batch': B * world,
+                       'images_per_step': R.cfg.N_CRITIC * B * world, 'parallelism': 'dp%d' % world,
+                       'hipgraph': bool(eng.graphed), 'last_d_cost': last_cost},
+            'step_mfma_frac': round(ITER_GFLOP * 1e9 / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure_roofline(trainer, next_batch, K, torch):
+    """One instrumented EAGER iteration: every conv-family launch is bracketed by HIP events on its
+    launch stream.  The dominant kernel = the variant with the largest summed duration."""
+    import ctgan_amd.gan_cifar_resnet as R
+    trainer.train_iteration(1, next_batch)             # eager warm-up (lazy allocations)
+    torch.cuda.synchronize()
+    K.PROFILE = []
+    try:
+        trainer.train_iteration(1, next_batch)
+        torch.cuda.synchronize()
+        prof = K.PROFILE
+    finally:
+        K.PROFILE = None
+    agg = {}
+    for name, flops, e0, e1 in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
+    if not agg:
+        return None
+    total_t = sum(a[2] for a in agg.values())
+    total_f = sum(a[1] for a in agg.values())
+    name, (cnt, fl, tt) = max(agg.items(), key=lambda kv: kv[1][2])
+    achieved = fl / tt / 1e12
+    return {
+        'bound': 'mfma', 'kernel': name, 'launches': cnt,
+        'flops_per_launch': round(fl / cnt / 1e9, 3), 'avg_launch_us': round(tt / cnt * 1e6, 2),
+        'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+        'kernel_share_of_conv_time': round(tt / total_t, 3),
+        'all_conv_kernels': {'achieved': round(total_f / total_t / 1e12, 2),
+                             'frac': round(total_f / total_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                             'time_ms': round(total_t * 1e3, 3), 'launches': len(prof)},
+        'by_kernel': {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3)}
+                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
+    }
+
+
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes
+    expose 256 logical CPUs but grant a 16-CPU quota; 256 torch threads there run ~20x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(lib, torch):
+    """The oracle (reference graph as written, torch-CPU fp32, all host cores): 1 D step + 1 G step."""
+    from oracle import nets as onets, steps as osteps, tflib_ref as oref
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    reg = oref.Registry(dtype=torch.float32)
+    for n, p in lib._params.items():
+        t = p.detach().cpu().clone()
+        tr_ = n not in lib._non_trainable
+        reg[n] = t.requires_grad_(tr_)
+        if not tr_:
+            reg.non_trainable.add(n)
+    cfg = onets.ResnetCfg()
+    B = 64
+    g = torch.Generator().manual_seed(0)
+    real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+    labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+    optD = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+    optG = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Generator')], 0.0, 0.9)
+    rnd = osteps.make_rnd_resnet_d(B, 128, g, dtype=torch.float32)
+    rg = osteps.make_rnd_resnet_g(B, 128, g, dtype=torch.float32)
+    t0 = time.perf_counter()
+    osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd, iteration=1, B=B)
+    td = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    osteps.resnet_g_step(reg, cfg, optG, rg, iteration=1, B=B)
+    tg = time.perf_counter() - t0
+    t_iter = tg + 5 * td
+    return {'value': round(5 * B / t_iter, 3), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
+            'sample': '1 critic step (%.2f s) + 1 generator step (%.2f s) of the oracle at full width, B=64, '
+                      'torch-CPU fp32 with %d threads; iteration = G + 5*D = %.2f s (TF1 itself is not installable)'
+                      % (td, tg, cores, t_iter)}
+
+
+if __name__ == '__main__':
+    main()

@@ -45,17 +45,26 @@ __global__ __launch_bounds__(CB * RL) void bn_stats_partial_kernel(const float* 
     }
 }
 
-__global__ void bn_stats_final_kernel(const double* __restrict__ part, BnShape s, float eps, float* __restrict__ mean,
-                                      float* __restrict__ rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int FL = 16;      // partial-row lanes of the finalisation workgroups
+__global__ __launch_bounds__(CB * FL) void bn_stats_final_kernel(const double* __restrict__ part, BnShape s, float eps,
+                                                              float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[2][FL][CB];
+    const int cl = threadIdx.x % CB, fl = threadIdx.x / CB;
+    const int c = blockIdx.x * CB + cl;
     const int g = blockIdx.y;
-    if (c >= s.c) return;
     const int per = s.n / s.groups;
     double a = 0., b = 0.;
-    for (int i = g * per * s.hc; i < (g + 1) * per * s.hc; ++i) {
-        a += part[(long long)i * 2 * s.c + c];
-        b += part[(long long)i * 2 * s.c + s.c + c];
-    }
+    if (c < s.c)
+        for (int i = g * per * s.hc + fl; i < (g + 1) * per * s.hc; i += FL) {
+            a += part[(long long)i * 2 * s.c + c];
+            b += part[(long long)i * 2 * s.c + s.c + c];
+        }
+    red[0][fl][cl] = a; red[1][fl][cl] = b;
+    __syncthreads();
+    if (fl != 0 || c >= s.c) return;
+    a = 0.; b = 0.;
+#pragma unroll
+    for (int r = 0; r < FL; ++r) { a += red[0][r][cl]; b += red[1][r][cl]; }
     const double cnt = (double)per * s.hw;
     const double m = a / cnt;
     double var = b / cnt - m * m;
@@ -118,43 +127,55 @@ __global__ __launch_bounds__(CB * RL) void bn_bwd_partial_kernel(
     }
 }
 
-// one thread per channel: walks the samples in order (deterministic), fills the label bins of
-// gscale/goffset and the per-group sums s12[g][2][c] = { sum dxhat, sum dxhat*xhat } / count
-__global__ void bn_bwd_final_kernel(const double* __restrict__ part, const float* __restrict__ scale,
+// per-sample totals: tot[sample][2][c] = sum over the sample's chunks   (grid = (n, c/64))
+__global__ __launch_bounds__(CB * RL) void bn_bwd_sample_kernel(const double* __restrict__ part, BnShape s,
+                                                               double* __restrict__ tot) {
+    __shared__ double red[2][RL][CB];
+    const int cl = threadIdx.x % CB, rl = threadIdx.x / CB;
+    const int c = blockIdx.y * CB + cl, sample = blockIdx.x;
+    double a = 0., b = 0.;
+    if (c < s.c)
+        for (int k = rl; k < s.hc; k += RL) {
+            const long long i = (long long)(sample * s.hc + k) * 2 * s.c;
+            a += part[i + c]; b += part[i + s.c + c];
+        }
+    red[0][rl][cl] = a; red[1][rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < s.c) {
+#pragma unroll
+        for (int r = 1; r < RL; ++r) { a += red[0][r][cl]; b += red[1][r][cl]; }
+        tot[(long long)sample * 2 * s.c + c] = a;
+        tot[(long long)sample * 2 * s.c + s.c + c] = b;
+    }
+}
+
+// one thread per channel walks the samples in order (deterministic): fills the label bins of
+// gscale/goffset (each thread owns its column) and s12[g][2][c] = {sum dxhat, sum dxhat*xhat}/count
+__global__ void bn_bwd_final_kernel(const double* __restrict__ tot, const float* __restrict__ scale,
                                     const int32_t* __restrict__ labels, BnShape s, int n_labels,
-                                    float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ s12) {
+                                    float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ s12,
+                                    double* __restrict__ bins /*[n_labels][2][c]*/) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= s.c) return;
     const int per = s.n / s.groups;
-    for (int l = 0; l < n_labels; ++l) { gscale[l * s.c + c] = 0.f; goffset[l * s.c + c] = 0.f; }
-    // label bins in fp64 registers are not indexable without scratch; accumulate through a second
-    // pass per label instead (n_labels <= 10, n <= a few hundred: negligible work)
-    for (int l = 0; l < n_labels; ++l) {
-        double da = 0., db = 0.;
-        for (int sample = 0; sample < s.n; ++sample) {
-            const int lab = labels ? labels[sample] : 0;
-            if (lab != l) continue;
-            for (int k = 0; k < s.hc; ++k) {
-                const long long i = (long long)(sample * s.hc + k) * 2 * s.c;
-                da += part[i + c]; db += part[i + s.c + c];
-            }
-        }
-        goffset[l * s.c + c] = (float)da;
-        gscale[l * s.c + c] = (float)db;
-    }
+    for (int l = 0; l < n_labels; ++l) { bins[(long long)(l * 2) * s.c + c] = 0.; bins[(long long)(l * 2 + 1) * s.c + c] = 0.; }
     const double cnt = (double)per * s.hw;
     for (int g = 0; g < s.groups; ++g) {
         double s1 = 0., s2 = 0.;
         for (int sample = g * per; sample < (g + 1) * per; ++sample) {
             const int lab = labels ? labels[sample] : 0;
             const double ga = scale[lab * s.c + c];
-            for (int k = 0; k < s.hc; ++k) {
-                const long long i = (long long)(sample * s.hc + k) * 2 * s.c;
-                s1 += part[i + c] * ga; s2 += part[i + s.c + c] * ga;
-            }
+            const double a = tot[(long long)sample * 2 * s.c + c], b = tot[(long long)sample * 2 * s.c + s.c + c];
+            s1 += a * ga; s2 += b * ga;
+            bins[(long long)(lab * 2) * s.c + c] += a;
+            bins[(long long)(lab * 2 + 1) * s.c + c] += b;
         }
         s12[(g * 2 + 0) * s.c + c] = (float)(s1 / cnt);
         s12[(g * 2 + 1) * s.c + c] = (float)(s2 / cnt);
+    }
+    for (int l = 0; l < n_labels; ++l) {
+        goffset[l * s.c + c] = (float)bins[(long long)(l * 2) * s.c + c];
+        gscale[l * s.c + c] = (float)bins[(long long)(l * 2 + 1) * s.c + c];
     }
 }
 
@@ -187,16 +208,18 @@ int check_shape(int n, int hw, int c, int groups, const char* who) {
 }
 BnShape mk(int n, int hw, int c, int groups) { return BnShape{n, hw, c, groups, (hw + POS - 1) / POS}; }
 size_t part_bytes(const BnShape& s) { return (size_t)s.n * s.hc * 2 * s.c * sizeof(double); }
+size_t tot_bytes(const BnShape& s) { return (size_t)s.n * 2 * s.c * sizeof(double); }
+size_t bins_bytes(const BnShape& s, int n_labels) { return (size_t)n_labels * 2 * s.c * sizeof(double); }
 
 }  // namespace
 
 extern "C" {
 
 size_t ctgan_bn_workspace_bytes(int32_t n, int32_t hw, int32_t c, int32_t groups, int32_t n_labels) {
-    (void)n_labels;
     if (n <= 0 || hw <= 0 || c <= 0 || groups <= 0) return 0;
+    if (n_labels < 1) n_labels = 1;
     const BnShape s = mk(n, hw, c, groups);
-    return part_bytes(s) + (size_t)groups * 2 * c * sizeof(float);
+    return part_bytes(s) + tot_bytes(s) + bins_bytes(s, n_labels) + (size_t)groups * 2 * c * sizeof(float);
 }
 
 int ctgan_bn_stats(const float* x, int32_t n, int32_t hw, int32_t c, int32_t groups, float eps, float* mean, float* rstd,
@@ -211,7 +234,7 @@ int ctgan_bn_stats(const float* x, int32_t n, int32_t hw, int32_t c, int32_t gro
                        static_cast<double*>(ws));
     rc = ctgan_check_launch("bn_stats_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + 127) / 128, groups), dim3(128), 0, st,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + CB - 1) / CB, groups), dim3(CB * FL), 0, st,
                        static_cast<const double*>(ws), s, eps, mean, rstd);
     return ctgan_check_launch("bn_stats_final");
 }
@@ -237,17 +260,23 @@ int ctgan_bn_bwd(const float* gy, const float* x, const float* mean, const float
     if (!gy || !x || !mean || !rstd || !scale || !offset || !gx || !gscale || !goffset || !ws || n_labels <= 0)
         return ctgan_fail(CTGAN_E_BADARG, "bn_bwd: bad argument");
     const BnShape s = mk(n, hw, c, groups);
-    if (ws_bytes < part_bytes(s) + (size_t)groups * 2 * c * sizeof(float))
+    if (ws_bytes < ctgan_bn_workspace_bytes(n, hw, c, groups, n_labels))
         return ctgan_fail(CTGAN_E_BADARG, "bn_bwd: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    double* part = static_cast<double*>(ws);
-    float* s12 = reinterpret_cast<float*>(static_cast<char*>(ws) + part_bytes(s));
+    char* wsb = static_cast<char*>(ws);
+    double* part = reinterpret_cast<double*>(wsb);
+    double* tot = reinterpret_cast<double*>(wsb + part_bytes(s));
+    double* bins = reinterpret_cast<double*>(wsb + part_bytes(s) + tot_bytes(s));
+    float* s12 = reinterpret_cast<float*>(wsb + part_bytes(s) + tot_bytes(s) + bins_bytes(s, n_labels));
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(n * s.hc, (c + CB - 1) / CB), dim3(CB * RL), 0, st, gy, x, mean, rstd,
                        scale, offset, labels, s, relu, part);
     rc = ctgan_check_launch("bn_bwd_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 63) / 64), dim3(64), 0, st, part, scale, labels, s, n_labels, gscale,
-                       goffset, s12);
+    hipLaunchKernelGGL(bn_bwd_sample_kernel, dim3(n, (c + CB - 1) / CB), dim3(CB * RL), 0, st, part, s, tot);
+    rc = ctgan_check_launch("bn_bwd_sample");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 63) / 64), dim3(64), 0, st, tot, scale, labels, s, n_labels, gscale,
+                       goffset, s12, bins);
     rc = ctgan_check_launch("bn_bwd_final");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ctgan_blocks((long long)n * hw * c, 256)), dim3(256), 0, st, gy, x, mean,

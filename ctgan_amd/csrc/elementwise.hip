@@ -154,28 +154,29 @@ __global__ void interpolate_kernel(const float* __restrict__ real, const float* 
     }
 }
 
-// column sums: stage 1 - each block sums a row range for all columns; stage 2 - sum partials
-__global__ void colsum_partial_kernel(const float* __restrict__ x, long long rows, int cols, long long ld,
-                                      float* __restrict__ part, int rows_per_block) {
+// column sums, two fixed-order stages.  Stage 1: a workgroup = RLANES row lanes x 64 columns walks a
+// contiguous row chunk (each wave load = 256 contiguous bytes), lanes are combined through LDS.
+// Stage 2: the same shape over the partial rows.
+constexpr int CS_COLS = 64, CS_LANES = 4;
+__global__ __launch_bounds__(CS_COLS * CS_LANES) void colsum_stage_kernel(const float* __restrict__ x, long long rows, int cols,
+                                                                         long long ld, float* __restrict__ out,
+                                                                         int rows_per_block) {
+    __shared__ float red[CS_LANES][CS_COLS];
+    const int cl = threadIdx.x % CS_COLS, rl = threadIdx.x / CS_COLS;
+    const int j = blockIdx.y * CS_COLS + cl;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
-    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
-        float s = 0.f;
-        for (long long r = r0; r < r1; ++r) s += x[r * ld + j];
-        part[(long long)blockIdx.x * cols + j] = s;
-    }
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nblk, int cols, float* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(long long)b * cols + j];
-    out[j] = s;
+    if (j < cols)
+        for (long long r = r0 + rl; r < r1; r += CS_LANES) s += x[r * ld + j];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && j < cols) out[(long long)blockIdx.x * cols + j] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 int colsum_plan(long long rows, int* rows_per_block) {
-    int nblk = (int)((rows + 63) / 64);
-    if (nblk > 1024) nblk = 1024;
+    int nblk = (int)((rows + 255) / 256);
+    if (nblk > 256) nblk = 256;
     if (nblk < 1) nblk = 1;
     *rows_per_block = (int)((rows + nblk - 1) / nblk);
     return (int)((rows + *rows_per_block - 1) / *rows_per_block);
@@ -297,13 +298,14 @@ int ctgan_colsum(const float* x, int64_t rows, int32_t cols, int64_t ld, float* 
     const int nblk = colsum_plan(rows, &rpb);
     if (!ws || ws_bytes < (size_t)nblk * cols * sizeof(float)) return ctgan_fail(CTGAN_E_BADARG, "colsum: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(s);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(cols >= 256 ? 256 : (cols + 63) / 64 * 64), 0, st, x,
-                       (long long)rows, cols, (long long)ld, static_cast<float*>(ws), rpb);
-    int rc = ctgan_check_launch("colsum_partial");
-    if (rc) return rc;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, static_cast<const float*>(ws),
-                       nblk, cols, out);
-    return ctgan_check_launch("colsum_final");
+    const int cblk = (cols + CS_COLS - 1) / CS_COLS;
+    hipLaunchKernelGGL(colsum_stage_kernel, dim3(nblk, cblk), dim3(CS_COLS * CS_LANES), 0, st, x, (long long)rows, cols,
+                       (long long)ld, nblk > 1 ? static_cast<float*>(ws) : out, rpb);
+    int rc = ctgan_check_launch("colsum_stage1");
+    if (rc || nblk == 1) return rc;
+    hipLaunchKernelGGL(colsum_stage_kernel, dim3(1, cblk), dim3(CS_COLS * CS_LANES), 0, st, static_cast<const float*>(ws),
+                       (long long)nblk, cols, (long long)cols, out, nblk);
+    return ctgan_check_launch("colsum_stage2");
 }
 
 }  // extern "C"

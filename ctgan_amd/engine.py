@@ -1,0 +1,121 @@
+"""hipGraph-captured D/G steps.
+
+A critic step is ~700 kernel launches issued from Python autograd; at MI355X speeds the host cannot
+keep up (launch-bound), so the whole (loss graph + backward + gradient packing [+ Adam]) of each step
+is captured once into a hipGraph and replayed.  Replay-safety: every random draw reads its Philox
+step counter from device memory, Adam reads lr / beta powers from device memory, inputs live in
+static buffers.  With world_size > 1 the all-reduce and the Adam kernels stay outside the graph.
+"""
+import torch
+
+from . import gan_cifar_resnet as R
+
+
+class GraphedTrainer:
+    def __init__(self, trainer, use_graphs=True, warmup=2):
+        self.t = trainer
+        B = R.cfg.BATCH_SIZE
+        dev = trainer.dev
+        self.real = torch.zeros(B, R.cfg.OUTPUT_DIM, dtype=torch.int32, device=dev)
+        self.labels = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.adam_in_graph = trainer.world == 1
+        self.d_graph = self.g_graph = None
+        self.d_out = self.g_out = None
+        self.graph_error = None
+        if use_graphs:
+            try:
+                self._capture(warmup)
+            except Exception as e:      # fall back to eager launches; bench.py reports it
+                self.graph_error = '%s: %s' % (type(e).__name__, e)
+                self.d_graph = self.g_graph = None
+                torch.cuda.synchronize()
+
+    # -- the region that is captured (everything between input copy and all-reduce / Adam)
+    def _d_body(self):
+        t = self.t
+        t.rng.begin_step()
+        out = t.d_losses(self.real, self.labels)
+        grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
+        t.d_opt.gather_grads(grads)
+        if self.adam_in_graph:
+            t.d_opt.step(1.0)
+        t.rng.end_step()
+        return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
+
+    def _g_body(self):
+        t = self.t
+        t.rng.begin_step()
+        out = t.g_losses()
+        grads = torch.autograd.grad(out['cost'], t.g_params, allow_unused=True)
+        t.g_opt.gather_grads(grads)
+        if self.adam_in_graph:
+            t.g_opt.step(1.0)
+        t.rng.end_step()
+        return {'cost': out['cost'].detach()}
+
+    def _capture(self, warmup):
+        t = self.t
+        t.d_opt.set_lr(0.0)       # warm-up / capture passes must not move the weights
+        t.g_opt.set_lr(0.0)
+        snap = [b.clone() for b in (t.d_opt.m, t.d_opt.v, t.d_opt.state, t.g_opt.m, t.g_opt.v, t.g_opt.state)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._d_body()
+                self._g_body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.d_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.d_graph):
+            self.d_out = self._d_body()
+        self.g_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_graph, pool=self.d_graph.pool()):
+            self.g_out = self._g_body()
+        torch.cuda.synchronize()
+        # undo the side effects of the warm-up passes on the optimizer slots
+        for b, sn in zip((t.d_opt.m, t.d_opt.v, t.d_opt.state, t.g_opt.m, t.g_opt.v, t.g_opt.state), snap):
+            b.copy_(sn)
+        t.d_opt.t = t.g_opt.t = 0
+
+    @property
+    def graphed(self):
+        return self.d_graph is not None
+
+    def d_step(self, real_int, labels, iteration=0):
+        t = self.t
+        if not self.graphed:
+            return t.d_step(real_int, labels, iteration=iteration)
+        self.real.copy_(real_int, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        t.d_opt.set_lr(t.lr(iteration))
+        self.d_graph.replay()
+        if not self.adam_in_graph:
+            t.allreduce(t.d_opt.grad)
+            t.d_opt.step(1.0 / t.world)
+        else:
+            t.d_opt.t += 1
+        return self.d_out
+
+    def g_step(self, iteration=0):
+        t = self.t
+        if not self.graphed:
+            return t.g_step(iteration=iteration)
+        t.g_opt.set_lr(t.lr(iteration))
+        self.g_graph.replay()
+        if not self.adam_in_graph:
+            t.allreduce(t.g_opt.grad)
+            t.g_opt.step(1.0 / t.world)
+        else:
+            t.g_opt.t += 1
+        return self.g_out
+
+    def train_iteration(self, iteration, next_batch):
+        """[G step if it>0] + N_CRITIC x (next batch, D step)   (TF/CT_gan_cifar_resnet.py:393-404)"""
+        if iteration > 0:
+            self.g_step(iteration)
+        out = None
+        for _ in range(R.cfg.N_CRITIC):
+            data, labels = next_batch()
+            out = self.d_step(data, labels, iteration)
+        return out

@@ -17,6 +17,35 @@ from ._lib import ConvDesc, I32x4, I64x4, check, lib
 
 _ws_cache = {}
 
+# Optional per-launch timing of the conv family (bench.py's roofline leg): when a list is
+# installed here every conv launch is bracketed by HIP events on the launch stream and
+# (kernel variant, algorithmic flops, start event, end event) is appended.
+PROFILE = None
+
+
+def _conv_flops(g, N):
+    return 2.0 * N * g.P * g.Q * g.K * g.R * g.S * g.C
+
+
+class _Timed:
+    def __init__(self, g, N):
+        self.on = PROFILE is not None
+        if self.on:
+            self.flops = _conv_flops(g, N)
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record(torch.cuda.current_stream())
+            PROFILE.append((last_kernel(), self.flops, self.e0, self.e1))
+        return False
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -126,8 +155,9 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None):
     if resid is not None:
         assert is_dense_like(resid, y)
     d = g.desc(N, x.stride(), y.stride())
-    check(lib.ctgan_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y),
-                               1 if relu else 0, _stream()), 'conv2d_fwd')
+    with _Timed(g, N):
+        check(lib.ctgan_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y),
+                                   1 if relu else 0, _stream()), 'conv2d_fwd')
     return y
 
 
@@ -144,8 +174,9 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None):
     d = g.desc(N, dx.stride(), gy.stride())
     nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, gy.device)
-    check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
-          'conv2d_dgrad')
+    with _Timed(g, N):
+        check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(dx), _ptr(ws), ws.numel(),
+                                     _stream()), 'conv2d_dgrad')
     return dx
 
 
@@ -159,8 +190,9 @@ def conv_wgrad(x, gy, g):
     d = g.desc(N, x.stride(), gy.stride())
     nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 2)
     ws = workspace(nb, x.device)
-    check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(ws), ws.numel(), _stream()),
-          'conv2d_wgrad')
+    with _Timed(g, N):
+        check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(ws), ws.numel(), _stream()),
+              'conv2d_wgrad')
     return dw
 
 

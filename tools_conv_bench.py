@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the conv kernel family on the shapes of the ResNet CT-WGAN step.
+usage: python tools_conv_bench.py [reps]   (GPU box)"""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+import ctgan_amd.kernels as K
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+SHAPES = [  # (label, N, C, H, K, k, up)
+    ('trunk 32x32 n=128', 128, 128, 32, 128, 3, False),
+    ('trunk 32x32 n=64 ', 64, 128, 32, 128, 3, False),
+    ('16x16 n=128      ', 128, 128, 16, 128, 3, False),
+    ('16x16 n=64       ', 64, 128, 16, 128, 3, False),
+    ('8x8 n=192        ', 192, 128, 8, 128, 3, False),
+    ('8x8 n=128        ', 128, 128, 8, 128, 3, False),
+    ('8x8 n=64         ', 64, 128, 8, 128, 3, False),
+    ('G up 16->32 n=128', 128, 128, 32, 128, 3, True),
+    ('G up 4->8 n=128  ', 128, 128, 8, 128, 3, True),
+    ('1x1 16x16 n=128  ', 128, 128, 16, 128, 1, False),
+    ('G.Output n=128   ', 128, 128, 32, 3, 3, False),
+    ('D.1.Conv1 n=128  ', 128, 3, 32, 128, 3, False),
+]
+
+
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+print('%-20s %28s %28s %28s' % ('shape', 'fwd', 'dgrad', 'wgrad'))
+for label, N, C, H, Ko, k, up in SHAPES:
+    g = K.ConvGeom(C, H, H, Ko, k, k, 1, up)
+    Hp = H // 2 if up else H
+    x = K.empty_cl(N, C, Hp, Hp, 'cuda').normal_()
+    w = torch.randn(k, k, C, Ko, device='cuda') * 0.05
+    gy = K.empty_cl(N, Ko, g.P, g.Q, 'cuda').normal_()
+    fl = 2.0 * N * g.P * g.Q * Ko * k * k * C
+    cols = []
+    t = timeit(lambda: K.conv_fwd(x, w, None, g)); cols.append('%7.1fus %6.1fTF %s' % (t * 1e6, fl / t / 1e12, K.last_kernel().split('<')[1][:14]))
+    if not up:
+        t = timeit(lambda: K.conv_dgrad(gy, w, g, N)); cols.append('%7.1fus %6.1fTF %s' % (t * 1e6, fl / t / 1e12, K.last_kernel().split('<')[1][:14]))
+    else:
+        cols.append('-')
+    t = timeit(lambda: K.conv_wgrad(x, gy, g)); cols.append('%7.1fus %6.1fTF %s' % (t * 1e6, fl / t / 1e12, K.last_kernel().split('<')[1][:20]))
+    print('%-20s %28s %28s %28s' % (label, *cols))
