@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -52,6 +53,9 @@ struct FwdParams {
     long long b_off, bs_r, bs_s, bs_c, bs_k;   // Wt(r,s,c,k) = B[b_off + r*bs_r + s*bs_s + c*bs_c + k*bs_k]
     long long ds_n, ds_p, ds_q, ds_k;          // D strides over (n,p,q,k)
     int relu;
+    int d_lin;                                 // D offset = m*ds_q + col*ds_k (pixel-linear output)
+    unsigned a_bytes, b_bytes;                 // byte extents of A and B (buffer-descriptor range checks)
+    int dbg;                                   // perf-diagnosis bits (env CTGAN_DBG): 1 no LDS store, 2 no global load, 4 no barrier
 };
 
 struct WgradParams {
@@ -314,6 +318,223 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------
+// Pipelined FWD / DGRAD kernel for the fully vectorisable case (C % (32*WAVES_K) == 0, unit channel
+// stride, 16-B aligned rows; filter rows contiguous in k).  Differences from the generic kernel:
+//   * two LDS stages, ONE barrier per K slice: while the MFMAs of slice t run, the registers
+//     holding slice t+1 are written to the other stage and the global loads of slice t+2 are issued;
+//   * B fragments are read PD steps ahead of the MFMA that consumes them (register ring), so a
+//     single wave per SIMD keeps the matrix pipe busy;
+//   * no LDS lookup tables or exec-masked loads in the loop: padding taps read a clamped address
+//     and are zeroed by a select when staged;
+//   * WAVES_K > 1 splits each slice between wave groups (for small M: more waves than output
+//     tiles), partial accumulators are combined through LDS at the end;
+//   * XCD-aware tile order: consecutive M tiles (which share halo rows) land on the same XCD / L2.
+template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pipe_kernel(const FwdParams p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, BKE = 32 * WAVES_K, LDAE = BKE + 4;
+    constexpr int STAGE = BM * LDAE + BKE * BN;
+    constexpr int AC = BKE / 4, BC = BN / 4;
+    constexpr int A_PER = (BM * AC) / NT, B_PER = (BKE * BC) / NT;
+    constexpr int PD = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);      // B prefetch distance (MFMA steps)
+    static_assert((BM * AC) % NT == 0 && (BKE * BC) % NT == 0 && A_PER >= 1 && B_PER >= 1, "tile/threads mismatch");
+    static_assert(NT % AC == 0 && NT % BC == 0, "loader mapping");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave % WAVES_K, wmn = wave / WAVES_K;
+    const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);         // block b runs on XCD b%8 (observed)
+    const int tiles_n = (p.Ng + BN - 1) / BN;
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.Kg / BKE;
+    const int cpt = g.C / BKE;
+    const int PQ = g.P * g.Q;
+
+    // Loader: buffer loads through wave-uniform resource descriptors.  The per-lane byte offset
+    // (voffset) of a pixel row is fixed for the whole kernel when the gather is an affine map
+    // (no upsample / dilation); the tap and channel-chunk displacement of a K slice is wave-uniform
+    // and rides in the scalar offset.  Padding taps use voffset = ~0u: the hardware range check
+    // (offset >= num_records) returns zeros, so no select and no branch is needed.
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+    const bool affine = (g.shift | g.mask) == 0;
+    const int a_chunk = tid % AC, a_row0 = tid / AC;
+    unsigned a_voff[A_PER];          // affine: full byte offset of (row, tap 0, chunk); else byte offset of (n, chunk)
+    int a_ih0[A_PER], a_iw0[A_PER];
+    bool a_valid[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int m = m0 + a_row0 + i * (NT / AC);
+        a_valid[i] = m < p.M;
+        const int mm = a_valid[i] ? m : 0;
+        const int n = mm / PQ, rem = mm - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+        a_ih0[i] = pp * g.stride - g.pad_t;
+        a_iw0[i] = qq * g.stride - g.pad_l;
+        long long o = (long long)n * g.s_n + a_chunk * 4;
+        if (affine) o += (long long)a_ih0[i] * g.s_h + (long long)a_iw0[i] * g.s_w;   // may be "negative": wraps consistently mod 2^32
+        a_voff[i] = (unsigned)(o * 4);
+    }
+    const int b_j4 = tid % BC, b_k0 = tid / BC;
+    const bool b_ok = (n0 + b_j4 * 4) < p.Ng;
+    unsigned b_voff[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+        b_voff[i] = b_ok ? (unsigned)(((long long)(b_k0 + i * (NT / BC)) * p.bs_c + b_j4 * 4) * 4) : 0xFFFFFFFFu;
+
+    float4 ra[A_PER], rb[B_PER];
+    int ld_r = 0, ld_s = 0, ld_c = 0;                                   // tap / channel-chunk of the NEXT slice to load
+
+    auto load_tile = [&]() {
+        const int c0 = ld_c * BKE;
+        if (affine) {
+            const unsigned soff = (unsigned)(((long long)ld_r * g.s_h + (long long)ld_s * g.s_w + c0) * 4);
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const bool ok = a_valid[i] & ((unsigned)(a_ih0[i] + ld_r) < (unsigned)g.H) & ((unsigned)(a_iw0[i] + ld_s) < (unsigned)g.W);
+                const unsigned vo = ok ? a_voff[i] + soff : 0xFFFFFFFFu;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, vo, 0, 0);
+                ra[i] = __builtin_bit_cast(float4, v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                int ih, iw;
+                const bool ok = a_valid[i] & src_index(a_ih0[i] + ld_r, g.shift, g.mask, g.H, ih) &
+                                src_index(a_iw0[i] + ld_s, g.shift, g.mask, g.W, iw);
+                const unsigned vo = ok ? a_voff[i] + (unsigned)(((long long)ih * g.s_h + (long long)iw * g.s_w + c0) * 4) : 0xFFFFFFFFu;
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, vo, 0, 0);
+                ra[i] = __builtin_bit_cast(float4, v);
+            }
+        }
+        const unsigned bsoff = (unsigned)((p.b_off + n0 + ld_r * p.bs_r + ld_s * p.bs_s + (long long)c0 * p.bs_c) * 4);
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_voff[i], bsoff, 0);
+            rb[i] = __builtin_bit_cast(float4, v);
+        }
+        if (++ld_c == cpt) { ld_c = 0; if (++ld_s == g.S) { ld_s = 0; ++ld_r; } }
+    };
+    auto store_tile = [&](float* As, float* Bs) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+            *reinterpret_cast<float4*>(&As[(a_row0 + i * (NT / AC)) * LDAE + a_chunk * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
+            *reinterpret_cast<float4*>(&Bs[(b_k0 + i * (NT / BC)) * BN + b_j4 * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tile();
+    store_tile(smem, smem + BM * LDAE);
+    if (nk > 1) load_tile();
+    __syncthreads();
+
+    const int h = lane >> 5, l31 = lane & 31;
+    const int a_rd = (wm * TM * 32 + l31) * LDAE + wk * 32 + h * 16;     // + i*32*LDAE + v*4
+    const int b_rd = (wk * 32 + h * 16) * BN + wn * TN * 32 + l31;        // + s*BN + j*32
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* As = smem + (kt & 1) * STAGE;
+        const float* Bs = As + BM * LDAE;
+        float* Asn = smem + ((kt + 1) & 1) * STAGE;
+        float* Bsn = Asn + BM * LDAE;
+        float4 a[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a[i][v] = *reinterpret_cast<const float4*>(&As[a_rd + i * 32 * LDAE + v * 4]);
+        float b[PD + 1][TN];
+#pragma unroll
+        for (int s0 = 0; s0 < PD; ++s0)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[s0][j] = Bs[b_rd + s0 * BN + j * 32];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s + PD < 16) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(s + PD) % (PD + 1)][j] = Bs[b_rd + (s + PD) * BN + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float4 av = a[i][s >> 2];
+                const float ae = (s & 3) == 0 ? av.x : (s & 3) == 1 ? av.y : (s & 3) == 2 ? av.z : av.w;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
+            }
+            if (s == 3 && kt + 1 < nk && !(p.dbg & 1)) store_tile(Asn, Bsn);             // registers hold slice kt+1
+            if (s == 7 && kt + 2 < nk && !(p.dbg & 2)) load_tile();                      // refill them with slice kt+2
+        }
+        if (!(p.dbg & 4)) __syncthreads();
+    }
+
+    if constexpr (WAVES_K > 1) {                                          // combine the K groups through LDS
+        float* red = smem;
+        constexpr int PER_WAVE = TM * TN * 16 * 64;
+#pragma unroll
+        for (int r = 1; r < WAVES_K; ++r) {
+            if (wk == r) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) red[wmn * PER_WAVE + ((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[i][j][e] += red[wmn * PER_WAVE + ((i * TN + j) * 16 + e) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wk != 0) return;
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        if (col >= p.Ng) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                long long off;
+                if (p.d_lin) {
+                    off = (long long)m * p.ds_q + col * p.ds_k;
+                } else {
+                    const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+                    off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
+                }
+                float v = acc[i][j][e] + bv;
+                if (p.resid) v += p.resid[off];
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.D[off] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // WGRAD kernel: grid = (tiles_m * tiles_n, splits)
 template <bool AVEC, bool BVEC, int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_kernel(const WgradParams p) {
@@ -508,6 +729,7 @@ __global__ void repack_dgrad_filter_kernel(const float* __restrict__ w, float* _
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 thread_local char g_last_kernel[128] = "";
+bool g_force_generic = false;   // tests: route vectorisable shapes through the table-driven kernel too
 
 template <bool AVEC, bool BVEC, int WM, int WN, int TM, int TN>
 int launch_fwd(const FwdParams& p, hipStream_t st) {
@@ -532,12 +754,54 @@ int dispatch_fwd_tile(const FwdParams& p, hipStream_t st) {
     return launch_fwd<AVEC, BVEC, 4, 1, 1, 1>(p, st);                             // 128x32
 }
 
-int run_fwd(const FwdParams& p, hipStream_t st) {
+template <int WM, int WN, int WK, int TM, int TN>
+int launch_fwd_pipe(const FwdParams& p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BKE = 32 * WK;
+    constexpr size_t smem_bytes = 2 * (size_t)(BM * (BKE + 4) + BKE * BN) * sizeof(float);
+    static bool attr_set = false;     // one-time opt-in to > 64 KB of dynamic LDS (idempotent; benign race)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d>", BM, BN, WK);
+    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
+    return ctgan_check_launch("igemm_fwd_pipe");
+}
+
+int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
+    // Work per launch in units of 32x32 output tiles; 1024 SIMDs want >= 1024 waves of work.
+    const long long M = p.M;
+    const long long t128 = ((M + 127) / 128) * ((p.Ng + 127) / 128);
+    if (t128 >= 512) return launch_fwd_pipe<2, 2, 1, 2, 2>(p, st);                     // 128x128, 2 blocks/CU
+    const long long t64 = ((M + 63) / 64) * ((p.Ng + 127) / 128);
+    if (t64 >= 384) return launch_fwd_pipe<1, 4, 1, 2, 1>(p, st);                      // 64x128
+    const long long t32 = ((M + 31) / 32) * ((p.Ng + 127) / 128);
+    if (t32 >= 256 || p.g.C % 64 != 0) return launch_fwd_pipe<1, 4, 1, 1, 1>(p, st);   // 32x128
+    return launch_fwd_pipe<1, 2, 2, 1, 1>(p, st);                                      // 32x64, K split over 2 wave groups
+}
+
+int run_fwd(const FwdParams& p0, hipStream_t st) {
+    FwdParams p = p0;
     const Geom& g = p.g;
+    p.d_lin = (p.ds_p == (long long)g.Q * p.ds_q) && (p.ds_n == (long long)g.P * g.Q * p.ds_q);
+    { const char* e = getenv("CTGAN_DBG"); p.dbg = e ? atoi(e) : 0; }
     const bool avec = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
     const bool bvec = p.bs_k == 1 && (p.Ng % 4 == 0) && (p.b_off % 4 == 0) && (p.bs_r % 4 == 0) && (p.bs_s % 4 == 0) &&
                       (p.bs_c % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
+    // byte extents for the buffer descriptors of the pipelined kernel (32-bit range => < 4 GiB)
+    const long long nimg = g.P > 0 ? (p.M + (long long)g.P * g.Q - 1) / ((long long)g.P * g.Q) : 0;
+    const long long a_elems = (nimg - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
+    const long long b_elems = (long long)g.R * g.S * g.C * p.Ng;
+    const bool small = a_elems > 0 && a_elems * 4 < (1LL << 32) && b_elems * 4 < (1LL << 32) && p.b_off >= 0 && p.bs_r >= 0 && p.bs_s >= 0;
+    if (avec && bvec && small && p.Ng > 64 && !g_force_generic) {
+        p.a_bytes = (unsigned)(a_elems * 4);
+        p.b_bytes = (unsigned)(b_elems * 4);
+        return dispatch_fwd_pipe(p, st);
+    }
     if (avec && bvec) return dispatch_fwd_tile<true, true>(p, st);
     if (avec) return dispatch_fwd_tile<true, false>(p, st);
     if (bvec) return dispatch_fwd_tile<false, true>(p, st);
@@ -653,6 +917,7 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
 extern "C" {
 
 const char* ctgan_last_kernel(void) { return g_last_kernel; }
+void ctgan_debug_force_generic(int on) { g_force_generic = on != 0; }
 
 size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
     if (!d) return 0;

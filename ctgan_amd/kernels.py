@@ -200,6 +200,11 @@ def last_kernel():
     return lib.ctgan_last_kernel().decode()
 
 
+def debug_force_generic(on):
+    """Tests only: route every conv through the table-driven generic kernels."""
+    lib.ctgan_debug_force_generic(1 if on else 0)
+
+
 def colsum_channels(gy):
     """sum over (n,h,w) of a channels-last [N,K,P,Q] tensor -> [K] (bias gradient)."""
     _need_dev(gy)

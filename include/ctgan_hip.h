@@ -62,6 +62,8 @@ int ctgan_version(void);
 const char* ctgan_last_error(void);
 /* which kernel variant the last conv call on this thread dispatched to (for tests/profiles)   */
 const char* ctgan_last_kernel(void);
+/* tests only: 1 = route every conv through the table-driven generic kernels                   */
+void ctgan_debug_force_generic(int on);
 
 /* ---- convolution family  (replaces tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112,
  *      tf.nn.conv2d_transpose TF/tflib/ops/deconv2d.py:97-103, tf.matmul

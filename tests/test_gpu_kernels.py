@@ -94,14 +94,18 @@ def test_conv_fwd_dgrad_wgrad(K, case):
 
 def test_conv_vector_and_generic_paths_agree_bitwise(K):
     """The vector loaders only change how tiles reach LDS: same MFMA order => identical bits.
-    A misaligned (offset-by-one-element) view forces the generic path on the same values."""
+    A misaligned (offset-by-one-element) view forces the scalar-gather path on the same values."""
     g = torch.Generator().manual_seed(7)
     x = torch.randn(4, 128, 8, 8, generator=g)
     w = torch.randn(3, 3, 128, 128, generator=g) * 0.03
     geom = K.ConvGeom(128, 8, 8, 128, 3, 3, 1, False)
     xa = cl(x)
-    y_vec = K.conv_fwd(xa, dev(w), None, geom)
-    k_vec = K.last_kernel()
+    K.debug_force_generic(True)
+    try:
+        y_vec = K.conv_fwd(xa, dev(w), None, geom)
+        k_vec = K.last_kernel()
+    finally:
+        K.debug_force_generic(False)
     buf = torch.empty(xa.numel() + 1, device='cuda')
     xb = buf[1:].view(4, 8, 8, 128).permute(0, 3, 1, 2)
     xb.copy_(xa)
@@ -112,6 +116,40 @@ def test_conv_vector_and_generic_paths_agree_bitwise(K):
     k_gen = K.last_kernel()
     assert 'avec,bvec' in k_vec and 'agen,bgen' in k_gen, (k_vec, k_gen)
     assert torch.equal(y_vec, y_gen)
+
+
+# (N, H, up, stride-2 dgrad?) -> every pipelined tile configuration, incl. the K-split one
+@pytest.mark.parametrize('N,H,up', [(128, 32, False), (64, 16, False), (24, 16, False), (64, 8, False), (7, 8, False),
+                                     (128, 8, True), (3, 4, False)])
+def test_pipelined_conv_matches_table_driven_kernel(K, N, H, up):
+    """igemm_fwd_pipe (double-buffered LDS, B prefetch ring, clamped-address padding, XCD tile order,
+    optional in-block K split) against the simple table-driven kernel on the same inputs."""
+    g = torch.Generator().manual_seed(N * 100 + H)
+    Hp = H // 2 if up else H
+    x = cl(torch.randn(N, 128, Hp, Hp, generator=g))
+    w = dev(torch.randn(3, 3, 128, 128, generator=g) * 0.03)
+    b = dev(torch.randn(128, generator=g))
+    geom = K.ConvGeom(128, H, H, 128, 3, 3, 1, up)
+    r = cl(torch.randn(N, 128, H, H, generator=g))
+    y = K.conv_fwd(x, w, b, geom, resid=r, relu=True)
+    name = K.last_kernel()
+    assert 'igemm_fwd_pipe' in name
+    K.debug_force_generic(True)
+    try:
+        y_ref = K.conv_fwd(x, w, b, geom, resid=r, relu=True)
+        assert 'igemm_fwd<' in K.last_kernel()
+        gy = cl(torch.randn(N, 128, H, H, generator=g))
+        dx_ref = None if up else K.conv_dgrad(gy, w, geom, N)
+    finally:
+        K.debug_force_generic(False)
+    if ',k1>' in name:
+        assert torch.equal(y, y_ref), name              # same summation order => same bits
+    else:
+        assert relerr(y, y_ref) < 1e-5, name             # K halves summed separately
+    if not up:
+        dx = K.conv_dgrad(gy, w, geom, N)
+        assert 'igemm_fwd_pipe' in K.last_kernel()
+        assert relerr(dx, dx_ref) < 1e-5
 
 
 def test_conv_is_deterministic(K):
