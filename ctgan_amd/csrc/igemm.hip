@@ -66,6 +66,8 @@ struct WgradParams {
     int Mtot, Ng, Kg;        // R*S*C, K, N*P*Q
     long long dy_n, dy_p, dy_q, dy_k;
     int chunk;               // pixels per split (multiple of BK)
+    int with_bias;           // 1: slab row Mtot receives the column sums of dy (bias gradient)
+    unsigned x_bytes, dy_bytes;
 };
 
 __device__ __forceinline__ bool src_index(int i, int shift, int mask, int lim, int& o) {
@@ -706,13 +708,173 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_kernel(con
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Pipelined WGRAD kernel (vector case: the M tile lies inside one filter tap, unit channel strides).
+// Same structure as igemm_fwd_pipe_kernel: two LDS stages / one barrier per 32-pixel slice, buffer
+// loads with hardware zero fill, operand prefetch ring.  Per-pixel gather offsets for slice t+3 are
+// produced by 32 lanes while slice t is multiplied (4-deep table ring).  Workgroups of the first
+// M tile also accumulate the column sums of the dy tiles they stage: the bias gradient rides along
+// as slab row Mtot at no extra HBM traffic.
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kernel(const WgradParams p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int STAGE = BK * BM + BK * BN;
+    constexpr int M4 = BM / 4, J4 = BN / 4;
+    constexpr int A_PER = (BK * M4) / NT, B_PER = (BK * J4) / NT;
+    constexpr int PD = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);
+    static_assert((BK * M4) % NT == 0 && (BK * J4) % NT == 0 && A_PER >= 1 && B_PER >= 1, "tile/threads mismatch");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ unsigned px_x[4][BK], px_y[4][BK];
+
+    const Geom& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.Ng + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int k_begin = blockIdx.y * p.chunk;
+    const int k_end = min(p.Kg, k_begin + p.chunk);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+    const int PQ = g.P * g.Q;
+    const int tap = m0 / g.C, c0 = m0 - tap * g.C;              // C % BM == 0
+    const int ar = tap / g.S, as_ = tap - ar * g.S;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.dy_bytes, 0x00020000);
+
+    auto fill_ptab = [&](int kt) {
+        if (tid < BK) {
+            const int px = k_begin + kt * BK + tid;
+            unsigned xo = 0xFFFFFFFFu, yo = 0xFFFFFFFFu;
+            if (px < k_end) {
+                const int n = px / PQ, rem = px - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+                int ih, iw;
+                const bool ok = src_index(pp * g.stride - g.pad_t + ar, g.shift, g.mask, g.H, ih) &
+                                src_index(qq * g.stride - g.pad_l + as_, g.shift, g.mask, g.W, iw);
+                if (ok) xo = (unsigned)(((long long)n * g.s_n + (long long)ih * g.s_h + (long long)iw * g.s_w) * 4);
+                yo = (unsigned)((n * p.dy_n + pp * p.dy_p + qq * p.dy_q) * 4);
+            }
+            px_x[kt & 3][tid] = xo; px_y[kt & 3][tid] = yo;
+        }
+    };
+
+    const int a_m4 = tid % M4, a_k0 = tid / M4;
+    const int b_j4 = tid % J4, b_k0 = tid / J4;
+    const unsigned a_const = (unsigned)((c0 + a_m4 * 4) * 4);
+    const bool b_ok = (n0 + b_j4 * 4) < p.Ng;
+    const unsigned b_const = (unsigned)((n0 + b_j4 * 4) * 4);
+    float4 ra[A_PER], rb[B_PER];
+
+    auto load_tile = [&](int kt) {
+        const int ring = kt & 3;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const unsigned xo = px_x[ring][a_k0 + i * (NT / M4)];
+            const unsigned vo = xo == 0xFFFFFFFFu ? xo : xo + a_const;
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, vo, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const unsigned yo = px_y[ring][b_k0 + i * (NT / J4)];
+            const unsigned vo = (yo == 0xFFFFFFFFu || !b_ok) ? 0xFFFFFFFFu : yo + b_const;
+            rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, vo, 0, 0));
+        }
+    };
+    auto store_tile = [&](float* As, float* Bs) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) *reinterpret_cast<float4*>(&As[(a_k0 + i * (NT / M4)) * BM + a_m4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) *reinterpret_cast<float4*>(&Bs[(b_k0 + i * (NT / J4)) * BN + b_j4 * 4]) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = p.with_bias && tile_m == 0 && tid < BN;
+
+    if (nk > 0) {
+        fill_ptab(0);
+        if (nk > 1) fill_ptab(1);
+        if (nk > 2) fill_ptab(2);
+        __syncthreads();
+        load_tile(0);
+        store_tile(smem, smem + BK * BM);
+        if (nk > 1) load_tile(1);
+        __syncthreads();
+    }
+    const int h = lane >> 5, l31 = lane & 31;
+    const int a_rd = h * 16 * BM + wm * TM * 32 + l31;
+    const int b_rd = h * 16 * BN + wn * TN * 32 + l31;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* As = smem + (kt & 1) * STAGE;
+        const float* Bs = As + BK * BM;
+        float* Asn = smem + ((kt + 1) & 1) * STAGE;
+        float* Bsn = Asn + BK * BM;
+        float a[PD + 1][TM], b[PD + 1][TN];
+#pragma unroll
+        for (int s0 = 0; s0 < PD; ++s0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[s0][i] = As[a_rd + s0 * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[s0][j] = Bs[b_rd + s0 * BN + j * 32];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s + PD < 16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(s + PD) % (PD + 1)][i] = As[a_rd + (s + PD) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(s + PD) % (PD + 1)][j] = Bs[b_rd + (s + PD) * BN + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % (PD + 1)][i], b[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
+            if (s == 3 && kt + 1 < nk) store_tile(Asn, Bsn);
+            if (s == 7 && kt + 2 < nk) load_tile(kt + 2);
+            if (s == 9 && kt + 3 < nk) fill_ptab(kt + 3);
+            if (s == 11 && do_bias) {
+                float t = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < BK; ++kk) t += Bs[kk * BN + tid];
+                bsum += t;
+            }
+        }
+        __syncthreads();
+    }
+
+    float* out = p.OUT + (long long)blockIdx.y * (p.Mtot + p.with_bias) * p.Ng;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 32 + j * 32 + l31;
+        if (col >= p.Ng) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < p.Mtot) out[(long long)m * p.Ng + col] = acc[i][j][e];
+            }
+    }
+    if (do_bias && n0 + tid < p.Ng) out[(long long)p.Mtot * p.Ng + n0 + tid] = bsum;
+}
+
 // out[i] = sum_s part[s][i]   (fixed order => deterministic)
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int splits) {
+// elements [0, n_main) go to `out`, the trailing n - n_main (bias row) to `out2`
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2,
+                                     long long n, long long n_main, int splits) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += part[(long long)k * n + i];
-    out[i] = s;
+    if (i < n_main) out[i] = s; else out2[i - n_main] = s;
 }
 
 // wT[r',s',k,c] = w[R-1-r', S-1-s', c, k]   (dgrad filter: rotate 180 degrees, swap I/O)
@@ -808,69 +970,121 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
     return dispatch_fwd_tile<false, false>(p, st);
 }
 
+// ---- weight-gradient planning (shared by the launcher and the workspace query) ------------
+enum WTile { W128x128, W64x128, W32x128, W64x64, W128x32 };
+struct WPlan { WTile tile; int bm, bn, tiles, splits, chunk; };
+
+WPlan wgrad_plan(int C, int Mtot, int Ng, int Kg) {
+    WPlan w;
+    if (C % 32 == 0) {           // vector-capable: the M tile must lie inside one filter tap
+        if (Ng > 64) {
+            // few pixels => prefer smaller tiles: more output tiles, fewer split-K slabs to reduce
+            if (C % 128 == 0 && Kg >= 49152) w.tile = W128x128;
+            else if (C % 64 == 0 && Kg >= 16384) w.tile = W64x128;
+            else if (C % 64 == 0) w.tile = W64x64;
+            else w.tile = W32x128;
+        } else if (Ng > 32) w.tile = (C % 64 == 0) ? W64x64 : W32x128;
+        else w.tile = (C % 128 == 0) ? W128x32 : W32x128;
+    } else {                     // generic gather: any M tile
+        if (Ng > 64) w.tile = Mtot > 64 ? W128x128 : Mtot > 32 ? W64x128 : W32x128;
+        else if (Ng > 32) w.tile = Mtot > 32 ? W64x64 : W32x128;
+        else w.tile = Mtot > 32 ? W128x32 : W32x128;
+    }
+    static const int dims[5][2] = {{128, 128}, {64, 128}, {32, 128}, {64, 64}, {128, 32}};
+    w.bm = dims[w.tile][0]; w.bn = dims[w.tile][1];
+    w.tiles = ((Mtot + w.bm - 1) / w.bm) * ((Ng + w.bn - 1) / w.bn);
+    ctgan_wgrad_split(w.tiles, Kg, &w.splits, &w.chunk);
+    return w;
+}
+
+size_t wgrad_slab_bytes(const WPlan& w, int Mtot, int Ng) {
+    return w.splits > 1 ? (size_t)w.splits * (Mtot + 1) * Ng * sizeof(float) : 0;
+}
+
 template <bool AVEC, bool BVEC, int WM, int WN, int TM, int TN>
-int launch_wgrad(WgradParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const int tiles = ((p.Mtot + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
-    int splits, chunk;
-    ctgan_wgrad_split(tiles, p.Kg, &splits, &chunk);
-    const size_t need = splits > 1 ? (size_t)splits * p.Mtot * p.Ng * sizeof(float) : 0;
-    if (need > ws_bytes) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
-    p.chunk = chunk;
-    p.OUT = splits > 1 ? static_cast<float*>(ws) : dw;
+int launch_wgrad(WgradParams p, const WPlan& w, float* dw, void* ws, hipStream_t st) {
+    p.chunk = w.chunk;
+    p.with_bias = 0;
+    p.OUT = w.splits > 1 ? static_cast<float*>(ws) : dw;
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad<%s,%s,%dx%d,split%d>", AVEC ? "avec" : "agen",
-             BVEC ? "bvec" : "bgen", BM, BN, splits);
-    hipLaunchKernelGGL((igemm_wgrad_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(tiles, splits), dim3(64 * WM * WN), 0, st, p);
+             BVEC ? "bvec" : "bgen", w.bm, w.bn, w.splits);
+    hipLaunchKernelGGL((igemm_wgrad_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(w.tiles, w.splits), dim3(64 * WM * WN), 0, st, p);
     int rc = ctgan_check_launch("igemm_wgrad");
     if (rc) return rc;
-    if (splits > 1) {
+    if (w.splits > 1) {
         const long long n = (long long)p.Mtot * p.Ng;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.OUT, dw, n, splits);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.OUT, dw, dw, n, n, w.splits);
         rc = ctgan_check_launch("splitk_reduce");
     }
     return rc;
 }
 
-// tile choice depends only on (C, Mtot, Ng) so that the workspace query can reproduce it
-enum WTile { W128x128, W64x128, W32x128, W64x64, W128x32 };
-WTile wgrad_tile_choice(int C, int Mtot, int Ng, int* bm, int* bn) {
-    WTile t;
-    if (C % 32 == 0) {           // AVEC-capable: the M tile must lie inside one filter tap
-        if (Ng > 64) t = (C % 128 == 0) ? W128x128 : (C % 64 == 0) ? W64x128 : W32x128;
-        else if (Ng > 32) t = (C % 64 == 0) ? W64x64 : W32x128;
-        else t = (C % 128 == 0) ? W128x32 : W32x128;
-    } else {                     // generic gather: any M tile
-        if (Ng > 64) t = Mtot > 64 ? W128x128 : Mtot > 32 ? W64x128 : W32x128;
-        else if (Ng > 32) t = Mtot > 32 ? W64x64 : W32x128;
-        else t = Mtot > 32 ? W128x32 : W32x128;
-    }
-    static const int dims[5][2] = {{128, 128}, {64, 128}, {32, 128}, {64, 64}, {128, 32}};
-    *bm = dims[t][0]; *bn = dims[t][1];
-    return t;
-}
-
 template <bool AVEC, bool BVEC>
-int dispatch_wgrad_tile(const WgradParams& p, float* dw, void* ws, size_t wsb, hipStream_t st) {
-    int bm, bn;
-    switch (wgrad_tile_choice(p.g.C, p.Mtot, p.Ng, &bm, &bn)) {
-        case W128x128: return launch_wgrad<AVEC, BVEC, 2, 2, 2, 2>(p, dw, ws, wsb, st);
-        case W64x128: return launch_wgrad<AVEC, BVEC, 1, 4, 2, 1>(p, dw, ws, wsb, st);
-        case W32x128: return launch_wgrad<AVEC, BVEC, 1, 4, 1, 1>(p, dw, ws, wsb, st);
-        case W64x64: return launch_wgrad<AVEC, BVEC, 2, 2, 1, 1>(p, dw, ws, wsb, st);
-        default: return launch_wgrad<AVEC, BVEC, 4, 1, 1, 1>(p, dw, ws, wsb, st);
+int dispatch_wgrad_tile(const WgradParams& p, const WPlan& w, float* dw, void* ws, hipStream_t st) {
+    switch (w.tile) {
+        case W128x128: return launch_wgrad<AVEC, BVEC, 2, 2, 2, 2>(p, w, dw, ws, st);
+        case W64x128: return launch_wgrad<AVEC, BVEC, 1, 4, 2, 1>(p, w, dw, ws, st);
+        case W32x128: return launch_wgrad<AVEC, BVEC, 1, 4, 1, 1>(p, w, dw, ws, st);
+        case W64x64: return launch_wgrad<AVEC, BVEC, 2, 2, 1, 1>(p, w, dw, ws, st);
+        default: return launch_wgrad<AVEC, BVEC, 4, 1, 1, 1>(p, w, dw, ws, st);
     }
 }
 
-int run_wgrad(const WgradParams& p, float* dw, void* ws, size_t wsb, hipStream_t st) {
+template <int WM, int WN, int TM, int TN>
+int launch_wgrad_pipe(WgradParams p, const WPlan& w, float* dw, float* db, void* ws, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr size_t smem_bytes = 2 * (size_t)(BK * BM + BK * BN) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_pipe_kernel<WM, WN, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    p.chunk = w.chunk;
+    p.with_bias = db ? 1 : 0;
+    // with a bias row the slab layout is [Mtot+1][Ng]; a single split still goes through the slab so that
+    // dw stays exactly [Mtot][Ng]
+    const bool direct = w.splits == 1 && !db;
+    p.OUT = direct ? dw : static_cast<float*>(ws);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad_pipe<%dx%d,split%d%s>", BM, BN, w.splits, db ? ",bias" : "");
+    hipLaunchKernelGGL((igemm_wgrad_pipe_kernel<WM, WN, TM, TN>), dim3(w.tiles, w.splits), dim3(64 * WM * WN), smem_bytes, st, p);
+    int rc = ctgan_check_launch("igemm_wgrad_pipe");
+    if (rc || direct) return rc;
+    const long long n_main = (long long)p.Mtot * p.Ng, n = n_main + (db ? p.Ng : 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.OUT, dw, db, n, n_main, w.splits);
+    return ctgan_check_launch("splitk_reduce");
+}
+
+// returns 1 if the bias gradient was produced by the fused path, 0 if not, <0 on error
+int run_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t wsb, hipStream_t st) {
     const Geom& g = p.g;
+    const WPlan w = wgrad_plan(g.C, p.Mtot, p.Ng, p.Kg);
+    const size_t need = (w.splits > 1 || db) ? (size_t)w.splits * (p.Mtot + 1) * p.Ng * sizeof(float) : 0;
+    if (need > wsb) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: workspace too small (%zu < %zu)", wsb, need);
     const bool avec = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
     const bool bvec = p.dy_k == 1 && (p.Ng % 4 == 0) && (p.dy_n % 4 == 0) && (p.dy_p % 4 == 0) && (p.dy_q % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.DY) & 15) == 0);
-    if (avec && bvec) return dispatch_wgrad_tile<true, true>(p, dw, ws, wsb, st);
-    if (avec) return dispatch_wgrad_tile<true, false>(p, dw, ws, wsb, st);
-    if (bvec) return dispatch_wgrad_tile<false, true>(p, dw, ws, wsb, st);
-    return dispatch_wgrad_tile<false, false>(p, dw, ws, wsb, st);
+    if (avec && bvec && !g_force_generic && (w.tile == W128x128 || w.tile == W64x128 || w.tile == W64x64)) {
+        const long long nimg = (p.Kg + (long long)g.P * g.Q - 1) / ((long long)g.P * g.Q);
+        const long long x_elems = (nimg - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
+        const long long y_elems = (nimg - 1) * p.dy_n + (long long)(g.P - 1) * p.dy_p + (long long)(g.Q - 1) * p.dy_q + p.Ng;
+        if (x_elems * 4 < (1LL << 32) && y_elems * 4 < (1LL << 32)) {
+            p.x_bytes = (unsigned)(x_elems * 4); p.dy_bytes = (unsigned)(y_elems * 4);
+            int rc;
+            if (w.tile == W128x128) rc = launch_wgrad_pipe<2, 2, 2, 2>(p, w, dw, db, ws, st);
+            else if (w.tile == W64x128) rc = launch_wgrad_pipe<1, 4, 2, 1>(p, w, dw, db, ws, st);
+            else rc = launch_wgrad_pipe<2, 2, 1, 1>(p, w, dw, db, ws, st);
+            return rc ? rc : (db ? 1 : 0);
+        }
+    }
+    int rc;
+    if (avec && bvec) rc = dispatch_wgrad_tile<true, true>(p, w, dw, ws, st);
+    else if (avec) rc = dispatch_wgrad_tile<true, false>(p, w, dw, ws, st);
+    else if (bvec) rc = dispatch_wgrad_tile<false, true>(p, w, dw, ws, st);
+    else rc = dispatch_wgrad_tile<false, false>(p, w, dw, ws, st);
+    return rc;
 }
 
 int check_desc(const ctgan_conv_desc* d, const char* who) {
@@ -924,11 +1138,9 @@ size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
     if (op == CTGAN_CONV_DGRAD) return (size_t)d->R * d->S * d->C * d->K * sizeof(float);
     if (op == CTGAN_CONV_WGRAD) {
         const int mt = d->R * d->S * d->C, Kg = d->N * d->P * d->Q;
-        int bm, bn, splits, chunk;
-        wgrad_tile_choice(d->C, mt, d->K, &bm, &bn);
-        const int tiles = ((mt + bm - 1) / bm) * ((d->K + bn - 1) / bn);
-        ctgan_wgrad_split(tiles, Kg, &splits, &chunk);
-        return splits > 1 ? (size_t)splits * mt * d->K * sizeof(float) : 0;
+        const WPlan w = wgrad_plan(d->C, mt, d->K, Kg);
+        // slabs (always sized for the bias row) + room for the stand-alone bias column sums
+        return (size_t)w.splits * (mt + 1) * d->K * sizeof(float) + ctgan_colsum_workspace_bytes(Kg, d->K);
     }
     return 0;
 }
@@ -985,8 +1197,8 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
     return run_fwd(p, st);
 }
 
-int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
-                       ctgan_stream_t stream) {
+int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
+                       size_t ws_bytes, ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_wgrad");
     if (rc) return rc;
     if (!x || !dy || !dw) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: null pointer");
@@ -995,8 +1207,24 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
     p.X = x; p.DY = dy; p.OUT = dw;
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
-    p.chunk = 0;
-    return run_wgrad(p, dw, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = run_wgrad(p, dw, db, ws, ws_bytes, st);
+    if (rc < 0) return rc;
+    if (db && rc == 0) {
+        // bias gradient not fused: column sums of dy.  Needs a pixel-linear channels-last dy.
+        // pixel-linear rows of K contiguous channels (strides of size-1 dims are irrelevant)
+        const long long ld = d->Q > 1 ? p.dy_q : (d->P > 1 ? p.dy_p : p.dy_n);
+        const bool lin = p.dy_k == 1 && (d->Q == 1 || p.dy_q == ld) && (d->P == 1 || p.dy_p == (long long)d->Q * ld) &&
+                         (d->N == 1 || p.dy_n == (long long)d->P * d->Q * ld);
+        if (!lin) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_wgrad: bias gradient needs a channels-last dy");
+        const WPlan w = wgrad_plan(d->C, p.Mtot, p.Ng, p.Kg);
+        const size_t slab = (size_t)w.splits * (p.Mtot + 1) * p.Ng * sizeof(float);
+        if (ws_bytes < slab + ctgan_colsum_workspace_bytes(p.Kg, p.Ng))
+            return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: workspace too small for the bias gradient");
+        return ctgan_colsum(dy, p.Kg, p.Ng, ld, db, static_cast<char*>(ws) + slab, ws_bytes - slab, stream);
+    }
+    return CTGAN_OK;
 }
 
 }  // extern "C"

@@ -60,9 +60,13 @@ class ConvFn(Function):
             else:
                 keep = ctx.x_strides if _is_plain_nchw(x) else None
                 gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep)
-        if ctx.needs_input_grad[1] and ctx.want_w:
+        need_w = ctx.needs_input_grad[1] and ctx.want_w
+        need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
+        if need_w and need_b:
+            gw, gb = ConvWgradBiasFn.apply(x, gy, g)       # bias gradient rides the wgrad kernel
+        elif need_w:
             gw = ConvWgradFn.apply(x, gy, g)
-        if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
+        elif need_b:
             gb = ChannelSumFn.apply(gy)
         if ctx.has_resid and ctx.needs_input_grad[3]:
             gr = gy
@@ -117,6 +121,32 @@ class ConvWgradFn(Function):
                 g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None)
         if ctx.needs_input_grad[1]:
             g_gy = ConvFn.apply(x, ggw, None, None, g, None)
+        return g_x, g_gy, None
+
+
+class ConvWgradBiasFn(Function):
+    """(gw, gb) = (sum_pixels x (x) gy, sum_pixels gy) in one launch."""
+
+    @staticmethod
+    def forward(ctx, x, gy, g):
+        ctx.g = g
+        ctx.N = x.shape[0]
+        ctx.save_for_backward(x, gy)
+        return K.conv_wgrad(x, gy, g, with_bias=True)
+
+    @staticmethod
+    def backward(ctx, ggw, ggb):
+        x, gy = ctx.saved_tensors
+        g = ctx.g
+        g_x = g_gy = None
+        ggw = ggw.contiguous()
+        if ctx.needs_input_grad[0]:
+            if g.x_up:
+                g_x = Pool2Fn.apply(ConvDgradFn.apply(gy, ggw, None, _no_up(g), ctx.N, None), 1.0)
+            else:
+                g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None)
+        if ctx.needs_input_grad[1]:
+            g_gy = ConvFn.apply(x, ggw, ggb, None, g, None)
         return g_x, g_gy, None
 
 

@@ -180,20 +180,23 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None):
     return dx
 
 
-def conv_wgrad(x, gy, g):
-    """dw[R,S,C,K] = sum over pixels of x (gathered) * gy."""
+def conv_wgrad(x, gy, g, with_bias=False):
+    """dw[R,S,C,K] = sum over pixels of x (gathered) * gy; with_bias also returns db[K] = sum of gy."""
     _need_dev(x, gy)
     N = x.shape[0]
     assert tuple(x.shape) == _x_phys_shape(g, N)
     assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
     dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+    db = torch.empty(g.K, dtype=torch.float32, device=x.device) if with_bias else None
+    if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous():
+        gy = to_channels_last(gy)
     d = g.desc(N, x.stride(), gy.stride())
     nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 2)
     ws = workspace(nb, x.device)
     with _Timed(g, N):
-        check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(ws), ws.numel(), _stream()),
-              'conv2d_wgrad')
-    return dw
+        check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
+                                     _stream()), 'conv2d_wgrad')
+    return (dw, db) if with_bias else dw
 
 
 def last_kernel():

@@ -77,8 +77,9 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
  * be 0).  With bias this is Deconv2D's forward (TF/tflib/ops/deconv2d.py:97-110).               */
 int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias,
                        float* dx, void* ws, size_t ws_bytes, ctgan_stream_t stream);
-/* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K)   */
-int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw,
+/* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K);
+ * db[k] = sum_{n,p,q} dy[n,k,p,q] when db != NULL (tf.nn.bias_add gradient, fused when possible) */
+int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                        void* ws, size_t ws_bytes, ctgan_stream_t stream);
 /* out[j] = sum_i x[i*ld + j], i<rows, j<cols (bias gradient; tf.nn.bias_add grad)             */
 int ctgan_colsum(const float* x, int64_t rows, int32_t cols, int64_t ld, float* out,

@@ -79,7 +79,12 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None):
 
 
 @_export
-def conv_wgrad(x, gy, g):
+def conv_wgrad(x, gy, g, with_bias=False):
+    gw = _conv_wgrad(x, gy, g)
+    return (gw, gy.sum(dim=(0, 2, 3))) if with_bias else gw
+
+
+def _conv_wgrad(x, gy, g):
     xp = TF.pad(_xin(x, g), _pads(g)).detach().requires_grad_(False)
     wz = torch.zeros(g.K, g.C, g.R, g.S, dtype=x.dtype, requires_grad=True)
     with torch.enable_grad():

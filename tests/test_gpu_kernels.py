@@ -85,6 +85,8 @@ def test_conv_fwd_dgrad_wgrad(K, case):
     assert relerr(gw, gw_ref) < 3e-5, K.last_kernel()
     gw_b = K.conv_wgrad(xd, dev(gy), geom)                     # NCHW-strided dy
     assert relerr(gw_b, gw_ref) < 3e-5, K.last_kernel()
+    gw_c, gb_c = K.conv_wgrad(xd, cl(gy), geom, with_bias=True)  # bias gradient fused where the pipelined kernel applies
+    assert relerr(gw_c, gw_ref) < 3e-5 and relerr(gb_c, gy.double().sum(dim=(0, 2, 3))) < 3e-5, K.last_kernel()
     if not up:
         gx = K.conv_dgrad(cl(gy), dev(w), geom, N)
         assert relerr(gx, gx_ref) < 2e-5, K.last_kernel()
@@ -150,6 +152,27 @@ def test_pipelined_conv_matches_table_driven_kernel(K, N, H, up):
         dx = K.conv_dgrad(gy, w, geom, N)
         assert 'igemm_fwd_pipe' in K.last_kernel()
         assert relerr(dx, dx_ref) < 1e-5
+
+
+@pytest.mark.parametrize('N,H,C,Ko', [(128, 32, 128, 128), (32, 16, 128, 128), (64, 16, 128, 128), (64, 8, 128, 128),
+                                      (5, 8, 64, 128), (3, 4, 256, 512), (9, 8, 128, 256)])
+def test_pipelined_wgrad_matches_table_driven_kernel(K, N, H, C, Ko):
+    g = torch.Generator().manual_seed(N + H + C)
+    x = cl(torch.randn(N, C, H, H, generator=g)); gy = cl(torch.randn(N, Ko, H, H, generator=g))
+    geom = K.ConvGeom(C, H, H, Ko, 3, 3, 1, False)
+    dw, db = K.conv_wgrad(x, gy, geom, with_bias=True)
+    name = K.last_kernel()
+    assert 'igemm_wgrad_pipe' in name and 'bias' in name
+    dw2 = K.conv_wgrad(x, gy, geom)
+    assert torch.equal(dw, dw2)                                   # bias row does not perturb the weights
+    K.debug_force_generic(True)
+    try:
+        ref = K.conv_wgrad(x, gy, geom)
+        assert 'igemm_wgrad<' in K.last_kernel()
+    finally:
+        K.debug_force_generic(False)
+    assert torch.equal(dw, ref), name                              # same split plan, same MFMA order => same bits
+    assert relerr(db, gy.double().sum(dim=(0, 2, 3))) < 2e-5
 
 
 def test_conv_is_deterministic(K):
