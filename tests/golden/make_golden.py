@@ -1,0 +1,143 @@
+#!/usr/bin/env python
+"""Regenerates the golden fixtures in this directory from the CPU oracle (fp64).
+
+The reference (Python-2 / TensorFlow-1.2.1) cannot be imported or run in the build container, so
+these vectors are produced by our own restatement of its graph (oracle/) - they pin the oracle
+against silent drift and give the GPU suite fixed inputs/outputs that do not depend on the oracle
+being importable.  "Parity unpinned" by the reference itself: see oracle/__init__.py.
+
+  python tests/golden/make_golden.py        # rewrites *.npz next to this file
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import nets, steps, tf_ops  # noqa: E402
+from oracle import tflib_ref as ops  # noqa: E402
+
+F64 = torch.float64
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def ops_fixture():
+    g = torch.Generator().manual_seed(1)
+    out = {}
+    # Conv2D: (N,C,H,W,K,k,stride) incl. odd sizes / asymmetric SAME pads
+    for i, (N, C, H, W, K, k, s) in enumerate([(2, 3, 8, 8, 8, 3, 1), (2, 8, 8, 8, 8, 1, 1), (2, 3, 8, 8, 8, 5, 2),
+                                               (2, 4, 7, 7, 6, 5, 2), (1, 4, 6, 5, 4, 3, 2), (2, 32, 8, 8, 32, 3, 1)]):
+        x = torch.randn(N, C, H, W, generator=g, dtype=F64).requires_grad_(True)
+        w = (torch.randn(k, k, C, K, generator=g, dtype=F64) / np.sqrt(k * k * C)).requires_grad_(True)
+        b = torch.randn(K, generator=g, dtype=F64)
+        y = tf_ops.bias_add_nchw(tf_ops.conv2d_same(x, w, s), b)
+        gy = torch.randn(y.shape, generator=g, dtype=F64)
+        gx, gw = torch.autograd.grad(y, [x, w], gy)
+        out.update({'conv%d_cfg' % i: np.array([N, C, H, W, K, k, s]), 'conv%d_x' % i: npy(x), 'conv%d_w' % i: npy(w),
+                    'conv%d_b' % i: npy(b), 'conv%d_y' % i: npy(y), 'conv%d_gy' % i: npy(gy), 'conv%d_gx' % i: npy(gx),
+                    'conv%d_gw' % i: npy(gw)})
+    # Deconv2D (k=5, stride 2) on H in {4,7,8}
+    for i, (N, Ci, Co, H) in enumerate([(2, 8, 4, 4), (1, 4, 4, 7), (2, 4, 3, 8)]):
+        x = torch.randn(N, Ci, H, H, generator=g, dtype=F64)
+        w = torch.randn(5, 5, Co, Ci, generator=g, dtype=F64) / np.sqrt(25 * Ci / 4)
+        b = torch.randn(Co, generator=g, dtype=F64)
+        y = tf_ops.bias_add_nchw(tf_ops.conv2d_transpose_same(x, w, 2), b)
+        out.update({'deconv%d_x' % i: npy(x), 'deconv%d_w' % i: npy(w), 'deconv%d_b' % i: npy(b), 'deconv%d_y' % i: npy(y)})
+    # elementwise
+    x = torch.randn(3, 8, 4, 4, generator=g, dtype=F64)
+    u = torch.rand(3, 8, 4, 4, generator=g, dtype=torch.float32).to(F64)
+    out.update(ew_x=npy(x), ew_u=npy(u), ew_drop08=npy(tf_ops.dropout(x, 0.8, u)), ew_drop05=npy(tf_ops.dropout(x, 0.5, u)),
+               ew_lrelu=npy(tf_ops.leaky_relu(x)), ew_pool=npy(tf_ops.mean_pool2(x)), ew_up=npy(tf_ops.upsample2(x)))
+    # batch norm: fused, axes [0], conditional
+    reg = ops.Registry(dtype=F64)
+    xb = torch.randn(6, 8, 4, 4, generator=g, dtype=F64) * 2 + 1
+    lab = torch.randint(0, 10, (6,), generator=g, dtype=torch.int32)
+    reg['cbn.scale'] = torch.rand(10, 8, generator=g, dtype=F64) + .5
+    reg['cbn.offset'] = torch.randn(10, 8, generator=g, dtype=F64)
+    reg['bn.scale'] = torch.rand(8, generator=g, dtype=F64) + .5
+    reg['bn.offset'] = torch.randn(8, generator=g, dtype=F64)
+    reg['bn.moving_mean'] = torch.zeros(8, dtype=F64); reg['bn.moving_variance'] = torch.ones(8, dtype=F64)
+    x2 = torch.randn(6, 40, generator=g, dtype=F64) + 2
+    reg['bn0.scale'] = torch.rand(1, 40, generator=g, dtype=F64) + .5
+    reg['bn0.offset'] = torch.randn(1, 40, generator=g, dtype=F64)
+    out.update(bn_x=npy(xb), bn_labels=npy(lab), cbn_scale=npy(reg['cbn.scale']), cbn_offset=npy(reg['cbn.offset']),
+               cbn_y=npy(ops.CondBatchnorm(reg, 'cbn', [0, 2, 3], xb, labels=lab, n_labels=10)),
+               bn_scale=npy(reg['bn.scale']), bn_offset=npy(reg['bn.offset']), bn_y=npy(ops.Batchnorm(reg, 'bn', [0, 2, 3], xb)),
+               bn0_x=npy(x2), bn0_scale=npy(reg['bn0.scale']), bn0_offset=npy(reg['bn0.offset']),
+               bn0_y=npy(ops.Batchnorm(reg, 'bn0', [0], x2)))
+    # loss heads
+    d, d_ = torch.randn(8, generator=g, dtype=F64), torch.randn(8, generator=g, dtype=F64)
+    f, f_ = torch.randn(8, 16, generator=g, dtype=F64), torch.randn(8, 16, generator=g, dtype=F64)
+    gr = torch.randn(8, 48, generator=g, dtype=F64) * 0.2
+    s = gr.norm(dim=1)
+    out.update(ct_d=npy(d), ct_d_=npy(d_), ct_f=npy(f), ct_f_=npy(f_), ct_M0=npy(steps.ct_term(d, d_, f, f_, 2.0, 0.0)),
+               ct_M05=npy(steps.ct_term(d, d_, f, f_, 2.0, 0.5)), gp_g=npy(gr), gp_val=npy(10 * ((s - 1) ** 2).mean()))
+    # TF Adam, 3 steps with changing lr
+    th = torch.randn(50, generator=g, dtype=F64); m = torch.zeros(50, dtype=F64); v = torch.zeros(50, dtype=F64)
+    grads, thetas = [], [npy(th)]
+    for t in range(1, 4):
+        gg = torch.randn(50, generator=g, dtype=F64)
+        th, m, v = tf_ops.tf_adam_step(th, gg, m, v, t, 2e-4 * (1 - t / 10.), 0.5, 0.9)
+        grads.append(npy(gg)); thetas.append(npy(th))
+    out.update(adam_g=np.stack(grads), adam_theta=np.stack(thetas))
+    np.savez_compressed(os.path.join(HERE, 'ops.npz'), **out)
+
+
+def resnet_fixture(dim=8, B=4, iters=2):
+    """Reduced-width ResNet CT-WGAN: initial weights, every random draw, and the loss / gradient-norm
+    trace of `iters` x (D step, G step) with teacher = the oracle itself (free running)."""
+    reg = ops.Registry(dtype=F64, seed=11)
+    cfg = nets.ResnetCfg(DIM_G=dim, DIM_D=dim)
+    lab0 = torch.zeros(2, dtype=torch.int32)
+    nets.resnet_discriminator(reg, cfg, nets.resnet_generator(reg, cfg, 2, lab0, torch.zeros(2, 128, dtype=F64)), lab0, 1., 1., 1.)
+    out = {'w.' + n: npy(t).astype(np.float32) for n, t in reg.items()}
+    for n, t in reg.items():                       # fp32-representable initial weights on both sides
+        with torch.no_grad():
+            t.copy_(t.float().double())
+    g = torch.Generator().manual_seed(21)
+    optD = steps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+    optG = steps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Generator')], 0.0, 0.9)
+    for it in range(iters):
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        rnd = steps.make_rnd_resnet_d(B, dim, g)
+        o = steps.resnet_d_step(reg, cfg, optD, real, labels, rnd, iteration=it, B=B)
+        pre = 'it%d.' % it
+        out[pre + 'real'] = npy(real); out[pre + 'labels'] = npy(labels)
+        for k, v in rnd.items():
+            if isinstance(v, list):
+                for j, t in enumerate(v):
+                    out[pre + 'd.%s.%d' % (k, j)] = npy(t).astype(np.float32)
+            else:
+                out[pre + 'd.' + k] = npy(v).astype(np.float32)
+        for k in ('cost', 'wgan', 'acgan', 'ct', 'gp', 'wgan_only', 'acc_real', 'acc_fake'):
+            out[pre + 'd.out.' + k] = npy(o[k])
+        out[pre + 'd.out.fake'] = npy(o['fake']).astype(np.float32)
+        out[pre + 'd.out.slopes'] = npy(o['slopes'])
+        out[pre + 'd.gradnorm'] = np.array([o['grads'][n].norm().item() for n in optD.names])
+        rg = steps.make_rnd_resnet_g(B, dim, g)
+        o = steps.resnet_g_step(reg, cfg, optG, rg, iteration=it + 1, B=B)
+        for j in range(2):
+            out[pre + 'g.z.%d' % j] = npy(rg['z'][j]).astype(np.float32)
+            out[pre + 'g.label_u.%d' % j] = npy(rg['label_u'][j]).astype(np.float32)
+            for i3 in range(3):
+                out[pre + 'g.u.%d.%d' % (j, i3)] = npy(rg['u'][j][i3]).astype(np.float32)
+        out[pre + 'g.out.cost'] = npy(o['cost'])
+        out[pre + 'g.gradnorm'] = np.array([o['grads'][n].norm().item() for n in optG.names])
+    out['d_names'] = np.array(optD.names); out['g_names'] = np.array(optG.names)
+    out['cfg'] = np.array([dim, B, iters])
+    np.savez_compressed(os.path.join(HERE, 'resnet_trace.npz'), **out)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(4)
+    ops_fixture()
+    resnet_fixture()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
