@@ -1,0 +1,100 @@
+"""Shared step of the two DCGAN scripts (MODE 'wgan-CT'): TF/CT_gan_cifar.py:102-154,190-204 and
+TF/CT_gan_mnist.py:110-179,232-249.  Loss = WGAN + consistency term (two dropout passes over the
+real batch) + LAMBDA * gradient penalty; Adam(1e-4, beta1=.5, beta2=.9), no LR decay.
+
+Exact restructuring: the three live critic calls of the reference (real with masks A, real with masks
+B, fake with masks C) are evaluated as ONE batch of 3B rows (dropout is elementwise, the critic has no
+batch-coupled op); the dead 4th call `disc_fake_2` and the extra generators are not executed.
+"""
+import torch
+
+from . import functional as F
+from . import kernels as K
+from . import tflib as lib
+from .optim import FlatAdam
+from .rng import DeviceRNG
+
+
+class DCGANTrainer:
+    def __init__(self, module, seed=2024, rank=0, world_size=1, allreduce=None):
+        """`module` = ctgan_amd.gan_cifar or ctgan_amd.gan_mnist (provides cfg, Generator, Discriminator,
+        real_prep, feat_shapes)."""
+        self.mod = module
+        self.dev = lib._dev()
+        self.rank, self.world, self.allreduce = rank, world_size, allreduce
+        self.rng = DeviceRNG(seed, rank, self.dev)
+        self.d_named = lib.named_params_with_name('Discriminator', trainable_only=True)
+        self.g_named = lib.named_params_with_name('Generator', trainable_only=True)
+        self.d_opt = FlatAdam(self.d_named, 0.5, 0.9)
+        self.g_opt = FlatAdam(self.g_named, 0.5, 0.9)
+        self.d_params = [p for _, p in self.d_named]
+        self.g_params = [p for _, p in self.g_named]
+
+    def _masks(self, n, rnd_key, rnd):
+        if rnd is not None:
+            return rnd[rnd_key]
+        return [self.rng.uniform(n, *s, channels_last=True) for s in self.mod.feat_shapes()]
+
+    def d_losses(self, real_in, rnd=None):
+        m, cfg = self.mod, self.mod.cfg
+        B = cfg.BATCH_SIZE
+        with torch.no_grad():
+            fake = m.Generator(B, noise=rnd['z'] if rnd is not None else None, rng=self.rng)
+            real = m.real_prep(real_in)
+            alpha = rnd['alpha'] if rnd is not None else self.rng.uniform(B, 1)
+            interp = K.interpolate(real, fake, alpha)
+            x3 = torch.cat([real, real, fake], 0)
+        if rnd is not None:
+            u = [torch.cat([a, b, c], 0) for a, b, c in zip(rnd['u_real'], rnd['u_real_'], rnd['u_fake'])]
+        else:
+            u = self._masks(3 * B, None, None)
+        d, f = m.Discriminator(x3, u=u)
+        wgan = F.mean_diff(d[B:], B, B, 0.0, 1.0) + F.mean_diff(d[:B], B, 0, -1.0, 0.0)   # mean(fake) - mean(real)
+        ct = F.consistency_term(d[:B], d[B:2 * B], f[:B], f[B:2 * B], cfg.LAMBDA_2, cfg.Factor_M)
+        interp.requires_grad_(True)
+        with F.weight_grads(False):         # LeakyReLU + dropout critic is piecewise linear
+            d_gp = m.Discriminator(interp, u=self._masks(B, 'u_gp', rnd))[0]
+        (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=torch.ones_like(d_gp), create_graph=True)
+        gp, slopes = F.gradient_penalty(grads, cfg.LAMBDA)
+        return {'cost': wgan + ct + gp, 'wgan_only': wgan, 'ct': ct, 'gp': gp, 'fake': fake, 'slopes': slopes,
+                'gp_grads': grads}
+
+    def g_losses(self, rnd=None):
+        m, B = self.mod, self.mod.cfg.BATCH_SIZE
+        x = m.Generator(B, noise=rnd['z'] if rnd is not None else None, rng=self.rng)
+        with F.weight_grads(False):
+            d, _ = m.Discriminator(x, u=self._masks(B, 'u_fake', rnd))
+        return {'cost': F.mean_diff(d, B, 0, -1.0, 0.0), 'samples': x}
+
+    def _apply(self, opt, grads):
+        opt.set_lr(self.mod.cfg.LR)
+        flat = opt.gather_grads(grads)
+        if self.allreduce is not None and self.world > 1:
+            self.allreduce(flat)
+        opt.step(grad_scale=1.0 / self.world)
+
+    def d_step(self, real_in, rnd=None):
+        self.rng.begin_step()
+        out = self.d_losses(real_in, rnd)
+        grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
+        self._apply(self.d_opt, grads)
+        self.rng.end_step()
+        out['grads'] = dict(zip([n for n, _ in self.d_named], grads))
+        return out
+
+    def g_step(self, rnd=None):
+        self.rng.begin_step()
+        out = self.g_losses(rnd)
+        grads = torch.autograd.grad(out['cost'], self.g_params, allow_unused=True)
+        self._apply(self.g_opt, grads)
+        self.rng.end_step()
+        out['grads'] = dict(zip([n for n, _ in self.g_named], grads))
+        return out
+
+    def train_iteration(self, iteration, next_batch):
+        if iteration > 0:
+            self.g_step()
+        out = None
+        for _ in range(self.mod.cfg.CRITIC_ITERS):
+            out = self.d_step(next_batch())
+        return out

@@ -355,6 +355,30 @@ def to_nchw(x):
     return Copy4dFn.apply(x, False)
 
 
+class CropFn(Function):
+    """x[:, :, :h, :w] as a dense channels-last tensor (MNIST generator, TF/CT_gan_mnist.py:76)."""
+
+    @staticmethod
+    def forward(ctx, x, h, w):
+        ctx.shape = x.shape
+        ctx.hw = (h, w)
+        v = x[:, :, :h, :w]
+        return K.copy4d(v, K.empty_cl(*v.shape, device=x.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w = ctx.hw
+        N, C, H, W = ctx.shape
+        full = K.empty_cl(N, C, H, W, device=g.device)
+        full.zero_()
+        K.copy4d(g, full[:, :, :h, :w])
+        return full, None, None
+
+
+def crop(x, h, w):
+    return CropFn.apply(x, h, w)
+
+
 class AddFn(Function):
     """a*x + b*y through the axpby kernel (used where the add cannot ride a conv epilogue)."""
 

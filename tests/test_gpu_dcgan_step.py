@@ -1,0 +1,105 @@
+"""DCGAN CT-WGAN steps (configs[0] MNIST 28x28 and [1] CIFAR 32x32) on the MI355X against the oracle:
+stride-2 5x5 convs with asymmetric SAME pads, Deconv2D as the adjoint, LeakyReLU+dropout critic,
+BN axes [0], MNIST crop, the 3B-row batched critic and the GP double backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets as onets, steps as osteps, tflib_ref as oref  # noqa: E402
+
+
+def _oracle_from_product(lib):
+    reg = oref.Registry(dtype=torch.float64)
+    for n, p in lib._params.items():
+        tr = n not in lib._non_trainable
+        reg[n] = p.detach().cpu().double().requires_grad_(tr)
+        if not tr:
+            reg.non_trainable.add(n)
+    return reg
+
+
+def _cmp(a, b, tol, what, atol=1e-6):
+    a = a.detach().cpu().double().reshape(-1); b = b.detach().cpu().double().reshape(-1)
+    err = (a - b).abs().max().item(); scale = b.abs().max().item()
+    assert err <= tol * scale + atol, '%s: max err %.3e vs scale %.3e' % (what, err, scale)
+
+
+def _l2(a, b, tol, what, atol=1e-7):
+    a = a.detach().cpu().double().reshape(-1); b = b.detach().cpu().double().reshape(-1)
+    err = (a - b).norm().item(); scale = b.norm().item()
+    assert err <= tol * scale + atol, '%s: L2 err %.3e vs norm %.3e' % (what, err, scale)
+
+
+def _f32(o):
+    if isinstance(o, list):
+        return [_f32(t) for t in o]
+    return o.float()
+
+
+def _dv(o):
+    if isinstance(o, list):
+        return [_dv(t) for t in o]
+    return o.float().cuda()
+
+
+@pytest.mark.parametrize('which,dim,B', [('cifar', 16, 8), ('mnist', 16, 6), ('mnist', 64, 50), ('cifar', 128, 16)])
+def test_dcgan_d_and_g_step(which, dim, B):
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    lib.delete_all_params(); lib.set_device(None)
+    g = torch.Generator().manual_seed(31)
+    if which == 'cifar':
+        import ctgan_amd.gan_cifar as M
+        G = lambda reg, n, z: onets.cifar_generator(reg, n, z, DIM=dim)          # noqa: E731
+        D = lambda reg, x, u: onets.cifar_discriminator(reg, x, u, DIM=dim)      # noqa: E731
+        real_in = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        real_o = 2 * ((real_in.double() / 255.) - .5)
+    else:
+        import ctgan_amd.gan_mnist as M
+        G = lambda reg, n, z: onets.mnist_generator(reg, n, z, DIM=dim)          # noqa: E731
+        D = lambda reg, x, u: onets.mnist_discriminator(reg, x, u, DIM=dim)      # noqa: E731
+        real_in = torch.rand(B, 784, generator=g)
+        real_o = real_in.double()
+    M.configure(DIM=dim, BATCH_SIZE=B)
+    try:
+        lib.set_seed(13)
+        with torch.no_grad():
+            x = M.Generator(2, noise=torch.zeros(2, 128, device='cuda'))
+            M.Discriminator(x, u=[torch.full((2,) + s, 0.9, device='cuda') for s in M.feat_shapes()])
+        tr = DCGANTrainer(M, seed=1)
+        reg = _oracle_from_product(lib)
+        rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
+        out = tr.d_step(real_in.cuda(), {k: _dv(v) for k, v in rnd.items()})
+        ref = osteps.dcgan_d_losses(reg, G, D, real_o, rnd)
+        gref = osteps.grads_of(ref['cost'], reg, 'Discriminator')
+        # fp32 twin of the oracle: the error ANY fp32 evaluation has (activation-sign flips near zero)
+        reg32 = oref.Registry(dtype=torch.float32)
+        for n, t in reg.items():
+            reg32[n] = t.detach().float().requires_grad_(t.requires_grad)
+        reg32.non_trainable = set(reg.non_trainable)
+        tw = osteps.dcgan_d_losses(reg32, G, D, real_o.float(), {k: _f32(v) for k, v in rnd.items()})
+        gtw = osteps.grads_of(tw['cost'], reg32, 'Discriminator')
+        rl2 = lambda a, b: ((a.double() - b).norm() / b.norm().clamp_min(1e-30)).item()   # noqa: E731
+        for k in ('cost', 'wgan_only', 'ct'):
+            _cmp(out[k], ref[k], 2e-4 if dim < 64 else 1e-3, '%s d.%s' % (which, k))
+        # at full width a few LeakyReLU inputs sit within fp32 round-off of 0 and flip slope (1 <-> 0.2) in any
+        # fp32 evaluation; the penalty is the loss term most sensitive to it.  North-star bound: 1e-3.
+        _cmp(out['gp'], M.cfg.LAMBDA * ref['gp'], 2e-4 if dim < 64 else 1e-3, which + ' d.gp')
+        _cmp(out['fake'], ref['fake'], 1e-4, which + ' generator samples')
+        _l2(out['gp_grads'], ref['gp_grads'], max(2e-3, 3 * rl2(tw['gp_grads'], ref['gp_grads'])), which + ' dD/dx_hat')
+        for n in gref:
+            _l2(out['grads'][n], gref[n], max(3e-3, 3 * rl2(gtw[n], gref[n])), which + ' dgrad ' + n, atol=2e-6)
+        lib.load_state_dict({n: t.detach().float() for n, t in reg.items()})     # undo the product's own update
+        rg = osteps.make_rnd_dcgan_g(B, M.feat_shapes(), g)
+        out = tr.g_step({k: _dv(v) for k, v in rg.items()})
+        ref = osteps.dcgan_g_losses(reg, G, D, B, rg)
+        _cmp(out['cost'], ref['cost'], 2e-4, which + ' g cost')
+        gref = osteps.grads_of(ref['cost'], reg, 'Generator')
+        for n in gref:
+            _l2(out['grads'][n], gref[n], 5e-3, which + ' ggrad ' + n, atol=2e-6)
+        # eager random path: one full loop iteration with device-side draws
+        o = tr.train_iteration(1, lambda: real_in.cuda())
+        assert torch.isfinite(o['cost']).item()
+    finally:
+        M.configure(); lib.delete_all_params()
