@@ -19,3 +19,13 @@ static inline unsigned ctgan_blocks(long long n, int per_block, int cap = 4096) 
     if (b > cap) b = cap;
     return (unsigned)b;
 }
+
+// skinny.hip: small-N linear layers (critic heads)
+bool ctgan_is_small_linear(const ctgan_conv_desc* d);
+int ctgan_small_linear_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu,
+                           hipStream_t st);
+int ctgan_small_linear_dgrad(const ctgan_conv_desc* d, const float* gy, const float* w, const float* bias, float* gx,
+                             hipStream_t st);
+int ctgan_small_linear_wgrad(const ctgan_conv_desc* d, const float* x, const float* gy, float* gw, float* gb, hipStream_t st);
+// per-thread name of the kernel variant the last conv call dispatched to
+void ctgan_set_last_kernel(const char* name);

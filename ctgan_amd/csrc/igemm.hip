@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
 //   * WAVES_K > 1 splits each slice between wave groups (for small M: more waves than output
 //     tiles), partial accumulators are combined through LDS at the end;
 //   * XCD-aware tile order: consecutive M tiles (which share halo rows) land on the same XCD / L2.
-template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN, int RD>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pipe_kernel(const FwdParams p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, BKE = 32 * WAVES_K, LDAE = BKE + 4;
@@ -388,10 +388,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
     for (int i = 0; i < B_PER; ++i)
         b_voff[i] = b_ok ? (unsigned)(((long long)(b_k0 + i * (NT / BC)) * p.bs_c + b_j4 * 4) * 4) : 0xFFFFFFFFu;
 
-    float4 ra[A_PER], rb[B_PER];
+    float4 ra[RD][A_PER], rb[RD][B_PER];                                // register ring: slices are loaded RD iterations ahead
     int ld_r = 0, ld_s = 0, ld_c = 0;                                   // tap / channel-chunk of the NEXT slice to load
 
-    auto load_tile = [&]() {
+    auto load_tile = [&](float4 (&ra)[A_PER], float4 (&rb)[B_PER]) {
         const int c0 = ld_c * BKE;
         if (affine) {
             const unsigned soff = (unsigned)(((long long)ld_r * g.s_h + (long long)ld_s * g.s_w + c0) * 4);
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
         }
         if (++ld_c == cpt) { ld_c = 0; if (++ld_s == g.S) { ld_s = 0; ++ld_r; } }
     };
-    auto store_tile = [&](float* As, float* Bs) {
+    auto store_tile = [&](const float4 (&ra)[A_PER], const float4 (&rb)[B_PER], float* As, float* Bs) {
 #pragma unroll
         for (int i = 0; i < A_PER; ++i)
             *reinterpret_cast<float4*>(&As[(a_row0 + i * (NT / AC)) * LDAE + a_chunk * 4]) = ra[i];
@@ -438,48 +438,58 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    load_tile();
-    store_tile(smem, smem + BM * LDAE);
-    if (nk > 1) load_tile();
+    // prologue: slice 0 -> stage 0; slices 1..RD -> ring slots (slice t lives in slot t % RD)
+    load_tile(ra[0], rb[0]);
+    store_tile(ra[0], rb[0], smem, smem + BM * LDAE);
+#pragma unroll
+    for (int t = 1; t <= RD; ++t)
+        if (t < nk) load_tile(ra[t % RD], rb[t % RD]);
     __syncthreads();
 
     const int h = lane >> 5, l31 = lane & 31;
     const int a_rd = (wm * TM * 32 + l31) * LDAE + wk * 32 + h * 16;     // + i*32*LDAE + v*4
     const int b_rd = (wk * 32 + h * 16) * BN + wn * TN * 32 + l31;        // + s*BN + j*32
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const float* As = smem + (kt & 1) * STAGE;
-        const float* Bs = As + BM * LDAE;
-        float* Asn = smem + ((kt + 1) & 1) * STAGE;
-        float* Bsn = Asn + BM * LDAE;
-        float4 a[TM][4];
+    for (int kt0 = 0; kt0 < nk; kt0 += RD) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int u = 0; u < RD; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nk) break;
+            constexpr int dummy = 0; (void)dummy;
+            const float* As = smem + (kt & 1) * STAGE;
+            const float* Bs = As + BM * LDAE;
+            float* Asn = smem + ((kt + 1) & 1) * STAGE;
+            float* Bsn = Asn + BM * LDAE;
+            float4 a[TM][4];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) a[i][v] = *reinterpret_cast<const float4*>(&As[a_rd + i * 32 * LDAE + v * 4]);
-        float b[PD + 1][TN];
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int s0 = 0; s0 < PD; ++s0)
+                for (int v = 0; v < 4; ++v) a[i][v] = *reinterpret_cast<const float4*>(&As[a_rd + i * 32 * LDAE + v * 4]);
+            float b[PD + 1][TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[s0][j] = Bs[b_rd + s0 * BN + j * 32];
+            for (int s0 = 0; s0 < PD; ++s0)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            if (s + PD < 16) {
+                for (int j = 0; j < TN; ++j) b[s0][j] = Bs[b_rd + s0 * BN + j * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[(s + PD) % (PD + 1)][j] = Bs[b_rd + (s + PD) * BN + j * 32];
+            for (int s = 0; s < 16; ++s) {
+                if (s + PD < 16) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[(s + PD) % (PD + 1)][j] = Bs[b_rd + (s + PD) * BN + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 av = a[i][s >> 2];
+                    const float ae = (s & 3) == 0 ? av.x : (s & 3) == 1 ? av.y : (s & 3) == 2 ? av.z : av.w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
+                }
+                // slot (u+1)%RD holds slice kt+1 (loaded RD iterations ago): stage it, then refill the slot
+                if (s == 0 && kt + 1 < nk && !(p.dbg & 1)) store_tile(ra[(u + 1) % RD], rb[(u + 1) % RD], Asn, Bsn);
+                if (s == 1 && kt + 1 + RD < nk && !(p.dbg & 2)) load_tile(ra[(u + 1) % RD], rb[(u + 1) % RD]);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float4 av = a[i][s >> 2];
-                const float ae = (s & 3) == 0 ? av.x : (s & 3) == 1 ? av.y : (s & 3) == 2 ? av.z : av.w;
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
-            }
-            if (s == 3 && kt + 1 < nk && !(p.dbg & 1)) store_tile(Asn, Bsn);             // registers hold slice kt+1
-            if (s == 7 && kt + 2 < nk && !(p.dbg & 2)) load_tile();                      // refill them with slice kt+2
+            if (!(p.dbg & 4)) __syncthreads();
         }
-        if (!(p.dbg & 4)) __syncthreads();
     }
 
     if constexpr (WAVES_K > 1) {                                          // combine the K groups through LDS
@@ -867,14 +877,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
 }
 
 // out[i] = sum_s part[s][i]   (fixed order => deterministic)
-// elements [0, n_main) go to `out`, the trailing n - n_main (bias row) to `out2`
+// elements [0, n_main) go to `out`, the trailing n - n_main (bias row) to `out2`.
+// One thread per 4 consecutive elements (16-B loads), 4 independent accumulators over the slabs so that
+// several loads are in flight; the summation order is fixed (slab k goes to accumulator k%4, then
+// (a0+a1)+(a2+a3)) => deterministic.   n and n_main are multiples of 4 (Ng % 4 == 0 on this path).
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2,
                                      long long n, long long n_main, int splits) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = i4 * 4;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(long long)k * n + i];
-    if (i < n_main) out[i] = s; else out2[i - n_main] = s;
+    if (((n | n_main) & 3) == 0) {
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)(k + 0) * n + i);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (long long)(k + 1) * n + i);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (long long)(k + 2) * n + i);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (long long)(k + 3) * n + i);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; k < splits; ++k) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+        float4 r;
+        r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
+        r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
+        if (i < n_main) *reinterpret_cast<float4*>(out + i) = r;
+        else *reinterpret_cast<float4*>(out2 + (i - n_main)) = r;
+    } else {
+        for (long long e = i; e < i + 4 && e < n; ++e) {
+            float s0 = 0.f;
+            for (int k = 0; k < splits; ++k) s0 += part[(long long)k * n + e];
+            if (e < n_main) out[e] = s0; else out2[e - n_main] = s0;
+        }
+    }
 }
 
 // wT[r',s',k,c] = w[R-1-r', S-1-s', c, k]   (dgrad filter: rotate 180 degrees, swap I/O)
@@ -916,33 +956,46 @@ int dispatch_fwd_tile(const FwdParams& p, hipStream_t st) {
     return launch_fwd<AVEC, BVEC, 4, 1, 1, 1>(p, st);                             // 128x32
 }
 
-template <int WM, int WN, int WK, int TM, int TN>
+template <int WM, int WN, int WK, int TM, int TN, int RD>
 int launch_fwd_pipe(const FwdParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BKE = 32 * WK;
     constexpr size_t smem_bytes = 2 * (size_t)(BM * (BKE + 4) + BKE * BN) * sizeof(float);
     static bool attr_set = false;     // one-time opt-in to > 64 KB of dynamic LDS (idempotent; benign race)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
         if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d>", BM, BN, WK);
-    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
+    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
     return ctgan_check_launch("igemm_fwd_pipe");
 }
 
 int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
     // Work per launch in units of 32x32 output tiles; 1024 SIMDs want >= 1024 waves of work.
     const long long M = p.M;
-    const long long t128 = ((M + 127) / 128) * ((p.Ng + 127) / 128);
-    if (t128 >= 512) return launch_fwd_pipe<2, 2, 1, 2, 2>(p, st);                     // 128x128, 2 blocks/CU
-    const long long t64 = ((M + 63) / 64) * ((p.Ng + 127) / 128);
-    if (t64 >= 384) return launch_fwd_pipe<1, 4, 1, 2, 1>(p, st);                      // 64x128
-    const long long t32 = ((M + 31) / 32) * ((p.Ng + 127) / 128);
-    if (t32 >= 256 || p.g.C % 64 != 0) return launch_fwd_pipe<1, 4, 1, 1, 1>(p, st);   // 32x128
-    return launch_fwd_pipe<1, 2, 2, 1, 1>(p, st);                                      // 32x64, K split over 2 wave groups
+    static const int force = [] { const char* e = getenv("CTGAN_FWD_CFG"); return e ? atoi(e) : 0; }();
+    int cfg = force;
+    if (!cfg) {
+        // measured on MI355X (tools_cfg_sweep.py, 128->128 3x3): the best tile shrinks with the number of
+        // output rows so that >= ~1024 waves exist; the register ring depth RD bought nothing (kept at 1)
+        const long long rows = M * ((p.Ng + 127) / 128);
+        if (rows >= 65536) cfg = 1;
+        else if (rows > 24576) cfg = 2;
+        else if (rows > 12288) cfg = 3;
+        else if (rows > 4096) cfg = 4;
+        else cfg = 5;
+    }
+    if ((cfg == 4 && p.g.C % 64 != 0) || (cfg == 5 && p.g.C % 128 != 0)) cfg = 3;
+    switch (cfg) {
+        case 1: return launch_fwd_pipe<2, 2, 1, 2, 2, 1>(p, st);   // 128x128, 2 blocks/CU
+        case 2: return launch_fwd_pipe<1, 4, 1, 2, 1, 1>(p, st);   // 64x128
+        case 3: return launch_fwd_pipe<1, 4, 1, 1, 1, 1>(p, st);   // 32x128
+        case 4: return launch_fwd_pipe<1, 2, 2, 1, 1, 1>(p, st);   // 32x64, K split over 2 wave groups
+        default: return launch_fwd_pipe<1, 1, 4, 1, 1, 1>(p, st);  // 32x32, K split over 4 wave groups
+    }
 }
 
 int run_fwd(const FwdParams& p0, hipStream_t st) {
@@ -1013,7 +1066,7 @@ int launch_wgrad(WgradParams p, const WPlan& w, float* dw, void* ws, hipStream_t
     if (rc) return rc;
     if (w.splits > 1) {
         const long long n = (long long)p.Mtot * p.Ng;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.OUT, dw, dw, n, n, w.splits);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, p.OUT, dw, dw, n, n, w.splits);
         rc = ctgan_check_launch("splitk_reduce");
     }
     return rc;
@@ -1052,7 +1105,7 @@ int launch_wgrad_pipe(WgradParams p, const WPlan& w, float* dw, float* db, void*
     int rc = ctgan_check_launch("igemm_wgrad_pipe");
     if (rc || direct) return rc;
     const long long n_main = (long long)p.Mtot * p.Ng, n = n_main + (db ? p.Ng : 0);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p.OUT, dw, db, n, n_main, w.splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, p.OUT, dw, db, n, n_main, w.splits);
     return ctgan_check_launch("splitk_reduce");
 }
 
@@ -1066,7 +1119,7 @@ int run_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t wsb, hipStre
                       ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
     const bool bvec = p.dy_k == 1 && (p.Ng % 4 == 0) && (p.dy_n % 4 == 0) && (p.dy_p % 4 == 0) && (p.dy_q % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.DY) & 15) == 0);
-    if (avec && bvec && !g_force_generic && (w.tile == W128x128 || w.tile == W64x128 || w.tile == W64x64)) {
+    if (avec && bvec && !g_force_generic && (w.tile == W128x128 || w.tile == W64x128 || w.tile == W64x64 || w.tile == W32x128)) {
         const long long nimg = (p.Kg + (long long)g.P * g.Q - 1) / ((long long)g.P * g.Q);
         const long long x_elems = (nimg - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
         const long long y_elems = (nimg - 1) * p.dy_n + (long long)(g.P - 1) * p.dy_p + (long long)(g.Q - 1) * p.dy_q + p.Ng;
@@ -1075,6 +1128,7 @@ int run_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t wsb, hipStre
             int rc;
             if (w.tile == W128x128) rc = launch_wgrad_pipe<2, 2, 2, 2>(p, w, dw, db, ws, st);
             else if (w.tile == W64x128) rc = launch_wgrad_pipe<1, 4, 2, 1>(p, w, dw, db, ws, st);
+            else if (w.tile == W32x128) rc = launch_wgrad_pipe<1, 4, 1, 1>(p, w, dw, db, ws, st);
             else rc = launch_wgrad_pipe<2, 2, 1, 1>(p, w, dw, db, ws, st);
             return rc ? rc : (db ? 1 : 0);
         }
@@ -1114,7 +1168,9 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
     // choose splits so that tiles*splits ~ k*256 workgroups (k small) with >= 4 slices per split
     const int max_splits = (Kg + 4 * BK - 1) / (4 * BK);
     int best = 1;
-    for (int k = 1; k <= 4; ++k) {
+    // one or two output tiles (few-channel / skinny weight gradients) are bound by the latency of streaming
+    // the pixel axis, not by MFMA: give every CU ~4 workgroups
+    for (int k = (tiles <= 2 ? 4 : 1); k <= 4; ++k) {
         int s = (256 * k) / tiles;
         if (s < 1) s = 1;
         if (s > max_splits) s = max_splits;
@@ -1127,6 +1183,8 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
     *splits = (Kg + ch - 1) / ch;
     *chunk = ch;
 }
+
+void ctgan_set_last_kernel(const char* name) { snprintf(g_last_kernel, sizeof g_last_kernel, "%s", name); }
 
 extern "C" {
 
@@ -1150,6 +1208,10 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     int rc = check_desc(d, "conv2d_fwd");
     if (rc) return rc;
     if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
+    if (ctgan_is_small_linear(d) && !resid && !g_force_generic) {
+        ctgan_set_last_kernel("linear_small_fwd");
+        return ctgan_small_linear_fwd(d, x, w, bias, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));
+    }
     FwdParams p;
     p.g = geom_from_x(d);
     p.A = x; p.B = w; p.bias = bias; p.resid = resid; p.D = y;
@@ -1160,13 +1222,26 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     return run_fwd(p, static_cast<hipStream_t>(stream));
 }
 
+int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* wt, ctgan_stream_t stream) {
+    if (!d || !w || !wt) return ctgan_fail(CTGAN_E_BADARG, "conv2d_repack_filter: null pointer");
+    const long long n = (long long)d->R * d->S * d->C * d->K;
+    hipLaunchKernelGGL(repack_dgrad_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), w, wt, d->R, d->S, d->C, d->K);
+    return ctgan_check_launch("repack_dgrad_filter");
+}
+
 int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, void* ws,
-                       size_t ws_bytes, ctgan_stream_t stream) {
+                       size_t ws_bytes, int flags, ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_dgrad");
     if (rc) return rc;
     if (!dy || !w || !dx) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: null pointer");
     if (d->x_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: x_up (pool the result instead)");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ctgan_is_small_linear(d) && !g_force_generic) {
+        ctgan_set_last_kernel("linear_small_dgrad");
+        if (flags & CTGAN_DGRAD_W_REPACKED) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: small linear takes the original filter");
+        return ctgan_small_linear_dgrad(d, dy, w, bias, dx, st);
+    }
     FwdParams p;
     Geom& g = p.g;
     g.H = d->P; g.W = d->Q;                 // physical source = dy
@@ -1181,7 +1256,10 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
     p.relu = 0;
     const size_t need = (size_t)d->R * d->S * d->C * d->K * sizeof(float);
     const bool repack = ws && ws_bytes >= need && (d->C % 4 == 0) && (d->K % 32 == 0);
-    if (repack) {
+    if (flags & CTGAN_DGRAD_W_REPACKED) {       // `w` already is wT[r',s',k,c] (ctgan_conv2d_repack_filter)
+        p.B = w;
+        p.b_off = 0; p.bs_r = (long long)d->S * d->K * d->C; p.bs_s = (long long)d->K * d->C; p.bs_c = d->C; p.bs_k = 1;
+    } else if (repack) {
         const long long n = (long long)d->R * d->S * d->C * d->K;
         hipLaunchKernelGGL(repack_dgrad_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w,
                            static_cast<float*>(ws), d->R, d->S, d->C, d->K);
@@ -1202,6 +1280,10 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
     int rc = check_desc(d, "conv2d_wgrad");
     if (rc) return rc;
     if (!x || !dy || !dw) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: null pointer");
+    if (ctgan_is_small_linear(d) && !g_force_generic) {
+        ctgan_set_last_kernel("linear_small_wgrad");
+        return ctgan_small_linear_wgrad(d, x, dy, dw, db, static_cast<hipStream_t>(stream));
+    }
     WgradParams p;
     p.g = geom_from_x(d);
     p.X = x; p.DY = dy; p.OUT = dw;

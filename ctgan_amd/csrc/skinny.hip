@@ -1,0 +1,204 @@
+// skinny.hip - kernels for the GEMM shapes where a 32x32 MFMA tile would be >90 % padding.
+//
+// * small-N linear (the critic heads: [n,128]x[128,1], [n,128]x[128,10], DCGAN [n,8192]x[8192,1]):
+//   forward = one wave per row with a shuffle reduction, data gradient = one thread per input
+//   element, weight/bias gradient = one thread per weight walking the rows in order (deterministic).
+//   These are latency-bound (a few KB); the point is a ~3 us launch instead of a ~30 us GEMM tile.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXN = 16;
+
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int rows, int C, int K, long long xs_n, long long xs_c,
+                                                               long long ys_n, long long ys_k, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float acc[MAXN];
+#pragma unroll
+    for (int j = 0; j < MAXN; ++j) acc[j] = 0.f;
+    const float* xr = x + (long long)row * xs_n;
+    for (int c = lane; c < C; c += 64) {
+        const float xv = xr[(long long)c * xs_c];
+        const float* wr = w + (long long)c * K;
+#pragma unroll
+        for (int j = 0; j < MAXN; ++j)
+            if (j < K) acc[j] = fmaf(xv, wr[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXN; ++j) {
+        if (j >= K) break;
+        float v = acc[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) {
+            v += bias ? bias[j] : 0.f;
+            if (relu) v = fmaxf(v, 0.f);
+            y[(long long)row * ys_n + j * ys_k] = v;
+        }
+    }
+}
+
+// gx[n,c] = sum_j gy[n,j] * w[c,j]
+__global__ void linear_small_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                          const float* __restrict__ bias, float* __restrict__ gx, int rows, int C, int K,
+                                          long long gs_n, long long gs_k, long long xs_n, long long xs_c) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)rows * C) return;
+    const int c = t % C;
+    const long long n = t / C;
+    const float* g = gy + n * gs_n;
+    const float* wr = w + (long long)c * K;
+    float s = bias ? bias[c] : 0.f;
+    for (int j = 0; j < K; ++j) s = fmaf(g[j * gs_k], wr[j], s);
+    gx[n * xs_n + (long long)c * xs_c] = s;
+}
+
+// gw[c,j] = sum_n x[n,c] * gy[n,j] ; gb[j] = sum_n gy[n,j]
+// workgroup = 64 channels x 16 row lanes for one output column j (grid.y = K [+1 for the bias]);
+// row lanes are combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void linear_small_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                float* __restrict__ gw, float* __restrict__ gb, int rows,
+                                                                int C, int K, long long xs_n, long long xs_c, long long gs_n,
+                                                                long long gs_k) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int j = blockIdx.y;
+    const bool is_bias = j == K;
+    float s = 0.f;
+    if (is_bias) {
+        if (blockIdx.x == 0 && cl < K)
+            for (int n = rl; n < rows; n += 16) s += gy[n * gs_n + cl * gs_k];
+    } else if (c < C) {
+        for (int n = rl; n < rows; n += 16) s = fmaf(x[n * xs_n + (long long)c * xs_c], gy[n * gs_n + j * gs_k], s);
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl != 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    if (is_bias) { if (blockIdx.x == 0 && cl < K) gb[cl] = t; }
+    else if (c < C) gw[(long long)c * K + j] = t;
+}
+
+}  // namespace
+
+bool ctgan_is_small_linear(const ctgan_conv_desc* d) {
+    return d->R == 1 && d->S == 1 && d->H == 1 && d->W == 1 && d->P == 1 && d->Q == 1 && d->stride == 1 && !d->x_up &&
+           d->K <= MAXN && d->N <= 65536;
+}
+
+int ctgan_small_linear_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((d->N + 3) / 4), dim3(256), 0, st, x, w, bias, y, d->N, d->C, d->K,
+                       (long long)d->xs[0], (long long)d->xs[1], (long long)d->ys[0], (long long)d->ys[1], relu);
+    return ctgan_check_launch("linear_small_fwd");
+}
+
+int ctgan_small_linear_dgrad(const ctgan_conv_desc* d, const float* gy, const float* w, const float* bias, float* gx,
+                             hipStream_t st) {
+    const long long t = (long long)d->N * d->C;
+    hipLaunchKernelGGL(linear_small_dgrad_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, st, gy, w, bias, gx, d->N,
+                       d->C, d->K, (long long)d->ys[0], (long long)d->ys[1], (long long)d->xs[0], (long long)d->xs[1]);
+    return ctgan_check_launch("linear_small_dgrad");
+}
+
+int ctgan_small_linear_wgrad(const ctgan_conv_desc* d, const float* x, const float* gy, float* gw, float* gb, hipStream_t st) {
+    hipLaunchKernelGGL(linear_small_wgrad_kernel, dim3((d->C + 63) / 64, d->K + (gb ? 1 : 0)), dim3(1024), 0, st, x, gy, gw, gb, d->N,
+                       d->C, d->K, (long long)d->xs[0], (long long)d->xs[1], (long long)d->ys[0], (long long)d->ys[1]);
+    return ctgan_check_launch("linear_small_wgrad");
+}
+
+// ------------------------------------------------------------------------------------------
+// im2col / col2im for convolutions with very few input channels (the critics' first conv on the
+// 3- or 1-channel image): a 3x3x3 conv has a 27-deep GEMM K axis that the vector
+// loaders cannot use (channel runs of 3 floats).  Expanding the image once into a channels-last
+// [N,P,Q,Cpad] patch tensor (27 -> 32 columns, 16.7 MB at n=128) turns the conv, its weight gradient
+// and its data gradient into 1x1 convs that run on the pipelined MFMA kernels; the expansion is
+// reused by forward and weight-gradient.
+namespace {
+
+struct ColGeom {
+    int N, C, H, W, R, S, stride, pad_t, pad_l, P, Q, Cpad;
+    long long xs_n, xs_c, xs_h, xs_w;
+};
+
+__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, ColGeom g, long long total) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int RSC = g.R * g.S * g.C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int col = i % g.Cpad;
+        long long t = i / g.Cpad;
+        const int q = t % g.Q; t /= g.Q;
+        const int p = t % g.P; const int n = t / g.P;
+        float v = 0.f;
+        if (col < RSC) {
+            const int tap = col / g.C, c = col - tap * g.C, r = tap / g.S, s = tap - r * g.S;
+            const int ih = p * g.stride - g.pad_t + r, iw = q * g.stride - g.pad_l + s;
+            if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) v = x[n * g.xs_n + c * g.xs_c + ih * g.xs_h + iw * g.xs_w];
+        }
+        cols[i] = v;
+    }
+}
+
+// dx[n,c,h,w] = sum over taps (r,s) with p*stride - pad_t + r == h (q likewise) of cols[n,p,q,(r*S+s)*C+c]
+__global__ void col2im_kernel(const float* __restrict__ cols, float* __restrict__ dx, ColGeom g, long long total) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        // iterate (n,h,w,c) with c fastest
+        const int c = i % g.C;
+        long long t = i / g.C;
+        const int w = t % g.W; t /= g.W;
+        const int h = t % g.H; const int n = t / g.H;
+        float acc = 0.f;
+        for (int r = 0; r < g.R; ++r) {
+            const int ph = h + g.pad_t - r;
+            if (ph < 0 || ph % g.stride) continue;
+            const int p = ph / g.stride;
+            if (p >= g.P) continue;
+            for (int s = 0; s < g.S; ++s) {
+                const int qw = w + g.pad_l - s;
+                if (qw < 0 || qw % g.stride) continue;
+                const int q = qw / g.stride;
+                if (q >= g.Q) continue;
+                acc += cols[(((long long)n * g.P + p) * g.Q + q) * g.Cpad + (r * g.S + s) * g.C + c];
+            }
+        }
+        dx[n * g.xs_n + c * g.xs_c + h * g.xs_h + w * g.xs_w] = acc;
+    }
+}
+
+ColGeom col_geom(const ctgan_conv_desc* d, int cpad) {
+    ColGeom g;
+    g.N = d->N; g.C = d->C; g.H = d->H; g.W = d->W; g.R = d->R; g.S = d->S; g.stride = d->stride;
+    g.pad_t = d->pad_t; g.pad_l = d->pad_l; g.P = d->P; g.Q = d->Q; g.Cpad = cpad;
+    g.xs_n = d->xs[0]; g.xs_c = d->xs[1]; g.xs_h = d->xs[2]; g.xs_w = d->xs[3];
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctgan_im2col(const ctgan_conv_desc* d, const float* x, int32_t cpad, float* cols, ctgan_stream_t stream) {
+    if (!d || !x || !cols || cpad < d->R * d->S * d->C || d->x_up) return ctgan_fail(CTGAN_E_BADARG, "im2col: bad argument");
+    const long long total = (long long)d->N * d->P * d->Q * cpad;
+    hipLaunchKernelGGL(im2col_kernel, dim3(ctgan_blocks(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, cols,
+                       col_geom(d, cpad), total);
+    return ctgan_check_launch("im2col");
+}
+
+int ctgan_col2im(const ctgan_conv_desc* d, const float* cols, int32_t cpad, float* dx, ctgan_stream_t stream) {
+    if (!d || !dx || !cols || cpad < d->R * d->S * d->C || d->x_up) return ctgan_fail(CTGAN_E_BADARG, "col2im: bad argument");
+    const long long total = (long long)d->N * d->C * d->H * d->W;
+    hipLaunchKernelGGL(col2im_kernel, dim3(ctgan_blocks(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), cols, dx,
+                       col_geom(d, cpad), total);
+    return ctgan_check_launch("col2im");
+}
+
+}  // extern "C"

@@ -9,6 +9,7 @@ static buffers.  With world_size > 1 the all-reduce and the Adam kernels stay ou
 import torch
 
 from . import gan_cifar_resnet as R
+from . import tflib as lib
 
 
 class GraphedTrainer:
@@ -33,6 +34,7 @@ class GraphedTrainer:
     # -- the region that is captured (everything between input copy and all-reduce / Adam)
     def _d_body(self):
         t = self.t
+        lib.bump_epoch()          # derived weight caches (rotated dgrad filters) must be rebuilt INSIDE this graph
         t.rng.begin_step()
         out = t.d_losses(self.real, self.labels)
         grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
@@ -44,6 +46,7 @@ class GraphedTrainer:
 
     def _g_body(self):
         t = self.t
+        lib.bump_epoch()
         t.rng.begin_step()
         out = t.g_losses()
         grads = torch.autograd.grad(out['cost'], t.g_params, allow_unused=True)

@@ -82,7 +82,7 @@ class ConvDgradFn(Function):
         ctx.want_w = _WEIGHT_GRADS
         ctx.has_b = b is not None
         ctx.save_for_backward(gy, w)
-        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b)
+        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g))
 
     @staticmethod
     def backward(ctx, ggx):
@@ -96,6 +96,26 @@ class ConvDgradFn(Function):
         if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
             g_b = ChannelSumFn.apply(ggx)
         return g_gy, g_w, g_b, None, None, None
+
+
+_REPACK = {}      # (epoch, data_ptr, R, S, C, K) -> rotated / I-O-swapped filter, valid until the weights change
+
+
+def _repacked(w, g):
+    """Registry parameters are used by several data gradients per step (dropout passes, GP backward and its
+    double backward): rotate the filter once per weight update instead of once per launch."""
+    from . import tflib as lib
+    if not (isinstance(w, torch.nn.Parameter) and K.dgrad_wants_repack(g)):
+        return None
+    ep = lib.epoch()
+    key = (ep, w.data_ptr(), g.R, g.S, g.C, g.K)
+    wt = _REPACK.get(key)
+    if wt is None:
+        for k in [k for k in _REPACK if k[0] != ep]:
+            del _REPACK[k]
+        wt = K.repack_filter(w, g)
+        _REPACK[key] = wt
+    return wt
 
 
 class ConvWgradFn(Function):
@@ -171,11 +191,46 @@ def _is_plain_nchw(x):
     return x.dim() == 4 and x.is_contiguous() and not x.permute(0, 2, 3, 1).is_contiguous()
 
 
+class Im2colFn(Function):
+    """Patch expansion of a few-channel image (linear; adjoint = Col2imFn)."""
+
+    @staticmethod
+    def forward(ctx, x, g, cpad):
+        ctx.g, ctx.N = g, x.shape[0]
+        ctx.x_strides = x.stride() if _is_plain_nchw(x) else None
+        return K.im2col(x, g, cpad)
+
+    @staticmethod
+    def backward(ctx, gcols):
+        return Col2imFn.apply(gcols, ctx.g, ctx.N, ctx.x_strides), None, None
+
+
+class Col2imFn(Function):
+    @staticmethod
+    def forward(ctx, cols, g, N, out_strides):
+        ctx.g, ctx.cpad = g, cols.shape[1]
+        return K.col2im(K.to_channels_last(cols), g, N, out_strides)
+
+    @staticmethod
+    def backward(ctx, gx):
+        return Im2colFn.apply(gx, ctx.g, ctx.cpad), None, None, None
+
+
 def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False):
     """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`."""
     R, S, C, Kout = w.shape
     N, Cx, H, W = x.shape
     assert Cx == C, 'channel mismatch: x has %d, filter expects %d' % (Cx, C)
+    if C <= 4 and not x_up and Kout % 4 == 0:
+        # few input channels: expand patches once, then the conv / wgrad / dgrad are 1x1 convs on the
+        # pipelined MFMA kernels (csrc/skinny.hip)
+        g = ConvGeom(C, H, W, Kout, R, S, stride, False)
+        cpad = -(-(R * S * C) // 32) * 32
+        cols = Im2colFn.apply(x, g, cpad)
+        w2 = w.reshape(R * S * C, Kout)
+        if cpad > R * S * C:
+            w2 = torch.cat([w2, w2.new_zeros(cpad - R * S * C, Kout)], 0)
+        return conv2d(cols, w2.view(1, 1, cpad, Kout), b, 1, resid, False, out_nchw)
     if x_up:
         H, W = 2 * H, 2 * W
     g = ConvGeom(C, H, W, Kout, R, S, stride, x_up)

@@ -161,9 +161,26 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None):
     return y
 
 
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None):
-    """dx = conv^T(gy, w) [+ bias]; dx logical [N,C,H,W] (channels-last unless out_strides given)."""
-    _need_dev(gy, w, bias)
+def repack_filter(w, g):
+    """wT[r',s',k,c] = w[R-1-r',S-1-s',c,k] (what conv_dgrad multiplies with); reuse it via `wt=`."""
+    _need_dev(w)
+    assert tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
+    wt = torch.empty((g.R, g.S, g.K, g.C), dtype=torch.float32, device=w.device)
+    d = g.desc(1, (0, 0, 0, 0), (0, 0, 0, 0))
+    check(lib.ctgan_conv2d_repack_filter(ctypes.byref(d), _ptr(w), _ptr(wt), _stream()), 'conv2d_repack_filter')
+    return wt
+
+
+def dgrad_wants_repack(g):
+    """True when conv_dgrad can run the vector kernels on a pre-repacked filter."""
+    small_linear = g.R == 1 and g.S == 1 and g.H == 1 and g.W == 1 and g.K <= 16
+    return g.C % 4 == 0 and g.K % 32 == 0 and not small_linear
+
+
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None):
+    """dx = conv^T(gy, w) [+ bias]; dx logical [N,C,H,W] (channels-last unless out_strides given).
+    `wt` = repack_filter(w, g) computed earlier (skips the per-call repack)."""
+    _need_dev(gy, w, bias, wt)
     assert not g.x_up
     assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
     assert tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
@@ -172,10 +189,16 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None):
     else:
         dx = torch.empty_strided((N, g.C, g.H, g.W), out_strides, dtype=torch.float32, device=gy.device)
     d = g.desc(N, dx.stride(), gy.stride())
+    if wt is not None:
+        assert tuple(wt.shape) == (g.R, g.S, g.K, g.C)
+        with _Timed(g, N):
+            check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(wt), _ptr(bias), _ptr(dx), None, 0, 1, _stream()),
+                  'conv2d_dgrad')
+        return dx
     nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, gy.device)
     with _Timed(g, N):
-        check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(dx), _ptr(ws), ws.numel(),
+        check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(dx), _ptr(ws), ws.numel(), 0,
                                      _stream()), 'conv2d_dgrad')
     return dx
 
@@ -197,6 +220,31 @@ def conv_wgrad(x, gy, g, with_bias=False):
         check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
                                      _stream()), 'conv2d_wgrad')
     return (dw, db) if with_bias else dw
+
+
+def im2col(x, g, cpad):
+    """x logical [N,C,H,W] (any strides) -> channels-last [N,cpad,P,Q] patch tensor."""
+    _need_dev(x)
+    N = x.shape[0]
+    assert tuple(x.shape) == (N, g.C, g.H, g.W) and not g.x_up
+    cols = empty_cl(N, cpad, g.P, g.Q, x.device)
+    d = g.desc(N, x.stride(), cols.stride())
+    check(lib.ctgan_im2col(ctypes.byref(d), _ptr(x), cpad, _ptr(cols), _stream()), 'im2col')
+    return cols
+
+
+def col2im(cols, g, N, out_strides=None):
+    """adjoint of im2col: channels-last [N,cpad,P,Q] -> dx logical [N,C,H,W]."""
+    _need_dev(cols)
+    cpad = cols.shape[1]
+    assert tuple(cols.shape) == (N, cpad, g.P, g.Q) and cols.permute(0, 2, 3, 1).is_contiguous()
+    if out_strides is None:
+        dx = empty_cl(N, g.C, g.H, g.W, cols.device)
+    else:
+        dx = torch.empty_strided((N, g.C, g.H, g.W), out_strides, dtype=torch.float32, device=cols.device)
+    d = g.desc(N, dx.stride(), cols.stride())
+    check(lib.ctgan_col2im(ctypes.byref(d), _ptr(cols), cpad, _ptr(dx), _stream()), 'col2im')
+    return dx
 
 
 def last_kernel():

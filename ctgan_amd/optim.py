@@ -7,6 +7,7 @@ parameter / gradient buffers double as the all-reduce buckets of the batch-shard
 import torch
 
 from . import kernels as K
+from . import tflib as lib
 
 
 class FlatAdam:
@@ -57,6 +58,7 @@ class FlatAdam:
         K.adam_step(self.theta, self.grad, self.m, self.v, self.state, self.beta1, self.beta2, self.eps, grad_scale)
         K.adam_advance(self.state, self.beta1, self.beta2)
         self.t += 1
+        lib.bump_epoch()              # weights changed: repacked-filter caches are stale
 
     def load_named_slots(self, m_by_name, v_by_name, t):
         """Overwrite the Adam slots from per-parameter tensors (teacher-forced parity tests, resume)."""

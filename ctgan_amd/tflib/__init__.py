@@ -17,6 +17,15 @@ _param_aliases = {}
 _non_trainable = set()
 _device = None
 _seed = 0
+_epoch = [0]        # bumped whenever parameter VALUES change (optimizer step, load): invalidates derived caches
+
+
+def bump_epoch():
+    _epoch[0] += 1
+
+
+def epoch():
+    return _epoch[0]
 
 
 def set_device(device):
@@ -75,6 +84,7 @@ def named_params_with_name(name, trainable_only=False):
 def delete_all_params():
     _params.clear()
     _non_trainable.clear()
+    bump_epoch()
 
 
 def alias_params(replace_dict):
@@ -101,6 +111,7 @@ def load_state_dict(sd, strict=True):
                 _params[n].copy_(v.to(_params[n].device, torch.float32))
         else:
             param(n, v.detach().to(torch.float32), trainable=not n.endswith(('.moving_mean', '.moving_variance')))
+    bump_epoch()
     if strict:
         missing = [n for n in _params if n not in sd]
         if missing:

@@ -64,7 +64,19 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None):
 
 
 @_export
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None):
+def repack_filter(w, g):
+    return torch.flip(w, (0, 1)).permute(0, 1, 3, 2).contiguous()
+
+
+@_export
+def dgrad_wants_repack(g):
+    return g.C % 4 == 0 and g.K % 32 == 0
+
+
+@_export
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None):
+    if wt is not None:
+        assert torch.equal(wt, repack_filter(w, g))
     full = TF.conv_transpose2d(gy, w.permute(3, 2, 0, 1), stride=g.stride)
     need_h, need_w = g.pad_t + g.H, g.pad_l + g.W
     full = TF.pad(full, (0, max(0, need_w - full.shape[3]), 0, max(0, need_h - full.shape[2])))
@@ -91,6 +103,34 @@ def _conv_wgrad(x, gy, g):
         y = TF.conv2d(xp, wz, stride=g.stride)
         (gw,) = torch.autograd.grad(y, wz, gy.detach())
     return gw.permute(2, 3, 1, 0).contiguous()
+
+
+@_export
+def im2col(x, g, cpad):
+    xp = TF.pad(x, _pads(g))
+    N = x.shape[0]
+    cols = x.new_zeros(N, cpad, g.P, g.Q)
+    for r in range(g.R):
+        for s in range(g.S):
+            patch = xp[:, :, r:r + (g.P - 1) * g.stride + 1:g.stride, s:s + (g.Q - 1) * g.stride + 1:g.stride]
+            cols[:, (r * g.S + s) * g.C:(r * g.S + s + 1) * g.C] = patch
+    return _cl(cols)
+
+
+@_export
+def col2im(cols, g, N, out_strides=None):
+    pl, pr, pt, pb = _pads(g)
+    xp = cols.new_zeros(N, g.C, g.H + pt + pb, g.W + pl + pr)
+    for r in range(g.R):
+        for s in range(g.S):
+            xp[:, :, r:r + (g.P - 1) * g.stride + 1:g.stride, s:s + (g.Q - 1) * g.stride + 1:g.stride] += \
+                cols[:, (r * g.S + s) * g.C:(r * g.S + s + 1) * g.C]
+    dx = xp[:, :, pt:pt + g.H, pl:pl + g.W]
+    if out_strides is None:
+        return _cl(dx)
+    out = torch.empty_strided(dx.shape, out_strides, dtype=dx.dtype)
+    out.copy_(dx)
+    return out
 
 
 @_export

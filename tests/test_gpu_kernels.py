@@ -49,6 +49,8 @@ CONV_CASES = [
     (7, 40, 6, 5, 24, 3, 1, 'cl', False),         # nothing aligned: fully generic
     (130, 128, 1, 1, 2048, 1, 1, 'cl', False),    # Linear 128->2048 as a 1x1 conv
     (64, 8192, 1, 1, 1, 1, 1, 'cl', False),       # DCGAN critic head (GEMV)
+    (192, 128, 1, 1, 10, 1, 1, 'cl', False),      # ACGAN head: small-N linear kernels
+    (70, 128, 1, 1, 1, 1, 1, 'cl', False),        # critic output head
 ]
 
 
@@ -173,6 +175,34 @@ def test_pipelined_wgrad_matches_table_driven_kernel(K, N, H, C, Ko):
         K.debug_force_generic(False)
     assert torch.equal(dw, ref), name                              # same split plan, same MFMA order => same bits
     assert relerr(db, gy.double().sum(dim=(0, 2, 3))) < 2e-5
+
+
+@pytest.mark.parametrize('N,C,H,Ko,k,st,layout', [(5, 3, 32, 128, 3, 1, 'nchw'), (3, 3, 32, 128, 5, 2, 'nchw'),
+                                                    (4, 1, 28, 64, 5, 2, 'cl'), (2, 3, 7, 16, 3, 1, 'cl')])
+def test_few_channel_conv_via_im2col(K, N, C, H, Ko, k, st, layout):
+    """functional.conv2d routes C<=4 convs through im2col + 1x1 MFMA convs; fwd, dgrad (col2im), wgrad,
+    bias grad and the double backward (GP path) against oracle autograd."""
+    import ctgan_amd.functional as F
+    g = torch.Generator().manual_seed(N + C + H)
+    x = torch.randn(N, C, H, H, generator=g); w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
+    b = torch.randn(Ko, generator=g)
+    xd = (cl(x) if layout == 'cl' else dev(x)).requires_grad_(True)
+    wd = dev(w).requires_grad_(True); bd = dev(b).requires_grad_(True)
+    y = F.conv2d(xd, wd, bd, stride=st)
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    yr = tf_ops.bias_add_nchw(tf_ops.conv2d_same(xr, wr, st), br)
+    assert relerr(y, yr) < 2e-5
+    gy = torch.randn(yr.shape, generator=g)
+    got = torch.autograd.grad(y, [xd, wd, bd], cl(gy), create_graph=True)
+    ref = torch.autograd.grad(yr, [xr, wr, br], gy.double(), create_graph=True)
+    for a, c in zip(got, ref):
+        assert relerr(a, c) < 3e-5
+    # second order: d/dw of <dL/dx, v>
+    v = torch.randn(x.shape, generator=g)
+    vd = cl(v) if layout == 'cl' else dev(v)
+    (gw2,) = torch.autograd.grad((got[0] * vd).sum(), wd)
+    (gw2r,) = torch.autograd.grad((ref[0] * v.double()).sum(), wr)
+    assert relerr(gw2, gw2r) < 3e-5
 
 
 def test_conv_is_deterministic(K):
