@@ -53,6 +53,8 @@ struct FwdParams {
     long long b_off, bs_r, bs_s, bs_c, bs_k;   // Wt(r,s,c,k) = B[b_off + r*bs_r + s*bs_s + c*bs_c + k*bs_k]
     long long ds_n, ds_p, ds_q, ds_k;          // D strides over (n,p,q,k)
     int relu;
+    int relu_in;                               // A values pass through max(.,0) when staged (conv(relu(x)))
+    const float* mask;                         // epilogue: keep the result only where mask[off] > 0 (ReLU backward)
     int d_lin;                                 // D offset = m*ds_q + col*ds_k (pixel-linear output)
     unsigned a_bytes, b_bytes;                 // byte extents of A and B (buffer-descriptor range checks)
     int dbg;                                   // perf-diagnosis bits (env CTGAN_DBG): 1 no LDS store, 2 no global load, 4 no barrier
@@ -66,6 +68,7 @@ struct WgradParams {
     int Mtot, Ng, Kg;        // R*S*C, K, N*P*Q
     long long dy_n, dy_p, dy_q, dy_k;
     int chunk;               // pixels per split (multiple of BK)
+    int relu_x;              // A values pass through max(.,0) when staged (wgrad of conv(relu(x)))
     int with_bias;           // 1: slab row Mtot receives the column sums of dy (bias gradient)
     unsigned x_bytes, dy_bytes;
 };
@@ -252,12 +255,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
 #pragma unroll
             for (int i = 0; i < A_VEC_PER; ++i) {
                 const int row = (tid >> 3) + i * (NT / 8);
-                *reinterpret_cast<float4*>(&As[row * LDA + chunk * 4]) = ra4[i];
+                float4 v = ra4[i];
+                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(&As[row * LDA + chunk * 4]) = v;
             }
         } else {
             const int kk = tid & 31;
 #pragma unroll
-            for (int i = 0; i < A_SCL_PER; ++i) As[((tid >> 5) + i * (NT / 32)) * LDA + kk] = ras[i];
+            for (int i = 0; i < A_SCL_PER; ++i) As[((tid >> 5) + i * (NT / 32)) * LDA + kk] = p.relu_in ? fmaxf(ras[i], 0.f) : ras[i];
         }
         if constexpr (BVEC) {
             constexpr int J4 = BN / 4;
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
                 const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
                 const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
                 float v = acc[i][j][e] + bv;
+                if (p.mask && !(p.mask[off] > 0.f)) v = 0.f;
                 if (p.resid) v += p.resid[off];
                 if (p.relu) v = fmaxf(v, 0.f);
                 p.D[off] = v;
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
 //   * WAVES_K > 1 splits each slice between wave groups (for small M: more waves than output
 //     tiles), partial accumulators are combined through LDS at the end;
 //   * XCD-aware tile order: consecutive M tiles (which share halo rows) land on the same XCD / L2.
-template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN, int RD>
+template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN, int RD, bool RELU_IN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pipe_kernel(const FwdParams p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, BKE = 32 * WAVES_K, LDAE = BKE + 4;
@@ -423,8 +429,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
     };
     auto store_tile = [&](const float4 (&ra)[A_PER], const float4 (&rb)[B_PER], float* As, float* Bs) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i)
-            *reinterpret_cast<float4*>(&As[(a_row0 + i * (NT / AC)) * LDAE + a_chunk * 4]) = ra[i];
+        for (int i = 0; i < A_PER; ++i) {
+            float4 v = ra[i];
+            if constexpr (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(&As[(a_row0 + i * (NT / AC)) * LDAE + a_chunk * 4]) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i)
             *reinterpret_cast<float4*>(&Bs[(b_k0 + i * (NT / BC)) * BN + b_j4 * 4]) = rb[i];
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
                     off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
                 }
                 float v = acc[i][j][e] + bv;
+                if (p.mask && !(p.mask[off] > 0.f)) v = 0.f;
                 if (p.resid) v += p.resid[off];
                 if (p.relu) v = fmaxf(v, 0.f);
                 p.D[off] = v;
@@ -660,11 +670,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_kernel(con
         if constexpr (AVEC) {
             constexpr int M4 = BM / 4;
 #pragma unroll
-            for (int i = 0; i < A_VEC_PER; ++i)
-                *reinterpret_cast<float4*>(&As[(tid / M4 + i * (NT / M4)) * BM + (tid % M4) * 4]) = ra4[i];
+            for (int i = 0; i < A_VEC_PER; ++i) {
+                float4 v = ra4[i];
+                if (p.relu_x) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(&As[(tid / M4 + i * (NT / M4)) * BM + (tid % M4) * 4]) = v;
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_SCL_PER; ++i) As[(tid / BM + i * (NT / BM)) * BM + tid % BM] = ras[i];
+            for (int i = 0; i < A_SCL_PER; ++i) As[(tid / BM + i * (NT / BM)) * BM + tid % BM] = p.relu_x ? fmaxf(ras[i], 0.f) : ras[i];
         }
         if constexpr (BVEC) {
             constexpr int J4 = BN / 4;
@@ -792,7 +805,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
     };
     auto store_tile = [&](float* As, float* Bs) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) *reinterpret_cast<float4*>(&As[(a_k0 + i * (NT / M4)) * BM + a_m4 * 4]) = ra[i];
+        for (int i = 0; i < A_PER; ++i) {
+            float4 v = ra[i];
+            if (p.relu_x) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(&As[(a_k0 + i * (NT / M4)) * BM + a_m4 * 4]) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) *reinterpret_cast<float4*>(&Bs[(b_k0 + i * (NT / J4)) * BN + b_j4 * 4]) = rb[i];
     };
@@ -956,21 +973,27 @@ int dispatch_fwd_tile(const FwdParams& p, hipStream_t st) {
     return launch_fwd<AVEC, BVEC, 4, 1, 1, 1>(p, st);                             // 128x32
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int RD>
-int launch_fwd_pipe(const FwdParams& p, hipStream_t st) {
+template <int WM, int WN, int WK, int TM, int TN, int RD, bool RELU_IN>
+int launch_fwd_pipe_impl(const FwdParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BKE = 32 * WK;
     constexpr size_t smem_bytes = 2 * (size_t)(BM * (BKE + 4) + BKE * BN) * sizeof(float);
     static bool attr_set = false;     // one-time opt-in to > 64 KB of dynamic LDS (idempotent; benign race)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
         if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
-    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d>", BM, BN, WK);
-    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d%s>", BM, BN, WK, RELU_IN ? ",relu" : "");
+    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
     return ctgan_check_launch("igemm_fwd_pipe");
+}
+
+template <int WM, int WN, int WK, int TM, int TN, int RD>
+int launch_fwd_pipe(const FwdParams& p, hipStream_t st) {
+    return p.relu_in ? launch_fwd_pipe_impl<WM, WN, WK, TM, TN, RD, true>(p, st)
+                     : launch_fwd_pipe_impl<WM, WN, WK, TM, TN, RD, false>(p, st);
 }
 
 int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
@@ -1208,7 +1231,7 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     int rc = check_desc(d, "conv2d_fwd");
     if (rc) return rc;
     if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
-    if (ctgan_is_small_linear(d) && !resid && !g_force_generic) {
+    if (ctgan_is_small_linear(d) && !resid && !(flags & CTGAN_IN_RELU) && !g_force_generic) {
         ctgan_set_last_kernel("linear_small_fwd");
         return ctgan_small_linear_fwd(d, x, w, bias, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));
     }
@@ -1219,6 +1242,8 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     p.b_off = 0; p.bs_r = (long long)d->S * d->C * d->K; p.bs_s = (long long)d->C * d->K; p.bs_c = d->K; p.bs_k = 1;
     p.ds_n = d->ys[0]; p.ds_k = d->ys[1]; p.ds_p = d->ys[2]; p.ds_q = d->ys[3];
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0;
+    p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
+    p.mask = nullptr;
     return run_fwd(p, static_cast<hipStream_t>(stream));
 }
 
@@ -1230,14 +1255,14 @@ int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* 
     return ctgan_check_launch("repack_dgrad_filter");
 }
 
-int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, void* ws,
-                       size_t ws_bytes, int flags, ctgan_stream_t stream) {
+int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, const float* mask,
+                       const float* resid, float* dx, void* ws, size_t ws_bytes, int flags, ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_dgrad");
     if (rc) return rc;
     if (!dy || !w || !dx) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: null pointer");
     if (d->x_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: x_up (pool the result instead)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ctgan_is_small_linear(d) && !g_force_generic) {
+    if (ctgan_is_small_linear(d) && !mask && !resid && !g_force_generic) {
         ctgan_set_last_kernel("linear_small_dgrad");
         if (flags & CTGAN_DGRAD_W_REPACKED) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: small linear takes the original filter");
         return ctgan_small_linear_dgrad(d, dy, w, bias, dx, st);
@@ -1250,7 +1275,7 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
     g.stride = 1; g.pad_t = d->R - 1 - d->pad_t; g.pad_l = d->S - 1 - d->pad_l;
     g.shift = d->stride == 2 ? 1 : 0; g.mask = d->stride == 2 ? 1 : 0;
     g.s_n = d->ys[0]; g.s_c = d->ys[1]; g.s_h = d->ys[2]; g.s_w = d->ys[3];
-    p.A = dy; p.bias = bias; p.resid = nullptr; p.D = dx;
+    p.A = dy; p.bias = bias; p.resid = resid; p.mask = mask; p.relu_in = 0; p.D = dx;
     p.M = d->N * d->H * d->W; p.Ng = d->C; p.Kg = d->R * d->S * d->K;
     p.ds_n = d->xs[0]; p.ds_k = d->xs[1]; p.ds_p = d->xs[2]; p.ds_q = d->xs[3];
     p.relu = 0;
@@ -1276,11 +1301,11 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
 }
 
 int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws,
-                       size_t ws_bytes, ctgan_stream_t stream) {
+                       size_t ws_bytes, int flags, ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_wgrad");
     if (rc) return rc;
     if (!x || !dy || !dw) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: null pointer");
-    if (ctgan_is_small_linear(d) && !g_force_generic) {
+    if (ctgan_is_small_linear(d) && !(flags & CTGAN_IN_RELU) && !g_force_generic) {
         ctgan_set_last_kernel("linear_small_wgrad");
         return ctgan_small_linear_wgrad(d, x, dy, dw, db, static_cast<hipStream_t>(stream));
     }
@@ -1290,6 +1315,7 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
     p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0;
+    p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = run_wgrad(p, dw, db, ws, ws_bytes, st);
     if (rc < 0) return rc;

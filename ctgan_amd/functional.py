@@ -35,67 +35,81 @@ def weight_grads(enabled):
 
 # --------------------------------------------------------------------------------- conv family
 class ConvFn(Function):
-    """y = conv(x, w) [+ b] [+ resid]   (SAME conv described by geometry g)"""
+    """y = conv(x, w) [+ b] [+ resid]; relu_in: y = conv(relu(x), w) ... without materialising relu(x)
+    (SAME conv described by geometry g)"""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, g, out_strides):
+    def forward(ctx, x, w, b, resid, g, out_strides, relu_in=False):
         ctx.g = g
         ctx.N = x.shape[0]
         ctx.x_strides = x.stride()
         ctx.want_w = _WEIGHT_GRADS
         ctx.has_b = b is not None
         ctx.has_resid = resid is not None
+        ctx.relu_in = bool(relu_in)
         ctx.save_for_backward(x, w)
-        return K.conv_fwd(x, w, b, g, resid=resid, out_strides=out_strides)
+        return K.conv_fwd(x, w, b, g, resid=resid, out_strides=out_strides, relu_in=relu_in)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         g = ctx.g
         gx = gw = gb = gr = None
+        mask = x if ctx.relu_in else None               # ReLU backward rides the dgrad epilogue
         if ctx.needs_input_grad[0]:
             if g.x_up:
-                gfull = ConvDgradFn.apply(gy, w, None, _no_up(g), ctx.N, None)
+                gfull = ConvDgradFn.apply(gy, w, None, _no_up(g), ctx.N, None, None)
                 gx = Pool2Fn.apply(gfull, 1.0)
+                if mask is not None:
+                    gx = LReluBwdFn.apply(gx, x, 0.0)
             else:
                 keep = ctx.x_strides if _is_plain_nchw(x) else None
-                gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep)
+                gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask)
         need_w = ctx.needs_input_grad[1] and ctx.want_w
         need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
         if need_w and need_b:
-            gw, gb = ConvWgradBiasFn.apply(x, gy, g)       # bias gradient rides the wgrad kernel
+            gw, gb = ConvWgradBiasFn.apply(x, gy, g, ctx.relu_in)       # bias gradient rides the wgrad kernel
         elif need_w:
-            gw = ConvWgradFn.apply(x, gy, g)
+            gw = ConvWgradFn.apply(x, gy, g, ctx.relu_in)
         elif need_b:
             gb = ChannelSumFn.apply(gy)
         if ctx.has_resid and ctx.needs_input_grad[3]:
             gr = gy
-        return gx, gw, gb, gr, None, None
+        return gx, gw, gb, gr, None, None, None
 
 
 class ConvDgradFn(Function):
-    """gx = conv^T(gy, w) [+ b]   (with b: Deconv2D's forward)"""
+    """gx = conv^T(gy, w) [+ b] [kept where mask > 0]   (with b: Deconv2D's forward; with mask: the data
+    gradient of conv(relu(x)) w.r.t. x, mask = x)"""
 
     @staticmethod
-    def forward(ctx, gy, w, b, g, N, out_strides):
+    def forward(ctx, gy, w, b, g, N, out_strides, mask=None):
         ctx.g = g
         ctx.want_w = _WEIGHT_GRADS
         ctx.has_b = b is not None
-        ctx.save_for_backward(gy, w)
-        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g))
+        ctx.has_mask = mask is not None
+        if mask is not None:
+            ctx.save_for_backward(gy, w, mask)
+        else:
+            ctx.save_for_backward(gy, w)
+        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask)
 
     @staticmethod
     def backward(ctx, ggx):
-        gy, w = ctx.saved_tensors
+        if ctx.has_mask:
+            gy, w, mask = ctx.saved_tensors
+            ggx = LReluBwdFn.apply(ggx, mask, 0.0)      # the mask is a constant of the second pass
+        else:
+            gy, w = ctx.saved_tensors
         g = ctx.g
         g_gy = g_w = g_b = None
         if ctx.needs_input_grad[0]:
-            g_gy = ConvFn.apply(ggx, w, None, None, g, None)
+            g_gy = ConvFn.apply(ggx, w, None, None, g, None, False)
         if ctx.needs_input_grad[1] and ctx.want_w:
-            g_w = ConvWgradFn.apply(ggx, gy, g)
+            g_w = ConvWgradFn.apply(ggx, gy, g, False)
         if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
             g_b = ChannelSumFn.apply(ggx)
-        return g_gy, g_w, g_b, None, None, None
+        return g_gy, g_w, g_b, None, None, None, None
 
 
 _REPACK = {}      # (epoch, data_ptr, R, S, C, K) -> rotated / I-O-swapped filter, valid until the weights change
@@ -118,56 +132,52 @@ def _repacked(w, g):
     return wt
 
 
+def _wgrad_backward(ctx, ggw, ggb):
+    x, gy = ctx.saved_tensors
+    g = ctx.g
+    g_x = g_gy = None
+    ggw = ggw.contiguous()
+    mask = x if ctx.relu_x else None
+    if ctx.needs_input_grad[0]:
+        if g.x_up:
+            g_x = Pool2Fn.apply(ConvDgradFn.apply(gy, ggw, None, _no_up(g), ctx.N, None, None), 1.0)
+            if mask is not None:
+                g_x = LReluBwdFn.apply(g_x, x, 0.0)
+        else:
+            g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None, mask)
+    if ctx.needs_input_grad[1]:
+        g_gy = ConvFn.apply(x, ggw, ggb, None, g, None, ctx.relu_x)
+    return g_x, g_gy
+
+
 class ConvWgradFn(Function):
-    """gw = sum_pixels x (x) gy"""
+    """gw = sum_pixels x (x) gy     (relu_x: x -> relu(x) on the fly)"""
 
     @staticmethod
-    def forward(ctx, x, gy, g):
-        ctx.g = g
-        ctx.N = x.shape[0]
+    def forward(ctx, x, gy, g, relu_x=False):
+        ctx.g, ctx.N, ctx.relu_x = g, x.shape[0], bool(relu_x)
         ctx.save_for_backward(x, gy)
-        return K.conv_wgrad(x, gy, g)
+        return K.conv_wgrad(x, gy, g, relu_x=relu_x)
 
     @staticmethod
     def backward(ctx, ggw):
-        x, gy = ctx.saved_tensors
-        g = ctx.g
-        g_x = g_gy = None
-        ggw = ggw.contiguous()
-        if ctx.needs_input_grad[0]:
-            if g.x_up:
-                g_x = Pool2Fn.apply(ConvDgradFn.apply(gy, ggw, None, _no_up(g), ctx.N, None), 1.0)
-            else:
-                g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None)
-        if ctx.needs_input_grad[1]:
-            g_gy = ConvFn.apply(x, ggw, None, None, g, None)
-        return g_x, g_gy, None
+        g_x, g_gy = _wgrad_backward(ctx, ggw, None)
+        return g_x, g_gy, None, None
 
 
 class ConvWgradBiasFn(Function):
     """(gw, gb) = (sum_pixels x (x) gy, sum_pixels gy) in one launch."""
 
     @staticmethod
-    def forward(ctx, x, gy, g):
-        ctx.g = g
-        ctx.N = x.shape[0]
+    def forward(ctx, x, gy, g, relu_x=False):
+        ctx.g, ctx.N, ctx.relu_x = g, x.shape[0], bool(relu_x)
         ctx.save_for_backward(x, gy)
-        return K.conv_wgrad(x, gy, g, with_bias=True)
+        return K.conv_wgrad(x, gy, g, with_bias=True, relu_x=relu_x)
 
     @staticmethod
     def backward(ctx, ggw, ggb):
-        x, gy = ctx.saved_tensors
-        g = ctx.g
-        g_x = g_gy = None
-        ggw = ggw.contiguous()
-        if ctx.needs_input_grad[0]:
-            if g.x_up:
-                g_x = Pool2Fn.apply(ConvDgradFn.apply(gy, ggw, None, _no_up(g), ctx.N, None), 1.0)
-            else:
-                g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None)
-        if ctx.needs_input_grad[1]:
-            g_gy = ConvFn.apply(x, ggw, ggb, None, g, None)
-        return g_x, g_gy, None
+        g_x, g_gy = _wgrad_backward(ctx, ggw, ggb)
+        return g_x, g_gy, None, None
 
 
 class ChannelSumFn(Function):
@@ -216,8 +226,9 @@ class Col2imFn(Function):
         return Im2colFn.apply(gx, ctx.g, ctx.cpad), None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False):
-    """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`."""
+def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False):
+    """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`.
+    relu_in=True computes conv(relu(x)) without materialising relu(x)."""
     R, S, C, Kout = w.shape
     N, Cx, H, W = x.shape
     assert Cx == C, 'channel mismatch: x has %d, filter expects %d' % (Cx, C)
@@ -230,6 +241,9 @@ def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False):
         w2 = w.reshape(R * S * C, Kout)
         if cpad > R * S * C:
             w2 = torch.cat([w2, w2.new_zeros(cpad - R * S * C, Kout)], 0)
+        if relu_in:
+            x = relu(x)
+            cols = Im2colFn.apply(x, g, cpad)
         return conv2d(cols, w2.view(1, 1, cpad, Kout), b, 1, resid, False, out_nchw)
     if x_up:
         H, W = 2 * H, 2 * W
@@ -237,7 +251,7 @@ def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False):
     out_strides = None
     if out_nchw:
         out_strides = (Kout * g.P * g.Q, g.P * g.Q, g.Q, 1)
-    return ConvFn.apply(x, w, b, resid, g, out_strides)
+    return ConvFn.apply(x, w, b, resid, g, out_strides, relu_in)
 
 
 def conv2d_transpose(x, w_hwoi, b=None, stride=2):
@@ -248,7 +262,7 @@ def conv2d_transpose(x, w_hwoi, b=None, stride=2):
     assert Cx == Cin
     g = ConvGeom(Cout, H * stride, W * stride, Cin, R, S, stride, False)
     assert (g.P, g.Q) == (H, W)
-    return ConvDgradFn.apply(x, w_hwoi, b, g, N, None)
+    return ConvDgradFn.apply(x, w_hwoi, b, g, N, None, None)
 
 
 def linear(x, w, b=None):

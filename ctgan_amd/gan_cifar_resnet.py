@@ -57,6 +57,11 @@ class Config:
 
 
 cfg = Config()
+import os as _os
+# A/B switch: fold the critic's ReLUs into the conv gathers / dgrad epilogues (relu(x) never materialised).
+# Measured on MI355X (profiles/README): neutral-to-slightly-slower than the stand-alone 7 us elementwise kernels,
+# because the mask read lengthens the MFMA kernels' un-overlapped epilogue.  Default off.
+FUSE_RELU = _os.environ.get('CTGAN_FUSE_RELU', '0') != '0'
 
 
 def configure(**kw):
@@ -67,6 +72,19 @@ def configure(**kw):
 
 def nonlinearity(x):
     return F.relu(x)
+
+
+def _norm_relu(name, inputs, labels=None, groups=1):
+    """Normalize followed by nonlinearity (:134-135,137-138).  Returns (tensor, relu_pending): with a norm the
+    ReLU is fused into the BN kernel; without one (the critic) it is deferred into the next conv's input
+    gather (`relu_in`), so relu(x) is never written to memory."""
+    if ('Generator' in name) and cfg.NORMALIZATION_G:
+        return Normalize(name, inputs, labels=labels, groups=groups, relu=True), False
+    if ('Discriminator' in name) and cfg.NORMALIZATION_D:
+        raise NotImplementedError('NORMALIZATION_D (Layernorm critic) is not built yet')
+    if not FUSE_RELU:
+        return F.relu(inputs), False
+    return inputs, True
 
 
 def Normalize(name, inputs, labels=None, groups=1, relu=False):
@@ -84,12 +102,13 @@ def Normalize(name, inputs, labels=None, groups=1, relu=False):
     return F.relu(inputs) if relu else inputs
 
 
-def ConvMeanPool(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None):
+def ConvMeanPool(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None, relu_in=False):
     """:89-92.  A 1x1 conv commutes with the mean pool: pool first (4x fewer MACs)."""
     if filter_size == 1:
+        assert not relu_in
         return _conv2d.Conv2D(name, input_dim, output_dim, 1, F.mean_pool2(inputs), he_init=he_init, biases=biases,
                               resid=resid)
-    out = _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases)
+    out = _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases, relu_in=relu_in)
     out = F.mean_pool2(out)
     return out if resid is None else F.add(out, resid)
 
@@ -100,13 +119,15 @@ def MeanPoolConv(name, input_dim, output_dim, filter_size, inputs, he_init=True,
     return _conv2d.Conv2D(name, input_dim, output_dim, filter_size, out, he_init=he_init, biases=biases, resid=resid)
 
 
-def UpsampleConv(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None):
+def UpsampleConv(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None, relu_in=False):
     """:100-107.  The nearest-2x upsample is folded into the conv's input gather (x_up); a 1x1
     conv commutes with it and runs on the small side."""
     if filter_size == 1:
         out = _conv2d.Conv2D(name, input_dim, output_dim, 1, inputs, he_init=he_init, biases=biases)
         out = F.upsample2(out)
         return out if resid is None else F.add(out, resid)
+    if relu_in:
+        inputs = F.relu(inputs)
     return _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases,
                           x_up=True, resid=resid)
 
@@ -116,34 +137,36 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
     """:109-141  (resample: None, 'down', or 'up')"""
     if resample not in (None, 'down', 'up'):
         raise Exception('invalid resample value')
-    out = Normalize(name + '.N1', inputs, labels=labels, groups=groups, relu=True)
+    out, r1 = _norm_relu(name + '.N1', inputs, labels=labels, groups=groups)
     if resample == 'down':
-        out = _conv2d.Conv2D(name + '.Conv1', input_dim, input_dim, filter_size, out)
-        out = Normalize(name + '.N2', out, labels=labels, groups=groups, relu=True)
-        out = ConvMeanPool(name + '.Conv2', input_dim, output_dim, filter_size, out)
+        out = _conv2d.Conv2D(name + '.Conv1', input_dim, input_dim, filter_size, out, relu_in=r1)
+        out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
+        out = ConvMeanPool(name + '.Conv2', input_dim, output_dim, filter_size, out, relu_in=r2)
         # shortcut = ConvMeanPool 1x1 (he_init=False); the residual add rides its epilogue
         return ConvMeanPool(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True, resid=out)
     if resample == 'up':
         shortcut = UpsampleConv(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
-        out = UpsampleConv(name + '.Conv1', input_dim, output_dim, filter_size, out)
-        out = Normalize(name + '.N2', out, labels=labels, groups=groups, relu=True)
-        return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut)
+        out = UpsampleConv(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
+        out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
+        return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2)
     # resample None
     if output_dim == input_dim:
         shortcut = inputs
     else:
         shortcut = _conv2d.Conv2D(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
-    out = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out)
-    out = Normalize(name + '.N2', out, labels=labels, groups=groups, relu=True)
-    return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut)
+    out = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
+    out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
+    return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2)
 
 
 def OptimizedResBlockDisc1(inputs):
     """:143-153"""
     D = cfg.DIM_D
     out = _conv2d.Conv2D('Discriminator.1.Conv1', 3, D, 3, inputs)
-    out = nonlinearity(out)
-    out = ConvMeanPool('Discriminator.1.Conv2', D, D, 3, out)
+    if FUSE_RELU:
+        out = ConvMeanPool('Discriminator.1.Conv2', D, D, 3, out, relu_in=True)    # nonlinearity folded into Conv2's gather
+    else:
+        out = ConvMeanPool('Discriminator.1.Conv2', D, D, 3, nonlinearity(out))
     return MeanPoolConv('Discriminator.1.Shortcut', 3, D, 1, inputs, he_init=False, biases=True, resid=out)
 
 

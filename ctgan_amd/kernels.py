@@ -142,8 +142,8 @@ def _x_phys_shape(g, N):
     return (N, g.C, g.H // 2, g.W // 2) if g.x_up else (N, g.C, g.H, g.W)
 
 
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None):
-    """y = conv(x,w) [+bias] [+resid] [relu].  x logical [N,C,H(/2),W(/2)], w HWIO contiguous."""
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False):
+    """y = conv(x,w) [+bias] [+resid] [relu]; relu_in: conv(relu(x)).  x logical [N,C,H(/2),W(/2)], w HWIO."""
     _need_dev(x, w, bias, resid)
     N = x.shape[0]
     assert tuple(x.shape) == _x_phys_shape(g, N), (tuple(x.shape), _x_phys_shape(g, N))
@@ -157,7 +157,7 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None):
     d = g.desc(N, x.stride(), y.stride())
     with _Timed(g, N):
         check(lib.ctgan_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y),
-                                   1 if relu else 0, _stream()), 'conv2d_fwd')
+                                   (1 if relu else 0) | (2 if relu_in else 0), _stream()), 'conv2d_fwd')
     return y
 
 
@@ -177,10 +177,10 @@ def dgrad_wants_repack(g):
     return g.C % 4 == 0 and g.K % 32 == 0 and not small_linear
 
 
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None):
-    """dx = conv^T(gy, w) [+ bias]; dx logical [N,C,H,W] (channels-last unless out_strides given).
-    `wt` = repack_filter(w, g) computed earlier (skips the per-call repack)."""
-    _need_dev(gy, w, bias, wt)
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None):
+    """dx = conv^T(gy, w) [+ bias] [kept where mask > 0] [+ resid]; dx logical [N,C,H,W] (channels-last
+    unless out_strides given).  `wt` = repack_filter(w, g) computed earlier (skips the per-call repack)."""
+    _need_dev(gy, w, bias, wt, mask, resid)
     assert not g.x_up
     assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
     assert tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
@@ -189,21 +189,25 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None):
     else:
         dx = torch.empty_strided((N, g.C, g.H, g.W), out_strides, dtype=torch.float32, device=gy.device)
     d = g.desc(N, dx.stride(), gy.stride())
+    if mask is not None:
+        mask = match_layout(mask, dx)
+    if resid is not None:
+        resid = match_layout(resid, dx)
     if wt is not None:
         assert tuple(wt.shape) == (g.R, g.S, g.K, g.C)
         with _Timed(g, N):
-            check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(wt), _ptr(bias), _ptr(dx), None, 0, 1, _stream()),
-                  'conv2d_dgrad')
+            check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(wt), _ptr(bias), _ptr(mask), _ptr(resid),
+                                         _ptr(dx), None, 0, 1, _stream()), 'conv2d_dgrad')
         return dx
     nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)
     ws = workspace(nb, gy.device)
     with _Timed(g, N):
-        check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(dx), _ptr(ws), ws.numel(), 0,
-                                     _stream()), 'conv2d_dgrad')
+        check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx),
+                                     _ptr(ws), ws.numel(), 0, _stream()), 'conv2d_dgrad')
     return dx
 
 
-def conv_wgrad(x, gy, g, with_bias=False):
+def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
     """dw[R,S,C,K] = sum over pixels of x (gathered) * gy; with_bias also returns db[K] = sum of gy."""
     _need_dev(x, gy)
     N = x.shape[0]
@@ -218,7 +222,7 @@ def conv_wgrad(x, gy, g, with_bias=False):
     ws = workspace(nb, x.device)
     with _Timed(g, N):
         check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
-                                     _stream()), 'conv2d_wgrad')
+                                     2 if relu_x else 0, _stream()), 'conv2d_wgrad')
     return (dw, db) if with_bias else dw
 
 

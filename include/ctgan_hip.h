@@ -55,7 +55,7 @@ typedef struct ctgan_conv_desc {
 } ctgan_conv_desc;
 
 enum { CTGAN_CONV_FWD = 0, CTGAN_CONV_DGRAD = 1, CTGAN_CONV_WGRAD = 2 };
-enum { CTGAN_EPI_RELU = 1 };
+enum { CTGAN_EPI_RELU = 1, CTGAN_IN_RELU = 2 };  /* relu on the result / on the gathered input (conv(relu(x))) */
 enum { CTGAN_DGRAD_W_REPACKED = 1 };
 
 /* ---- library ------------------------------------------------------------------------------ */
@@ -76,8 +76,11 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
                      const float* resid, float* y, int flags, ctgan_stream_t stream);
 /* dx = adjoint of conv w.r.t. x, applied to dy [+ bias[c]] (dx has the strides d->xs; x_up must
  * be 0).  With bias this is Deconv2D's forward (TF/tflib/ops/deconv2d.py:97-110).               */
+/* epilogue: dx = (conv^T(dy,w) + bias) [kept only where mask > 0: the ReLU backward of conv(relu(x)),
+ * mask = x] [+ resid].  mask and resid have the strides of dx.                                    */
 int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias,
-                       float* dx, void* ws, size_t ws_bytes, int flags, ctgan_stream_t stream);
+                       const float* mask, const float* resid, float* dx, void* ws, size_t ws_bytes,
+                       int flags, ctgan_stream_t stream);
 /* wt[r',s',k,c] = w[R-1-r',S-1-s',c,k]: the rotated, I/O-swapped filter the data gradient multiplies
  * with.  Callers that run several dgrads per weight update repack once and pass
  * CTGAN_DGRAD_W_REPACKED (then `w` is wt and no workspace is needed).                            */
@@ -85,7 +88,8 @@ int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* 
 /* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K);
  * db[k] = sum_{n,p,q} dy[n,k,p,q] when db != NULL (tf.nn.bias_add gradient, fused when possible) */
 int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
-                       void* ws, size_t ws_bytes, ctgan_stream_t stream);
+                       void* ws, size_t ws_bytes, int flags /* CTGAN_IN_RELU: x -> relu(x) */,
+                       ctgan_stream_t stream);
 /* Patch expansion for convs with very few input channels (first critic conv, TF/CT_gan_cifar_resnet.py:
  * 144,150; TF/CT_gan_cifar.py:84; TF/CT_gan_mnist.py:92): cols[n,p,q,(r*S+s)*C+c] = x[n,c,p*st-pt+r,q*st-pl+s]
  * (zero outside the image and for columns >= R*S*C; cols is channels-last [N,P,Q,cpad], contiguous).

@@ -46,7 +46,9 @@ def _xin(x, g):
 
 
 @_export
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None):
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False):
+    if relu_in:
+        x = torch.relu(x)
     xp = TF.pad(_xin(x, g), _pads(g))
     y = TF.conv2d(xp, w.permute(3, 2, 0, 1), stride=g.stride)
     assert y.shape[2:] == (g.P, g.Q)
@@ -74,7 +76,7 @@ def dgrad_wants_repack(g):
 
 
 @_export
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None):
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None):
     if wt is not None:
         assert torch.equal(wt, repack_filter(w, g))
     full = TF.conv_transpose2d(gy, w.permute(3, 2, 0, 1), stride=g.stride)
@@ -83,6 +85,10 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None):
     dx = full[:, :, g.pad_t:g.pad_t + g.H, g.pad_l:g.pad_l + g.W]
     if bias is not None:
         dx = dx + bias.view(1, -1, 1, 1)
+    if mask is not None:
+        dx = torch.where(mask > 0, dx, torch.zeros_like(dx))
+    if resid is not None:
+        dx = dx + resid
     if out_strides is None:
         return _cl(dx)
     out = torch.empty_strided(dx.shape, out_strides, dtype=dx.dtype)
@@ -91,7 +97,9 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None):
 
 
 @_export
-def conv_wgrad(x, gy, g, with_bias=False):
+def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
+    if relu_x:
+        x = torch.relu(x)
     gw = _conv_wgrad(x, gy, g)
     return (gw, gy.sum(dim=(0, 2, 3))) if with_bias else gw
 

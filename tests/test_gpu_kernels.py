@@ -146,7 +146,7 @@ def test_pipelined_conv_matches_table_driven_kernel(K, N, H, up):
         dx_ref = None if up else K.conv_dgrad(gy, w, geom, N)
     finally:
         K.debug_force_generic(False)
-    if ',k1>' in name:
+    if ',k1' in name:
         assert torch.equal(y, y_ref), name              # same summation order => same bits
     else:
         assert relerr(y, y_ref) < 1e-5, name             # K halves summed separately
@@ -203,6 +203,26 @@ def test_few_channel_conv_via_im2col(K, N, C, H, Ko, k, st, layout):
     (gw2,) = torch.autograd.grad((got[0] * vd).sum(), wd)
     (gw2r,) = torch.autograd.grad((ref[0] * v.double()).sum(), wr)
     assert relerr(gw2, gw2r) < 3e-5
+
+
+@pytest.mark.parametrize('N,C,H,Ko,k', [(64, 128, 32, 128, 3), (16, 128, 8, 128, 3), (3, 40, 6, 24, 3), (8, 128, 16, 128, 1)])
+def test_fused_relu_in_and_mask_epilogue(K, N, C, H, Ko, k):
+    """conv(relu(x)) with the ReLU applied while staging the tile; its data gradient with the ReLU mask
+    (+ residual) in the epilogue; its weight gradient with relu-on-load - vs the unfused composition."""
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(N, C, H, H, generator=g); w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
+    b = torch.randn(Ko, generator=g); gy = torch.randn(N, Ko, H, H, generator=g); r = torch.randn(N, C, H, H, generator=g)
+    geom = K.ConvGeom(C, H, H, Ko, k, k, 1, False)
+    xd, wd, bd, gyd, rd = cl(x), dev(w), dev(b), cl(gy), cl(r)
+    xr = K.lrelu_fwd(xd, 0.0)
+    y = K.conv_fwd(xd, wd, bd, geom, relu_in=True)
+    assert torch.equal(y, K.conv_fwd(xr, wd, bd, geom)), K.last_kernel()
+    dx = K.conv_dgrad(gyd, wd, geom, N, mask=xd, resid=rd)
+    ref = K.axpby(K.lrelu_bwd(K.conv_dgrad(gyd, wd, geom, N), xd, 0.0), rd, 1.0, 1.0)
+    assert torch.equal(dx, ref), K.last_kernel()
+    dw, db = K.conv_wgrad(xd, gyd, geom, with_bias=True, relu_x=True)
+    dw2, db2 = K.conv_wgrad(xr, gyd, geom, with_bias=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), K.last_kernel()
 
 
 def test_conv_is_deterministic(K):
