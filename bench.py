@@ -36,6 +36,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets the\n'
+                    'multi-rank code path be exercised on a single-GPU box (all ranks share cuda:0)')
     args = ap.parse_args()
 
     import numpy as np
@@ -43,7 +45,9 @@ def main():
     import torch.distributed as dist
 
     from ctgan_amd import ddp
-    rank, world, local = ddp.init_from_env()
+    rank, world, local = ddp.init_from_env(backend=args.backend)
+    if local >= torch.cuda.device_count():
+        local = local % max(torch.cuda.device_count(), 1)       # test mode only (ranks share a device)
     if world != args.gpus:
         if rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
@@ -117,6 +121,7 @@ def main():
         }
         print(json.dumps(rec))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -124,15 +129,20 @@ def measure_roofline(trainer, next_batch, K, torch):
     """One instrumented EAGER iteration: every conv-family launch is bracketed by HIP events on its
     launch stream.  The dominant kernel = the variant with the largest summed duration."""
     import ctgan_amd.gan_cifar_resnet as R
-    trainer.train_iteration(1, next_batch)             # eager warm-up (lazy allocations)
-    torch.cuda.synchronize()
-    K.PROFILE = []
+    # rank 0 only: this pass must not enter a collective (the other ranks are not here)
+    saved_world, trainer.world = trainer.world, 1
     try:
-        trainer.train_iteration(1, next_batch)
+        trainer.train_iteration(1, next_batch)         # eager warm-up (lazy allocations)
         torch.cuda.synchronize()
-        prof = K.PROFILE
+        K.PROFILE = []
+        try:
+            trainer.train_iteration(1, next_batch)
+            torch.cuda.synchronize()
+            prof = K.PROFILE
+        finally:
+            K.PROFILE = None
     finally:
-        K.PROFILE = None
+        trainer.world = saved_world
     agg = {}
     for name, flops, e0, e1 in prof:
         a = agg.setdefault(name, [0, 0.0, 0.0])
