@@ -153,11 +153,20 @@ def measure_roofline(trainer, next_batch, K, torch):
     total_f = sum(a[1] for a in agg.values())
     name, (cnt, fl, tt) = max(agg.items(), key=lambda kv: kv[1][2])
     achieved = fl / tt / 1e12
+    traffic = None
+    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), scaled by flops
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        if pmc['kernel'] == name:
+            traffic = {'hbm_bytes_per_launch': round(pmc['hbm_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
+                       'algorithmic_bytes_per_launch': round(pmc['algorithmic_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
+                       'source': 'profiles/r01_pmc_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, scaled to this launch mix)'}
+    except Exception:
+        traffic = None
     return {
         'bound': 'mfma', 'kernel': name, 'launches': cnt,
         'flops_per_launch': round(fl / cnt / 1e9, 3), 'avg_launch_us': round(tt / cnt * 1e6, 2),
         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+        'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
         'kernel_share_of_conv_time': round(tt / total_t, 3),
         'all_conv_kernels': {'achieved': round(total_f / total_t / 1e12, 2),
                              'frac': round(total_f / total_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
