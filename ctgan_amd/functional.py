@@ -19,6 +19,9 @@ from . import kernels as K
 from .kernels import ConvGeom
 
 _WEIGHT_GRADS = True
+# ReLU backward of conv(relu(x)): False = stand-alone mask kernel on the data gradient (measured faster: the
+# dgrad epilogue is the un-overlapped tail of an MFMA kernel), True = mask read inside the dgrad epilogue
+MASK_IN_DGRAD_EPILOGUE = False
 
 
 @contextlib.contextmanager
@@ -64,7 +67,10 @@ class ConvFn(Function):
                     gx = LReluBwdFn.apply(gx, x, 0.0)
             else:
                 keep = ctx.x_strides if _is_plain_nchw(x) else None
-                gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask)
+                if mask is not None and not MASK_IN_DGRAD_EPILOGUE:
+                    gx = LReluBwdFn.apply(ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, None), x, 0.0)
+                else:
+                    gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask)
         need_w = ctx.needs_input_grad[1] and ctx.want_w
         need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
         if need_w and need_b:
@@ -112,24 +118,49 @@ class ConvDgradFn(Function):
         return g_gy, g_w, g_b, None, None, None, None
 
 
-_REPACK = {}      # (epoch, data_ptr, R, S, C, K) -> rotated / I-O-swapped filter, valid until the weights change
+_REPACK = {}      # (epoch, data_ptr, R, S, C, K) -> (rotated / I-O-swapped filter, ready event, producer stream)
 
 
 def _repacked(w, g):
     """Registry parameters are used by several data gradients per step (dropout passes, GP backward and its
-    double backward): rotate the filter once per weight update instead of once per launch."""
+    double backward): rotate the filter once per weight update instead of once per launch.  A consumer on
+    another stream waits for the producer's event."""
     from . import tflib as lib
     if not (isinstance(w, torch.nn.Parameter) and K.dgrad_wants_repack(g)):
         return None
     ep = lib.epoch()
     key = (ep, w.data_ptr(), g.R, g.S, g.C, g.K)
-    wt = _REPACK.get(key)
-    if wt is None:
+    hit = _REPACK.get(key)
+    if hit is None:
         for k in [k for k in _REPACK if k[0] != ep]:
             del _REPACK[k]
         wt = K.repack_filter(w, g)
-        _REPACK[key] = wt
+        ev, st = None, None
+        if wt.is_cuda:
+            st = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(st)
+        _REPACK[key] = (wt, ev, st)
+        return wt
+    wt, ev, st = hit
+    if ev is not None and torch.cuda.current_stream() != st:
+        torch.cuda.current_stream().wait_event(ev)
     return wt
+
+
+def prepare_dgrad_filters(params):
+    """Rotate the filters of `params` now, on the current stream (call before forking side streams)."""
+    for w in params:
+        if w.dim() == 4:
+            R, S, C, Kout = w.shape
+        elif w.dim() == 2:
+            R, S, (C, Kout) = 1, 1, w.shape
+        else:
+            continue
+        g = ConvGeom(C, 1 if w.dim() == 2 else 8, 1 if w.dim() == 2 else 8, Kout, R, S, 1, False)
+        wv = w if w.dim() == 4 else None
+        if wv is not None:
+            _repacked(wv, g)
 
 
 def _wgrad_backward(ctx, ggw, ggb):
@@ -143,6 +174,8 @@ def _wgrad_backward(ctx, ggw, ggb):
             g_x = Pool2Fn.apply(ConvDgradFn.apply(gy, ggw, None, _no_up(g), ctx.N, None, None), 1.0)
             if mask is not None:
                 g_x = LReluBwdFn.apply(g_x, x, 0.0)
+        elif mask is not None and not MASK_IN_DGRAD_EPILOGUE:
+            g_x = LReluBwdFn.apply(ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None, None), x, 0.0)
         else:
             g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None, mask)
     if ctx.needs_input_grad[1]:

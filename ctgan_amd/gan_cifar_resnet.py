@@ -59,9 +59,11 @@ class Config:
 cfg = Config()
 import os as _os
 # A/B switch: fold the critic's ReLUs into the conv gathers / dgrad epilogues (relu(x) never materialised).
-# Measured on MI355X (profiles/README): neutral-to-slightly-slower than the stand-alone 7 us elementwise kernels,
-# because the mask read lengthens the MFMA kernels' un-overlapped epilogue.  Default off.
-FUSE_RELU = _os.environ.get('CTGAN_FUSE_RELU', '0') != '0'
+# Measured on MI355X (tools_fuse_bench.py): the forward gather and the wgrad relu-on-load are free (the relu(x)
+# tensor is never written or re-read); the mask in the dgrad EPILOGUE is not (it lengthens the un-overlapped tail of
+# an MFMA kernel by as much as the stand-alone mask kernel costs), so the backward keeps the stand-alone kernel
+# (functional.MASK_IN_DGRAD_EPILOGUE = False).
+FUSE_RELU = _os.environ.get('CTGAN_FUSE_RELU', '1') != '0'
 
 
 def configure(**kw):
@@ -238,6 +240,19 @@ def _cat_rows(a, b):
     return torch.cat([a, b], dim=0)
 
 
+class _nullctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+# A/B switch: gradient-penalty branch on a side stream (parallel hipGraph branch).  Measured neutral (-1 %):
+# every kernel of the step already spans all CUs, so overlap only adds contention.  Default off.
+GP_SIDE_STREAM = _os.environ.get('CTGAN_GP_STREAM', '0') != '0'
+
+
 class Trainer:
     """Owns the optimizers, the random streams and the D/G step (the session of the reference)."""
 
@@ -253,6 +268,13 @@ class Trainer:
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
 
+    def _gp_stream(self):
+        if not (GP_SIDE_STREAM and self.dev.type == 'cuda'):
+            return None
+        if getattr(self, '_gp_side', None) is None:
+            self._gp_side = torch.cuda.Stream(device=self.dev)
+        return self._gp_side
+
     # ------------------------------------------------------------------ losses
     def d_losses(self, real_int, labels, rnd=None):
         """Critic loss graph :194-305.  `rnd` (parity mode) injects every random draw; see
@@ -267,6 +289,24 @@ class Trainer:
             alpha = rnd['alpha'] if rnd is not None else rng.uniform(B, 1)
             interp = K.interpolate(real, fake, alpha)
             rf = _cat_rows(real, fake)
+
+        # gradient penalty :277-286, issued FIRST and on a side stream: it is independent of the two dropout
+        # passes until the losses are summed, so the GPU overlaps its small launches (n=64 rows) with the main
+        # branch (hipGraph capture turns the two streams into parallel graph branches).  The critic is piecewise
+        # linear (no normalisation in D), so the penalty reaches the weights only through the backward ops:
+        # skip the forward's own wgrads.
+        interp.requires_grad_(True)
+        side = self._gp_stream()
+        if side is not None:
+            F.prepare_dgrad_filters(self.d_params)
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side) if side is not None else _nullctx():
+            with F.weight_grads(not _critic_piecewise_linear()):
+                u_gp = rnd['u_gp'] if rnd is not None else None
+                d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng)[0]
+            ones = torch.ones_like(d_gp)
+            (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
+            gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
 
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
         h = DiscriminatorTrunk(rf)
@@ -291,16 +331,10 @@ class Trainer:
             out['acc_real'], out['acc_fake'] = hit_r / B, hit_f / B
         else:
             acgan = None
-
-        # gradient penalty :277-286 - the critic is piecewise linear (no normalisation in D), so the
-        # penalty reaches the weights only through the backward ops: skip the forward's own wgrads
-        interp.requires_grad_(True)
-        with F.weight_grads(not _critic_piecewise_linear()):
-            u_gp = rnd['u_gp'] if rnd is not None else None
-            d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng)[0]
-        ones = torch.ones_like(d_gp)
-        (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
-        gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            for t in (gp, slopes, grads):
+                t.record_stream(torch.cuda.current_stream())
 
         disc_wgan = wgan + ct + gp
         cost = disc_wgan + cfg.ACGAN_SCALE * acgan if acgan is not None else disc_wgan

@@ -67,8 +67,9 @@ def _need_dev(*ts):
 
 
 def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer (stream-ordered reuse)."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer per (device, stream): reuse is ordered by the stream it belongs to, so
+    branches of a step that run on different streams never share split-K slabs."""
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == 'cuda' else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
