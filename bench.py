@@ -102,6 +102,9 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         roofline = measure_roofline(trainer, next_batch, K, torch)
+    gp_unit = None
+    if not args.no_roofline and rank == 0:
+        gp_unit = measure_gp_unit(trainer, batches[0], torch)
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(lib, torch)
@@ -117,7 +120,7 @@ def main():
                        'images_per_step': R.cfg.N_CRITIC * B * world, 'parallelism': 'dp%d' % world,
                        'hipgraph': bool(eng.graphed), 'last_d_cost': last_cost},
             'step_mfma_frac': round(ITER_GFLOP * 1e9 / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'gp_unit': gp_unit, 'cpu_baseline': cpu,
         }
         print(json.dumps(rec))
     if world > 1:
@@ -174,6 +177,48 @@ def measure_roofline(trainer, next_batch, K, torch):
         'by_kernel': {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3)}
                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
     }
+
+
+def measure_gp_unit(trainer, batch, torch):
+    """The north star's primary unit: critic forward + gradient-penalty backward at B=64
+    = forward (F_D) + data gradient to x_hat (F_D) + double backward (conv(ggx,W) and wgrad(ggx,gy): 2 F_D)
+    = 4*B*F_D = 139.30 GFLOP; target <= 1.48 ms (60 % of the fp32 MFMA peak)."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    B = R.cfg.BATCH_SIZE
+    real_int, labels = batch
+    x = torch.randn(B, R.cfg.OUTPUT_DIM, device=real_int.device).mul_(0.5)
+
+    def unit():
+        trainer.rng.begin_step()
+        xi = x.detach().requires_grad_(True)
+        with F.weight_grads(False):
+            d = R.Discriminator(xi, labels, 0.8, 0.5, 0.5, rng=trainer.rng)[0]
+        (g,) = torch.autograd.grad(d, xi, grad_outputs=torch.ones_like(d), create_graph=True)
+        gp, _ = F.gradient_penalty(g, R.cfg.GP_LAMBDA)
+        return torch.autograd.grad(gp, trainer.d_params, allow_unused=True)
+
+    try:
+        for _ in range(2):
+            unit()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            unit()
+        reps = 20
+        graph.replay(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            graph.replay()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+    except Exception as e:          # report, never fail the bench over the sub-benchmark
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    gflop = 4 * B * 544.148e-3
+    return {'what': 'critic forward + GP backward (dD/dx_hat, then d(GP)/d(theta)), B=64, hipGraph replay',
+            'ms': round(ms, 4), 'gflop': round(gflop, 2), 'achieved': round(gflop / ms, 2), 'unit': 'TFLOP/s',
+            'frac': round(gflop / ms / PEAK_F32_MFMA_TFLOPS, 4), 'target_frac': 0.60}
 
 
 def host_cores():

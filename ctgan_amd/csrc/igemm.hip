@@ -337,10 +337,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
 //   * WAVES_K > 1 splits each slice between wave groups (for small M: more waves than output
 //     tiles), partial accumulators are combined through LDS at the end;
 //   * XCD-aware tile order: consecutive M tiles (which share halo rows) land on the same XCD / L2.
-template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN, int RD, bool RELU_IN>
+template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN, int RD, bool RELU_IN, int KSUB>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pipe_kernel(const FwdParams p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
-    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, BKE = 32 * WAVES_K, LDAE = BKE + 4;
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, BKE = 32 * WAVES_K * KSUB, LDAE = BKE + 4;   // KSUB 32-deep slices per wave per stage
     constexpr int STAGE = BM * LDAE + BKE * BN;
     constexpr int AC = BKE / 4, BC = BN / 4;
     constexpr int A_PER = (BM * AC) / NT, B_PER = (BKE * BC) / NT;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
     const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
     int bid = blockIdx.x;
     const int nb = gridDim.x;
-    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);         // block b runs on XCD b%8 (observed)
+    if ((nb & 7) == 0 && !(p.dbg & 16)) bid = (bid & 7) * (nb >> 3) + (bid >> 3);         // block b runs on XCD b%8 (observed)
     const int tiles_n = (p.Ng + BN - 1) / BN;
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -456,8 +456,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
     __syncthreads();
 
     const int h = lane >> 5, l31 = lane & 31;
-    const int a_rd = (wm * TM * 32 + l31) * LDAE + wk * 32 + h * 16;     // + i*32*LDAE + v*4
-    const int b_rd = (wk * 32 + h * 16) * BN + wn * TN * 32 + l31;        // + s*BN + j*32
+    const int a_rd0 = (wm * TM * 32 + l31) * LDAE + wk * KSUB * 32 + h * 16;   // + sub*32 + i*32*LDAE + v*4
+    const int b_rd0 = (wk * KSUB * 32 + h * 16) * BN + wn * TN * 32 + l31;     // + sub*32*BN + s*BN + j*32
 
     for (int kt0 = 0; kt0 < nk; kt0 += RD) {
 #pragma unroll
@@ -469,6 +469,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
             const float* Bs = As + BM * LDAE;
             float* Asn = smem + ((kt + 1) & 1) * STAGE;
             float* Bsn = Asn + BM * LDAE;
+#pragma unroll
+            for (int sub = 0; sub < KSUB; ++sub) {
+            const int a_rd = a_rd0 + sub * 32, b_rd = b_rd0 + sub * 32 * BN;
             float4 a[TM][4];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -485,6 +488,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
 #pragma unroll
                     for (int j = 0; j < TN; ++j) b[(s + PD) % (PD + 1)][j] = Bs[b_rd + (s + PD) * BN + j * 32];
                 }
+                // keep the prefetch ABOVE this step's MFMAs: hipcc otherwise sinks the ds_read to just before its
+                // use and every group of MFMAs then starts with an exposed LDS round trip
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const float4 av = a[i][s >> 2];
@@ -494,8 +500,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
                 }
                 // slot (u+1)%RD holds slice kt+1 (loaded RD iterations ago): stage it, then refill the slot
-                if (s == 0 && kt + 1 < nk && !(p.dbg & 1)) store_tile(ra[(u + 1) % RD], rb[(u + 1) % RD], Asn, Bsn);
-                if (s == 1 && kt + 1 + RD < nk && !(p.dbg & 2)) load_tile(ra[(u + 1) % RD], rb[(u + 1) % RD]);
+                if (sub == 0 && s == 0 && kt + 1 < nk && !(p.dbg & 1)) store_tile(ra[(u + 1) % RD], rb[(u + 1) % RD], Asn, Bsn);
+                if (sub == 0 && s == 1 && kt + 1 + RD < nk && !(p.dbg & 2)) load_tile(ra[(u + 1) % RD], rb[(u + 1) % RD]);
+                // waves that are in their MFMA stretch win arbitration over a co-resident wave that is staging
+                if (sub == 0 && s == 1) __builtin_amdgcn_s_setprio(1);
+                if (sub == KSUB - 1 && s == 15) __builtin_amdgcn_s_setprio(0);
+            }
             }
             if (!(p.dbg & 4)) __syncthreads();
         }
@@ -859,6 +869,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[(s + PD) % (PD + 1)][j] = Bs[b_rd + (s + PD) * BN + j * 32];
             }
+            __builtin_amdgcn_sched_barrier(0);     // prefetch stays above this step's MFMAs (see igemm_fwd_pipe_kernel)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -973,27 +984,27 @@ int dispatch_fwd_tile(const FwdParams& p, hipStream_t st) {
     return launch_fwd<AVEC, BVEC, 4, 1, 1, 1>(p, st);                             // 128x32
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int RD, bool RELU_IN>
+template <int WM, int WN, int WK, int TM, int TN, int RD, bool RELU_IN, int KSUB>
 int launch_fwd_pipe_impl(const FwdParams& p, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BKE = 32 * WK;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BKE = 32 * WK * KSUB;
     constexpr size_t smem_bytes = 2 * (size_t)(BM * (BKE + 4) + BKE * BN) * sizeof(float);
     static bool attr_set = false;     // one-time opt-in to > 64 KB of dynamic LDS (idempotent; benign race)
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN, KSUB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
         if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
-    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d%s>", BM, BN, WK, RELU_IN ? ",relu" : "");
-    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d%s%s>", BM, BN, WK, KSUB > 1 ? ",bk64" : "", RELU_IN ? ",relu" : "");
+    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN, KSUB>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
     return ctgan_check_launch("igemm_fwd_pipe");
 }
 
-template <int WM, int WN, int WK, int TM, int TN, int RD>
+template <int WM, int WN, int WK, int TM, int TN, int RD, int KSUB = 1>
 int launch_fwd_pipe(const FwdParams& p, hipStream_t st) {
-    return p.relu_in ? launch_fwd_pipe_impl<WM, WN, WK, TM, TN, RD, true>(p, st)
-                     : launch_fwd_pipe_impl<WM, WN, WK, TM, TN, RD, false>(p, st);
+    return p.relu_in ? launch_fwd_pipe_impl<WM, WN, WK, TM, TN, RD, true, KSUB>(p, st)
+                     : launch_fwd_pipe_impl<WM, WN, WK, TM, TN, RD, false, KSUB>(p, st);
 }
 
 int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
@@ -1011,12 +1022,14 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
         else if (rows > 4096) cfg = 4;
         else cfg = 5;
     }
-    if ((cfg == 4 && p.g.C % 64 != 0) || (cfg == 5 && p.g.C % 128 != 0)) cfg = 3;
+    if (((cfg == 4 || cfg == 6 || cfg == 7) && p.g.C % 64 != 0) || (cfg == 5 && p.g.C % 128 != 0)) cfg = cfg >= 6 ? 1 : 3;
     switch (cfg) {
         case 1: return launch_fwd_pipe<2, 2, 1, 2, 2, 1>(p, st);   // 128x128, 2 blocks/CU
         case 2: return launch_fwd_pipe<1, 4, 1, 2, 1, 1>(p, st);   // 64x128
         case 3: return launch_fwd_pipe<1, 4, 1, 1, 1, 1>(p, st);   // 32x128
         case 4: return launch_fwd_pipe<1, 2, 2, 1, 1, 1>(p, st);   // 32x64, K split over 2 wave groups
+        case 6: return launch_fwd_pipe<2, 2, 1, 2, 2, 1, 2>(p, st);  // 128x128, 64-deep stages (1 block/CU)
+        case 7: return launch_fwd_pipe<1, 4, 1, 2, 1, 1, 2>(p, st);  // 64x128, 64-deep stages
         default: return launch_fwd_pipe<1, 1, 4, 1, 1, 1>(p, st);  // 32x32, K split over 4 wave groups
     }
 }
