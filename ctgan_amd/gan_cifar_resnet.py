@@ -412,5 +412,46 @@ class Trainer:
         return s, ((s + 1.) * (255. / 2)).to(torch.int32)
 
 
+def train(data_dir, n_examples=50000, iters=None, out_dir='.', seed=2024, use_graphs=True, sample_every=100,
+          checkpoint_every=1000, resume=None, log=print):
+    """The module-level training loop of the reference (TF/CT_gan_cifar_resnet.py:350-434) minus the Inception
+    score (needs the 2015 Inception graph + network): CIFAR-10 generator factories, `time` /
+    `cost` / `wgan` / `acgan` / `acc_real` / `acc_fake` series through tflib.plot, fixed-noise sample grids every
+    `sample_every` iterations (:341-348, :429), checkpoints every `checkpoint_every` (build-only)."""
+    import os
+    import time
+
+    from . import checkpoint
+    from .engine import GraphedTrainer
+    from .tflib import cifar10, plot, save_images
+    iters = cfg.ITERS if iters is None else iters
+    build_params()
+    trainer = Trainer(seed=seed)
+    start = checkpoint.load(resume, trainer) if resume else 0
+    eng = GraphedTrainer(trainer, use_graphs=use_graphs)
+    train_gen, dev_gen = cifar10.load(cfg.BATCH_SIZE, data_dir, n_examples)
+    feed = cifar10.prefetch_to_device(cifar10.inf_train_gen(train_gen), trainer.dev)
+    fixed_noise = trainer.rng.normal(100, 128)
+    fixed_labels = torch.arange(10, dtype=torch.int32, device=trainer.dev).repeat(10)
+    plot.log_path = os.path.join(out_dir, 'log.jsonl')
+    for iteration in range(start, iters):
+        t0 = time.time()
+        out = eng.train_iteration(iteration, lambda: next(feed))
+        plot.plot('cost', out['cost'].item())
+        if out.get('acgan') is not None:
+            for k in ('wgan', 'acgan', 'acc_real', 'acc_fake'):
+                plot.plot(k, out[k].item())
+        plot.plot('time', time.time() - t0)
+        if iteration % sample_every == sample_every - 1:
+            _, px = trainer.generate_samples(fixed_noise, fixed_labels)
+            save_images.save_images(px.reshape(100, 3, 32, 32).cpu().numpy(), os.path.join(out_dir, 'samples_%d.png' % iteration))
+        if checkpoint_every and iteration % checkpoint_every == checkpoint_every - 1:
+            checkpoint.save(os.path.join(out_dir, 'checkpoint.pt'), trainer, iteration + 1)
+        if iteration < 500 or iteration % 1000 == 999:
+            plot.flush()
+        plot.tick()
+    return trainer
+
+
 def _critic_piecewise_linear():
     return not cfg.NORMALIZATION_D
