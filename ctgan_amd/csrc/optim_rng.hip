@@ -23,6 +23,19 @@ __global__ void adam_advance_kernel(float* state, float b1, float b2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] *= b1; state[2] *= b2; }
 }
 
+// Gather separately allocated gradient tensors into the flat bucket in ONE launch.  The pointer table travels
+// by value in the kernel arguments (no device table, no host->device copy => hipGraph-capture safe: the
+// arguments are baked into the graph node and the graph's allocations are static).  grid.y = tensor index.
+constexpr int PACK_MAX = 64;
+struct PackTable { const float* src[PACK_MAX]; long long dst_off[PACK_MAX]; long long n[PACK_MAX]; };
+__global__ void pack_kernel(const PackTable t, float* __restrict__ flat) {
+    const float* src = t.src[blockIdx.y];
+    const long long off = t.dst_off[blockIdx.y], n = t.n[blockIdx.y];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        flat[off + i] = src ? src[i] : 0.f;
+}
+
 // ---- Philox4x32-10 (Salmon et al., SC'11); constants of the Random123 reference
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
@@ -117,6 +130,23 @@ int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n,
     hipLaunchKernelGGL(adam_kernel, dim3(ctgan_blocks(n, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), theta, g, m,
                        v, (long long)n, state, beta1, beta2, eps, grad_scale);
     return ctgan_check_launch("adam_step");
+}
+int ctgan_pack(const float* const* srcs, const int64_t* dst_offs, const int64_t* counts, int32_t n_tensors, float* flat,
+               ctgan_stream_t s) {
+    if (!srcs || !dst_offs || !counts || !flat || n_tensors <= 0) return ctgan_fail(CTGAN_E_BADARG, "pack: bad argument");
+    for (int base = 0; base < n_tensors; base += PACK_MAX) {
+        PackTable t;
+        const int cnt = n_tensors - base < PACK_MAX ? n_tensors - base : PACK_MAX;
+        long long mx = 1;
+        for (int i = 0; i < cnt; ++i) {
+            t.src[i] = srcs[base + i]; t.dst_off[i] = dst_offs[base + i]; t.n[i] = counts[base + i];
+            if (t.n[i] > mx) mx = t.n[i];
+        }
+        hipLaunchKernelGGL(pack_kernel, dim3(ctgan_blocks(mx, 256, 64), cnt), dim3(256), 0, static_cast<hipStream_t>(s), t, flat);
+        int rc = ctgan_check_launch("pack");
+        if (rc) return rc;
+    }
+    return CTGAN_OK;
 }
 int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t s) {
     if (!state) return ctgan_fail(CTGAN_E_BADARG, "adam_advance: null");

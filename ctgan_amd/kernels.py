@@ -568,6 +568,16 @@ def adam_step(theta, g, m, v, state, beta1, beta2, eps=1e-8, grad_scale=1.0):
                               grad_scale, _stream()), 'adam_step')
 
 
+def pack(srcs, dst_offs, counts, flat):
+    """flat[off_i : off_i+n_i] = srcs[i] (None = zeros) for all i in one launch (per 64 tensors)."""
+    _need_dev(flat, *[t for t in srcs if t is not None])
+    n = len(srcs)
+    P = (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in srcs])
+    O = (ctypes.c_int64 * n)(*dst_offs)
+    C = (ctypes.c_int64 * n)(*counts)
+    check(lib.ctgan_pack(P, O, C, n, _ptr(flat), _stream()), 'pack')
+
+
 def adam_advance(state, beta1, beta2):
     _need_dev(state)
     check(lib.ctgan_adam_advance(_ptr(state), beta1, beta2, _stream()), 'adam_advance')

@@ -36,6 +36,8 @@ class FlatAdam:
         self.state = torch.tensor([0.0, self.beta1, self.beta2, 0.0], dtype=torch.float32, device=dev)
         self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == 'cuda' else torch.zeros(1)
         self.t = 0
+        self._keepalive = []
+        self.offsets = [sum(self.sizes[:i]) for i in range(len(self.sizes))]
 
     def set_lr(self, lr):
         """Host -> device copy of the scalar learning rate (outside any captured graph)."""
@@ -43,14 +45,20 @@ class FlatAdam:
         self.state[0:1].copy_(self._lr_host, non_blocking=True)
 
     def gather_grads(self, grads):
-        """Pack per-parameter gradients (None = zero) into the flat bucket."""
-        off = 0
-        for g, n in zip(grads, self.sizes):
-            if g is None:
-                self.grad[off:off + n].zero_()
-            else:
-                self.grad[off:off + n].copy_(g.reshape(-1))
-            off += n
+        """Pack per-parameter gradients (None = zero) into the flat bucket with ONE kernel (the pointer table rides
+        in the kernel arguments: no per-variable copy, hipGraph-capture safe)."""
+        if self.grad.device.type != 'cuda':
+            off = 0
+            for g, n in zip(grads, self.sizes):
+                if g is None:
+                    self.grad[off:off + n].zero_()
+                else:
+                    self.grad[off:off + n].copy_(g.reshape(-1))
+                off += n
+            return self.grad
+        srcs = [g.contiguous() if g is not None else None for g in grads]
+        K.pack(srcs, self.offsets, self.sizes, self.grad)
+        self._keepalive = srcs          # sources stay allocated until the next gather
         return self.grad
 
     def step(self, grad_scale=1.0):

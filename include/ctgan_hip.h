@@ -193,6 +193,12 @@ int ctgan_mean_diff_bwd(const float* gout, int32_t na, int32_t nb, float sa, flo
 int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, const float* state,
                     float beta1, float beta2, float eps, float grad_scale, ctgan_stream_t stream);
 int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t stream);
+/* flat[dst_offs[i] : dst_offs[i] + counts[i]] = srcs[i][0:counts[i]] (srcs[i] == NULL: zeros), i < n_tensors, in one
+ * launch per 64 tensors.  The three arrays are HOST arrays (the pointers are device pointers); they are passed to
+ * the kernel by value, so the call is hipGraph-capture safe.  This is the gradient bucket of compute_gradients
+ * (TF/CT_gan_cifar_resnet.py:335-336) without one copy per variable.                                   */
+int ctgan_pack(const float* const* srcs, const int64_t* dst_offs, const int64_t* counts, int32_t n_tensors,
+               float* flat, ctgan_stream_t stream);
 
 /* ---- RNG: Philox4x32-10 counter-based streams (tf.random_uniform / tf.random_normal /
  *      dropout masks :157,202,277,319).  counter base is read from device memory
