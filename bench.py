@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--gp-unit-only', action='store_true', help='run only the critic-forward + GP-backward sub-benchmark')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets the\n'
                     'multi-rank code path be exercised on a single-GPU box (all ranks share cuda:0)')
     args = ap.parse_args()
@@ -77,6 +78,9 @@ def main():
         cursor[0] = (cursor[0] + 1) % len(batches)
         return batches[cursor[0]]
 
+    if args.gp_unit_only:
+        print(json.dumps(measure_gp_unit(trainer, batches[0], torch)))
+        return
     eng = GraphedTrainer(trainer, use_graphs=not args.no_graph)
     if eng.graph_error and rank == 0:
         print('hipGraph capture failed, running eager: ' + eng.graph_error, file=sys.stderr)

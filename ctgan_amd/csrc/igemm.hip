@@ -1068,8 +1068,10 @@ WPlan wgrad_plan(int C, int Mtot, int Ng, int Kg) {
     if (C % 32 == 0) {           // vector-capable: the M tile must lie inside one filter tap
         if (Ng > 64) {
             // few pixels => prefer smaller tiles: more output tiles, fewer split-K slabs to reduce
-            if (C % 128 == 0 && Kg >= 49152) w.tile = W128x128;
-            else if (C % 64 == 0 && Kg >= 16384) w.tile = W64x128;
+            // measured (tools_wgrad_sweep.py): ~2 workgroups per CU with the largest tile that still leaves
+            // >= ~16 K slices per split
+            if (C % 128 == 0 && Kg >= 32768) w.tile = W128x128;
+            else if (C % 64 == 0 && Kg >= 8192) w.tile = W64x128;
             else if (C % 64 == 0) w.tile = W64x64;
             else w.tile = W32x128;
         } else if (Ng > 32) w.tile = (C % 64 == 0) ? W64x64 : W32x128;
@@ -1079,6 +1081,8 @@ WPlan wgrad_plan(int C, int Mtot, int Ng, int Kg) {
         else if (Ng > 32) w.tile = Mtot > 32 ? W64x64 : W32x128;
         else w.tile = Mtot > 32 ? W128x32 : W32x128;
     }
+    static const int force_tile = [] { const char* e = getenv("CTGAN_WGRAD_TILE"); return e ? atoi(e) : -1; }();
+    if (force_tile >= 0 && C % 128 == 0 && Ng > 64) w.tile = (WTile)force_tile;     // tuning sweeps only
     static const int dims[5][2] = {{128, 128}, {64, 128}, {32, 128}, {64, 64}, {128, 32}};
     w.bm = dims[w.tile][0]; w.bn = dims[w.tile][1];
     w.tiles = ((Mtot + w.bm - 1) / w.bm) * ((Ng + w.bn - 1) / w.bn);
@@ -1206,7 +1210,8 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
     int best = 1;
     // one or two output tiles (few-channel / skinny weight gradients) are bound by the latency of streaming
     // the pixel axis, not by MFMA: give every CU ~4 workgroups
-    for (int k = (tiles <= 2 ? 4 : 1); k <= 4; ++k) {
+    static const int force_k = [] { const char* e = getenv("CTGAN_WGRAD_K"); return e ? atoi(e) : 0; }();
+    for (int k = (force_k ? force_k : (tiles <= 2 ? 4 : 2)); k <= 4; ++k) {
         int s = (256 * k) / tiles;
         if (s < 1) s = 1;
         if (s > max_splits) s = max_splits;
