@@ -149,33 +149,48 @@ __global__ __launch_bounds__(CB * RL) void bn_bwd_sample_kernel(const double* __
     }
 }
 
-// one thread per channel walks the samples in order (deterministic): fills the label bins of
-// gscale/goffset (each thread owns its column) and s12[g][2][c] = {sum dxhat, sum dxhat*xhat}/count
-__global__ void bn_bwd_final_kernel(const double* __restrict__ tot, const float* __restrict__ scale,
-                                    const int32_t* __restrict__ labels, BnShape s, int n_labels,
-                                    float* __restrict__ gscale, float* __restrict__ goffset, float* __restrict__ s12,
-                                    double* __restrict__ bins /*[n_labels][2][c]*/) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= s.c) return;
+// Finalisation of the BN backward reductions.  grid = (c/64, n_labels + groups), 64 channels x 16 sample lanes:
+//   blockIdx.y <  n_labels : label bin l:  goffset[l][c] = sum_{labels[s]==l} a_s, gscale[l][c] = sum b_s
+//   blockIdx.y >= n_labels : group g:      s12[g][{0,1}][c] = sum_s {a_s, b_s} * scale[labels[s]][c] / count
+// lanes are combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(64 * 16) void bn_bwd_final_kernel(const double* __restrict__ tot, const float* __restrict__ scale,
+                                                             const int32_t* __restrict__ labels, BnShape s, int n_labels,
+                                                             float* __restrict__ gscale, float* __restrict__ goffset,
+                                                             float* __restrict__ s12) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int job = blockIdx.y;
     const int per = s.n / s.groups;
-    for (int l = 0; l < n_labels; ++l) { bins[(long long)(l * 2) * s.c + c] = 0.; bins[(long long)(l * 2 + 1) * s.c + c] = 0.; }
-    const double cnt = (double)per * s.hw;
-    for (int g = 0; g < s.groups; ++g) {
-        double s1 = 0., s2 = 0.;
-        for (int sample = g * per; sample < (g + 1) * per; ++sample) {
-            const int lab = labels ? labels[sample] : 0;
-            const double ga = scale[lab * s.c + c];
-            const double a = tot[(long long)sample * 2 * s.c + c], b = tot[(long long)sample * 2 * s.c + s.c + c];
-            s1 += a * ga; s2 += b * ga;
-            bins[(long long)(lab * 2) * s.c + c] += a;
-            bins[(long long)(lab * 2 + 1) * s.c + c] += b;
+    double a = 0., b = 0.;
+    if (c < s.c) {
+        if (job < n_labels) {
+            for (int sample = sl; sample < s.n; sample += 16) {
+                const int lab = labels ? labels[sample] : 0;
+                if (lab != job) continue;
+                a += tot[(long long)sample * 2 * s.c + c]; b += tot[(long long)sample * 2 * s.c + s.c + c];
+            }
+        } else {
+            const int g = job - n_labels;
+            for (int sample = g * per + sl; sample < (g + 1) * per; sample += 16) {
+                const int lab = labels ? labels[sample] : 0;
+                const double ga = scale[lab * s.c + c];
+                a += tot[(long long)sample * 2 * s.c + c] * ga; b += tot[(long long)sample * 2 * s.c + s.c + c] * ga;
+            }
         }
-        s12[(g * 2 + 0) * s.c + c] = (float)(s1 / cnt);
-        s12[(g * 2 + 1) * s.c + c] = (float)(s2 / cnt);
     }
-    for (int l = 0; l < n_labels; ++l) {
-        goffset[l * s.c + c] = (float)bins[(long long)(l * 2) * s.c + c];
-        gscale[l * s.c + c] = (float)bins[(long long)(l * 2 + 1) * s.c + c];
+    red[0][sl][cl] = a; red[1][sl][cl] = b;
+    __syncthreads();
+    if (sl != 0 || c >= s.c) return;
+    a = 0.; b = 0.;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a += red[0][r][cl]; b += red[1][r][cl]; }
+    if (job < n_labels) {
+        goffset[job * s.c + c] = (float)a; gscale[job * s.c + c] = (float)b;
+    } else {
+        const int g = job - n_labels;
+        const double cnt = (double)per * s.hw;
+        s12[(g * 2 + 0) * s.c + c] = (float)(a / cnt); s12[(g * 2 + 1) * s.c + c] = (float)(b / cnt);
     }
 }
 
@@ -275,8 +290,9 @@ int ctgan_bn_bwd(const float* gy, const float* x, const float* mean, const float
     hipLaunchKernelGGL(bn_bwd_sample_kernel, dim3(n, (c + CB - 1) / CB), dim3(CB * RL), 0, st, part, s, tot);
     rc = ctgan_check_launch("bn_bwd_sample");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 63) / 64), dim3(64), 0, st, tot, scale, labels, s, n_labels, gscale,
-                       goffset, s12, bins);
+    (void)bins;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 63) / 64, n_labels + groups), dim3(64 * 16), 0, st, tot, scale, labels, s,
+                       n_labels, gscale, goffset, s12);
     rc = ctgan_check_launch("bn_bwd_final");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ctgan_blocks((long long)n * hw * c, 256)), dim3(256), 0, st, gy, x, mean,

@@ -114,15 +114,21 @@ __global__ void upsample2_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
-// x [n, hw, c] channels-last -> y[n,c] = scale * sum_hw ; one thread per (n,c), coalesced over c
-__global__ void spatial_sum_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int hw, int c, float scale) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)n * c) return;
-    const int nn = i / c, cc = i - (long long)nn * c;
-    const float* b = x + (long long)nn * hw * c + cc;
+// x [n, hw, c] channels-last -> y[n,c] = scale * sum_hw.  Workgroup = 64 channels x 4 position lanes of one
+// sample (coalesced 256-B rows, 4 independent accumulation chains), lanes combined through LDS in fixed order.
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int hw, int c,
+                                                         float scale) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int cc = blockIdx.y * 64 + cl, nn = blockIdx.x;
     float s = 0.f;
-    for (int k = 0; k < hw; ++k) s += b[(long long)k * c];
-    y[i] = scale * s;
+    if (cc < c) {
+        const float* b = x + (long long)nn * hw * c + cc;
+        for (int k = pl; k < hw; k += 4) s += b[(long long)k * c];
+    }
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && cc < c) y[(long long)nn * c + cc] = scale * ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
 __global__ void spatial_bcast_kernel(const float* __restrict__ g, float* __restrict__ y, int n, int hw, int c, float scale) {
@@ -257,9 +263,8 @@ int ctgan_upsample2(const float* x, const int64_t xs[4], float* y, const int64_t
 
 int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale, ctgan_stream_t s) {
     if (!x || !y || n <= 0 || hw <= 0 || c <= 0) return ctgan_fail(CTGAN_E_BADARG, "spatial_sum: bad argument");
-    const long long t = (long long)n * c;
-    hipLaunchKernelGGL(spatial_sum_kernel, dim3((unsigned)((t + TPB - 1) / TPB)), dim3(TPB), 0,
-                       static_cast<hipStream_t>(s), x, y, n, hw, c, scale);
+    hipLaunchKernelGGL(spatial_sum_kernel, dim3(n, (c + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(s), x, y, n, hw, c,
+                       scale);
     return ctgan_check_launch("spatial_sum");
 }
 int ctgan_spatial_bcast(const float* g, float* y, int32_t n, int32_t hw, int32_t c, float scale, ctgan_stream_t s) {

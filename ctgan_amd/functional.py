@@ -22,6 +22,18 @@ _WEIGHT_GRADS = True
 # ReLU backward of conv(relu(x)): False = stand-alone mask kernel on the data gradient (measured faster: the
 # dgrad epilogue is the un-overlapped tail of an MFMA kernel), True = mask read inside the dgrad epilogue
 MASK_IN_DGRAD_EPILOGUE = False
+# Launch the weight gradient of a conv on a side stream, concurrently with its data gradient (the two are
+# independent): the prologue / epilogue of one kernel overlaps the MFMA stretch of the other.  A/B switch.
+import os as _os
+WGRAD_SIDE_STREAM = _os.environ.get('CTGAN_WGRAD_STREAM', '0') != '0'
+_side = {}
+
+
+def _side_stream(dev):
+    st = _side.get(dev)
+    if st is None:
+        st = _side[dev] = torch.cuda.Stream(device=dev)
+    return st
 
 
 @contextlib.contextmanager
@@ -59,6 +71,26 @@ class ConvFn(Function):
         g = ctx.g
         gx = gw = gb = gr = None
         mask = x if ctx.relu_in else None               # ReLU backward rides the dgrad epilogue
+        need_w = ctx.needs_input_grad[1] and ctx.want_w
+        need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
+        # first-order backward only (under create_graph the wgrad must stay an autograd node)
+        fork = WGRAD_SIDE_STREAM and need_w and gy.is_cuda and ctx.needs_input_grad[0] and not torch.is_grad_enabled()
+        ctx_join = None
+        if fork:
+            side = _side_stream(gy.device)
+            side.wait_stream(torch.cuda.current_stream())      # gy is ready; the dgrad below is NOT waited for
+            with torch.cuda.stream(side):
+                if need_b:
+                    gw, gb = K.conv_wgrad(x, gy, g, with_bias=True, relu_x=ctx.relu_in)
+                else:
+                    gw = K.conv_wgrad(x, gy, g, relu_x=ctx.relu_in)
+            ctx_join = side
+        elif need_w and need_b:
+            gw, gb = ConvWgradBiasFn.apply(x, gy, g, ctx.relu_in)       # bias gradient rides the wgrad kernel
+        elif need_w:
+            gw = ConvWgradFn.apply(x, gy, g, ctx.relu_in)
+        elif need_b:
+            gb = ChannelSumFn.apply(gy)
         if ctx.needs_input_grad[0]:
             if g.x_up:
                 gfull = ConvDgradFn.apply(gy, w, None, _no_up(g), ctx.N, None, None)
@@ -71,16 +103,13 @@ class ConvFn(Function):
                     gx = LReluBwdFn.apply(ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, None), x, 0.0)
                 else:
                     gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask)
-        need_w = ctx.needs_input_grad[1] and ctx.want_w
-        need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
-        if need_w and need_b:
-            gw, gb = ConvWgradBiasFn.apply(x, gy, g, ctx.relu_in)       # bias gradient rides the wgrad kernel
-        elif need_w:
-            gw = ConvWgradFn.apply(x, gy, g, ctx.relu_in)
-        elif need_b:
-            gb = ChannelSumFn.apply(gy)
         if ctx.has_resid and ctx.needs_input_grad[3]:
             gr = gy
+        if fork:
+            torch.cuda.current_stream().wait_stream(ctx_join)
+            for t in (gw, gb):
+                if t is not None:
+                    t.record_stream(torch.cuda.current_stream())
         return gx, gw, gb, gr, None, None, None
 
 
