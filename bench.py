@@ -134,7 +134,9 @@ def main():
 
 def measure_roofline(trainer, next_batch, K, torch):
     """One instrumented EAGER iteration: every conv-family launch is bracketed by HIP events on its
-    launch stream.  The dominant kernel = the variant with the largest summed duration."""
+    launch stream (4 back-to-back repeats per bracket, time / 4: a single-launch bracket carries ~10 us of
+    event overhead and disagrees with rocprofv3's kernel durations).  The dominant kernel = the variant
+    with the largest summed duration."""
     import ctgan_amd.gan_cifar_resnet as R
     # rank 0 only: this pass must not enter a collective (the other ranks are not here)
     saved_world, trainer.world = trainer.world, 1
@@ -142,18 +144,20 @@ def measure_roofline(trainer, next_batch, K, torch):
         trainer.train_iteration(1, next_batch)         # eager warm-up (lazy allocations)
         torch.cuda.synchronize()
         K.PROFILE = []
+        K.PROFILE_REPS = 4          # each (idempotent) conv launch runs 4x inside its event bracket: amortises the event overhead
         try:
             trainer.train_iteration(1, next_batch)
             torch.cuda.synchronize()
             prof = K.PROFILE
         finally:
             K.PROFILE = None
+            K.PROFILE_REPS = 1
     finally:
         trainer.world = saved_world
     agg = {}
-    for name, flops, e0, e1 in prof:
+    for name, flops, e0, e1, reps in prof:
         a = agg.setdefault(name, [0, 0.0, 0.0])
-        a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3
+        a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
     if not agg:
         return None
     total_t = sum(a[2] for a in agg.values())

@@ -60,6 +60,8 @@ SIGNATURES = {
     'ctgan_copy4d': (c_int, [_p, POINTER(c_int64), _p, POINTER(c_int64), POINTER(c_int32), _p]),
     'ctgan_pool2': (c_int, [_p, POINTER(c_int64), _p, POINTER(c_int64), POINTER(c_int32), c_float, _p]),
     'ctgan_upsample2': (c_int, [_p, POINTER(c_int64), _p, POINTER(c_int64), POINTER(c_int32), c_float, _p]),
+    'ctgan_filter_spread': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
+    'ctgan_filter_fold': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
     'ctgan_spatial_sum': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
     'ctgan_spatial_bcast': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
     'ctgan_real_prep': (c_int, [_p, _p, _p, c_int64, c_float, _p]),

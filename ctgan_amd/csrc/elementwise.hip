@@ -194,6 +194,49 @@ Dims4 mk(const int32_t dims[4], const int64_t xs[4], const int64_t ys[4]) {
     return p;
 }
 
+// Filter of a conv fused with a 2x resampling (see ctgan_filter_spread in the header).
+//   spread: out[u,v,c,k] = scale * sum_{a,b in {0,1}} w[u-a, v-b, c, k]        (out is (R+1) x (S+1))
+//   flip  : the result is written as out[R-u, S-v, k, c] (rotated, I/O swapped: the transposed-conv filter)
+__global__ void filter_spread_kernel(const float* __restrict__ w, float* __restrict__ out, int R, int S, int C, int K,
+                                     float scale, int flip) {
+    const long long n = (long long)(R + 1) * (S + 1) * C * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K); long long r = i / K;
+        const int c = (int)(r % C); r /= C;
+        const int v = (int)(r % (S + 1)), u = (int)(r / (S + 1));
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int rr = u - a, ss = v - b;
+                if (rr >= 0 && rr < R && ss >= 0 && ss < S) acc += w[(((long long)rr * S + ss) * C + c) * K + k];
+            }
+        const long long o = flip ? ((((long long)(R - u) * (S + 1) + (S - v)) * K + k) * C + c) : i;
+        out[o] = scale * acc;
+    }
+}
+// fold (the adjoint): out[r,s,c,k] = scale * sum_{a,b} W4[r+a, s+b, c, k];  flip: W4[u,v,c,k] = w4[R-u, S-v, k, c]
+__global__ void filter_fold_kernel(const float* __restrict__ w4, float* __restrict__ out, int R, int S, int C, int K,
+                                   float scale, int flip) {
+    const long long n = (long long)R * S * C * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K); long long r = i / K;
+        const int c = (int)(r % C); r /= C;
+        const int ss = (int)(r % S), rr = (int)(r / S);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int u = rr + a, v = ss + b;
+                acc += flip ? w4[(((long long)(R - u) * (S + 1) + (S - v)) * K + k) * C + c]
+                            : w4[(((long long)u * (S + 1) + v) * C + c) * K + k];
+            }
+        out[i] = scale * acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -259,6 +302,23 @@ int ctgan_upsample2(const float* x, const int64_t xs[4], float* y, const int64_t
     hipLaunchKernelGGL(upsample2_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), x, y,
                        mk(ydims, xs, ys), scale, n);
     return ctgan_check_launch("upsample2");
+}
+
+int ctgan_filter_spread(const float* w, float* out, int32_t R, int32_t S, int32_t C, int32_t K, float scale, int32_t flip,
+                        ctgan_stream_t s) {
+    if (!w || !out || R <= 0 || S <= 0 || C <= 0 || K <= 0) return ctgan_fail(CTGAN_E_BADARG, "filter_spread: bad argument");
+    const long long n = (long long)(R + 1) * (S + 1) * C * K;
+    hipLaunchKernelGGL(filter_spread_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), w, out, R, S,
+                       C, K, scale, flip);
+    return ctgan_check_launch("filter_spread");
+}
+int ctgan_filter_fold(const float* w4, float* out, int32_t R, int32_t S, int32_t C, int32_t K, float scale, int32_t flip,
+                      ctgan_stream_t s) {
+    if (!w4 || !out || R <= 0 || S <= 0 || C <= 0 || K <= 0) return ctgan_fail(CTGAN_E_BADARG, "filter_fold: bad argument");
+    const long long n = (long long)R * S * C * K;
+    hipLaunchKernelGGL(filter_fold_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), w4, out, R, S, C,
+                       K, scale, flip);
+    return ctgan_check_launch("filter_fold");
 }
 
 int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale, ctgan_stream_t s) {

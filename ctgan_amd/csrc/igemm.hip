@@ -58,7 +58,29 @@ struct FwdParams {
     int d_lin;                                 // D offset = m*ds_q + col*ds_k (pixel-linear output)
     unsigned a_bytes, b_bytes;                 // byte extents of A and B (buffer-descriptor range checks)
     int dbg;                                   // perf-diagnosis bits (env CTGAN_DBG): 1 no LDS store, 2 no global load, 4 no barrier
+    // Output-phase decomposition of a stride-2 data gradient: dx pixels of parity (a,b) are a stride-1 conv of
+    // dy with the taps of that parity only (no multiplies by the dilation zeros).  phases = 4: the M tile
+    // index carries the phase; M / P / Q describe ONE phase grid; R,S = taps per phase (zero-padded to a common
+    // count when R or S is odd).
+    int phases, ph_tiles_m;
+    int ph_pad_t[2], ph_pad_l[2];              // top pad of row parity a / left pad of column parity b
+    long long ph_b_stride;                     // filter elements per phase
+    long long ph_d_h, ph_d_w;                  // D offset of phase (a,b) = a*ph_d_h + b*ph_d_w
 };
+
+struct PhaseSel { int pad_t, pad_l; long long b_off, d_off; };
+__device__ __forceinline__ PhaseSel select_phase(const FwdParams& p, int& tile_m) {
+    PhaseSel s{p.g.pad_t, p.g.pad_l, p.b_off, 0};
+    if (p.phases > 1) {
+        const int ph = tile_m / p.ph_tiles_m;
+        tile_m -= ph * p.ph_tiles_m;
+        const int a = ph >> 1, b = ph & 1;
+        s.pad_t = p.ph_pad_t[a]; s.pad_l = p.ph_pad_l[b];
+        s.b_off = p.b_off + ph * p.ph_b_stride;
+        s.d_off = a * p.ph_d_h + b * p.ph_d_w;
+    }
+    return s;
+}
 
 struct WgradParams {
     Geom g;
@@ -150,7 +172,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.Ng + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    int tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    const PhaseSel ph = select_phase(p, tile_m);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = (p.Kg + BK - 1) / BK;
     const int PQ = g.P * g.Q;
@@ -160,8 +184,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
         if (m < p.M) {
             const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
             row_off[i] = (long long)n * g.s_n;
-            row_ih0[i] = pp * g.stride - g.pad_t;
-            row_iw0[i] = qq * g.stride - g.pad_l;
+            row_ih0[i] = pp * g.stride - ph.pad_t;
+            row_iw0[i] = qq * g.stride - ph.pad_l;
         } else {
             row_off[i] = -1; row_ih0[i] = 0; row_iw0[i] = 0;
         }
@@ -173,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
                 const int tap = gk / g.C, c = gk - tap * g.C, r = tap / g.S, s = tap - r * g.S;
                 ka_r[buf][tid] = r; ka_s[buf][tid] = s;
                 ka_coff[buf][tid] = (long long)c * g.s_c;
-                kb_off[buf][tid] = p.b_off + r * p.bs_r + s * p.bs_s + c * p.bs_c;
+                kb_off[buf][tid] = ph.b_off + r * p.bs_r + s * p.bs_s + c * p.bs_c;
             } else {
                 ka_r[buf][tid] = 0; ka_s[buf][tid] = 0; ka_coff[buf][tid] = -1; kb_off[buf][tid] = -1;
             }
@@ -314,7 +338,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
                 const int m = m0 + row;
                 if (m >= p.M) continue;
                 const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
-                const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
+                const long long off = ph.d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
                 float v = acc[i][j][e] + bv;
                 if (p.mask && !(p.mask[off] > 0.f)) v = 0.f;
                 if (p.resid) v += p.resid[off];
@@ -357,7 +381,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
     const int nb = gridDim.x;
     if ((nb & 7) == 0 && !(p.dbg & 16)) bid = (bid & 7) * (nb >> 3) + (bid >> 3);         // block b runs on XCD b%8 (observed)
     const int tiles_n = (p.Ng + BN - 1) / BN;
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m = bid / tiles_n;
+    const int tile_n = bid - tile_m * tiles_n;
+    const PhaseSel ph = select_phase(p, tile_m);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = p.Kg / BKE;
     const int cpt = g.C / BKE;
@@ -381,8 +407,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
         a_valid[i] = m < p.M;
         const int mm = a_valid[i] ? m : 0;
         const int n = mm / PQ, rem = mm - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
-        a_ih0[i] = pp * g.stride - g.pad_t;
-        a_iw0[i] = qq * g.stride - g.pad_l;
+        a_ih0[i] = pp * g.stride - ph.pad_t;
+        a_iw0[i] = qq * g.stride - ph.pad_l;
         long long o = (long long)n * g.s_n + a_chunk * 4;
         if (affine) o += (long long)a_ih0[i] * g.s_h + (long long)a_iw0[i] * g.s_w;   // may be "negative": wraps consistently mod 2^32
         a_voff[i] = (unsigned)(o * 4);
@@ -419,7 +445,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
                 ra[i] = __builtin_bit_cast(float4, v);
             }
         }
-        const unsigned bsoff = (unsigned)((p.b_off + n0 + ld_r * p.bs_r + ld_s * p.bs_s + (long long)c0 * p.bs_c) * 4);
+        const unsigned bsoff = (unsigned)((ph.b_off + n0 + ld_r * p.bs_r + ld_s * p.bs_s + (long long)c0 * p.bs_c) * 4);
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_voff[i], bsoff, 0);
@@ -554,7 +580,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
                     off = (long long)m * p.ds_q + col * p.ds_k;
                 } else {
                     const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
-                    off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
+                    off = ph.d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col * p.ds_k;
                 }
                 float v = acc[i][j][e] + bv;
                 if (p.mask && !(p.mask[off] > 0.f)) v = 0.f;
@@ -956,6 +982,36 @@ __global__ void repack_dgrad_filter_kernel(const float* __restrict__ w, float* _
     wt[i] = w[(((long long)(R - 1 - r) * S + (S - 1 - s)) * C + c) * K + k];
 }
 
+// Phase-major filter of a stride-2 data gradient (see FwdParams::phases):
+//   wt[ph=(a,b)][t][v][k][c] = w[u][x][c][k],  u = u0(a) + 2*(Tr-1-t),  x = x0(b) + 2*(Ts-1-v)   (0 where u >= R or x >= S)
+// u0(a) = (a + pad_t) & 1: the filter rows that reach dx rows of parity a.
+__global__ void repack_dgrad_phase_filter_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int S, int C, int K,
+                                                 int pad_t, int pad_l) {
+    const int Tr = (R + 1) / 2, Ts = (S + 1) / 2;
+    const long long per = (long long)Tr * Ts * K * C, n = 4 * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int ph = (int)(i / per);
+        long long r = i - ph * per;
+        const int c = (int)(r % C); r /= C;
+        const int k = (int)(r % K); r /= K;
+        const int v = (int)(r % Ts), t = (int)(r / Ts);
+        const int a = ph >> 1, b = ph & 1;
+        const int u = ((a + pad_t) & 1) + 2 * (Tr - 1 - t), x = ((b + pad_l) & 1) + 2 * (Ts - 1 - v);
+        wt[i] = (u < R && x < S) ? w[(((long long)u * S + x) * C + c) * K + k] : 0.f;
+    }
+}
+
+// shape-only rule shared by the repack, the workspace query and the launcher
+inline bool dgrad_phase_mode(const ctgan_conv_desc* d) {
+    static const bool off = [] { const char* e = getenv("CTGAN_DGRAD_PHASES"); return e && atoi(e) == 0; }();
+    return !off && d->stride == 2 && !(d->H & 1) && !(d->W & 1) && (d->C % 4 == 0) && (d->K % 32 == 0) &&
+           d->P * 2 == d->H && d->Q * 2 == d->W;
+}
+inline size_t dgrad_filter_elems(const ctgan_conv_desc* d) {
+    if (dgrad_phase_mode(d)) return (size_t)4 * ((d->R + 1) / 2) * ((d->S + 1) / 2) * d->K * d->C;
+    return (size_t)d->R * d->S * d->C * d->K;
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 thread_local char g_last_kernel[128] = "";
@@ -964,10 +1020,12 @@ bool g_force_generic = false;   // tests: route vectorisable shapes through the 
 template <bool AVEC, bool BVEC, int WM, int WN, int TM, int TN>
 int launch_fwd(const FwdParams& p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
-    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd<%s,%s,%dx%d>", AVEC ? "avec" : "agen",
-             BVEC ? "bvec" : "bgen", BM, BN);
-    hipLaunchKernelGGL((igemm_fwd_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(tiles), dim3(64 * WM * WN), 0, st, p);
+    FwdParams q = p;
+    q.ph_tiles_m = (p.M + BM - 1) / BM;
+    const int tiles = q.ph_tiles_m * (p.phases > 1 ? p.phases : 1) * ((p.Ng + BN - 1) / BN);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd<%s,%s,%dx%d%s>", AVEC ? "avec" : "agen",
+             BVEC ? "bvec" : "bgen", BM, BN, p.phases > 1 ? ",ph4" : "");
+    hipLaunchKernelGGL((igemm_fwd_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(tiles), dim3(64 * WM * WN), 0, st, q);
     return ctgan_check_launch("igemm_fwd");
 }
 
@@ -995,9 +1053,12 @@ int launch_fwd_pipe_impl(const FwdParams& p, hipStream_t st) {
         if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.Ng + BN - 1) / BN);
-    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d%s%s>", BM, BN, WK, KSUB > 1 ? ",bk64" : "", RELU_IN ? ",relu" : "");
-    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN, KSUB>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, p);
+    FwdParams q = p;
+    q.ph_tiles_m = (p.M + BM - 1) / BM;
+    const int tiles = q.ph_tiles_m * (p.phases > 1 ? p.phases : 1) * ((p.Ng + BN - 1) / BN);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d%s%s%s>", BM, BN, WK, KSUB > 1 ? ",bk64" : "", RELU_IN ? ",relu" : "",
+             p.phases > 1 ? ",ph4" : "");
+    hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN, KSUB>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, q);
     return ctgan_check_launch("igemm_fwd_pipe");
 }
 
@@ -1015,7 +1076,7 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
     if (!cfg) {
         // measured on MI355X (tools_cfg_sweep.py, 128->128 3x3): the best tile shrinks with the number of
         // output rows so that >= ~1024 waves exist; the register ring depth RD bought nothing (kept at 1)
-        const long long rows = M * ((p.Ng + 127) / 128);
+        const long long rows = M * (p.phases > 1 ? p.phases : 1) * ((p.Ng + 127) / 128);
         if (rows >= 65536) cfg = 1;
         else if (rows > 24576) cfg = 2;
         else if (rows > 12288) cfg = 3;
@@ -1037,7 +1098,7 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
 int run_fwd(const FwdParams& p0, hipStream_t st) {
     FwdParams p = p0;
     const Geom& g = p.g;
-    p.d_lin = (p.ds_p == (long long)g.Q * p.ds_q) && (p.ds_n == (long long)g.P * g.Q * p.ds_q);
+    p.d_lin = (p.phases <= 1) && (p.ds_p == (long long)g.Q * p.ds_q) && (p.ds_n == (long long)g.P * g.Q * p.ds_q);
     { const char* e = getenv("CTGAN_DBG"); p.dbg = e ? atoi(e) : 0; }
     const bool avec = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
@@ -1046,7 +1107,7 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
     // byte extents for the buffer descriptors of the pipelined kernel (32-bit range => < 4 GiB)
     const long long nimg = g.P > 0 ? (p.M + (long long)g.P * g.Q - 1) / ((long long)g.P * g.Q) : 0;
     const long long a_elems = (nimg - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
-    const long long b_elems = (long long)g.R * g.S * g.C * p.Ng;
+    const long long b_elems = (long long)(p.phases > 1 ? p.phases : 1) * g.R * g.S * g.C * p.Ng;
     const bool small = a_elems > 0 && a_elems * 4 < (1LL << 32) && b_elems * 4 < (1LL << 32) && p.b_off >= 0 && p.bs_r >= 0 && p.bs_s >= 0;
     if (avec && bvec && small && p.Ng > 64 && !g_force_generic) {
         p.a_bytes = (unsigned)(a_elems * 4);
@@ -1234,7 +1295,7 @@ void ctgan_debug_force_generic(int on) { g_force_generic = on != 0; }
 
 size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
     if (!d) return 0;
-    if (op == CTGAN_CONV_DGRAD) return (size_t)d->R * d->S * d->C * d->K * sizeof(float);
+    if (op == CTGAN_CONV_DGRAD) return dgrad_filter_elems(d) * sizeof(float);
     if (op == CTGAN_CONV_WGRAD) {
         const int mt = d->R * d->S * d->C, Kg = d->N * d->P * d->Q;
         const WPlan w = wgrad_plan(d->C, mt, d->K, Kg);
@@ -1262,12 +1323,18 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0;
     p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
     p.mask = nullptr;
+    p.phases = 1;
     return run_fwd(p, static_cast<hipStream_t>(stream));
 }
 
 int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* wt, ctgan_stream_t stream) {
     if (!d || !w || !wt) return ctgan_fail(CTGAN_E_BADARG, "conv2d_repack_filter: null pointer");
-    const long long n = (long long)d->R * d->S * d->C * d->K;
+    const long long n = (long long)dgrad_filter_elems(d);
+    if (dgrad_phase_mode(d)) {
+        hipLaunchKernelGGL(repack_dgrad_phase_filter_kernel, dim3(ctgan_blocks(n, 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), w, wt, d->R, d->S, d->C, d->K, d->pad_t, d->pad_l);
+        return ctgan_check_launch("repack_dgrad_phase_filter");
+    }
     hipLaunchKernelGGL(repack_dgrad_filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), w, wt, d->R, d->S, d->C, d->K);
     return ctgan_check_launch("repack_dgrad_filter");
@@ -1288,18 +1355,49 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
     FwdParams p;
     Geom& g = p.g;
     g.H = d->P; g.W = d->Q;                 // physical source = dy
-    g.P = d->H; g.Q = d->W;                 // rows enumerate dx pixels
-    g.R = d->R; g.S = d->S; g.C = d->K;     // channels per tap = dy channels
-    g.stride = 1; g.pad_t = d->R - 1 - d->pad_t; g.pad_l = d->S - 1 - d->pad_l;
-    g.shift = d->stride == 2 ? 1 : 0; g.mask = d->stride == 2 ? 1 : 0;
+    g.C = d->K;                             // channels per tap = dy channels
     g.s_n = d->ys[0]; g.s_c = d->ys[1]; g.s_h = d->ys[2]; g.s_w = d->ys[3];
     p.A = dy; p.bias = bias; p.resid = resid; p.mask = mask; p.relu_in = 0; p.D = dx;
-    p.M = d->N * d->H * d->W; p.Ng = d->C; p.Kg = d->R * d->S * d->K;
+    p.Ng = d->C;
     p.ds_n = d->xs[0]; p.ds_k = d->xs[1]; p.ds_p = d->xs[2]; p.ds_q = d->xs[3];
     p.relu = 0;
-    const size_t need = (size_t)d->R * d->S * d->C * d->K * sizeof(float);
-    const bool repack = ws && ws_bytes >= need && (d->C % 4 == 0) && (d->K % 32 == 0);
-    if (flags & CTGAN_DGRAD_W_REPACKED) {       // `w` already is wT[r',s',k,c] (ctgan_conv2d_repack_filter)
+    p.phases = 1;
+    const size_t need = dgrad_filter_elems(d) * sizeof(float);
+    const bool pre = (flags & CTGAN_DGRAD_W_REPACKED) != 0;
+    const bool repack = !pre && ws && ws_bytes >= need && (d->C % 4 == 0) && (d->K % 32 == 0);
+    if (dgrad_phase_mode(d) && (pre || repack)) {
+        // stride 2: four stride-1 convs of dy, one per output parity, in one launch
+        const int Tr = (d->R + 1) / 2, Ts = (d->S + 1) / 2;
+        g.P = d->H / 2; g.Q = d->W / 2;     // rows enumerate the dx pixels of ONE phase
+        g.R = Tr; g.S = Ts;
+        g.stride = 1; g.pad_t = 0; g.pad_l = 0; g.shift = 0; g.mask = 0;
+        p.M = d->N * g.P * g.Q; p.Kg = Tr * Ts * d->K;
+        p.phases = 4;
+        for (int a = 0; a < 2; ++a) {
+            const int u0 = (a + d->pad_t) & 1, x0 = (a + d->pad_l) & 1;
+            p.ph_pad_t[a] = Tr - 1 - (a + d->pad_t - u0) / 2;
+            p.ph_pad_l[a] = Ts - 1 - (a + d->pad_l - x0) / 2;
+        }
+        p.ph_b_stride = (long long)Tr * Ts * d->K * d->C;
+        p.ph_d_h = d->xs[2]; p.ph_d_w = d->xs[3];
+        p.ds_p = 2 * d->xs[2]; p.ds_q = 2 * d->xs[3];
+        if (repack) {
+            hipLaunchKernelGGL(repack_dgrad_phase_filter_kernel, dim3(ctgan_blocks((long long)dgrad_filter_elems(d), 256)), dim3(256), 0, st,
+                               w, static_cast<float*>(ws), d->R, d->S, d->C, d->K, d->pad_t, d->pad_l);
+            rc = ctgan_check_launch("repack_dgrad_phase_filter");
+            if (rc) return rc;
+        }
+        p.B = pre ? w : static_cast<const float*>(ws);
+        p.b_off = 0; p.bs_r = (long long)Ts * d->K * d->C; p.bs_s = (long long)d->K * d->C; p.bs_c = d->C; p.bs_k = 1;
+        return run_fwd(p, st);
+    }
+    if (pre && dgrad_phase_mode(d)) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: phase-mode filter expected");
+    g.P = d->H; g.Q = d->W;                 // rows enumerate dx pixels
+    g.R = d->R; g.S = d->S;
+    g.stride = 1; g.pad_t = d->R - 1 - d->pad_t; g.pad_l = d->S - 1 - d->pad_l;
+    g.shift = d->stride == 2 ? 1 : 0; g.mask = d->stride == 2 ? 1 : 0;
+    p.M = d->N * d->H * d->W; p.Kg = d->R * d->S * d->K;
+    if (pre) {                                  // `w` already is wT[r',s',k,c] (ctgan_conv2d_repack_filter)
         p.B = w;
         p.b_off = 0; p.bs_r = (long long)d->S * d->K * d->C; p.bs_s = (long long)d->K * d->C; p.bs_c = d->C; p.bs_k = 1;
     } else if (repack) {

@@ -155,9 +155,10 @@ def _repacked(w, g):
     double backward): rotate the filter once per weight update instead of once per launch.  A consumer on
     another stream waits for the producer's event."""
     from . import tflib as lib
-    if not (isinstance(w, torch.nn.Parameter) and K.dgrad_wants_repack(g)):
-        return None
     ep = lib.epoch()
+    stable = isinstance(w, torch.nn.Parameter) or _DERIVED_PTRS.get(w.data_ptr()) == ep
+    if not (stable and K.dgrad_wants_repack(g)):
+        return None
     key = (ep, w.data_ptr(), g.R, g.S, g.C, g.K)
     hit = _REPACK.get(key)
     if hit is None:
@@ -288,12 +289,21 @@ class Col2imFn(Function):
         return Im2colFn.apply(gx, ctx.g, ctx.cpad), None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False):
+def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False, pool=False):
     """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`.
-    relu_in=True computes conv(relu(x)) without materialising relu(x)."""
+    relu_in=True computes conv(relu(x)) without materialising relu(x); pool=True returns
+    mean_pool2(conv(x) + b) [+ resid]; x_up=True convolves upsample2(x)."""
     R, S, C, Kout = w.shape
     N, Cx, H, W = x.shape
     assert Cx == C, 'channel mismatch: x has %d, filter expects %d' % (Cx, C)
+    fusable = RESAMPLE_FUSION and stride == 1 and R % 2 == 1 and S % 2 == 1 and R > 1 and C % 32 == 0 and Kout % 32 == 0
+    if pool:
+        if fusable and not out_nchw and H % 2 == 0 and W % 2 == 0:
+            return conv2d_mean_pool(x, w, b, resid, relu_in)
+        out = mean_pool2(conv2d(x, w, b, stride, None, x_up, False, relu_in))
+        return out if resid is None else add(out, resid)
+    if x_up and fusable and resid is None and not relu_in and not out_nchw:
+        return upsample_conv2d(x, w, b)
     if C <= 4 and not x_up and Kout % 4 == 0:
         # few input channels: expand patches once, then the conv / wgrad / dgrad are 1x1 convs on the
         # pipelined MFMA kernels (csrc/skinny.hip)
@@ -334,6 +344,84 @@ def linear(x, w, b=None):
     x4 = x.reshape(n, cin, 1, 1)
     y = conv2d(x4, w.view(1, 1, cin, cout), b)
     return y.reshape(n, cout)
+
+
+# --------------------------------------------------------------------------------- resampled convs
+# pool2(conv3x3(x, w)) and conv3x3(upsample2(x), w) are single stride-2 (transposed) convs with the 4x4 filter
+# spread(w) = sum of the four one-tap shifts of w: 16 taps per low-resolution pixel instead of 4 x 9 (2.25x
+# fewer multiplies, no full-resolution intermediate, no pool / upsample kernel).  The identity is exact in
+# real arithmetic; in fp32 it changes the summation order like any other GEMM tiling does.
+_DERIVED = {}         # (epoch, data_ptr of the parameter, scale, flip) -> spread filter
+_DERIVED_PTRS = {}    # data_ptr of a cached spread filter -> epoch (lets the dgrad repack cache key on it)
+RESAMPLE_FUSION = _os.environ.get('CTGAN_RESAMPLE_FUSION', '1') != '0'
+
+
+class FilterSpreadFn(Function):
+    """[R,S,C,K] -> scale * spread (flip: rotated + I/O swapped); linear, adjoint = FilterFoldFn."""
+
+    @staticmethod
+    def forward(ctx, w, scale, flip):
+        ctx.scale, ctx.flip = scale, flip
+        if isinstance(w, torch.nn.Parameter):
+            from . import tflib as lib
+            ep = lib.epoch()
+            key = (ep, w.data_ptr(), scale, flip)
+            hit = _DERIVED.get(key)
+            if hit is None:
+                for k in [k for k in _DERIVED if k[0] != ep]:
+                    _DERIVED_PTRS.pop(_DERIVED[k][0].data_ptr(), None)
+                    del _DERIVED[k]
+                out = K.filter_spread(w, scale, flip)
+                ev, st = None, None
+                if out.is_cuda:
+                    st = torch.cuda.current_stream()
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                _DERIVED[key] = (out, ev, st)
+                _DERIVED_PTRS[out.data_ptr()] = ep
+                return out.detach()
+            out, ev, st = hit
+            if ev is not None and torch.cuda.current_stream() != st:
+                torch.cuda.current_stream().wait_event(ev)
+            return out.detach()
+        return K.filter_spread(w.contiguous(), scale, flip)
+
+    @staticmethod
+    def backward(ctx, g):
+        return FilterFoldFn.apply(g, ctx.scale, ctx.flip), None, None
+
+
+class FilterFoldFn(Function):
+    @staticmethod
+    def forward(ctx, w4, scale, flip):
+        ctx.scale, ctx.flip = scale, flip
+        return K.filter_fold(w4.contiguous(), scale, flip)
+
+    @staticmethod
+    def backward(ctx, g):
+        return FilterSpreadFn.apply(g, ctx.scale, ctx.flip), None, None
+
+
+def conv2d_mean_pool(x, w, b=None, resid=None, relu_in=False):
+    """mean_pool2(conv2d(x, w) + b) [+ resid] as ONE stride-2 conv (TF/CT_gan_cifar_resnet.py:89-92)."""
+    R, S, C, Kout = w.shape
+    N, Cx, H, W = x.shape
+    assert Cx == C and H % 2 == 0 and W % 2 == 0 and R % 2 == 1 and S % 2 == 1
+    w4 = FilterSpreadFn.apply(w, 0.25, False)
+    g = ConvGeom(C, H, W, Kout, R + 1, S + 1, 2, False)
+    assert (g.pad_t, g.pad_l) == ((R - 1) // 2, (S - 1) // 2)
+    return ConvFn.apply(x, w4, b, resid, g, None, relu_in)
+
+
+def upsample_conv2d(x, w, b=None):
+    """conv2d(upsample2(x), w) + b as ONE stride-2 transposed conv (TF/CT_gan_cifar_resnet.py:100-107)."""
+    R, S, C, Kout = w.shape
+    N, Cx, H, W = x.shape
+    assert Cx == C and R % 2 == 1 and S % 2 == 1
+    w4 = FilterSpreadFn.apply(w, 1.0, True)                       # [R+1,S+1,Kout,C]: HWIO filter of the adjoint conv
+    g = ConvGeom(Kout, 2 * H, 2 * W, C, R + 1, S + 1, 2, False)    # the strided conv whose data gradient this is
+    assert (g.P, g.Q) == (H, W) and (g.pad_t, g.pad_l) == ((R - 1) // 2, (S - 1) // 2)
+    return ConvDgradFn.apply(x, w4, b, g, N, None, None)
 
 
 # --------------------------------------------------------------------------------- mask ops

@@ -110,9 +110,9 @@ def ConvMeanPool(name, input_dim, output_dim, filter_size, inputs, he_init=True,
         assert not relu_in
         return _conv2d.Conv2D(name, input_dim, output_dim, 1, F.mean_pool2(inputs), he_init=he_init, biases=biases,
                               resid=resid)
-    out = _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases, relu_in=relu_in)
-    out = F.mean_pool2(out)
-    return out if resid is None else F.add(out, resid)
+    # conv + mean pool = one stride-2 conv with the spread (k+1)x(k+1) filter (functional.conv2d_mean_pool)
+    return _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases, relu_in=relu_in,
+                          pool=True, resid=resid)
 
 
 def MeanPoolConv(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None):
@@ -122,8 +122,9 @@ def MeanPoolConv(name, input_dim, output_dim, filter_size, inputs, he_init=True,
 
 
 def UpsampleConv(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None, relu_in=False):
-    """:100-107.  The nearest-2x upsample is folded into the conv's input gather (x_up); a 1x1
-    conv commutes with it and runs on the small side."""
+    """:100-107.  upsample + conv = one stride-2 transposed conv with the spread (k+1)x(k+1) filter
+    (functional.upsample_conv2d; falls back to the x_up input gather for unaligned channel counts); a 1x1
+    conv commutes with the upsample and runs on the small side."""
     if filter_size == 1:
         out = _conv2d.Conv2D(name, input_dim, output_dim, 1, inputs, he_init=he_init, biases=biases)
         out = F.upsample2(out)

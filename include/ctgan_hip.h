@@ -129,6 +129,17 @@ int ctgan_pool2(const float* x, const int64_t xs[4], float* y, const int64_t ys[
  * also the adjoint of pool2)                                                                   */
 int ctgan_upsample2(const float* x, const int64_t xs[4], float* y, const int64_t ys[4],
                     const int32_t ydims[4] /* n,c,h,w */, float scale, ctgan_stream_t stream);
+/* Filters of a conv fused with its 2x resampling (exact algebra, fewer multiplies):
+ *   ConvMeanPool (TF/CT_gan_cifar_resnet.py:89-92): pool2(conv_RxS(x, w))  = conv_{(R+1)x(S+1), stride 2}(x, spread(w)/4)
+ *   UpsampleConv (:100-107):   conv_RxS(upsample2(x), w) = conv2d_transpose_{(R+1)x(S+1), stride 2}(x, flipped spread(w))
+ * spread: out[u,v,c,k] = scale * sum_{a,b in {0,1}} w[u-a, v-b, c, k]   (w is [R,S,C,K], out [(R+1),(S+1),C,K]);
+ * flip != 0 writes the rotated, I/O-swapped filter out[R-u, S-v, k, c] instead ([(R+1),(S+1),K,C]).        */
+int ctgan_filter_spread(const float* w, float* out, int32_t R, int32_t S, int32_t C, int32_t K, float scale,
+                        int32_t flip, ctgan_stream_t stream);
+/* the adjoint map (weight gradient back to the RxS filter): out[r,s,c,k] = scale * sum_{a,b} W[r+a, s+b, c, k],
+ * W = w4 (flip == 0) or its un-flipped view W[u,v,c,k] = w4[R-u, S-v, k, c] (flip != 0)                      */
+int ctgan_filter_fold(const float* w4, float* out, int32_t R, int32_t S, int32_t C, int32_t K, float scale,
+                      int32_t flip, ctgan_stream_t stream);
 /* y[n,c] = scale * sum_{hw} x[n,hw,c]  (tf.reduce_mean(axis=[2,3]) :179) on channels-last x    */
 int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale,
                       ctgan_stream_t stream);

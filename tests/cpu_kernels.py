@@ -231,6 +231,28 @@ def upsample2(x, scale):
 
 
 @_export
+def filter_spread(w, scale, flip):
+    R, S, C, Ko = w.shape
+    out = torch.zeros(R + 1, S + 1, C, Ko, dtype=w.dtype)
+    for a in (0, 1):
+        for b in (0, 1):
+            out[a:a + R, b:b + S] += w
+    out = out * scale
+    if flip:
+        out = torch.flip(out, (0, 1)).permute(0, 1, 3, 2)
+    return out.contiguous()
+
+
+@_export
+def filter_fold(w4, scale, flip):
+    if flip:
+        w4 = torch.flip(w4, (0, 1)).permute(0, 1, 3, 2)
+    R, S = w4.shape[0] - 1, w4.shape[1] - 1
+    out = sum(w4[a:a + R, b:b + S] for a in (0, 1) for b in (0, 1))
+    return (out * scale).contiguous()
+
+
+@_export
 def spatial_sum(x, scale):
     return (x.sum(dim=(2, 3)) * scale).contiguous()
 

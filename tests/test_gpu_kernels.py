@@ -45,6 +45,10 @@ CONV_CASES = [
     (2, 3, 32, 32, 128, 5, 2, 'nchw', False),     # DCGAN critic layer 1 (stride 2, asymmetric pad)
     (2, 128, 16, 16, 256, 5, 2, 'cl', False),     # DCGAN critic layer 2
     (3, 64, 7, 7, 96, 5, 2, 'cl', False),         # odd size, pad (2,2); K=96 -> partial N tile
+    (8, 128, 32, 32, 128, 4, 2, 'cl', False),     # ConvMeanPool as one 4x4 stride-2 conv; dgrad = 4 output phases of 2x2 taps
+    (3, 128, 16, 16, 128, 4, 2, 'cl', False),     # same, small M
+    (5, 64, 8, 12, 96, 4, 2, 'cl', False),        # phases with a partial N tile, H != W
+    (2, 32, 8, 8, 64, 5, 2, 'cl', False),         # phase dgrad, odd filter (3/2-tap phases zero-padded), table-driven kernel
     (2, 1, 28, 28, 64, 5, 2, 'cl', False),        # MNIST layer 1
     (7, 40, 6, 5, 24, 3, 1, 'cl', False),         # nothing aligned: fully generic
     (130, 128, 1, 1, 2048, 1, 1, 'cl', False),    # Linear 128->2048 as a 1x1 conv
@@ -94,6 +98,88 @@ def test_conv_fwd_dgrad_wgrad(K, case):
         assert relerr(gx, gx_ref) < 2e-5, K.last_kernel()
         gx2 = K.conv_dgrad(dev(gy), dev(w), geom, N, out_strides=tuple(x.stride()), bias=None)
         assert gx2.is_contiguous() and relerr(gx2, gx_ref) < 2e-5
+
+
+@pytest.mark.parametrize('N,H,C,Ko,k', [(64, 32, 128, 128, 4), (16, 16, 128, 128, 4), (3, 16, 128, 256, 5), (2, 8, 64, 96, 4)])
+def test_stride2_dgrad_phase_decomposition(K, N, H, C, Ko, k):
+    """Stride-2 data gradient as four stride-1 convs (one per output parity, one launch): pipelined and
+    table-driven kernels, pre-repacked phase filter, bias / mask / resid epilogue, NCHW output."""
+    g = torch.Generator().manual_seed(N + H + k)
+    geom = K.ConvGeom(C, H, H, Ko, k, k, 2, False)
+    w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
+    gy = torch.randn(N, Ko, H // 2, H // 2, generator=g)
+    x_ = torch.zeros(N, C, H, H, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(tf_ops.conv2d_same(x_, w.double(), 2), x_, gy.double())
+    dx = K.conv_dgrad(cl(gy), dev(w), geom, N)
+    name = K.last_kernel()
+    assert 'ph4' in name, name
+    assert relerr(dx, ref) < 2e-5, name
+    wt = K.repack_filter(dev(w), geom)
+    b = torch.randn(C, generator=g); m = torch.randn(ref.shape, generator=g); r = torch.randn(ref.shape, generator=g)
+    dx2 = K.conv_dgrad(cl(gy), dev(w), geom, N, bias=dev(b), wt=wt, mask=cl(m), resid=cl(r))
+    ref2 = torch.where(m.double() > 0, ref + b.double().view(1, -1, 1, 1), torch.zeros_like(ref)) + r.double()
+    assert relerr(dx2, ref2) < 2e-5
+    dx3 = K.conv_dgrad(dev(gy), dev(w), geom, N, out_strides=tuple(torch.empty(ref.shape).stride()))
+    assert dx3.is_contiguous() and relerr(dx3, ref) < 2e-5
+    K.debug_force_generic(True)
+    try:
+        dx4 = K.conv_dgrad(cl(gy), dev(w), geom, N)
+        assert 'igemm_fwd<' in K.last_kernel() and 'ph4' in K.last_kernel()
+    finally:
+        K.debug_force_generic(False)
+    assert relerr(dx4, ref) < 2e-5
+    if 'pipe' in name and ',k1' in name:
+        assert torch.equal(dx, dx4)          # same taps, same order
+
+
+@pytest.mark.parametrize('mode', ['pool', 'up'])
+@pytest.mark.parametrize('N,C,Ko,H', [(6, 128, 128, 16), (3, 64, 96, 8)])
+def test_fused_resample_convs_on_gpu(K, mode, N, C, Ko, H):
+    """functional.conv2d_mean_pool / upsample_conv2d (spread 4x4 filter, stride-2 conv / phase dgrad) against the
+    reference formulation conv->pool / upsample->conv of the oracle: values, gradients, GP-style double backward."""
+    import ctgan_amd.functional as F
+    g = torch.Generator().manual_seed(N + C + H)
+    x = torch.randn(N, C, H, H, generator=g); w = torch.randn(3, 3, C, Ko, generator=g) / np.sqrt(9 * C)
+    b = torch.randn(Ko, generator=g)
+    xd = cl(x).requires_grad_(True); wd = dev(w).requires_grad_(True); bd = dev(b).requires_grad_(True)
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    if mode == 'pool':
+        y = F.conv2d(xd, wd, bd, pool=True)
+        yr = tf_ops.bias_add_nchw(tf_ops.conv2d_same(xr, wr, 1), br)
+        yr = (yr[:, :, ::2, ::2] + yr[:, :, 1::2, ::2] + yr[:, :, ::2, 1::2] + yr[:, :, 1::2, 1::2]) / 4.
+    else:
+        y = F.conv2d(xd, wd, bd, x_up=True)
+        yr = tf_ops.bias_add_nchw(tf_ops.conv2d_same(tf_ops.upsample2(xr), wr, 1), br)
+    assert tuple(y.shape) == tuple(yr.shape) and relerr(y, yr) < 2e-5
+    gy = torch.randn(yr.shape, generator=g)
+    got = torch.autograd.grad(y, [xd, wd, bd], cl(gy), create_graph=True)
+    ref = torch.autograd.grad(yr, [xr, wr, br], gy.double(), create_graph=True)
+    for a, c in zip(got, ref):
+        assert relerr(a, c) < 3e-5
+    v = torch.randn(x.shape, generator=g)
+    (gw2,) = torch.autograd.grad((got[0] * cl(v)).sum(), [wd]); (gw2r,) = torch.autograd.grad((ref[0] * v.double()).sum(), [wr])
+    assert relerr(gw2, gw2r) < 3e-5
+
+
+def test_filter_spread_fold(K):
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(3, 3, 40, 24, generator=g)
+    for flip in (False, True):
+        ref = torch.zeros(4, 4, 40, 24, dtype=torch.float64)
+        for a in (0, 1):
+            for b in (0, 1):
+                ref[a:a + 3, b:b + 3] += w.double()
+        ref = ref * 0.25
+        if flip:
+            ref = torch.flip(ref, (0, 1)).permute(0, 1, 3, 2)
+        got = K.filter_spread(dev(w), 0.25, flip)
+        assert tuple(got.shape) == tuple(ref.shape) and relerr(got, ref) < 1e-6
+        u = torch.randn(ref.shape, generator=g)
+        ud = u.double()
+        if flip:
+            ud = torch.flip(ud, (0, 1)).permute(0, 1, 3, 2)
+        fref = sum(ud[a:a + 3, b:b + 3] for a in (0, 1) for b in (0, 1)) * 0.5
+        assert relerr(K.filter_fold(dev(u), 0.5, flip), fref) < 1e-6
 
 
 def test_conv_vector_and_generic_paths_agree_bitwise(K):

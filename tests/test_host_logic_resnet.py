@@ -142,3 +142,50 @@ def test_eager_rng_path_runs(small):
     assert torch.isfinite(out['cost']) and not torch.equal(before, tr.d_opt.theta)
     s, px = tr.generate_samples(torch.zeros(10, 128), torch.arange(10, dtype=torch.int32))
     assert s.shape == (10, 3072) and px.dtype == torch.int32 and px.min() >= 0 and px.max() <= 255
+
+
+def test_steps_match_oracle_with_fused_resampling_convs(cpu_kernels, monkeypatch):
+    """Width 32 switches ConvMeanPool / UpsampleConv to the single stride-2 (transposed) conv with the spread
+    4x4 filter (functional.conv2d_mean_pool / upsample_conv2d): the oracle keeps the reference formulation
+    (conv -> pool, upsample -> conv; TF/CT_gan_cifar_resnet.py:89-107), so this is the parity check of the
+    restructuring through a whole critic step (incl. the gradient-penalty double backward) and generator step."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    calls = {'pool': 0, 'up': 0}
+    orig_pool, orig_up = F.conv2d_mean_pool, F.upsample_conv2d
+    monkeypatch.setattr(F, 'conv2d_mean_pool', lambda *a, **k: (calls.__setitem__('pool', calls['pool'] + 1), orig_pool(*a, **k))[1])
+    monkeypatch.setattr(F, 'upsample_conv2d', lambda *a, **k: (calls.__setitem__('up', calls['up'] + 1), orig_up(*a, **k))[1])
+    B, dim = 2, 32
+    lib.set_seed(11)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    try:
+        R.build_params('cpu')
+        reg = _oracle_from_product(lib)
+        cfg = onets.ResnetCfg(DIM_G=dim, DIM_D=dim)
+        g = torch.Generator().manual_seed(3)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        rnd64 = osteps.make_rnd_resnet_d(B, dim, g)
+        rnd32 = {k: ([t.float() for t in v] if isinstance(v, list) else v.float()) for k, v in rnd64.items()}
+        tr = R.Trainer(seed=1)
+        optD = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+        optG = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Generator')], 0.0, 0.9)
+        out = tr.d_step(real, labels, rnd32, iteration=0)
+        ref = osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd64, iteration=0, B=B)
+        assert calls['pool'] > 0 and calls['up'] > 0
+        for k in ('cost', 'wgan', 'acgan', 'ct', 'gp'):
+            _cmp(out[k], ref[k], 2e-4, 'd_step.%s' % k)
+        _cmp(out['gp_grads'], ref['gp_grads'], 2e-4, 'gp grads')
+        for n in ref['grads']:
+            _cmp(out['grads'][n], ref['grads'][n], 5e-4, 'dgrad ' + n)
+        rg64 = osteps.make_rnd_resnet_g(B, dim, g)
+        rg32 = {'z': [t.float() for t in rg64['z']], 'label_u': [t.float() for t in rg64['label_u']],
+                'u': [[t.float() for t in tw] for tw in rg64['u']]}
+        out = tr.g_step(rg32, iteration=1)
+        ref = osteps.resnet_g_step(reg, cfg, optG, rg64, iteration=1, B=B)
+        _cmp(out['cost'], ref['cost'], 2e-4, 'g cost')
+        for n in ref['grads']:
+            _cmp(out['grads'][n], ref['grads'][n], 1e-3, 'ggrad ' + n)
+    finally:
+        R.configure()
