@@ -56,6 +56,7 @@ struct FwdParams {
     int relu_in;                               // A values pass through max(.,0) when staged (conv(relu(x)))
     const float* mask;                         // epilogue: keep the result only where mask[off] > 0 (ReLU backward)
     int d_lin;                                 // D offset = m*ds_q + col*ds_k (pixel-linear output)
+    int d_vec;                                 // unit channel stride, 16-B aligned rows of D / mask / resid: float4 epilogue
     unsigned a_bytes, b_bytes;                 // byte extents of A and B (buffer-descriptor range checks)
     int dbg;                                   // perf-diagnosis bits (env CTGAN_DBG): 1 no LDS store, 2 no global load, 4 no barrier
     // Output-phase decomposition of a stride-2 data gradient: dx pixels of parity (a,b) are a stride-1 conv of
@@ -561,9 +562,72 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
             }
             __syncthreads();
         }
-        if (wk != 0) return;
     }
 
+    if (p.d_vec) {
+        // Vector epilogue: the accumulators go through LDS (free after the K loop) so that every lane owns 4
+        // consecutive channels of one pixel: 16-B stores, and the mask / residual operands are fetched as 16-B
+        // loads that are all in flight before the first store (no load->store serialisation).
+        constexpr int LDC = BN + 8;                 // +8: the two lane halves (rows r, r+4) hit disjoint banks
+        constexpr int C4 = BN / 4, ROWS_PER = NT / C4, ITERS = BM / ROWS_PER;
+        static_assert(NT % C4 == 0 && BM % ROWS_PER == 0, "epilogue mapping");
+        static_assert(BM * LDC <= 2 * STAGE, "epilogue tile must fit the staging buffers");
+        float* ct = smem;
+        if constexpr (WAVES_K == 1) __syncthreads();        // (the K-group reduction above ends with a barrier)
+        if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        ct[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + l31] = acc[i][j][e];
+        }
+        __syncthreads();
+        const int c4 = tid % C4, r0 = tid / C4;
+        const int col = n0 + c4 * 4;
+        if (col < p.Ng) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
+            constexpr int BATCH = ITERS < 8 ? ITERS : 8;
+#pragma unroll
+            for (int b0 = 0; b0 < ITERS; b0 += BATCH) {
+                long long off[BATCH];
+                float4 mv[BATCH], rv[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int m = m0 + r0 + (b0 + u) * ROWS_PER;
+                    off[u] = -1;
+                    if (m < p.M) {
+                        if (p.d_lin) {
+                            off[u] = (long long)m * p.ds_q + col;
+                        } else {
+                            const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+                            off[u] = ph.d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+                        }
+                        if (p.mask) mv[u] = *reinterpret_cast<const float4*>(p.mask + off[u]);
+                        if (p.resid) rv[u] = *reinterpret_cast<const float4*>(p.resid + off[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    if (off[u] < 0) continue;
+                    float4 v = *reinterpret_cast<const float4*>(&ct[(r0 + (b0 + u) * ROWS_PER) * LDC + c4 * 4]);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (p.mask) {
+                        v.x = mv[u].x > 0.f ? v.x : 0.f; v.y = mv[u].y > 0.f ? v.y : 0.f;
+                        v.z = mv[u].z > 0.f ? v.z : 0.f; v.w = mv[u].w > 0.f ? v.w : 0.f;
+                    }
+                    if (p.resid) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(p.D + off[u]) = v;
+                }
+            }
+        }
+        return;
+    }
+
+    if (wk != 0) return;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * TN * 32 + j * 32 + l31;
@@ -1100,6 +1164,10 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
     const Geom& g = p.g;
     p.d_lin = (p.phases <= 1) && (p.ds_p == (long long)g.Q * p.ds_q) && (p.ds_n == (long long)g.P * g.Q * p.ds_q);
     { const char* e = getenv("CTGAN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    p.d_vec = !(p.dbg & 32) && p.ds_k == 1 && (p.Ng % 4 == 0) && (p.ds_n % 4 == 0) && (p.ds_p % 4 == 0) && (p.ds_q % 4 == 0) &&
+              (p.phases <= 1 || ((p.ph_d_h % 4 == 0) && (p.ph_d_w % 4 == 0))) && al16(p.D) && al16(p.mask) && al16(p.resid) &&
+              al16(p.bias);
     const bool avec = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
     const bool bvec = p.bs_k == 1 && (p.Ng % 4 == 0) && (p.b_off % 4 == 0) && (p.bs_r % 4 == 0) && (p.bs_s % 4 == 0) &&

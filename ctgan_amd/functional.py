@@ -19,12 +19,12 @@ from . import kernels as K
 from .kernels import ConvGeom
 
 _WEIGHT_GRADS = True
-# ReLU backward of conv(relu(x)): False = stand-alone mask kernel on the data gradient (measured faster: the
-# dgrad epilogue is the un-overlapped tail of an MFMA kernel), True = mask read inside the dgrad epilogue
-MASK_IN_DGRAD_EPILOGUE = False
+# ReLU backward of conv(relu(x)): True = mask read inside the dgrad epilogue (16-B loads issued ahead of the
+# stores), False = stand-alone mask kernel on the data gradient.  A/B switch CTGAN_MASK_EPI.
+import os as _os
+MASK_IN_DGRAD_EPILOGUE = _os.environ.get('CTGAN_MASK_EPI', '1') != '0'
 # Launch the weight gradient of a conv on a side stream, concurrently with its data gradient (the two are
 # independent): the prologue / epilogue of one kernel overlaps the MFMA stretch of the other.  A/B switch.
-import os as _os
 WGRAD_SIDE_STREAM = _os.environ.get('CTGAN_WGRAD_STREAM', '0') != '0'
 _side = {}
 
