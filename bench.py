@@ -155,7 +155,7 @@ def measure_roofline(trainer, next_batch, K, torch):
     finally:
         trainer.world = saved_world
     agg = {}
-    for name, flops, e0, e1, reps in prof:
+    for name, flops, e0, e1, reps, _shape in prof:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
     if not agg:

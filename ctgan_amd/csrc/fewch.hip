@@ -1,0 +1,572 @@
+// fewch.hip - direct (VALU) kernels for convolutions with <= 4 channels on one side.
+//
+// The CT-WGAN nets touch 3-channel images at both ends: the critic's first block (3 -> 128, 3x3 and the 1x1
+// shortcut; TF/CT_gan_cifar_resnet.py:143-153), the generator's output conv (128 -> 3, :165) and, through
+// the gradient penalty, their data gradients.  As implicit GEMMs these have one dimension of 3 (of a 32-wide
+// MFMA tile) or a reduction depth of 27; they are HBM-bound streaming problems, so they run as plain fp32 FMA
+// kernels whose job is to touch every byte of the wide ("many"-channel) tensor exactly once, coalesced:
+//
+//   f2m   : few -> many   y[n,p,q,k]  = sum_{r,s,c<CS} X(n, p*st-pt+r, q*st-pl+s, c) * w(r,s,c,k)
+//           (first critic conv forward; data gradient of the generator's output conv)
+//           the few-channel image band sits in LDS (zero padding materialised), each thread owns 4 output
+//           channels and keeps its R*S*CS filter slice in registers; stores are 16 B per lane.
+//   m2f   : many -> few   y[n,j,p,q]  = sum_{r,s,c} X(n, p-pt+r, q-pl+s, c) * w(r,s,c,j)            (stride 1)
+//           (generator output conv forward; data gradient of the first critic conv)
+//           the wide band sits in LDS once; a group of C/4 lanes owns one pixel (4 channels per lane, filter
+//           slice in registers) and reduces its JS partial sums with cross-lane adds.
+//   wgrad : dW(r,s,few,many) = sum_px MANY(px) * FEW(px shifted by the tap)
+//           one 16-B load of the wide tensor per lane and pixel, the few-channel band in LDS (one 16-B LDS read
+//           per tap), R*S*JS float4 accumulators per lane; per-workgroup partial filters are combined in a fixed
+//           order (LDS tree inside the workgroup, slab reduction across workgroups) => deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// packed fp32 FMA (v_pk_fma_f32): two lanes of fp32 per VALU lane and cycle
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+struct Acc4 { f32x2 lo, hi; };
+__device__ __forceinline__ void fma4(float s, const Acc4& w, Acc4& a) {
+    const f32x2 sv = {s, s};
+    a.lo = pkfma(sv, w.lo, a.lo); a.hi = pkfma(sv, w.hi, a.hi);
+}
+__device__ __forceinline__ float4 to_f4(const Acc4& a) { return make_float4(a.lo.x, a.lo.y, a.hi.x, a.hi.y); }
+__device__ __forceinline__ Acc4 to_acc(const float4& v) { Acc4 a; a.lo = f32x2{v.x, v.y}; a.hi = f32x2{v.z, v.w}; return a; }
+
+// v + (v of the DPP-selected lane): one v_add_f32 with a DPP operand
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, t);
+}
+// sum over a 16-lane row, valid in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ few -> many
+struct F2MParams {
+    const float* x; long long xs_n, xs_c, xs_h, xs_w; int H, W;      // few-channel input, any strides
+    float* y; long long ys_n, ys_p, ys_q; int P, Q, KM;               // many-channel output, unit channel stride
+    const float* w; long long w_off, ws_r, ws_s, ws_c, ws_k;           // w(r,s,c,k) = w[w_off + r*ws_r + s*ws_s + c*ws_c + k*ws_k]
+    const float* bias; const float* resid;
+    int N, stride, pad_t, pad_l, relu, relu_in, band;                  // band = output rows per workgroup
+};
+
+template <int R, int S, int CS>
+__global__ __launch_bounds__(NT) void f2m_kernel(const F2MParams p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // [CS][TR][TW]
+    const int tid = threadIdx.x;
+    const int KQ = p.KM >> 2, PXP = NT / KQ;
+    const int bands = (p.P + p.band - 1) / p.band;
+    const int n = blockIdx.x / bands, b = blockIdx.x - n * bands;
+    const int p0 = b * p.band, np = min(p.band, p.P - p0);
+    const int TR = (p.band - 1) * p.stride + R, TW = (p.Q - 1) * p.stride + S;
+    const int ih0 = p0 * p.stride - p.pad_t, iw0 = -p.pad_l;
+    for (int i = tid; i < CS * TR * TW; i += NT) {
+        const int c = i / (TR * TW), rem = i - c * TR * TW, tr = rem / TW, tw = rem - tr * TW;
+        const int ih = ih0 + tr, iw = iw0 + tw;
+        float v = 0.f;
+        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+            v = p.x[n * p.xs_n + c * p.xs_c + ih * p.xs_h + iw * p.xs_w];
+        tile[i] = p.relu_in ? fmaxf(v, 0.f) : v;
+    }
+    const int kq = tid % KQ, pl = tid / KQ;
+    Acc4 wr[R * S * CS];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float* q = p.w + p.w_off + r * p.ws_r + s * p.ws_s + c * p.ws_c + (long long)(kq * 4) * p.ws_k;
+                if (p.ws_k == 1) wr[(r * S + s) * CS + c] = to_acc(*reinterpret_cast<const float4*>(q));
+                else wr[(r * S + s) * CS + c] = to_acc(make_float4(q[0], q[p.ws_k], q[2 * p.ws_k], q[3 * p.ws_k]));
+            }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + kq * 4);
+    __syncthreads();
+    const int npx = np * p.Q;
+    int pr = 0, qc = pl;
+    while (qc >= p.Q) { qc -= p.Q; ++pr; }
+    for (int px = pl; px < npx; px += PXP) {
+        Acc4 acc = to_acc(bv);
+        const float* base = tile + (pr * p.stride) * TW + qc * p.stride;
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float* row = base + (c * TR + r) * TW;
+#pragma unroll
+                for (int s = 0; s < S; ++s) fma4(row[s], wr[(r * S + s) * CS + c], acc);
+            }
+        const long long off = n * p.ys_n + (long long)(p0 + pr) * p.ys_p + (long long)qc * p.ys_q + kq * 4;
+        float4 o = to_f4(acc);
+        if (p.resid) {
+            const float4 rv = *reinterpret_cast<const float4*>(p.resid + off);
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(p.y + off) = o;
+        qc += PXP;
+        while (qc >= p.Q) { qc -= p.Q; ++pr; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ many -> few
+struct M2FParams {
+    const float* x; long long xs_n, xs_h, xs_w; int H, W, CM;         // many-channel input, channels-last
+    float* y; long long ys_n, ys_c, ys_p, ys_q; int P, Q;              // few-channel output, any strides
+    const float* w; long long w_off, ws_r, ws_s, ws_c, ws_j;            // w(r,s,c_many,j_few)
+    const float* bias;
+    int N, pad_t, pad_l, band, total, relu_in;                          // total = N * bands workgroup tasks
+};
+
+template <int R, int S, int JS>
+__global__ __launch_bounds__(NT) void m2f_kernel(const M2FParams p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];       // [TR][TW][CM]
+    const int tid = threadIdx.x;
+    const int LPP = p.CM >> 2, GROUPS = NT / LPP;                      // lanes per pixel (16 / 32 / 64)
+    const int l = tid % LPP, grp = tid / LPP;
+    const int bands = (p.P + p.band - 1) / p.band;
+    const int TR = p.band + R - 1, TW = p.Q + S - 1;
+    f32x2 wlo[R * S][JS], whi[R * S][JS];
+#pragma unroll
+    for (int t = 0; t < R * S; ++t)
+#pragma unroll
+        for (int j = 0; j < JS; ++j) {
+            const float* q = p.w + p.w_off + (t / S) * p.ws_r + (t % S) * p.ws_s + (long long)(l * 4) * p.ws_c + j * p.ws_j;
+            wlo[t][j] = f32x2{q[0], q[p.ws_c]}; whi[t][j] = f32x2{q[2 * p.ws_c], q[3 * p.ws_c]};
+        }
+    float bj[JS];
+#pragma unroll
+    for (int j = 0; j < JS; ++j) bj[j] = p.bias ? p.bias[j] : 0.f;
+
+    for (int task = blockIdx.x; task < p.total; task += gridDim.x) {
+        const int n = task / bands, b = task - n * bands;
+        const int p0 = b * p.band, np = min(p.band, p.P - p0);
+        __syncthreads();                                                 // previous band fully consumed
+        for (int i = tid; i < TR * TW * LPP; i += NT) {
+            const int c4 = i % LPP, pix = i / LPP, tr = pix / TW, tw = pix - tr * TW;
+            const int ih = p0 - p.pad_t + tr, iw = tw - p.pad_l;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(p.x + n * p.xs_n + ih * p.xs_h + iw * p.xs_w + c4 * 4);
+            if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            reinterpret_cast<float4*>(tile)[i] = v;
+        }
+        __syncthreads();
+        const int npx = np * p.Q;
+        int pr = 0, qc = grp;
+        while (qc >= p.Q) { qc -= p.Q; ++pr; }
+        for (int px = grp; px < npx; px += GROUPS) {
+            f32x2 acc[JS];
+#pragma unroll
+            for (int j = 0; j < JS; ++j) acc[j] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float4 xv = reinterpret_cast<const float4*>(tile)[((pr + r) * TW + qc + s) * LPP + l];
+                    const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
+#pragma unroll
+                    for (int j = 0; j < JS; ++j) acc[j] = pkfma(xhi, whi[r * S + s][j], pkfma(xlo, wlo[r * S + s][j], acc[j]));
+                }
+            float red[JS];
+#pragma unroll
+            for (int j = 0; j < JS; ++j) {
+                float v = row16_sum(acc[j].x + acc[j].y);                  // 16-lane rows by DPP, the rest by one permute each
+                if (LPP >= 32) v += __shfl_xor(v, 16, 64);
+                if (LPP >= 64) v += __shfl_xor(v, 32, 64);
+                red[j] = v;
+            }
+            if (l == 0) {
+                const long long off = n * p.ys_n + (long long)(p0 + pr) * p.ys_p + (long long)qc * p.ys_q;
+#pragma unroll
+                for (int j = 0; j < JS; ++j) p.y[off + j * p.ys_c] = red[j] + bj[j];
+            }
+            qc += GROUPS;
+            while (qc >= p.Q) { qc -= p.Q; ++pr; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct FWParams {
+    const float* many; long long ms_n, ms_h, ms_w; int MH, MW, CM;    // wide operand [N, MH, MW, CM], channels-last
+    const float* few; long long fs_n, fs_c, fs_h, fs_w; int FH, FW;    // few-channel operand [N, JS, FH, FW], any strides
+    int fst;                                                           // few row of (many row h, tap r) = h*fst + off_r[r]
+    int off_r[5], off_s[5];
+    float* slab;                                                       // [workgroups][n_out]
+    int N, band, bands, total, relu_many, relu_few, few_in, with_bias, n_out, n_main;
+};
+
+// few_in  (C small): many = dy, few = x:   dW[(tap*JS + j)*CM + c]   bias (sum of dy) at n_main + c
+// few_out (K small): many = x,  few = dy:  dW[(tap*CM + c)*JS + j]   bias (sum of dy) at n_main + j
+// Persistent workgroups: each walks its (image, row band) tasks with the accumulators kept in registers, so there
+// is one partial filter ("slab") per workgroup, not per band.
+template <int R, int S, int JS>
+__global__ __launch_bounds__(NT) void fw_wgrad_kernel(const FWParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* tile = reinterpret_cast<float4*>(smem);                     // [TR][TW] few-channel pixels (padded to 4)
+    const int tid = threadIdx.x;
+    const int LPP = p.CM >> 2, GROUPS = NT / LPP;
+    const int l = tid % LPP, grp = tid / LPP;
+    int rmin = p.off_r[0], rmax = p.off_r[0], smin = p.off_s[0], smax = p.off_s[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) { rmin = min(rmin, p.off_r[r]); rmax = max(rmax, p.off_r[r]); }
+#pragma unroll
+    for (int s = 1; s < S; ++s) { smin = min(smin, p.off_s[s]); smax = max(smax, p.off_s[s]); }
+    const int tw0 = smin, TW = (p.MW - 1) * p.fst + smax - smin + 1;
+
+    Acc4 acc[R * S * JS];
+#pragma unroll
+    for (int i = 0; i < R * S * JS; ++i) { acc[i].lo = f32x2{0.f, 0.f}; acc[i].hi = f32x2{0.f, 0.f}; }
+    float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int task = blockIdx.x; task < p.total; task += gridDim.x) {
+        const int n = task / p.bands, b = task - n * p.bands;
+        const int h0 = b * p.band, nh = min(p.band, p.MH - h0);
+        const int tr0 = h0 * p.fst + rmin, TR = (nh - 1) * p.fst + rmax - rmin + 1;
+        __syncthreads();                                                 // previous band fully consumed
+        for (int i = tid; i < TR * TW; i += NT) {
+            const int tr = i / TW, tw = i - tr * TW;
+            const int fh = tr0 + tr, fw = tw0 + tw;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)fh < (unsigned)p.FH && (unsigned)fw < (unsigned)p.FW) {
+#pragma unroll
+                for (int j = 0; j < JS; ++j) {
+                    const float t = p.few[n * p.fs_n + j * p.fs_c + fh * p.fs_h + fw * p.fs_w];
+                    v[j] = p.relu_few ? fmaxf(t, 0.f) : t;
+                }
+            }
+            tile[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        for (int hr = grp; hr < nh; hr += GROUPS) {
+            const float* mrow = p.many + n * p.ms_n + (long long)(h0 + hr) * p.ms_h + l * 4;
+            float4 mv = *reinterpret_cast<const float4*>(mrow);
+            for (int w = 0; w < p.MW; ++w) {
+                float4 cur = mv;
+                if (w + 1 < p.MW) mv = *reinterpret_cast<const float4*>(mrow + (long long)(w + 1) * p.ms_w);
+                if (p.relu_many) { cur.x = fmaxf(cur.x, 0.f); cur.y = fmaxf(cur.y, 0.f); cur.z = fmaxf(cur.z, 0.f); cur.w = fmaxf(cur.w, 0.f); }
+                if (p.few_in) { accb.x += cur.x; accb.y += cur.y; accb.z += cur.z; accb.w += cur.w; }
+                const Acc4 cm = to_acc(cur);
+                const float4* trow = tile + (hr * p.fst - rmin) * TW + (w * p.fst - smin);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float4 fv = trow[p.off_r[r] * TW + p.off_s[s]];
+                        const float f[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+                        for (int j = 0; j < JS; ++j) fma4(f[j], cm, acc[(r * S + s) * JS + j]);
+                    }
+                if (!p.few_in) {                                         // bias of the few-channel dy: the pixel itself (tap offset 0)
+                    const float4 fv = trow[0];
+                    accb.x += fv.x; accb.y += fv.y; accb.z += fv.z; accb.w += fv.w;
+                }
+            }
+        }
+    }
+    __syncthreads();                                                     // tile no longer needed: LDS becomes the reduction buffer
+    float4* red = reinterpret_cast<float4*>(smem);
+    constexpr int NA = R * S * JS + 1;
+    for (int half = GROUPS >> 1; half >= 1; half >>= 1) {
+        if (grp >= half && grp < 2 * half) {
+            float4* dst = red + ((grp - half) * LPP + l) * NA;
+#pragma unroll
+            for (int i = 0; i < R * S * JS; ++i) dst[i] = to_f4(acc[i]);
+            dst[R * S * JS] = accb;
+        }
+        __syncthreads();
+        if (grp < half) {
+            const float4* src = red + (grp * LPP + l) * NA;
+#pragma unroll
+            for (int i = 0; i < R * S * JS; ++i) {
+                const Acc4 v = to_acc(src[i]);
+                acc[i].lo += v.lo; acc[i].hi += v.hi;
+            }
+            const float4 v = src[R * S * JS];
+            accb.x += v.x; accb.y += v.y; accb.z += v.z; accb.w += v.w;
+        }
+        __syncthreads();
+    }
+    if (grp == 0) {
+        float* out = p.slab + (long long)blockIdx.x * p.n_out;
+        if (p.few_in) {
+#pragma unroll
+            for (int i = 0; i < R * S * JS; ++i) *reinterpret_cast<float4*>(out + (long long)i * p.CM + l * 4) = to_f4(acc[i]);
+            if (p.with_bias) *reinterpret_cast<float4*>(out + p.n_main + l * 4) = accb;
+        } else {
+#pragma unroll
+            for (int t = 0; t < R * S; ++t)
+#pragma unroll
+                for (int j = 0; j < JS; ++j) {
+                    const float4 a = to_f4(acc[t * JS + j]);
+                    float* o = out + ((long long)t * p.CM + l * 4) * JS + j;
+                    o[0] = a.x; o[JS] = a.y; o[2 * JS] = a.z; o[3 * JS] = a.w;
+                }
+            if (p.with_bias && l == 0) *reinterpret_cast<float4*>(out + p.n_main) = accb;
+        }
+    }
+}
+
+// dw = sum over workgroup slabs, fixed order: 16 slab lanes x 16 column groups (float4) per workgroup, then a
+// 16-way LDS combine.  n_tot (filter + bias section) is a multiple of 4; db receives the first nb bias values.
+__global__ __launch_bounds__(NT) void fw_reduce_kernel(const float* __restrict__ slab, int stride, int blocks, float* __restrict__ dw,
+                                                      int n_main, float* __restrict__ db, int nb, int n_tot) {
+    __shared__ float4 part[16][16];
+    const int cg = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int col = (blockIdx.x * 16 + cg) * 4;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (col < n_tot) {
+        int k = sl;
+        for (; k + 16 < blocks; k += 32) {
+            const float4 v0 = *reinterpret_cast<const float4*>(slab + (long long)k * stride + col);
+            const float4 v1 = *reinterpret_cast<const float4*>(slab + (long long)(k + 16) * stride + col);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        }
+        if (k < blocks) {
+            const float4 v0 = *reinterpret_cast<const float4*>(slab + (long long)k * stride + col);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+    }
+    part[sl][cg] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    __syncthreads();
+    if (sl == 0 && col < n_tot) {
+        float4 r = part[0][cg];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = part[k][cg]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        const float rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = col + e;
+            if (i < n_main) dw[i] = rv[e];
+            else if (i - n_main < nb) db[i - n_main] = rv[e];
+        }
+    }
+}
+
+bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+bool many_ok(int c) { return c == 64 || c == 128 || c == 256; }
+
+template <typename KernelT>
+int set_smem(KernelT k, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// instantiated (R, S, few) triples: 3x3x3 (CIFAR critic conv 1 / generator output), 1x1x3 (critic shortcut), 5x5x1 (MNIST)
+int tap_case(int R, int S, int few) {
+    if (R == 3 && S == 3 && few == 3) return 1;
+    if (R == 1 && S == 1 && few == 3) return 2;
+    if (R == 5 && S == 5 && few == 1) return 3;
+    if (R == 3 && S == 3 && few == 1) return 4;
+    return 0;
+}
+
+int pick_band(int N, int rows, int unit) {         // rows per workgroup: >= ~512 workgroups when the batch allows it
+    int band = unit;
+    while (band * 2 <= rows && (long long)N * ((rows + band * 2 - 1) / (band * 2)) >= 512) band *= 2;
+    return band;
+}
+
+}  // namespace
+
+// ---- host entry points (called from igemm.hip's C-ABI functions) -------------------------------------------
+bool ctgan_fewch_handles(const ctgan_conv_desc* d) {
+    static const bool off = [] { const char* e = getenv("CTGAN_FEWCH"); return e && atoi(e) == 0; }();
+    if (off || d->x_up) return false;
+    if (d->C <= 4 && tap_case(d->R, d->S, d->C) && many_ok(d->K)) return true;                       // few -> many
+    if (d->K <= 4 && d->stride == 1 && tap_case(d->R, d->S, d->K) && many_ok(d->C)) return true;     // many -> few
+    return false;
+}
+
+// launch helpers -------------------------------------------------------------------------------------------
+static int launch_f2m(const F2MParams& p, int R, int S, int CS, hipStream_t st) {
+    const int bands = (p.P + p.band - 1) / p.band;
+    const int TR = (p.band - 1) * p.stride + R, TW = (p.Q - 1) * p.stride + S;
+    const size_t smem = (size_t)CS * TR * TW * sizeof(float);
+    const dim3 grid(p.N * bands), blk(NT);
+    switch (tap_case(R, S, CS)) {
+        case 1: hipLaunchKernelGGL((f2m_kernel<3, 3, 3>), grid, blk, smem, st, p); break;
+        case 2: hipLaunchKernelGGL((f2m_kernel<1, 1, 3>), grid, blk, smem, st, p); break;
+        case 3: hipLaunchKernelGGL((f2m_kernel<5, 5, 1>), grid, blk, smem, st, p); break;
+        case 4: hipLaunchKernelGGL((f2m_kernel<3, 3, 1>), grid, blk, smem, st, p); break;
+        default: return ctgan_fail(CTGAN_E_UNSUPPORTED, "fewch f2m: taps");
+    }
+    return ctgan_check_launch("fewch_f2m");
+}
+
+static int launch_m2f(const M2FParams& p, int R, int S, int JS, hipStream_t st) {
+    const int TR = p.band + R - 1, TW = p.Q + S - 1;
+    const size_t smem = (size_t)TR * TW * p.CM * sizeof(float);
+    const int grid = p.total < 512 ? p.total : 512;
+    int rc = 0;
+    switch (tap_case(R, S, JS)) {
+        case 1: rc = set_smem(&m2f_kernel<3, 3, 3>, smem); if (!rc) hipLaunchKernelGGL((m2f_kernel<3, 3, 3>), dim3(grid), dim3(NT), smem, st, p); break;
+        case 2: rc = set_smem(&m2f_kernel<1, 1, 3>, smem); if (!rc) hipLaunchKernelGGL((m2f_kernel<1, 1, 3>), dim3(grid), dim3(NT), smem, st, p); break;
+        case 3: rc = set_smem(&m2f_kernel<5, 5, 1>, smem); if (!rc) hipLaunchKernelGGL((m2f_kernel<5, 5, 1>), dim3(grid), dim3(NT), smem, st, p); break;
+        case 4: rc = set_smem(&m2f_kernel<3, 3, 1>, smem); if (!rc) hipLaunchKernelGGL((m2f_kernel<3, 3, 1>), dim3(grid), dim3(NT), smem, st, p); break;
+        default: return ctgan_fail(CTGAN_E_UNSUPPORTED, "fewch m2f: taps");
+    }
+    if (rc) return rc;
+    return ctgan_check_launch("fewch_m2f");
+}
+
+// forward: returns 1 when handled, 0 when the caller should use the GEMM kernels, < 0 on error
+int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid, float* y,
+                    int relu, int relu_in, hipStream_t st) {
+    if (!ctgan_fewch_handles(d)) return 0;
+    if (d->C <= 4) {
+        if (d->ys[1] != 1 || (d->ys[0] | d->ys[2] | d->ys[3]) % 4 || !al16(y) || !al16(resid) || !al16(bias)) return 0;
+        F2MParams p;
+        p.x = x; p.xs_n = d->xs[0]; p.xs_c = d->xs[1]; p.xs_h = d->xs[2]; p.xs_w = d->xs[3]; p.H = d->H; p.W = d->W;
+        p.y = y; p.ys_n = d->ys[0]; p.ys_p = d->ys[2]; p.ys_q = d->ys[3]; p.P = d->P; p.Q = d->Q; p.KM = d->K;
+        p.w = w; p.w_off = 0; p.ws_r = (long long)d->S * d->C * d->K; p.ws_s = (long long)d->C * d->K; p.ws_c = d->K; p.ws_k = 1;
+        p.bias = bias; p.resid = resid;
+        p.N = d->N; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.relu = relu; p.relu_in = relu_in;
+        p.band = pick_band(d->N, d->P, 4);
+        ctgan_set_last_kernel("fewch_f2m");
+        const int rc = launch_f2m(p, d->R, d->S, d->C, st);
+        return rc ? rc : 1;
+    }
+    if (resid || relu) return 0;
+    if (d->xs[1] != 1 || (d->xs[0] | d->xs[2] | d->xs[3]) % 4 || !al16(x)) return 0;
+    M2FParams p;
+    p.x = x; p.xs_n = d->xs[0]; p.xs_h = d->xs[2]; p.xs_w = d->xs[3]; p.H = d->H; p.W = d->W; p.CM = d->C;
+    p.y = y; p.ys_n = d->ys[0]; p.ys_c = d->ys[1]; p.ys_p = d->ys[2]; p.ys_q = d->ys[3]; p.P = d->P; p.Q = d->Q;
+    p.w = w; p.w_off = 0; p.ws_r = (long long)d->S * d->C * d->K; p.ws_s = (long long)d->C * d->K; p.ws_c = d->K; p.ws_j = 1;
+    p.bias = bias;
+    p.N = d->N; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.relu_in = relu_in;
+    p.band = 2;
+    if ((size_t)(p.band + d->R - 1) * (d->Q + d->S - 1) * d->C * 4 > 150 * 1024) return 0;
+    p.total = d->N * ((d->P + p.band - 1) / p.band);
+    ctgan_set_last_kernel("fewch_m2f");
+    const int rc = launch_m2f(p, d->R, d->S, d->K, st);
+    return rc ? rc : 1;
+}
+
+// data gradient dx = conv^T(dy, w) (+ bias): returns 1 / 0 / < 0 like ctgan_fewch_fwd
+int ctgan_fewch_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, hipStream_t st) {
+    if (!ctgan_fewch_handles(d) || d->stride != 1) return 0;
+    const long long tapR = (long long)d->S * d->C * d->K, tapS = (long long)d->C * d->K;
+    const long long rot_off = (long long)(d->R - 1) * tapR + (long long)(d->S - 1) * tapS;       // w(R-1-r, S-1-s, ., .)
+    if (d->C <= 4) {
+        // dy has many channels, dx few: many -> few with the rotated filter, w'(r,s,k,c) = w[R-1-r,S-1-s,c,k]
+        if (d->ys[1] != 1 || (d->ys[0] | d->ys[2] | d->ys[3]) % 4 || !al16(dy)) return 0;
+        M2FParams p;
+        p.x = dy; p.xs_n = d->ys[0]; p.xs_h = d->ys[2]; p.xs_w = d->ys[3]; p.H = d->P; p.W = d->Q; p.CM = d->K;
+        p.y = dx; p.ys_n = d->xs[0]; p.ys_c = d->xs[1]; p.ys_p = d->xs[2]; p.ys_q = d->xs[3]; p.P = d->H; p.Q = d->W;
+        p.w = w; p.w_off = rot_off; p.ws_r = -tapR; p.ws_s = -tapS; p.ws_c = 1; p.ws_j = d->K;
+        p.bias = bias;
+        p.N = d->N; p.pad_t = d->R - 1 - d->pad_t; p.pad_l = d->S - 1 - d->pad_l; p.relu_in = 0;
+        p.band = 2;
+        if ((size_t)(p.band + d->R - 1) * (p.Q + d->S - 1) * p.CM * 4 > 150 * 1024) return 0;
+        p.total = d->N * ((p.P + p.band - 1) / p.band);
+        ctgan_set_last_kernel("fewch_m2f(dgrad)");
+        const int rc = launch_m2f(p, d->R, d->S, d->C, st);
+        return rc ? rc : 1;
+    }
+    // dy has few channels, dx many: few -> many with w'(r,s,j,c) = w[R-1-r,S-1-s,c,j]
+    if (d->xs[1] != 1 || (d->xs[0] | d->xs[2] | d->xs[3]) % 4 || !al16(dx) || !al16(bias)) return 0;
+    F2MParams p;
+    p.x = dy; p.xs_n = d->ys[0]; p.xs_c = d->ys[1]; p.xs_h = d->ys[2]; p.xs_w = d->ys[3]; p.H = d->P; p.W = d->Q;
+    p.y = dx; p.ys_n = d->xs[0]; p.ys_p = d->xs[2]; p.ys_q = d->xs[3]; p.P = d->H; p.Q = d->W; p.KM = d->C;
+    p.w = w; p.w_off = rot_off; p.ws_r = -tapR; p.ws_s = -tapS; p.ws_c = 1; p.ws_k = d->K;
+    p.bias = bias; p.resid = nullptr;
+    p.N = d->N; p.stride = 1; p.pad_t = d->R - 1 - d->pad_t; p.pad_l = d->S - 1 - d->pad_l; p.relu = 0; p.relu_in = 0;
+    p.band = pick_band(d->N, p.P, 4);
+    ctgan_set_last_kernel("fewch_f2m(dgrad)");
+    const int rc = launch_f2m(p, d->R, d->S, d->K, st);
+    return rc ? rc : 1;
+}
+
+static void fw_plan(const ctgan_conv_desc* d, int* band, int* bands, int* n_main, int* n_out) {
+    const int rows = d->C <= 4 ? d->P : d->H;              // rows of the many-channel operand
+    const int cm = d->C <= 4 ? d->K : d->C;
+    const int unit = NT / (cm / 4);                        // one row per lane group
+    *band = pick_band(d->N, rows, unit);
+    *bands = (rows + *band - 1) / *band;
+    *n_main = d->R * d->S * d->C * d->K;
+    *n_out = *n_main + ((d->C <= 4 ? d->K : d->K) + 3) / 4 * 4;
+}
+
+size_t ctgan_fewch_wgrad_workspace(const ctgan_conv_desc* d) {
+    if (!ctgan_fewch_handles(d)) return 0;
+    int band, bands, n_main, n_out;
+    fw_plan(d, &band, &bands, &n_main, &n_out);
+    return (size_t)d->N * bands * n_out * sizeof(float);
+}
+
+int ctgan_fewch_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                      int relu_x, hipStream_t st) {
+    if (!ctgan_fewch_handles(d)) return 0;
+    const bool few_in = d->C <= 4;
+    FWParams p;
+    if (few_in) {
+        if (d->ys[1] != 1 || (d->ys[0] | d->ys[2] | d->ys[3]) % 4 || !al16(dy)) return 0;
+        p.many = dy; p.ms_n = d->ys[0]; p.ms_h = d->ys[2]; p.ms_w = d->ys[3]; p.MH = d->P; p.MW = d->Q; p.CM = d->K;
+        p.few = x; p.fs_n = d->xs[0]; p.fs_c = d->xs[1]; p.fs_h = d->xs[2]; p.fs_w = d->xs[3]; p.FH = d->H; p.FW = d->W;
+        p.fst = d->stride;
+        for (int r = 0; r < d->R; ++r) p.off_r[r] = r - d->pad_t;
+        for (int s = 0; s < d->S; ++s) p.off_s[s] = s - d->pad_l;
+        p.relu_many = 0; p.relu_few = relu_x;
+    } else {
+        if (d->xs[1] != 1 || (d->xs[0] | d->xs[2] | d->xs[3]) % 4 || !al16(x)) return 0;
+        p.many = x; p.ms_n = d->xs[0]; p.ms_h = d->xs[2]; p.ms_w = d->xs[3]; p.MH = d->H; p.MW = d->W; p.CM = d->C;
+        p.few = dy; p.fs_n = d->ys[0]; p.fs_c = d->ys[1]; p.fs_h = d->ys[2]; p.fs_w = d->ys[3]; p.FH = d->P; p.FW = d->Q;
+        p.fst = 1;
+        for (int r = 0; r < d->R; ++r) p.off_r[r] = d->pad_t - r;
+        for (int s = 0; s < d->S; ++s) p.off_s[s] = d->pad_l - s;
+        p.relu_many = relu_x; p.relu_few = 0;
+    }
+    p.few_in = few_in ? 1 : 0; p.with_bias = db ? 1 : 0; p.N = d->N;
+    fw_plan(d, &p.band, &p.bands, &p.n_main, &p.n_out);
+    p.total = d->N * p.bands;
+    const int blocks = p.total < 256 ? p.total : 256;
+    const size_t need = (size_t)blocks * p.n_out * sizeof(float);
+    if (!ws || ws_bytes < need) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    p.slab = static_cast<float*>(ws);
+    const int JS = few_in ? d->C : d->K;
+    const int LPP = p.CM / 4, GROUPS = NT / LPP;
+    int rspan = 0, sspan = 0;
+    for (int r = 0; r < d->R; ++r) for (int r2 = 0; r2 < d->R; ++r2) if (p.off_r[r] - p.off_r[r2] > rspan) rspan = p.off_r[r] - p.off_r[r2];
+    for (int s = 0; s < d->S; ++s) for (int s2 = 0; s2 < d->S; ++s2) if (p.off_s[s] - p.off_s[s2] > sspan) sspan = p.off_s[s] - p.off_s[s2];
+    const size_t tile_b = (size_t)((p.band - 1) * p.fst + rspan + 1) * ((p.MW - 1) * p.fst + sspan + 1) * 16;
+    const size_t red_b = (size_t)(GROUPS / 2) * LPP * (d->R * d->S * JS + 1) * 16;
+    const size_t smem = tile_b > red_b ? tile_b : red_b;
+    if (smem > 150 * 1024) return 0;
+    int rc = 0;
+    const dim3 grid(blocks), blk(NT);
+    switch (tap_case(d->R, d->S, JS)) {
+        case 1: rc = set_smem(&fw_wgrad_kernel<3, 3, 3>, smem); if (!rc) hipLaunchKernelGGL((fw_wgrad_kernel<3, 3, 3>), grid, blk, smem, st, p); break;
+        case 2: rc = set_smem(&fw_wgrad_kernel<1, 1, 3>, smem); if (!rc) hipLaunchKernelGGL((fw_wgrad_kernel<1, 1, 3>), grid, blk, smem, st, p); break;
+        case 3: rc = set_smem(&fw_wgrad_kernel<5, 5, 1>, smem); if (!rc) hipLaunchKernelGGL((fw_wgrad_kernel<5, 5, 1>), grid, blk, smem, st, p); break;
+        case 4: rc = set_smem(&fw_wgrad_kernel<3, 3, 1>, smem); if (!rc) hipLaunchKernelGGL((fw_wgrad_kernel<3, 3, 1>), grid, blk, smem, st, p); break;
+        default: return 0;
+    }
+    if (rc) return rc;
+    rc = ctgan_check_launch("fewch_wgrad");
+    if (rc) return rc;
+    ctgan_set_last_kernel(few_in ? "fewch_wgrad(few_in)" : "fewch_wgrad(few_out)");
+    const int nb = db ? d->K : 0;
+    const int n_tot = db ? p.n_out : p.n_main;
+    hipLaunchKernelGGL(fw_reduce_kernel, dim3((n_tot + 63) / 64), dim3(NT), 0, st, p.slab, p.n_out, blocks, dw, p.n_main, db, nb, n_tot);
+    rc = ctgan_check_launch("fewch_reduce");
+    return rc ? rc : 1;
+}

@@ -1337,17 +1337,26 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
     // choose splits so that tiles*splits ~ k*256 workgroups (k small) with >= 4 slices per split
     const int max_splits = (Kg + 4 * BK - 1) / (4 * BK);
     int best = 1;
-    // one or two output tiles (few-channel / skinny weight gradients) are bound by the latency of streaming
-    // the pixel axis, not by MFMA: give every CU ~4 workgroups
+    // one or two output tiles (few-channel / skinny weight gradients): a streaming reduction over the pixel axis,
+    // bound by load latency.  Measured (tools_skinny_w.py): ~384 pixels per workgroup, at most one workgroup per CU;
+    // more splits only add slab traffic and pipeline fill/drain.
     static const int force_k = [] { const char* e = getenv("CTGAN_WGRAD_K"); return e ? atoi(e) : 0; }();
-    for (int k = (force_k ? force_k : (tiles <= 2 ? 4 : 2)); k <= 4; ++k) {
-        int s = (256 * k) / tiles;
-        if (s < 1) s = 1;
-        if (s > max_splits) s = max_splits;
-        best = s;
-        if ((double)tiles * s >= 0.9 * 256 * k || s == max_splits) break;
+    if (tiles <= 2 && !force_k) {
+        best = Kg / 384;
+        if (best > 256 / tiles) best = 256 / tiles;
+        if (best > max_splits) best = max_splits;
+    } else {
+        for (int k = (force_k ? force_k : 2); k <= 4; ++k) {
+            int s = (256 * k) / tiles;
+            if (s < 1) s = 1;
+            if (s > max_splits) s = max_splits;
+            best = s;
+            if ((double)tiles * s >= 0.9 * 256 * k || s == max_splits) break;
+        }
     }
     if (best < 1) best = 1;
+    static const int force_s = [] { const char* e = getenv("CTGAN_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
+    if (force_s > 0) best = force_s < max_splits ? force_s : max_splits;      // tuning sweeps only
     int ch = (Kg + best - 1) / best;
     ch = ((ch + BK - 1) / BK) * BK;
     *splits = (Kg + ch - 1) / ch;
@@ -1368,7 +1377,9 @@ size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
         const int mt = d->R * d->S * d->C, Kg = d->N * d->P * d->Q;
         const WPlan w = wgrad_plan(d->C, mt, d->K, Kg);
         // slabs (always sized for the bias row) + room for the stand-alone bias column sums
-        return (size_t)w.splits * (mt + 1) * d->K * sizeof(float) + ctgan_colsum_workspace_bytes(Kg, d->K);
+        const size_t gemm = (size_t)w.splits * (mt + 1) * d->K * sizeof(float) + ctgan_colsum_workspace_bytes(Kg, d->K);
+        const size_t few = ctgan_fewch_wgrad_workspace(d);
+        return gemm > few ? gemm : few;
     }
     return 0;
 }
@@ -1381,6 +1392,11 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     if (ctgan_is_small_linear(d) && !resid && !(flags & CTGAN_IN_RELU) && !g_force_generic) {
         ctgan_set_last_kernel("linear_small_fwd");
         return ctgan_small_linear_fwd(d, x, w, bias, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));
+    }
+    if (!g_force_generic) {
+        rc = ctgan_fewch_fwd(d, x, w, bias, resid, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, (flags & CTGAN_IN_RELU) ? 1 : 0,
+                             static_cast<hipStream_t>(stream));
+        if (rc) return rc < 0 ? rc : CTGAN_OK;
     }
     FwdParams p;
     p.g = geom_from_x(d);
@@ -1419,6 +1435,10 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
         ctgan_set_last_kernel("linear_small_dgrad");
         if (flags & CTGAN_DGRAD_W_REPACKED) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: small linear takes the original filter");
         return ctgan_small_linear_dgrad(d, dy, w, bias, dx, st);
+    }
+    if (!mask && !resid && !(flags & CTGAN_DGRAD_W_REPACKED) && !g_force_generic) {
+        rc = ctgan_fewch_dgrad(d, dy, w, bias, dx, st);
+        if (rc) return rc < 0 ? rc : CTGAN_OK;
     }
     FwdParams p;
     Geom& g = p.g;
@@ -1492,6 +1512,10 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
     if (ctgan_is_small_linear(d) && !(flags & CTGAN_IN_RELU) && !g_force_generic) {
         ctgan_set_last_kernel("linear_small_wgrad");
         return ctgan_small_linear_wgrad(d, x, dy, dw, db, static_cast<hipStream_t>(stream));
+    }
+    if (!g_force_generic) {
+        rc = ctgan_fewch_wgrad(d, x, dy, dw, db, ws, ws_bytes, (flags & CTGAN_IN_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));
+        if (rc) return rc < 0 ? rc : CTGAN_OK;
     }
     WgradParams p;
     p.g = geom_from_x(d);

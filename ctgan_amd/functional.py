@@ -54,7 +54,7 @@ class ConvFn(Function):
     (SAME conv described by geometry g)"""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, g, out_strides, relu_in=False):
+    def forward(ctx, x, w, b, resid, g, out_strides, relu_in=False, fork=False):
         ctx.g = g
         ctx.N = x.shape[0]
         ctx.x_strides = x.stride()
@@ -62,13 +62,23 @@ class ConvFn(Function):
         ctx.has_b = b is not None
         ctx.has_resid = resid is not None
         ctx.relu_in = bool(relu_in)
+        ctx.fork = bool(fork)
         ctx.save_for_backward(x, w)
-        return K.conv_fwd(x, w, b, g, resid=resid, out_strides=out_strides, relu_in=relu_in)
+        if fork:
+            ctx.set_materialize_grads(False)       # an unused shortcut branch must not cost a zero-filled add
+        y = K.conv_fwd(x, w, b, g, resid=resid, out_strides=out_strides, relu_in=relu_in)
+        if fork:
+            # second output = x itself (for the block's shortcut branch): x then has ONE consumer in the autograd
+            # graph and the shortcut's gradient arrives here, where it rides the dgrad epilogue as `resid`
+            return y, x.view_as(x)
+        return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_fork=None):
         x, w = ctx.saved_tensors
         g = ctx.g
+        if gy is None:                                   # fork only: y itself was not used
+            return g_fork, None, None, None, None, None, None, None
         gx = gw = gb = gr = None
         mask = x if ctx.relu_in else None               # ReLU backward rides the dgrad epilogue
         need_w = ctx.needs_input_grad[1] and ctx.want_w
@@ -101,8 +111,15 @@ class ConvFn(Function):
                 keep = ctx.x_strides if _is_plain_nchw(x) else None
                 if mask is not None and not MASK_IN_DGRAD_EPILOGUE:
                     gx = LReluBwdFn.apply(ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, None), x, 0.0)
+                    if g_fork is not None:
+                        gx = add(gx, g_fork)
                 else:
-                    gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask)
+                    gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask, g_fork)
+                g_fork = None
+            if g_fork is not None:
+                gx = add(gx, g_fork)
+        elif g_fork is not None:
+            gx = g_fork
         if ctx.has_resid and ctx.needs_input_grad[3]:
             gr = gy
         if fork:
@@ -110,7 +127,7 @@ class ConvFn(Function):
             for t in (gw, gb):
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream())
-        return gx, gw, gb, gr, None, None, None
+        return gx, gw, gb, gr, None, None, None, None
 
 
 class ConvDgradFn(Function):
@@ -118,19 +135,21 @@ class ConvDgradFn(Function):
     gradient of conv(relu(x)) w.r.t. x, mask = x)"""
 
     @staticmethod
-    def forward(ctx, gy, w, b, g, N, out_strides, mask=None):
+    def forward(ctx, gy, w, b, g, N, out_strides, mask=None, resid=None):
         ctx.g = g
         ctx.want_w = _WEIGHT_GRADS
         ctx.has_b = b is not None
         ctx.has_mask = mask is not None
+        ctx.has_resid = resid is not None
         if mask is not None:
             ctx.save_for_backward(gy, w, mask)
         else:
             ctx.save_for_backward(gy, w)
-        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask)
+        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid)
 
     @staticmethod
     def backward(ctx, ggx):
+        g_res = ggx if (ctx.has_resid and ctx.needs_input_grad[7]) else None    # added after the mask
         if ctx.has_mask:
             gy, w, mask = ctx.saved_tensors
             ggx = LReluBwdFn.apply(ggx, mask, 0.0)      # the mask is a constant of the second pass
@@ -144,7 +163,7 @@ class ConvDgradFn(Function):
             g_w = ConvWgradFn.apply(ggx, gy, g, False)
         if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
             g_b = ChannelSumFn.apply(ggx)
-        return g_gy, g_w, g_b, None, None, None, None
+        return g_gy, g_w, g_b, None, None, None, None, g_res
 
 
 _REPACK = {}      # (epoch, data_ptr, R, S, C, K) -> (rotated / I-O-swapped filter, ready event, producer stream)
@@ -289,22 +308,30 @@ class Col2imFn(Function):
         return Im2colFn.apply(gx, ctx.g, ctx.cpad), None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False, pool=False):
+def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False, pool=False, fork=False):
     """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`.
     relu_in=True computes conv(relu(x)) without materialising relu(x); pool=True returns
     mean_pool2(conv(x) + b) [+ resid]; x_up=True convolves upsample2(x)."""
     R, S, C, Kout = w.shape
     N, Cx, H, W = x.shape
     assert Cx == C, 'channel mismatch: x has %d, filter expects %d' % (Cx, C)
-    fusable = RESAMPLE_FUSION and stride == 1 and R % 2 == 1 and S % 2 == 1 and R > 1 and C % 32 == 0 and Kout % 32 == 0
+    if fork:
+        # returns (y, x'): x' is x for the caller's shortcut branch (see ConvFn.forward)
+        if pool or x_up or out_nchw or C <= 4 or not FORK_FUSION:
+            return conv2d(x, w, b, stride, resid, x_up, out_nchw, relu_in, pool), x
+        g = ConvGeom(C, H, W, Kout, R, S, stride, False)
+        return ConvFn.apply(x, w, b, resid, g, None, relu_in, True)
+    fusable = RESAMPLE_FUSION and stride == 1 and R % 2 == 1 and S % 2 == 1 and C % 32 == 0 and Kout % 32 == 0
     if pool:
         if fusable and not out_nchw and H % 2 == 0 and W % 2 == 0:
             return conv2d_mean_pool(x, w, b, resid, relu_in)
         out = mean_pool2(conv2d(x, w, b, stride, None, x_up, False, relu_in))
         return out if resid is None else add(out, resid)
-    if x_up and fusable and resid is None and not relu_in and not out_nchw:
+    if x_up and fusable and R > 1 and resid is None and not relu_in and not out_nchw:
         return upsample_conv2d(x, w, b)
-    if C <= 4 and not x_up and Kout % 4 == 0:
+    if C <= 4 and not x_up and stride == 1 and K.fewch_handles(ConvGeom(C, H, W, Kout, R, S, stride, False)):
+        pass          # direct few-channel kernels (csrc/fewch.hip) behind the ordinary conv entry points
+    elif C <= 4 and not x_up and Kout % 4 == 0:
         # few input channels: expand patches once, then the conv / wgrad / dgrad are 1x1 convs on the
         # pipelined MFMA kernels (csrc/skinny.hip)
         g = ConvGeom(C, H, W, Kout, R, S, stride, False)
@@ -354,6 +381,8 @@ def linear(x, w, b=None):
 _DERIVED = {}         # (epoch, data_ptr of the parameter, scale, flip) -> spread filter
 _DERIVED_PTRS = {}    # data_ptr of a cached spread filter -> epoch (lets the dgrad repack cache key on it)
 RESAMPLE_FUSION = _os.environ.get('CTGAN_RESAMPLE_FUSION', '1') != '0'
+# residual blocks: the shortcut's gradient is added in the epilogue of the main branch's first data gradient
+FORK_FUSION = _os.environ.get('CTGAN_FORK_FUSION', '1') != '0'
 
 
 class FilterSpreadFn(Function):

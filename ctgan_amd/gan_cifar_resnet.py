@@ -108,6 +108,9 @@ def ConvMeanPool(name, input_dim, output_dim, filter_size, inputs, he_init=True,
     """:89-92.  A 1x1 conv commutes with the mean pool: pool first (4x fewer MACs)."""
     if filter_size == 1:
         assert not relu_in
+        if F.RESAMPLE_FUSION and input_dim % 32 == 0 and output_dim % 32 == 0:
+            # pool + 1x1 conv = one 2x2 stride-2 conv (no pooled intermediate, no upsample kernel in the backward)
+            return _conv2d.Conv2D(name, input_dim, output_dim, 1, inputs, he_init=he_init, biases=biases, pool=True, resid=resid)
         return _conv2d.Conv2D(name, input_dim, output_dim, 1, F.mean_pool2(inputs), he_init=he_init, biases=biases,
                               resid=resid)
     # conv + mean pool = one stride-2 conv with the spread (k+1)x(k+1) filter (functional.conv2d_mean_pool)
@@ -142,7 +145,10 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
         raise Exception('invalid resample value')
     out, r1 = _norm_relu(name + '.N1', inputs, labels=labels, groups=groups)
     if resample == 'down':
-        out = _conv2d.Conv2D(name + '.Conv1', input_dim, input_dim, filter_size, out, relu_in=r1)
+        if r1:      # critic: `inputs` feeds Conv1 and the shortcut; fork=True returns it back for the shortcut
+            out, inputs = _conv2d.Conv2D(name + '.Conv1', input_dim, input_dim, filter_size, out, relu_in=True, fork=True)
+        else:
+            out = _conv2d.Conv2D(name + '.Conv1', input_dim, input_dim, filter_size, out, relu_in=r1)
         out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
         out = ConvMeanPool(name + '.Conv2', input_dim, output_dim, filter_size, out, relu_in=r2)
         # shortcut = ConvMeanPool 1x1 (he_init=False); the residual add rides its epilogue
@@ -153,11 +159,14 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
         out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
         return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2)
     # resample None
+    if r1:
+        out, inputs = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=True, fork=True)
     if output_dim == input_dim:
         shortcut = inputs
     else:
         shortcut = _conv2d.Conv2D(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
-    out = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
+    if not r1:
+        out = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
     out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
     return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2)
 

@@ -44,7 +44,7 @@ def _timed(g, N, launch):
     for _ in range(PROFILE_REPS):
         launch()
     e1.record(st)
-    PROFILE.append((last_kernel(), _conv_flops(g, N), e0, e1, PROFILE_REPS))
+    PROFILE.append((last_kernel(), _conv_flops(g, N), e0, e1, PROFILE_REPS, (N, g.C, g.H, g.W, g.K, g.R, g.stride, int(g.x_up))))
 
 
 def _stream():
@@ -137,6 +137,17 @@ class ConvGeom:
         d.xs = I64x4(*xs)
         d.ys = I64x4(*ys)
         return d
+
+
+def fewch_handles(g):
+    """Mirror of ctgan_fewch_handles (csrc/fewch.hip): convs with <= 4 channels on one side that run on the direct
+    FMA kernels (forward, data gradient and weight gradient) instead of the im2col / GEMM route."""
+    taps = {(3, 3, 3), (1, 1, 3), (5, 5, 1), (3, 3, 1)}
+    if g.x_up:
+        return False
+    if g.C <= 4 and (g.R, g.S, g.C) in taps and g.K in (64, 128, 256):
+        return True
+    return g.K <= 4 and g.stride == 1 and (g.R, g.S, g.K) in taps and g.C in (64, 128, 256)
 
 
 def _x_phys_shape(g, N):

@@ -1,5 +1,7 @@
 """Parity of every HIP kernel family against the CPU oracle (fp64 truth), through the C-ABI.
 Runs on the MI355X box only (`-m gpu`)."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -61,7 +63,7 @@ CONV_CASES = [
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d_%s%s' % (c[:8] + ('_up' if c[8] else '',)))
 def test_conv_fwd_dgrad_wgrad(K, case):
     N, C, H, W, Ko, k, st, layout, up = case
-    g = torch.Generator().manual_seed(hash(case) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 1000)   # hash() of a str is per-process random
     Hp, Wp = (H // 2, W // 2) if up else (H, W)
     x = torch.randn(N, C, Hp, Wp, generator=g)
     w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
@@ -92,7 +94,9 @@ def test_conv_fwd_dgrad_wgrad(K, case):
     gw_b = K.conv_wgrad(xd, dev(gy), geom)                     # NCHW-strided dy
     assert relerr(gw_b, gw_ref) < 3e-5, K.last_kernel()
     gw_c, gb_c = K.conv_wgrad(xd, cl(gy), geom, with_bias=True)  # bias gradient fused where the pipelined kernel applies
-    assert relerr(gw_c, gw_ref) < 3e-5 and relerr(gb_c, gy.double().sum(dim=(0, 2, 3))) < 3e-5, K.last_kernel()
+    gb_ref = gy.double().sum(dim=(0, 2, 3))
+    gb_scale = gy.double().abs().sum(dim=(0, 2, 3)).max().item()       # a sum of N(0,1) draws may cancel to ~0
+    assert relerr(gw_c, gw_ref) < 3e-5 and (gb_c.cpu().double() - gb_ref).abs().max().item() < 1e-6 * gb_scale, K.last_kernel()
     if not up:
         gx = K.conv_dgrad(cl(gy), dev(w), geom, N)
         assert relerr(gx, gx_ref) < 2e-5, K.last_kernel()
@@ -180,6 +184,54 @@ def test_filter_spread_fold(K):
             ud = torch.flip(ud, (0, 1)).permute(0, 1, 3, 2)
         fref = sum(ud[a:a + 3, b:b + 3] for a in (0, 1) for b in (0, 1)) * 0.5
         assert relerr(K.filter_fold(dev(u), 0.5, flip), fref) < 1e-6
+
+
+@pytest.mark.parametrize('N,C,H,Ko,k,st,layout', [(5, 3, 32, 128, 3, 1, 'nchw'), (64, 3, 32, 128, 3, 1, 'nchw'), (4, 3, 16, 128, 1, 1, 'cl'),
+                                                    (3, 128, 32, 3, 3, 1, 'cl'), (33, 128, 32, 3, 3, 1, 'cl'), (6, 64, 8, 3, 3, 1, 'cl'),
+                                                    (4, 1, 28, 64, 5, 2, 'cl'), (2, 256, 8, 3, 3, 1, 'cl')])
+def test_few_channel_direct_kernels(K, N, C, H, Ko, k, st, layout):
+    """csrc/fewch.hip: convs with <= 4 channels on one side (critic conv 1 and its shortcut, generator output conv,
+    MNIST first conv) run on direct FMA kernels for forward, data gradient and weight gradient (+ bias)."""
+    g = torch.Generator().manual_seed(N * 7 + C + H)
+    geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+    assert K.fewch_handles(geom)
+    x = torch.randn(N, C, H, H, generator=g); w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
+    b = torch.randn(Ko, generator=g)
+    xd = cl(x) if layout == 'cl' else dev(x)
+    ref = tf_ops.bias_add_nchw(tf_ops.conv2d_same(x.double(), w.double(), st), b.double())
+    y = K.conv_fwd(xd, dev(w), dev(b), geom)
+    assert 'fewch' in K.last_kernel(), K.last_kernel()
+    assert relerr(y, ref) < 2e-5
+    if C <= 4:
+        r = torch.randn(ref.shape, generator=g)
+        y2 = K.conv_fwd(xd, dev(w), dev(b), geom, resid=cl(r), relu=True, relu_in=True)
+        ref2 = torch.relu(tf_ops.bias_add_nchw(tf_ops.conv2d_same(torch.relu(x.double()), w.double(), st), b.double()) + r.double())
+        assert 'fewch' in K.last_kernel() and relerr(y2, ref2) < 2e-5
+    else:
+        y3 = K.conv_fwd(xd, dev(w), dev(b), geom, out_strides=tuple(torch.empty(ref.shape).stride()))      # NCHW output (G.Output)
+        assert 'fewch' in K.last_kernel() and y3.is_contiguous() and relerr(y3, ref) < 2e-5
+    gy = torch.randn(ref.shape, generator=g)
+    x_ = x.double().clone().requires_grad_(True); w_ = w.double().clone().requires_grad_(True)
+    gx_ref, gw_ref = torch.autograd.grad(tf_ops.conv2d_same(x_, w_, st), [x_, w_], gy.double())
+    gyd = cl(gy) if C <= 4 else dev(gy)          # the few-channel side may be plain NCHW
+    gw, gb = K.conv_wgrad(xd, gyd, geom, with_bias=True)
+    assert 'fewch_wgrad' in K.last_kernel(), K.last_kernel()
+    gb_scale = gy.double().abs().sum(dim=(0, 2, 3)).max().item()
+    assert relerr(gw, gw_ref) < 3e-5 and (gb.cpu().double() - gy.double().sum(dim=(0, 2, 3))).abs().max().item() < 1e-6 * gb_scale
+    gw2 = K.conv_wgrad(xd, gyd, geom)
+    assert torch.equal(gw, gw2)
+    if st == 1:
+        gx = K.conv_dgrad(gyd, dev(w), geom, N, out_strides=tuple(x.stride()) if layout == 'nchw' else None)
+        assert 'fewch' in K.last_kernel(), K.last_kernel()
+        assert relerr(gx, gx_ref) < 2e-5
+    # the table-driven GEMM kernels remain the cross-check
+    K.debug_force_generic(True)
+    try:
+        y_gen = K.conv_fwd(xd, dev(w), dev(b), geom)
+        assert 'fewch' not in K.last_kernel()
+    finally:
+        K.debug_force_generic(False)
+    assert relerr(y, y_gen) < 1e-5
 
 
 def test_conv_vector_and_generic_paths_agree_bitwise(K):
