@@ -124,6 +124,7 @@ def main():
                        'images_per_step': R.cfg.N_CRITIC * B * world, 'parallelism': 'dp%d' % world,
                        'hipgraph': bool(eng.graphed), 'last_d_cost': last_cost},
             'step_mfma_frac': round(ITER_GFLOP * 1e9 / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+            'step_mfma_frac_note': 'FLOPs of the REFERENCE formulation (SURVEY 8(d), 2990.5 GFLOP / iteration) / time / fp32 MFMA peak; the executed FLOP count is lower (resampled convs run as stride-2 convs with the spread filter), see roofline for executed-FLOP kernel rates',
             'roofline': roofline, 'gp_unit': gp_unit, 'cpu_baseline': cpu,
         }
         print(json.dumps(rec))
@@ -156,6 +157,7 @@ def measure_roofline(trainer, next_batch, K, torch):
         trainer.world = saved_world
     agg = {}
     for name, flops, e0, e1, reps, _shape in prof:
+        name = name.replace(',ph4', '')      # the 4-phase dgrad is a launch mode of the same kernel symbol (what rocprofv3 reports)
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
     if not agg:
