@@ -29,6 +29,13 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class FilterJob(ctypes.Structure):
+    """struct ctgan_filter_job (include/ctgan_hip.h)."""
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p),
+                ('R', c_int32), ('S', c_int32), ('C', c_int32), ('K', c_int32),
+                ('kind', c_int32), ('pad_t', c_int32), ('pad_l', c_int32), ('scale', ctypes.c_float)]
+
+
 I64x4 = c_int64 * 4
 I32x4 = c_int32 * 4
 _p = c_void_p          # device pointers and the stream travel as void*
@@ -62,6 +69,7 @@ SIGNATURES = {
     'ctgan_upsample2': (c_int, [_p, POINTER(c_int64), _p, POINTER(c_int64), POINTER(c_int32), c_float, _p]),
     'ctgan_filter_spread': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
     'ctgan_filter_fold': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
+    'ctgan_filter_batch': (c_int, [_p, c_int32, _p]),
     'ctgan_spatial_sum': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
     'ctgan_spatial_bcast': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
     'ctgan_real_prep': (c_int, [_p, _p, _p, c_int64, c_float, _p]),

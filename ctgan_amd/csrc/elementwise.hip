@@ -237,6 +237,57 @@ __global__ void filter_fold_kernel(const float* __restrict__ w4, float* __restri
     }
 }
 
+// All derived filters of a weight update in one launch (blockIdx.y = job): the rotated / phase-major layouts the
+// data-gradient kernels multiply with, and the spread filters of the resampled convs.
+struct FilterJobs { ctgan_filter_job j[CTGAN_FILTER_BATCH]; };
+__global__ void filter_batch_kernel(const FilterJobs t) {
+    const ctgan_filter_job& jb = t.j[blockIdx.y];
+    const int R = jb.R, S = jb.S, C = jb.C, K = jb.K;
+    const float* __restrict__ w = jb.src;
+    float* __restrict__ out = jb.dst;
+    const long long stride = (long long)gridDim.x * blockDim.x, i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb.kind == CTGAN_FILTER_ROTATE) {              // wt[r',s',k,c] = w[R-1-r',S-1-s',c,k]
+        const long long n = (long long)R * S * C * K;
+        for (long long i = i0; i < n; i += stride) {
+            const int c = (int)(i % C); long long r = i / C;
+            const int k = (int)(r % K); r /= K;
+            const int s = (int)(r % S), rr = (int)(r / S);
+            out[i] = w[(((long long)(R - 1 - rr) * S + (S - 1 - s)) * C + c) * K + k];
+        }
+    } else if (jb.kind == CTGAN_FILTER_PHASES) {       // see repack_dgrad_phase_filter_kernel (igemm.hip)
+        const int Tr = (R + 1) / 2, Ts = (S + 1) / 2;
+        const long long per = (long long)Tr * Ts * K * C, n = 4 * per;
+        for (long long i = i0; i < n; i += stride) {
+            const int ph = (int)(i / per);
+            long long r = i - ph * per;
+            const int c = (int)(r % C); r /= C;
+            const int k = (int)(r % K); r /= K;
+            const int v = (int)(r % Ts), tt = (int)(r / Ts);
+            const int a = ph >> 1, b = ph & 1;
+            const int u = ((a + jb.pad_t) & 1) + 2 * (Tr - 1 - tt), x = ((b + jb.pad_l) & 1) + 2 * (Ts - 1 - v);
+            out[i] = (u < R && x < S) ? w[(((long long)u * S + x) * C + c) * K + k] : 0.f;
+        }
+    } else {                                            // spread (kind SPREAD) / rotated + swapped spread (SPREAD_FLIP)
+        const int flip = jb.kind == CTGAN_FILTER_SPREAD_FLIP;
+        const long long n = (long long)(R + 1) * (S + 1) * C * K;
+        for (long long i = i0; i < n; i += stride) {
+            const int k = (int)(i % K); long long r = i / K;
+            const int c = (int)(r % C); r /= C;
+            const int v = (int)(r % (S + 1)), u = (int)(r / (S + 1));
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int rr = u - a, ss = v - b;
+                    if (rr >= 0 && rr < R && ss >= 0 && ss < S) acc += w[(((long long)rr * S + ss) * C + c) * K + k];
+                }
+            const long long o = flip ? ((((long long)(R - u) * (S + 1) + (S - v)) * K + k) * C + c) : i;
+            out[o] = jb.scale * acc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -319,6 +370,24 @@ int ctgan_filter_fold(const float* w4, float* out, int32_t R, int32_t S, int32_t
     hipLaunchKernelGGL(filter_fold_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), w4, out, R, S, C,
                        K, scale, flip);
     return ctgan_check_launch("filter_fold");
+}
+
+int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t s) {
+    if (!jobs || n < 0) return ctgan_fail(CTGAN_E_BADARG, "filter_batch: bad argument");
+    for (int32_t base = 0; base < n; base += CTGAN_FILTER_BATCH) {
+        FilterJobs t;
+        const int m = n - base < CTGAN_FILTER_BATCH ? n - base : CTGAN_FILTER_BATCH;
+        for (int i = 0; i < m; ++i) {
+            t.j[i] = jobs[base + i];
+            if (!t.j[i].src || !t.j[i].dst || t.j[i].R <= 0 || t.j[i].S <= 0 || t.j[i].C <= 0 || t.j[i].K <= 0 || t.j[i].kind < 0 ||
+                t.j[i].kind > CTGAN_FILTER_SPREAD_FLIP)
+                return ctgan_fail(CTGAN_E_BADARG, "filter_batch: bad job %d", base + i);
+        }
+        hipLaunchKernelGGL(filter_batch_kernel, dim3(256, m), dim3(TPB), 0, static_cast<hipStream_t>(s), t);
+        const int rc = ctgan_check_launch("filter_batch");
+        if (rc) return rc;
+    }
+    return CTGAN_OK;
 }
 
 int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale, ctgan_stream_t s) {

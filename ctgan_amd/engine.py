@@ -8,6 +8,7 @@ static buffers.  With world_size > 1 the all-reduce and the Adam kernels stay ou
 """
 import torch
 
+from . import functional as F
 from . import gan_cifar_resnet as R
 from . import tflib as lib
 
@@ -35,6 +36,7 @@ class GraphedTrainer:
     def _d_body(self):
         t = self.t
         lib.bump_epoch()          # derived weight caches (rotated dgrad filters) must be rebuilt INSIDE this graph
+        F.prepare_filters()       # ... all of them in one or two launches
         t.rng.begin_step()
         out = t.d_losses(self.real, self.labels)
         grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
@@ -47,6 +49,7 @@ class GraphedTrainer:
     def _g_body(self):
         t = self.t
         lib.bump_epoch()
+        F.prepare_filters()
         t.rng.begin_step()
         out = t.g_losses()
         grads = torch.autograd.grad(out['cost'], t.g_params, allow_unused=True)

@@ -26,6 +26,7 @@ MASK_IN_DGRAD_EPILOGUE = _os.environ.get('CTGAN_MASK_EPI', '1') != '0'
 # Launch the weight gradient of a conv on a side stream, concurrently with its data gradient (the two are
 # independent): the prologue / epilogue of one kernel overlaps the MFMA stretch of the other.  A/B switch.
 WGRAD_SIDE_STREAM = _os.environ.get('CTGAN_WGRAD_STREAM', '0') != '0'
+WGRAD_SIDE_MAX_ROWS = int(_os.environ.get('CTGAN_WGRAD_STREAM_ROWS', '0'))     # 0 = any size; else only convs with N*P*Q <= this
 _side = {}
 
 
@@ -84,7 +85,8 @@ class ConvFn(Function):
         need_w = ctx.needs_input_grad[1] and ctx.want_w
         need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
         # first-order backward only (under create_graph the wgrad must stay an autograd node)
-        fork = WGRAD_SIDE_STREAM and need_w and gy.is_cuda and ctx.needs_input_grad[0] and not torch.is_grad_enabled()
+        fork = (WGRAD_SIDE_STREAM and need_w and gy.is_cuda and ctx.needs_input_grad[0] and not torch.is_grad_enabled()
+                and (WGRAD_SIDE_MAX_ROWS == 0 or ctx.N * g.P * g.Q <= WGRAD_SIDE_MAX_ROWS))
         ctx_join = None
         if fork:
             side = _side_stream(gy.device)
@@ -166,50 +168,89 @@ class ConvDgradFn(Function):
         return g_gy, g_w, g_b, None, None, None, None, g_res
 
 
-_REPACK = {}      # (epoch, data_ptr, R, S, C, K) -> (rotated / I-O-swapped filter, ready event, producer stream)
+# ---- derived-filter cache ---------------------------------------------------------------------------------
+# Registry parameters are used by several kernels per step in layouts other than HWIO: the rotated / phase-major
+# filters of the data gradients (dropout passes, GP backward and its double backward) and the spread filters of the
+# resampled convs.  Each derived layout lives in a persistent buffer that is rebuilt once per weight version
+# (`lib.epoch()`): lazily on first use, or - `prepare_filters()` - all of them in one or two launches at the start
+# of a step.  A consumer on another stream waits for the producer's event.
+class _FilterEntry:
+    __slots__ = ('src', 'buf', 'kind', 'pad', 'scale', 'epoch', 'ev', 'st', 'level')
+
+
+_FCACHE = {}          # (src data_ptr, kind, R, S, C, K, pad_t, pad_l, scale) -> _FilterEntry
+_SPREAD_BUFS = {}     # data_ptr of a cached spread buffer -> its entry (a spread filter's dgrad layouts are cached too)
+_hooked = [False]
+
+
+def clear_filter_cache():
+    _FCACHE.clear()
+    _SPREAD_BUFS.clear()
+
+
+def _mark_built(entries, ep):
+    st = ev = None
+    if entries and entries[0].buf.is_cuda:
+        st = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(st)
+    for e in entries:
+        e.epoch, e.ev, e.st = ep, ev, st
+
+
+def _cached_filter(src, kind, pad=(0, 0), scale=1.0):
+    """Derived layout `kind` of `src` (a registry Parameter, or a cached spread filter); None if not cacheable."""
+    from . import tflib as lib
+    ep = lib.epoch()
+    parent = None
+    if not isinstance(src, torch.nn.Parameter):
+        parent = _SPREAD_BUFS.get(src.data_ptr())
+        if parent is None or parent.epoch != ep:
+            return None
+    key = (src.data_ptr(), kind) + tuple(src.shape) + tuple(pad) + (scale,)
+    e = _FCACHE.get(key)
+    if e is None:
+        if not _hooked[0]:
+            lib.on_delete_all_params(clear_filter_cache)
+            _hooked[0] = True
+        e = _FilterEntry()
+        e.src = parent.buf if parent is not None else src
+        e.buf = torch.empty(K.filter_job_shape(kind, *src.shape), dtype=torch.float32, device=src.device)
+        e.kind, e.pad, e.scale, e.epoch, e.ev, e.st = kind, tuple(pad), scale, -1, None, None
+        e.level = 1 if parent is not None else 0
+        _FCACHE[key] = e
+        if kind in (K.FILTER_SPREAD, K.FILTER_SPREAD_FLIP):
+            _SPREAD_BUFS[e.buf.data_ptr()] = e
+    if e.epoch != ep:
+        K.filter_batch([(e.src, e.buf, e.kind, e.pad[0], e.pad[1], e.scale)])
+        _mark_built([e], ep)
+    elif e.ev is not None and torch.cuda.current_stream() != e.st:
+        torch.cuda.current_stream().wait_event(e.ev)
+    return e.buf
+
+
+def prepare_filters():
+    """Rebuild every known derived filter for the current weight version now, on the current stream: one launch
+    for the layouts derived from parameters, one for the dgrad layouts of spread filters."""
+    from . import tflib as lib
+    ep = lib.epoch()
+    for level in (0, 1):
+        todo = [e for e in _FCACHE.values() if e.level == level and e.epoch != ep]
+        if todo:
+            K.filter_batch([(e.src, e.buf, e.kind, e.pad[0], e.pad[1], e.scale) for e in todo])
+            _mark_built(todo, ep)
 
 
 def _repacked(w, g):
-    """Registry parameters are used by several data gradients per step (dropout passes, GP backward and its
-    double backward): rotate the filter once per weight update instead of once per launch.  A consumer on
-    another stream waits for the producer's event."""
-    from . import tflib as lib
-    ep = lib.epoch()
-    stable = isinstance(w, torch.nn.Parameter) or _DERIVED_PTRS.get(w.data_ptr()) == ep
-    if not (stable and K.dgrad_wants_repack(g)):
+    if not K.dgrad_wants_repack(g):
         return None
-    key = (ep, w.data_ptr(), g.R, g.S, g.C, g.K)
-    hit = _REPACK.get(key)
-    if hit is None:
-        for k in [k for k in _REPACK if k[0] != ep]:
-            del _REPACK[k]
-        wt = K.repack_filter(w, g)
-        ev, st = None, None
-        if wt.is_cuda:
-            st = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(st)
-        _REPACK[key] = (wt, ev, st)
-        return wt
-    wt, ev, st = hit
-    if ev is not None and torch.cuda.current_stream() != st:
-        torch.cuda.current_stream().wait_event(ev)
-    return wt
+    kind = K.dgrad_filter_kind(g)
+    return _cached_filter(w, kind, (g.pad_t, g.pad_l) if kind == K.FILTER_PHASES else (0, 0))
 
 
 def prepare_dgrad_filters(params):
-    """Rotate the filters of `params` now, on the current stream (call before forking side streams)."""
-    for w in params:
-        if w.dim() == 4:
-            R, S, C, Kout = w.shape
-        elif w.dim() == 2:
-            R, S, (C, Kout) = 1, 1, w.shape
-        else:
-            continue
-        g = ConvGeom(C, 1 if w.dim() == 2 else 8, 1 if w.dim() == 2 else 8, Kout, R, S, 1, False)
-        wv = w if w.dim() == 4 else None
-        if wv is not None:
-            _repacked(wv, g)
+    """Kept for callers that fork side streams: make sure the derived filters exist on the current stream."""
+    prepare_filters()
 
 
 def _wgrad_backward(ctx, ggw, ggb):
@@ -378,8 +419,6 @@ def linear(x, w, b=None):
 # spread(w) = sum of the four one-tap shifts of w: 16 taps per low-resolution pixel instead of 4 x 9 (2.25x
 # fewer multiplies, no full-resolution intermediate, no pool / upsample kernel).  The identity is exact in
 # real arithmetic; in fp32 it changes the summation order like any other GEMM tiling does.
-_DERIVED = {}         # (epoch, data_ptr of the parameter, scale, flip) -> spread filter
-_DERIVED_PTRS = {}    # data_ptr of a cached spread filter -> epoch (lets the dgrad repack cache key on it)
 RESAMPLE_FUSION = _os.environ.get('CTGAN_RESAMPLE_FUSION', '1') != '0'
 # residual blocks: the shortcut's gradient is added in the epilogue of the main branch's first data gradient
 FORK_FUSION = _os.environ.get('CTGAN_FORK_FUSION', '1') != '0'
@@ -392,27 +431,8 @@ class FilterSpreadFn(Function):
     def forward(ctx, w, scale, flip):
         ctx.scale, ctx.flip = scale, flip
         if isinstance(w, torch.nn.Parameter):
-            from . import tflib as lib
-            ep = lib.epoch()
-            key = (ep, w.data_ptr(), scale, flip)
-            hit = _DERIVED.get(key)
-            if hit is None:
-                for k in [k for k in _DERIVED if k[0] != ep]:
-                    _DERIVED_PTRS.pop(_DERIVED[k][0].data_ptr(), None)
-                    del _DERIVED[k]
-                out = K.filter_spread(w, scale, flip)
-                ev, st = None, None
-                if out.is_cuda:
-                    st = torch.cuda.current_stream()
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                _DERIVED[key] = (out, ev, st)
-                _DERIVED_PTRS[out.data_ptr()] = ep
-                return out.detach()
-            out, ev, st = hit
-            if ev is not None and torch.cuda.current_stream() != st:
-                torch.cuda.current_stream().wait_event(ev)
-            return out.detach()
+            buf = _cached_filter(w, K.FILTER_SPREAD_FLIP if flip else K.FILTER_SPREAD, (0, 0), scale)
+            return buf.detach()
         return K.filter_spread(w.contiguous(), scale, flip)
 
     @staticmethod

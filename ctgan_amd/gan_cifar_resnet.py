@@ -379,6 +379,7 @@ class Trainer:
 
     def d_step(self, real_int, labels, rnd=None, iteration=0, set_lr=True):
         """session.run([..., disc_train_op]) :402"""
+        F.prepare_filters()
         self.rng.begin_step()
         out = self.d_losses(real_int, labels, rnd)
         grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
@@ -389,6 +390,7 @@ class Trainer:
 
     def g_step(self, rnd=None, iteration=0, set_lr=True):
         """session.run([gen_train_op]) :397"""
+        F.prepare_filters()
         self.rng.begin_step()
         out = self.g_losses(rnd)
         grads = torch.autograd.grad(out['cost'], self.g_params, allow_unused=True)

@@ -402,6 +402,38 @@ def upsample2(x, scale):
     return y
 
 
+FILTER_ROTATE, FILTER_PHASES, FILTER_SPREAD, FILTER_SPREAD_FLIP = 0, 1, 2, 3
+
+
+def filter_job_shape(kind, R, S, C, Ko):
+    """Shape of the tensor a filter job writes (the dgrad layouts are opaque 1-D buffers)."""
+    if kind == FILTER_ROTATE:
+        return (R * S * C * Ko,)
+    if kind == FILTER_PHASES:
+        return (4 * ((R + 1) // 2) * ((S + 1) // 2) * C * Ko,)
+    return (R + 1, S + 1, Ko, C) if kind == FILTER_SPREAD_FLIP else (R + 1, S + 1, C, Ko)
+
+
+def filter_batch(jobs):
+    """jobs: list of (src [R,S,C,K], dst, kind, pad_t, pad_l, scale) - every derived filter in one launch per 24."""
+    from ._lib import FilterJob
+    if not jobs:
+        return
+    arr = (FilterJob * len(jobs))()
+    for i, (src, dst, kind, pad_t, pad_l, scale) in enumerate(jobs):
+        _need_dev(src, dst)
+        R, S, C, Ko = src.shape
+        assert src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == filter_job_shape(kind, R, S, C, Ko)
+        arr[i] = FilterJob(src.data_ptr(), dst.data_ptr(), R, S, C, Ko, kind, pad_t, pad_l, scale)
+    check(lib.ctgan_filter_batch(arr, len(jobs), _stream()), 'filter_batch')
+
+
+def dgrad_filter_kind(g):
+    """Which layout conv_dgrad wants pre-repacked for geometry g (mirror of dgrad_phase_mode in csrc/igemm.hip)."""
+    phase = g.stride == 2 and g.H % 2 == 0 and g.W % 2 == 0 and g.C % 4 == 0 and g.K % 32 == 0 and g.P * 2 == g.H and g.Q * 2 == g.W
+    return FILTER_PHASES if phase else FILTER_ROTATE
+
+
 def filter_spread(w, scale, flip):
     """[R,S,C,K] -> scale * (sum of the four one-tap shifts) as [(R+1),(S+1),C,K]; flip: rotated and I/O swapped
     [(R+1),(S+1),K,C] (the conv2d_transpose filter of UpsampleConv)."""

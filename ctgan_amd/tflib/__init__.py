@@ -81,10 +81,21 @@ def named_params_with_name(name, trainable_only=False):
     return [(n, p) for n, p in _params.items() if name in n and not (trainable_only and n in _non_trainable)]
 
 
+_delete_hooks = []
+
+
+def on_delete_all_params(fn):
+    """Register a callback run by delete_all_params (derived-weight caches hold references to parameters)."""
+    if fn not in _delete_hooks:
+        _delete_hooks.append(fn)
+
+
 def delete_all_params():
     _params.clear()
     _non_trainable.clear()
     bump_epoch()
+    for fn in _delete_hooks:
+        fn()
 
 
 def alias_params(replace_dict):

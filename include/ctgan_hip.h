@@ -140,6 +140,27 @@ int ctgan_filter_spread(const float* w, float* out, int32_t R, int32_t S, int32_
  * W = w4 (flip == 0) or its un-flipped view W[u,v,c,k] = w4[R-u, S-v, k, c] (flip != 0)                      */
 int ctgan_filter_fold(const float* w4, float* out, int32_t R, int32_t S, int32_t C, int32_t K, float scale,
                       int32_t flip, ctgan_stream_t stream);
+/* All derived filters of one weight update in a single launch (per CTGAN_FILTER_BATCH jobs): every job reads an
+ * HWIO filter src[R,S,C,K] and writes one derived layout.  `jobs` is a HOST array; it travels in the kernel
+ * arguments, so the call is hipGraph-capture safe.
+ *   CTGAN_FILTER_ROTATE      dst[R,S,K,C]            = what ctgan_conv2d_repack_filter writes for a stride-1 conv
+ *   CTGAN_FILTER_PHASES      dst[4][ceil(R/2)][ceil(S/2)][K][C] = ... for a stride-2 conv with pads (pad_t, pad_l)
+ *   CTGAN_FILTER_SPREAD      dst[(R+1),(S+1),C,K]    = ctgan_filter_spread(scale, flip = 0)
+ *   CTGAN_FILTER_SPREAD_FLIP dst[(R+1),(S+1),K,C]    = ctgan_filter_spread(scale, flip = 1)                  */
+#define CTGAN_FILTER_ROTATE 0
+#define CTGAN_FILTER_PHASES 1
+#define CTGAN_FILTER_SPREAD 2
+#define CTGAN_FILTER_SPREAD_FLIP 3
+#define CTGAN_FILTER_BATCH 24
+typedef struct ctgan_filter_job {
+    const float* src;
+    float* dst;
+    int32_t R, S, C, K;
+    int32_t kind;
+    int32_t pad_t, pad_l;
+    float scale;
+} ctgan_filter_job;
+int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t stream);
 /* y[n,c] = scale * sum_{hw} x[n,hw,c]  (tf.reduce_mean(axis=[2,3]) :179) on channels-last x    */
 int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale,
                       ctgan_stream_t stream);

@@ -78,7 +78,8 @@ def dgrad_wants_repack(g):
 @_export
 def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None):
     if wt is not None:
-        assert torch.equal(wt, repack_filter(w, g))
+        ref = repack_filter(w, g).reshape(-1)
+        assert torch.equal(wt.reshape(-1)[:ref.numel()], ref)
     full = TF.conv_transpose2d(gy, w.permute(3, 2, 0, 1), stride=g.stride)
     need_h, need_w = g.pad_t + g.H, g.pad_l + g.W
     full = TF.pad(full, (0, max(0, need_w - full.shape[3]), 0, max(0, need_h - full.shape[2])))
@@ -241,6 +242,18 @@ def filter_spread(w, scale, flip):
     if flip:
         out = torch.flip(out, (0, 1)).permute(0, 1, 3, 2)
     return out.contiguous()
+
+
+@_export
+def filter_batch(jobs):
+    for src, dst, kind, pad_t, pad_l, scale in jobs:
+        R, S, C, Ko = src.shape
+        if kind in (2, 3):
+            dst.copy_(filter_spread(src, scale, kind == 3))
+        else:       # the mock's conv_dgrad only knows the plain rotated layout; phase buffers are larger: fill the head
+            rot = torch.flip(src, (0, 1)).permute(0, 1, 3, 2).contiguous().reshape(-1)
+            dst.zero_()
+            dst[:rot.numel()] = rot
 
 
 @_export

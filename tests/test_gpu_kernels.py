@@ -554,3 +554,24 @@ def test_errors_surface_as_python_exceptions(K):
     x = torch.zeros(4, device='cuda')
     with pytest.raises(ValueError):
         K.dropout(x, x, 0.0)                               # keep must be in (0,1]
+
+
+def test_filter_batch_matches_single_kernels(K):
+    """ctgan_filter_batch (all derived filters of a weight update in one launch) against the stand-alone kernels."""
+    g = torch.Generator().manual_seed(9)
+    w3 = dev(torch.randn(3, 3, 64, 96, generator=g)); w4 = dev(torch.randn(4, 4, 32, 64, generator=g)); w5 = dev(torch.randn(5, 5, 32, 64, generator=g))
+    g3 = K.ConvGeom(64, 8, 8, 96, 3, 3, 1, False); g4 = K.ConvGeom(32, 8, 8, 64, 4, 4, 2, False); g5 = K.ConvGeom(32, 8, 8, 64, 5, 5, 2, False)
+    assert K.dgrad_filter_kind(g3) == K.FILTER_ROTATE and K.dgrad_filter_kind(g4) == K.FILTER_PHASES
+    jobs = []
+    for w, gg in ((w3, g3), (w4, g4), (w5, g5)):
+        kind = K.dgrad_filter_kind(gg)
+        jobs.append((w, torch.empty(K.filter_job_shape(kind, *w.shape), device='cuda'), kind, gg.pad_t, gg.pad_l, 1.0))
+    for flip, kind in ((False, K.FILTER_SPREAD), (True, K.FILTER_SPREAD_FLIP)):
+        jobs.append((w3, torch.empty(K.filter_job_shape(kind, *w3.shape), device='cuda'), kind, 0, 0, 0.25))
+    jobs = jobs * 6                                  # > CTGAN_FILTER_BATCH jobs: several launches
+    jobs = [(s, torch.empty_like(d), k, a, b, c) for (s, d, k, a, b, c) in jobs]
+    K.filter_batch(jobs)
+    for (src, dst, kind, pt, pl, scale), gg in zip(jobs[:3], (g3, g4, g5)):
+        assert torch.equal(dst, K.repack_filter(src, gg).reshape(-1))
+    assert torch.equal(jobs[3][1], K.filter_spread(w3, 0.25, False)) and torch.equal(jobs[4][1], K.filter_spread(w3, 0.25, True))
+    assert torch.equal(jobs[-1][1], jobs[4][1]) and torch.equal(jobs[-3][1].reshape(-1), jobs[2][1].reshape(-1))
