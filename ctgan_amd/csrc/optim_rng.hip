@@ -75,6 +75,31 @@ __global__ void rng_uniform_kernel(float* __restrict__ out, long long n, uint64_
         }
     }
 }
+// tf.nn.dropout with the uniform draw generated in the kernel: y = x/keep * floor(keep + u), u = element i of the
+// Philox stream (seed, sid, step) - exactly the value rng_uniform_kernel would have written at physical index i.
+__global__ void dropout_rng_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float keep, float inv,
+                                   uint64_t seed, uint32_t sid, const uint64_t* __restrict__ ctr) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long nblk = (n + 3) >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        uint32_t c[4];
+        draw4(seed, sid, step, (uint32_t)b, c);
+        const long long i = b * 4;
+        if (vec && i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            float4 o;
+            o.x = v.x * inv * floorf(keep + u01(c[0])); o.y = v.y * inv * floorf(keep + u01(c[1]));
+            o.z = v.z * inv * floorf(keep + u01(c[2])); o.w = v.w * inv * floorf(keep + u01(c[3]));
+            *reinterpret_cast<float4*>(y + i) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) y[i + k] = x[i + k] * inv * floorf(keep + u01(c[k]));
+        }
+    }
+}
 __global__ void rng_normal_kernel(float* __restrict__ out, long long n, uint64_t seed, uint32_t sid,
                                   const uint64_t* __restrict__ ctr) {
     const uint64_t step = ctr ? ctr[0] : 0;
@@ -161,6 +186,15 @@ int ctgan_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, 
     hipLaunchKernelGGL(rng_uniform_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0,
                        static_cast<hipStream_t>(s), out, (long long)n, seed, (uint32_t)stream_id, ctr, lo, hi);
     return ctgan_check_launch("rng_uniform");
+}
+int ctgan_dropout_rng(const float* x, float* y, int64_t n, float keep, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
+                      ctgan_stream_t s) {
+    if (!x || !y || n < 0 || n >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "dropout_rng: bad argument");
+    if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "dropout_rng: keep=%g not in (0,1]", keep);
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(dropout_rng_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, y,
+                       (long long)n, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr);
+    return ctgan_check_launch("dropout_rng");
 }
 int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t s) {
     if (!out || n < 0 || n >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "rng_normal: bad argument");

@@ -525,9 +525,31 @@ class DropoutFn(Function):
         return DropoutFn.apply(gy, u, ctx.keep), None, None
 
 
-def dropout(x, keep_prob, u):
+class DropoutRngFn(Function):
+    """tf.nn.dropout whose mask is regenerated from the Philox stream (seed, site, device step counter) wherever it
+    is needed (forward, backward, double backward): no uniform tensor, no mask tensor.  Linear in x, self-adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, keep, seed, sid, ctr, strides):
+        if strides is not None and tuple(x.stride()) != tuple(strides):
+            x = K.copy4d(x, torch.empty_strided(x.shape, strides, dtype=x.dtype, device=x.device))   # same physical order as the forward
+        ctx.cfg = (keep, seed, sid, ctr, tuple(x.stride()))
+        return K.dropout_rng(x, keep, seed, sid, ctr)
+
+    @staticmethod
+    def backward(ctx, gy):
+        keep, seed, sid, ctr, strides = ctx.cfg
+        return DropoutRngFn.apply(gy, keep, seed, sid, ctr, strides), None, None, None, None, None
+
+
+def dropout(x, keep_prob, u=None, rng=None):
+    """u: explicit uniform draw (parity tests); else the mask comes from `rng` (DeviceRNG) inside the kernel."""
     if keep_prob == 1.0:
         return x
+    if u is None:
+        if not K.is_dense(x):
+            x = x.contiguous()
+        return DropoutRngFn.apply(x, float(keep_prob), rng.seed, rng._sid(), rng.ctr, None)
     return DropoutFn.apply(x, u, float(keep_prob))
 
 

@@ -73,7 +73,7 @@ def Discriminator(inputs, u=None, rng=None):
     D = cfg.DIM
 
     def drop(x, i):
-        return F.dropout(x, 0.5, u[i] if u is not None else rng.uniform(*x.shape, channels_last=True))
+        return F.dropout(x, 0.5, u[i]) if u is not None else F.dropout(x, 0.5, rng=rng)
     output = inputs.reshape(-1, 3, 32, 32)
     output = _conv2d.Conv2D('Discriminator.1', 3, D, 5, output, stride=2)
     output = drop(LeakyReLU(output), 0)

@@ -210,16 +210,16 @@ def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None):
     """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186)."""
     D = cfg.DIM_D
 
-    def draw(i, like):
-        if u is not None:
-            return u[i]
-        return rng.uniform(*like.shape, channels_last=True)
+    def drop(i, x, kp):
+        if kp == 1.0:
+            return x
+        return F.dropout(x, kp, u[i]) if u is not None else F.dropout(x, kp, rng=rng)
 
-    out = F.dropout(h, kp1, None if kp1 == 1.0 else draw(0, h))
+    out = drop(0, h, kp1)
     out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None)
-    out = F.dropout(out, kp2, None if kp2 == 1.0 else draw(1, out))
+    out = drop(1, out, kp2)
     out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None)
-    out = F.dropout(out, kp3, None if kp3 == 1.0 else draw(2, out))
+    out = drop(2, out, kp3)
     out = nonlinearity(out)
     output2 = F.spatial_mean(out)
     output_wgan = _linear.Linear('Discriminator.Output', D, 1, output2).reshape(-1)

@@ -72,7 +72,7 @@ def Discriminator(inputs, u=None, rng=None):
     D = cfg.DIM
 
     def drop(x, i):
-        return F.dropout(x, 0.5, u[i] if u is not None else rng.uniform(*x.shape, channels_last=True))
+        return F.dropout(x, 0.5, u[i]) if u is not None else F.dropout(x, 0.5, rng=rng)
     output = inputs.reshape(-1, 1, 28, 28)
     output = _conv2d.Conv2D('Discriminator.1', 1, D, 5, output, stride=2)
     output = drop(LeakyReLU(output), 0)

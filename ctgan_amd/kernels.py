@@ -309,6 +309,15 @@ def dropout(x, u, keep):
     return y
 
 
+def dropout_rng(x, keep, seed, stream_id, ctr):
+    """dropout whose uniform draw is element i of the Philox stream (seed, stream_id, ctr[0]) at x's PHYSICAL index i."""
+    _need_dev(x)
+    assert ctr.is_cuda and ctr.dtype == torch.int64
+    y = _ew_out(x)
+    check(lib.ctgan_dropout_rng(_ptr(x), _ptr(y), x.numel(), keep, seed, stream_id, _ptr(ctr), _stream()), 'dropout_rng')
+    return y
+
+
 def tanh_fwd(x):
     _need_dev(x)
     y = _ew_out(x)

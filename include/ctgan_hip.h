@@ -235,6 +235,11 @@ int ctgan_pack(const float* const* srcs, const int64_t* dst_offs, const int64_t*
 /* ---- RNG: Philox4x32-10 counter-based streams (tf.random_uniform / tf.random_normal /
  *      dropout masks :157,202,277,319).  counter base is read from device memory
  *      (`ctr[0]`, advanced by ctgan_rng_advance) so captured graphs draw fresh numbers. -------- */
+/* tf.nn.dropout with its mask drawn inside the kernel: y[i] = x[i]/keep * floor(keep + u_i), where u_i is what
+ * ctgan_rng_uniform(out, n, seed, stream_id, ctr, 0, 1) writes to out[i].  The backward (and its backward) is the
+ * same call on the gradient with the same (seed, stream_id, ctr) - no mask tensor is stored.              */
+int ctgan_dropout_rng(const float* x, float* y, int64_t n, float keep, uint64_t seed, uint64_t stream_id,
+                      const uint64_t* ctr, ctgan_stream_t stream);
 int ctgan_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
                       float lo, float hi, ctgan_stream_t stream);
 int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,

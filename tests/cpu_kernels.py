@@ -174,6 +174,13 @@ def dropout(x, u, keep):
 
 
 @_export
+def dropout_rng(x, keep, seed, stream_id, ctr):
+    u = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype)
+    rng_uniform(u, seed, stream_id, ctr)
+    return dropout(x, u, keep)
+
+
+@_export
 def tanh_fwd(x):
     return _like(torch.tanh(x), x)
 

@@ -575,3 +575,30 @@ def test_filter_batch_matches_single_kernels(K):
         assert torch.equal(dst, K.repack_filter(src, gg).reshape(-1))
     assert torch.equal(jobs[3][1], K.filter_spread(w3, 0.25, False)) and torch.equal(jobs[4][1], K.filter_spread(w3, 0.25, True))
     assert torch.equal(jobs[-1][1], jobs[4][1]) and torch.equal(jobs[-3][1].reshape(-1), jobs[2][1].reshape(-1))
+
+
+def test_fused_philox_dropout_equals_draw_then_dropout(K):
+    """ctgan_dropout_rng regenerates the mask from (seed, site, device counter): bit-identical to drawing the
+    uniform tensor first; backward and double backward reuse the same mask."""
+    import ctgan_amd.functional as F
+    from ctgan_amd.rng import DeviceRNG
+    g = torch.Generator().manual_seed(2)
+    x = cl(torch.randn(6, 128, 8, 8, generator=g))
+    ctr = torch.full((1,), 5, dtype=torch.int64, device='cuda')
+    u = K.rng_uniform(K.empty_cl(6, 128, 8, 8, 'cuda'), 77, 3, ctr)
+    assert torch.equal(K.dropout_rng(x, 0.8, 77, 3, ctr), K.dropout(x, u, 0.8))
+    xs = dev(torch.randn(1001, generator=g))                      # ragged tail, 1-D
+    us = K.rng_uniform(torch.empty(1001, device='cuda'), 77, 4, ctr)
+    assert torch.equal(K.dropout_rng(xs, 0.5, 77, 4, ctr), K.dropout(xs, us, 0.5))
+    rng = DeviceRNG(seed=77, rank=0, device='cuda'); rng.ctr.fill_(5)
+    rng.begin_step(); rng._site = 3
+    xr = x.clone().requires_grad_(True)
+    y = F.dropout(xr, 0.8, rng=rng)
+    assert torch.equal(y, K.dropout(x, u, 0.8))
+    gy = dev(torch.randn(6, 128, 8, 8, generator=g)).requires_grad_(True)   # NCHW-contiguous: other physical order than x
+    (gx,) = torch.autograd.grad(y, xr, gy, create_graph=True)
+    m = K.dropout(torch.ones_like(x), u, 0.8)
+    assert relerr(gx, gy.detach() * m) < 1e-6
+    v = cl(torch.randn(6, 128, 8, 8, generator=g))
+    (ggy,) = torch.autograd.grad(gx, gy, v)                        # double backward: the same mask again
+    assert relerr(ggy, v * m) < 1e-6
