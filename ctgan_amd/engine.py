@@ -20,6 +20,12 @@ class GraphedTrainer:
         dev = trainer.dev
         self.real = torch.zeros(B, R.cfg.OUTPUT_DIM, dtype=torch.int32, device=dev)
         self.labels = torch.zeros(B, dtype=torch.int32, device=dev)
+        # fake batches come from one batched generator forward per iteration (Trainer.generate_fakes)
+        self.batch_fakes = R.BATCH_FAKES
+        self.labels_all = torch.zeros(B * R.cfg.N_CRITIC, dtype=torch.int32, device=dev)
+        self.fake = torch.zeros(B, R.cfg.OUTPUT_DIM, dtype=torch.float32, device=dev) if self.batch_fakes else None
+        self.f_graph = None
+        self.fake_all = None
         self.adam_in_graph = trainer.world == 1
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
@@ -38,13 +44,17 @@ class GraphedTrainer:
         lib.bump_epoch()          # derived weight caches (rotated dgrad filters) must be rebuilt INSIDE this graph
         F.prepare_filters()       # ... all of them in one or two launches
         t.rng.begin_step()
-        out = t.d_losses(self.real, self.labels)
+        out = t.d_losses(self.real, self.labels, fake=self.fake)
         grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
         t.d_opt.gather_grads(grads)
         if self.adam_in_graph:
             t.d_opt.step(1.0)
         t.rng.end_step()
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
+
+    def _f_body(self):
+        lib.bump_epoch()
+        return self.t.generate_fakes(self.labels_all)
 
     def _g_body(self):
         t = self.t
@@ -68,6 +78,8 @@ class GraphedTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
+                if self.batch_fakes:
+                    self._f_body()
                 self._d_body()
                 self._g_body()
         torch.cuda.current_stream().wait_stream(s)
@@ -78,6 +90,10 @@ class GraphedTrainer:
         self.g_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_graph, pool=self.d_graph.pool()):
             self.g_out = self._g_body()
+        if self.batch_fakes:
+            self.f_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.f_graph, pool=self.d_graph.pool()):
+                self.fake_all = self._f_body()
         torch.cuda.synchronize()
         # undo the side effects of the warm-up passes on the optimizer slots
         for b, sn in zip((t.d_opt.m, t.d_opt.v, t.d_opt.state, t.g_opt.m, t.g_opt.v, t.g_opt.state), snap):
@@ -88,12 +104,16 @@ class GraphedTrainer:
     def graphed(self):
         return self.d_graph is not None
 
-    def d_step(self, real_int, labels, iteration=0):
+    def d_step(self, real_int, labels, iteration=0, fake=None):
         t = self.t
         if not self.graphed:
-            return t.d_step(real_int, labels, iteration=iteration)
+            return t.d_step(real_int, labels, iteration=iteration, fake=fake)
         self.real.copy_(real_int, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
+        if self.batch_fakes:
+            if fake is None:          # stand-alone critic step: draw its fake batch now (eager, no-grad)
+                fake = t.generate_fakes(self.labels)[0]
+            self.fake.copy_(fake, non_blocking=True)
         t.d_opt.set_lr(t.lr(iteration))
         self.d_graph.replay()
         if not self.adam_in_graph:
@@ -121,7 +141,20 @@ class GraphedTrainer:
         if iteration > 0:
             self.g_step(iteration)
         out = None
-        for _ in range(R.cfg.N_CRITIC):
-            data, labels = next_batch()
-            out = self.d_step(data, labels, iteration)
+        if not self.batch_fakes:
+            for _ in range(R.cfg.N_CRITIC):
+                data, labels = next_batch()
+                out = self.d_step(data, labels, iteration)
+            return out
+        batches = [next_batch() for _ in range(R.cfg.N_CRITIC)]
+        B = R.cfg.BATCH_SIZE
+        if self.graphed:
+            for i, (_, lab) in enumerate(batches):
+                self.labels_all[i * B:(i + 1) * B].copy_(lab, non_blocking=True)
+            self.f_graph.replay()
+            fakes = self.fake_all
+        else:
+            fakes = self.t.generate_fakes(torch.cat([lab for _, lab in batches], 0))
+        for i, (data, labels) in enumerate(batches):
+            out = self.d_step(data, labels, iteration, fake=fakes[i])
         return out

@@ -263,6 +263,10 @@ class _nullctx:
 GP_SIDE_STREAM = _os.environ.get('CTGAN_GP_STREAM', '0') != '0'
 
 
+# Draw the fake batches of all N_CRITIC critic steps of an iteration in one generator forward (Trainer.generate_fakes)
+BATCH_FAKES = _os.environ.get('CTGAN_BATCH_FAKES', '1') != '0'
+
+
 class Trainer:
     """Owns the optimizers, the random streams and the D/G step (the session of the reference)."""
 
@@ -286,14 +290,15 @@ class Trainer:
         return self._gp_side
 
     # ------------------------------------------------------------------ losses
-    def d_losses(self, real_int, labels, rnd=None):
+    def d_losses(self, real_int, labels, rnd=None, fake=None):
         """Critic loss graph :194-305.  `rnd` (parity mode) injects every random draw; see
         oracle/steps.make_rnd_resnet_d for the keys and shapes."""
         B = cfg.BATCH_SIZE
         rng = self.rng
         with torch.no_grad():
-            z = torch.cat(rnd['z'], 0) if rnd is not None else None
-            fake = Generator(B, labels, noise=z, groups=2, rng=rng)
+            if fake is None:      # `fake`: samples drawn earlier from the SAME generator weights (generate_fakes)
+                z = torch.cat(rnd['z'], 0) if rnd is not None else None
+                fake = Generator(B, labels, noise=z, groups=2, rng=rng)
             deq = rnd['dequant'] if rnd is not None else rng.uniform(B, cfg.OUTPUT_DIM, lo=0.0, hi=1. / 128)
             real = K.real_prep(real_int, deq, 256.0)
             alpha = rnd['alpha'] if rnd is not None else rng.uniform(B, 1)
@@ -377,11 +382,26 @@ class Trainer:
         decay = max(0., 1. - float(iteration) / cfg.ITERS) if cfg.DECAY else 1.
         return cfg.LR * decay
 
-    def d_step(self, real_int, labels, rnd=None, iteration=0, set_lr=True):
+    def generate_fakes(self, labels_all):
+        """The fake batches of the next len(labels_all)/B critic steps in ONE generator forward.  The generator does
+        not change between the N_CRITIC critic updates of an iteration (:393-404), so drawing their fake batches
+        together is the same computation as drawing them one per step - each critic step's batch keeps its own two
+        BN statistic groups (the reference's two towers, :207-213) - at 5x the rows per kernel launch."""
+        B = cfg.BATCH_SIZE
+        n = labels_all.shape[0]
+        assert n % B == 0
+        F.prepare_filters()
+        self.rng.begin_step()
+        with torch.no_grad():
+            fake = Generator(n, labels_all, groups=2 * (n // B), rng=self.rng)
+        self.rng.end_step()
+        return fake.reshape(n // B, B, cfg.OUTPUT_DIM)
+
+    def d_step(self, real_int, labels, rnd=None, iteration=0, set_lr=True, fake=None):
         """session.run([..., disc_train_op]) :402"""
         F.prepare_filters()
         self.rng.begin_step()
-        out = self.d_losses(real_int, labels, rnd)
+        out = self.d_losses(real_int, labels, rnd, fake=fake)
         grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
         self._apply(self.d_opt, grads, iteration, set_lr)
         self.rng.end_step()
@@ -412,9 +432,15 @@ class Trainer:
         if iteration > 0:
             self.g_step(iteration=iteration)
         out = None
-        for _ in range(cfg.N_CRITIC):
-            data, labels = next_batch()
-            out = self.d_step(data, labels, iteration=iteration)
+        if not BATCH_FAKES:
+            for _ in range(cfg.N_CRITIC):
+                data, labels = next_batch()
+                out = self.d_step(data, labels, iteration=iteration)
+            return out
+        batches = [next_batch() for _ in range(cfg.N_CRITIC)]
+        fakes = self.generate_fakes(torch.cat([lab for _, lab in batches], 0))
+        for i, (data, labels) in enumerate(batches):
+            out = self.d_step(data, labels, iteration=iteration, fake=fakes[i])
         return out
 
     def generate_samples(self, noise, labels):

@@ -189,3 +189,23 @@ def test_steps_match_oracle_with_fused_resampling_convs(cpu_kernels, monkeypatch
             _cmp(out['grads'][n], ref['grads'][n], 1e-3, 'ggrad ' + n)
     finally:
         R.configure()
+
+
+def test_batched_fake_generation_equals_per_step_generation(small):
+    """Trainer.generate_fakes draws the fake batches of all N_CRITIC critic steps in one generator forward with one
+    pair of BN statistic groups per step: row block i equals the generator run on step i's noise / labels alone."""
+    R, lib = small
+    g = torch.Generator().manual_seed(4)
+    B, NC = 4, 3
+    z = torch.randn(NC * B, 128, generator=g)
+    lab = torch.randint(0, 10, (NC * B,), generator=g, dtype=torch.int32)
+    allx = R.Generator(NC * B, lab, noise=z, groups=2 * NC)
+    for i in range(NC):
+        xi = R.Generator(B, lab[i * B:(i + 1) * B], noise=z[i * B:(i + 1) * B], groups=2)
+        _cmp(allx[i * B:(i + 1) * B], xi, 1e-6, 'step %d' % i)
+    tr = R.Trainer(seed=3)
+    fakes = tr.generate_fakes(lab[:2 * B])
+    assert tuple(fakes.shape) == (2, B, 3072) and torch.isfinite(fakes).all()
+    real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+    out = tr.d_step(real, lab[:B], fake=fakes[0])
+    assert torch.isfinite(out['cost']) and torch.equal(out['fake'], fakes[0])
