@@ -138,6 +138,106 @@ __global__ void mean_diff_bwd_kernel(const float* __restrict__ gout, int na, int
     gx[i] = gout[0] * (i < na ? sa / (float)na : sb / (float)nb);
 }
 
+
+// ---- all critic loss heads of one D step in one launch (forward) / one launch (backward) ------------------
+// d [3B], f [3B,nf], a [3B,ncls] are the outputs of the batched dropout passes: rows [0,B) real pass 1,
+// [B,2B) fake pass 1, [2B,3B) real pass 2.
+//   wgan  = mean(d[B:2B]) - mean(d[0:B])                                               (:244)
+//   CT_i  = l2*(d_i - d_{2B+i})^2 + 0.1*l2*mean_j (f_ij - f_{2B+i,j})^2;  ct = mean_i max(CT_i - M, 0)   (:288-291)
+//   acgan = mean_i softmax-CE(a[i], labels[i]),  i < B                                  (:246-248)
+//   out = {wgan + ct + scale*acgan, wgan, ct, acgan}
+__global__ __launch_bounds__(256) void critic_heads_fwd_kernel(const float* __restrict__ d, const float* __restrict__ f,
+                                                               const float* __restrict__ a, const int32_t* __restrict__ labels,
+                                                               int B, int nf, int ncls, float l2, float M, float scale,
+                                                               float* __restrict__ ct_i, float* __restrict__ probs,
+                                                               float* __restrict__ out) {
+    __shared__ float sh[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = w; i < B; i += 4) {                       // one wave per row
+        float s = 0.f;
+        for (int j = lane; j < nf; j += 64) { const float t = f[(long long)i * nf + j] - f[(long long)(2 * B + i) * nf + j]; s += t * t; }
+        s = wave_sum(s);
+        if (lane == 0) { const float t = d[i] - d[2 * B + i]; ct_i[i] = l2 * t * t + l2 * 0.1f * (s / (float)nf); }
+    }
+    __syncthreads();
+    float sr = 0.f, sf = 0.f, sc = 0.f, sl = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        sr += d[i]; sf += d[B + i];
+        sc += fmaxf(ct_i[i] - M, 0.f);
+        if (a) {
+            const float* z = a + (long long)i * ncls;
+            float mx = z[0];
+            for (int k = 1; k < ncls; ++k) mx = fmaxf(mx, z[k]);
+            float se = 0.f;
+            for (int k = 0; k < ncls; ++k) se += expf(z[k] - mx);
+            const float lse = logf(se);
+            for (int k = 0; k < ncls; ++k) probs[(long long)i * ncls + k] = expf(z[k] - mx - lse);
+            sl += (mx + lse) - z[labels[i]];
+        }
+    }
+    sr = block_sum(sr, sh); sf = block_sum(sf, sh); sc = block_sum(sc, sh); sl = block_sum(sl, sh);
+    if (threadIdx.x == 0) {
+        const float wgan = sf / (float)B - sr / (float)B, ct = sc / (float)B, ac = a ? sl / (float)B : 0.f;
+        out[0] = (wgan + ct) + scale * ac; out[1] = wgan; out[2] = ct; out[3] = ac;
+    }
+}
+// gradients w.r.t. d [3B], f [3B,nf], a [3B,ncls] in one pass (every element written, zeros included);
+// gout[4] = upstream gradients of {cost, wgan, ct, acgan}
+__global__ void critic_heads_bwd_kernel(const float* __restrict__ d, const float* __restrict__ f, const float* __restrict__ probs,
+                                        const int32_t* __restrict__ labels, const float* __restrict__ ct_i,
+                                        const float* __restrict__ gout, int n_gout, int B, int nf, int ncls, float l2, float M,
+                                        float scale, float* __restrict__ gd, float* __restrict__ gf, float* __restrict__ ga) {
+    const float g0 = gout[0], g1 = n_gout > 1 ? gout[1] : 0.f, g2 = n_gout > 1 ? gout[2] : 0.f, g3 = n_gout > 1 ? gout[3] : 0.f;
+    const float cw = (g0 + g1) / (float)B, cc = (g0 + g2) / (float)B, ca = (g0 * scale + g3) / (float)B;
+    const long long n_f = 3LL * B * nf, n_a = ga ? 3LL * B * ncls : 0, total = n_f + n_a + 3LL * B;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        if (t < n_f) {
+            const int row = (int)(t / nf), j = (int)(t - (long long)row * nf);
+            float v = 0.f;
+            if (row < B || row >= 2 * B) {
+                const int i = row < B ? row : row - 2 * B;
+                // tf.maximum(CT_i - M, 0): the gradient goes to the first argument where it is >= the second (TF MaximumGrad)
+                const float on = (ct_i[i] - M >= 0.f) ? cc : 0.f;
+                v = on * l2 * 0.1f * 2.f * (f[(long long)i * nf + j] - f[(long long)(2 * B + i) * nf + j]) / (float)nf;
+                if (row >= 2 * B) v = -v;
+            }
+            gf[t] = v;
+        } else if (t < n_f + n_a) {
+            const long long q = t - n_f;
+            const int row = (int)(q / ncls), k = (int)(q - (long long)row * ncls);
+            ga[q] = row < B ? ca * (probs[q] - (labels[row] == k ? 1.f : 0.f)) : 0.f;
+        } else {
+            const int row = (int)(t - n_f - n_a);
+            float v;
+            if (row < B || row >= 2 * B) {
+                const int i = row < B ? row : row - 2 * B;
+                const float on = (ct_i[i] - M >= 0.f) ? cc : 0.f;
+                v = on * l2 * 2.f * (d[i] - d[2 * B + i]);
+                v = row < B ? v - cw : -v;
+            } else {
+                v = cw;
+            }
+            gd[row] = v;
+        }
+    }
+}
+// accuracies of the clean pass (:249-266): logits [2B, ncls] (real rows then fake rows), labels [B]; acc[0] real, acc[1] fake
+__global__ __launch_bounds__(256) void accuracy2_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels, int B,
+                                                        int ncls, float* __restrict__ acc) {
+    __shared__ float sh[4];
+    float cr = 0.f, cf = 0.f;
+    for (int i = threadIdx.x; i < 2 * B; i += 256) {
+        const float* z = logits + (long long)i * ncls;
+        float mx = z[0]; int am = 0;
+        for (int k = 1; k < ncls; ++k) if (z[k] > mx) { mx = z[k]; am = k; }
+        const float hit = (am == labels[i < B ? i : i - B]) ? 1.f : 0.f;
+        if (i < B) cr += hit; else cf += hit;
+    }
+    cr = block_sum(cr, sh); cf = block_sum(cf, sh);
+    if (threadIdx.x == 0) { acc[0] = cr / (float)B; acc[1] = cf / (float)B; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -192,6 +292,31 @@ int ctgan_softmax_ce_bwd(const float* probs, const int32_t* labels, const float*
     hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3((b * ncls + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(s), probs,
                        labels, gout, b, ncls, glogits);
     return ctgan_check_launch("softmax_ce_bwd");
+}
+
+int ctgan_critic_heads_fwd(const float* d, const float* f, const float* a, const int32_t* labels, int32_t B, int32_t nf,
+                           int32_t ncls, float lambda2, float M, float acgan_scale, float* ct_i, float* probs, float* out,
+                           ctgan_stream_t s) {
+    if (!d || !f || !ct_i || !out || B <= 0 || nf <= 0 || (a && (!labels || !probs || ncls <= 0)))
+        return ctgan_fail(CTGAN_E_BADARG, "critic_heads_fwd: bad argument");
+    hipLaunchKernelGGL(critic_heads_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d, f, a, labels, B, nf, ncls,
+                       lambda2, M, acgan_scale, ct_i, probs, out);
+    return ctgan_check_launch("critic_heads_fwd");
+}
+int ctgan_critic_heads_bwd(const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
+                           const float* gout, int32_t n_gout, int32_t B, int32_t nf, int32_t ncls, float lambda2, float M,
+                           float acgan_scale, float* gd, float* gf, float* ga, ctgan_stream_t s) {
+    if (!d || !f || !ct_i || !gout || (n_gout != 1 && n_gout != 4) || !gd || !gf || B <= 0 || nf <= 0 || (ga && (!probs || !labels || ncls <= 0)))
+        return ctgan_fail(CTGAN_E_BADARG, "critic_heads_bwd: bad argument");
+    const long long total = 3LL * B * nf + (ga ? 3LL * B * ncls : 0) + 3LL * B;
+    hipLaunchKernelGGL(critic_heads_bwd_kernel, dim3(ctgan_blocks(total, 256)), dim3(256), 0, static_cast<hipStream_t>(s), d, f, probs,
+                       labels, ct_i, gout, n_gout, B, nf, ncls, lambda2, M, acgan_scale, gd, gf, ga);
+    return ctgan_check_launch("critic_heads_bwd");
+}
+int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32_t ncls, float* acc, ctgan_stream_t s) {
+    if (!logits || !labels || !acc || B <= 0 || ncls <= 0) return ctgan_fail(CTGAN_E_BADARG, "accuracy2: bad argument");
+    hipLaunchKernelGGL(accuracy2_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), logits, labels, B, ncls, acc);
+    return ctgan_check_launch("accuracy2");
 }
 
 int ctgan_mean_diff_fwd(const float* x, int32_t na, int32_t nb, float sa, float sb, float* out, ctgan_stream_t s) {

@@ -820,6 +820,46 @@ class MeanDiffFn(Function):
         return K.mean_diff_bwd(gout, *ctx.cfg), None, None, None, None
 
 
+class CriticHeadsFn(Function):
+    """All loss heads of the batched dropout passes in one kernel: (cost_without_gp, wgan, ct, acgan)."""
+
+    @staticmethod
+    def forward(ctx, d, f, a, labels, B, lam2, M, scale):
+        d, f = d.contiguous(), f.contiguous()
+        a = a.contiguous() if a is not None else None
+        out, ct_i, probs = K.critic_heads_fwd(d, f, a, labels, B, lam2, M, scale)
+        ctx.cfg = (B, lam2, M, scale)
+        ctx.labels = labels
+        ctx.has_a = a is not None
+        ctx.set_materialize_grads(False)
+        if a is not None:
+            ctx.save_for_backward(d, f, ct_i, probs)
+        else:
+            ctx.save_for_backward(d, f, ct_i)
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3):
+        B, lam2, M, scale = ctx.cfg
+        if ctx.has_a:
+            d, f, ct_i, probs = ctx.saved_tensors
+        else:
+            (d, f, ct_i), probs = ctx.saved_tensors, None
+        if g1 is None and g2 is None and g3 is None:         # the usual case: only the summed cost is differentiated
+            gout = g0.reshape(1).contiguous()
+        else:
+            z = lambda g: g.reshape(1) if g is not None else d.new_zeros(1)
+            gout = torch.cat([z(g0), z(g1), z(g2), z(g3)])
+        gd, gf, ga = K.critic_heads_bwd(d, f, probs, ctx.labels, ct_i, gout, B, lam2, M, scale)
+        return gd, gf, ga, None, None, None, None, None
+
+
+def critic_heads(d_all, f_all, a_all, labels, B, lam2=2.0, M=0.0, acgan_scale=1.0):
+    """(wgan + ct + acgan_scale*acgan, wgan, ct, acgan) of the batched dropout passes (rows: real pass 1, fake pass 1,
+    real pass 2)."""
+    return CriticHeadsFn.apply(d_all, f_all, a_all, labels, int(B), float(lam2), float(M), float(acgan_scale))
+
+
 def gradient_penalty(g, lam):
     return GradPenaltyFn.apply(g, float(lam))
 

@@ -331,19 +331,16 @@ class Trainer:
             u = None
         tail_in = _cat_rows(h, h[:B])
         d_all, f_all, a_all = DiscriminatorTail(tail_in, 0.8, 0.5, 0.5, u=u, rng=rng)
-        d1, d2_real = d_all[:2 * B], d_all[2 * B:]
-        f1_real, f2_real = f_all[:B], f_all[2 * B:]
-
         out = {}
-        wgan = F.mean_diff(d1, B, B, -1.0, 1.0)                              # mean(fake) - mean(real)  :244
-        ct = F.consistency_term(d1[:B], d2_real, f1_real, f2_real, cfg.LAMBDA_2, cfg.Factor_M)
-        if cfg.CONDITIONAL and cfg.ACGAN:
-            acgan, _ = F.softmax_cross_entropy(a_all[:B], labels)           # pass-1 logits, real half :246-248
+        # every loss head of the two dropout passes in one kernel (fwd) / one kernel (bwd): wgan :244, CT :288-291, ACGAN :246-248
+        use_ac = cfg.CONDITIONAL and cfg.ACGAN
+        heads, wgan, ct, acgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2, cfg.Factor_M,
+                                                cfg.ACGAN_SCALE if use_ac else 0.0)
+        if use_ac:
             with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
                 _, _, a_clean = DiscriminatorTail(h.detach(), 1.0, 1.0, 1.0)
-                _, hit_r = F.softmax_cross_entropy(a_clean[:B], labels)
-                _, hit_f = F.softmax_cross_entropy(a_clean[B:], labels)
-            out['acc_real'], out['acc_fake'] = hit_r / B, hit_f / B
+                acc = K.accuracy2(a_clean.contiguous(), labels, B)
+            out['acc_real'], out['acc_fake'] = acc[0], acc[1]
         else:
             acgan = None
         if side is not None:
@@ -351,10 +348,11 @@ class Trainer:
             for t in (gp, slopes, grads):
                 t.record_stream(torch.cuda.current_stream())
 
-        disc_wgan = wgan + ct + gp
-        cost = disc_wgan + cfg.ACGAN_SCALE * acgan if acgan is not None else disc_wgan
+        cost = heads + gp
+        with torch.no_grad():
+            disc_wgan = wgan + ct + gp          # logged only (disc_wgan :304)
         out.update(cost=cost, wgan=disc_wgan, acgan=acgan, wgan_only=wgan, ct=ct, gp=gp, slopes=slopes, fake=fake,
-                   real=real, d_real=d1[:B], d_fake=d1[B:], gp_grads=grads)
+                   real=real, d_real=d_all[:B], d_fake=d_all[B:2 * B], gp_grads=grads)
         return out
 
     def g_losses(self, rnd=None):

@@ -645,6 +645,39 @@ def pack(srcs, dst_offs, counts, flat):
     check(lib.ctgan_pack(P, O, C, n, _ptr(flat), _stream()), 'pack')
 
 
+def critic_heads_fwd(d, f, a, labels, B, lam2, M, scale):
+    """-> (out[4] = cost, wgan, ct, acgan; ct_i [B]; probs [B,ncls] or None)."""
+    _need_dev(d, f, a, labels)
+    assert d.is_contiguous() and f.is_contiguous() and d.numel() == 3 * B and f.shape[0] == 3 * B
+    assert a is None or (a.is_contiguous() and a.shape[0] == 3 * B)
+    out = torch.empty(4, dtype=torch.float32, device=d.device)
+    ct_i = torch.empty(B, dtype=torch.float32, device=d.device)
+    ncls = a.shape[1] if a is not None else 0
+    probs = torch.empty(B, ncls, dtype=torch.float32, device=d.device) if a is not None else None
+    check(lib.ctgan_critic_heads_fwd(_ptr(d), _ptr(f), _ptr(a), _ptr(labels), B, f.shape[1], ncls, lam2, M, scale, _ptr(ct_i),
+                                     _ptr(probs), _ptr(out), _stream()), 'critic_heads_fwd')
+    return out, ct_i, probs
+
+
+def critic_heads_bwd(d, f, probs, labels, ct_i, gout, B, lam2, M, scale):
+    _need_dev(d, f, probs, labels, ct_i, gout)
+    assert gout.is_contiguous() and gout.numel() in (1, 4)
+    gd = torch.empty_like(d); gf = torch.empty_like(f)
+    ncls = probs.shape[1] if probs is not None else 0
+    ga = torch.empty(3 * B, ncls, dtype=torch.float32, device=d.device) if probs is not None else None
+    check(lib.ctgan_critic_heads_bwd(_ptr(d), _ptr(f), _ptr(probs), _ptr(labels), _ptr(ct_i), _ptr(gout), gout.numel(), B, f.shape[1], ncls, lam2, M,
+                                     scale, _ptr(gd), _ptr(gf), _ptr(ga), _stream()), 'critic_heads_bwd')
+    return gd, gf, ga
+
+
+def accuracy2(logits, labels, B):
+    _need_dev(logits, labels)
+    assert logits.is_contiguous() and logits.shape[0] == 2 * B
+    acc = torch.empty(2, dtype=torch.float32, device=logits.device)
+    check(lib.ctgan_accuracy2(_ptr(logits), _ptr(labels), B, logits.shape[1], _ptr(acc), _stream()), 'accuracy2')
+    return acc
+
+
 def adam_advance(state, beta1, beta2):
     _need_dev(state)
     check(lib.ctgan_adam_advance(_ptr(state), beta1, beta2, _stream()), 'adam_advance')

@@ -392,6 +392,46 @@ def softmax_ce_bwd(probs, labels, gout):
 
 
 @_export
+def critic_heads_fwd(d, f, a, labels, B, lam2, M, scale):
+    wgan = d[B:2 * B].mean() - d[:B].mean()
+    ct_i = lam2 * (d[:B] - d[2 * B:]) ** 2 + 0.1 * lam2 * ((f[:B] - f[2 * B:]) ** 2).mean(dim=1)
+    ct = torch.clamp(ct_i - M, min=0).mean()
+    if a is not None:
+        probs = torch.softmax(a[:B], dim=1)
+        ac = -torch.log(probs[torch.arange(B), labels.long()]).mean()
+    else:
+        probs, ac = None, torch.zeros(())
+    return torch.stack([wgan + ct + scale * ac, wgan, ct, ac]).float(), ct_i, probs
+
+
+@_export
+def critic_heads_bwd(d, f, probs, labels, ct_i, gout, B, lam2, M, scale):
+    gout = gout.reshape(-1)
+    if gout.numel() == 1:
+        gout = torch.cat([gout, gout.new_zeros(3)])
+    cw, cc, ca = (gout[0] + gout[1]) / B, (gout[0] + gout[2]) / B, (gout[0] * scale + gout[3]) / B
+    on = (ct_i - M >= 0).to(d.dtype) * cc
+    gd = torch.zeros_like(d); gf = torch.zeros_like(f)
+    v = on * lam2 * 2 * (d[:B] - d[2 * B:])
+    gd[:B] = v - cw; gd[B:2 * B] = cw; gd[2 * B:] = -v
+    vf = on[:, None] * lam2 * 0.1 * 2 * (f[:B] - f[2 * B:]) / f.shape[1]
+    gf[:B] = vf; gf[2 * B:] = -vf
+    ga = None
+    if probs is not None:
+        ga = torch.zeros(3 * B, probs.shape[1], dtype=d.dtype)
+        oh = torch.zeros_like(probs); oh[torch.arange(B), labels.long()] = 1
+        ga[:B] = ca * (probs - oh)
+    return gd, gf, ga
+
+
+@_export
+def accuracy2(logits, labels, B):
+    am = logits.argmax(dim=1)
+    lab = labels.long()
+    return torch.stack([(am[:B] == lab).float().mean(), (am[B:] == lab).float().mean()])
+
+
+@_export
 def mean_diff_fwd(x, na, nb, sa, sb):
     out = x.new_zeros(())
     if na:

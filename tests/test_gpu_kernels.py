@@ -602,3 +602,38 @@ def test_fused_philox_dropout_equals_draw_then_dropout(K):
     v = cl(torch.randn(6, 128, 8, 8, generator=g))
     (ggy,) = torch.autograd.grad(gx, gy, v)                        # double backward: the same mask again
     assert relerr(ggy, v * m) < 1e-6
+
+
+@pytest.mark.parametrize('with_a', [True, False])
+def test_fused_critic_heads(K, with_a):
+    """ctgan_critic_heads_fwd/bwd against the separate reference formulas (:244-248, :288-291) in fp64 autograd."""
+    import ctgan_amd.functional as F
+    g = torch.Generator().manual_seed(8)
+    B, nf, ncls = 16, 128, 10
+    d = torch.randn(3 * B, generator=g); f = torch.randn(3 * B, nf, generator=g); a = torch.randn(3 * B, ncls, generator=g)
+    lab = torch.randint(0, ncls, (B,), generator=g, dtype=torch.int32)
+    lam2, M, scale = 2.0, 0.3, 0.7
+    dr = d.double().requires_grad_(True); fr = f.double().requires_grad_(True); ar = a.double().requires_grad_(True)
+    wgan = dr[B:2 * B].mean() - dr[:B].mean()
+    ct_i = lam2 * (dr[:B] - dr[2 * B:]) ** 2 + 0.1 * lam2 * ((fr[:B] - fr[2 * B:]) ** 2).mean(dim=1)
+    ct = torch.clamp(ct_i - M, min=0).mean()
+    ac = torch.nn.functional.cross_entropy(ar[:B], lab.long()) if with_a else torch.zeros((), dtype=torch.float64)
+    cost = wgan + ct + (scale * ac if with_a else 0)
+    dd = dev(d).requires_grad_(True); fd = dev(f).requires_grad_(True); ad = dev(a).requires_grad_(True)
+    got = F.critic_heads(dd, fd, ad if with_a else None, dev(lab), B, lam2, M, scale if with_a else 0.0)
+    for x, y in zip(got, (cost, wgan, ct, ac)):
+        assert abs(x.item() - y.item()) < 2e-5 * max(1.0, abs(y.item()))
+    ins = [dd, fd] + ([ad] if with_a else []); rins = [dr, fr] + ([ar] if with_a else [])
+    gg = torch.autograd.grad(got[0], ins, retain_graph=True); gr = torch.autograd.grad(cost, rins, retain_graph=True)
+    for x, y in zip(gg, gr):
+        assert relerr(x, y) < 2e-5
+    # gradients of the individual heads (n_gout = 4 path)
+    w = [0.3, -1.1, 0.6, 0.9]
+    comb = sum(wi * gi for wi, gi in zip(w, got)); combr = w[0] * cost + w[1] * wgan + w[2] * ct + w[3] * ac
+    gg = torch.autograd.grad(comb, ins); gr = torch.autograd.grad(combr, rins)
+    for x, y in zip(gg, gr):
+        assert relerr(x, y) < 2e-5
+    acc = K.accuracy2(dev(a[:2 * B].contiguous()), dev(lab), B)
+    am = a[:2 * B].argmax(dim=1)
+    assert abs(acc[0].item() - (am[:B] == lab.long()).float().mean().item()) < 1e-6
+    assert abs(acc[1].item() - (am[B:] == lab.long()).float().mean().item()) < 1e-6
