@@ -1141,13 +1141,20 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
         // measured on MI355X (tools_cfg_sweep.py, 128->128 3x3): the best tile shrinks with the number of
         // output rows so that >= ~1024 waves exist; the register ring depth RD bought nothing (kept at 1)
         const long long rows = M * (p.phases > 1 ? p.phases : 1) * ((p.Ng + 127) / 128);
-        if (rows >= 65536) cfg = 1;
+        if (rows >= 65536) {
+            // wave quantisation: 128x128 tiles run 2 per CU (512 slots), 64x128 tiles 3 per CU (768 slots); a last round
+            // that is mostly empty costs more than the smaller tile's lower MFMA : LDS ratio (measured: 640 tiles 252 us
+            // as 128x128, 198 us as 64x128)
+            const long long t1 = (rows + 127) / 128, t2 = (rows + 63) / 64;
+            const double e1 = (double)t1 / (double)(((t1 + 511) / 512) * 512), e2 = 0.95 * (double)t2 / (double)(((t2 + 767) / 768) * 768);
+            cfg = e1 >= e2 ? 1 : 2;
+        }
         else if (rows > 24576) cfg = 2;
-        else if (rows > 12288) cfg = 3;
+        else if (rows > 12288) cfg = (p.g.C % 64 == 0) ? 8 : 3;
         else if (rows > 4096) cfg = 4;
         else cfg = 5;
     }
-    if (((cfg == 4 || cfg == 6 || cfg == 7) && p.g.C % 64 != 0) || (cfg == 5 && p.g.C % 128 != 0)) cfg = cfg >= 6 ? 1 : 3;
+    if (((cfg == 4 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 9) && p.g.C % 64 != 0) || (cfg == 5 && p.g.C % 128 != 0)) cfg = (cfg == 6 || cfg == 7) ? 1 : 3;
     switch (cfg) {
         case 1: return launch_fwd_pipe<2, 2, 1, 2, 2, 1>(p, st);   // 128x128, 2 blocks/CU
         case 2: return launch_fwd_pipe<1, 4, 1, 2, 1, 1>(p, st);   // 64x128
@@ -1155,6 +1162,8 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
         case 4: return launch_fwd_pipe<1, 2, 2, 1, 1, 1>(p, st);   // 32x64, K split over 2 wave groups
         case 6: return launch_fwd_pipe<2, 2, 1, 2, 2, 1, 2>(p, st);  // 128x128, 64-deep stages (1 block/CU)
         case 7: return launch_fwd_pipe<1, 4, 1, 2, 1, 1, 2>(p, st);  // 64x128, 64-deep stages
+        case 8: return launch_fwd_pipe<2, 2, 2, 1, 1, 1>(p, st);   // 64x64, 8 waves: 2x2 tiles x 2 K groups
+        case 9: return launch_fwd_pipe<2, 1, 2, 1, 1, 1>(p, st);   // 64x32, 2 K groups
         default: return launch_fwd_pipe<1, 1, 4, 1, 1, 1>(p, st);  // 32x32, K split over 4 wave groups
     }
 }
