@@ -47,6 +47,9 @@ SIGNATURES = {
     'ctgan_last_error': (c_char_p, []),
     'ctgan_last_kernel': (c_char_p, []),
     'ctgan_debug_force_generic': (None, [c_int]),
+    'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
+    'ctgan_conv2d_wgrad_multi': (c_int, [POINTER(ConvDesc), c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), _p, _p, _p,
+                                         c_size_t, _p]),
     'ctgan_conv2d_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d_fwd': (c_int, [_D, _p, _p, _p, _p, _p, c_int, _p]),
     'ctgan_conv2d_dgrad': (c_int, [_D, _p, _p, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),

@@ -94,6 +94,12 @@ struct WgradParams {
     int relu_x;              // A values pass through max(.,0) when staged (wgrad of conv(relu(x)))
     int with_bias;           // 1: slab row Mtot receives the column sums of dy (bias gradient)
     unsigned x_bytes, dy_bytes;
+    // Multi-segment mode (pipelined kernel only): the pixel axis is the concatenation of up to CTGAN_WGRAD_MAX_SEGS
+    // (x, dy) pairs of the same geometry - the uses of one filter in different passes of a step - so their weight
+    // gradients come out of ONE launch, already summed.  A split never straddles segments: blockIdx.y in
+    // [split0[s], split0[s+1]) works on segment s only.
+    int nseg;
+    struct Seg { const float* X; const float* DY; int Kg, split0, relu_x, bias; unsigned x_bytes, dy_bytes; } seg[CTGAN_WGRAD_MAX_SEGS];
 };
 
 __device__ __forceinline__ bool src_index(int i, int shift, int mask, int lim, int& o) {
@@ -856,14 +862,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
     const int tiles_n = (p.Ng + BN - 1) / BN;
     const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int k_begin = blockIdx.y * p.chunk;
-    const int k_end = min(p.Kg, k_begin + p.chunk);
+    const float* Xp = p.X; const float* DYp = p.DY;
+    int seg_kg = p.Kg, split = blockIdx.y, relu_x = p.relu_x, seg_bias = 1;
+    unsigned x_bytes = p.x_bytes, dy_bytes = p.dy_bytes;
+    if (p.nseg > 0) {
+        int si = 0;
+#pragma unroll
+        for (int t = 1; t < CTGAN_WGRAD_MAX_SEGS; ++t)
+            if (t < p.nseg && (int)blockIdx.y >= p.seg[t].split0) si = t;
+        Xp = p.seg[si].X; DYp = p.seg[si].DY; seg_kg = p.seg[si].Kg; split = blockIdx.y - p.seg[si].split0;
+        relu_x = p.seg[si].relu_x; seg_bias = p.seg[si].bias; x_bytes = p.seg[si].x_bytes; dy_bytes = p.seg[si].dy_bytes;
+    }
+    const int k_begin = split * p.chunk;
+    const int k_end = min(seg_kg, k_begin + p.chunk);
     const int nk = (k_end - k_begin + BK - 1) / BK;
     const int PQ = g.P * g.Q;
     const int tap = m0 / g.C, c0 = m0 - tap * g.C;              // C % BM == 0
     const int ar = tap / g.S, as_ = tap - ar * g.S;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xp), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DYp), 0, dy_bytes, 0x00020000);
 
     auto fill_ptab = [&](int kt) {
         if (tid < BK) {
@@ -907,7 +924,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             float4 v = ra[i];
-            if (p.relu_x) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (relu_x) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(&As[(a_k0 + i * (NT / M4)) * BM + a_m4 * 4]) = v;
         }
 #pragma unroll
@@ -922,7 +939,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     float bsum = 0.f;
-    const bool do_bias = p.with_bias && tile_m == 0 && tid < BN;
+    const bool bias_row = p.with_bias && tile_m == 0 && tid < BN;       // this thread owns a column of the slab's bias row
+    const bool do_bias = bias_row && seg_bias;                           // ... and this segment's dy contributes to it
 
     if (nk > 0) {
         fill_ptab(0);
@@ -991,7 +1009,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
                 if (m < p.Mtot) out[(long long)m * p.Ng + col] = acc[i][j][e];
             }
     }
-    if (do_bias && n0 + tid < p.Ng) out[(long long)p.Mtot * p.Ng + n0 + tid] = bsum;
+    if (bias_row && n0 + tid < p.Ng) out[(long long)p.Mtot * p.Ng + n0 + tid] = bsum;
 }
 
 // out[i] = sum_s part[s][i]   (fixed order => deterministic)
@@ -1531,7 +1549,7 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
     p.X = x; p.DY = dy; p.OUT = dw;
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
-    p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0;
+    p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0; p.nseg = 0;
     p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = run_wgrad(p, dw, db, ws, ws_bytes, st);
@@ -1553,3 +1571,83 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
 }
 
 }  // extern "C"
+
+// ---- multi-segment weight gradient ---------------------------------------------------------------------------
+namespace {
+struct MultiPlan { WPlan w; int seg_splits[CTGAN_WGRAD_MAX_SEGS]; int splits; };
+MultiPlan multi_plan(const ctgan_conv_desc* d, int nseg, const int32_t* Ns) {
+    MultiPlan m;
+    const int mt = d->R * d->S * d->C;
+    long long kg = 0;
+    for (int i = 0; i < nseg; ++i) kg += (long long)Ns[i] * d->P * d->Q;
+    m.w = wgrad_plan(d->C, mt, d->K, (int)kg);
+    m.splits = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const long long k = (long long)Ns[i] * d->P * d->Q;
+        m.seg_splits[i] = (int)((k + m.w.chunk - 1) / m.w.chunk);
+        m.splits += m.seg_splits[i];
+    }
+    return m;
+}
+}  // namespace
+
+extern "C" size_t ctgan_conv2d_wgrad_multi_workspace_bytes(const ctgan_conv_desc* d, int32_t nseg, const int32_t* Ns) {
+    if (!d || !Ns || nseg < 1 || nseg > CTGAN_WGRAD_MAX_SEGS) return 0;
+    const MultiPlan m = multi_plan(d, nseg, Ns);
+    return (size_t)m.splits * ((size_t)d->R * d->S * d->C + 1) * d->K * sizeof(float);
+}
+
+extern "C" int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs, const float* const* dys,
+                                        const int32_t* Ns, const int32_t* seg_flags, float* dw, float* db, void* ws, size_t ws_bytes,
+                                        ctgan_stream_t stream) {
+    int rc = check_desc(d, "conv2d_wgrad_multi");
+    if (rc) return rc;
+    if (!xs || !dys || !Ns || !seg_flags || !dw || nseg < 1 || nseg > CTGAN_WGRAD_MAX_SEGS)
+        return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: bad argument");
+    if (g_force_generic || ctgan_is_small_linear(d) || ctgan_fewch_handles(d))
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_wgrad_multi: shape is served by another kernel family");
+    WgradParams p;
+    p.g = geom_from_x(d);
+    const Geom& g = p.g;
+    p.X = xs[0]; p.DY = dys[0]; p.OUT = dw;
+    p.Mtot = d->R * d->S * d->C; p.Ng = d->K;
+    p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
+    p.relu_x = 0; p.x_bytes = p.dy_bytes = 0;
+    const MultiPlan m = multi_plan(d, nseg, Ns);
+    const WPlan& w = m.w;
+    bool ok = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) && p.dy_k == 1 && (p.Ng % 4 == 0) &&
+              (p.dy_n % 4 == 0) && (p.dy_p % 4 == 0) && (p.dy_q % 4 == 0) &&
+              (w.tile == W128x128 || w.tile == W64x128 || w.tile == W64x64 || w.tile == W32x128);
+    long long kg = 0;
+    int split0 = 0;
+    bool any_bias = false;
+    for (int i = 0; i < nseg && ok; ++i) {
+        if (!xs[i] || !dys[i] || Ns[i] <= 0) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: bad segment %d", i);
+        ok = ok && ((reinterpret_cast<uintptr_t>(xs[i]) | reinterpret_cast<uintptr_t>(dys[i])) & 15) == 0;
+        const long long x_elems = (long long)(Ns[i] - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
+        const long long y_elems = (long long)(Ns[i] - 1) * p.dy_n + (long long)(g.P - 1) * p.dy_p + (long long)(g.Q - 1) * p.dy_q + p.Ng;
+        ok = ok && x_elems * 4 < (1LL << 32) && y_elems * 4 < (1LL << 32);
+        WgradParams::Seg& sg = p.seg[i];
+        sg.X = xs[i]; sg.DY = dys[i]; sg.Kg = Ns[i] * d->P * d->Q; sg.split0 = split0;
+        sg.relu_x = (seg_flags[i] & CTGAN_IN_RELU) ? 1 : 0; sg.bias = (seg_flags[i] & CTGAN_WGRAD_SEG_BIAS) ? 1 : 0;
+        sg.x_bytes = (unsigned)(x_elems * 4); sg.dy_bytes = (unsigned)(y_elems * 4);
+        any_bias = any_bias || sg.bias;
+        split0 += m.seg_splits[i];
+        kg += sg.Kg;
+    }
+    if (!ok) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_wgrad_multi: operands do not qualify for the pipelined kernel");
+    if (any_bias != (db != nullptr)) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: db must be given iff a segment carries the bias flag");
+    p.nseg = nseg; p.Kg = (int)kg;
+    const size_t need = (size_t)m.splits * (p.Mtot + 1) * p.Ng * sizeof(float);
+    if (!ws || ws_bytes < need) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: workspace too small (%zu < %zu)", ws_bytes, need);
+    WPlan w2 = w;
+    w2.splits = m.splits;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // a single split without bias would write dw directly; the multi path always goes through the slabs
+    if (w2.splits == 1 && !db) w2.splits = 1;
+    if (w.tile == W128x128) rc = launch_wgrad_pipe<2, 2, 2, 2>(p, w2, dw, db, ws, st);
+    else if (w.tile == W64x128) rc = launch_wgrad_pipe<1, 4, 2, 1>(p, w2, dw, db, ws, st);
+    else if (w.tile == W32x128) rc = launch_wgrad_pipe<1, 4, 1, 1>(p, w2, dw, db, ws, st);
+    else rc = launch_wgrad_pipe<2, 2, 1, 1>(p, w2, dw, db, ws, st);
+    return rc;
+}

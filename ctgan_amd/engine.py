@@ -45,7 +45,8 @@ class GraphedTrainer:
         F.prepare_filters()       # ... all of them in one or two launches
         t.rng.begin_step()
         out = t.d_losses(self.real, self.labels, fake=self.fake)
-        grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
+        with F.deferred_wgrads():
+            grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
         t.d_opt.gather_grads(grads)
         if self.adam_in_graph:
             t.d_opt.step(1.0)

@@ -49,6 +49,94 @@ def weight_grads(enabled):
         _WEIGHT_GRADS = old
 
 
+# ---- deferred weight gradients ------------------------------------------------------------------------------
+# Inside `deferred_wgrads()` (wrapped around the first-order torch.autograd.grad of a step) a conv's weight gradient is
+# not launched where autograd asks for it: the (x, dy) pair is queued under its filter, the FIRST request of a filter
+# returns the (still empty) result buffer, later requests of the same filter return None, and on exit every filter
+# gets ONE multi-segment launch (K.conv_wgrad_multi) that sums its uses - the dropout passes and the gradient-penalty
+# double backward - instead of one wgrad + reduction per use and an autograd `add` per extra use.
+_DEFER = {'on': False, 'groups': None, 'post': None}
+DEFER_WGRADS = _os.environ.get('CTGAN_DEFER_WGRADS', '1') != '0'
+
+
+class _WgradGroup:
+    __slots__ = ('g', 'segs', 'dw', 'db')
+
+
+@contextlib.contextmanager
+def deferred_wgrads():
+    if not DEFER_WGRADS or _DEFER['on']:
+        yield
+        return
+    _DEFER.update(on=True, groups={}, post=[])
+    try:
+        yield
+    finally:
+        groups, post = _DEFER['groups'], _DEFER['post']
+        _DEFER.update(on=False, groups=None, post=None)
+        for grp in groups.values():
+            _flush_group(grp)
+        for fn in post:
+            fn()
+
+
+def _flush_group(grp):
+    segs = grp.segs
+    try:
+        for i in range(0, len(segs), K.WGRAD_MAX_SEGS):
+            chunk = segs[i:i + K.WGRAD_MAX_SEGS]
+            if i == 0:
+                K.conv_wgrad_multi(chunk, grp.g, grp.dw, grp.db if any(sg[3] for sg in chunk) else None)
+                if grp.db is not None and not any(sg[3] for sg in chunk):
+                    grp.db.zero_()
+            else:                                               # more uses than one launch takes: accumulate
+                dw2 = torch.empty_like(grp.dw)
+                db2 = torch.empty_like(grp.db) if (grp.db is not None and any(sg[3] for sg in chunk)) else None
+                K.conv_wgrad_multi(chunk, grp.g, dw2, db2)
+                grp.dw.copy_(K.axpby(grp.dw, dw2, 1.0, 1.0))
+                if db2 is not None:
+                    grp.db.copy_(K.axpby(grp.db, db2, 1.0, 1.0))
+    except NotImplementedError:                                 # shape outside the pipelined kernel: one call per use
+        first = True
+        for x, gy, relu_x, with_bias in segs:
+            r = K.conv_wgrad(x, gy, grp.g, with_bias=with_bias, relu_x=relu_x)
+            gw, gb = r if with_bias else (r, None)
+            grp.dw.copy_(gw if first else K.axpby(grp.dw, gw, 1.0, 1.0))
+            if gb is not None:
+                grp.db.copy_(gb)
+            first = False
+
+
+def _wgrad(x, gy, w, g, relu_x, with_bias):
+    """Weight (and bias) gradient of one use of filter `w`: launched now, or queued (see deferred_wgrads).
+    Returns (gw, gb); either may be None when another request of the same filter already owns the result."""
+    stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _SPREAD_BUFS     # same identity in every pass of the step
+    defer = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
+             and g.C % 32 == 0 and g.K % 4 == 0 and not K.fewch_handles(g) and not (g.R == 1 and g.H == 1 and g.W == 1))
+    if not defer:
+        if with_bias:
+            return K.conv_wgrad(x, gy, g, with_bias=True, relu_x=relu_x)
+        return K.conv_wgrad(x, gy, g, relu_x=relu_x), None
+    if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous():
+        gy = K.to_channels_last(gy)
+    gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
+    key = (w.data_ptr(), gk)
+    grp = _DEFER['groups'].get(key)
+    if grp is not None and (grp.segs[0][0].stride()[1:] != x.stride()[1:] or grp.segs[0][1].stride()[1:] != gy.stride()[1:]):
+        key = (w.data_ptr(), gk, x.stride(), gy.stride())       # another memory layout of the same filter's operands
+        grp = _DEFER['groups'].get(key)
+    gw = gb = None
+    if grp is None:
+        grp = _WgradGroup()
+        grp.g, grp.segs, grp.db = g, [], None
+        grp.dw = gw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+        _DEFER['groups'][key] = grp
+    if with_bias and grp.db is None:
+        grp.db = gb = torch.empty(g.K, dtype=torch.float32, device=x.device)
+    grp.segs.append((x, gy, bool(relu_x), bool(with_bias)))
+    return gw, gb
+
+
 # --------------------------------------------------------------------------------- conv family
 class ConvFn(Function):
     """y = conv(x, w) [+ b] [+ resid]; relu_in: y = conv(relu(x), w) ... without materialising relu(x)
@@ -97,6 +185,8 @@ class ConvFn(Function):
                 else:
                     gw = K.conv_wgrad(x, gy, g, relu_x=ctx.relu_in)
             ctx_join = side
+        elif need_w and not torch.is_grad_enabled():
+            gw, gb = _wgrad(x, gy, w, g, ctx.relu_in, need_b)          # first-order pass: may be queued (deferred_wgrads)
         elif need_w and need_b:
             gw, gb = ConvWgradBiasFn.apply(x, gy, g, ctx.relu_in)       # bias gradient rides the wgrad kernel
         elif need_w:
@@ -162,7 +252,10 @@ class ConvDgradFn(Function):
         if ctx.needs_input_grad[0]:
             g_gy = ConvFn.apply(ggx, w, None, None, g, None, False)
         if ctx.needs_input_grad[1] and ctx.want_w:
-            g_w = ConvWgradFn.apply(ggx, gy, g, False)
+            if torch.is_grad_enabled():
+                g_w = ConvWgradFn.apply(ggx, gy, g, False)
+            else:
+                g_w, _ = _wgrad(ggx, gy, w, g, False, False)
         if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
             g_b = ChannelSumFn.apply(ggx)
         return g_gy, g_w, g_b, None, None, None, None, g_res
@@ -430,6 +523,7 @@ class FilterSpreadFn(Function):
     @staticmethod
     def forward(ctx, w, scale, flip):
         ctx.scale, ctx.flip = scale, flip
+        ctx.set_materialize_grads(False)      # an absent gradient (its wgrad was merged into another use's) must stay absent
         if isinstance(w, torch.nn.Parameter):
             buf = _cached_filter(w, K.FILTER_SPREAD_FLIP if flip else K.FILTER_SPREAD, (0, 0), scale)
             return buf.detach()
@@ -437,6 +531,17 @@ class FilterSpreadFn(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        if _DEFER['on'] and not torch.is_grad_enabled():
+            # g may be a queued weight gradient that is only filled when the queue is flushed: fold after that
+            g = g.contiguous()
+            R, S = g.shape[0] - 1, g.shape[1] - 1
+            C, Ko = (g.shape[3], g.shape[2]) if ctx.flip else (g.shape[2], g.shape[3])
+            out = torch.empty((R, S, C, Ko), dtype=torch.float32, device=g.device)
+            scale, flip = ctx.scale, ctx.flip
+            _DEFER['post'].append(lambda: K.filter_fold(g, scale, flip, out=out))
+            return out, None, None
         return FilterFoldFn.apply(g, ctx.scale, ctx.flip), None, None
 
 

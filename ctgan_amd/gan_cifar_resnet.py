@@ -400,7 +400,8 @@ class Trainer:
         F.prepare_filters()
         self.rng.begin_step()
         out = self.d_losses(real_int, labels, rnd, fake=fake)
-        grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
+        with F.deferred_wgrads():
+            grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
         self._apply(self.d_opt, grads, iteration, set_lr)
         self.rng.end_step()
         out['grads'] = dict(zip([n for n, _ in self.d_named], grads))

@@ -231,6 +231,36 @@ def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
     return (dw, db) if with_bias else dw
 
 
+WGRAD_MAX_SEGS = 3
+
+
+def conv_wgrad_multi(segs, g, dw, db=None):
+    """dw (and db) = sum over segments of the weight (bias) gradient: segs = [(x, gy, relu_x, with_bias), ...], all of
+    geometry g and identical strides.  One launch + one reduction (csrc: ctgan_conv2d_wgrad_multi); raises
+    NotImplementedError for shapes outside the pipelined kernel."""
+    n = len(segs)
+    assert 1 <= n <= WGRAD_MAX_SEGS
+    x0, gy0 = segs[0][0], segs[0][1]
+    for x, gy, _, _ in segs:
+        _need_dev(x, gy)
+        assert tuple(x.shape[1:]) == _x_phys_shape(g, 1)[1:] and tuple(gy.shape[1:]) == (g.K, g.P, g.Q)
+        assert x.stride() == x0.stride() or x.shape[0] == 1 or x0.shape[0] == 1 or x.stride()[1:] == x0.stride()[1:]
+        assert x.stride()[1:] == x0.stride()[1:] and gy.stride()[1:] == gy0.stride()[1:] and x.shape[0] == gy.shape[0]
+    assert tuple(dw.shape) == (g.R, g.S, g.C, g.K) and dw.is_contiguous()
+    d = g.desc(x0.shape[0], x0.stride(), gy0.stride())
+    # per-image strides must not depend on the segment's batch size (dense tensors: they do not)
+    Ns = (ctypes.c_int32 * n)(*[sg[0].shape[0] for sg in segs])
+    X = (ctypes.c_void_p * n)(*[sg[0].data_ptr() for sg in segs])
+    Y = (ctypes.c_void_p * n)(*[sg[1].data_ptr() for sg in segs])
+    Fl = (ctypes.c_int32 * n)(*[(2 if sg[2] else 0) | (4 if sg[3] else 0) for sg in segs])
+    nb = lib.ctgan_conv2d_wgrad_multi_workspace_bytes(ctypes.byref(d), n, Ns)
+    ws = workspace(nb, x0.device)
+    tot = sum(sg[0].shape[0] for sg in segs)
+    _timed(g, tot, lambda: check(lib.ctgan_conv2d_wgrad_multi(ctypes.byref(d), n, X, Y, Ns, Fl, _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+                                 'conv2d_wgrad_multi'))
+    return dw, db
+
+
 def im2col(x, g, cpad):
     """x logical [N,C,H,W] (any strides) -> channels-last [N,cpad,P,Q] patch tensor."""
     _need_dev(x)
@@ -454,13 +484,15 @@ def filter_spread(w, scale, flip):
     return out
 
 
-def filter_fold(w4, scale, flip):
+def filter_fold(w4, scale, flip, out=None):
     """Adjoint of filter_spread: [(R+1),(S+1),C,K] (flip: [(R+1),(S+1),K,C]) -> [R,S,C,K]."""
     _need_dev(w4)
     assert w4.is_contiguous()
     R, S = w4.shape[0] - 1, w4.shape[1] - 1
     C, Ko = (w4.shape[3], w4.shape[2]) if flip else (w4.shape[2], w4.shape[3])
-    out = torch.empty((R, S, C, Ko), dtype=torch.float32, device=w4.device)
+    if out is None:
+        out = torch.empty((R, S, C, Ko), dtype=torch.float32, device=w4.device)
+    assert tuple(out.shape) == (R, S, C, Ko) and out.is_contiguous()
     check(lib.ctgan_filter_fold(_ptr(w4), _ptr(out), R, S, C, Ko, scale, 1 if flip else 0, _stream()), 'filter_fold')
     return out
 

@@ -66,6 +66,18 @@ const char* ctgan_last_kernel(void);
 /* tests only: 1 = route every conv through the table-driven generic kernels                   */
 void ctgan_debug_force_generic(int on);
 
+/* Weight gradient of ONE filter over several (x, dy) pairs of the same geometry and strides (the uses of the filter in
+ * different passes of a step: the dropout passes and the gradient-penalty double backward,
+ * TF/CT_gan_cifar_resnet.py:284,335-336 sum them in tf.gradients): dw = sum_s wgrad(xs[s], dys[s]) in one launch + one
+ * fixed-order reduction.  d->N is ignored (Ns[s] rows per segment); seg_flags[s] = CTGAN_IN_RELU (x -> relu(x)) |
+ * CTGAN_WGRAD_SEG_BIAS (dys[s] contributes to db).  Returns CTGAN_E_UNSUPPORTED for shapes outside the pipelined
+ * kernel (caller falls back to ctgan_conv2d_wgrad per segment).                                               */
+#define CTGAN_WGRAD_MAX_SEGS 3
+#define CTGAN_WGRAD_SEG_BIAS 4
+size_t ctgan_conv2d_wgrad_multi_workspace_bytes(const ctgan_conv_desc* d, int32_t nseg, const int32_t* Ns);
+int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs, const float* const* dys,
+                             const int32_t* Ns, const int32_t* seg_flags, float* dw, float* db, void* ws,
+                             size_t ws_bytes, ctgan_stream_t stream);
 /* ---- convolution family  (replaces tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112,
  *      tf.nn.conv2d_transpose TF/tflib/ops/deconv2d.py:97-103, tf.matmul
  *      TF/tflib/ops/linear.py:132-137 (as 1x1 conv on a 1x1 image), and the conv gradient nodes

@@ -105,6 +105,21 @@ def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
     return (gw, gy.sum(dim=(0, 2, 3))) if with_bias else gw
 
 
+@_export
+def conv_wgrad_multi(segs, g, dw, db=None):
+    acc = None; accb = None
+    for x, gy, relu_x, with_bias in segs:
+        gw = conv_wgrad(x, gy, g, relu_x=relu_x)
+        acc = gw if acc is None else acc + gw
+        if with_bias:
+            b = gy.sum(dim=(0, 2, 3))
+            accb = b if accb is None else accb + b
+    dw.copy_(acc)
+    if db is not None:
+        db.copy_(accb)
+    return dw, db
+
+
 def _conv_wgrad(x, gy, g):
     xp = TF.pad(_xin(x, g), _pads(g)).detach().requires_grad_(False)
     wz = torch.zeros(g.K, g.C, g.R, g.S, dtype=x.dtype, requires_grad=True)
@@ -264,12 +279,15 @@ def filter_batch(jobs):
 
 
 @_export
-def filter_fold(w4, scale, flip):
+def filter_fold(w4, scale, flip, out=None):
     if flip:
         w4 = torch.flip(w4, (0, 1)).permute(0, 1, 3, 2)
     R, S = w4.shape[0] - 1, w4.shape[1] - 1
-    out = sum(w4[a:a + R, b:b + S] for a in (0, 1) for b in (0, 1))
-    return (out * scale).contiguous()
+    res = (sum(w4[a:a + R, b:b + S] for a in (0, 1) for b in (0, 1)) * scale).contiguous()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 @_export

@@ -637,3 +637,30 @@ def test_fused_critic_heads(K, with_a):
     am = a[:2 * B].argmax(dim=1)
     assert abs(acc[0].item() - (am[:B] == lab.long()).float().mean().item()) < 1e-6
     assert abs(acc[1].item() - (am[B:] == lab.long()).float().mean().item()) < 1e-6
+
+
+@pytest.mark.parametrize('C,H,Ko,k,st,Ns', [(128, 8, 128, 3, 1, (12, 4)), (128, 16, 128, 4, 2, (8, 4, 2)), (64, 8, 96, 1, 1, (5,)),
+                                            (128, 32, 128, 3, 1, (64, 16))])
+def test_multi_segment_wgrad(K, C, H, Ko, k, st, Ns):
+    """ctgan_conv2d_wgrad_multi: one launch over several (x, dy) pairs of one filter = the sum of the separate weight
+    gradients; per-segment relu-on-load and bias flags."""
+    g = torch.Generator().manual_seed(C + H + sum(Ns))
+    geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+    segs, ref_w, ref_b = [], 0, 0
+    for i, n in enumerate(Ns):
+        x = cl(torch.randn(n, C, H, H, generator=g)); gy = cl(torch.randn(n, Ko, geom.P, geom.Q, generator=g))
+        relu_x, with_bias = (i % 2 == 0), (i == 0)
+        segs.append((x, gy, relu_x, with_bias))
+        r = K.conv_wgrad(x, gy, geom, with_bias=with_bias, relu_x=relu_x)
+        ref_w = ref_w + (r[0] if with_bias else r).double()
+        if with_bias:
+            ref_b = ref_b + r[1].double()
+    dw = torch.empty(k, k, C, Ko, device='cuda'); db = torch.empty(Ko, device='cuda')
+    K.conv_wgrad_multi(segs, geom, dw, db)
+    assert 'igemm_wgrad_pipe' in K.last_kernel()
+    assert relerr(dw, ref_w) < 1e-5 and relerr(db, ref_b) < 1e-5
+    dw2 = torch.empty_like(dw)
+    K.conv_wgrad_multi([(x, gy, r, False) for x, gy, r, _ in segs], geom, dw2, None)
+    assert torch.equal(dw, dw2)                                    # the bias row does not perturb the weights
+    K.conv_wgrad_multi(segs, geom, dw2, db)
+    assert torch.equal(dw, dw2)                                    # deterministic

@@ -209,3 +209,41 @@ def test_batched_fake_generation_equals_per_step_generation(small):
     real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
     out = tr.d_step(real, lab[:B], fake=fakes[0])
     assert torch.isfinite(out['cost']) and torch.equal(out['fake'], fakes[0])
+
+
+def test_deferred_multi_segment_wgrads_equal_immediate_wgrads(cpu_kernels):
+    """functional.deferred_wgrads queues the weight gradients of a critic step per filter and launches one
+    multi-segment wgrad per filter on exit (dropout passes + GP double backward summed in the kernel): the parameter
+    gradients must equal those of the immediate path, for plain, pooled (spread-filter) and shortcut convs."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    B, dim = 4, 32
+    lib.set_seed(7)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    try:
+        R.build_params('cpu')
+        tr = R.Trainer(seed=1)
+        g = torch.Generator().manual_seed(100)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        rnd = osteps.make_rnd_resnet_d(B, dim, g, dtype=torch.float32)
+        res, ngroups = {}, 0
+        for mode in (False, True):
+            F.DEFER_WGRADS = mode
+            tr.rng.begin_step()
+            out = tr.d_losses(real, labels, rnd)
+            with F.deferred_wgrads():
+                grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+                if mode:
+                    ngroups = len(F._DEFER['groups'])
+                    assert all(len(grp.segs) == 2 for grp in F._DEFER['groups'].values())     # main pass + GP double backward
+            res[mode] = [None if x is None else x.clone() for x in grads]
+        assert ngroups >= 8
+        for (n, _), a, b in zip(tr.d_named, res[False], res[True]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                _cmp(b, a, 1e-5, 'deferred ' + n, atol=1e-7)
+    finally:
+        F.DEFER_WGRADS = True
+        R.configure()
