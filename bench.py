@@ -199,14 +199,19 @@ def measure_gp_unit(trainer, batch, torch):
     real_int, labels = batch
     x = torch.randn(B, R.cfg.OUTPUT_DIM, device=real_int.device).mul_(0.5)
 
+    import ctgan_amd.tflib as lib
+
     def unit():
+        lib.bump_epoch()                      # as in a training step: the weights changed since the last unit ...
+        F.prepare_filters()                   # ... so every derived filter layout is rebuilt (one or two launches)
         trainer.rng.begin_step()
         xi = x.detach().requires_grad_(True)
         with F.weight_grads(False):
             d = R.Discriminator(xi, labels, 0.8, 0.5, 0.5, rng=trainer.rng)[0]
         (g,) = torch.autograd.grad(d, xi, grad_outputs=torch.ones_like(d), create_graph=True)
         gp, _ = F.gradient_penalty(g, R.cfg.GP_LAMBDA)
-        return torch.autograd.grad(gp, trainer.d_params, allow_unused=True)
+        with F.deferred_wgrads():
+            return torch.autograd.grad(gp, trainer.d_params, allow_unused=True)
 
     try:
         for _ in range(2):

@@ -201,6 +201,120 @@ __global__ __launch_bounds__(NT) void m2f_kernel(const M2FParams p) {
     }
 }
 
+// ---- many -> few, 3x3, 128 channels: row-ring variant ----------------------------------------------------------
+// The band kernel above stages a tile, waits, computes, and so exposes the full load latency once per band.  Here
+// a workgroup walks a strip of output rows with a ring of 8 input-row slots in LDS that is filled by DIRECT
+// global->LDS loads (global_load_lds_dwordx4: no registers, no LDS store instruction): the rows of the next 4
+// iterations are always in flight while the current row is multiplied, and every input row is fetched once per
+// strip.  vmcnt is managed by hand (the compiler does not see asm loads): nothing else touches vector memory inside
+// the loop - the filter slice is loaded first, the outputs are parked in LDS and written after the loop.
+constexpr int RING_NT = 512, RING_SLOTS = 8, RING_AHEAD = 3;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_load16(const void* gptr, unsigned lds_byte_off /* wave-uniform */) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte_off) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n <= 8 here
+    switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(0xF70 | 0); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0xF70 | 1); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0xF70 | 2); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0xF70 | 3); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0xF70 | 4); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0xF70 | 5); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0xF70 | 6); break;
+        default: __builtin_amdgcn_s_waitcnt(0xF70 | 0); break;
+    }
+}
+
+template <int JS>
+__global__ __launch_bounds__(RING_NT) void m2f_ring_kernel(const M2FParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [8 slots][W+2 px][128 ch] then [band][JS][W] outputs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = tid & 31, grp = tid >> 5;                            // 16 pixel groups of 32 lanes (4 channels per lane)
+    const int W = p.W, H = p.H;
+    const int strips = (p.P + p.band - 1) / p.band;
+    const int n = blockIdx.x / strips, sidx = blockIdx.x - n * strips;
+    const int p0 = sidx * p.band, np = min(p.band, p.P - p0);
+    const int slot_f4 = (W + 2) * 32;
+    float4* tile4 = reinterpret_cast<float4*>(smem);
+    float* obuf = smem + RING_SLOTS * slot_f4 * 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < RING_SLOTS * 64; i += RING_NT) {             // halo columns: never written by the row loads
+        const int slot = i >> 6, side = (i >> 5) & 1, c = i & 31;
+        tile4[slot * slot_f4 + (side ? (W + 1) * 32 : 0) + c] = zero4;
+    }
+    f32x2 wlo[9][JS], whi[9][JS];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < JS; ++j) {
+            const float* q = p.w + p.w_off + (t / 3) * p.ws_r + (t % 3) * p.ws_s + (long long)(l * 4) * p.ws_c + j * p.ws_j;
+            wlo[t][j] = f32x2{q[0], q[p.ws_c]}; whi[t][j] = f32x2{q[2 * p.ws_c], q[3 * p.ws_c]};
+        }
+    __builtin_amdgcn_s_waitcnt(0xF70 | 0);                             // filter slice in registers before any row load is issued
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int LPR = W >> 4;                                            // direct loads per wave and row (2 pixels = 1 KB each)
+    const float* img = p.x + (long long)n * p.xs_n;
+    auto issue_row = [&](int r) {                                      // input row r into slot (r+1)%8; zero rows outside the image
+        const int slot = (r + 1) & (RING_SLOTS - 1);
+        if (r < 0 || r >= H) {
+            for (int i = tid; i < W * 32; i += RING_NT) tile4[slot * slot_f4 + 32 + i] = zero4;
+            return;
+        }
+        const float* rowp = img + (long long)r * p.xs_h + (lane & 31) * 4;
+        for (int c = 0; c < LPR; ++c) {
+            const int chunk = c * 8 + wave;
+            const unsigned dst = (unsigned)((slot * slot_f4 + (1 + 2 * chunk) * 32) * 16);
+            lds_load16(rowp + (long long)(2 * chunk + (lane >> 5)) * p.xs_w, __builtin_amdgcn_readfirstlane(dst));
+        }
+    };
+    const int last_row = p0 + np;                                      // highest input row any output of the strip reads
+    for (int r = p0 - 1; r <= p0 + RING_AHEAD && r <= last_row; ++r) issue_row(r);
+
+    for (int pp = 0; pp < np; ++pp) {
+        const int prow = p0 + pp;
+        if (prow + 1 + RING_AHEAD <= last_row) issue_row(prow + 1 + RING_AHEAD);
+        int after = 0;                                                 // loads issued after those of row prow+1
+        for (int r = prow + 2; r <= prow + 1 + RING_AHEAD && r <= last_row; ++r) after += (r >= 0 && r < H) ? LPR : 0;
+        wait_vmcnt(after);
+        __syncthreads();                                               // rows prow-1 .. prow+1 complete and visible to every wave
+        const float4* r0 = tile4 + ((prow + 0) & (RING_SLOTS - 1)) * slot_f4;      // slot of input row prow-1
+        const float4* r1 = tile4 + ((prow + 1) & (RING_SLOTS - 1)) * slot_f4;
+        const float4* r2 = tile4 + ((prow + 2) & (RING_SLOTS - 1)) * slot_f4;
+        for (int qc = grp; qc < W; qc += 16) {
+            f32x2 acc[JS];
+#pragma unroll
+            for (int j = 0; j < JS; ++j) acc[j] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float4* rowp = r == 0 ? r0 : (r == 1 ? r1 : r2);
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    float4 xv = rowp[(qc + s2) * 32 + l];
+                    if (p.relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
+                    const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
+#pragma unroll
+                    for (int j = 0; j < JS; ++j) acc[j] = pkfma(xhi, whi[r * 3 + s2][j], pkfma(xlo, wlo[r * 3 + s2][j], acc[j]));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < JS; ++j) {
+                float v = row16_sum(acc[j].x + acc[j].y);
+                v += __shfl_xor(v, 16, 64);
+                if (l == 0) obuf[(pp * JS + j) * W + qc] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < np * JS * W; i += RING_NT) {
+        const int qc = i % W, j = (i / W) % JS, pp = i / (W * JS);
+        p.y[n * p.ys_n + (long long)j * p.ys_c + (long long)(p0 + pp) * p.ys_p + (long long)qc * p.ys_q] = obuf[i] + (p.bias ? p.bias[j] : 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 struct FWParams {
     const float* many; long long ms_n, ms_h, ms_w; int MH, MW, CM;    // wide operand [N, MH, MW, CM], channels-last
@@ -412,7 +526,28 @@ static int launch_f2m(const F2MParams& p, int R, int S, int CS, hipStream_t st) 
     return ctgan_check_launch("fewch_f2m");
 }
 
+static bool m2f_ring_ok(const M2FParams& p, int R, int S) {
+    static const bool off = [] { const char* e = getenv("CTGAN_M2F_RING"); return e && atoi(e) == 0; }();
+    return !off && R == 3 && S == 3 && p.CM == 128 && p.pad_t == 1 && p.pad_l == 1 && (p.W == 32 || p.W == 16) && p.P == p.H && p.Q == p.W &&
+           (p.xs_w % 4 == 0) && (p.xs_h % 4 == 0) && (p.xs_n % 4 == 0);
+}
+
+template <int JS>
+static int launch_m2f_ring(M2FParams p, hipStream_t st) {
+    p.band = p.P >= 8 ? 8 : p.P;                                      // strip rows per workgroup
+    const int strips = (p.P + p.band - 1) / p.band;
+    const size_t smem = (size_t)RING_SLOTS * (p.W + 2) * 128 * 4 + (size_t)p.band * JS * p.W * 4;
+    int rc = set_smem(&m2f_ring_kernel<JS>, smem);
+    if (rc) return rc;
+    hipLaunchKernelGGL((m2f_ring_kernel<JS>), dim3(p.N * strips), dim3(RING_NT), smem, st, p);
+    return ctgan_check_launch("fewch_m2f_ring");
+}
+
 static int launch_m2f(const M2FParams& p, int R, int S, int JS, hipStream_t st) {
+    if (m2f_ring_ok(p, R, S)) {
+        if (JS == 3) return launch_m2f_ring<3>(p, st);
+        if (JS == 1) return launch_m2f_ring<1>(p, st);
+    }
     const int TR = p.band + R - 1, TW = p.Q + S - 1;
     const size_t smem = (size_t)TR * TW * p.CM * sizeof(float);
     const int grid = p.total < 512 ? p.total : 512;

@@ -1169,10 +1169,13 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
         }
         else if (rows > 24576) cfg = 2;
         else if (rows > 12288) cfg = (p.g.C % 64 == 0) ? 8 : 3;
-        else if (rows > 4096) cfg = 4;
+        else if (rows > 8192) cfg = 4;
+        else if (rows > 4096) cfg = (p.g.C % 128 == 0) ? 11 : 4;      // 64x64 x 4 K groups (16 waves): less L2 traffic per MFMA
+        else if (rows > 2048) cfg = (p.g.C % 128 == 0) ? 10 : 4;      // 32x64 x 4 K groups (8 waves, one workgroup per CU)
         else cfg = 5;
     }
-    if (((cfg == 4 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 9) && p.g.C % 64 != 0) || (cfg == 5 && p.g.C % 128 != 0)) cfg = (cfg == 6 || cfg == 7) ? 1 : 3;
+    if (((cfg == 4 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 9) && p.g.C % 64 != 0) || ((cfg == 5 || cfg == 10 || cfg == 11) && p.g.C % 128 != 0))
+        cfg = (cfg == 6 || cfg == 7) ? 1 : 3;
     switch (cfg) {
         case 1: return launch_fwd_pipe<2, 2, 1, 2, 2, 1>(p, st);   // 128x128, 2 blocks/CU
         case 2: return launch_fwd_pipe<1, 4, 1, 2, 1, 1>(p, st);   // 64x128
@@ -1182,6 +1185,8 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
         case 7: return launch_fwd_pipe<1, 4, 1, 2, 1, 1, 2>(p, st);  // 64x128, 64-deep stages
         case 8: return launch_fwd_pipe<2, 2, 2, 1, 1, 1>(p, st);   // 64x64, 8 waves: 2x2 tiles x 2 K groups
         case 9: return launch_fwd_pipe<2, 1, 2, 1, 1, 1>(p, st);   // 64x32, 2 K groups
+        case 10: return launch_fwd_pipe<1, 2, 4, 1, 1, 1>(p, st);  // 32x64, 4 K groups (8 waves, 1 workgroup / CU)
+        case 11: return launch_fwd_pipe<2, 2, 4, 1, 1, 1>(p, st);  // 64x64, 4 K groups (16 waves)
         default: return launch_fwd_pipe<1, 1, 4, 1, 1, 1>(p, st);  // 32x32, K split over 4 wave groups
     }
 }
