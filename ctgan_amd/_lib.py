@@ -36,6 +36,12 @@ class FilterJob(ctypes.Structure):
                 ('kind', c_int32), ('pad_t', c_int32), ('pad_l', c_int32), ('scale', ctypes.c_float)]
 
 
+class EpilogueExt(ctypes.Structure):
+    """struct ctgan_epilogue_ext (include/ctgan_hip.h)."""
+    _fields_ = [('drop_keep', ctypes.c_float), ('drop_seed', ctypes.c_uint64), ('drop_stream_id', ctypes.c_uint64),
+                ('drop_ctr', ctypes.c_void_p)]
+
+
 I64x4 = c_int64 * 4
 I32x4 = c_int32 * 4
 _p = c_void_p          # device pointers and the stream travel as void*
@@ -52,6 +58,8 @@ SIGNATURES = {
                                          c_size_t, _p]),
     'ctgan_conv2d_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d_fwd': (c_int, [_D, _p, _p, _p, _p, _p, c_int, _p]),
+    'ctgan_conv2d_fwd_ex': (c_int, [_D, _p, _p, _p, _p, _p, c_int, POINTER(EpilogueExt), _p]),
+    'ctgan_conv2d_dgrad_ex': (c_int, [_D, _p, _p, _p, _p, _p, _p, _p, c_size_t, c_int, POINTER(EpilogueExt), _p]),
     'ctgan_conv2d_dgrad': (c_int, [_D, _p, _p, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_conv2d_repack_filter': (c_int, [_D, _p, _p, _p]),
     'ctgan_conv2d_wgrad': (c_int, [_D, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),
@@ -61,6 +69,7 @@ SIGNATURES = {
     'ctgan_colsum_workspace_bytes': (c_size_t, [c_int64, c_int32]),
     'ctgan_lrelu_fwd': (c_int, [_p, _p, c_int64, c_float, _p]),
     'ctgan_lrelu_bwd': (c_int, [_p, _p, _p, c_int64, c_float, _p]),
+    'ctgan_lrelu_bwd_scaled': (c_int, [_p, _p, _p, c_int64, c_float, c_float, _p]),
     'ctgan_dropout': (c_int, [_p, _p, _p, c_int64, c_float, _p]),
     'ctgan_tanh_fwd': (c_int, [_p, _p, c_int64, _p]),
     'ctgan_tanh_bwd': (c_int, [_p, _p, _p, c_int64, _p]),

@@ -61,6 +61,7 @@ int launch2(const float* x, const float* z, float* y, long long n, F f, ctgan_st
 
 struct LReluF { float a; __device__ float operator()(float x) const { return x > 0.f ? x : a * x; } };
 struct LReluB { float a; __device__ float operator()(float g, float r) const { return r > 0.f ? g : a * g; } };
+struct LReluBS { float a, sc; __device__ float operator()(float g, float r) const { return (r > 0.f ? g : a * g) * sc; } };
 struct DropF { float keep, inv; __device__ float operator()(float x, float u) const { return x * inv * floorf(keep + u); } };
 struct TanhF { __device__ float operator()(float x) const { return tanhf(x); } };
 struct TanhB { __device__ float operator()(float g, float y) const { return g * (1.f - y * y); } };
@@ -297,6 +298,9 @@ int ctgan_lrelu_fwd(const float* x, float* y, int64_t n, float alpha, ctgan_stre
 }
 int ctgan_lrelu_bwd(const float* gy, const float* ref, float* gx, int64_t n, float alpha, ctgan_stream_t s) {
     return launch2(gy, ref, gx, n, LReluB{alpha}, s, "lrelu_bwd");
+}
+int ctgan_lrelu_bwd_scaled(const float* gy, const float* ref, float* gx, int64_t n, float alpha, float scale, ctgan_stream_t s) {
+    return launch2(gy, ref, gx, n, LReluBS{alpha, scale}, s, "lrelu_bwd_scaled");
 }
 int ctgan_dropout(const float* x, const float* u, float* y, int64_t n, float keep, ctgan_stream_t s) {
     if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "dropout: keep=%g not in (0,1]", keep);

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "philox.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -63,6 +64,11 @@ struct FwdParams {
     // dy with the taps of that parity only (no multiplies by the dilation zeros).  phases = 4: the M tile
     // index carries the phase; M / P / Q describe ONE phase grid; R,S = taps per phase (zero-padded to a common
     // count when R or S is odd).
+    // dropout of the RESULT inside the epilogue (vector epilogue only): y *= floor(keep + u)/keep with u = element
+    // off/4 .. of the Philox stream (seed, sid, ctr[0]) at the physical offset off of y - what ctgan_dropout_rng
+    // applied to y would compute.  Used for the dropout that follows a conv (forward) and for the mask a data
+    // gradient has to be multiplied with (backward).
+    int drop; float drop_keep; unsigned long long drop_seed; unsigned drop_sid; const unsigned long long* drop_ctr;
     int phases, ph_tiles_m;
     int ph_pad_t[2], ph_pad_l[2];              // top pad of row parity a / left pad of column parity b
     long long ph_b_stride;                     // filter elements per phase
@@ -592,6 +598,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
         __syncthreads();
         const int c4 = tid % C4, r0 = tid / C4;
         const int col = n0 + c4 * 4;
+        const uint64_t drop_step = p.drop ? (p.drop_ctr ? p.drop_ctr[0] : 0) : 0;
         if (col < p.Ng) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
@@ -626,6 +633,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
                     }
                     if (p.resid) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (p.drop) {
+                        uint32_t c[4];
+                        ctgan_philox::draw4(p.drop_seed, p.drop_sid, drop_step, (uint32_t)(off[u] >> 2), c);
+                        const float inv = 1.f / p.drop_keep;
+                        v.x *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[0])); v.y *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[1]));
+                        v.z *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[2])); v.w *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[3]));
+                    }
                     *reinterpret_cast<float4*>(p.D + off[u]) = v;
                 }
             }
@@ -1209,11 +1223,12 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
     const long long a_elems = (nimg - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
     const long long b_elems = (long long)(p.phases > 1 ? p.phases : 1) * g.R * g.S * g.C * p.Ng;
     const bool small = a_elems > 0 && a_elems * 4 < (1LL << 32) && b_elems * 4 < (1LL << 32) && p.b_off >= 0 && p.bs_r >= 0 && p.bs_s >= 0;
-    if (avec && bvec && small && p.Ng > 64 && !g_force_generic) {
+    if (avec && bvec && small && p.Ng > 64 && !g_force_generic && (!p.drop || p.d_vec)) {
         p.a_bytes = (unsigned)(a_elems * 4);
         p.b_bytes = (unsigned)(b_elems * 4);
         return dispatch_fwd_pipe(p, st);
     }
+    if (p.drop) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d: epilogue dropout needs the pipelined kernel with a vector epilogue");
     if (avec && bvec) return dispatch_fwd_tile<true, true>(p, st);
     if (avec) return dispatch_fwd_tile<true, false>(p, st);
     if (bvec) return dispatch_fwd_tile<false, true>(p, st);
@@ -1418,14 +1433,28 @@ size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
 
 int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                      float* y, int flags, ctgan_stream_t stream) {
+    return ctgan_conv2d_fwd_ex(d, x, w, bias, resid, y, flags, nullptr, stream);
+}
+
+static void set_drop(FwdParams& p, const ctgan_epilogue_ext* ext) {
+    p.drop = 0; p.drop_keep = 1.f; p.drop_seed = 0; p.drop_sid = 0; p.drop_ctr = nullptr;
+    if (ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f) {
+        p.drop = 1; p.drop_keep = ext->drop_keep; p.drop_seed = ext->drop_seed; p.drop_sid = (unsigned)ext->drop_stream_id;
+        p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
+    }
+}
+
+int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
+                        float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_fwd");
+    const bool want_drop = ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f;
     if (rc) return rc;
     if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
-    if (ctgan_is_small_linear(d) && !resid && !(flags & CTGAN_IN_RELU) && !g_force_generic) {
+    if (ctgan_is_small_linear(d) && !resid && !(flags & CTGAN_IN_RELU) && !g_force_generic && !want_drop) {
         ctgan_set_last_kernel("linear_small_fwd");
         return ctgan_small_linear_fwd(d, x, w, bias, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));
     }
-    if (!g_force_generic) {
+    if (!g_force_generic && !want_drop) {
         rc = ctgan_fewch_fwd(d, x, w, bias, resid, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, (flags & CTGAN_IN_RELU) ? 1 : 0,
                              static_cast<hipStream_t>(stream));
         if (rc) return rc < 0 ? rc : CTGAN_OK;
@@ -1440,6 +1469,7 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
     p.mask = nullptr;
     p.phases = 1;
+    set_drop(p, ext);
     return run_fwd(p, static_cast<hipStream_t>(stream));
 }
 
@@ -1458,17 +1488,24 @@ int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* 
 
 int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, const float* mask,
                        const float* resid, float* dx, void* ws, size_t ws_bytes, int flags, ctgan_stream_t stream) {
+    return ctgan_conv2d_dgrad_ex(d, dy, w, bias, mask, resid, dx, ws, ws_bytes, flags, nullptr, stream);
+}
+
+int ctgan_conv2d_dgrad_ex(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, const float* mask,
+                          const float* resid, float* dx, void* ws, size_t ws_bytes, int flags, const ctgan_epilogue_ext* ext,
+                          ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_dgrad");
+    const bool want_drop = ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f;
     if (rc) return rc;
     if (!dy || !w || !dx) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: null pointer");
     if (d->x_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: x_up (pool the result instead)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ctgan_is_small_linear(d) && !mask && !resid && !g_force_generic) {
+    if (ctgan_is_small_linear(d) && !mask && !resid && !g_force_generic && !want_drop) {
         ctgan_set_last_kernel("linear_small_dgrad");
         if (flags & CTGAN_DGRAD_W_REPACKED) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: small linear takes the original filter");
         return ctgan_small_linear_dgrad(d, dy, w, bias, dx, st);
     }
-    if (!mask && !resid && !(flags & CTGAN_DGRAD_W_REPACKED) && !g_force_generic) {
+    if (!mask && !resid && !(flags & CTGAN_DGRAD_W_REPACKED) && !g_force_generic && !want_drop) {
         rc = ctgan_fewch_dgrad(d, dy, w, bias, dx, st);
         if (rc) return rc < 0 ? rc : CTGAN_OK;
     }
@@ -1482,6 +1519,7 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
     p.ds_n = d->xs[0]; p.ds_k = d->xs[1]; p.ds_p = d->xs[2]; p.ds_q = d->xs[3];
     p.relu = 0;
     p.phases = 1;
+    set_drop(p, ext);
     const size_t need = dgrad_filter_elems(d) * sizeof(float);
     const bool pre = (flags & CTGAN_DGRAD_W_REPACKED) != 0;
     const bool repack = !pre && ws && ws_bytes >= need && (d->C % 4 == 0) && (d->K % 32 == 0);

@@ -143,7 +143,13 @@ class ConvFn(Function):
     (SAME conv described by geometry g)"""
 
     @staticmethod
-    def forward(ctx, x, w, b, resid, g, out_strides, relu_in=False, fork=False):
+    def forward(ctx, x, w, b, resid, g, out_strides, relu_in=False, fork=False, epi=None):
+        # epi (critic tail, dropout fused into the conv kernels): dict with
+        #   out_drop / in_drop = (keep, seed, site, ctr) dropout specs, out_relu, out_drop_bwd_fused
+        epi = epi or {}
+        ctx.out_drop, ctx.in_drop = epi.get('out_drop'), epi.get('in_drop')
+        ctx.out_relu = bool(epi.get('out_relu'))
+        ctx.out_drop_bwd_fused = bool(epi.get('out_drop_bwd_fused'))
         ctx.g = g
         ctx.N = x.shape[0]
         ctx.x_strides = x.stride()
@@ -152,10 +158,13 @@ class ConvFn(Function):
         ctx.has_resid = resid is not None
         ctx.relu_in = bool(relu_in)
         ctx.fork = bool(fork)
-        ctx.save_for_backward(x, w)
         if fork:
             ctx.set_materialize_grads(False)       # an unused shortcut branch must not cost a zero-filled add
-        y = K.conv_fwd(x, w, b, g, resid=resid, out_strides=out_strides, relu_in=relu_in)
+        y = K.conv_fwd(x, w, b, g, resid=resid, relu=ctx.out_relu, out_strides=out_strides, relu_in=relu_in, drop=ctx.out_drop)
+        if ctx.out_relu:
+            ctx.save_for_backward(x, w, y)         # y > 0  <=>  pre-activation > 0 and the element survived the dropout
+        else:
+            ctx.save_for_backward(x, w)
         if fork:
             # second output = x itself (for the block's shortcut branch): x then has ONE consumer in the autograd
             # graph and the shortcut's gradient arrives here, where it rides the dgrad epilogue as `resid`
@@ -164,10 +173,18 @@ class ConvFn(Function):
 
     @staticmethod
     def backward(ctx, gy, g_fork=None):
-        x, w = ctx.saved_tensors
+        if ctx.out_relu:
+            x, w, y = ctx.saved_tensors
+        else:
+            x, w = ctx.saved_tensors
         g = ctx.g
         if gy is None:                                   # fork only: y itself was not used
-            return g_fork, None, None, None, None, None, None, None
+            return g_fork, None, None, None, None, None, None, None, None
+        # gradient w.r.t. the conv result z, given the gradient w.r.t. y = dropout(relu(z))
+        if ctx.out_relu:
+            gy = LReluBwdFn.apply(gy, y, 0.0, (1.0 / ctx.out_drop[0]) if ctx.out_drop is not None else 1.0)
+        elif ctx.out_drop is not None and not ctx.out_drop_bwd_fused:
+            gy = DropoutRngFn.apply(gy, ctx.out_drop[0], ctx.out_drop[1], ctx.out_drop[2], ctx.out_drop[3], _cl_strides(gy.shape))
         gx = gw = gb = gr = None
         mask = x if ctx.relu_in else None               # ReLU backward rides the dgrad epilogue
         need_w = ctx.needs_input_grad[1] and ctx.want_w
@@ -205,8 +222,10 @@ class ConvFn(Function):
                     gx = LReluBwdFn.apply(ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, None), x, 0.0)
                     if g_fork is not None:
                         gx = add(gx, g_fork)
+                    if ctx.in_drop is not None:
+                        gx = DropoutRngFn.apply(gx, ctx.in_drop[0], ctx.in_drop[1], ctx.in_drop[2], ctx.in_drop[3], _cl_strides(gx.shape))
                 else:
-                    gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask, g_fork)
+                    gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask, g_fork, ctx.in_drop)
                 g_fork = None
             if g_fork is not None:
                 gx = add(gx, g_fork)
@@ -219,7 +238,7 @@ class ConvFn(Function):
             for t in (gw, gb):
                 if t is not None:
                     t.record_stream(torch.cuda.current_stream())
-        return gx, gw, gb, gr, None, None, None, None
+        return gx, gw, gb, gr, None, None, None, None, None
 
 
 class ConvDgradFn(Function):
@@ -227,20 +246,23 @@ class ConvDgradFn(Function):
     gradient of conv(relu(x)) w.r.t. x, mask = x)"""
 
     @staticmethod
-    def forward(ctx, gy, w, b, g, N, out_strides, mask=None, resid=None):
+    def forward(ctx, gy, w, b, g, N, out_strides, mask=None, resid=None, drop=None):
         ctx.g = g
         ctx.want_w = _WEIGHT_GRADS
         ctx.has_b = b is not None
         ctx.has_mask = mask is not None
         ctx.has_resid = resid is not None
+        ctx.drop = drop                                # dropout mask the result is multiplied with (after mask and resid)
         if mask is not None:
             ctx.save_for_backward(gy, w, mask)
         else:
             ctx.save_for_backward(gy, w)
-        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid)
+        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid, drop=drop)
 
     @staticmethod
     def backward(ctx, ggx):
+        if ctx.drop is not None:                        # the dropout mask is a constant of the second pass
+            ggx = DropoutRngFn.apply(ggx, ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], _cl_strides(ggx.shape))
         g_res = ggx if (ctx.has_resid and ctx.needs_input_grad[7]) else None    # added after the mask
         if ctx.has_mask:
             gy, w, mask = ctx.saved_tensors
@@ -258,7 +280,7 @@ class ConvDgradFn(Function):
                 g_w, _ = _wgrad(ggx, gy, w, g, False, False)
         if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
             g_b = ChannelSumFn.apply(ggx)
-        return g_gy, g_w, g_b, None, None, None, None, g_res
+        return g_gy, g_w, g_b, None, None, None, None, g_res, None
 
 
 # ---- derived-filter cache ---------------------------------------------------------------------------------
@@ -409,6 +431,12 @@ class ChannelSumFn(Function):
         return g.view(1, -1, 1, 1).expand(ctx.shape)
 
 
+def _cl_strides(shape):
+    """Strides of a dense channels-last tensor of logical shape [N,C,H,W] (what the conv kernels write)."""
+    N, C, H, W = shape
+    return (H * W * C, 1, W * C, C)
+
+
 def _no_up(g):
     return ConvGeom(g.C, g.H, g.W, g.K, g.R, g.S, g.stride, False)
 
@@ -442,7 +470,7 @@ class Col2imFn(Function):
         return Im2colFn.apply(gx, ctx.g, ctx.cpad), None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False, pool=False, fork=False):
+def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False, pool=False, fork=False, epi=None):
     """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`.
     relu_in=True computes conv(relu(x)) without materialising relu(x); pool=True returns
     mean_pool2(conv(x) + b) [+ resid]; x_up=True convolves upsample2(x)."""
@@ -452,9 +480,10 @@ def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_
     if fork:
         # returns (y, x'): x' is x for the caller's shortcut branch (see ConvFn.forward)
         if pool or x_up or out_nchw or C <= 4 or not FORK_FUSION:
+            assert epi is None
             return conv2d(x, w, b, stride, resid, x_up, out_nchw, relu_in, pool), x
         g = ConvGeom(C, H, W, Kout, R, S, stride, False)
-        return ConvFn.apply(x, w, b, resid, g, None, relu_in, True)
+        return ConvFn.apply(x, w, b, resid, g, None, relu_in, True, epi)
     fusable = RESAMPLE_FUSION and stride == 1 and R % 2 == 1 and S % 2 == 1 and C % 32 == 0 and Kout % 32 == 0
     if pool:
         if fusable and not out_nchw and H % 2 == 0 and W % 2 == 0:
@@ -484,7 +513,7 @@ def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_
     out_strides = None
     if out_nchw:
         out_strides = (Kout * g.P * g.Q, g.P * g.Q, g.Q, 1)
-    return ConvFn.apply(x, w, b, resid, g, out_strides, relu_in)
+    return ConvFn.apply(x, w, b, resid, g, out_strides, relu_in, False, epi)
 
 
 def conv2d_transpose(x, w_hwoi, b=None, stride=2):
@@ -595,15 +624,15 @@ class LReluFn(Function):
 
 class LReluBwdFn(Function):
     @staticmethod
-    def forward(ctx, gy, ref, alpha):
-        ctx.alpha = alpha
+    def forward(ctx, gy, ref, alpha, scale=1.0):
+        ctx.alpha, ctx.scale = alpha, scale
         ctx.save_for_backward(ref)
-        return K.lrelu_bwd(gy, ref, alpha)
+        return K.lrelu_bwd(gy, ref, alpha, scale)
 
     @staticmethod
     def backward(ctx, ggx):
         (ref,) = ctx.saved_tensors
-        return LReluBwdFn.apply(ggx, ref, ctx.alpha), None, None
+        return LReluBwdFn.apply(ggx, ref, ctx.alpha, ctx.scale), None, None, None
 
 
 def relu(x):
@@ -635,26 +664,39 @@ class DropoutRngFn(Function):
     is needed (forward, backward, double backward): no uniform tensor, no mask tensor.  Linear in x, self-adjoint."""
 
     @staticmethod
-    def forward(ctx, x, keep, seed, sid, ctr, strides):
+    def forward(ctx, x, keep, seed, sid, ctr, strides, bwd_fused=False):
         if strides is not None and tuple(x.stride()) != tuple(strides):
             x = K.copy4d(x, torch.empty_strided(x.shape, strides, dtype=x.dtype, device=x.device))   # same physical order as the forward
         ctx.cfg = (keep, seed, sid, ctr, tuple(x.stride()))
+        ctx.bwd_fused = bool(bwd_fused)       # the consumer's data gradient already carries this mask (conv dgrad epilogue)
         return K.dropout_rng(x, keep, seed, sid, ctr)
 
     @staticmethod
     def backward(ctx, gy):
+        if ctx.bwd_fused:
+            return gy, None, None, None, None, None, None
         keep, seed, sid, ctr, strides = ctx.cfg
-        return DropoutRngFn.apply(gy, keep, seed, sid, ctr, strides), None, None, None, None, None
+        return DropoutRngFn.apply(gy, keep, seed, sid, ctr, strides), None, None, None, None, None, None
 
 
-def dropout(x, keep_prob, u=None, rng=None):
-    """u: explicit uniform draw (parity tests); else the mask comes from `rng` (DeviceRNG) inside the kernel."""
+def drop_spec(rng, keep_prob):
+    """(keep, seed, site, counter) of the next dropout call site of `rng`; None for keep_prob == 1."""
+    if keep_prob == 1.0:
+        return None
+    return (float(keep_prob), rng.seed, rng._sid(), rng.ctr)
+
+
+def dropout(x, keep_prob, u=None, rng=None, spec=None, bwd_fused=False):
+    """u: explicit uniform draw (parity tests); else the mask comes from `rng` (DeviceRNG) inside the kernel.
+    spec: a drop_spec drawn earlier; bwd_fused: the consumer's data gradient applies the mask (conv epilogue)."""
     if keep_prob == 1.0:
         return x
     if u is None:
         if not K.is_dense(x):
             x = x.contiguous()
-        return DropoutRngFn.apply(x, float(keep_prob), rng.seed, rng._sid(), rng.ctr, None)
+        if spec is None:
+            spec = drop_spec(rng, keep_prob)
+        return DropoutRngFn.apply(x, spec[0], spec[1], spec[2], spec[3], None, bwd_fused)
     return DropoutFn.apply(x, u, float(keep_prob))
 
 

@@ -139,7 +139,7 @@ def UpsampleConv(name, input_dim, output_dim, filter_size, inputs, he_init=True,
 
 
 def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=None, no_dropout=False, labels=None,
-                  groups=1):
+                  groups=1, in_drop=None, out_epi=None):
     """:109-141  (resample: None, 'down', or 'up')"""
     if resample not in (None, 'down', 'up'):
         raise Exception('invalid resample value')
@@ -158,9 +158,13 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
         out = UpsampleConv(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
         out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
         return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2)
-    # resample None
+    # resample None.  in_drop: `inputs` is the result of that dropout - its mask is applied to the block's input gradient
+    # in Conv1's dgrad epilogue; out_epi: dropout (/ ReLU) applied to the block's result in Conv2's epilogue.
     if r1:
-        out, inputs = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=True, fork=True)
+        out, inputs = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=True, fork=True,
+                                     epi={'in_drop': in_drop} if in_drop is not None else None)
+    else:
+        assert in_drop is None
     if output_dim == input_dim:
         shortcut = inputs
     else:
@@ -168,7 +172,7 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
     if not r1:
         out = _conv2d.Conv2D(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
     out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
-    return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2)
+    return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2, epi=out_epi)
 
 
 def OptimizedResBlockDisc1(inputs):
@@ -210,17 +214,29 @@ def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None):
     """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186)."""
     D = cfg.DIM_D
 
-    def drop(i, x, kp):
-        if kp == 1.0:
-            return x
-        return F.dropout(x, kp, u[i]) if u is not None else F.dropout(x, kp, rng=rng)
+    fuse = DROP_FUSION and FUSE_RELU and F.FORK_FUSION and u is None and rng is not None and min(kp1, kp2, kp3) < 1.0 \
+        and max(kp1, kp2, kp3) < 1.0
+    if fuse:
+        # dropout -> block 3 -> dropout -> block 4 -> dropout -> relu with the masks inside the conv kernels: forward in the
+        # epilogue of the conv that produces the tensor, backward in the dgrad epilogue of the conv that consumed it
+        s1, s2, s3 = F.drop_spec(rng, kp1), F.drop_spec(rng, kp2), F.drop_spec(rng, kp3)
+        out = F.dropout(h, kp1, spec=s1, bwd_fused=True)
+        out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None, in_drop=s1,
+                            out_epi={'out_drop': s2, 'out_drop_bwd_fused': True})
+        out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None, in_drop=s2,
+                            out_epi={'out_drop': s3, 'out_relu': True})           # = relu(dropout(.)): both are >= 0 scalings
+    else:
+        def drop(i, x, kp):
+            if kp == 1.0:
+                return x
+            return F.dropout(x, kp, u[i]) if u is not None else F.dropout(x, kp, rng=rng)
 
-    out = drop(0, h, kp1)
-    out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None)
-    out = drop(1, out, kp2)
-    out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None)
-    out = drop(2, out, kp3)
-    out = nonlinearity(out)
+        out = drop(0, h, kp1)
+        out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None)
+        out = drop(1, out, kp2)
+        out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None)
+        out = drop(2, out, kp3)
+        out = nonlinearity(out)
     output2 = F.spatial_mean(out)
     output_wgan = _linear.Linear('Discriminator.Output', D, 1, output2).reshape(-1)
     if cfg.CONDITIONAL and cfg.ACGAN:
@@ -261,6 +277,8 @@ class _nullctx:
 # A/B switch: gradient-penalty branch on a side stream (parallel hipGraph branch).  Measured neutral (-1 %):
 # every kernel of the step already spans all CUs, so overlap only adds contention.  Default off.
 GP_SIDE_STREAM = _os.environ.get('CTGAN_GP_STREAM', '0') != '0'
+# A/B switch: the tail's dropouts (and the final ReLU) inside the neighbouring conv kernels (see DiscriminatorTail)
+DROP_FUSION = _os.environ.get('CTGAN_DROP_FUSION', '1') != '0'
 
 
 # Draw the fake batches of all N_CRITIC critic steps of an iteration in one generator forward (Trainer.generate_fakes)

@@ -154,8 +154,19 @@ def _x_phys_shape(g, N):
     return (N, g.C, g.H // 2, g.W // 2) if g.x_up else (N, g.C, g.H, g.W)
 
 
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False):
-    """y = conv(x,w) [+bias] [+resid] [relu]; relu_in: conv(relu(x)).  x logical [N,C,H(/2),W(/2)], w HWIO."""
+def _ext(drop):
+    """drop = (keep, seed, stream_id, ctr) -> ctgan_epilogue_ext*, or None."""
+    if drop is None:
+        return None
+    from ._lib import EpilogueExt
+    keep, seed, sid, ctr = drop
+    assert ctr.is_cuda and ctr.dtype == torch.int64
+    return ctypes.byref(EpilogueExt(keep, seed, sid, ctr.data_ptr()))
+
+
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None):
+    """y = conv(x,w) [+bias] [+resid] [relu] [dropout]; relu_in: conv(relu(x)).  x logical [N,C,H(/2),W(/2)], w HWIO.
+    drop = (keep, seed, stream_id, ctr): tf.nn.dropout of the result inside the epilogue (== dropout_rng(y, ...))."""
     _need_dev(x, w, bias, resid)
     N = x.shape[0]
     assert tuple(x.shape) == _x_phys_shape(g, N), (tuple(x.shape), _x_phys_shape(g, N))
@@ -167,8 +178,15 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
     if resid is not None:
         assert is_dense_like(resid, y)
     d = g.desc(N, x.stride(), y.stride())
-    _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y), (1 if relu else 0) | (2 if relu_in else 0), _stream()), 'conv2d_fwd'))
-    return y
+    fl = (1 if relu else 0) | (2 if relu_in else 0)
+    if drop is not None:
+        try:
+            _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y), fl, _ext(drop), _stream()), 'conv2d_fwd'))
+            return y
+        except NotImplementedError:          # no vector epilogue for this call: dropout as its own pass
+            pass
+    _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y), fl, _stream()), 'conv2d_fwd'))
+    return y if drop is None else dropout_rng(y, *drop)
 
 
 def repack_filter(w, g):
@@ -188,9 +206,10 @@ def dgrad_wants_repack(g):
     return g.C % 4 == 0 and g.K % 32 == 0 and not small_linear
 
 
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None):
-    """dx = conv^T(gy, w) [+ bias] [kept where mask > 0] [+ resid]; dx logical [N,C,H,W] (channels-last
-    unless out_strides given).  `wt` = repack_filter(w, g) computed earlier (skips the per-call repack)."""
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None, drop=None):
+    """dx = conv^T(gy, w) [+ bias] [kept where mask > 0] [+ resid] [dropout]; dx logical [N,C,H,W] (channels-last
+    unless out_strides given).  `wt` = repack_filter(w, g) computed earlier (skips the per-call repack).
+    drop = (keep, seed, stream_id, ctr): the result is multiplied by that dropout's mask (== dropout_rng(dx, ...))."""
     _need_dev(gy, w, bias, wt, mask, resid)
     assert not g.x_up
     assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
@@ -206,12 +225,18 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
         resid = match_layout(resid, dx)
     if wt is not None:
         assert wt.numel() * 4 == lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)
-        _timed(g, N, lambda: check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(wt), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), None, 0, 1, _stream()), 'conv2d_dgrad'))
-        return dx
-    nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)
-    ws = workspace(nb, gy.device)
-    _timed(g, N, lambda: check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(w), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), _ptr(ws), ws.numel(), 0, _stream()), 'conv2d_dgrad'))
-    return dx
+        filt, ws_p, ws_n, fl = wt, None, 0, 1
+    else:
+        ws = workspace(lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1), gy.device)
+        filt, ws_p, ws_n, fl = w, ws, ws.numel(), 0
+    if drop is not None:
+        try:
+            _timed(g, N, lambda: check(lib.ctgan_conv2d_dgrad_ex(ctypes.byref(d), _ptr(gy), _ptr(filt), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), _ptr(ws_p), ws_n, fl, _ext(drop), _stream()), 'conv2d_dgrad'))
+            return dx
+        except NotImplementedError:
+            pass
+    _timed(g, N, lambda: check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(filt), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), _ptr(ws_p), ws_n, fl, _stream()), 'conv2d_dgrad'))
+    return dx if drop is None else dropout_rng(dx, *drop)
 
 
 def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
@@ -323,11 +348,14 @@ def lrelu_fwd(x, alpha):
     return y
 
 
-def lrelu_bwd(gy, ref, alpha):
+def lrelu_bwd(gy, ref, alpha, scale=1.0):
     _need_dev(gy, ref)
     gy = match_layout(gy, ref)
     gx = _ew_out(ref)
-    check(lib.ctgan_lrelu_bwd(_ptr(gy), _ptr(ref), _ptr(gx), ref.numel(), alpha, _stream()), 'lrelu_bwd')
+    if scale == 1.0:
+        check(lib.ctgan_lrelu_bwd(_ptr(gy), _ptr(ref), _ptr(gx), ref.numel(), alpha, _stream()), 'lrelu_bwd')
+    else:
+        check(lib.ctgan_lrelu_bwd_scaled(_ptr(gy), _ptr(ref), _ptr(gx), ref.numel(), alpha, scale, _stream()), 'lrelu_bwd_scaled')
     return gx
 
 

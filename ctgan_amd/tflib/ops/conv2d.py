@@ -33,7 +33,9 @@ def Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, mask_
 
     `**fuse` (build-only): resid=tensor added in the conv epilogue, x_up=True reads the input through
     a nearest 2x upsample, out_nchw=True writes an NCHW-contiguous result, relu_in=True computes
-    Conv2D(relu(inputs)) without materialising the ReLU (the pre-activation blocks of the critic).
+    Conv2D(relu(inputs)) without materialising the ReLU (the pre-activation blocks of the critic), fork=True also
+    returns the input (residual blocks), epi={...} fuses the neighbouring dropout / ReLU into the conv kernels
+    (functional.ConvFn).
     """
     if mask_type is not None:
         raise NotImplementedError('masked convolutions are never enabled by the CT scripts')

@@ -66,6 +66,22 @@ const char* ctgan_last_kernel(void);
 /* tests only: 1 = route every conv through the table-driven generic kernels                   */
 void ctgan_debug_force_generic(int on);
 
+/* Optional epilogue extension of ctgan_conv2d_fwd / ctgan_conv2d_dgrad: tf.nn.dropout (:173-177) applied to the
+ * RESULT inside the kernel, y *= floor(keep + u)/keep, where u is what ctgan_rng_uniform(.., seed, stream_id, ctr)
+ * writes at the same physical offset (i.e. exactly ctgan_dropout_rng of the result, without the extra pass).  The
+ * forward uses it for a dropout that follows a conv; the backward for the dropout mask a data gradient is multiplied
+ * with.  drop_keep outside (0,1) = no dropout.  CTGAN_E_UNSUPPORTED unless the pipelined kernel with the 16-B
+ * epilogue serves the call (caller then applies ctgan_dropout_rng itself).                                    */
+typedef struct ctgan_epilogue_ext {
+    float drop_keep;
+    uint64_t drop_seed, drop_stream_id;
+    const uint64_t* drop_ctr;
+} ctgan_epilogue_ext;
+int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
+                        float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream);
+int ctgan_conv2d_dgrad_ex(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias,
+                          const float* mask, const float* resid, float* dx, void* ws, size_t ws_bytes, int flags,
+                          const ctgan_epilogue_ext* ext, ctgan_stream_t stream);
 /* Weight gradient of ONE filter over several (x, dy) pairs of the same geometry and strides (the uses of the filter in
  * different passes of a step: the dropout passes and the gradient-penalty double backward,
  * TF/CT_gan_cifar_resnet.py:284,335-336 sum them in tf.gradients): dw = sum_s wgrad(xs[s], dys[s]) in one launch + one
@@ -119,6 +135,10 @@ int ctgan_lrelu_fwd(const float* x, float* y, int64_t n, float alpha, ctgan_stre
 /* gx = ref>0 ? gy : alpha*gy  (ref = forward input or output; same sign)                      */
 int ctgan_lrelu_bwd(const float* gy, const float* ref, float* gx, int64_t n, float alpha,
                     ctgan_stream_t stream);
+/* gx = scale * (ref>0 ? gy : alpha*gy): backward of y = dropout(relu(z)) computed in a conv epilogue, where
+ * ref = y (y > 0 iff z > 0 and the element was kept) and scale = 1/keep                          */
+int ctgan_lrelu_bwd_scaled(const float* gy, const float* ref, float* gx, int64_t n, float alpha, float scale,
+                           ctgan_stream_t stream);
 /* tf.nn.dropout: y = x/keep * floor(keep + u)  (TF/CT_gan_cifar_resnet.py:173-177); the
  * backward is the same call on the gradient.                                                  */
 int ctgan_dropout(const float* x, const float* u, float* y, int64_t n, float keep,

@@ -46,7 +46,9 @@ def _xin(x, g):
 
 
 @_export
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False):
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None):
+    if drop is not None:
+        return dropout_rng(conv_fwd(x, w, bias, g, resid, relu, out_strides, relu_in), *drop)
     if relu_in:
         x = torch.relu(x)
     xp = TF.pad(_xin(x, g), _pads(g))
@@ -76,7 +78,9 @@ def dgrad_wants_repack(g):
 
 
 @_export
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None):
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None, drop=None):
+    if drop is not None:
+        return dropout_rng(conv_dgrad(gy, w, g, N, out_strides, bias, wt, mask, resid), *drop)
     if wt is not None:
         ref = repack_filter(w, g).reshape(-1)
         assert torch.equal(wt.reshape(-1)[:ref.numel()], ref)
@@ -179,8 +183,8 @@ def _like(val, ref):
 
 
 @_export
-def lrelu_bwd(gy, ref, alpha):
-    return _like(torch.where(ref > 0, gy, alpha * gy), ref)
+def lrelu_bwd(gy, ref, alpha, scale=1.0):
+    return _like(torch.where(ref > 0, gy, alpha * gy) * scale, ref)
 
 
 @_export

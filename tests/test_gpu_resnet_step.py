@@ -209,3 +209,37 @@ def test_train_iteration_and_samples(setup):
     s, px = tr.generate_samples(torch.randn(100, 128, device='cuda'),
                                 torch.arange(10, dtype=torch.int32, device='cuda').repeat(10))
     assert s.shape == (100, 3072) and px.min() >= 0 and px.max() <= 255
+
+
+@pytest.mark.parametrize('dim,B', [(32, 6), (128, 16)])
+def test_dropout_fused_into_conv_epilogues_equals_separate_dropout_kernels(setup, dim, B):
+    """DiscriminatorTail with the dropout masks (and the final ReLU) inside the conv kernels - forward in the producing
+    conv's epilogue, backward in the consuming conv's dgrad epilogue - against the same tail with stand-alone dropout
+    kernels, on identical Philox streams: outputs, parameter gradients and the gradient-penalty double backward."""
+    import ctgan_amd.functional as F
+    R, lib = setup(dim, B)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, 3072, generator=g).mul_(0.5).cuda()
+    lab = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32).cuda()
+    tr = R.Trainer(seed=9)
+    params = tr.d_params
+    res = {}
+    for mode in (False, True):
+        R.DROP_FUSION = mode
+        try:
+            tr.rng.begin_step()
+            xi = x.clone().requires_grad_(True)
+            d, f, a = R.Discriminator(xi, lab, 0.8, 0.5, 0.5, rng=tr.rng)
+            (gx,) = torch.autograd.grad(d, xi, torch.ones_like(d), create_graph=True)
+            gp, _ = F.gradient_penalty(gx, 10.0)
+            cost = d.mean() + (f * f).mean() + a.mean() + gp
+            grads = torch.autograd.grad(cost, params, allow_unused=True)
+            res[mode] = (d.detach(), f.detach(), a.detach(), gx.detach(), [None if t is None else t.detach() for t in grads])
+        finally:
+            R.DROP_FUSION = True
+    for i in range(4):
+        assert _rel_l2(res[True][i], res[False][i]) < 1e-6, i
+    for (n, _), a_, b_ in zip(tr.d_named, res[True][4], res[False][4]):
+        assert (a_ is None) == (b_ is None), n
+        if a_ is not None and b_.abs().max() > 0:
+            assert _rel_l2(a_, b_) < 2e-5, n
