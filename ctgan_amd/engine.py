@@ -41,8 +41,10 @@ class GraphedTrainer:
     # -- the region that is captured (everything between input copy and all-reduce / Adam)
     def _d_body(self):
         t = self.t
-        lib.bump_epoch()          # derived weight caches (rotated dgrad filters) must be rebuilt INSIDE this graph
-        F.prepare_filters()       # ... all of them in one or two launches
+        # the critic's weights change between replays (its Adam step): its derived filter layouts must be rebuilt INSIDE
+        # this graph - all of them in one or two launches.  The generator's are not used here (fake batches are inputs).
+        lib.bump_epoch('Discriminator' if self.batch_fakes else None)
+        F.prepare_filters()
         t.rng.begin_step()
         out = t.d_losses(self.real, self.labels, fake=self.fake)
         with F.deferred_wgrads():
@@ -54,7 +56,7 @@ class GraphedTrainer:
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
 
     def _f_body(self):
-        lib.bump_epoch()
+        lib.bump_epoch('Generator')      # runs after the generator update of the iteration
         return self.t.generate_fakes(self.labels_all)
 
     def _g_body(self):

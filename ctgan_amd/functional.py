@@ -290,7 +290,7 @@ class ConvDgradFn(Function):
 # (`lib.epoch()`): lazily on first use, or - `prepare_filters()` - all of them in one or two launches at the start
 # of a step.  A consumer on another stream waits for the producer's event.
 class _FilterEntry:
-    __slots__ = ('src', 'buf', 'kind', 'pad', 'scale', 'epoch', 'ev', 'st', 'level')
+    __slots__ = ('src', 'buf', 'kind', 'pad', 'scale', 'epoch', 'ev', 'st', 'level', 'group')
 
 
 _FCACHE = {}          # (src data_ptr, kind, R, S, C, K, pad_t, pad_l, scale) -> _FilterEntry
@@ -303,24 +303,24 @@ def clear_filter_cache():
     _SPREAD_BUFS.clear()
 
 
-def _mark_built(entries, ep):
+def _mark_built(entries):
+    from . import tflib as lib
     st = ev = None
     if entries and entries[0].buf.is_cuda:
         st = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(st)
     for e in entries:
-        e.epoch, e.ev, e.st = ep, ev, st
+        e.epoch, e.ev, e.st = lib.epoch(e.group), ev, st
 
 
 def _cached_filter(src, kind, pad=(0, 0), scale=1.0):
     """Derived layout `kind` of `src` (a registry Parameter, or a cached spread filter); None if not cacheable."""
     from . import tflib as lib
-    ep = lib.epoch()
     parent = None
     if not isinstance(src, torch.nn.Parameter):
         parent = _SPREAD_BUFS.get(src.data_ptr())
-        if parent is None or parent.epoch != ep:
+        if parent is None or parent.epoch != lib.epoch(parent.group):
             return None
     key = (src.data_ptr(), kind) + tuple(src.shape) + tuple(pad) + (scale,)
     e = _FCACHE.get(key)
@@ -333,12 +333,13 @@ def _cached_filter(src, kind, pad=(0, 0), scale=1.0):
         e.buf = torch.empty(K.filter_job_shape(kind, *src.shape), dtype=torch.float32, device=src.device)
         e.kind, e.pad, e.scale, e.epoch, e.ev, e.st = kind, tuple(pad), scale, -1, None, None
         e.level = 1 if parent is not None else 0
+        e.group = parent.group if parent is not None else lib.group_of(src)     # network whose updates invalidate it
         _FCACHE[key] = e
         if kind in (K.FILTER_SPREAD, K.FILTER_SPREAD_FLIP):
             _SPREAD_BUFS[e.buf.data_ptr()] = e
-    if e.epoch != ep:
+    if e.epoch != lib.epoch(e.group):
         K.filter_batch([(e.src, e.buf, e.kind, e.pad[0], e.pad[1], e.scale)])
-        _mark_built([e], ep)
+        _mark_built([e])
     elif e.ev is not None and torch.cuda.current_stream() != e.st:
         torch.cuda.current_stream().wait_event(e.ev)
     return e.buf
@@ -348,12 +349,11 @@ def prepare_filters():
     """Rebuild every known derived filter for the current weight version now, on the current stream: one launch
     for the layouts derived from parameters, one for the dgrad layouts of spread filters."""
     from . import tflib as lib
-    ep = lib.epoch()
     for level in (0, 1):
-        todo = [e for e in _FCACHE.values() if e.level == level and e.epoch != ep]
+        todo = [e for e in _FCACHE.values() if e.level == level and e.epoch != lib.epoch(e.group)]
         if todo:
             K.filter_batch([(e.src, e.buf, e.kind, e.pad[0], e.pad[1], e.scale) for e in todo])
-            _mark_built(todo, ep)
+            _mark_built(todo)
 
 
 def _repacked(w, g):

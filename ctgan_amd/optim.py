@@ -17,6 +17,8 @@ class FlatAdam:
         self.params = [p for _, p in named_params]
         if not self.params:
             raise ValueError('empty parameter list')
+        heads = {n.split('.')[0] for n in self.names}
+        self.group = heads.pop() if len(heads) == 1 else None     # one network per optimizer: only its caches go stale on step()
         dev = self.params[0].device
         self.beta1, self.beta2, self.eps = float(beta1), float(beta2), float(eps)
         self.sizes = [p.numel() for p in self.params]
@@ -66,7 +68,7 @@ class FlatAdam:
         K.adam_step(self.theta, self.grad, self.m, self.v, self.state, self.beta1, self.beta2, self.eps, grad_scale)
         K.adam_advance(self.state, self.beta1, self.beta2)
         self.t += 1
-        lib.bump_epoch()              # weights changed: repacked-filter caches are stale
+        lib.bump_epoch(self.group)    # this network's weights changed: its derived-filter caches are stale
 
     def load_named_slots(self, m_by_name, v_by_name, t):
         """Overwrite the Adam slots from per-parameter tensors (teacher-forced parity tests, resume)."""

@@ -18,14 +18,28 @@ _non_trainable = set()
 _device = None
 _seed = 0
 _epoch = [0]        # bumped whenever parameter VALUES change (optimizer step, load): invalidates derived caches
+_group_epoch = {}   # network ('Discriminator', 'Generator', ...) -> extra bumps of that network's parameters only
 
 
-def bump_epoch():
-    _epoch[0] += 1
+def bump_epoch(group=None):
+    """Parameter values changed: all of them (group=None) or those of one network (first component of their names)."""
+    if group is None:
+        _epoch[0] += 1
+    else:
+        _group_epoch[group] = _group_epoch.get(group, 0) + 1
 
 
-def epoch():
-    return _epoch[0]
+def epoch(group=None):
+    """Version of the parameter values of `group` (or of the whole registry)."""
+    return (_epoch[0], _group_epoch.get(group, 0)) if group is not None else (_epoch[0], sum(_group_epoch.values()))
+
+
+def group_of(tensor):
+    """Network a registered parameter belongs to (first component of its name); None if not registered."""
+    for name, p in _params.items():
+        if p is tensor:
+            return name.split('.')[0]
+    return None
 
 
 def set_device(device):
