@@ -58,6 +58,7 @@ struct FwdParams {
     const float* mask;                         // epilogue: keep the result only where mask[off] > 0 (ReLU backward)
     int d_lin;                                 // D offset = m*ds_q + col*ds_k (pixel-linear output)
     int d_vec;                                 // unit channel stride, 16-B aligned rows of D / mask / resid: float4 epilogue
+    int resid_up;                              // resid is the dense channels-last [N, P/2, Q/2, Ng] tensor, read through a nearest-2x upsample
     unsigned a_bytes, b_bytes;                 // byte extents of A and B (buffer-descriptor range checks)
     int dbg;                                   // perf-diagnosis bits (env CTGAN_DBG): 1 no LDS store, 2 no global load, 4 no barrier
     // Output-phase decomposition of a stride-2 data gradient: dx pixels of parity (a,b) are a stride-1 conv of
@@ -619,7 +620,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
                             off[u] = ph.d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
                         }
                         if (p.mask) mv[u] = *reinterpret_cast<const float4*>(p.mask + off[u]);
-                        if (p.resid) rv[u] = *reinterpret_cast<const float4*>(p.resid + off[u]);
+                        if (p.resid) {
+                            long long ro = off[u];
+                            if (p.resid_up) {
+                                const int n = m / PQ, rem = m - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+                                ro = (((long long)n * (g.P >> 1) + (pp >> 1)) * (g.Q >> 1) + (qq >> 1)) * p.Ng + col;
+                            }
+                            rv[u] = *reinterpret_cast<const float4*>(p.resid + ro);
+                        }
                     }
                 }
 #pragma unroll
@@ -1223,12 +1231,13 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
     const long long a_elems = (nimg - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
     const long long b_elems = (long long)(p.phases > 1 ? p.phases : 1) * g.R * g.S * g.C * p.Ng;
     const bool small = a_elems > 0 && a_elems * 4 < (1LL << 32) && b_elems * 4 < (1LL << 32) && p.b_off >= 0 && p.bs_r >= 0 && p.bs_s >= 0;
-    if (avec && bvec && small && p.Ng > 64 && !g_force_generic && (!p.drop || p.d_vec)) {
+    if (avec && bvec && small && p.Ng > 64 && !g_force_generic && ((!p.drop && !p.resid_up) || p.d_vec)) {
         p.a_bytes = (unsigned)(a_elems * 4);
         p.b_bytes = (unsigned)(b_elems * 4);
         return dispatch_fwd_pipe(p, st);
     }
-    if (p.drop) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d: epilogue dropout needs the pipelined kernel with a vector epilogue");
+    if (p.drop || p.resid_up)
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d: epilogue dropout / upsampled residual need the pipelined kernel with a vector epilogue");
     if (avec && bvec) return dispatch_fwd_tile<true, true>(p, st);
     if (avec) return dispatch_fwd_tile<true, false>(p, st);
     if (bvec) return dispatch_fwd_tile<false, true>(p, st);
@@ -1454,7 +1463,7 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
         ctgan_set_last_kernel("linear_small_fwd");
         return ctgan_small_linear_fwd(d, x, w, bias, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));
     }
-    if (!g_force_generic && !want_drop) {
+    if (!g_force_generic && !want_drop && !(flags & CTGAN_RESID_UP)) {
         rc = ctgan_fewch_fwd(d, x, w, bias, resid, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, (flags & CTGAN_IN_RELU) ? 1 : 0,
                              static_cast<hipStream_t>(stream));
         if (rc) return rc < 0 ? rc : CTGAN_OK;
@@ -1469,6 +1478,8 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
     p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
     p.mask = nullptr;
     p.phases = 1;
+    p.resid_up = (resid && (flags & CTGAN_RESID_UP)) ? 1 : 0;
+    if (p.resid_up && ((d->P | d->Q) & 1)) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: CTGAN_RESID_UP needs even P, Q");
     set_drop(p, ext);
     return run_fwd(p, static_cast<hipStream_t>(stream));
 }
@@ -1519,6 +1530,7 @@ int ctgan_conv2d_dgrad_ex(const ctgan_conv_desc* d, const float* dy, const float
     p.ds_n = d->xs[0]; p.ds_k = d->xs[1]; p.ds_p = d->xs[2]; p.ds_q = d->xs[3];
     p.relu = 0;
     p.phases = 1;
+    p.resid_up = 0;
     set_drop(p, ext);
     const size_t need = dgrad_filter_elems(d) * sizeof(float);
     const bool pre = (flags & CTGAN_DGRAD_W_REPACKED) != 0;

@@ -150,6 +150,7 @@ class ConvFn(Function):
         ctx.out_drop, ctx.in_drop = epi.get('out_drop'), epi.get('in_drop')
         ctx.out_relu = bool(epi.get('out_relu'))
         ctx.out_drop_bwd_fused = bool(epi.get('out_drop_bwd_fused'))
+        ctx.resid_up = bool(epi.get('resid_up')) and resid is not None      # resid is the low-resolution shortcut
         ctx.g = g
         ctx.N = x.shape[0]
         ctx.x_strides = x.stride()
@@ -160,7 +161,8 @@ class ConvFn(Function):
         ctx.fork = bool(fork)
         if fork:
             ctx.set_materialize_grads(False)       # an unused shortcut branch must not cost a zero-filled add
-        y = K.conv_fwd(x, w, b, g, resid=resid, relu=ctx.out_relu, out_strides=out_strides, relu_in=relu_in, drop=ctx.out_drop)
+        y = K.conv_fwd(x, w, b, g, resid=resid, relu=ctx.out_relu, out_strides=out_strides, relu_in=relu_in, drop=ctx.out_drop,
+                       resid_up=ctx.resid_up)
         if ctx.out_relu:
             ctx.save_for_backward(x, w, y)         # y > 0  <=>  pre-activation > 0 and the element survived the dropout
         else:
@@ -232,7 +234,7 @@ class ConvFn(Function):
         elif g_fork is not None:
             gx = g_fork
         if ctx.has_resid and ctx.needs_input_grad[3]:
-            gr = gy
+            gr = Pool2Fn.apply(gy, 1.0) if ctx.resid_up else gy
         if fork:
             torch.cuda.current_stream().wait_stream(ctx_join)
             for t in (gw, gb):

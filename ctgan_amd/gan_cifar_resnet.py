@@ -154,10 +154,16 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
         # shortcut = ConvMeanPool 1x1 (he_init=False); the residual add rides its epilogue
         return ConvMeanPool(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True, resid=out)
     if resample == 'up':
-        shortcut = UpsampleConv(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
+        if RESID_UP_FUSION and output_dim % 32 == 0:
+            # 1x1 shortcut conv on the small side; its nearest-2x upsample happens where Conv2's epilogue reads it
+            shortcut = _conv2d.Conv2D(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
+            epi = {'resid_up': True}
+        else:
+            shortcut = UpsampleConv(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
+            epi = None
         out = UpsampleConv(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
         out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
-        return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2)
+        return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2, epi=epi)
     # resample None.  in_drop: `inputs` is the result of that dropout - its mask is applied to the block's input gradient
     # in Conv1's dgrad epilogue; out_epi: dropout (/ ReLU) applied to the block's result in Conv2's epilogue.
     if r1:
@@ -279,6 +285,8 @@ class _nullctx:
 GP_SIDE_STREAM = _os.environ.get('CTGAN_GP_STREAM', '0') != '0'
 # A/B switch: the tail's dropouts (and the final ReLU) inside the neighbouring conv kernels (see DiscriminatorTail)
 DROP_FUSION = _os.environ.get('CTGAN_DROP_FUSION', '1') != '0'
+# A/B switch: the generator's upsampled 1x1 shortcut is read at low resolution by the epilogue of the block's last conv
+RESID_UP_FUSION = _os.environ.get('CTGAN_RESID_UP', '1') != '0'
 
 
 # Draw the fake batches of all N_CRITIC critic steps of an iteration in one generator forward (Trainer.generate_fakes)

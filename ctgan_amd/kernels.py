@@ -164,7 +164,7 @@ def _ext(drop):
     return ctypes.byref(EpilogueExt(keep, seed, sid, ctr.data_ptr()))
 
 
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None):
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False):
     """y = conv(x,w) [+bias] [+resid] [relu] [dropout]; relu_in: conv(relu(x)).  x logical [N,C,H(/2),W(/2)], w HWIO.
     drop = (keep, seed, stream_id, ctr): tf.nn.dropout of the result inside the epilogue (== dropout_rng(y, ...))."""
     _need_dev(x, w, bias, resid)
@@ -175,10 +175,19 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
         y = empty_cl(N, g.K, g.P, g.Q, x.device)
     else:
         y = torch.empty_strided((N, g.K, g.P, g.Q), out_strides, dtype=torch.float32, device=x.device)
-    if resid is not None:
+    if resid is not None and resid_up:
+        assert tuple(resid.shape) == (N, g.K, g.P // 2, g.Q // 2) and resid.permute(0, 2, 3, 1).is_contiguous()
+    elif resid is not None:
         assert is_dense_like(resid, y)
     d = g.desc(N, x.stride(), y.stride())
-    fl = (1 if relu else 0) | (2 if relu_in else 0)
+    fl = (1 if relu else 0) | (2 if relu_in else 0) | (8 if (resid_up and resid is not None) else 0)
+    if fl & 8:
+        try:
+            _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y), fl, _ext(drop), _stream()), 'conv2d_fwd'))
+            return y
+        except NotImplementedError:          # no vector epilogue: materialise the upsampled residual
+            resid = upsample2(resid, 1.0)
+            fl &= ~8
     if drop is not None:
         try:
             _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y), fl, _ext(drop), _stream()), 'conv2d_fwd'))

@@ -55,7 +55,9 @@ typedef struct ctgan_conv_desc {
 } ctgan_conv_desc;
 
 enum { CTGAN_CONV_FWD = 0, CTGAN_CONV_DGRAD = 1, CTGAN_CONV_WGRAD = 2 };
-enum { CTGAN_EPI_RELU = 1, CTGAN_IN_RELU = 2 };  /* relu on the result / on the gathered input (conv(relu(x))) */
+enum { CTGAN_EPI_RELU = 1, CTGAN_IN_RELU = 2,    /* relu on the result / on the gathered input (conv(relu(x))) */
+       CTGAN_RESID_UP = 8 };                      /* fwd: `resid` is the dense channels-last [N,K,P/2,Q/2] tensor and is added
+                                                    * through a nearest-2x upsample (UpsampleConv shortcut, :100-107,130) */
 enum { CTGAN_DGRAD_W_REPACKED = 1 };
 
 /* ---- library ------------------------------------------------------------------------------ */

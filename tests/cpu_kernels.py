@@ -46,7 +46,9 @@ def _xin(x, g):
 
 
 @_export
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None):
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False):
+    if resid is not None and resid_up:
+        resid = upsample2(resid, 1.0)
     if drop is not None:
         return dropout_rng(conv_fwd(x, w, bias, g, resid, relu, out_strides, relu_in), *drop)
     if relu_in:

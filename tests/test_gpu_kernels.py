@@ -664,3 +664,17 @@ def test_multi_segment_wgrad(K, C, H, Ko, k, st, Ns):
     assert torch.equal(dw, dw2)                                    # the bias row does not perturb the weights
     K.conv_wgrad_multi(segs, geom, dw2, db)
     assert torch.equal(dw, dw2)                                    # deterministic
+
+
+@pytest.mark.parametrize('N,H', [(5, 16), (130, 8), (64, 32)])
+def test_conv_epilogue_reads_low_resolution_residual(K, N, H):
+    """CTGAN_RESID_UP: the residual operand is the [N,K,P/2,Q/2] tensor, added through a nearest-2x upsample inside the
+    conv epilogue (generator 'up' block shortcut) - bit-identical to adding the materialised upsample."""
+    g = torch.Generator().manual_seed(N + H)
+    geom = K.ConvGeom(128, H, H, 128, 3, 3, 1, False)
+    x = cl(torch.randn(N, 128, H, H, generator=g)); w = dev(torch.randn(3, 3, 128, 128, generator=g) * 0.03)
+    b = dev(torch.randn(128, generator=g)); r = cl(torch.randn(N, 128, H // 2, H // 2, generator=g))
+    y = K.conv_fwd(x, w, b, geom, resid=r, resid_up=True, relu_in=True)
+    assert 'igemm_fwd_pipe' in K.last_kernel()
+    y_ref = K.conv_fwd(x, w, b, geom, resid=K.upsample2(r, 1.0), relu_in=True)
+    assert torch.equal(y, y_ref)
