@@ -82,6 +82,11 @@ SIGNATURES = {
     'ctgan_filter_spread': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
     'ctgan_filter_fold': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
     'ctgan_filter_batch': (c_int, [_p, c_int32, _p]),
+    'ctgan_mul': (c_int, [_p, _p, _p, c_int64, _p]),
+    'ctgan_rsqrt': (c_int, [_p, _p, c_int64, c_float, _p]),
+    'ctgan_sample_sum': (c_int, [_p, _p, c_int32, c_int64, c_float, _p]),
+    'ctgan_sample_bcast': (c_int, [_p, _p, c_int32, c_int64, c_float, _p]),
+    'ctgan_channel_affine': (c_int, [_p, _p, _p, _p, c_int64, c_int32, _p]),
     'ctgan_spatial_sum': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
     'ctgan_spatial_bcast': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p]),
     'ctgan_real_prep': (c_int, [_p, _p, _p, c_int64, c_float, _p]),

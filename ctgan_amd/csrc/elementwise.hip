@@ -62,6 +62,8 @@ int launch2(const float* x, const float* z, float* y, long long n, F f, ctgan_st
 struct LReluF { float a; __device__ float operator()(float x) const { return x > 0.f ? x : a * x; } };
 struct LReluB { float a; __device__ float operator()(float g, float r) const { return r > 0.f ? g : a * g; } };
 struct LReluBS { float a, sc; __device__ float operator()(float g, float r) const { return (r > 0.f ? g : a * g) * sc; } };
+struct MulF { __device__ float operator()(float x, float y) const { return x * y; } };
+struct RsqrtF { float eps; __device__ float operator()(float x) const { return 1.f / sqrtf(x + eps); } };
 struct DropF { float keep, inv; __device__ float operator()(float x, float u) const { return x * inv * floorf(keep + u); } };
 struct TanhF { __device__ float operator()(float x) const { return tanhf(x); } };
 struct TanhB { __device__ float operator()(float g, float y) const { return g * (1.f - y * y); } };
@@ -289,6 +291,37 @@ __global__ void filter_batch_kernel(const FilterJobs t) {
     }
 }
 
+// ---- per-sample / per-channel primitives of Layernorm (TF/tflib/ops/layernorm.py:6-20) ---------------------------
+// x dense [n][m] (any inner layout): y[i] = scale * sum_j x[i][j]   (one workgroup per sample, fixed-order tree)
+__global__ __launch_bounds__(256) void sample_sum_kernel(const float* __restrict__ x, float* __restrict__ y, long long m, float scale) {
+    __shared__ float sh[4];
+    const float* row = x + (long long)blockIdx.x * m;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long j = threadIdx.x;
+    for (; j + 768 < m; j += 1024) { s0 += row[j]; s1 += row[j + 256]; s2 += row[j + 512]; s3 += row[j + 768]; }
+    for (; j < m; j += 256) s0 += row[j];
+    float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) y[blockIdx.x] = scale * ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+// y[i][j] = scale * v[i]
+__global__ void sample_bcast_kernel(const float* __restrict__ v, float* __restrict__ y, long long m, long long total, float scale) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) y[i] = scale * v[i / m];
+}
+// channels-last x [rows][c]: y = x * s[c] + o[c]   (o may be NULL)
+__global__ void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ sc, const float* __restrict__ of,
+                                      float* __restrict__ y, int c, long long total) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int ch = (int)(i % c);
+        y[i] = x[i] * sc[ch] + (of ? of[ch] : 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -392,6 +425,28 @@ int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t s
         if (rc) return rc;
     }
     return CTGAN_OK;
+}
+
+int ctgan_mul(const float* x, const float* y, float* out, int64_t n, ctgan_stream_t s) { return launch2(x, y, out, n, MulF{}, s, "mul"); }
+int ctgan_rsqrt(const float* x, float* y, int64_t n, float eps, ctgan_stream_t s) { return launch1(x, y, n, RsqrtF{eps}, s, "rsqrt"); }
+int ctgan_sample_sum(const float* x, float* y, int32_t n, int64_t m, float scale, ctgan_stream_t s) {
+    if (!x || !y || n <= 0 || m <= 0) return ctgan_fail(CTGAN_E_BADARG, "sample_sum: bad argument");
+    hipLaunchKernelGGL(sample_sum_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(s), x, y, (long long)m, scale);
+    return ctgan_check_launch("sample_sum");
+}
+int ctgan_sample_bcast(const float* v, float* y, int32_t n, int64_t m, float scale, ctgan_stream_t s) {
+    if (!v || !y || n <= 0 || m <= 0) return ctgan_fail(CTGAN_E_BADARG, "sample_bcast: bad argument");
+    const long long total = (long long)n * m;
+    hipLaunchKernelGGL(sample_bcast_kernel, dim3(ctgan_blocks(total, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), v, y, (long long)m,
+                       total, scale);
+    return ctgan_check_launch("sample_bcast");
+}
+int ctgan_channel_affine(const float* x, const float* scale, const float* offset, float* y, int64_t rows, int32_t c, ctgan_stream_t s) {
+    if (!x || !scale || !y || rows <= 0 || c <= 0) return ctgan_fail(CTGAN_E_BADARG, "channel_affine: bad argument");
+    const long long total = (long long)rows * c;
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(ctgan_blocks(total, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), x, scale, offset, y,
+                       c, total);
+    return ctgan_check_launch("channel_affine");
 }
 
 int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale, ctgan_stream_t s) {

@@ -909,6 +909,113 @@ def batch_norm(x, scale, offset, labels=None, groups=1, relu=False):
     return BatchNormFn.apply(x, scale, offset, labels, groups, relu)
 
 
+# --------------------------------------------------------------------------------- layer norm (config[4] critic)
+# TF/tflib/ops/layernorm.py:6-20 = tf.nn.moments over (C,H,W) per sample + tf.nn.batch_normalization with a per-channel
+# scale / offset.  The critic is differentiated TWICE through it (gradient penalty), so the operator is a composition
+# of five kernel-backed maps whose backwards are again members of the set (mul, rsqrt, per-sample sum / broadcast,
+# per-channel affine + the existing axpby / channel sum): every derivative order is a composition of the same kernels.
+class MulFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return K.mul(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (MulFn.apply(g, b) if ctx.needs_input_grad[0] else None), (MulFn.apply(g, a) if ctx.needs_input_grad[1] else None)
+
+
+class RsqrtFn(Function):
+    @staticmethod
+    def forward(ctx, v, eps):
+        r = K.rsqrt(v, eps)
+        ctx.save_for_backward(r)
+        return r
+
+    @staticmethod
+    def backward(ctx, g):
+        (r,) = ctx.saved_tensors                      # d/dv (v+eps)^(-1/2) = -1/2 r^3
+        return ScaleFn.apply(MulFn.apply(g, MulFn.apply(MulFn.apply(r, r), r)), -0.5), None
+
+
+class SampleSumFn(Function):
+    """[N, ...] -> [N], scale * sum over the non-batch axes; adjoint = SampleBcastFn."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        ctx.save_for_backward(x)                      # only its shape / layout are used
+        return K.sample_sum(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return SampleBcastFn.apply(g.contiguous(), x, ctx.scale), None
+
+
+class SampleBcastFn(Function):
+    @staticmethod
+    def forward(ctx, v, like, scale):
+        ctx.scale = scale
+        return K.sample_bcast(v, like, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return SampleSumFn.apply(g if K.is_dense(g) else g.contiguous(), ctx.scale), None, None
+
+
+class ChannelAffineFn(Function):
+    """y = x * s[c] + o[c] on a channels-last [N,C,H,W] (or [N,C]) tensor."""
+
+    @staticmethod
+    def forward(ctx, x, s, o):
+        ctx.has_o = o is not None
+        ctx.save_for_backward(x, s)
+        return K.channel_affine(x, s, o)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = K.match_layout(g, x) if g.dim() == 4 else g.contiguous()
+        gx = ChannelAffineFn.apply(g, s, None) if ctx.needs_input_grad[0] else None
+        gs = _channel_sum(MulFn.apply(g, x)) if ctx.needs_input_grad[1] else None
+        go = _channel_sum(g) if (ctx.has_o and ctx.needs_input_grad[2]) else None
+        return gx, gs, go
+
+
+class _ChannelSum2dFn(Function):
+    """[N,C] -> [C]."""
+
+    @staticmethod
+    def forward(ctx, g):
+        ctx.n = g.shape[0]
+        return K.colsum_channels(g.reshape(g.shape[0], g.shape[1], 1, 1))
+
+    @staticmethod
+    def backward(ctx, gg):
+        return gg.reshape(1, -1).expand(ctx.n, -1).contiguous()
+
+
+def _channel_sum(t):
+    return ChannelSumFn.apply(t) if t.dim() == 4 else _ChannelSum2dFn.apply(t)
+
+
+def layer_norm(x, scale, offset, eps=1e-5):
+    """Per-sample normalisation over all non-batch axes, then per-channel scale / offset (TF/tflib/ops/layernorm.py)."""
+    if x.dim() == 4 and not x.permute(0, 2, 3, 1).is_contiguous():
+        x = to_channels_last(x)
+    elif x.dim() == 2:
+        x = x.contiguous()
+    inv = 1.0 / x[0].numel()
+    m = SampleSumFn.apply(x, inv)
+    xc = AddFn.apply(x, SampleBcastFn.apply(m, x, 1.0), 1.0, -1.0)
+    v = SampleSumFn.apply(MulFn.apply(xc, xc), inv)               # biased variance (tf.nn.moments)
+    r = RsqrtFn.apply(v, float(eps))
+    xh = MulFn.apply(xc, SampleBcastFn.apply(r, x, 1.0))
+    return ChannelAffineFn.apply(xh, scale, offset)
+
+
 # --------------------------------------------------------------------------------- loss heads
 class GradPenaltyFn(Function):
     """lambda * mean((||g_b|| - 1)^2)"""

@@ -25,6 +25,7 @@ from .rng import DeviceRNG
 from .tflib.ops import batchnorm as _bn
 from .tflib.ops import cond_batchnorm as _cbn
 from .tflib.ops import conv2d as _conv2d
+from .tflib.ops import layernorm as _ln
 from .tflib.ops import linear as _linear
 
 
@@ -83,7 +84,7 @@ def _norm_relu(name, inputs, labels=None, groups=1):
     if ('Generator' in name) and cfg.NORMALIZATION_G:
         return Normalize(name, inputs, labels=labels, groups=groups, relu=True), False
     if ('Discriminator' in name) and cfg.NORMALIZATION_D:
-        raise NotImplementedError('NORMALIZATION_D (Layernorm critic) is not built yet')
+        return F.relu(Normalize(name, inputs, labels=labels)), False         # Layernorm critic: not piecewise linear
     if not FUSE_RELU:
         return F.relu(inputs), False
     return inputs, True
@@ -96,7 +97,7 @@ def Normalize(name, inputs, labels=None, groups=1, relu=False):
     if cfg.CONDITIONAL and cfg.ACGAN and ('Discriminator' in name):
         labels = None
     if ('Discriminator' in name) and cfg.NORMALIZATION_D:
-        raise NotImplementedError('NORMALIZATION_D (Layernorm critic) is not built yet')
+        return _ln.Layernorm(name, [1, 2, 3], inputs)        # :76-77 (the main-tree op takes no labels, layernorm.py:6)
     elif ('Generator' in name) and cfg.NORMALIZATION_G:
         if labels is not None:
             return _cbn.Batchnorm(name, [0, 2, 3], inputs, labels=labels, n_labels=10, groups=groups, relu=relu)
@@ -220,7 +221,7 @@ def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None):
     """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186)."""
     D = cfg.DIM_D
 
-    fuse = DROP_FUSION and FUSE_RELU and F.FORK_FUSION and u is None and rng is not None and min(kp1, kp2, kp3) < 1.0 \
+    fuse = DROP_FUSION and FUSE_RELU and F.FORK_FUSION and not cfg.NORMALIZATION_D and u is None and rng is not None \
         and max(kp1, kp2, kp3) < 1.0
     if fuse:
         # dropout -> block 3 -> dropout -> block 4 -> dropout -> relu with the masks inside the conv kernels: forward in the

@@ -534,6 +534,52 @@ def filter_fold(w4, scale, flip, out=None):
     return out
 
 
+def mul(x, y):
+    """Elementwise product of two dense tensors of the same shape and layout."""
+    _need_dev(x, y)
+    y = match_layout(y, x) if x.dim() == 4 else y
+    assert x.shape == y.shape and x.stride() == y.stride() and is_dense(x)
+    out = _ew_out(x)
+    check(lib.ctgan_mul(_ptr(x), _ptr(y), _ptr(out), x.numel(), _stream()), 'mul')
+    return out
+
+
+def rsqrt(x, eps):
+    _need_dev(x)
+    assert is_dense(x)
+    y = _ew_out(x)
+    check(lib.ctgan_rsqrt(_ptr(x), _ptr(y), x.numel(), eps, _stream()), 'rsqrt')
+    return y
+
+
+def sample_sum(x, scale):
+    """[N, ...] dense -> [N]: scale * sum over everything but the batch axis."""
+    _need_dev(x)
+    assert is_dense(x) and x.stride(0) == x[0].numel()
+    y = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(lib.ctgan_sample_sum(_ptr(x), _ptr(y), x.shape[0], x[0].numel(), scale, _stream()), 'sample_sum')
+    return y
+
+
+def sample_bcast(v, like, scale):
+    """[N] -> tensor with the shape and layout of `like` (dense, batch-major): out[n, ...] = scale * v[n]."""
+    _need_dev(v, like)
+    assert is_dense(like) and like.stride(0) == like[0].numel() and v.is_contiguous() and v.numel() == like.shape[0]
+    y = _ew_out(like)
+    check(lib.ctgan_sample_bcast(_ptr(v), _ptr(y), like.shape[0], like[0].numel(), scale, _stream()), 'sample_bcast')
+    return y
+
+
+def channel_affine(x, scale, offset=None):
+    """x [N,C,H,W] channels-last (or [N,C]): x * scale[c] + offset[c]."""
+    _need_dev(x, scale, offset)
+    C = x.shape[1]
+    assert (x.dim() == 2 and x.is_contiguous()) or (x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous())
+    y = _ew_out(x)
+    check(lib.ctgan_channel_affine(_ptr(x), _ptr(scale), _ptr(offset), _ptr(y), x.numel() // C, C, _stream()), 'channel_affine')
+    return y
+
+
 def spatial_sum(x, scale):
     """[N,C,H,W] channels-last -> [N,C], scale * sum over (h,w)."""
     _need_dev(x)

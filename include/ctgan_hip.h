@@ -195,6 +195,19 @@ typedef struct ctgan_filter_job {
     float scale;
 } ctgan_filter_job;
 int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t stream);
+/* ---- Layernorm primitives (TF/tflib/ops/layernorm.py:6-20: tf.nn.moments over (C,H,W) per sample +
+ *      tf.nn.batch_normalization with per-channel scale/offset).  The operator is composed of these linear /
+ *      elementwise maps so that its first AND second derivatives (gradient penalty through a layer-normalised
+ *      critic, config[4]) are compositions of the same kernels. ---------------------------------------------- */
+int ctgan_mul(const float* x, const float* y, float* out, int64_t n, ctgan_stream_t stream);           /* out = x*y    */
+int ctgan_rsqrt(const float* x, float* y, int64_t n, float eps, ctgan_stream_t stream);               /* 1/sqrt(x+eps) */
+/* y[i] = scale * sum_j x[i][j] for a dense [n][m] tensor (per-sample reduction, fixed order)                    */
+int ctgan_sample_sum(const float* x, float* y, int32_t n, int64_t m, float scale, ctgan_stream_t stream);
+/* y[i][j] = scale * v[i]  (its adjoint)                                                                         */
+int ctgan_sample_bcast(const float* v, float* y, int32_t n, int64_t m, float scale, ctgan_stream_t stream);
+/* channels-last x [rows][c]: y = x*scale[c] + offset[c] (offset may be NULL)                                    */
+int ctgan_channel_affine(const float* x, const float* scale, const float* offset, float* y, int64_t rows, int32_t c,
+                         ctgan_stream_t stream);
 /* y[n,c] = scale * sum_{hw} x[n,hw,c]  (tf.reduce_mean(axis=[2,3]) :179) on channels-last x    */
 int ctgan_spatial_sum(const float* x, float* y, int32_t n, int32_t hw, int32_t c, float scale,
                       ctgan_stream_t stream);

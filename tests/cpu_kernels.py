@@ -297,6 +297,35 @@ def filter_fold(w4, scale, flip, out=None):
 
 
 @_export
+def mul(x, y):
+    return _like(x * y, x)
+
+
+@_export
+def rsqrt(x, eps):
+    return _like(1.0 / torch.sqrt(x + eps), x)
+
+
+@_export
+def sample_sum(x, scale):
+    return x.reshape(x.shape[0], -1).sum(dim=1) * scale
+
+
+@_export
+def sample_bcast(v, like, scale):
+    return _like((v * scale).reshape([-1] + [1] * (like.dim() - 1)).expand(like.shape), like)
+
+
+@_export
+def channel_affine(x, scale, offset=None):
+    shp = [1, -1] + [1] * (x.dim() - 2)
+    y = x * scale.reshape(shp)
+    if offset is not None:
+        y = y + offset.reshape(shp)
+    return _like(y, x)
+
+
+@_export
 def spatial_sum(x, scale):
     return (x.sum(dim=(2, 3)) * scale).contiguous()
 

@@ -243,3 +243,31 @@ def test_dropout_fused_into_conv_epilogues_equals_separate_dropout_kernels(setup
         assert (a_ is None) == (b_ is None), n
         if a_ is not None and b_.abs().max() > 0:
             assert _rel_l2(a_, b_) < 2e-5, n
+
+
+def test_layernorm_critic_d_step_on_gpu(setup):
+    """NORMALIZATION_D=True: the gradient penalty differentiates Layernorm twice (functional.layer_norm primitives)."""
+    import ctgan_amd.gan_cifar_resnet as R0
+    import ctgan_amd.tflib as lib0
+    dim, B = 32, 4
+    lib0.delete_all_params(); lib0.set_seed(5)
+    R0.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B, NORMALIZATION_D=True)
+    try:
+        R0.build_params()
+        reg = _oracle_from_product(lib0)
+        cfg = onets.ResnetCfg(DIM_G=dim, DIM_D=dim, NORMALIZATION_D=True)
+        g = torch.Generator().manual_seed(2)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        rnd = osteps.make_rnd_resnet_d(B, dim, g)
+        tr = R0.Trainer(seed=1)
+        optD = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+        out = tr.d_step(real.cuda(), labels.cuda(), {k: _to_dev(v) for k, v in rnd.items()}, iteration=0)
+        ref = osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd, iteration=0, B=B)
+        for k in ('cost', 'wgan', 'acgan', 'ct', 'gp'):
+            _cmp(out[k], ref[k], 5e-4, 'd_step.%s' % k, atol=1e-6)
+        _cmp_l2(out['gp_grads'], ref['gp_grads'], 2e-3, 'dD/dx_hat')
+        for n in ref['grads']:
+            _cmp_l2(out['grads'][n], ref['grads'][n], 5e-3, 'dgrad ' + n, atol=1e-7)
+    finally:
+        lib0.delete_all_params(); R0.configure()

@@ -247,3 +247,36 @@ def test_deferred_multi_segment_wgrads_equal_immediate_wgrads(cpu_kernels):
     finally:
         F.DEFER_WGRADS = True
         R.configure()
+
+
+def test_layernorm_critic_step_matches_oracle(cpu_kernels):
+    """NORMALIZATION_D=True (TF/CT_gan_cifar_resnet.py:76-77: Layernorm after every critic conv input): the critic is no
+    longer piecewise linear, so the gradient penalty differentiates Layernorm twice - forward, losses and every critic
+    gradient of a D step against the oracle."""
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    B, dim = 4, 8
+    lib.set_seed(13)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B, NORMALIZATION_D=True)
+    try:
+        R.build_params('cpu')
+        assert any('.N1.scale' in n for n in lib._params if n.startswith('Discriminator.'))
+        reg = _oracle_from_product(lib)
+        cfg = onets.ResnetCfg(DIM_G=dim, DIM_D=dim, NORMALIZATION_D=True)
+        g = torch.Generator().manual_seed(5)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        rnd64 = osteps.make_rnd_resnet_d(B, dim, g)
+        rnd32 = {k: ([t.float() for t in v] if isinstance(v, list) else v.float()) for k, v in rnd64.items()}
+        tr = R.Trainer(seed=1)
+        optD = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+        out = tr.d_step(real, labels, rnd32, iteration=0)
+        ref = osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd64, iteration=0, B=B)
+        for k in ('cost', 'wgan', 'acgan', 'ct', 'gp'):
+            _cmp(out[k], ref[k], 5e-4, 'd_step.%s' % k)
+        _cmp(out['gp_grads'], ref['gp_grads'], 5e-4, 'gp grads')
+        assert set(out['grads']) == set(ref['grads'])
+        for n in ref['grads']:
+            _cmp(out['grads'][n], ref['grads'][n], 2e-3, 'dgrad ' + n, atol=1e-6)
+    finally:
+        R.configure()
