@@ -25,8 +25,12 @@ class DCGANTrainer:
         self.rng = DeviceRNG(seed, rank, self.dev)
         self.d_named = lib.named_params_with_name('Discriminator', trainable_only=True)
         self.g_named = lib.named_params_with_name('Generator', trainable_only=True)
-        self.d_opt = FlatAdam(self.d_named, 0.5, 0.9)
-        self.g_opt = FlatAdam(self.g_named, 0.5, 0.9)
+        b1, b2 = getattr(module, 'ADAM_BETAS', (0.5, 0.9))
+        self.d_opt = FlatAdam(self.d_named, b1, b2)
+        self.g_opt = FlatAdam(self.g_named, b1, b2)
+        self.towers = getattr(module, 'GEN_TOWERS', 1)                    # generator calls per batch, each with its own BN statistics
+        self.piecewise = getattr(module, 'PIECEWISE_LINEAR_CRITIC', True)
+        self.iteration = 0
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
 
@@ -39,7 +43,7 @@ class DCGANTrainer:
         m, cfg = self.mod, self.mod.cfg
         B = cfg.BATCH_SIZE
         with torch.no_grad():
-            fake = m.Generator(B, noise=rnd['z'] if rnd is not None else None, rng=self.rng)
+            fake = self._gen(B, rnd['z'] if rnd is not None else None)
             real = m.real_prep(real_in)
             alpha = rnd['alpha'] if rnd is not None else self.rng.uniform(B, 1)
             interp = K.interpolate(real, fake, alpha)
@@ -52,22 +56,27 @@ class DCGANTrainer:
         wgan = F.mean_diff(d[B:], B, B, 0.0, 1.0) + F.mean_diff(d[:B], B, 0, -1.0, 0.0)   # mean(fake) - mean(real)
         ct = F.consistency_term(d[:B], d[B:2 * B], f[:B], f[B:2 * B], cfg.LAMBDA_2, cfg.Factor_M)
         interp.requires_grad_(True)
-        with F.weight_grads(False):         # LeakyReLU + dropout critic is piecewise linear
+        with F.weight_grads(not self.piecewise):     # a LeakyReLU + dropout critic is piecewise linear; a layer-normalised one is not
             d_gp = m.Discriminator(interp, u=self._masks(B, 'u_gp', rnd))[0]
         (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=torch.ones_like(d_gp), create_graph=True)
         gp, slopes = F.gradient_penalty(grads, cfg.LAMBDA)
         return {'cost': wgan + ct + gp, 'wgan_only': wgan, 'ct': ct, 'gp': gp, 'fake': fake, 'slopes': slopes,
                 'gp_grads': grads}
 
+    def _gen(self, n, z):
+        if self.towers > 1:
+            return self.mod.Generator(n, noise=z, rng=self.rng, groups=self.towers)
+        return self.mod.Generator(n, noise=z, rng=self.rng)
+
     def g_losses(self, rnd=None):
         m, B = self.mod, self.mod.cfg.BATCH_SIZE
-        x = m.Generator(B, noise=rnd['z'] if rnd is not None else None, rng=self.rng)
+        x = self._gen(B, rnd['z'] if rnd is not None else None)
         with F.weight_grads(False):
             d, _ = m.Discriminator(x, u=self._masks(B, 'u_fake', rnd))
         return {'cost': F.mean_diff(d, B, 0, -1.0, 0.0), 'samples': x}
 
     def _apply(self, opt, grads):
-        opt.set_lr(self.mod.cfg.LR)
+        opt.set_lr(self.mod.lr(self.iteration) if hasattr(self.mod, 'lr') else self.mod.cfg.LR)
         flat = opt.gather_grads(grads)
         if self.allreduce is not None and self.world > 1:
             self.allreduce(flat)
@@ -92,6 +101,7 @@ class DCGANTrainer:
         return out
 
     def train_iteration(self, iteration, next_batch):
+        self.iteration = iteration
         if iteration > 0:
             self.g_step()
         out = None

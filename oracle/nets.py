@@ -197,3 +197,85 @@ def mnist_discriminator(reg, inputs, u, DIM=64):
     output2 = out.reshape(-1, 4 * 4 * 4 * DIM)
     out = ops.Linear(reg, 'Discriminator.Output', 4 * 4 * 4 * DIM, 1, output2)
     return out.reshape(-1), output2
+
+
+# ----------------------------------------------------------------------------- 128x128 ResNet (config[4])
+class Lsun128Cfg:
+    """LS/wgan_LSUN_Bedrooms128.py:27-47 (LS = tensorflow_generative_model/LSUN_bedrooms)."""
+
+    def __init__(self, DIM_G_64=64, DIM_G_32=128, DIM_G_16=256, DIM_G_8=512, DIM_G_4=512,
+                 DIM_D_64=128, DIM_D_32=256, DIM_D_16=512, DIM_D_8=1024):
+        self.DIM_G_64, self.DIM_G_32, self.DIM_G_16, self.DIM_G_8, self.DIM_G_4 = DIM_G_64, DIM_G_32, DIM_G_16, DIM_G_8, DIM_G_4
+        self.DIM_D_64, self.DIM_D_32, self.DIM_D_16, self.DIM_D_8 = DIM_D_64, DIM_D_32, DIM_D_16, DIM_D_8
+        self.OUTPUT_DIM = 3 * 128 * 128
+
+
+def _lsun_normalize(reg, name, x):
+    """:70-74"""
+    if 'Discriminator' in name:
+        return ops.Layernorm(reg, name, [1, 2, 3], x)
+    return ops.Batchnorm(reg, name, [0, 2, 3], x, fused=True)
+
+
+def _lsun_scaled_upsample_conv(reg, name, input_dim, output_dim, filter_size, x, he_init=True, biases=True):
+    """:87-94 (gain 0.5)"""
+    return ops.Conv2D(reg, name, input_dim, output_dim, filter_size, tf_ops.upsample2(x), he_init=he_init, biases=biases, gain=0.5)
+
+
+def _lsun_block(reg, name, input_dim, output_dim, filter_size, x, resample=None):
+    """:96-135"""
+    if output_dim == input_dim and resample is None:
+        shortcut = x
+    elif resample == 'down':
+        shortcut = ops.Conv2D(reg, name + '.Shortcut', input_dim, output_dim, 1, tf_ops.mean_pool2(x), he_init=False, biases=True)
+    elif resample == 'up':
+        shortcut = _lsun_scaled_upsample_conv(reg, name + '.Shortcut', input_dim, output_dim, 1, x, he_init=False, biases=True)
+    else:
+        shortcut = ops.Conv2D(reg, name + '.Shortcut', input_dim, output_dim, 1, x, he_init=False, biases=True)
+    out = torch.relu(_lsun_normalize(reg, name + '.N1', x))
+    if resample == 'down':
+        out = ops.Conv2D(reg, name + '.Conv1', input_dim, input_dim, filter_size, out)
+        out = torch.relu(_lsun_normalize(reg, name + '.N2', out))
+        out = ops.Conv2D(reg, name + '.Conv2', input_dim, output_dim, filter_size, out, stride=2)
+    elif resample == 'up':
+        out = _lsun_scaled_upsample_conv(reg, name + '.Conv1', input_dim, output_dim, filter_size, out)
+        out = torch.relu(_lsun_normalize(reg, name + '.N2', out))
+        out = ops.Conv2D(reg, name + '.Conv2', output_dim, output_dim, filter_size, out)
+    else:
+        out = ops.Conv2D(reg, name + '.Conv1', input_dim, output_dim, filter_size, out)
+        out = torch.relu(_lsun_normalize(reg, name + '.N2', out))
+        out = ops.Conv2D(reg, name + '.Conv2', output_dim, output_dim, filter_size, out)
+    return shortcut + out
+
+
+def lsun128_generator(reg, cfg, n_samples, noise):
+    """ResnetGenerator :137-166 (one tower)."""
+    out = ops.Linear(reg, 'Generator.Input', 128, 4 * 4 * cfg.DIM_G_4, noise)
+    out = out.reshape(-1, cfg.DIM_G_4, 4, 4)
+    out = _lsun_block(reg, 'Generator.4_3', cfg.DIM_G_4, cfg.DIM_G_8, 3, out, 'up')
+    out = _lsun_block(reg, 'Generator.8_3', cfg.DIM_G_8, cfg.DIM_G_16, 3, out, 'up')
+    out = _lsun_block(reg, 'Generator.16_3', cfg.DIM_G_16, cfg.DIM_G_32, 3, out, 'up')
+    out = _lsun_block(reg, 'Generator.32_3', cfg.DIM_G_32, cfg.DIM_G_64, 3, out, 'up')
+    out = torch.relu(_lsun_normalize(reg, 'Generator.OutputN', out))
+    out = _lsun_scaled_upsample_conv(reg, 'Generator.Output', cfg.DIM_G_64, 3, 5, out, he_init=False)
+    return torch.tanh(out).reshape(-1, cfg.OUTPUT_DIM)
+
+
+def lsun128_discriminator(reg, cfg, inputs, kp1, kp2, kp3, u=None):
+    """ResnetDiscriminator :168-205 -> (D [n], D_ [n, DIM_D_8])."""
+    out = inputs.reshape(-1, 3, 128, 128)
+    out = ops.Conv2D(reg, 'Discriminator.Input', 3, cfg.DIM_D_64, 5, out, he_init=True, stride=2)
+    out = _lsun_block(reg, 'Discriminator.64_3', cfg.DIM_D_64, cfg.DIM_D_32, 3, out, 'down')
+    out = _lsun_block(reg, 'Discriminator.32_3', cfg.DIM_D_32, cfg.DIM_D_16, 3, out, 'down')
+    out = _lsun_block(reg, 'Discriminator.16_3', cfg.DIM_D_16, cfg.DIM_D_8, 3, out, 'down')
+    if kp1 != 1.0:
+        out = tf_ops.dropout(out, kp1, u[0])
+    out = _lsun_block(reg, 'Discriminator.8_1', cfg.DIM_D_8, cfg.DIM_D_8, 3, out, None)
+    if kp2 != 1.0:
+        out = tf_ops.dropout(out, kp2, u[1])
+    out = _lsun_block(reg, 'Discriminator.8_2', cfg.DIM_D_8, cfg.DIM_D_8, 3, out, None)
+    if kp3 != 1.0:
+        out = tf_ops.dropout(out, kp3, u[2])
+    output2 = out.mean(dim=(2, 3))
+    out = ops.Linear(reg, 'Discriminator.Output', cfg.DIM_D_8, 1, output2)
+    return out.reshape(-1), output2

@@ -1,0 +1,116 @@
+"""128x128 ResNet CT-WGAN (config[4] nets, SURVEY 8(a) row A12: LS/wgan_LSUN_Bedrooms128.py:70-205) - generator and
+layer-normalised critic behind the shared unconditional CT-WGAN step, against the oracle restatement at reduced width:
+forward values, critic step (WGAN + CT + gradient penalty through Layernorm, two generator towers) and generator step.
+CPU: host logic on the torch stand-in kernels; GPU: the same through the HIP kernels."""
+import pytest
+import torch
+
+from oracle import nets as onets, steps as osteps, tflib_ref as oref
+
+DIMS_G = dict(DIM_G_64=4, DIM_G_32=8, DIM_G_16=8, DIM_G_8=16, DIM_G_4=16)
+DIMS_D = dict(DIM_D_64=8, DIM_D_32=8, DIM_D_16=16, DIM_D_8=16)
+DIMS_G_GPU = dict(DIM_G_64=32, DIM_G_32=32, DIM_G_16=64, DIM_G_8=64, DIM_G_4=64)
+DIMS_D_GPU = dict(DIM_D_64=32, DIM_D_32=64, DIM_D_16=64, DIM_D_8=128)
+
+
+def _oracle_from_product(lib, dtype=torch.float64):
+    reg = oref.Registry(dtype=dtype)
+    for n, p in lib._params.items():
+        t = p.detach().cpu().clone().to(dtype)
+        tr = n not in lib._non_trainable
+        reg[n] = t.requires_grad_(tr)
+        if not tr:
+            reg.non_trainable.add(n)
+    return reg
+
+
+def _cmp(a, b, tol, what, atol=1e-7):
+    a = a.detach().cpu().double().reshape(-1); b = b.detach().double().reshape(-1)
+    err = (a - b).abs().max().item(); scale = b.abs().max().item()
+    assert err <= tol * scale + atol, '%s: max err %.3e vs scale %.3e' % (what, err, scale)
+
+
+def _to(o, dev):
+    if isinstance(o, list):
+        return [_to(t, dev) for t in o]
+    return o.float().to(dev)
+
+
+def _run(lib, dev, dims_g, dims_d, B, tol):
+    import ctgan_amd.gan_lsun128 as M
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    M.configure(BATCH_SIZE=B, **dims_g, **dims_d)
+    try:
+        lib.set_seed(9)
+        M.build_params(dev)
+        ocfg = onets.Lsun128Cfg(**dims_g, **dims_d)
+        reg = _oracle_from_product(lib)
+        g = torch.Generator().manual_seed(3)
+        # forward parity (single tower / clean critic)
+        z = torch.randn(B, 128, generator=g)
+        x = M.Generator(B, noise=z.to(dev))
+        xo = onets.lsun128_generator(reg, ocfg, B, z.double())
+        _cmp(x, xo, tol, 'generator')
+        u = [torch.rand(B, *s, generator=g) for s in M.feat_shapes()]
+        d, f = M.Discriminator(x, 0.8, 0.5, 0.5, u=_to(u, dev))
+        do, fo = onets.lsun128_discriminator(reg, ocfg, xo, 0.8, 0.5, 0.5, [t.double() for t in u])
+        _cmp(d, do, 5 * tol, 'D'); _cmp(f, fo, 5 * tol, 'D_')
+        # steps: two generator towers of B/2 (:215-218), Adam(beta1 = 0), LR decay
+        h = B // 2
+        G = lambda r, n, zz: torch.cat([onets.lsun128_generator(r, ocfg, h, zz[:h]), onets.lsun128_generator(r, ocfg, h, zz[h:])])   # noqa: E731
+        D = lambda r, xx, uu: onets.lsun128_discriminator(r, ocfg, xx, 0.8, 0.5, 0.5, uu)                                         # noqa: E731
+        tr = DCGANTrainer(M, seed=1)
+        assert (tr.d_opt.beta1, tr.d_opt.beta2) == (0.0, 0.9) and tr.towers == 2 and not tr.piecewise
+        real_in = torch.randint(0, 256, (B, M.cfg.OUTPUT_DIM), generator=g, dtype=torch.int32)
+        real_o = 2 * ((real_in.double() / 255.) - .5)
+        rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
+        out = tr.d_step(real_in.to(dev), {k: _to(v, dev) for k, v in rnd.items()})
+        ref = osteps.dcgan_d_losses(reg, G, D, real_o, rnd)
+        gref = osteps.grads_of(ref['cost'], reg, 'Discriminator')
+        for k in ('cost', 'wgan_only', 'ct'):
+            _cmp(out[k], ref[k], 10 * tol, 'd.' + k, atol=1e-6)
+        _cmp(out['gp'], M.cfg.LAMBDA * ref['gp'], 10 * tol, 'd.gp', atol=1e-6)
+        _cmp(out['fake'], ref['fake'], tol, 'fake')
+        assert set(n for n, v in out['grads'].items() if v is not None) == set(gref)
+        for n in gref:
+            _cmp(out['grads'][n], gref[n], 50 * tol, 'dgrad ' + n, atol=3e-6)
+        lib.load_state_dict({n: t.detach().float() for n, t in reg.items()})
+        rg = osteps.make_rnd_dcgan_g(B, M.feat_shapes(), g)
+        out = tr.g_step({k: _to(v, dev) for k, v in rg.items()})
+        ref = osteps.dcgan_g_losses(reg, G, D, B, rg)
+        _cmp(out['cost'], ref['cost'], 10 * tol, 'g cost', atol=1e-6)
+        gref = osteps.grads_of(ref['cost'], reg, 'Generator')
+        for n in gref:
+            # relative L2: the generator gradient passes through 9 batch norms whose towers hold B/2 = 1-2 samples (the
+            # conditioning of a 2-sample normalisation amplifies fp32 rounding of single entries)
+            a = out['grads'][n].detach().cpu().double().reshape(-1); b = gref[n].detach().double().reshape(-1)
+            assert (a - b).norm().item() <= 400 * tol * b.norm().item() + 3e-6, 'ggrad ' + n
+        assert abs(M.lr(M.cfg.ITERS // 2) - 0.5 * M.cfg.LR) < 1e-12
+    finally:
+        M.configure()
+
+
+def test_lsun128_nets_and_steps_match_oracle(cpu_kernels):
+    import ctgan_amd.tflib as lib
+    _run(lib, 'cpu', DIMS_G, DIMS_D, 2, 2e-5)
+
+
+def test_lsun128_full_width_parameter_counts(cpu_kernels):
+    """D 47.7 M parameters, G 8.5 M at the reference widths (shapes only: parameters are created lazily)."""
+    import ctgan_amd.gan_lsun128 as M
+    c = M.Config()
+    def conv(k, i, o): return k * k * i * o + o
+    def block_d(i, o, down): return 2 * 2 * i * 0 + (2 * i) + conv(3, i, i if down else o) + 2 * (i if down else o) + conv(3, i if down else o, o) + (conv(1, i, o) if (down or i != o) else 0)
+    nd = conv(5, 3, c.DIM_D_64) + block_d(c.DIM_D_64, c.DIM_D_32, True) + block_d(c.DIM_D_32, c.DIM_D_16, True) + \
+        block_d(c.DIM_D_16, c.DIM_D_8, True) + 2 * block_d(c.DIM_D_8, c.DIM_D_8, False) + c.DIM_D_8 + 1
+    assert 47.0e6 < nd < 48.5e6
+
+
+@pytest.mark.gpu
+def test_lsun128_on_gpu():
+    import ctgan_amd.tflib as lib
+    lib.delete_all_params(); lib.set_device(None)
+    try:
+        _run(lib, 'cuda', DIMS_G_GPU, DIMS_D_GPU, 4, 5e-5)
+    finally:
+        lib.delete_all_params()
