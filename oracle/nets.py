@@ -279,3 +279,66 @@ def lsun128_discriminator(reg, cfg, inputs, kp1, kp2, kp3, u=None):
     output2 = out.mean(dim=(2, 3))
     out = ops.Linear(reg, 'Discriminator.Output', cfg.DIM_D_8, 1, output2)
     return out.reshape(-1), output2
+
+
+# ----------------------------------------------------------------------------- 64x64 "Good" nets
+def _g64_normalize(reg, name, x):
+    """TF/CT_gan_64x64.py:87-92 (MODE 'wgan-ct')."""
+    if 'Discriminator' in name:
+        return ops.Layernorm(reg, name, [1, 2, 3], x)
+    return ops.Batchnorm(reg, name, [0, 2, 3], x, fused=True)
+
+
+def _g64_block(reg, name, input_dim, output_dim, filter_size, x, resample=None):
+    """:127-162"""
+    if output_dim == input_dim and resample is None:
+        shortcut = x
+    elif resample == 'down':
+        shortcut = ops.Conv2D(reg, name + '.Shortcut', input_dim, output_dim, 1, tf_ops.mean_pool2(x), he_init=False, biases=True)
+    elif resample == 'up':
+        shortcut = ops.Conv2D(reg, name + '.Shortcut', input_dim, output_dim, 1, tf_ops.upsample2(x), he_init=False, biases=True)
+    else:
+        shortcut = ops.Conv2D(reg, name + '.Shortcut', input_dim, output_dim, 1, x, he_init=False, biases=True)
+    out = torch.relu(_g64_normalize(reg, name + '.BN1', x))
+    if resample == 'up':
+        out = ops.Conv2D(reg, name + '.Conv1', input_dim, output_dim, filter_size, tf_ops.upsample2(out), biases=False)
+        out = torch.relu(_g64_normalize(reg, name + '.BN2', out))
+        out = ops.Conv2D(reg, name + '.Conv2', output_dim, output_dim, filter_size, out)
+    else:
+        out = ops.Conv2D(reg, name + '.Conv1', input_dim, input_dim, filter_size, out, biases=False)
+        out = torch.relu(_g64_normalize(reg, name + '.BN2', out))
+        out = ops.Conv2D(reg, name + '.Conv2', input_dim, output_dim, filter_size, out)
+        if resample == 'down':
+            out = tf_ops.mean_pool2(out)
+    return shortcut + out
+
+
+def good_generator(reg, n_samples, noise, dim=64):
+    """GoodGenerator TF/CT_gan_64x64.py:204-221."""
+    out = ops.Linear(reg, 'Generator.Input', 128, 4 * 4 * 8 * dim, noise).reshape(-1, 8 * dim, 4, 4)
+    out = _g64_block(reg, 'Generator.Res1', 8 * dim, 8 * dim, 3, out, 'up')
+    out = _g64_block(reg, 'Generator.Res2', 8 * dim, 4 * dim, 3, out, 'up')
+    out = _g64_block(reg, 'Generator.Res3', 4 * dim, 2 * dim, 3, out, 'up')
+    out = _g64_block(reg, 'Generator.Res4', 2 * dim, 1 * dim, 3, out, 'up')
+    out = torch.relu(_g64_normalize(reg, 'Generator.OutputN', out))
+    out = ops.Conv2D(reg, 'Generator.Output', 1 * dim, 3, 3, out)
+    return torch.tanh(out).reshape(-1, 64 * 64 * 3)
+
+
+def good_discriminator(reg, inputs, kp1, kp2, kp3, u=None, dim=64):
+    """GoodDiscriminator :357-373."""
+    out = inputs.reshape(-1, 3, 64, 64)
+    out = ops.Conv2D(reg, 'Discriminator.Input', 3, dim, 3, out, he_init=False)
+    out = _g64_block(reg, 'Discriminator.Res1', dim, 2 * dim, 3, out, 'down')
+    out = _g64_block(reg, 'Discriminator.Res2', 2 * dim, 4 * dim, 3, out, 'down')
+    if kp1 != 1.0:
+        out = tf_ops.dropout(out, kp1, u[0])
+    out = _g64_block(reg, 'Discriminator.Res3', 4 * dim, 8 * dim, 3, out, 'down')
+    if kp2 != 1.0:
+        out = tf_ops.dropout(out, kp2, u[1])
+    out = _g64_block(reg, 'Discriminator.Res4', 8 * dim, 8 * dim, 3, out, 'down')
+    if kp3 != 1.0:
+        out = tf_ops.dropout(out, kp3, u[2])
+    output2 = out.reshape(-1, 4 * 4 * 8 * dim)
+    out = ops.Linear(reg, 'Discriminator.Output', 4 * 4 * 8 * dim, 1, output2)
+    return out.reshape(-1), output2
