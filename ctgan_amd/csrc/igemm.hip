@@ -1636,11 +1636,18 @@ MultiPlan multi_plan(const ctgan_conv_desc* d, int nseg, const int32_t* Ns) {
     long long kg = 0;
     for (int i = 0; i < nseg; ++i) kg += (long long)Ns[i] * d->P * d->Q;
     m.w = wgrad_plan(d->C, mt, d->K, (int)kg);
-    m.splits = 0;
-    for (int i = 0; i < nseg; ++i) {
-        const long long k = (long long)Ns[i] * d->P * d->Q;
-        m.seg_splits[i] = (int)((k + m.w.chunk - 1) / m.w.chunk);
-        m.splits += m.seg_splits[i];
+    // a split never straddles segments, so rounding each segment up can exceed the planned number of workgroups by
+    // nseg-1 - one more than a full round of the chip costs a whole extra round: grow the chunk until it fits
+    const int target = m.w.splits;
+    for (;;) {
+        m.splits = 0;
+        for (int i = 0; i < nseg; ++i) {
+            const long long k = (long long)Ns[i] * d->P * d->Q;
+            m.seg_splits[i] = (int)((k + m.w.chunk - 1) / m.w.chunk);
+            m.splits += m.seg_splits[i];
+        }
+        if (m.splits <= target || nseg == 1) break;
+        m.w.chunk += BK;
     }
     return m;
 }
