@@ -188,6 +188,7 @@ class ConvFn(Function):
         elif ctx.out_drop is not None and not ctx.out_drop_bwd_fused:
             gy = DropoutRngFn.apply(gy, ctx.out_drop[0], ctx.out_drop[1], ctx.out_drop[2], ctx.out_drop[3], _cl_strides(gy.shape))
         gx = gw = gb = gr = None
+        gr_alias = None
         mask = x if ctx.relu_in else None               # ReLU backward rides the dgrad epilogue
         need_w = ctx.needs_input_grad[1] and ctx.want_w
         need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
@@ -226,6 +227,8 @@ class ConvFn(Function):
                         gx = add(gx, g_fork)
                     if ctx.in_drop is not None:
                         gx = DropoutRngFn.apply(gx, ctx.in_drop[0], ctx.in_drop[1], ctx.in_drop[2], ctx.in_drop[3], _cl_strides(gx.shape))
+                elif ctx.has_resid and ctx.needs_input_grad[3] and torch.is_grad_enabled() and FORK_FUSION and not ctx.resid_up:
+                    gx, gr_alias = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask, g_fork, ctx.in_drop, True)
                 else:
                     gx = ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, mask, g_fork, ctx.in_drop)
                 g_fork = None
@@ -234,7 +237,7 @@ class ConvFn(Function):
         elif g_fork is not None:
             gx = g_fork
         if ctx.has_resid and ctx.needs_input_grad[3]:
-            gr = Pool2Fn.apply(gy, 1.0) if ctx.resid_up else gy
+            gr = gr_alias if gr_alias is not None else (Pool2Fn.apply(gy, 1.0) if ctx.resid_up else gy)
         if fork:
             torch.cuda.current_stream().wait_stream(ctx_join)
             for t in (gw, gb):
@@ -248,7 +251,13 @@ class ConvDgradFn(Function):
     gradient of conv(relu(x)) w.r.t. x, mask = x)"""
 
     @staticmethod
-    def forward(ctx, gy, w, b, g, N, out_strides, mask=None, resid=None, drop=None):
+    def forward(ctx, gy, w, b, g, N, out_strides, mask=None, resid=None, drop=None, fork=False):
+        # fork: also return gy itself (the gradient that passes straight through the conv's residual input), so that gy has
+        # ONE consumer in the first-backward graph and, in the double backward, the gradient arriving through that branch
+        # is added in the epilogue of the conv this node launches (resid) instead of by an autograd `add`.
+        ctx.fork = bool(fork)
+        if fork:
+            ctx.set_materialize_grads(False)
         ctx.g = g
         ctx.want_w = _WEIGHT_GRADS
         ctx.has_b = b is not None
@@ -259,10 +268,13 @@ class ConvDgradFn(Function):
             ctx.save_for_backward(gy, w, mask)
         else:
             ctx.save_for_backward(gy, w)
-        return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid, drop=drop)
+        dx = K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid, drop=drop)
+        return (dx, gy.view_as(gy)) if fork else dx
 
     @staticmethod
-    def backward(ctx, ggx):
+    def backward(ctx, ggx, gg_fork=None):
+        if ggx is None:                                 # fork only: dx itself was not used
+            return gg_fork, None, None, None, None, None, None, None, None, None
         if ctx.drop is not None:                        # the dropout mask is a constant of the second pass
             ggx = DropoutRngFn.apply(ggx, ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], _cl_strides(ggx.shape))
         g_res = ggx if (ctx.has_resid and ctx.needs_input_grad[7]) else None    # added after the mask
@@ -274,7 +286,9 @@ class ConvDgradFn(Function):
         g = ctx.g
         g_gy = g_w = g_b = None
         if ctx.needs_input_grad[0]:
-            g_gy = ConvFn.apply(ggx, w, None, None, g, None, False)
+            g_gy = ConvFn.apply(ggx, w, None, gg_fork, g, None, False)        # + the fork branch's gradient, in the epilogue
+        elif gg_fork is not None:
+            g_gy = gg_fork
         if ctx.needs_input_grad[1] and ctx.want_w:
             if torch.is_grad_enabled():
                 g_w = ConvWgradFn.apply(ggx, gy, g, False)
@@ -282,7 +296,7 @@ class ConvDgradFn(Function):
                 g_w, _ = _wgrad(ggx, gy, w, g, False, False)
         if ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w:
             g_b = ChannelSumFn.apply(ggx)
-        return g_gy, g_w, g_b, None, None, None, None, g_res, None
+        return g_gy, g_w, g_b, None, None, None, None, g_res, None, None
 
 
 # ---- derived-filter cache ---------------------------------------------------------------------------------
