@@ -148,9 +148,9 @@ __global__ void mean_diff_bwd_kernel(const float* __restrict__ gout, int na, int
 //   out = {wgan + ct + scale*acgan, wgan, ct, acgan}
 __global__ __launch_bounds__(256) void critic_heads_fwd_kernel(const float* __restrict__ d, const float* __restrict__ f,
                                                                const float* __restrict__ a, const int32_t* __restrict__ labels,
-                                                               int B, int nf, int ncls, float l2, float M, float scale,
-                                                               float* __restrict__ ct_i, float* __restrict__ probs,
-                                                               float* __restrict__ out) {
+                                                               const float* __restrict__ gp, int B, int nf, int ncls, float l2,
+                                                               float M, float scale, float* __restrict__ ct_i,
+                                                               float* __restrict__ probs, float* __restrict__ out) {
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = w; i < B; i += 4) {                       // one wave per row
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void critic_heads_fwd_kernel(const float* __re
     sr = block_sum(sr, sh); sf = block_sum(sf, sh); sc = block_sum(sc, sh); sl = block_sum(sl, sh);
     if (threadIdx.x == 0) {
         const float wgan = sf / (float)B - sr / (float)B, ct = sc / (float)B, ac = a ? sl / (float)B : 0.f;
-        out[0] = (wgan + ct) + scale * ac; out[1] = wgan; out[2] = ct; out[3] = ac;
+        const float pen = gp ? gp[0] : 0.f;                    // gradient penalty of the step (:284-286), computed elsewhere
+        out[0] = ((wgan + ct) + pen) + scale * ac; out[1] = wgan; out[2] = ct; out[3] = ac; out[4] = (wgan + ct) + pen;
     }
 }
 // gradients w.r.t. d [3B], f [3B,nf], a [3B,ncls] in one pass (every element written, zeros included);
@@ -294,12 +295,12 @@ int ctgan_softmax_ce_bwd(const float* probs, const int32_t* labels, const float*
     return ctgan_check_launch("softmax_ce_bwd");
 }
 
-int ctgan_critic_heads_fwd(const float* d, const float* f, const float* a, const int32_t* labels, int32_t B, int32_t nf,
-                           int32_t ncls, float lambda2, float M, float acgan_scale, float* ct_i, float* probs, float* out,
-                           ctgan_stream_t s) {
+int ctgan_critic_heads_fwd(const float* d, const float* f, const float* a, const int32_t* labels, const float* gp, int32_t B,
+                           int32_t nf, int32_t ncls, float lambda2, float M, float acgan_scale, float* ct_i, float* probs,
+                           float* out, ctgan_stream_t s) {
     if (!d || !f || !ct_i || !out || B <= 0 || nf <= 0 || (a && (!labels || !probs || ncls <= 0)))
         return ctgan_fail(CTGAN_E_BADARG, "critic_heads_fwd: bad argument");
-    hipLaunchKernelGGL(critic_heads_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d, f, a, labels, B, nf, ncls,
+    hipLaunchKernelGGL(critic_heads_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d, f, a, labels, gp, B, nf, ncls,
                        lambda2, M, acgan_scale, ct_i, probs, out);
     return ctgan_check_launch("critic_heads_fwd");
 }

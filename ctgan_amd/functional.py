@@ -1094,10 +1094,11 @@ class CriticHeadsFn(Function):
     """All loss heads of the batched dropout passes in one kernel: (cost_without_gp, wgan, ct, acgan)."""
 
     @staticmethod
-    def forward(ctx, d, f, a, labels, B, lam2, M, scale):
+    def forward(ctx, d, f, a, labels, B, lam2, M, scale, gp=None):
         d, f = d.contiguous(), f.contiguous()
         a = a.contiguous() if a is not None else None
-        out, ct_i, probs = K.critic_heads_fwd(d, f, a, labels, B, lam2, M, scale)
+        out, ct_i, probs = K.critic_heads_fwd(d, f, a, labels, B, lam2, M, scale, gp.reshape(1) if gp is not None else None)
+        ctx.has_gp = gp is not None
         ctx.cfg = (B, lam2, M, scale)
         ctx.labels = labels
         ctx.has_a = a is not None
@@ -1106,10 +1107,11 @@ class CriticHeadsFn(Function):
             ctx.save_for_backward(d, f, ct_i, probs)
         else:
             ctx.save_for_backward(d, f, ct_i)
-        return out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(out[4])
+        return out[0], out[1], out[2], out[3], out[4]
 
     @staticmethod
-    def backward(ctx, g0, g1, g2, g3):
+    def backward(ctx, g0, g1, g2, g3, _g4=None):
         B, lam2, M, scale = ctx.cfg
         if ctx.has_a:
             d, f, ct_i, probs = ctx.saved_tensors
@@ -1121,13 +1123,13 @@ class CriticHeadsFn(Function):
             z = lambda g: g.reshape(1) if g is not None else d.new_zeros(1)
             gout = torch.cat([z(g0), z(g1), z(g2), z(g3)])
         gd, gf, ga = K.critic_heads_bwd(d, f, probs, ctx.labels, ct_i, gout, B, lam2, M, scale)
-        return gd, gf, ga, None, None, None, None, None
+        return gd, gf, ga, None, None, None, None, None, (g0.reshape(()) if (ctx.has_gp and g0 is not None) else None)
 
 
-def critic_heads(d_all, f_all, a_all, labels, B, lam2=2.0, M=0.0, acgan_scale=1.0):
-    """(wgan + ct + acgan_scale*acgan, wgan, ct, acgan) of the batched dropout passes (rows: real pass 1, fake pass 1,
-    real pass 2)."""
-    return CriticHeadsFn.apply(d_all, f_all, a_all, labels, int(B), float(lam2), float(M), float(acgan_scale))
+def critic_heads(d_all, f_all, a_all, labels, B, lam2=2.0, M=0.0, acgan_scale=1.0, gp=None):
+    """(wgan + ct + gp + acgan_scale*acgan, wgan, ct, acgan, wgan + ct + gp) of the batched dropout passes (rows: real pass 1,
+    fake pass 1, real pass 2); gp = the step's gradient-penalty scalar (differentiable input)."""
+    return CriticHeadsFn.apply(d_all, f_all, a_all, labels, int(B), float(lam2), float(M), float(acgan_scale), gp)
 
 
 def gradient_penalty(g, lam):

@@ -361,8 +361,8 @@ class Trainer:
         out = {}
         # every loss head of the two dropout passes in one kernel (fwd) / one kernel (bwd): wgan :244, CT :288-291, ACGAN :246-248
         use_ac = cfg.CONDITIONAL and cfg.ACGAN
-        heads, wgan, ct, acgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2, cfg.Factor_M,
-                                                cfg.ACGAN_SCALE if use_ac else 0.0)
+        cost, wgan, ct, acgan, disc_wgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2,
+                                                          cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp if side is None else None)
         if use_ac:
             with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
                 _, _, a_clean = DiscriminatorTail(h.detach(), 1.0, 1.0, 1.0)
@@ -375,9 +375,10 @@ class Trainer:
             for t in (gp, slopes, grads):
                 t.record_stream(torch.cuda.current_stream())
 
-        cost = heads + gp
-        with torch.no_grad():
-            disc_wgan = wgan + ct + gp          # logged only (disc_wgan :304)
+        if side is not None:                     # GP branch on a side stream: joined above, added here
+            cost = cost + gp
+            with torch.no_grad():
+                disc_wgan = disc_wgan + gp
         out.update(cost=cost, wgan=disc_wgan, acgan=acgan, wgan_only=wgan, ct=ct, gp=gp, slopes=slopes, fake=fake,
                    real=real, d_real=d_all[:B], d_fake=d_all[B:2 * B], gp_grads=grads)
         return out

@@ -760,16 +760,16 @@ def pack(srcs, dst_offs, counts, flat):
     check(lib.ctgan_pack(P, O, C, n, _ptr(flat), _stream()), 'pack')
 
 
-def critic_heads_fwd(d, f, a, labels, B, lam2, M, scale):
-    """-> (out[4] = cost, wgan, ct, acgan; ct_i [B]; probs [B,ncls] or None)."""
-    _need_dev(d, f, a, labels)
+def critic_heads_fwd(d, f, a, labels, B, lam2, M, scale, gp=None):
+    """-> (out[5] = cost (incl. gp), wgan, ct, acgan, wgan + ct + gp; ct_i [B]; probs [B,ncls] or None)."""
+    _need_dev(d, f, a, labels, gp)
     assert d.is_contiguous() and f.is_contiguous() and d.numel() == 3 * B and f.shape[0] == 3 * B
     assert a is None or (a.is_contiguous() and a.shape[0] == 3 * B)
-    out = torch.empty(4, dtype=torch.float32, device=d.device)
+    out = torch.empty(5, dtype=torch.float32, device=d.device)
     ct_i = torch.empty(B, dtype=torch.float32, device=d.device)
     ncls = a.shape[1] if a is not None else 0
     probs = torch.empty(B, ncls, dtype=torch.float32, device=d.device) if a is not None else None
-    check(lib.ctgan_critic_heads_fwd(_ptr(d), _ptr(f), _ptr(a), _ptr(labels), B, f.shape[1], ncls, lam2, M, scale, _ptr(ct_i),
+    check(lib.ctgan_critic_heads_fwd(_ptr(d), _ptr(f), _ptr(a), _ptr(labels), _ptr(gp), B, f.shape[1], ncls, lam2, M, scale, _ptr(ct_i),
                                      _ptr(probs), _ptr(out), _stream()), 'critic_heads_fwd')
     return out, ct_i, probs
 

@@ -267,12 +267,13 @@ int ctgan_mean_diff_bwd(const float* gout, int32_t na, int32_t nb, float sa, flo
 
 /* All loss heads of one critic step over the batched dropout passes (TF/CT_gan_cifar_resnet.py:244-248,288-291):
  * d [3B], f [3B,nf], a [3B,ncls] (a may be NULL) with rows [0,B) = real pass 1, [B,2B) = fake pass 1, [2B,3B) = real
- * pass 2.  out[4] = {wgan + ct + acgan_scale*acgan, wgan, ct, acgan}; ct_i [B] and probs [B,ncls] are kept for the
+ * pass 2.  out[5] = {wgan + ct + gp + acgan_scale*acgan, wgan, ct, acgan, wgan + ct + gp} with gp = the step's gradient
+ * penalty scalar (device pointer, may be NULL = 0; :284-286, :304); ct_i [B] and probs [B,ncls] are kept for the
  * backward, which writes the full gradients gd [3B], gf [3B,nf], ga [3B,ncls] given gout[n_gout] = upstream
  * gradients of the four outputs (n_gout = 4) or of the summed cost only (n_gout = 1).  One launch each instead of ~25. */
-int ctgan_critic_heads_fwd(const float* d, const float* f, const float* a, const int32_t* labels, int32_t B, int32_t nf,
-                           int32_t ncls, float lambda2, float M, float acgan_scale, float* ct_i, float* probs, float* out,
-                           ctgan_stream_t stream);
+int ctgan_critic_heads_fwd(const float* d, const float* f, const float* a, const int32_t* labels, const float* gp,
+                           int32_t B, int32_t nf, int32_t ncls, float lambda2, float M, float acgan_scale, float* ct_i,
+                           float* probs, float* out, ctgan_stream_t stream);
 int ctgan_critic_heads_bwd(const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
                            const float* gout, int32_t n_gout, int32_t B, int32_t nf, int32_t ncls, float lambda2,
                            float M, float acgan_scale, float* gd, float* gf, float* ga, ctgan_stream_t stream);

@@ -445,7 +445,7 @@ def softmax_ce_bwd(probs, labels, gout):
 
 
 @_export
-def critic_heads_fwd(d, f, a, labels, B, lam2, M, scale):
+def critic_heads_fwd(d, f, a, labels, B, lam2, M, scale, gp=None):
     wgan = d[B:2 * B].mean() - d[:B].mean()
     ct_i = lam2 * (d[:B] - d[2 * B:]) ** 2 + 0.1 * lam2 * ((f[:B] - f[2 * B:]) ** 2).mean(dim=1)
     ct = torch.clamp(ct_i - M, min=0).mean()
@@ -454,7 +454,8 @@ def critic_heads_fwd(d, f, a, labels, B, lam2, M, scale):
         ac = -torch.log(probs[torch.arange(B), labels.long()]).mean()
     else:
         probs, ac = None, torch.zeros(())
-    return torch.stack([wgan + ct + scale * ac, wgan, ct, ac]).float(), ct_i, probs
+    pen = gp.reshape(()) if gp is not None else torch.zeros(())
+    return torch.stack([wgan + ct + pen + scale * ac, wgan, ct, ac, wgan + ct + pen]).float(), ct_i, probs
 
 
 @_export

@@ -620,7 +620,12 @@ def test_fused_critic_heads(K, with_a):
     ac = torch.nn.functional.cross_entropy(ar[:B], lab.long()) if with_a else torch.zeros((), dtype=torch.float64)
     cost = wgan + ct + (scale * ac if with_a else 0)
     dd = dev(d).requires_grad_(True); fd = dev(f).requires_grad_(True); ad = dev(a).requires_grad_(True)
-    got = F.critic_heads(dd, fd, ad if with_a else None, dev(lab), B, lam2, M, scale if with_a else 0.0)
+    gpv = dev(torch.tensor(0.37)).requires_grad_(True)
+    got = F.critic_heads(dd, fd, ad if with_a else None, dev(lab), B, lam2, M, scale if with_a else 0.0, gp=gpv)
+    assert abs(got[4].item() - (wgan + ct + 0.37).item()) < 2e-5
+    (g_gp,) = torch.autograd.grad(got[0], gpv, retain_graph=True)
+    assert abs(g_gp.item() - 1.0) < 1e-6
+    cost = cost + 0.37
     for x, y in zip(got, (cost, wgan, ct, ac)):
         assert abs(x.item() - y.item()) < 2e-5 * max(1.0, abs(y.item()))
     ins = [dd, fd] + ([ad] if with_a else []); rins = [dr, fr] + ([ar] if with_a else [])
