@@ -130,6 +130,7 @@ struct M2FParams {
     const float* w; long long w_off, ws_r, ws_s, ws_c, ws_j;            // w(r,s,c_many,j_few)
     const float* bias;
     int N, pad_t, pad_l, band, total, relu_in;                          // total = N * bands workgroup tasks
+    int dbg;                                                            // perf diagnosis (env CTGAN_M2F_DBG): 1 no row loads, 2 no compute
 };
 
 template <int R, int S, int JS>
@@ -245,17 +246,24 @@ __global__ __launch_bounds__(RING_NT) void m2f_ring_kernel(const M2FParams p) {
         const int slot = i >> 6, side = (i >> 5) & 1, c = i & 31;
         tile4[slot * slot_f4 + (side ? (W + 1) * 32 : 0) + c] = zero4;
     }
+    // filter: staged once per workgroup through LDS ([tap][j][128 channels], ~7 coalesced loads per thread) - a direct
+    // per-thread gather is 108 dword loads per thread and cost more than the whole strip's arithmetic
+    float* wbuf = obuf + p.band * JS * W;
+    for (int i = tid; i < 9 * JS * 128; i += RING_NT) {
+        const int c = i & 127, tj = i >> 7, j = tj % JS, t = tj / JS;
+        wbuf[i] = p.w[p.w_off + (t / 3) * p.ws_r + (t % 3) * p.ws_s + (long long)c * p.ws_c + j * p.ws_j];
+    }
+    __builtin_amdgcn_s_waitcnt(0xF70 | 0);                             // all ordinary loads retired before any row load is issued
+    __syncthreads();
     f32x2 wlo[9][JS], whi[9][JS];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < JS; ++j) {
-            const float* q = p.w + p.w_off + (t / 3) * p.ws_r + (t % 3) * p.ws_s + (long long)(l * 4) * p.ws_c + j * p.ws_j;
-            wlo[t][j] = f32x2{q[0], q[p.ws_c]}; whi[t][j] = f32x2{q[2 * p.ws_c], q[3 * p.ws_c]};
+            const float4 q = *reinterpret_cast<const float4*>(&wbuf[(t * JS + j) * 128 + l * 4]);
+            wlo[t][j] = f32x2{q.x, q.y}; whi[t][j] = f32x2{q.z, q.w};
         }
-    __builtin_amdgcn_s_waitcnt(0xF70 | 0);                             // filter slice in registers before any row load is issued
     __builtin_amdgcn_sched_barrier(0);
-
     const int LPR = W >> 4;                                            // direct loads per wave and row (2 pixels = 1 KB each)
     const float* img = p.x + (long long)n * p.xs_n;
     auto issue_row = [&](int r) {                                      // input row r into slot (r+1)%8; zero rows outside the image
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(RING_NT) void m2f_ring_kernel(const M2FParams p) {
             for (int i = tid; i < W * 32; i += RING_NT) tile4[slot * slot_f4 + 32 + i] = zero4;
             return;
         }
+        if (p.dbg & 1) return;
         const float* rowp = img + (long long)r * p.xs_h + (lane & 31) * 4;
         for (int c = 0; c < LPR; ++c) {
             const int chunk = c * 8 + wave;
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(RING_NT) void m2f_ring_kernel(const M2FParams p) {
         const float4* r0 = tile4 + ((prow + 0) & (RING_SLOTS - 1)) * slot_f4;      // slot of input row prow-1
         const float4* r1 = tile4 + ((prow + 1) & (RING_SLOTS - 1)) * slot_f4;
         const float4* r2 = tile4 + ((prow + 2) & (RING_SLOTS - 1)) * slot_f4;
-        for (int qc = grp; qc < W; qc += 16) {
+        for (int qc = grp; qc < W && !(p.dbg & 2); qc += 16) {
             f32x2 acc[JS];
 #pragma unroll
             for (int j = 0; j < JS; ++j) acc[j] = f32x2{0.f, 0.f};
@@ -534,9 +543,12 @@ static bool m2f_ring_ok(const M2FParams& p, int R, int S) {
 
 template <int JS>
 static int launch_m2f_ring(M2FParams p, hipStream_t st) {
+    static const int force_band = [] { const char* e = getenv("CTGAN_M2F_BAND"); return e ? atoi(e) : 0; }();
+    { const char* e = getenv("CTGAN_M2F_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.band = p.P >= 8 ? 8 : p.P;                                      // strip rows per workgroup
+    if (force_band > 0 && force_band <= p.P) p.band = force_band;
     const int strips = (p.P + p.band - 1) / p.band;
-    const size_t smem = (size_t)RING_SLOTS * (p.W + 2) * 128 * 4 + (size_t)p.band * JS * p.W * 4;
+    const size_t smem = (size_t)RING_SLOTS * (p.W + 2) * 128 * 4 + (size_t)p.band * JS * p.W * 4 + (size_t)9 * JS * 128 * 4;
     int rc = set_smem(&m2f_ring_kernel<JS>, smem);
     if (rc) return rc;
     hipLaunchKernelGGL((m2f_ring_kernel<JS>), dim3(p.N * strips), dim3(RING_NT), smem, st, p);
@@ -582,7 +594,7 @@ int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, co
     }
     if (resid || relu) return 0;
     if (d->xs[1] != 1 || (d->xs[0] | d->xs[2] | d->xs[3]) % 4 || !al16(x)) return 0;
-    M2FParams p;
+    M2FParams p; p.dbg = 0;
     p.x = x; p.xs_n = d->xs[0]; p.xs_h = d->xs[2]; p.xs_w = d->xs[3]; p.H = d->H; p.W = d->W; p.CM = d->C;
     p.y = y; p.ys_n = d->ys[0]; p.ys_c = d->ys[1]; p.ys_p = d->ys[2]; p.ys_q = d->ys[3]; p.P = d->P; p.Q = d->Q;
     p.w = w; p.w_off = 0; p.ws_r = (long long)d->S * d->C * d->K; p.ws_s = (long long)d->C * d->K; p.ws_c = d->K; p.ws_j = 1;
@@ -604,7 +616,7 @@ int ctgan_fewch_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w,
     if (d->C <= 4) {
         // dy has many channels, dx few: many -> few with the rotated filter, w'(r,s,k,c) = w[R-1-r,S-1-s,c,k]
         if (d->ys[1] != 1 || (d->ys[0] | d->ys[2] | d->ys[3]) % 4 || !al16(dy)) return 0;
-        M2FParams p;
+        M2FParams p; p.dbg = 0;
         p.x = dy; p.xs_n = d->ys[0]; p.xs_h = d->ys[2]; p.xs_w = d->ys[3]; p.H = d->P; p.W = d->Q; p.CM = d->K;
         p.y = dx; p.ys_n = d->xs[0]; p.ys_c = d->xs[1]; p.ys_p = d->xs[2]; p.ys_q = d->xs[3]; p.P = d->H; p.Q = d->W;
         p.w = w; p.w_off = rot_off; p.ws_r = -tapR; p.ws_s = -tapS; p.ws_c = 1; p.ws_j = d->K;
