@@ -551,30 +551,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
         }
     }
 
-    if constexpr (WAVES_K > 1) {                                          // combine the K groups through LDS
+    if constexpr (WAVES_K > 1) {                                          // combine the K groups through LDS: one round
         float* red = smem;
         constexpr int PER_WAVE = TM * TN * 16 * 64;
+        constexpr int GROUPS_MN = WAVES_M * WAVES_N;
+        static_assert((size_t)(WAVES_K - 1) * GROUPS_MN * PER_WAVE <= 2 * (size_t)STAGE, "K-group reduction buffer must fit the staging buffers");
+        if (wk != 0) {
 #pragma unroll
-        for (int r = 1; r < WAVES_K; ++r) {
-            if (wk == r) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) red[wmn * PER_WAVE + ((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
-            }
-            __syncthreads();
-            if (wk == 0) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[i][j][e] += red[wmn * PER_WAVE + ((i * TN + j) * 16 + e) * 64 + lane];
-            }
-            __syncthreads();
+                    for (int e = 0; e < 16; ++e)
+                        red[((wk - 1) * GROUPS_MN + wmn) * PER_WAVE + ((i * TN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
         }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int r = 1; r < WAVES_K; ++r)                             // fixed order r = 1, 2, 3: deterministic
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            acc[i][j][e] += red[((r - 1) * GROUPS_MN + wmn) * PER_WAVE + ((i * TN + j) * 16 + e) * 64 + lane];
+        }
+        __syncthreads();
     }
 
     if (p.d_vec) {
