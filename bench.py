@@ -207,7 +207,7 @@ def measure_gp_unit(trainer, batch, torch):
         trainer.rng.begin_step()
         xi = x.detach().requires_grad_(True)
         with F.weight_grads(False):
-            d = R.Discriminator(xi, labels, 0.8, 0.5, 0.5, rng=trainer.rng)[0]
+            d = R.Discriminator(xi, labels, 0.8, 0.5, 0.5, rng=trainer.rng, heads=('wgan',))[0]
         (g,) = torch.autograd.grad(d, xi, grad_outputs=torch.ones_like(d), create_graph=True)
         gp, _ = F.gradient_penalty(g, R.cfg.GP_LAMBDA)
         with F.deferred_wgrads():

@@ -217,8 +217,9 @@ def DiscriminatorTrunk(inputs):
     return ResidualBlock('Discriminator.2', D, D, 3, out, resample='down')
 
 
-def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None):
-    """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186)."""
+def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None, heads=('wgan', 'acgan')):
+    """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186).
+    `heads`: which of the two linear heads the caller consumes (the other one is not launched)."""
     D = cfg.DIM_D
 
     fuse = DROP_FUSION and FUSE_RELU and F.FORK_FUSION and not cfg.NORMALIZATION_D and u is None and rng is not None \
@@ -245,17 +246,17 @@ def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None):
         out = drop(2, out, kp3)
         out = nonlinearity(out)
     output2 = F.spatial_mean(out)
-    output_wgan = _linear.Linear('Discriminator.Output', D, 1, output2).reshape(-1)
-    if cfg.CONDITIONAL and cfg.ACGAN:
+    output_wgan = _linear.Linear('Discriminator.Output', D, 1, output2).reshape(-1) if 'wgan' in heads else None
+    if cfg.CONDITIONAL and cfg.ACGAN and 'acgan' in heads:
         output_acgan = _linear.Linear('Discriminator.ACGANOutput', D, 10, output2)
         return output_wgan, output2, output_acgan
     return output_wgan, output2, None
 
 
-def Discriminator(inputs, labels, kp1, kp2, kp3, u=None, rng=None):
+def Discriminator(inputs, labels, kp1, kp2, kp3, u=None, rng=None, heads=('wgan', 'acgan')):
     """:169-186 - returns (D [n], D_ [n,DIM_D], acgan logits [n,10] or None).
     `u` = the three dropout uniforms [n,DIM_D,8,8] (explicit draws); else drawn from `rng`."""
-    return DiscriminatorTail(DiscriminatorTrunk(inputs), kp1, kp2, kp3, u=u, rng=rng)
+    return DiscriminatorTail(DiscriminatorTrunk(inputs), kp1, kp2, kp3, u=u, rng=rng, heads=heads)
 
 
 def build_params(device=None):
@@ -345,7 +346,7 @@ class Trainer:
         with torch.cuda.stream(side) if side is not None else _nullctx():
             with F.weight_grads(not _critic_piecewise_linear()):
                 u_gp = rnd['u_gp'] if rnd is not None else None
-                d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng)[0]
+                d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng, heads=('wgan',))[0]
             ones = torch.ones_like(d_gp)
             (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
             gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
@@ -365,7 +366,7 @@ class Trainer:
                                                           cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp if side is None else None)
         if use_ac:
             with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
-                _, _, a_clean = DiscriminatorTail(h.detach(), 1.0, 1.0, 1.0)
+                _, _, a_clean = DiscriminatorTail(h.detach(), 1.0, 1.0, 1.0, heads=('acgan',))
                 acc = K.accuracy2(a_clean.contiguous(), labels, B)
             out['acc_real'], out['acc_fake'] = acc[0], acc[1]
         else:
