@@ -1191,6 +1191,9 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
             const long long t1 = (rows + 127) / 128, t2 = (rows + 63) / 64;
             const double e1 = (double)t1 / (double)(((t1 + 511) / 512) * 512), e2 = 0.95 * (double)t2 / (double)(((t2 + 767) / 768) * 768);
             cfg = e1 >= e2 ? 1 : 2;
+            // the 4-phase data gradient has only 16 K slices per tile: three resident 64x128 workgroups per CU cover the
+            // per-tile prologue / epilogue better than two 128x128 ones once there are several rounds (tools_ph4_sweep.py)
+            if (p.phases > 1 && rows >= 131072) cfg = 2;
         }
         else if (rows > 24576) cfg = 2;
         else if (rows > 12288) cfg = (p.g.C % 64 == 0) ? 8 : 3;
