@@ -184,12 +184,12 @@ class ConvFn(Function):
             return g_fork, None, None, None, None, None, None, None, None
         # gradient w.r.t. the conv result z, given the gradient w.r.t. y = dropout(relu(z))
         if ctx.out_relu:
-            gy = LReluBwdFn.apply(gy, y, 0.0, (1.0 / ctx.out_drop[0]) if ctx.out_drop is not None else 1.0)
+            gy = _relu_mask(gy, y, 0.0, (1.0 / ctx.out_drop[0]) if ctx.out_drop is not None else 1.0)
         elif ctx.out_drop is not None and not ctx.out_drop_bwd_fused:
             gy = DropoutRngFn.apply(gy, ctx.out_drop[0], ctx.out_drop[1], ctx.out_drop[2], ctx.out_drop[3], _cl_strides(gy.shape))
         gx = gw = gb = gr = None
         gr_alias = None
-        mask = x if ctx.relu_in else None               # ReLU backward rides the dgrad epilogue
+        mask = x.detach() if ctx.relu_in else None      # ReLU backward rides the dgrad epilogue (a constant: no graph edge)
         need_w = ctx.needs_input_grad[1] and ctx.want_w
         need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
         # first-order backward only (under create_graph the wgrad must stay an autograd node)
@@ -218,11 +218,11 @@ class ConvFn(Function):
                 gfull = ConvDgradFn.apply(gy, w, None, _no_up(g), ctx.N, None, None)
                 gx = Pool2Fn.apply(gfull, 1.0)
                 if mask is not None:
-                    gx = LReluBwdFn.apply(gx, x, 0.0)
+                    gx = _relu_mask(gx, x, 0.0)
             else:
                 keep = ctx.x_strides if _is_plain_nchw(x) else None
                 if mask is not None and not MASK_IN_DGRAD_EPILOGUE:
-                    gx = LReluBwdFn.apply(ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, None), x, 0.0)
+                    gx = _relu_mask(ConvDgradFn.apply(gy, w, None, g, ctx.N, keep, None), x, 0.0)
                     if g_fork is not None:
                         gx = add(gx, g_fork)
                     if ctx.in_drop is not None:
@@ -280,7 +280,7 @@ class ConvDgradFn(Function):
         g_res = ggx if (ctx.has_resid and ctx.needs_input_grad[7]) else None    # added after the mask
         if ctx.has_mask:
             gy, w, mask = ctx.saved_tensors
-            ggx = LReluBwdFn.apply(ggx, mask, 0.0)      # the mask is a constant of the second pass
+            ggx = _relu_mask(ggx, mask, 0.0)      # the mask is a constant of the second pass
         else:
             gy, w = ctx.saved_tensors
         g = ctx.g
@@ -389,14 +389,14 @@ def _wgrad_backward(ctx, ggw, ggb):
     g = ctx.g
     g_x = g_gy = None
     ggw = ggw.contiguous()
-    mask = x if ctx.relu_x else None
+    mask = x.detach() if ctx.relu_x else None
     if ctx.needs_input_grad[0]:
         if g.x_up:
             g_x = Pool2Fn.apply(ConvDgradFn.apply(gy, ggw, None, _no_up(g), ctx.N, None, None), 1.0)
             if mask is not None:
-                g_x = LReluBwdFn.apply(g_x, x, 0.0)
+                g_x = _relu_mask(g_x, x, 0.0)
         elif mask is not None and not MASK_IN_DGRAD_EPILOGUE:
-            g_x = LReluBwdFn.apply(ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None, None), x, 0.0)
+            g_x = _relu_mask(ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None, None), x, 0.0)
         else:
             g_x = ConvDgradFn.apply(gy, ggw, None, g, ctx.N, None, mask)
     if ctx.needs_input_grad[1]:
@@ -635,7 +635,14 @@ class LReluFn(Function):
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
-        return LReluBwdFn.apply(gy, y, ctx.alpha), None
+        return _relu_mask(gy, y, ctx.alpha), None
+
+
+def _relu_mask(gy, ref, alpha, scale=1.0):
+    """gy * (ref > 0 ? 1 : alpha) * scale.  `ref` enters DETACHED: the mask's derivative w.r.t. ref is zero almost everywhere,
+    and a graph edge to the forward activation would make the engine walk the whole forward graph in the double backward
+    (ten data gradients of exact zeros per gradient-penalty pass - what TF executes as written)."""
+    return LReluBwdFn.apply(gy, ref.detach(), alpha, scale)
 
 
 class LReluBwdFn(Function):
@@ -648,7 +655,7 @@ class LReluBwdFn(Function):
     @staticmethod
     def backward(ctx, ggx):
         (ref,) = ctx.saved_tensors
-        return LReluBwdFn.apply(ggx, ref, ctx.alpha, ctx.scale), None, None, None
+        return _relu_mask(ggx, ref, ctx.alpha, ctx.scale), None, None, None
 
 
 def relu(x):
