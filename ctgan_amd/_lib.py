@@ -36,6 +36,12 @@ class FilterJob(ctypes.Structure):
                 ('kind', c_int32), ('pad_t', c_int32), ('pad_l', c_int32), ('scale', ctypes.c_float)]
 
 
+class WgradGroup(ctypes.Structure):
+    """struct ctgan_wgrad_group (include/ctgan_hip.h)."""
+    _fields_ = [('d', ConvDesc), ('nseg', c_int32), ('Ns', c_int32 * 3), ('seg_flags', c_int32 * 3),
+                ('xs', ctypes.c_void_p * 3), ('dys', ctypes.c_void_p * 3), ('dw', ctypes.c_void_p), ('db', ctypes.c_void_p)]
+
+
 class EpilogueExt(ctypes.Structure):
     """struct ctgan_epilogue_ext (include/ctgan_hip.h)."""
     _fields_ = [('drop_keep', ctypes.c_float), ('drop_seed', ctypes.c_uint64), ('drop_stream_id', ctypes.c_uint64),
@@ -56,6 +62,8 @@ SIGNATURES = {
     'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     'ctgan_conv2d_wgrad_multi': (c_int, [POINTER(ConvDesc), c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), _p, _p, _p,
                                          c_size_t, _p]),
+    'ctgan_conv2d_wgrad_group_workspace_bytes': (c_size_t, [POINTER(WgradGroup), c_int32]),
+    'ctgan_conv2d_wgrad_group': (c_int, [POINTER(WgradGroup), c_int32, _p, c_size_t, _p]),
     'ctgan_conv2d_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d_fwd': (c_int, [_D, _p, _p, _p, _p, _p, c_int, _p]),
     'ctgan_conv2d_fwd_ex': (c_int, [_D, _p, _p, _p, _p, _p, c_int, POINTER(EpilogueExt), _p]),

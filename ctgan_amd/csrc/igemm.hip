@@ -870,7 +870,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_kernel(con
 // M tile also accumulate the column sums of the dy tiles they stage: the bias gradient rides along
 // as slab row Mtot at no extra HBM traffic.
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_pipe_body(const WgradParams& p, const int bx, const int by) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int STAGE = BK * BM + BK * BN;
@@ -885,17 +885,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.Ng + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int tile_m = bx / tiles_n, tile_n = bx - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const float* Xp = p.X; const float* DYp = p.DY;
-    int seg_kg = p.Kg, split = blockIdx.y, relu_x = p.relu_x, seg_bias = 1;
+    int seg_kg = p.Kg, split = by, relu_x = p.relu_x, seg_bias = 1;
     unsigned x_bytes = p.x_bytes, dy_bytes = p.dy_bytes;
     if (p.nseg > 0) {
         int si = 0;
 #pragma unroll
         for (int t = 1; t < CTGAN_WGRAD_MAX_SEGS; ++t)
-            if (t < p.nseg && (int)blockIdx.y >= p.seg[t].split0) si = t;
-        Xp = p.seg[si].X; DYp = p.seg[si].DY; seg_kg = p.seg[si].Kg; split = blockIdx.y - p.seg[si].split0;
+            if (t < p.nseg && by >= p.seg[t].split0) si = t;
+        Xp = p.seg[si].X; DYp = p.seg[si].DY; seg_kg = p.seg[si].Kg; split = by - p.seg[si].split0;
         relu_x = p.seg[si].relu_x; seg_bias = p.seg[si].bias; x_bytes = p.seg[si].x_bytes; dy_bytes = p.seg[si].dy_bytes;
     }
     const int k_begin = split * p.chunk;
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
         __syncthreads();
     }
 
-    float* out = p.OUT + (long long)blockIdx.y * (p.Mtot + p.with_bias) * p.Ng;
+    float* out = p.OUT + (long long)by * (p.Mtot + p.with_bias) * p.Ng;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * TN * 32 + j * 32 + l31;
@@ -1035,6 +1035,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
             }
     }
     if (bias_row && n0 + tid < p.Ng) out[(long long)p.Mtot * p.Ng + n0 + tid] = bsum;
+}
+
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kernel(const WgradParams p) {
+    wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(p, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Several weight gradients of the SAME tile configuration in one launch (the deferred weight gradients of a step are
+// independent of each other): workgroup b works on problem i with block0[i] <= b < block0[i+1], tile-major inside the
+// problem like the single-problem grid.  Problems are ordered longest chunk first.
+struct WgradGroupParams {
+    int n;
+    int block0[CTGAN_WGRAD_GROUP_MAX + 1];
+    int tiles[CTGAN_WGRAD_GROUP_MAX];
+    WgradParams p[CTGAN_WGRAD_GROUP_MAX];
+};
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_group_kernel(const WgradGroupParams gp) {
+    const int b = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int t = 1; t < CTGAN_WGRAD_GROUP_MAX; ++t)
+        if (t < gp.n && b >= gp.block0[t]) i = t;
+    const int r = b - gp.block0[i];
+    const int by = r / gp.tiles[i];
+    wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(gp.p[i], r - by * gp.tiles[i], by);
 }
 
 // out[i] = sum_s part[s][i]   (fixed order => deterministic)
@@ -1252,6 +1279,39 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
 
 // ---- weight-gradient planning (shared by the launcher and the workspace query) ------------
 enum WTile { W128x128, W64x128, W32x128, W64x64, W128x32 };
+// the split-K reductions of several weight gradients in one launch: blockIdx.y = job
+struct ReduceJob { const float* part; float* out; float* out2; long long n, n_main; int splits, pad; };
+struct ReduceJobs { int n; int pad; ReduceJob j[CTGAN_REDUCE_BATCH]; };
+__global__ void splitk_reduce_batch_kernel(const ReduceJobs jobs) {
+    const ReduceJob& jb = jobs.j[blockIdx.y];
+    const long long n = jb.n, n_main = jb.n_main;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;       // n, n_main multiples of 4 on this path
+    if (i >= n) return;
+    const float* part = jb.part;
+    const int splits = jb.splits;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {                                                   // same order as splitk_reduce_kernel
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)(k + 0) * n + i);
+        const float4 v1 = *reinterpret_cast<const float4*>(part + (long long)(k + 1) * n + i);
+        const float4 v2 = *reinterpret_cast<const float4*>(part + (long long)(k + 2) * n + i);
+        const float4 v3 = *reinterpret_cast<const float4*>(part + (long long)(k + 3) * n + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; k < splits; ++k) {
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float4 r;
+    r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
+    r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
+    if (i < n_main) *reinterpret_cast<float4*>(jb.out + i) = r;
+    else *reinterpret_cast<float4*>(jb.out2 + (i - n_main)) = r;
+}
+
 struct WPlan { WTile tile; int bm, bn, tiles, splits, chunk; };
 
 WPlan wgrad_plan(int C, int Mtot, int Ng, int Kg) {
@@ -1665,23 +1725,23 @@ extern "C" size_t ctgan_conv2d_wgrad_multi_workspace_bytes(const ctgan_conv_desc
     return (size_t)m.splits * ((size_t)d->R * d->S * d->C + 1) * d->K * sizeof(float);
 }
 
-extern "C" int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs, const float* const* dys,
-                                        const int32_t* Ns, const int32_t* seg_flags, float* dw, float* db, void* ws, size_t ws_bytes,
-                                        ctgan_stream_t stream) {
-    int rc = check_desc(d, "conv2d_wgrad_multi");
+namespace {
+// validates one multi-segment weight gradient and fills its kernel parameters / plan (no launch)
+int prepare_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs, const float* const* dys, const int32_t* Ns,
+                  const int32_t* seg_flags, const float* dw, const float* db, WgradParams& p, MultiPlan& m, const char* who) {
+    int rc = check_desc(d, who);
     if (rc) return rc;
     if (!xs || !dys || !Ns || !seg_flags || !dw || nseg < 1 || nseg > CTGAN_WGRAD_MAX_SEGS)
-        return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: bad argument");
+        return ctgan_fail(CTGAN_E_BADARG, "%s: bad argument", who);
     if (g_force_generic || ctgan_is_small_linear(d) || ctgan_fewch_handles(d))
-        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_wgrad_multi: shape is served by another kernel family");
-    WgradParams p;
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "%s: shape is served by another kernel family", who);
     p.g = geom_from_x(d);
     const Geom& g = p.g;
-    p.X = xs[0]; p.DY = dys[0]; p.OUT = dw;
+    p.X = xs[0]; p.DY = dys[0]; p.OUT = nullptr;
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
     p.relu_x = 0; p.x_bytes = p.dy_bytes = 0;
-    const MultiPlan m = multi_plan(d, nseg, Ns);
+    m = multi_plan(d, nseg, Ns);
     const WPlan& w = m.w;
     bool ok = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) && p.dy_k == 1 && (p.Ng % 4 == 0) &&
               (p.dy_n % 4 == 0) && (p.dy_p % 4 == 0) && (p.dy_q % 4 == 0) &&
@@ -1690,7 +1750,7 @@ extern "C" int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, 
     int split0 = 0;
     bool any_bias = false;
     for (int i = 0; i < nseg && ok; ++i) {
-        if (!xs[i] || !dys[i] || Ns[i] <= 0) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: bad segment %d", i);
+        if (!xs[i] || !dys[i] || Ns[i] <= 0) return ctgan_fail(CTGAN_E_BADARG, "%s: bad segment %d", who, i);
         ok = ok && ((reinterpret_cast<uintptr_t>(xs[i]) | reinterpret_cast<uintptr_t>(dys[i])) & 15) == 0;
         const long long x_elems = (long long)(Ns[i] - 1) * g.s_n + (long long)(g.H - 1) * g.s_h + (long long)(g.W - 1) * g.s_w + g.C;
         const long long y_elems = (long long)(Ns[i] - 1) * p.dy_n + (long long)(g.P - 1) * p.dy_p + (long long)(g.Q - 1) * p.dy_q + p.Ng;
@@ -1703,19 +1763,125 @@ extern "C" int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, 
         split0 += m.seg_splits[i];
         kg += sg.Kg;
     }
-    if (!ok) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_wgrad_multi: operands do not qualify for the pipelined kernel");
-    if (any_bias != (db != nullptr)) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: db must be given iff a segment carries the bias flag");
+    if (!ok) return ctgan_fail(CTGAN_E_UNSUPPORTED, "%s: operands do not qualify for the pipelined kernel", who);
+    if (any_bias != (db != nullptr)) return ctgan_fail(CTGAN_E_BADARG, "%s: db must be given iff a segment carries the bias flag", who);
     p.nseg = nseg; p.Kg = (int)kg;
+    return CTGAN_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_wgrad_pipe_group(const WgradGroupParams& gp, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr size_t smem_bytes = 2 * (size_t)(BK * BM + BK * BN) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_pipe_group_kernel<WM, WN, TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return ctgan_fail(CTGAN_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad_pipe_group<%dx%d,n%d>", BM, BN, gp.n);
+    hipLaunchKernelGGL((igemm_wgrad_pipe_group_kernel<WM, WN, TM, TN>), dim3(gp.block0[gp.n]), dim3(64 * WM * WN), smem_bytes, st, gp);
+    return ctgan_check_launch("igemm_wgrad_pipe_group");
+}
+}  // namespace
+
+extern "C" int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs, const float* const* dys,
+                                        const int32_t* Ns, const int32_t* seg_flags, float* dw, float* db, void* ws, size_t ws_bytes,
+                                        ctgan_stream_t stream) {
+    WgradParams p;
+    MultiPlan m;
+    int rc = prepare_multi(d, nseg, xs, dys, Ns, seg_flags, dw, db, p, m, "conv2d_wgrad_multi");
+    if (rc) return rc;
+    const WPlan& w = m.w;
     const size_t need = (size_t)m.splits * (p.Mtot + 1) * p.Ng * sizeof(float);
     if (!ws || ws_bytes < need) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: workspace too small (%zu < %zu)", ws_bytes, need);
     WPlan w2 = w;
     w2.splits = m.splits;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // a single split without bias would write dw directly; the multi path always goes through the slabs
-    if (w2.splits == 1 && !db) w2.splits = 1;
     if (w.tile == W128x128) rc = launch_wgrad_pipe<2, 2, 2, 2>(p, w2, dw, db, ws, st);
     else if (w.tile == W64x128) rc = launch_wgrad_pipe<1, 4, 2, 1>(p, w2, dw, db, ws, st);
     else if (w.tile == W32x128) rc = launch_wgrad_pipe<1, 4, 1, 1>(p, w2, dw, db, ws, st);
     else rc = launch_wgrad_pipe<2, 2, 1, 1>(p, w2, dw, db, ws, st);
     return rc;
+}
+
+// ---- grouped weight gradients: every deferred weight gradient of a step in one launch per tile configuration, and ONE
+// launch for all their split-K reductions --------------------------------------------------------------------------------
+namespace {
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+}
+extern "C" size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n) {
+    if (!groups || n < 1) return 0;
+    size_t tot = 0;
+    for (int i = 0; i < n; ++i)
+        tot += align256(ctgan_conv2d_wgrad_multi_workspace_bytes(&groups[i].d, groups[i].nseg, groups[i].Ns));
+    return tot;
+}
+
+extern "C" int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+    if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_group: bad argument");
+    static thread_local MultiPlan M[CTGAN_WGRAD_GROUP_LIMIT];
+    static thread_local WgradParams PT[CTGAN_WGRAD_GROUP_LIMIT];
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {                        // validate everything before the first launch
+        const ctgan_wgrad_group& G = groups[i];
+        int rc = prepare_multi(&G.d, G.nseg, G.xs, G.dys, G.Ns, G.seg_flags, G.dw, G.db, PT[i], M[i], "conv2d_wgrad_group");
+        if (rc) return rc;
+        const size_t need = (size_t)M[i].splits * (PT[i].Mtot + 1) * PT[i].Ng * sizeof(float);
+        if (!ws || off + need > ws_bytes) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_group: workspace too small");
+        PT[i].OUT = reinterpret_cast<float*>(static_cast<char*>(ws) + off);
+        PT[i].chunk = M[i].w.chunk;
+        PT[i].with_bias = G.db ? 1 : 0;
+        off += align256(need);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static const WTile order[4] = {W128x128, W64x128, W64x64, W32x128};
+    for (int t = 0; t < 4; ++t) {
+        int idx[CTGAN_WGRAD_GROUP_LIMIT], cnt = 0;
+        for (int i = 0; i < n; ++i) if (M[i].w.tile == order[t]) idx[cnt++] = i;
+        // longest chunk first: the workgroups that run longest start first
+        for (int a = 1; a < cnt; ++a)
+            for (int b = a; b > 0 && M[idx[b]].w.chunk > M[idx[b - 1]].w.chunk; --b) { const int x = idx[b]; idx[b] = idx[b - 1]; idx[b - 1] = x; }
+        for (int base = 0; base < cnt; base += CTGAN_WGRAD_GROUP_MAX) {
+            WgradGroupParams gp;
+            gp.n = (cnt - base) < CTGAN_WGRAD_GROUP_MAX ? (cnt - base) : CTGAN_WGRAD_GROUP_MAX;
+            int b0 = 0;
+            for (int k = 0; k < CTGAN_WGRAD_GROUP_MAX; ++k) {
+                if (k < gp.n) {
+                    const int i = idx[base + k];
+                    gp.block0[k] = b0; gp.tiles[k] = M[i].w.tiles; gp.p[k] = PT[i];
+                    b0 += M[i].w.tiles * M[i].splits;
+                } else {
+                    gp.block0[k] = b0; gp.tiles[k] = 1; gp.p[k] = PT[idx[base]];
+                }
+            }
+            gp.block0[CTGAN_WGRAD_GROUP_MAX] = b0;
+            for (int k = gp.n; k <= CTGAN_WGRAD_GROUP_MAX; ++k) gp.block0[k] = b0;
+            int rc;
+            if (order[t] == W128x128) rc = launch_wgrad_pipe_group<2, 2, 2, 2>(gp, st);
+            else if (order[t] == W64x128) rc = launch_wgrad_pipe_group<1, 4, 2, 1>(gp, st);
+            else if (order[t] == W32x128) rc = launch_wgrad_pipe_group<1, 4, 1, 1>(gp, st);
+            else rc = launch_wgrad_pipe_group<2, 2, 1, 1>(gp, st);
+            if (rc) return rc;
+        }
+    }
+    for (int base = 0; base < n; base += CTGAN_REDUCE_BATCH) {
+        ReduceJobs jobs;
+        jobs.n = (n - base) < CTGAN_REDUCE_BATCH ? (n - base) : CTGAN_REDUCE_BATCH;
+        jobs.pad = 0;
+        long long max_n = 0;
+        for (int k = 0; k < CTGAN_REDUCE_BATCH; ++k) {
+            const int i = base + (k < jobs.n ? k : 0);
+            const long long n_main = (long long)PT[i].Mtot * PT[i].Ng, nn = n_main + (groups[i].db ? PT[i].Ng : 0);
+            jobs.j[k].part = PT[i].OUT; jobs.j[k].out = groups[i].dw; jobs.j[k].out2 = groups[i].db ? groups[i].db : groups[i].dw;
+            jobs.j[k].n = nn; jobs.j[k].n_main = n_main; jobs.j[k].splits = M[i].splits; jobs.j[k].pad = 0;
+            if (k < jobs.n && nn > max_n) max_n = nn;
+        }
+        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)((max_n / 4 + 255) / 256), jobs.n), dim3(256), 0, st, jobs);
+        int rc = ctgan_check_launch("splitk_reduce_batch");
+        if (rc) return rc;
+    }
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad_pipe_group<n%d>", n);
+    return CTGAN_OK;
 }

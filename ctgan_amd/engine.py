@@ -65,7 +65,8 @@ class GraphedTrainer:
         F.prepare_filters()
         t.rng.begin_step()
         out = t.g_losses()
-        grads = torch.autograd.grad(out['cost'], t.g_params, allow_unused=True)
+        with F.deferred_wgrads():
+            grads = torch.autograd.grad(out['cost'], t.g_params, allow_unused=True)
         t.g_opt.gather_grads(grads)
         if self.adam_in_graph:
             t.g_opt.step(1.0)

@@ -57,6 +57,8 @@ def weight_grads(enabled):
 # double backward - instead of one wgrad + reduction per use and an autograd `add` per extra use.
 _DEFER = {'on': False, 'groups': None, 'post': None}
 DEFER_WGRADS = _os.environ.get('CTGAN_DEFER_WGRADS', '1') != '0'
+# A/B switch: all queued weight gradients in one launch per tile configuration + one launch for their reductions
+WGRAD_GROUPED = _os.environ.get('CTGAN_WGRAD_GROUPED', '1') != '0'
 
 
 class _WgradGroup:
@@ -74,10 +76,29 @@ def deferred_wgrads():
     finally:
         groups, post = _DEFER['groups'], _DEFER['post']
         _DEFER.update(on=False, groups=None, post=None)
-        for grp in groups.values():
-            _flush_group(grp)
+        _flush_groups(list(groups.values()))
         for fn in post:
             fn()
+
+
+def _flush_groups(grps):
+    """All queued weight gradients: one grouped launch per tile configuration + one reduction launch when every group
+    fits the pipelined kernel (K.conv_wgrad_group), else group by group."""
+    simple = [g for g in grps if len(g.segs) <= K.WGRAD_MAX_SEGS]
+    if WGRAD_GROUPED and len(simple) > 1 and K.PROFILE is None:
+        for g in simple:                                   # a queued bias buffer no segment contributes to
+            if g.db is not None and not any(sg[3] for sg in g.segs):
+                g.db.zero_()
+        todo = simple
+        try:
+            for i in range(0, len(todo), K.WGRAD_GROUP_LIMIT):
+                K.conv_wgrad_group([(g.segs, g.g, g.dw, g.db if any(sg[3] for sg in g.segs) else None)
+                                    for g in todo[i:i + K.WGRAD_GROUP_LIMIT]])
+            grps = [g for g in grps if len(g.segs) > K.WGRAD_MAX_SEGS]
+        except NotImplementedError:
+            pass                                           # nothing was launched: fall back below
+    for grp in grps:
+        _flush_group(grp)
 
 
 def _flush_group(grp):

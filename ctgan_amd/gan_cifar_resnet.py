@@ -441,7 +441,8 @@ class Trainer:
         F.prepare_filters()
         self.rng.begin_step()
         out = self.g_losses(rnd)
-        grads = torch.autograd.grad(out['cost'], self.g_params, allow_unused=True)
+        with F.deferred_wgrads():
+            grads = torch.autograd.grad(out['cost'], self.g_params, allow_unused=True)
         self._apply(self.g_opt, grads, iteration, set_lr)
         self.rng.end_step()
         out['grads'] = dict(zip([n for n, _ in self.g_named], grads))

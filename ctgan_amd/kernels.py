@@ -295,6 +295,44 @@ def conv_wgrad_multi(segs, g, dw, db=None):
     return dw, db
 
 
+WGRAD_GROUP_LIMIT = 32
+
+
+def conv_wgrad_group(groups):
+    """groups = [(segs, g, dw, db), ...] - each entry as for conv_wgrad_multi, for DIFFERENT filters: one launch per
+    tile configuration for all of them plus one launch for all split-K reductions (csrc: ctgan_conv2d_wgrad_group).
+    Raises NotImplementedError (nothing launched) if any entry is outside the pipelined kernel."""
+    from ._lib import WgradGroup
+    n = len(groups)
+    assert 1 <= n <= WGRAD_GROUP_LIMIT
+    arr = (WgradGroup * n)()
+    dev = groups[0][0][0][0].device
+    for i, (segs, g, dw, db) in enumerate(groups):
+        assert 1 <= len(segs) <= WGRAD_MAX_SEGS
+        x0, gy0 = segs[0][0], segs[0][1]
+        for x, gy, _, _ in segs:
+            _need_dev(x, gy)
+            assert tuple(x.shape[1:]) == _x_phys_shape(g, 1)[1:] and tuple(gy.shape[1:]) == (g.K, g.P, g.Q)
+            assert x.stride()[1:] == x0.stride()[1:] and gy.stride()[1:] == gy0.stride()[1:] and x.shape[0] == gy.shape[0]
+        assert tuple(dw.shape) == (g.R, g.S, g.C, g.K) and dw.is_contiguous()
+        assert (db is not None) == any(sg[3] for sg in segs)
+        G = arr[i]
+        G.d = g.desc(x0.shape[0], x0.stride(), gy0.stride())
+        G.nseg = len(segs)
+        for k, sg in enumerate(segs):
+            G.Ns[k] = sg[0].shape[0]
+            G.seg_flags[k] = (2 if sg[2] else 0) | (4 if sg[3] else 0)
+            G.xs[k] = sg[0].data_ptr()
+            G.dys[k] = sg[1].data_ptr()
+        G.dw = dw.data_ptr()
+        G.db = db.data_ptr() if db is not None else None
+    nb = lib.ctgan_conv2d_wgrad_group_workspace_bytes(arr, n)
+    if nb == 0:
+        raise NotImplementedError('conv2d_wgrad_group: unsupported group')
+    ws = workspace(nb, dev)
+    check(lib.ctgan_conv2d_wgrad_group(arr, n, _ptr(ws), ws.numel(), _stream()), 'conv2d_wgrad_group')
+
+
 def im2col(x, g, cpad):
     """x logical [N,C,H,W] (any strides) -> channels-last [N,cpad,P,Q] patch tensor."""
     _need_dev(x)

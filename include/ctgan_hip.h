@@ -96,6 +96,26 @@ size_t ctgan_conv2d_wgrad_multi_workspace_bytes(const ctgan_conv_desc* d, int32_
 int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs, const float* const* dys,
                              const int32_t* Ns, const int32_t* seg_flags, float* dw, float* db, void* ws,
                              size_t ws_bytes, ctgan_stream_t stream);
+/* Several such weight gradients (different filters / geometries) at once: the deferred weight gradients of a step are
+ * independent of each other, so they share ONE launch per tile configuration (workgroup -> problem table in the kernel
+ * arguments, at most CTGAN_WGRAD_GROUP_MAX problems per launch) and ONE launch for all their split-K reductions.
+ * Validates every group before the first launch: CTGAN_E_UNSUPPORTED means nothing ran (fall back per group).   */
+#define CTGAN_WGRAD_GROUP_MAX 8      /* problems per grouped kernel launch */
+#define CTGAN_WGRAD_GROUP_LIMIT 32   /* groups per call */
+#define CTGAN_REDUCE_BATCH 16        /* reductions per launch */
+typedef struct ctgan_wgrad_group {
+    ctgan_conv_desc d;               /* d.N ignored, as in ctgan_conv2d_wgrad_multi */
+    int32_t nseg;
+    int32_t Ns[CTGAN_WGRAD_MAX_SEGS];
+    int32_t seg_flags[CTGAN_WGRAD_MAX_SEGS];
+    const float* xs[CTGAN_WGRAD_MAX_SEGS];
+    const float* dys[CTGAN_WGRAD_MAX_SEGS];
+    float* dw;
+    float* db;                       /* NULL unless a segment carries CTGAN_WGRAD_SEG_BIAS */
+} ctgan_wgrad_group;
+size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n);
+int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes,
+                             ctgan_stream_t stream);
 /* ---- convolution family  (replaces tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112,
  *      tf.nn.conv2d_transpose TF/tflib/ops/deconv2d.py:97-103, tf.matmul
  *      TF/tflib/ops/linear.py:132-137 (as 1x1 conv on a 1x1 image), and the conv gradient nodes

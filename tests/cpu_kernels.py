@@ -126,6 +126,12 @@ def conv_wgrad_multi(segs, g, dw, db=None):
     return dw, db
 
 
+@_export
+def conv_wgrad_group(groups):
+    for segs, g, dw, db in groups:
+        conv_wgrad_multi(segs, g, dw, db)
+
+
 def _conv_wgrad(x, gy, g):
     xp = TF.pad(_xin(x, g), _pads(g)).detach().requires_grad_(False)
     wz = torch.zeros(g.K, g.C, g.R, g.S, dtype=x.dtype, requires_grad=True)

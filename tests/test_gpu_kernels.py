@@ -671,6 +671,34 @@ def test_multi_segment_wgrad(K, C, H, Ko, k, st, Ns):
     assert torch.equal(dw, dw2)                                    # deterministic
 
 
+def test_grouped_wgrad_equals_separate_launches(K):
+    """ctgan_conv2d_wgrad_group: the queued weight gradients of a step (different filters, geometries and tile
+    configurations, several segments each) from one launch per tile configuration + one reduction launch are
+    bit-identical to one ctgan_conv2d_wgrad_multi call per filter."""
+    g = torch.Generator().manual_seed(77)
+    cases = [(128, 8, 128, 3, 1, (64, 64, 32)), (128, 8, 128, 3, 1, (96,)), (128, 16, 128, 4, 2, (48, 16)), (128, 16, 128, 2, 2, (40,)),
+             (128, 16, 128, 3, 1, (64, 8)), (128, 32, 128, 4, 2, (32, 8)), (64, 8, 96, 1, 1, (5,)), (128, 8, 128, 3, 1, (7, 3)),
+             (128, 4, 128, 3, 1, (16,)), (128, 8, 128, 3, 1, (33,)), (128, 8, 128, 3, 1, (34,))]
+    groups, refs = [], []
+    for ci, (C, H, Ko, k, st, Ns) in enumerate(cases):
+        geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+        segs = []
+        for i, n in enumerate(Ns):
+            x = cl(torch.randn(n, C, H, H, generator=g)); gy = cl(torch.randn(n, Ko, geom.P, geom.Q, generator=g))
+            segs.append((x, gy, (i + ci) % 2 == 0, i == 0 and ci % 3 != 2))
+        has_b = any(sg[3] for sg in segs)
+        dw = torch.empty(k, k, C, Ko, device='cuda'); db = torch.empty(Ko, device='cuda') if has_b else None
+        dw_r = torch.empty_like(dw); db_r = torch.empty_like(db) if has_b else None
+        K.conv_wgrad_multi(segs, geom, dw_r, db_r)
+        groups.append((segs, geom, dw, db)); refs.append((dw_r, db_r))
+    K.conv_wgrad_group(groups)
+    assert 'igemm_wgrad_pipe_group' in K.last_kernel()
+    for (segs, geom, dw, db), (dw_r, db_r) in zip(groups, refs):
+        assert torch.equal(dw, dw_r), (geom.H, geom.R)
+        if db is not None:
+            assert torch.equal(db, db_r)
+
+
 @pytest.mark.parametrize('N,H', [(5, 16), (130, 8), (64, 32)])
 def test_conv_epilogue_reads_low_resolution_residual(K, N, H):
     """CTGAN_RESID_UP: the residual operand is the [N,K,P/2,Q/2] tensor, added through a nearest-2x upsample inside the

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Ordered launch sequence of the LAST unit in a rocprofv3 kernel trace (rocpd SQLite), the unit being delimited by a
 marker kernel (default gp_mean_kernel: one per `bench.py --gp-unit-only` replay), with per-launch durations averaged
-over the last `reps` units.  usage: python tools_prof_seq.py results.db [marker=gp_mean_kernel] [reps=10]"""
+over the last `reps` units.  usage: python tools_prof_seq.py results.db [marker=gp_mean_kernel] [reps=10] [back=0]
+(back = k: show the unit k markers before the last one instead, e.g. marker adam_kernel, reps 1, back 5 = the generator
+step of the last iteration of a `bench.py --no-roofline` trace)"""
 import re
 import sqlite3
 import sys
@@ -13,7 +15,7 @@ def short(n):
     return (m.group(1) if m else n)[:60]
 
 
-def main(path, marker='gp_mean_kernel', reps=10):
+def main(path, marker='gp_mean_kernel', reps=10, back=0):
     db = sqlite3.connect(path)
     cur = db.cursor()
     sym_cols = [r[1] for r in cur.execute("pragma table_info(rocpd_info_kernel_symbol)")]
@@ -23,6 +25,8 @@ def main(path, marker='gp_mean_kernel', reps=10):
     rows = cur.execute("select s.%s, d.start, d.end, %s from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
                        "on d.kernel_id = s.id order by d.start" % (namecol, gx)).fetchall()
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    if back:
+        marks = marks[:-back]
     if len(marks) < reps + 1:
         print('not enough markers', len(marks)); return
     L = marks[-1] - marks[-2]
@@ -44,4 +48,5 @@ def main(path, marker='gp_mean_kernel', reps=10):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'gp_mean_kernel', int(sys.argv[3]) if len(sys.argv) > 3 else 10)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else 'gp_mean_kernel', int(sys.argv[3]) if len(sys.argv) > 3 else 10,
+         int(sys.argv[4]) if len(sys.argv) > 4 else 0)
