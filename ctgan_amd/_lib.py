@@ -114,6 +114,13 @@ SIGNATURES = {
     'ctgan_mean_diff_bwd': (c_int, [_p, c_int32, c_int32, c_float, c_float, _p, _p]),
     'ctgan_critic_heads_fwd': (c_int, [_p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_float, c_float, c_float, _p, _p, _p, _p]),
     'ctgan_critic_heads_bwd': (c_int, [_p, _p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, _p, _p, _p, _p]),
+    'ctgan_tail_heads_fwd': (c_int, [_p, c_int32, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int32, _p, _p, _p, _p]),
+    'ctgan_tail_critic_heads_fwd': (c_int, [_p, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int32, _p, _p, c_float, c_float, c_float,
+                                            _p, _p, _p, _p, _p, _p, _p, _p]),
+    'ctgan_tail_heads_bwd': (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float,
+                                     _p, _p, _p, _p, _p, _p, _p, _p]),
+    'ctgan_gp_head_grad': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p, _p]),
+    'ctgan_gp_head_wgrad': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p, _p]),
     'ctgan_accuracy2': (c_int, [_p, _p, c_int32, c_int32, _p, _p]),
     'ctgan_adam_step': (c_int, [_p, _p, _p, _p, c_int64, _p, c_float, c_float, c_float, c_float, _p]),
     'ctgan_adam_advance': (c_int, [_p, c_float, c_float, _p]),

@@ -239,6 +239,249 @@ __global__ __launch_bounds__(256) void accuracy2_kernel(const float* __restrict_
     if (threadIdx.x == 0) { acc[0] = cr / (float)B; acc[1] = cf / (float)B; }
 }
 
+
+// ---- the critic's output head fused around the loss heads (CIFAR ResNet critic, TF/CT_gan_cifar_resnet.py:179-186) -----
+// y = relu(dropout(.)) output of the last residual block, physical [n][hw][nf] (nf % 4 == 0, nf <= 1024).  Per row:
+//   f[row,:] = mean_hw y [relu'd first if `relu`]   (:179-180 relu, reduce_mean over axes 2,3)
+//   d[row]   = f . w_out + b_out                    (:181 Linear nf -> 1)
+//   a[row,:] = f . w_ac + b_ac                      (:183 Linear nf -> ncls)
+// replaces [relu +] spatial_sum + two linear launches.  blockDim = 256.
+__device__ __forceinline__ void head_row(const float* __restrict__ yr, int hw, int nf, int relu, const float* __restrict__ w_out,
+                                         const float* __restrict__ b_out, const float* __restrict__ w_ac, const float* __restrict__ b_ac,
+                                         int ncls, float* part /*[<=1024]*/, float* fs /*[nf]*/, float* f_row, float* d_row, float* a_row,
+                                         float* d_sh) {
+    const int tid = threadIdx.x;
+    const int nf4 = nf >> 2;
+    const int S = 256 / nf4;                          // position slices (nf4 <= 256)
+    const int s = tid / nf4, j4 = tid - s * nf4;
+    if (s < S) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int p = s; p < hw; p += S) {
+            float4 v = *reinterpret_cast<const float4*>(yr + (long long)p * nf + j4 * 4);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(part + s * nf + j4 * 4) = acc;
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)hw;
+    for (int j = tid; j < nf; j += 256) {
+        float acc = part[j];
+        for (int q = 1; q < S; ++q) acc += part[q * nf + j];
+        acc *= inv;
+        fs[j] = acc;
+        f_row[j] = acc;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    const int nout = (w_out ? 1 : 0) + (w_ac ? ncls : 0);
+    for (int o = w; o < nout; o += 4) {
+        const bool is_d = w_out && o == 0;
+        const int k = o - (w_out ? 1 : 0);
+        float acc = 0.f;
+        if (is_d) { for (int j = lane; j < nf; j += 64) acc += fs[j] * w_out[j]; }
+        else      { for (int j = lane; j < nf; j += 64) acc += fs[j] * w_ac[(long long)j * ncls + k]; }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            if (is_d) { const float v = acc + (b_out ? b_out[0] : 0.f); d_row[0] = v; if (d_sh) d_sh[0] = v; }
+            else a_row[k] = acc + (b_ac ? b_ac[k] : 0.f);
+        }
+    }
+    __syncthreads();
+}
+
+// pair_B == 0: one workgroup per row.  pair_B == B > 0 (critic step, rows = real pass 1 | fake pass 1 | real pass 2):
+// workgroup r < B handles rows r and 2B + r and also writes the per-sample loss terms of ctgan_critic_heads_fwd
+// (ct_i[r], probs[r,:], ce_i[r] = softmax-CE of a[r] against labels[r]); workgroup r in [B, 2B) handles row r.
+__global__ __launch_bounds__(256) void tail_heads_rows_kernel(const float* __restrict__ y, int hw, int nf, int relu,
+                                                              const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                              const float* __restrict__ w_ac, const float* __restrict__ b_ac, int ncls,
+                                                              float* __restrict__ f, float* __restrict__ d, float* __restrict__ a,
+                                                              int pair_B, const int32_t* __restrict__ labels, float l2,
+                                                              float* __restrict__ ct_i, float* __restrict__ probs, float* __restrict__ ce_i) {
+    __shared__ __attribute__((aligned(16))) float part[1024];
+    __shared__ float fs0[1024], fs1[1024];
+    __shared__ float dsh[2];
+    __shared__ float sh[4];
+    const int r = blockIdx.x;
+    const long long row_elems = (long long)hw * nf;
+    head_row(y + r * row_elems, hw, nf, relu, w_out, b_out, w_ac, b_ac, ncls, part, fs0, f + (long long)r * nf, d ? d + r : nullptr,
+             a ? a + (long long)r * ncls : nullptr, dsh);
+    if (pair_B == 0 || r >= pair_B) return;
+    const int r2 = 2 * pair_B + r;
+    head_row(y + r2 * row_elems, hw, nf, relu, w_out, b_out, w_ac, b_ac, ncls, part, fs1, f + (long long)r2 * nf, d ? d + r2 : nullptr,
+             a ? a + (long long)r2 * ncls : nullptr, dsh + 1);
+    float sq = 0.f;
+    for (int j = threadIdx.x; j < nf; j += 256) { const float t = fs0[j] - fs1[j]; sq += t * t; }
+    sq = block_sum(sq, sh);
+    if (threadIdx.x == 0) {
+        const float t = dsh[0] - dsh[1];
+        ct_i[r] = l2 * t * t + l2 * 0.1f * (sq / (float)nf);                     // :288-290
+        if (a) {
+            const float* z = a + (long long)r * ncls;                            // written above by this workgroup
+            float mx = z[0];
+            for (int k = 1; k < ncls; ++k) mx = fmaxf(mx, z[k]);
+            float se = 0.f;
+            for (int k = 0; k < ncls; ++k) se += expf(z[k] - mx);
+            const float lse = logf(se);
+            for (int k = 0; k < ncls; ++k) probs[(long long)r * ncls + k] = expf(z[k] - mx - lse);
+            ce_i[r] = (mx + lse) - z[labels[r]];                                 // :246-248
+        }
+    }
+}
+// the batch means over those per-sample terms: out[5] as ctgan_critic_heads_fwd
+__global__ __launch_bounds__(256) void critic_heads_final_kernel(const float* __restrict__ d, const float* __restrict__ ct_i,
+                                                                 const float* __restrict__ ce_i, const float* __restrict__ gp, int B,
+                                                                 float M, float scale, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float sr = 0.f, sf = 0.f, sc = 0.f, sl = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        sr += d[i]; sf += d[B + i];
+        sc += fmaxf(ct_i[i] - M, 0.f);
+        if (ce_i) sl += ce_i[i];
+    }
+    sr = block_sum(sr, sh); sf = block_sum(sf, sh); sc = block_sum(sc, sh); sl = block_sum(sl, sh);
+    if (threadIdx.x == 0) {
+        const float wgan = sf / (float)B - sr / (float)B, ct = sc / (float)B, ac = ce_i ? sl / (float)B : 0.f;
+        const float pen = gp ? gp[0] : 0.f;
+        out[0] = ((wgan + ct) + pen) + scale * ac; out[1] = wgan; out[2] = ct; out[3] = ac; out[4] = (wgan + ct) + pen;
+    }
+}
+
+// per-row upstream gradients of the critic loss heads (the formulas of critic_heads_bwd_kernel)
+struct HeadCoef { float cw, cc, ca; };
+__device__ __forceinline__ HeadCoef head_coef(const float* gout, int n_gout, int B, float scale) {
+    const float g0 = gout[0], g1 = n_gout > 1 ? gout[1] : 0.f, g2 = n_gout > 1 ? gout[2] : 0.f, g3 = n_gout > 1 ? gout[3] : 0.f;
+    HeadCoef c;
+    c.cw = (g0 + g1) / (float)B; c.cc = (g0 + g2) / (float)B; c.ca = (g0 * scale + g3) / (float)B;
+    return c;
+}
+__device__ __forceinline__ float head_gd(const float* d, const float* ct_i, int row, int B, float l2, float M, HeadCoef c) {
+    if (row < B || row >= 2 * B) {
+        const int i = row < B ? row : row - 2 * B;
+        const float on = (ct_i[i] - M >= 0.f) ? c.cc : 0.f;
+        const float v = on * l2 * 2.f * (d[i] - d[2 * B + i]);
+        return row < B ? v - c.cw : -v;
+    }
+    return c.cw;
+}
+
+// Backward of {rows kernel + loss heads + relu/dropout mask of the last conv} in one launch.
+//   workgroups [0, 3B): gy[row,hw,j] = y > 0 ? (gf[j] + gd*w_out[j] + sum_k ga[k]*w_ac[j,k]) / hw * mask_scale : 0
+//   workgroups [3B, ..): gw_out[j] = sum_row f[row,j]*gd[row], gb_out = sum gd, gw_ac[j,k] = sum_row f[row,j]*ga[row,k], gb_ac
+// (fixed summation order over rows => deterministic).  blockDim = 256; dynamic shared: max(nf, 3B) floats.
+__global__ __launch_bounds__(256) void tail_heads_bwd_kernel(const float* __restrict__ y, const float* __restrict__ d,
+                                                             const float* __restrict__ f, const float* __restrict__ probs,
+                                                             const int32_t* __restrict__ labels, const float* __restrict__ ct_i,
+                                                             const float* __restrict__ gout, int n_gout, int B, int hw, int nf, int ncls,
+                                                             float l2, float M, float scale, float mask_scale,
+                                                             const float* __restrict__ w_out, const float* __restrict__ w_ac,
+                                                             float* __restrict__ gy, float* __restrict__ gw_out, float* __restrict__ gb_out,
+                                                             float* __restrict__ gw_ac, float* __restrict__ gb_ac) {
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x;
+    const HeadCoef c = head_coef(gout, n_gout, B, scale);
+    if ((int)blockIdx.x < 3 * B) {
+        const int row = blockIdx.x;
+        const float gd = head_gd(d, ct_i, row, B, l2, M, c);
+        float* t = sm;                                   // [nf]
+        for (int j = tid; j < nf; j += 256) {
+            float v = 0.f;
+            if (row < B || row >= 2 * B) {
+                const int i = row < B ? row : row - 2 * B;
+                const float on = (ct_i[i] - M >= 0.f) ? c.cc : 0.f;
+                v = on * l2 * 0.1f * 2.f * (f[(long long)i * nf + j] - f[(long long)(2 * B + i) * nf + j]) / (float)nf;
+                if (row >= 2 * B) v = -v;
+            }
+            v += gd * w_out[j];
+            if (w_ac && row < B) {
+                const int lab = labels[row];
+                for (int k = 0; k < ncls; ++k)
+                    v += c.ca * (probs[(long long)row * ncls + k] - (lab == k ? 1.f : 0.f)) * w_ac[(long long)j * ncls + k];
+            }
+            t[j] = v * (1.f / (float)hw);
+        }
+        __syncthreads();
+        const long long base = (long long)row * hw * nf;
+        const int n4 = (hw * nf) >> 2;                   // nf % 4 == 0
+        for (int q = tid; q < n4; q += 256) {
+            const int j = (q * 4) % nf;
+            const float4 yv = *reinterpret_cast<const float4*>(y + base + (long long)q * 4);
+            float4 o;
+            o.x = yv.x > 0.f ? t[j] * mask_scale : 0.f;     o.y = yv.y > 0.f ? t[j + 1] * mask_scale : 0.f;
+            o.z = yv.z > 0.f ? t[j + 2] * mask_scale : 0.f; o.w = yv.w > 0.f ? t[j + 3] * mask_scale : 0.f;
+            *reinterpret_cast<float4*>(gy + base + (long long)q * 4) = o;
+        }
+        return;
+    }
+    float* gds = sm;                                     // [3B]
+    for (int r = tid; r < 3 * B; r += 256) gds[r] = head_gd(d, ct_i, r, B, l2, M, c);
+    __syncthreads();
+    const int nac = w_ac ? ncls : 0;
+    const int n_w = nf * (1 + nac), n_all = n_w + 1 + nac;
+    const int lane = tid & 63;
+    const int idx = ((int)blockIdx.x - 3 * B) * 4 + (tid >> 6);          // one wave per output, lanes over rows (fixed order)
+    if (idx >= n_all) return;
+    float acc = 0.f;
+    if (idx < nf) {
+        for (int r = lane; r < 3 * B; r += 64) acc += f[(long long)r * nf + idx] * gds[r];
+    } else if (idx < n_w) {
+        const int q = idx - nf, k = q / nf, j = q - k * nf;
+        for (int r = lane; r < B; r += 64)
+            acc += f[(long long)r * nf + j] * (c.ca * (probs[(long long)r * ncls + k] - (labels[r] == k ? 1.f : 0.f)));
+    } else if (idx == n_w) {
+        for (int r = lane; r < 3 * B; r += 64) acc += gds[r];
+    } else {
+        const int k = idx - n_w - 1;
+        for (int r = lane; r < B; r += 64) acc += c.ca * (probs[(long long)r * ncls + k] - (labels[r] == k ? 1.f : 0.f));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (idx < nf) gw_out[idx] = acc;
+        else if (idx < n_w) { const int q = idx - nf, k = q / nf, j = q - k * nf; gw_ac[(long long)j * ncls + k] = acc; }
+        else if (idx == n_w) gb_out[0] = acc;
+        else gb_ac[idx - n_w - 1] = acc;
+    }
+}
+
+// Gradient-penalty branch: dD/dy of D = mean_hw(y) . w_out for the last block's output y = relu(dropout(z)), taken w.r.t. z:
+//   gz[row,hw,j] = y > 0 ? w_out[j] / hw * mask_scale : 0      (the value D(x_hat) itself is never needed, :284)
+__global__ void gp_head_grad_kernel(const float* __restrict__ y, const float* __restrict__ w_out, long long n4, int nf, float s,
+                                    float* __restrict__ gz) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4) return;
+    const int j = (int)((q * 4) % nf);
+    const float4 yv = *reinterpret_cast<const float4*>(y + q * 4);
+    const float4 wv = *reinterpret_cast<const float4*>(w_out + j);
+    float4 o;
+    o.x = yv.x > 0.f ? wv.x * s : 0.f; o.y = yv.y > 0.f ? wv.y * s : 0.f;
+    o.z = yv.z > 0.f ? wv.z * s : 0.f; o.w = yv.w > 0.f ? wv.w * s : 0.f;
+    *reinterpret_cast<float4*>(gz + q * 4) = o;
+}
+// its adjoint w.r.t. w_out (the double backward): gw[j] = s * sum_{row,hw : y > 0} gg[row,hw,j].  One workgroup per 4 channels.
+__global__ __launch_bounds__(1024) void gp_head_wgrad_kernel(const float* __restrict__ gg, const float* __restrict__ y, long long rows,
+                                                             int nf, float s, float* __restrict__ gw) {
+    __shared__ float4 sh[16];
+    const int j = blockIdx.x * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (long long r = threadIdx.x; r < rows; r += 1024) {
+        const float4 g = *reinterpret_cast<const float4*>(gg + r * nf + j);
+        const float4 yv = *reinterpret_cast<const float4*>(y + r * nf + j);
+        acc.x += yv.x > 0.f ? g.x : 0.f; acc.y += yv.y > 0.f ? g.y : 0.f;
+        acc.z += yv.z > 0.f ? g.z : 0.f; acc.w += yv.w > 0.f ? g.w : 0.f;
+    }
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 t = sh[0];
+        for (int w = 1; w < 16; ++w) { t.x += sh[w].x; t.y += sh[w].y; t.z += sh[w].z; t.w += sh[w].w; }
+        gw[j] = t.x * s; gw[j + 1] = t.y * s; gw[j + 2] = t.z * s; gw[j + 3] = t.w * s;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -313,6 +556,64 @@ int ctgan_critic_heads_bwd(const float* d, const float* f, const float* probs, c
     hipLaunchKernelGGL(critic_heads_bwd_kernel, dim3(ctgan_blocks(total, 256)), dim3(256), 0, static_cast<hipStream_t>(s), d, f, probs,
                        labels, ct_i, gout, n_gout, B, nf, ncls, lambda2, M, acgan_scale, gd, gf, ga);
     return ctgan_check_launch("critic_heads_bwd");
+}
+int ctgan_tail_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, int32_t relu, const float* w_out, const float* b_out,
+                         const float* w_ac, const float* b_ac, int32_t ncls, float* f, float* d, float* a, ctgan_stream_t s) {
+    if (!y || !f || n <= 0 || hw <= 0 || nf <= 0 || (nf & 3) || nf > 1024 || (w_out && !d) || (w_ac && (!a || ncls <= 0)) ||
+        (reinterpret_cast<uintptr_t>(y) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "tail_heads_fwd: bad argument");
+    hipLaunchKernelGGL(tail_heads_rows_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(s), y, hw, nf, relu, w_out, b_out, w_ac,
+                       b_ac, ncls, f, d, a, 0, (const int32_t*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return ctgan_check_launch("tail_heads_rows");
+}
+int ctgan_tail_critic_heads_fwd(const float* y, int32_t B, int32_t hw, int32_t nf, const float* w_out, const float* b_out,
+                                const float* w_ac, const float* b_ac, int32_t ncls, const int32_t* labels, const float* gp,
+                                float lambda2, float M, float acgan_scale, float* f, float* d, float* a, float* ct_i, float* probs,
+                                float* ce_i, float* out, ctgan_stream_t s) {
+    if (!y || !f || !d || !w_out || !ct_i || !out || B <= 0 || hw <= 0 || nf <= 0 || (nf & 3) || nf > 1024 ||
+        (w_ac && (!a || !labels || !probs || !ce_i || ncls <= 0)) || (reinterpret_cast<uintptr_t>(y) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "tail_critic_heads_fwd: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    hipLaunchKernelGGL(tail_heads_rows_kernel, dim3(2 * B), dim3(256), 0, st, y, hw, nf, 0, w_out, b_out, w_ac, b_ac, ncls, f, d,
+                       w_ac ? a : (float*)nullptr, B, labels, lambda2, ct_i, probs, ce_i);
+    int rc = ctgan_check_launch("tail_heads_rows");
+    if (rc) return rc;
+    hipLaunchKernelGGL(critic_heads_final_kernel, dim3(1), dim3(256), 0, st, d, ct_i, w_ac ? ce_i : (const float*)nullptr, gp, B, M,
+                       acgan_scale, out);
+    return ctgan_check_launch("critic_heads_final");
+}
+int ctgan_tail_heads_bwd(const float* y, const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
+                         const float* gout, int32_t n_gout, int32_t B, int32_t hw, int32_t nf, int32_t ncls, float lambda2, float M,
+                         float acgan_scale, float mask_scale, const float* w_out, const float* w_ac, float* gy, float* gw_out,
+                         float* gb_out, float* gw_ac, float* gb_ac, ctgan_stream_t s) {
+    if (!y || !d || !f || !ct_i || !gout || (n_gout != 1 && n_gout != 4) || !w_out || !gy || !gw_out || !gb_out || B <= 0 || hw <= 0 ||
+        nf <= 0 || (nf & 3) || (w_ac && (!probs || !labels || !gw_ac || !gb_ac || ncls <= 0)))
+        return ctgan_fail(CTGAN_E_BADARG, "tail_heads_bwd: bad argument");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gy)) & 15) return ctgan_fail(CTGAN_E_BADARG, "tail_heads_bwd: unaligned");
+    const int nac = w_ac ? ncls : 0;
+    const int wblocks = (nf * (1 + nac) + 1 + nac + 3) / 4;               // one wave per output
+    const size_t sh = (size_t)(nf > 3 * B ? nf : 3 * B) * sizeof(float);
+    hipLaunchKernelGGL(tail_heads_bwd_kernel, dim3(3 * B + wblocks), dim3(256), sh, static_cast<hipStream_t>(s), y, d, f, probs, labels, ct_i,
+                       gout, n_gout, B, hw, nf, ncls, lambda2, M, acgan_scale, mask_scale, w_out, w_ac, gy, gw_out, gb_out, gw_ac, gb_ac);
+    return ctgan_check_launch("tail_heads_bwd");
+}
+int ctgan_gp_head_grad(const float* y, const float* w_out, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gz,
+                       ctgan_stream_t s) {
+    if (!y || !w_out || !gz || n <= 0 || hw <= 0 || nf <= 0 || (nf & 3)) return ctgan_fail(CTGAN_E_BADARG, "gp_head_grad: bad argument");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gz) | reinterpret_cast<uintptr_t>(w_out)) & 15)
+        return ctgan_fail(CTGAN_E_BADARG, "gp_head_grad: unaligned");
+    const long long n4 = (long long)n * hw * nf / 4;
+    hipLaunchKernelGGL(gp_head_grad_kernel, dim3(ctgan_blocks(n4, 256)), dim3(256), 0, static_cast<hipStream_t>(s), y, w_out, n4, nf,
+                       mask_scale / (float)hw, gz);
+    return ctgan_check_launch("gp_head_grad");
+}
+int ctgan_gp_head_wgrad(const float* gg, const float* y, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gw,
+                        ctgan_stream_t s) {
+    if (!gg || !y || !gw || n <= 0 || hw <= 0 || nf <= 0 || (nf & 3)) return ctgan_fail(CTGAN_E_BADARG, "gp_head_wgrad: bad argument");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gg)) & 15) return ctgan_fail(CTGAN_E_BADARG, "gp_head_wgrad: unaligned");
+    hipLaunchKernelGGL(gp_head_wgrad_kernel, dim3(nf / 4), dim3(1024), 0, static_cast<hipStream_t>(s), gg, y, (long long)n * hw, nf,
+                       mask_scale / (float)hw, gw);
+    return ctgan_check_launch("gp_head_wgrad");
 }
 int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32_t ncls, float* acc, ctgan_stream_t s) {
     if (!logits || !labels || !acc || B <= 0 || ncls <= 0) return ctgan_fail(CTGAN_E_BADARG, "accuracy2: bad argument");

@@ -171,6 +171,7 @@ class ConvFn(Function):
         ctx.out_drop, ctx.in_drop = epi.get('out_drop'), epi.get('in_drop')
         ctx.out_relu = bool(epi.get('out_relu'))
         ctx.out_drop_bwd_fused = bool(epi.get('out_drop_bwd_fused'))
+        ctx.mask_done = bool(epi.get('mask_done'))      # the consumer returns the gradient w.r.t. the conv result itself
         ctx.resid_up = bool(epi.get('resid_up')) and resid is not None      # resid is the low-resolution shortcut
         ctx.g = g
         ctx.N = x.shape[0]
@@ -204,7 +205,9 @@ class ConvFn(Function):
         if gy is None:                                   # fork only: y itself was not used
             return g_fork, None, None, None, None, None, None, None, None
         # gradient w.r.t. the conv result z, given the gradient w.r.t. y = dropout(relu(z))
-        if ctx.out_relu:
+        if ctx.mask_done:
+            pass
+        elif ctx.out_relu:
             gy = _relu_mask(gy, y, 0.0, (1.0 / ctx.out_drop[0]) if ctx.out_drop is not None else 1.0)
         elif ctx.out_drop is not None and not ctx.out_drop_bwd_fused:
             gy = DropoutRngFn.apply(gy, ctx.out_drop[0], ctx.out_drop[1], ctx.out_drop[2], ctx.out_drop[3], _cl_strides(gy.shape))
@@ -1152,6 +1155,76 @@ class CriticHeadsFn(Function):
             gout = torch.cat([z(g0), z(g1), z(g2), z(g3)])
         gd, gf, ga = K.critic_heads_bwd(d, f, probs, ctx.labels, ct_i, gout, B, lam2, M, scale)
         return gd, gf, ga, None, None, None, None, None, (g0.reshape(()) if (ctx.has_gp and g0 is not None) else None)
+
+
+class CriticTailHeadsFn(Function):
+    """reduce_mean + both Linear heads + all loss heads of the batched dropout passes, forward in two launches and backward
+    in one (TF/CT_gan_cifar_resnet.py:179-186,244-248,288-291).  y = the last block's relu(dropout(.)) output [3B,nf,H,W]
+    (dense channels-last), produced by a conv with epi['mask_done']: the gradient returned for y is already the gradient
+    w.r.t. the conv result (mask and 1/keep applied here).  First-order only."""
+
+    @staticmethod
+    def forward(ctx, y, w_out, b_out, w_ac, b_ac, labels, B, lam2, M, scale, mask_scale, gp=None):
+        out, f, d, a, ct_i, probs = K.tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp.reshape(1) if gp is not None else None,
+                                                            lam2, M, scale)
+        ctx.has_gp = gp is not None
+        ctx.cfg = (B, lam2, M, scale, mask_scale)
+        ctx.labels = labels
+        ctx.has_a = a is not None
+        ctx.set_materialize_grads(False)
+        if a is not None:
+            ctx.save_for_backward(y, w_out, w_ac, d, f, ct_i, probs)
+        else:
+            ctx.save_for_backward(y, w_out, d, f, ct_i)
+        ctx.mark_non_differentiable(out[4], d)
+        return out[0], out[1], out[2], out[3], out[4], d
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g0, g1, g2, g3, _g4=None, _gd=None):
+        B, lam2, M, scale, mask_scale = ctx.cfg
+        if ctx.has_a:
+            y, w_out, w_ac, d, f, ct_i, probs = ctx.saved_tensors
+        else:
+            (y, w_out, d, f, ct_i), w_ac, probs = ctx.saved_tensors, None, None
+        if g1 is None and g2 is None and g3 is None:
+            gout = g0.reshape(1).contiguous()
+        else:
+            z = lambda g: g.reshape(1) if g is not None else d.new_zeros(1)
+            gout = torch.cat([z(g0), z(g1), z(g2), z(g3)])
+        gy, gw_out, gb_out, gw_ac, gb_ac = K.tail_heads_bwd(y, d, f, probs, ctx.labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac)
+        return (gy, gw_out, gb_out, gw_ac, gb_ac, None, None, None, None, None, None,
+                (g0.reshape(()) if (ctx.has_gp and g0 is not None) else None))
+
+
+def critic_tail_heads(y, w_out, b_out, w_ac, b_ac, labels, B, lam2=2.0, M=0.0, acgan_scale=1.0, mask_scale=1.0, gp=None):
+    """-> (cost, wgan, ct, acgan, wgan + ct + gp, d [3B]); see CriticTailHeadsFn."""
+    return CriticTailHeadsFn.apply(y, w_out, b_out, w_ac, b_ac, labels, int(B), float(lam2), float(M), float(acgan_scale),
+                                   float(mask_scale), gp)
+
+
+class GpHeadGradFn(Function):
+    """dD/dz at the last block of the critic for the gradient-penalty branch (:284): D = mean_hw(relu(dropout(z))) . w_out, so
+    gz = (y > 0) * w_out / hw / keep with y = relu(dropout(z)) - one launch instead of head forward + ones + Linear data
+    gradient + broadcast + mask; its adjoint w.r.t. w_out is the only thing the double backward needs from it."""
+
+    @staticmethod
+    def forward(ctx, y, w_out, mask_scale):
+        ctx.mask_scale = mask_scale
+        ctx.save_for_backward(y, w_out)
+        return K.gp_head_grad(y, w_out, mask_scale)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gg):
+        y, w_out = ctx.saved_tensors
+        if not gg.permute(0, 2, 3, 1).is_contiguous():
+            gg = K.to_channels_last(gg)
+        return None, K.gp_head_wgrad(gg, y, ctx.mask_scale, w_out), None
+
+
+def gp_head_grad(y, w_out, mask_scale):
+    return GpHeadGradFn.apply(y.detach(), w_out, float(mask_scale))
 
 
 def critic_heads(d_all, f_all, a_all, labels, B, lam2=2.0, M=0.0, acgan_scale=1.0, gp=None):

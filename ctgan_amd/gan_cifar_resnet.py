@@ -217,34 +217,45 @@ def DiscriminatorTrunk(inputs):
     return ResidualBlock('Discriminator.2', D, D, 3, out, resample='down')
 
 
-def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None, heads=('wgan', 'acgan')):
-    """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186).
-    `heads`: which of the two linear heads the caller consumes (the other one is not launched)."""
-    D = cfg.DIM_D
+def _tail_fusable(kp1, kp2, kp3, u, rng):
+    return (DROP_FUSION and FUSE_RELU and F.FORK_FUSION and not cfg.NORMALIZATION_D and u is None and rng is not None
+            and max(kp1, kp2, kp3) < 1.0)
 
-    fuse = DROP_FUSION and FUSE_RELU and F.FORK_FUSION and not cfg.NORMALIZATION_D and u is None and rng is not None \
-        and max(kp1, kp2, kp3) < 1.0
-    if fuse:
+
+def DiscriminatorTailBody(h, kp1, kp2, kp3, u=None, rng=None, mask_done=False):
+    """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu (:173-179).  mask_done (fused path only): the consumer
+    of the result returns the gradient w.r.t. the last conv's result, relu/dropout mask included (F.critic_tail_heads,
+    F.gp_head_grad)."""
+    D = cfg.DIM_D
+    if _tail_fusable(kp1, kp2, kp3, u, rng):
         # dropout -> block 3 -> dropout -> block 4 -> dropout -> relu with the masks inside the conv kernels: forward in the
         # epilogue of the conv that produces the tensor, backward in the dgrad epilogue of the conv that consumed it
         s1, s2, s3 = F.drop_spec(rng, kp1), F.drop_spec(rng, kp2), F.drop_spec(rng, kp3)
         out = F.dropout(h, kp1, spec=s1, bwd_fused=True)
         out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None, in_drop=s1,
                             out_epi={'out_drop': s2, 'out_drop_bwd_fused': True})
-        out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None, in_drop=s2,
-                            out_epi={'out_drop': s3, 'out_relu': True})           # = relu(dropout(.)): both are >= 0 scalings
-    else:
-        def drop(i, x, kp):
-            if kp == 1.0:
-                return x
-            return F.dropout(x, kp, u[i]) if u is not None else F.dropout(x, kp, rng=rng)
+        return ResidualBlock('Discriminator.4', D, D, 3, out, resample=None, in_drop=s2,
+                             out_epi={'out_drop': s3, 'out_relu': True, 'mask_done': mask_done})    # = relu(dropout(.)): both are >= 0 scalings
+    assert not mask_done
 
-        out = drop(0, h, kp1)
-        out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None)
-        out = drop(1, out, kp2)
-        out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None)
-        out = drop(2, out, kp3)
-        out = nonlinearity(out)
+    def drop(i, x, kp):
+        if kp == 1.0:
+            return x
+        return F.dropout(x, kp, u[i]) if u is not None else F.dropout(x, kp, rng=rng)
+
+    out = drop(0, h, kp1)
+    out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None)
+    out = drop(1, out, kp2)
+    out = ResidualBlock('Discriminator.4', D, D, 3, out, resample=None)
+    out = drop(2, out, kp3)
+    return nonlinearity(out)
+
+
+def DiscriminatorTail(h, kp1, kp2, kp3, u=None, rng=None, heads=('wgan', 'acgan')):
+    """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu -> mean -> heads (:173-186).
+    `heads`: which of the two linear heads the caller consumes (the other one is not launched)."""
+    D = cfg.DIM_D
+    out = DiscriminatorTailBody(h, kp1, kp2, kp3, u=u, rng=rng)
     output2 = F.spatial_mean(out)
     output_wgan = _linear.Linear('Discriminator.Output', D, 1, output2).reshape(-1) if 'wgan' in heads else None
     if cfg.CONDITIONAL and cfg.ACGAN and 'acgan' in heads:
@@ -289,6 +300,11 @@ GP_SIDE_STREAM = _os.environ.get('CTGAN_GP_STREAM', '0') != '0'
 DROP_FUSION = _os.environ.get('CTGAN_DROP_FUSION', '1') != '0'
 # A/B switch: the generator's upsampled 1x1 shortcut is read at low resolution by the epilogue of the block's last conv
 RESID_UP_FUSION = _os.environ.get('CTGAN_RESID_UP', '1') != '0'
+
+
+# A/B switch: the critic's output head (mean, both Linear layers) fused around the loss heads (F.critic_tail_heads) and the
+# gradient-penalty branch started from dD/dz of the last block directly (F.gp_head_grad)
+HEAD_FUSION = _os.environ.get('CTGAN_HEAD_FUSION', '1') != '0'
 
 
 # Draw the fake batches of all N_CRITIC critic steps of an iteration in one generator forward (Trainer.generate_fakes)
@@ -344,11 +360,21 @@ class Trainer:
             F.prepare_dgrad_filters(self.d_params)
             side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side) if side is not None else _nullctx():
+            fuse_heads = (HEAD_FUSION and rnd is None and _critic_piecewise_linear() and _tail_fusable(0.8, 0.5, 0.5, None, rng)
+                          and cfg.DIM_D % 4 == 0)
             with F.weight_grads(not _critic_piecewise_linear()):
-                u_gp = rnd['u_gp'] if rnd is not None else None
-                d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng, heads=('wgan',))[0]
-            ones = torch.ones_like(d_gp)
-            (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
+                if fuse_heads:
+                    y_gp = DiscriminatorTailBody(DiscriminatorTrunk(interp), 0.8, 0.5, 0.5, rng=rng, mask_done=True)
+                else:
+                    u_gp = rnd['u_gp'] if rnd is not None else None
+                    d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng, heads=('wgan',))[0]
+            if fuse_heads:
+                # D(x_hat) itself is never used: start the backward at the last block with dD/dz (one launch)
+                gz = F.gp_head_grad(y_gp, lib.param('Discriminator.Output.W'), 1.0 / 0.5)
+                (grads,) = torch.autograd.grad(y_gp, interp, grad_outputs=gz, create_graph=True)
+            else:
+                ones = torch.ones_like(d_gp)
+                (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
             gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
 
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
@@ -358,15 +384,34 @@ class Trainer:
         else:
             u = None
         tail_in = _cat_rows(h, h[:B])
-        d_all, f_all, a_all = DiscriminatorTail(tail_in, 0.8, 0.5, 0.5, u=u, rng=rng)
         out = {}
-        # every loss head of the two dropout passes in one kernel (fwd) / one kernel (bwd): wgan :244, CT :288-291, ACGAN :246-248
         use_ac = cfg.CONDITIONAL and cfg.ACGAN
-        cost, wgan, ct, acgan, disc_wgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2,
-                                                          cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp if side is None else None)
+        if fuse_heads:
+            # mean + both Linear heads + every loss head: two launches forward, one backward (gradient w.r.t. the last conv's
+            # result and the head weights)
+            y = DiscriminatorTailBody(tail_in, 0.8, 0.5, 0.5, rng=rng, mask_done=True)
+            P = lib.param
+            cost, wgan, ct, acgan, disc_wgan, d_all = F.critic_tail_heads(
+                y, P('Discriminator.Output.W'), P('Discriminator.Output.b'),
+                P('Discriminator.ACGANOutput.W') if use_ac else None, P('Discriminator.ACGANOutput.b') if use_ac else None,
+                labels, B, cfg.LAMBDA_2, cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, gp if side is None else None)
+        else:
+            d_all, f_all, a_all = DiscriminatorTail(tail_in, 0.8, 0.5, 0.5, u=u, rng=rng)
+            # every loss head of the two dropout passes in one kernel (fwd) / one kernel (bwd): wgan :244, CT :288-291, ACGAN :246-248
+            cost, wgan, ct, acgan, disc_wgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2,
+                                                              cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp if side is None else None)
         if use_ac:
             with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
-                _, _, a_clean = DiscriminatorTail(h.detach(), 1.0, 1.0, 1.0, heads=('acgan',))
+                if fuse_heads:       # relu + mean + Linear in one launch
+                    D = cfg.DIM_D
+                    yc = ResidualBlock('Discriminator.4', D, D, 3, ResidualBlock('Discriminator.3', D, D, 3, h.detach(), resample=None),
+                                       resample=None)
+                    if not yc.permute(0, 2, 3, 1).is_contiguous():
+                        yc = F.to_channels_last(yc)
+                    _, _, a_clean = K.tail_heads_fwd(yc, None, None, lib.param('Discriminator.ACGANOutput.W'),
+                                                     lib.param('Discriminator.ACGANOutput.b'), relu=True)
+                else:
+                    _, _, a_clean = DiscriminatorTail(h.detach(), 1.0, 1.0, 1.0, heads=('acgan',))
                 acc = K.accuracy2(a_clean.contiguous(), labels, B)
             out['acc_real'], out['acc_fake'] = acc[0], acc[1]
         else:

@@ -823,6 +823,85 @@ def critic_heads_bwd(d, f, probs, labels, ct_i, gout, B, lam2, M, scale):
     return gd, gf, ga
 
 
+def _cl_rows(y):
+    """(n, hw, nf) of a dense channels-last 4-D tensor [n,nf,H,W] (the layout the fused head kernels read)."""
+    assert y.dim() == 4 and y.permute(0, 2, 3, 1).is_contiguous(), 'fused heads want a dense channels-last tensor'
+    return y.shape[0], y.shape[2] * y.shape[3], y.shape[1]
+
+
+def tail_heads_fwd(y, w_out, b_out, w_ac, b_ac, relu=False):
+    """f [n,nf] = mean_hw y (of relu(y) if relu), d [n] = f.w_out + b_out, a [n,ncls] = f.w_ac + b_ac (either head may be
+    None) - one launch."""
+    _need_dev(y, w_out, b_out, w_ac, b_ac)
+    n, hw, nf = _cl_rows(y)
+    f = torch.empty(n, nf, dtype=torch.float32, device=y.device)
+    d = torch.empty(n, dtype=torch.float32, device=y.device) if w_out is not None else None
+    ncls = w_ac.shape[1] if w_ac is not None else 0
+    a = torch.empty(n, ncls, dtype=torch.float32, device=y.device) if w_ac is not None else None
+    assert w_out is None or (w_out.is_contiguous() and w_out.numel() == nf)
+    assert w_ac is None or (w_ac.is_contiguous() and w_ac.shape[0] == nf)
+    check(lib.ctgan_tail_heads_fwd(_ptr(y), n, hw, nf, 1 if relu else 0, _ptr(w_out), _ptr(b_out), _ptr(w_ac), _ptr(b_ac), ncls, _ptr(f),
+                                   _ptr(d), _ptr(a), _stream()), 'tail_heads_fwd')
+    return f, d, a
+
+
+def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, scale):
+    """tail_heads_fwd over the 3B rows of a critic step + critic_heads_fwd, two launches.
+    -> (out[5], f [3B,nf], d [3B], a [3B,ncls] or None, ct_i [B], probs [B,ncls] or None)."""
+    _need_dev(y, w_out, b_out, w_ac, b_ac, labels, gp)
+    n, hw, nf = _cl_rows(y)
+    assert n == 3 * B and w_out.is_contiguous() and w_out.numel() == nf
+    dev = y.device
+    f = torch.empty(n, nf, dtype=torch.float32, device=dev)
+    d = torch.empty(n, dtype=torch.float32, device=dev)
+    ncls = w_ac.shape[1] if w_ac is not None else 0
+    a = torch.empty(n, ncls, dtype=torch.float32, device=dev) if w_ac is not None else None
+    probs = torch.empty(B, ncls, dtype=torch.float32, device=dev) if w_ac is not None else None
+    ce_i = torch.empty(B, dtype=torch.float32, device=dev) if w_ac is not None else None
+    ct_i = torch.empty(B, dtype=torch.float32, device=dev)
+    out = torch.empty(5, dtype=torch.float32, device=dev)
+    check(lib.ctgan_tail_critic_heads_fwd(_ptr(y), B, hw, nf, _ptr(w_out), _ptr(b_out), _ptr(w_ac), _ptr(b_ac), ncls, _ptr(labels), _ptr(gp),
+                                          lam2, M, scale, _ptr(f), _ptr(d), _ptr(a), _ptr(ct_i), _ptr(probs), _ptr(ce_i), _ptr(out),
+                                          _stream()), 'tail_critic_heads_fwd')
+    return out, f, d, a, ct_i, probs
+
+
+def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac):
+    """-> (gy like y: gradient w.r.t. the last block's pre-activation; gw_out, gb_out, gw_ac, gb_ac) - one launch."""
+    _need_dev(y, d, f, probs, labels, ct_i, gout, w_out, w_ac)
+    n, hw, nf = _cl_rows(y)
+    assert n == 3 * B and gout.is_contiguous() and gout.numel() in (1, 4)
+    gy = empty_cl(n, nf, y.shape[2], y.shape[3], y.device)
+    gw_out = torch.empty_like(w_out); gb_out = torch.empty(1, dtype=torch.float32, device=y.device)
+    ncls = w_ac.shape[1] if w_ac is not None else 0
+    gw_ac = torch.empty_like(w_ac) if w_ac is not None else None
+    gb_ac = torch.empty(ncls, dtype=torch.float32, device=y.device) if w_ac is not None else None
+    check(lib.ctgan_tail_heads_bwd(_ptr(y), _ptr(d), _ptr(f), _ptr(probs), _ptr(labels), _ptr(ct_i), _ptr(gout), gout.numel(), B, hw, nf, ncls,
+                                   lam2, M, scale, mask_scale, _ptr(w_out), _ptr(w_ac), _ptr(gy), _ptr(gw_out), _ptr(gb_out), _ptr(gw_ac),
+                                   _ptr(gb_ac), _stream()), 'tail_heads_bwd')
+    return gy, gw_out, gb_out, gw_ac, gb_ac
+
+
+def gp_head_grad(y, w_out, mask_scale):
+    """gz = (y > 0) * w_out / hw * mask_scale  (dD/dz of D = mean_hw(relu(dropout(z))) . w_out)."""
+    _need_dev(y, w_out)
+    n, hw, nf = _cl_rows(y)
+    assert w_out.is_contiguous() and w_out.numel() == nf
+    gz = empty_cl(n, nf, y.shape[2], y.shape[3], y.device)
+    check(lib.ctgan_gp_head_grad(_ptr(y), _ptr(w_out), n, hw, nf, mask_scale, _ptr(gz), _stream()), 'gp_head_grad')
+    return gz
+
+
+def gp_head_wgrad(gg, y, mask_scale, like):
+    """gw_out = mask_scale / hw * sum over (row, hw) with y > 0 of gg  (adjoint of gp_head_grad w.r.t. w_out)."""
+    _need_dev(gg, y)
+    n, hw, nf = _cl_rows(y)
+    assert tuple(gg.shape) == tuple(y.shape) and gg.permute(0, 2, 3, 1).is_contiguous()
+    gw = torch.empty_like(like)
+    check(lib.ctgan_gp_head_wgrad(_ptr(gg), _ptr(y), n, hw, nf, mask_scale, _ptr(gw), _stream()), 'gp_head_wgrad')
+    return gw
+
+
 def accuracy2(logits, labels, B):
     _need_dev(logits, labels)
     assert logits.is_contiguous() and logits.shape[0] == 2 * B

@@ -297,6 +297,35 @@ int ctgan_critic_heads_fwd(const float* d, const float* f, const float* a, const
 int ctgan_critic_heads_bwd(const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
                            const float* gout, int32_t n_gout, int32_t B, int32_t nf, int32_t ncls, float lambda2,
                            float M, float acgan_scale, float* gd, float* gf, float* ga, ctgan_stream_t stream);
+/* The critic's output head fused around those loss heads (TF/CT_gan_cifar_resnet.py:179-186): y = the last residual
+ * block's relu(dropout(.)) output, dense channels-last [n][hw][nf].
+ *   tail_heads_fwd: f [n,nf] = mean over hw (:180; of relu(y) when relu != 0, :179), d [n] = f.w_out + b_out (:181, w_out [nf,1]; NULL = skip),
+ *                   a [n,ncls] = f.w_ac + b_ac (:183, w_ac [nf,ncls]; NULL = skip) - one launch for reduce_mean + 2 Linear.
+ *   tail_heads_bwd: given the saved d, f, probs, ct_i of ctgan_critic_heads_fwd and gout as in ctgan_critic_heads_bwd, writes
+ *                   gy [3B][hw][nf] = the gradient w.r.t. the last block's PRE-activation (head gradients pushed through both
+ *                   Linear layers, the mean and the relu/dropout mask y > 0 with its 1/keep = mask_scale) and the head
+ *                   weight gradients gw_out [nf], gb_out [1], gw_ac [nf,ncls], gb_ac [ncls] - one launch instead of nine.
+ *   gp_head_grad / gp_head_wgrad: the gradient-penalty branch needs only dD/dz (:284): gz = (y > 0) * w_out / hw *
+ *                   mask_scale, and in the double backward gw_out[j] = mask_scale / hw * sum_{y > 0} gg[.,.,j].            */
+int ctgan_tail_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, int32_t relu, const float* w_out,
+                         const float* b_out, const float* w_ac, const float* b_ac, int32_t ncls, float* f, float* d,
+                         float* a, ctgan_stream_t stream);
+/* tail_heads_fwd on the 3B rows of a critic step (relu = 0) + ctgan_critic_heads_fwd in two launches: the workgroup of
+ * real sample i owns both of its dropout passes (rows i and 2B+i) and writes ct_i[i], probs[i,:] and ce_i[i] (scratch
+ * [B]); a one-workgroup kernel then takes the batch means into out[5].                                                */
+int ctgan_tail_critic_heads_fwd(const float* y, int32_t B, int32_t hw, int32_t nf, const float* w_out, const float* b_out,
+                                const float* w_ac, const float* b_ac, int32_t ncls, const int32_t* labels,
+                                const float* gp, float lambda2, float M, float acgan_scale, float* f, float* d, float* a,
+                                float* ct_i, float* probs, float* ce_i, float* out, ctgan_stream_t stream);
+int ctgan_tail_heads_bwd(const float* y, const float* d, const float* f, const float* probs, const int32_t* labels,
+                         const float* ct_i, const float* gout, int32_t n_gout, int32_t B, int32_t hw, int32_t nf,
+                         int32_t ncls, float lambda2, float M, float acgan_scale, float mask_scale, const float* w_out,
+                         const float* w_ac, float* gy, float* gw_out, float* gb_out, float* gw_ac, float* gb_ac,
+                         ctgan_stream_t stream);
+int ctgan_gp_head_grad(const float* y, const float* w_out, int32_t n, int32_t hw, int32_t nf, float mask_scale,
+                       float* gz, ctgan_stream_t stream);
+int ctgan_gp_head_wgrad(const float* gg, const float* y, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gw,
+                        ctgan_stream_t stream);
 /* ACGAN accuracies of the clean critic pass (:249-266): logits [2B,ncls] (real rows, then fake rows); acc[2]   */
 int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32_t ncls, float* acc,
                     ctgan_stream_t stream);

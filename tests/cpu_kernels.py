@@ -485,6 +485,47 @@ def critic_heads_bwd(d, f, probs, labels, ct_i, gout, B, lam2, M, scale):
 
 
 @_export
+def tail_heads_fwd(y, w_out, b_out, w_ac, b_ac, relu=False):
+    f = (torch.relu(y) if relu else y).mean(dim=(2, 3))
+    d = (f @ w_out.reshape(-1, 1)).reshape(-1) + (b_out if b_out is not None else 0) if w_out is not None else None
+    a = f @ w_ac + (b_ac if b_ac is not None else 0) if w_ac is not None else None
+    return f, d, a
+
+
+@_export
+def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, scale):
+    f, d, a = tail_heads_fwd(y, w_out, b_out, w_ac, b_ac)
+    out, ct_i, probs = critic_heads_fwd(d, f, a, labels, B, lam2, M, scale, gp)
+    return out, f, d, a, ct_i, probs
+
+
+@_export
+def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac):
+    gd, gf, ga = critic_heads_bwd(d, f, probs if w_ac is not None else None, labels, ct_i, gout, B, lam2, M, scale)
+    t = gf + gd[:, None] * w_out.reshape(1, -1)
+    if w_ac is not None:
+        t = t + ga @ w_ac.t()
+    hw = y.shape[2] * y.shape[3]
+    gy = (t / hw)[:, :, None, None] * (y > 0).to(y.dtype) * mask_scale
+    gw_out = (f.t() @ gd).reshape(w_out.shape); gb_out = gd.sum().reshape(1)
+    gw_ac = f.t() @ ga if w_ac is not None else None
+    gb_ac = ga.sum(dim=0) if w_ac is not None else None
+    return gy.contiguous(memory_format=torch.channels_last), gw_out, gb_out, gw_ac, gb_ac
+
+
+@_export
+def gp_head_grad(y, w_out, mask_scale):
+    hw = y.shape[2] * y.shape[3]
+    return ((y > 0).to(y.dtype) * (w_out.reshape(1, -1, 1, 1) / hw * mask_scale)).contiguous(memory_format=torch.channels_last)
+
+
+@_export
+def gp_head_wgrad(gg, y, mask_scale, like):
+    hw = y.shape[2] * y.shape[3]
+    return ((gg * (y > 0).to(y.dtype)).sum(dim=(0, 2, 3)) * (mask_scale / hw)).reshape(like.shape)
+
+
+@_export
 def accuracy2(logits, labels, B):
     am = logits.argmax(dim=1)
     lab = labels.long()
@@ -530,21 +571,27 @@ def adam_advance(state, beta1, beta2):
 _gen = torch.Generator().manual_seed(0)
 
 
+def _gen_for(seed, stream_id, ctr):
+    """Counter-based like the device streams: the draw depends on (seed, call site, step counter) only."""
+    step = int(ctr.reshape(-1)[0]) if torch.is_tensor(ctr) else int(ctr or 0)
+    return torch.Generator().manual_seed((int(seed) * 1000003 + int(stream_id) * 7919 + step * 104729) % (1 << 62))
+
+
 @_export
 def rng_uniform(out, seed, stream_id, ctr, lo=0.0, hi=1.0):
-    out.copy_(lo + (hi - lo) * torch.rand(out.shape, generator=_gen))
+    out.copy_(lo + (hi - lo) * torch.rand(out.shape, generator=_gen_for(seed, stream_id, ctr)))
     return out
 
 
 @_export
 def rng_normal(out, seed, stream_id, ctr):
-    out.copy_(torch.randn(out.shape, generator=_gen))
+    out.copy_(torch.randn(out.shape, generator=_gen_for(seed, stream_id, ctr)))
     return out
 
 
 @_export
 def rng_labels(out, nlab, seed, stream_id, ctr):
-    out.copy_((torch.rand(out.shape, generator=_gen) * nlab).to(torch.int32))
+    out.copy_((torch.rand(out.shape, generator=_gen_for(seed, stream_id, ctr)) * nlab).to(torch.int32))
     return out
 
 

@@ -644,6 +644,63 @@ def test_fused_critic_heads(K, with_a):
     assert abs(acc[1].item() - (am[B:] == lab.long()).float().mean().item()) < 1e-6
 
 
+@pytest.mark.parametrize('B,nf,H,with_a', [(16, 128, 8, True), (5, 32, 4, True), (7, 64, 8, False), (3, 256, 2, True)])
+def test_fused_critic_tail_heads(K, B, nf, H, with_a):
+    """F.critic_tail_heads (reduce_mean + both Linear heads + loss heads, TF/CT_gan_cifar_resnet.py:179-186,244-248,288-291)
+    and F.gp_head_grad against the same graph in fp64 torch autograd: losses, critic outputs, the gradient w.r.t. the last
+    conv's result (mask and 1/keep included), the head weight gradients; and the gp head's double backward."""
+    import ctgan_amd.functional as F
+    g = torch.Generator().manual_seed(B * 1000 + nf)
+    ncls, keep = 10, 0.5
+    z = torch.randn(3 * B, nf, H, H, generator=g)
+    mask = (torch.rand(3 * B, nf, H, H, generator=g) < keep).float() / keep
+    y = torch.relu(z) * mask                                    # = relu(dropout(z)), what the last conv's epilogue writes
+    w_out = torch.randn(nf, 1, generator=g) * 0.1; b_out = torch.randn(1, generator=g)
+    w_ac = torch.randn(nf, ncls, generator=g) * 0.1; b_ac = torch.randn(ncls, generator=g)
+    lab = torch.randint(0, ncls, (B,), generator=g, dtype=torch.int32)
+    lam2, M, scale = 2.0, 0.05, 0.7
+    zr = z.double().requires_grad_(True)
+    P = [t.double().requires_grad_(True) for t in (w_out, b_out, w_ac, b_ac)]
+    fr = (torch.relu(zr) * mask.double()).mean(dim=(2, 3))
+    dr = (fr @ P[0]).reshape(-1) + P[1]
+    ar = fr @ P[2] + P[3]
+    wgan = dr[B:2 * B].mean() - dr[:B].mean()
+    ct_i = lam2 * (dr[:B] - dr[2 * B:]) ** 2 + 0.1 * lam2 * ((fr[:B] - fr[2 * B:]) ** 2).mean(dim=1)
+    ct = torch.clamp(ct_i - M, min=0).mean()
+    ac = torch.nn.functional.cross_entropy(ar[:B], lab.long()) if with_a else torch.zeros((), dtype=torch.float64)
+    cost = wgan + ct + 0.37 + (scale * ac if with_a else 0)
+    yd = cl(y).requires_grad_(True)
+    Pd = [dev(t).requires_grad_(True) for t in (w_out, b_out, w_ac, b_ac)]
+    gpv = dev(torch.tensor(0.37)).requires_grad_(True)
+    got = F.critic_tail_heads(yd, Pd[0], Pd[1], Pd[2] if with_a else None, Pd[3] if with_a else None, dev(lab), B, lam2, M,
+                              scale if with_a else 0.0, 1.0 / keep, gp=gpv)
+    for x, ref in zip(got[:4], (cost, wgan, ct, ac)):
+        assert abs(x.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+    assert relerr(got[5], dr) < 1e-5
+    ins = [yd, Pd[0], Pd[1]] + ([Pd[2], Pd[3]] if with_a else [])
+    rins = [zr, P[0], P[1]] + ([P[2], P[3]] if with_a else [])
+    gg = torch.autograd.grad(got[0], ins, retain_graph=True); gr = torch.autograd.grad(cost, rins, retain_graph=True)
+    scale_all = max(float(t.abs().max()) for t in gr)
+    for x, ref in zip(gg, gr):
+        assert float((x.cpu().double() - ref).norm()) <= 2e-5 * float(ref.norm()) + 1e-6 * scale_all
+    w = [0.3, -1.1, 0.6, 0.9]                                    # the four heads differentiated separately (n_gout = 4)
+    comb = sum(wi * gi for wi, gi in zip(w, got[:4])); combr = w[0] * cost + w[1] * wgan + w[2] * ct + w[3] * ac
+    gg = torch.autograd.grad(comb, ins); gr = torch.autograd.grad(combr, rins, retain_graph=True)
+    for x, ref in zip(gg, gr):
+        assert float((x.cpu().double() - ref).norm()) <= 2e-5 * float(ref.norm()) + 1e-6 * scale_all
+    # relu inside the mean (clean pass)
+    f2, _, a2 = K.tail_heads_fwd(cl(z), None, None, dev(w_ac), dev(b_ac), relu=True)
+    assert relerr(f2, torch.relu(z).mean(dim=(2, 3))) < 1e-6 and relerr(a2, torch.relu(z).mean(dim=(2, 3)) @ w_ac + b_ac) < 1e-5
+    # gradient-penalty head: gz = d(mean_hw(y) . w_out)/dz and its adjoint w.r.t. w_out
+    gz = F.gp_head_grad(yd.detach(), Pd[0], 1.0 / keep)
+    (gz_ref,) = torch.autograd.grad(dr.sum(), zr, retain_graph=True)
+    assert relerr(gz, gz_ref) < 1e-6
+    v = torch.randn(3 * B, nf, H, H, generator=g)
+    (gw,) = torch.autograd.grad(gz, Pd[0], cl(v))
+    gw_ref = ((v.double() * (y > 0).double()).sum(dim=(0, 2, 3)) / (keep * H * H)).reshape(nf, 1)
+    assert relerr(gw, gw_ref) < 1e-5
+
+
 @pytest.mark.parametrize('C,H,Ko,k,st,Ns', [(128, 8, 128, 3, 1, (12, 4)), (128, 16, 128, 4, 2, (8, 4, 2)), (64, 8, 96, 1, 1, (5,)),
                                             (128, 32, 128, 3, 1, (64, 16))])
 def test_multi_segment_wgrad(K, C, H, Ko, k, st, Ns):

@@ -249,6 +249,36 @@ def test_deferred_multi_segment_wgrads_equal_immediate_wgrads(cpu_kernels):
         R.configure()
 
 
+def test_fused_critic_heads_equal_separate_heads(small):
+    """Host wiring of HEAD_FUSION (CriticTailHeadsFn, GpHeadGradFn, ConvFn 'mask_done') against the op-by-op head, on the
+    CPU stand-ins and identical random streams."""
+    import ctgan_amd.functional as F
+    R, lib = small
+    B = R.cfg.BATCH_SIZE
+    g = torch.Generator().manual_seed(3)
+    real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+    lab = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+    tr = R.Trainer(seed=4)
+    fake = tr.generate_fakes(lab)[0]
+    res = {}
+    for mode in (False, True):
+        R.HEAD_FUSION = mode
+        try:
+            tr.rng.begin_step()
+            out = tr.d_losses(real, lab, fake=fake)
+            grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+            res[mode] = ({k: out[k].detach().clone() for k in ('cost', 'wgan', 'ct', 'acgan', 'gp', 'd_real', 'd_fake', 'gp_grads')},
+                         [None if t is None else t.detach().clone() for t in grads])
+        finally:
+            R.HEAD_FUSION = True
+    for k, v in res[True][0].items():
+        _cmp(v, res[False][0][k], 1e-5, k)
+    for (n, _), a_, b_ in zip(tr.d_named, res[True][1], res[False][1]):
+        assert (a_ is None) == (b_ is None), n
+        if a_ is not None:
+            _cmp(a_, b_, 2e-5, n)
+
+
 def test_layernorm_critic_step_matches_oracle(cpu_kernels):
     """NORMALIZATION_D=True (TF/CT_gan_cifar_resnet.py:76-77: Layernorm after every critic conv input): the critic is no
     longer piecewise linear, so the gradient penalty differentiates Layernorm twice - forward, losses and every critic
