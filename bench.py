@@ -206,10 +206,7 @@ def measure_gp_unit(trainer, batch, torch):
         F.prepare_filters()                   # ... so every derived filter layout is rebuilt (one or two launches)
         trainer.rng.begin_step()
         xi = x.detach().requires_grad_(True)
-        with F.weight_grads(False):
-            d = R.Discriminator(xi, labels, 0.8, 0.5, 0.5, rng=trainer.rng, heads=('wgan',))[0]
-        (g,) = torch.autograd.grad(d, xi, grad_outputs=torch.ones_like(d), create_graph=True)
-        gp, _ = F.gradient_penalty(g, R.cfg.GP_LAMBDA)
+        gp, _, _ = R.gradient_penalty_branch(xi, labels, trainer.rng)       # exactly the branch the critic step runs
         with F.deferred_wgrads():
             return torch.autograd.grad(gp, trainer.d_params, allow_unused=True)
 

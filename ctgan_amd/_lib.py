@@ -33,7 +33,8 @@ class FilterJob(ctypes.Structure):
     """struct ctgan_filter_job (include/ctgan_hip.h)."""
     _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p),
                 ('R', c_int32), ('S', c_int32), ('C', c_int32), ('K', c_int32),
-                ('kind', c_int32), ('pad_t', c_int32), ('pad_l', c_int32), ('scale', ctypes.c_float)]
+                ('kind', c_int32), ('pad_t', c_int32), ('pad_l', c_int32), ('scale', ctypes.c_float),
+                ('pre', c_int32), ('pre_scale', ctypes.c_float)]
 
 
 class WgradGroup(ctypes.Structure):

@@ -241,52 +241,79 @@ __global__ void filter_fold_kernel(const float* __restrict__ w4, float* __restri
 }
 
 // All derived filters of a weight update in one launch (blockIdx.y = job): the rotated / phase-major layouts the
-// data-gradient kernels multiply with, and the spread filters of the resampled convs.
+// data-gradient kernels multiply with, the spread filters of the resampled convs, and the data-gradient layouts OF the
+// spread filters straight from the parameter (job.pre) - so nothing in the launch depends on another job's output.
+// Every output tap plane is a C x K matrix that is a (scaled sum of up to four) source tap plane(s), or the transpose of it:
+// one workgroup moves one 32 x 32 tile with coalesced reads (k inner) and coalesced writes (through LDS when transposed).
 struct FilterJobs { ctgan_filter_job j[CTGAN_FILTER_BATCH]; };
-__global__ void filter_batch_kernel(const FilterJobs t) {
+__global__ __launch_bounds__(256) void filter_batch_kernel(const FilterJobs t) {
     const ctgan_filter_job& jb = t.j[blockIdx.y];
-    const int R = jb.R, S = jb.S, C = jb.C, K = jb.K;
-    const float* __restrict__ w = jb.src;
-    float* __restrict__ out = jb.dst;
-    const long long stride = (long long)gridDim.x * blockDim.x, i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (jb.kind == CTGAN_FILTER_ROTATE) {              // wt[r',s',k,c] = w[R-1-r',S-1-s',c,k]
-        const long long n = (long long)R * S * C * K;
-        for (long long i = i0; i < n; i += stride) {
-            const int c = (int)(i % C); long long r = i / C;
-            const int k = (int)(r % K); r /= K;
-            const int s = (int)(r % S), rr = (int)(r / S);
-            out[i] = w[(((long long)(R - 1 - rr) * S + (S - 1 - s)) * C + c) * K + k];
-        }
-    } else if (jb.kind == CTGAN_FILTER_PHASES) {       // see repack_dgrad_phase_filter_kernel (igemm.hip)
-        const int Tr = (R + 1) / 2, Ts = (S + 1) / 2;
-        const long long per = (long long)Tr * Ts * K * C, n = 4 * per;
-        for (long long i = i0; i < n; i += stride) {
-            const int ph = (int)(i / per);
-            long long r = i - ph * per;
-            const int c = (int)(r % C); r /= C;
-            const int k = (int)(r % K); r /= K;
-            const int v = (int)(r % Ts), tt = (int)(r / Ts);
-            const int a = ph >> 1, b = ph & 1;
-            const int u = ((a + jb.pad_t) & 1) + 2 * (Tr - 1 - tt), x = ((b + jb.pad_l) & 1) + 2 * (Ts - 1 - v);
-            out[i] = (u < R && x < S) ? w[(((long long)u * S + x) * C + c) * K + k] : 0.f;
-        }
-    } else {                                            // spread (kind SPREAD) / rotated + swapped spread (SPREAD_FLIP)
-        const int flip = jb.kind == CTGAN_FILTER_SPREAD_FLIP;
-        const long long n = (long long)(R + 1) * (S + 1) * C * K;
-        for (long long i = i0; i < n; i += stride) {
-            const int k = (int)(i % K); long long r = i / K;
-            const int c = (int)(r % C); r /= C;
-            const int v = (int)(r % (S + 1)), u = (int)(r / (S + 1));
-            float acc = 0.f;
+    const int R = jb.R, S = jb.S, C = jb.C, K = jb.K;            // the SOURCE parameter w[R,S,C,K]
+    const int pre = jb.pre ? jb.pre : ((jb.kind == CTGAN_FILTER_SPREAD || jb.kind == CTGAN_FILTER_SPREAD_FLIP) ? jb.kind : 0);
+    const int kind = (jb.kind == CTGAN_FILTER_SPREAD || jb.kind == CTGAN_FILTER_SPREAD_FLIP) ? -1 : jb.kind;   // -1: materialise E itself
+    const float sc = jb.pre ? jb.pre_scale : ((kind == -1) ? jb.scale : 1.f);
+    const int Re = pre ? R + 1 : R, Se = pre ? S + 1 : S;        // taps of the effective filter E
+    const int tc = (C + 31) >> 5, tk = (K + 31) >> 5, tiles = tc * tk;
+    int planes;
+    const int Tr = (Re + 1) / 2, Ts = (Se + 1) / 2;
+    if (kind == CTGAN_FILTER_PHASES) planes = 4 * Tr * Ts; else planes = Re * Se;
+    const int plane = blockIdx.x / tiles;
+    if (plane >= planes) return;
+    const int tile = blockIdx.x - plane * tiles;
+    const int c0 = (tile / tk) * 32, k0 = (tile % tk) * 32;
+    // effective tap (u, v) of E this output plane holds, -1 = zero plane
+    int u, v;
+    if (kind == CTGAN_FILTER_PHASES) {
+        const int ph = plane / (Tr * Ts), r = plane - ph * Tr * Ts, tt = r / Ts, vv = r - tt * Ts;
+        const int a = ph >> 1, bb = ph & 1;
+        u = ((a + jb.pad_t) & 1) + 2 * (Tr - 1 - tt); v = ((bb + jb.pad_l) & 1) + 2 * (Ts - 1 - vv);
+        if (u >= Re || v >= Se) u = -1;
+    } else if (kind == CTGAN_FILTER_ROTATE) {
+        u = Re - 1 - plane / Se; v = Se - 1 - plane % Se;
+    } else {
+        u = plane / Se; v = plane % Se;
+    }
+    // E of a flipped spread is the rotated, I/O-swapped spread: tap (u,v) of E = transpose of spread tap (R-u, S-v)
+    bool transpose = (kind != -1);                                // the dgrad layouts are [k][c] of E
+    if (pre == CTGAN_FILTER_SPREAD_FLIP) { transpose = !transpose; if (u >= 0) { u = R - u; v = S - v; } }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    float val[4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, k = k0 + tx;
+        float acc = 0.f;
+        if (u >= 0 && c < C && k < K) {
+            if (pre) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int rr = u - a, ss = v - b;
-                    if (rr >= 0 && rr < R && ss >= 0 && ss < S) acc += w[(((long long)rr * S + ss) * C + c) * K + k];
-                }
-            const long long o = flip ? ((((long long)(R - u) * (S + 1) + (S - v)) * K + k) * C + c) : i;
-            out[o] = jb.scale * acc;
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int rr = u - a, ss = v - bb;
+                        if (rr >= 0 && rr < R && ss >= 0 && ss < S) acc += jb.src[(((long long)rr * S + ss) * C + c) * K + k];
+                    }
+                acc = sc * acc;
+            } else {
+                acc = jb.src[(((long long)u * S + v) * C + c) * K + k];
+            }
+        }
+        val[i] = acc;
+    }
+    float* out = jb.dst + (long long)plane * C * K;
+    if (!transpose) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, k = k0 + tx;
+            if (c < C && k < K) out[(long long)c * K + k] = val[i];
+        }
+    } else {
+        __shared__ float tl[32][33];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tl[ty + 8 * i][tx] = val[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, c = c0 + tx;
+            if (c < C && k < K) out[(long long)k * C + c] = tl[tx][ty + 8 * i];
         }
     }
 }
@@ -414,13 +441,19 @@ int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t s
     for (int32_t base = 0; base < n; base += CTGAN_FILTER_BATCH) {
         FilterJobs t;
         const int m = n - base < CTGAN_FILTER_BATCH ? n - base : CTGAN_FILTER_BATCH;
+        int blocks = 0;
         for (int i = 0; i < m; ++i) {
-            t.j[i] = jobs[base + i];
-            if (!t.j[i].src || !t.j[i].dst || t.j[i].R <= 0 || t.j[i].S <= 0 || t.j[i].C <= 0 || t.j[i].K <= 0 || t.j[i].kind < 0 ||
-                t.j[i].kind > CTGAN_FILTER_SPREAD_FLIP)
+            const ctgan_filter_job& j = t.j[i] = jobs[base + i];
+            const bool spread = j.kind == CTGAN_FILTER_SPREAD || j.kind == CTGAN_FILTER_SPREAD_FLIP;
+            if (!j.src || !j.dst || j.R <= 0 || j.S <= 0 || j.C <= 0 || j.K <= 0 || j.kind < 0 || j.kind > CTGAN_FILTER_SPREAD_FLIP ||
+                (j.pre != 0 && j.pre != CTGAN_FILTER_SPREAD && j.pre != CTGAN_FILTER_SPREAD_FLIP) || (j.pre && spread))
                 return ctgan_fail(CTGAN_E_BADARG, "filter_batch: bad job %d", base + i);
+            const int Re = (j.pre || spread) ? j.R + 1 : j.R, Se = (j.pre || spread) ? j.S + 1 : j.S;
+            const int planes = j.kind == CTGAN_FILTER_PHASES ? 4 * ((Re + 1) / 2) * ((Se + 1) / 2) : Re * Se;
+            const int b = planes * ((j.C + 31) / 32) * ((j.K + 31) / 32);
+            if (b > blocks) blocks = b;
         }
-        hipLaunchKernelGGL(filter_batch_kernel, dim3(256, m), dim3(TPB), 0, static_cast<hipStream_t>(s), t);
+        hipLaunchKernelGGL(filter_batch_kernel, dim3(blocks, m), dim3(256), 0, static_cast<hipStream_t>(s), t);
         const int rc = ctgan_check_launch("filter_batch");
         if (rc) return rc;
     }

@@ -1810,12 +1810,39 @@ extern "C" int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, 
 // launch for all their split-K reductions --------------------------------------------------------------------------------
 namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// A grouped launch fills the chip with the workgroups of ALL its problems, so each problem can take fewer, longer splits than
+// the stand-alone plan (which fills the chip by itself): fewer partial slabs to write and to reduce.
+void coarsen_plan(MultiPlan& m, WgradParams& p, int div) {
+    if (div == 100) return;
+    int chunk = (int)((long long)m.w.chunk * div / 100);
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    if (chunk < 4 * BK) chunk = 4 * BK;
+    m.w.chunk = chunk;
+    m.splits = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        p.seg[i].split0 = m.splits;
+        m.seg_splits[i] = (p.seg[i].Kg + chunk - 1) / chunk;
+        m.splits += m.seg_splits[i];
+    }
+}
+int group_div() {
+    static const int v = [] { const char* e = getenv("CTGAN_WGRAD_GROUP_PCT"); return e ? atoi(e) : 100; }();     // chunk scale, percent
+    return v < 10 ? 10 : v;
+}
 }
 extern "C" size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n) {
     if (!groups || n < 1) return 0;
     size_t tot = 0;
-    for (int i = 0; i < n; ++i)
-        tot += align256(ctgan_conv2d_wgrad_multi_workspace_bytes(&groups[i].d, groups[i].nseg, groups[i].Ns));
+    for (int i = 0; i < n; ++i) {
+        const ctgan_wgrad_group& G = groups[i];
+        if (G.nseg < 1 || G.nseg > CTGAN_WGRAD_MAX_SEGS) return 0;
+        MultiPlan m = multi_plan(&G.d, G.nseg, G.Ns);
+        WgradParams p;
+        p.nseg = G.nseg;
+        for (int k = 0; k < G.nseg; ++k) p.seg[k].Kg = G.Ns[k] * G.d.P * G.d.Q;
+        if (n > 1) coarsen_plan(m, p, group_div());
+        tot += align256((size_t)m.splits * ((size_t)G.d.R * G.d.S * G.d.C + 1) * G.d.K * sizeof(float));
+    }
     return tot;
 }
 
@@ -1828,6 +1855,7 @@ extern "C" int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t
         const ctgan_wgrad_group& G = groups[i];
         int rc = prepare_multi(&G.d, G.nseg, G.xs, G.dys, G.Ns, G.seg_flags, G.dw, G.db, PT[i], M[i], "conv2d_wgrad_group");
         if (rc) return rc;
+        if (n > 1) coarsen_plan(M[i], PT[i], group_div());
         const size_t need = (size_t)M[i].splits * (PT[i].Mtot + 1) * PT[i].Ng * sizeof(float);
         if (!ws || off + need > ws_bytes) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_group: workspace too small");
         PT[i].OUT = reinterpret_cast<float*>(static_cast<char*>(ws) + off);

@@ -330,7 +330,10 @@ class ConvDgradFn(Function):
 # (`lib.epoch()`): lazily on first use, or - `prepare_filters()` - all of them in one or two launches at the start
 # of a step.  A consumer on another stream waits for the producer's event.
 class _FilterEntry:
-    __slots__ = ('src', 'buf', 'kind', 'pad', 'scale', 'epoch', 'ev', 'st', 'level', 'group')
+    __slots__ = ('src', 'buf', 'kind', 'pad', 'scale', 'epoch', 'ev', 'st', 'group', 'pre', 'pre_scale')
+
+    def job(self):
+        return (self.src, self.buf, self.kind, self.pad[0], self.pad[1], self.scale, self.pre, self.pre_scale)
 
 
 _FCACHE = {}          # (src data_ptr, kind, R, S, C, K, pad_t, pad_l, scale) -> _FilterEntry
@@ -369,16 +372,17 @@ def _cached_filter(src, kind, pad=(0, 0), scale=1.0):
             lib.on_delete_all_params(clear_filter_cache)
             _hooked[0] = True
         e = _FilterEntry()
-        e.src = parent.buf if parent is not None else src
+        # a layout OF a cached spread filter is built straight from the parameter (job.pre): no job depends on another one
+        e.src = parent.src if parent is not None else src
+        e.pre, e.pre_scale = (parent.kind, parent.scale) if parent is not None else (0, 1.0)
         e.buf = torch.empty(K.filter_job_shape(kind, *src.shape), dtype=torch.float32, device=src.device)
         e.kind, e.pad, e.scale, e.epoch, e.ev, e.st = kind, tuple(pad), scale, -1, None, None
-        e.level = 1 if parent is not None else 0
         e.group = parent.group if parent is not None else lib.group_of(src)     # network whose updates invalidate it
         _FCACHE[key] = e
         if kind in (K.FILTER_SPREAD, K.FILTER_SPREAD_FLIP):
             _SPREAD_BUFS[e.buf.data_ptr()] = e
     if e.epoch != lib.epoch(e.group):
-        K.filter_batch([(e.src, e.buf, e.kind, e.pad[0], e.pad[1], e.scale)])
+        K.filter_batch([e.job()])
         _mark_built([e])
     elif e.ev is not None and torch.cuda.current_stream() != e.st:
         torch.cuda.current_stream().wait_event(e.ev)
@@ -386,14 +390,13 @@ def _cached_filter(src, kind, pad=(0, 0), scale=1.0):
 
 
 def prepare_filters():
-    """Rebuild every known derived filter for the current weight version now, on the current stream: one launch
-    for the layouts derived from parameters, one for the dgrad layouts of spread filters."""
+    """Rebuild every known derived filter for the current weight version now, on the current stream, in one launch (the
+    data-gradient layouts of spread filters are computed from the parameter, not from the spread buffer)."""
     from . import tflib as lib
-    for level in (0, 1):
-        todo = [e for e in _FCACHE.values() if e.level == level and e.epoch != lib.epoch(e.group)]
-        if todo:
-            K.filter_batch([(e.src, e.buf, e.kind, e.pad[0], e.pad[1], e.scale) for e in todo])
-            _mark_built(todo)
+    todo = [e for e in _FCACHE.values() if e.epoch != lib.epoch(e.group)]
+    if todo:
+        K.filter_batch([e.job() for e in todo])
+        _mark_built(todo)
 
 
 def _repacked(w, g):

@@ -311,6 +311,32 @@ HEAD_FUSION = _os.environ.get('CTGAN_HEAD_FUSION', '1') != '0'
 BATCH_FAKES = _os.environ.get('CTGAN_BATCH_FAKES', '1') != '0'
 
 
+def _heads_fusable(rnd, rng):
+    return (HEAD_FUSION and rnd is None and _critic_piecewise_linear() and _tail_fusable(0.8, 0.5, 0.5, None, rng)
+            and cfg.DIM_D % 4 == 0 and cfg.DIM_D <= 1024)
+
+
+def gradient_penalty_branch(interp, labels, rng, rnd=None):
+    """GP = lambda * mean((||dD(x_hat)/dx_hat||_2 - 1)^2) with its own dropout masks (:277-286): critic forward on x_hat,
+    data gradient back to x_hat under create_graph.  -> (gp, slopes, dD/dx_hat).  interp must require grad."""
+    fuse_heads = _heads_fusable(rnd, rng)
+    with F.weight_grads(not _critic_piecewise_linear()):
+        if fuse_heads:
+            y_gp = DiscriminatorTailBody(DiscriminatorTrunk(interp), 0.8, 0.5, 0.5, rng=rng, mask_done=True)
+        else:
+            u_gp = rnd['u_gp'] if rnd is not None else None
+            d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng, heads=('wgan',))[0]
+    if fuse_heads:
+        # D(x_hat) itself is never used: start the backward at the last block with dD/dz (one launch)
+        gz = F.gp_head_grad(y_gp, lib.param('Discriminator.Output.W'), 1.0 / 0.5)
+        (grads,) = torch.autograd.grad(y_gp, interp, grad_outputs=gz, create_graph=True)
+    else:
+        ones = torch.ones_like(d_gp)
+        (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
+    gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
+    return gp, slopes, grads
+
+
 class Trainer:
     """Owns the optimizers, the random streams and the D/G step (the session of the reference)."""
 
@@ -360,22 +386,8 @@ class Trainer:
             F.prepare_dgrad_filters(self.d_params)
             side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side) if side is not None else _nullctx():
-            fuse_heads = (HEAD_FUSION and rnd is None and _critic_piecewise_linear() and _tail_fusable(0.8, 0.5, 0.5, None, rng)
-                          and cfg.DIM_D % 4 == 0)
-            with F.weight_grads(not _critic_piecewise_linear()):
-                if fuse_heads:
-                    y_gp = DiscriminatorTailBody(DiscriminatorTrunk(interp), 0.8, 0.5, 0.5, rng=rng, mask_done=True)
-                else:
-                    u_gp = rnd['u_gp'] if rnd is not None else None
-                    d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng, heads=('wgan',))[0]
-            if fuse_heads:
-                # D(x_hat) itself is never used: start the backward at the last block with dD/dz (one launch)
-                gz = F.gp_head_grad(y_gp, lib.param('Discriminator.Output.W'), 1.0 / 0.5)
-                (grads,) = torch.autograd.grad(y_gp, interp, grad_outputs=gz, create_graph=True)
-            else:
-                ones = torch.ones_like(d_gp)
-                (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
-            gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
+            fuse_heads = _heads_fusable(rnd, rng)
+            gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd)
 
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
         h = DiscriminatorTrunk(rf)

@@ -529,16 +529,24 @@ def filter_job_shape(kind, R, S, C, Ko):
 
 
 def filter_batch(jobs):
-    """jobs: list of (src [R,S,C,K], dst, kind, pad_t, pad_l, scale) - every derived filter in one launch per 24."""
+    """jobs: list of (src [R,S,C,K], dst, kind, pad_t, pad_l, scale[, pre, pre_scale]) - every derived filter in one launch
+    per 40.  pre = FILTER_SPREAD / FILTER_SPREAD_FLIP: `kind` (ROTATE / PHASES) is taken of that spread of src (scale
+    pre_scale) without materialising it: dst has the shape the layout of the spread buffer would have."""
     from ._lib import FilterJob
     if not jobs:
         return
     arr = (FilterJob * len(jobs))()
-    for i, (src, dst, kind, pad_t, pad_l, scale) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        src, dst, kind, pad_t, pad_l, scale = job[:6]
+        pre, pre_scale = (job[6], job[7]) if len(job) > 6 else (0, 1.0)
         _need_dev(src, dst)
         R, S, C, Ko = src.shape
-        assert src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == filter_job_shape(kind, R, S, C, Ko)
-        arr[i] = FilterJob(src.data_ptr(), dst.data_ptr(), R, S, C, Ko, kind, pad_t, pad_l, scale)
+        if pre:
+            eff = (R + 1, S + 1, Ko, C) if pre == FILTER_SPREAD_FLIP else (R + 1, S + 1, C, Ko)
+        else:
+            eff = (R, S, C, Ko)
+        assert src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == filter_job_shape(kind, *eff)
+        arr[i] = FilterJob(src.data_ptr(), dst.data_ptr(), R, S, C, Ko, kind, pad_t, pad_l, scale, pre, pre_scale)
     check(lib.ctgan_filter_batch(arr, len(jobs), _stream()), 'filter_batch')
 
 

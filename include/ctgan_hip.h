@@ -205,7 +205,10 @@ int ctgan_filter_fold(const float* w4, float* out, int32_t R, int32_t S, int32_t
 #define CTGAN_FILTER_PHASES 1
 #define CTGAN_FILTER_SPREAD 2
 #define CTGAN_FILTER_SPREAD_FLIP 3
-#define CTGAN_FILTER_BATCH 24
+/* pre = CTGAN_FILTER_SPREAD / _SPREAD_FLIP with kind = ROTATE / PHASES: the layout is taken OF the spread filter
+ * (pre_scale = its scale; its taps are (R+1) x (S+1), and for _SPREAD_FLIP its channel roles are swapped) straight from
+ * src, bit-identical to running the spread job first and the layout job on its output - but independent of it.          */
+#define CTGAN_FILTER_BATCH 40
 typedef struct ctgan_filter_job {
     const float* src;
     float* dst;
@@ -213,6 +216,8 @@ typedef struct ctgan_filter_job {
     int32_t kind;
     int32_t pad_t, pad_l;
     float scale;
+    int32_t pre;
+    float pre_scale;
 } ctgan_filter_job;
 int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t stream);
 /* ---- Layernorm primitives (TF/tflib/ops/layernorm.py:6-20: tf.nn.moments over (C,H,W) per sample +

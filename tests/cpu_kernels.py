@@ -280,7 +280,10 @@ def filter_spread(w, scale, flip):
 
 @_export
 def filter_batch(jobs):
-    for src, dst, kind, pad_t, pad_l, scale in jobs:
+    for job in jobs:
+        src, dst, kind, pad_t, pad_l, scale = job[:6]
+        if len(job) > 6 and job[6]:
+            src = filter_spread(src, job[7], job[6] == 3)
         R, S, C, Ko = src.shape
         if kind in (2, 3):
             dst.copy_(filter_spread(src, scale, kind == 3))

@@ -575,6 +575,22 @@ def test_filter_batch_matches_single_kernels(K):
         assert torch.equal(dst, K.repack_filter(src, gg).reshape(-1))
     assert torch.equal(jobs[3][1], K.filter_spread(w3, 0.25, False)) and torch.equal(jobs[4][1], K.filter_spread(w3, 0.25, True))
     assert torch.equal(jobs[-1][1], jobs[4][1]) and torch.equal(jobs[-3][1].reshape(-1), jobs[2][1].reshape(-1))
+    # composed jobs: the data-gradient layout OF a spread filter straight from the parameter (job.pre) is bit-identical to
+    # the layout job run on the materialised spread filter; odd channel counts exercise the ragged 32 x 32 tiles
+    for C, Ko in ((64, 96), (40, 72)):
+        w = dev(torch.randn(3, 3, C, Ko, generator=g))
+        for flip, pre in ((False, K.FILTER_SPREAD), (True, K.FILTER_SPREAD_FLIP)):
+            sp = K.filter_spread(w, 0.25, flip)                               # [4,4,C,K] or [4,4,K,C]
+            Ce, Ke = sp.shape[2], sp.shape[3]
+            gs = K.ConvGeom(Ce, 8, 8, Ke, 4, 4, 2, False)
+            for kind in (K.FILTER_PHASES, K.FILTER_ROTATE):
+                ref = torch.empty(K.filter_job_shape(kind, *sp.shape), device='cuda')
+                K.filter_batch([(sp, ref, kind, gs.pad_t, gs.pad_l, 1.0)])
+                got = torch.empty_like(ref)
+                K.filter_batch([(w, got, kind, gs.pad_t, gs.pad_l, 1.0, pre, 0.25)])
+                assert torch.equal(got, ref), (C, Ko, flip, kind)
+                if kind == K.dgrad_filter_kind(gs):
+                    assert torch.equal(ref, K.repack_filter(sp, gs).reshape(-1))
 
 
 def test_fused_philox_dropout_equals_draw_then_dropout(K):

@@ -1,13 +1,2 @@
 run() { echo "== $*"; env "$@" python bench.py --no-roofline --no-cpu-baseline --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
-run X=1
-run HIP_FORCE_DEV_KERNARG=1
-run HIP_FORCE_DEV_KERNARG=0
-run DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
-run DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
-run AMD_OPT_FLUSH=0
-run AMD_OPT_FLUSH=1
-run DEBUG_HIP_GRAPH_BATCH_SIZE=1024
-run GPU_FLUSH_ON_EXECUTION=1
-run ROC_USE_FGS_KERNARG=0
-run DEBUG_HIP_KERNARG_COPY_OPT=0
-run X=2
+for v in "$@"; do run $v; done
