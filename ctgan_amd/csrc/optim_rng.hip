@@ -120,6 +120,68 @@ __global__ void rng_labels_kernel(int32_t* __restrict__ out, long long n, int nl
         }
     }
 }
+// ---- critic-step input preparation in one launch (TF/CT_gan_cifar_resnet.py:201-202,226,277-283) ---------------------------
+//   real   = 2*(x/denom - .5) + U[lo,hi)          (dequantisation noise = element i of stream sid_deq)
+//   interp = real + alpha*(fake - real)            (alpha[row] = element row of stream sid_alpha, U[0,1))
+//   rf     = [real ; fake]                         (the batch of the two dropout passes)
+// bit-identical draws to rng_uniform_kernel on [b,d] / [b,1] tensors followed by real_prep / interpolate / concat.  d % 4 == 0.
+__global__ void critic_prep_kernel(const int32_t* __restrict__ xi, const float* __restrict__ fake, long long n4, int d, uint64_t seed,
+                                   uint32_t sid_deq, uint32_t sid_alpha, const uint64_t* __restrict__ ctr, float lo, float hi, float denom,
+                                   float* __restrict__ rf, float* __restrict__ interp) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4) return;
+    const long long i = q * 4;
+    const int row = (int)(i / d);
+    uint32_t c[4], ca[4];
+    draw4(seed, sid_deq, step, (uint32_t)q, c);
+    draw4(seed, sid_alpha, step, (uint32_t)(row >> 2), ca);
+    const float alpha = 0.f + (1.f - 0.f) * u01(ca[row & 3]);
+    const int4 xv = *reinterpret_cast<const int4*>(xi + i);
+    const float4 fv = *reinterpret_cast<const float4*>(fake + i);
+    float4 r, o;
+    r.x = 2.f * (((float)xv.x / denom) - .5f); r.x += lo + (hi - lo) * u01(c[0]);
+    r.y = 2.f * (((float)xv.y / denom) - .5f); r.y += lo + (hi - lo) * u01(c[1]);
+    r.z = 2.f * (((float)xv.z / denom) - .5f); r.z += lo + (hi - lo) * u01(c[2]);
+    r.w = 2.f * (((float)xv.w / denom) - .5f); r.w += lo + (hi - lo) * u01(c[3]);
+    o.x = r.x + alpha * (fv.x - r.x); o.y = r.y + alpha * (fv.y - r.y);
+    o.z = r.z + alpha * (fv.z - r.z); o.w = r.w + alpha * (fv.w - r.w);
+    *reinterpret_cast<float4*>(rf + i) = r;
+    *reinterpret_cast<float4*>(rf + n4 * 4 + i) = fv;
+    *reinterpret_cast<float4*>(interp + i) = o;
+}
+
+// ---- [x ; x[0:n_extra]] with tf.nn.dropout on the result, one launch (the input of the critic tail for the two dropout passes,
+// pass 2 on the real half only, :226-227,288-291): dst row r < n_src reads src row r, row n_src + r' reads src row r'.
+// Dropout draws = element index of dst in stream sid (as dropout_rng_kernel on the concatenated tensor); keep >= 1: plain concat.
+__global__ void rows_cat_dropout_kernel(const float* __restrict__ src, long long row4, long long n4_src, long long n4_dst, float keep,
+                                        float inv, uint64_t seed, uint32_t sid, const uint64_t* __restrict__ ctr, float* __restrict__ dst) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4_dst) return;
+    const long long sq = q < n4_src ? q : q - n4_src;
+    float4 v = *reinterpret_cast<const float4*>(src + sq * 4);
+    if (keep < 1.f) {
+        uint32_t c[4];
+        draw4(seed, sid, step, (uint32_t)q, c);
+        v.x = v.x * inv * floorf(keep + u01(c[0])); v.y = v.y * inv * floorf(keep + u01(c[1]));
+        v.z = v.z * inv * floorf(keep + u01(c[2])); v.w = v.w * inv * floorf(keep + u01(c[3]));
+    }
+    *reinterpret_cast<float4*>(dst + q * 4) = v;
+    (void)row4;
+}
+// adjoint of the concat: gsrc[r] = g[r] + (r < n_extra ? g[n_src + r] : 0)
+__global__ void rows_cat_bwd_kernel(const float* __restrict__ g, long long n4_src, long long n4_extra, float* __restrict__ gsrc) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4_src) return;
+    float4 v = *reinterpret_cast<const float4*>(g + q * 4);
+    if (q < n4_extra) {
+        const float4 w = *reinterpret_cast<const float4*>(g + (n4_src + q) * 4);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    *reinterpret_cast<float4*>(gsrc + q * 4) = v;
+}
+
 __global__ void rng_advance_kernel(uint64_t* ctr, uint64_t by) {
     if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += by;
 }
@@ -190,6 +252,35 @@ int ctgan_rng_labels(int32_t* out, int64_t n, int32_t nlab, uint64_t seed, uint6
     hipLaunchKernelGGL(rng_labels_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0,
                        static_cast<hipStream_t>(s), out, (long long)n, nlab, seed, (uint32_t)stream_id, ctr);
     return ctgan_check_launch("rng_labels");
+}
+int ctgan_critic_prep(const int32_t* x_int, const float* fake, int32_t b, int32_t d, uint64_t seed, uint64_t sid_deq, uint64_t sid_alpha,
+                      const uint64_t* ctr, float lo, float hi, float denom, float* rf, float* interp, ctgan_stream_t s) {
+    if (!x_int || !fake || !rf || !interp || b <= 0 || d <= 0 || (d & 3) ||
+        ((reinterpret_cast<uintptr_t>(x_int) | reinterpret_cast<uintptr_t>(fake) | reinterpret_cast<uintptr_t>(rf) | reinterpret_cast<uintptr_t>(interp)) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "critic_prep: bad argument");
+    const long long n4 = (long long)b * d / 4;
+    hipLaunchKernelGGL(critic_prep_kernel, dim3(ctgan_blocks(n4, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(s), x_int, fake, n4,
+                       d, seed, (uint32_t)sid_deq, (uint32_t)sid_alpha, ctr, lo, hi, denom, rf, interp);
+    return ctgan_check_launch("critic_prep");
+}
+int ctgan_rows_cat_dropout(const float* src, int64_t n_src, int64_t n_extra, int64_t row_elems, float keep, uint64_t seed,
+                           uint64_t stream_id, const uint64_t* ctr, float* dst, ctgan_stream_t s) {
+    if (!src || !dst || n_src <= 0 || n_extra < 0 || n_extra > n_src || row_elems <= 0 || (row_elems & 3) || !(keep > 0.f) ||
+        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) || (n_src + n_extra) * row_elems >= (1LL << 34))
+        return ctgan_fail(CTGAN_E_BADARG, "rows_cat_dropout: bad argument");
+    const long long n4_src = n_src * row_elems / 4, n4_dst = (n_src + n_extra) * row_elems / 4;
+    hipLaunchKernelGGL(rows_cat_dropout_kernel, dim3(ctgan_blocks(n4_dst, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(s), src,
+                       (long long)row_elems / 4, n4_src, n4_dst, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr, dst);
+    return ctgan_check_launch("rows_cat_dropout");
+}
+int ctgan_rows_cat_bwd(const float* g, int64_t n_src, int64_t n_extra, int64_t row_elems, float* gsrc, ctgan_stream_t s) {
+    if (!g || !gsrc || n_src <= 0 || n_extra < 0 || n_extra > n_src || row_elems <= 0 || (row_elems & 3) ||
+        ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gsrc)) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "rows_cat_bwd: bad argument");
+    const long long n4_src = n_src * row_elems / 4, n4_extra = n_extra * row_elems / 4;
+    hipLaunchKernelGGL(rows_cat_bwd_kernel, dim3(ctgan_blocks(n4_src, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(s), g, n4_src,
+                       n4_extra, gsrc);
+    return ctgan_check_launch("rows_cat_bwd");
 }
 int ctgan_rng_advance(uint64_t* ctr, uint64_t by, ctgan_stream_t s) {
     if (!ctr) return ctgan_fail(CTGAN_E_BADARG, "rng_advance: null");

@@ -729,6 +729,28 @@ class DropoutRngFn(Function):
         return DropoutRngFn.apply(gy, keep, seed, sid, ctr, strides), None, None, None, None, None, None
 
 
+class RowsCatDropFn(Function):
+    """dropout([x ; x[:n_extra]]) in one launch; the dropout's backward is applied by the consumer (conv dgrad epilogue,
+    `bwd_fused`), so the backward here is the concat's adjoint alone - one launch instead of slice + zero-fill + add."""
+
+    @staticmethod
+    def forward(ctx, x, n_extra, keep, seed, sid, ctr):
+        ctx.cfg = (x.shape[0], n_extra)
+        return K.rows_cat_dropout(x, n_extra, keep, seed, sid, ctr)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, n_extra = ctx.cfg
+        if not K.is_dense(g) or (g.dim() == 4 and not g.is_contiguous() and not g.permute(0, 2, 3, 1).is_contiguous()):
+            g = g.contiguous()
+        return K.rows_cat_bwd(g, n, n_extra), None, None, None, None, None
+
+
+def rows_cat_dropout(x, n_extra, spec):
+    """spec = drop_spec(...): (keep, seed, site, ctr).  The consumer must apply the mask in its backward (in_drop=spec)."""
+    return RowsCatDropFn.apply(x, int(n_extra), spec[0], spec[1], spec[2], spec[3])
+
+
 def drop_spec(rng, keep_prob):
     """(keep, seed, site, counter) of the next dropout call site of `rng`; None for keep_prob == 1."""
     if keep_prob == 1.0:

@@ -222,7 +222,7 @@ def _tail_fusable(kp1, kp2, kp3, u, rng):
             and max(kp1, kp2, kp3) < 1.0)
 
 
-def DiscriminatorTailBody(h, kp1, kp2, kp3, u=None, rng=None, mask_done=False):
+def DiscriminatorTailBody(h, kp1, kp2, kp3, u=None, rng=None, mask_done=False, cat_extra=0):
     """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu (:173-179).  mask_done (fused path only): the consumer
     of the result returns the gradient w.r.t. the last conv's result, relu/dropout mask included (F.critic_tail_heads,
     F.gp_head_grad)."""
@@ -231,12 +231,15 @@ def DiscriminatorTailBody(h, kp1, kp2, kp3, u=None, rng=None, mask_done=False):
         # dropout -> block 3 -> dropout -> block 4 -> dropout -> relu with the masks inside the conv kernels: forward in the
         # epilogue of the conv that produces the tensor, backward in the dgrad epilogue of the conv that consumed it
         s1, s2, s3 = F.drop_spec(rng, kp1), F.drop_spec(rng, kp2), F.drop_spec(rng, kp3)
-        out = F.dropout(h, kp1, spec=s1, bwd_fused=True)
+        if cat_extra:       # the tail's input is [h ; h[:cat_extra]] (pass 2 on the real half): concat + dropout in one launch
+            out = F.rows_cat_dropout(h, cat_extra, s1)
+        else:
+            out = F.dropout(h, kp1, spec=s1, bwd_fused=True)
         out = ResidualBlock('Discriminator.3', D, D, 3, out, resample=None, in_drop=s1,
                             out_epi={'out_drop': s2, 'out_drop_bwd_fused': True})
         return ResidualBlock('Discriminator.4', D, D, 3, out, resample=None, in_drop=s2,
                              out_epi={'out_drop': s3, 'out_relu': True, 'mask_done': mask_done})    # = relu(dropout(.)): both are >= 0 scalings
-    assert not mask_done
+    assert not mask_done and not cat_extra
 
     def drop(i, x, kp):
         if kp == 1.0:
@@ -307,6 +310,10 @@ RESID_UP_FUSION = _os.environ.get('CTGAN_RESID_UP', '1') != '0'
 HEAD_FUSION = _os.environ.get('CTGAN_HEAD_FUSION', '1') != '0'
 
 
+# A/B switch: dequantisation, interpolation and the [real ; fake] concat of a critic step in one launch
+PREP_FUSION = _os.environ.get('CTGAN_PREP_FUSION', '1') != '0'
+
+
 # Draw the fake batches of all N_CRITIC critic steps of an iteration in one generator forward (Trainer.generate_fakes)
 BATCH_FAKES = _os.environ.get('CTGAN_BATCH_FAKES', '1') != '0'
 
@@ -369,11 +376,16 @@ class Trainer:
             if fake is None:      # `fake`: samples drawn earlier from the SAME generator weights (generate_fakes)
                 z = torch.cat(rnd['z'], 0) if rnd is not None else None
                 fake = Generator(B, labels, noise=z, groups=2, rng=rng)
-            deq = rnd['dequant'] if rnd is not None else rng.uniform(B, cfg.OUTPUT_DIM, lo=0.0, hi=1. / 128)
-            real = K.real_prep(real_int, deq, 256.0)
-            alpha = rnd['alpha'] if rnd is not None else rng.uniform(B, 1)
-            interp = K.interpolate(real, fake, alpha)
-            rf = _cat_rows(real, fake)
+            if PREP_FUSION and rnd is None and cfg.OUTPUT_DIM % 4 == 0 and real_int.is_contiguous() and fake.is_contiguous():
+                # dequantised reals, x_hat and the [real ; fake] batch in one launch (same Philox call sites as below)
+                rf, interp = K.critic_prep(real_int, fake, rng.seed, rng._sid(), rng._sid(), rng.ctr, 0.0, 1. / 128, 256.0)
+                real = rf[:B]
+            else:
+                deq = rnd['dequant'] if rnd is not None else rng.uniform(B, cfg.OUTPUT_DIM, lo=0.0, hi=1. / 128)
+                real = K.real_prep(real_int, deq, 256.0)
+                alpha = rnd['alpha'] if rnd is not None else rng.uniform(B, 1)
+                interp = K.interpolate(real, fake, alpha)
+                rf = _cat_rows(real, fake)
 
         # gradient penalty :277-286, issued FIRST and on a side stream: it is independent of the two dropout
         # passes until the losses are summed, so the GPU overlaps its small launches (n=64 rows) with the main
@@ -395,19 +407,19 @@ class Trainer:
             u = [_cat_rows(a, b[:B]) for a, b in zip(rnd['u_pass1'], rnd['u_pass2'])]
         else:
             u = None
-        tail_in = _cat_rows(h, h[:B])
         out = {}
         use_ac = cfg.CONDITIONAL and cfg.ACGAN
         if fuse_heads:
             # mean + both Linear heads + every loss head: two launches forward, one backward (gradient w.r.t. the last conv's
             # result and the head weights)
-            y = DiscriminatorTailBody(tail_in, 0.8, 0.5, 0.5, rng=rng, mask_done=True)
+            y = DiscriminatorTailBody(h, 0.8, 0.5, 0.5, rng=rng, mask_done=True, cat_extra=B)
             P = lib.param
             cost, wgan, ct, acgan, disc_wgan, d_all = F.critic_tail_heads(
                 y, P('Discriminator.Output.W'), P('Discriminator.Output.b'),
                 P('Discriminator.ACGANOutput.W') if use_ac else None, P('Discriminator.ACGANOutput.b') if use_ac else None,
                 labels, B, cfg.LAMBDA_2, cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, gp if side is None else None)
         else:
+            tail_in = _cat_rows(h, h[:B])
             d_all, f_all, a_all = DiscriminatorTail(tail_in, 0.8, 0.5, 0.5, u=u, rng=rng)
             # every loss head of the two dropout passes in one kernel (fwd) / one kernel (bwd): wgan :244, CT :288-291, ACGAN :246-248
             cost, wgan, ct, acgan, disc_wgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2,

@@ -943,6 +943,51 @@ def rng_labels(out, nlab, seed, stream_id, ctr):
     return out
 
 
+def critic_prep(x_int, fake, seed, sid_deq, sid_alpha, ctr, lo, hi, denom):
+    """-> (rf [2B,d] = [real ; fake], interp [B,d]) in one launch: dequantised reals, x_hat and the batch of the two dropout
+    passes; the draws are those of rng_uniform on [B,d] (stream sid_deq) and [B,1] (stream sid_alpha)."""
+    _need_dev(x_int, fake)
+    B, d = x_int.shape
+    assert x_int.dtype == torch.int32 and x_int.is_contiguous() and fake.is_contiguous() and tuple(fake.shape) == (B, d)
+    assert ctr.is_cuda and ctr.dtype == torch.int64
+    rf = torch.empty(2 * B, d, dtype=torch.float32, device=x_int.device)
+    interp = torch.empty(B, d, dtype=torch.float32, device=x_int.device)
+    check(lib.ctgan_critic_prep(_ptr(x_int), _ptr(fake), B, d, seed, sid_deq, sid_alpha, _ptr(ctr), lo, hi, denom, _ptr(rf), _ptr(interp),
+                                _stream()), 'critic_prep')
+    return rf, interp
+
+
+def rows_cat_dropout(x, n_extra, keep, seed, stream_id, ctr):
+    """dropout([x ; x[:n_extra]], keep) along dim 0 in one launch (x dense, rows contiguous); keep = 1: plain concat."""
+    _need_dev(x)
+    assert is_dense(x) and ctr.is_cuda and ctr.dtype == torch.int64
+    n = x.shape[0]
+    row = x.numel() // n
+    if x.dim() == 4 and not x.is_contiguous():
+        out = empty_cl(n + n_extra, x.shape[1], x.shape[2], x.shape[3], x.device)
+        assert x.permute(0, 2, 3, 1).is_contiguous()
+    else:
+        assert x.is_contiguous()
+        out = torch.empty((n + n_extra,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    check(lib.ctgan_rows_cat_dropout(_ptr(x), n, n_extra, row, keep, seed, stream_id, _ptr(ctr), _ptr(out), _stream()), 'rows_cat_dropout')
+    return out
+
+
+def rows_cat_bwd(g, n_src, n_extra):
+    """adjoint of [x ; x[:n_extra]]: g[:n_src] with g[n_src:] added onto its first n_extra rows."""
+    _need_dev(g)
+    assert is_dense(g) and g.shape[0] == n_src + n_extra
+    row = g.numel() // g.shape[0]
+    if g.dim() == 4 and not g.is_contiguous():
+        assert g.permute(0, 2, 3, 1).is_contiguous()
+        out = empty_cl(n_src, g.shape[1], g.shape[2], g.shape[3], g.device)
+    else:
+        assert g.is_contiguous()
+        out = torch.empty((n_src,) + tuple(g.shape[1:]), dtype=torch.float32, device=g.device)
+    check(lib.ctgan_rows_cat_bwd(_ptr(g), n_src, n_extra, row, _ptr(out), _stream()), 'rows_cat_bwd')
+    return out
+
+
 def rng_advance(ctr, by=1):
     assert ctr.is_cuda and ctr.dtype == torch.int64
     check(lib.ctgan_rng_advance(_ptr(ctr), by, _stream()), 'rng_advance')

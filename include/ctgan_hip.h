@@ -365,6 +365,20 @@ int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, c
 int ctgan_rng_labels(int32_t* out, int64_t n, int32_t nlab, uint64_t seed, uint64_t stream_id,
                      const uint64_t* ctr, ctgan_stream_t stream);
 int ctgan_rng_advance(uint64_t* ctr, uint64_t by, ctgan_stream_t stream);
+/* Critic-step input preparation in one launch (TF/CT_gan_cifar_resnet.py:201-202,226,277-283): rf [2b,d] = [real ; fake]
+ * with real = 2*(x_int/denom - .5) + U[lo,hi) (stream sid_deq, element i), interp [b,d] = real + alpha*(fake - real) with
+ * alpha[row] = U[0,1) (stream sid_alpha, element row) - the same draws as ctgan_rng_uniform on [b,d] and [b,1] tensors
+ * followed by ctgan_real_prep, ctgan_interpolate and a concat.  d % 4 == 0.                                              */
+int ctgan_critic_prep(const int32_t* x_int, const float* fake, int32_t b, int32_t d, uint64_t seed, uint64_t sid_deq,
+                      uint64_t sid_alpha, const uint64_t* ctr, float lo, float hi, float denom, float* rf, float* interp,
+                      ctgan_stream_t stream);
+/* dst [n_src + n_extra rows] = tf.nn.dropout([src ; src[0:n_extra]], keep) in one launch (input of the critic tail for the
+ * two dropout passes, pass 2 on the real half only, :226-227); draws as ctgan_dropout_rng on the concatenated tensor;
+ * keep = 1: plain concat.  rows_cat_bwd: the concat's adjoint gsrc[r] = g[r] + g[n_src + r] (r < n_extra).                */
+int ctgan_rows_cat_dropout(const float* src, int64_t n_src, int64_t n_extra, int64_t row_elems, float keep, uint64_t seed,
+                           uint64_t stream_id, const uint64_t* ctr, float* dst, ctgan_stream_t stream);
+int ctgan_rows_cat_bwd(const float* g, int64_t n_src, int64_t n_extra, int64_t row_elems, float* gsrc, ctgan_stream_t stream);
+
 
 #ifdef __cplusplus
 }

@@ -599,5 +599,29 @@ def rng_labels(out, nlab, seed, stream_id, ctr):
 
 
 @_export
+def critic_prep(x_int, fake, seed, sid_deq, sid_alpha, ctr, lo, hi, denom):
+    B, d = x_int.shape
+    deq = rng_uniform(torch.empty(B, d), seed, sid_deq, ctr, lo, hi)
+    real = real_prep(x_int, deq, denom)
+    alpha = rng_uniform(torch.empty(B, 1), seed, sid_alpha, ctr)
+    return torch.cat([real, fake], 0), interpolate(real, fake, alpha)
+
+
+@_export
+def rows_cat_dropout(x, n_extra, keep, seed, stream_id, ctr):
+    y = torch.cat([x, x[:n_extra]], 0)
+    if x.dim() == 4:
+        y = y.contiguous(memory_format=torch.channels_last)
+    return dropout_rng(y, keep, seed, stream_id, ctr) if keep < 1.0 else y
+
+
+@_export
+def rows_cat_bwd(g, n_src, n_extra):
+    out = g[:n_src].clone()
+    out[:n_extra] += g[n_src:]
+    return out
+
+
+@_export
 def rng_advance(ctr, by=1):
     ctr += by

@@ -660,6 +660,31 @@ def test_fused_critic_heads(K, with_a):
     assert abs(acc[1].item() - (am[B:] == lab.long()).float().mean().item()) < 1e-6
 
 
+def test_critic_prep_and_rows_cat_dropout_equal_their_compositions(K):
+    """ctgan_critic_prep = rng_uniform + real_prep + rng_uniform + interpolate + concat; ctgan_rows_cat_dropout = concat +
+    dropout_rng; ctgan_rows_cat_bwd = the concat's adjoint - all on the same Philox streams."""
+    g = torch.Generator().manual_seed(12)
+    B, d = 7, 3072
+    xi = dev(torch.randint(0, 256, (B, d), generator=g, dtype=torch.int32)); fake = dev(torch.rand(B, d, generator=g) * 2 - 1)
+    ctr = torch.full((1,), 9, dtype=torch.int64, device='cuda')
+    rf, interp = K.critic_prep(xi, fake, 2024, 5, 6, ctr, 0.0, 1. / 128, 256.0)
+    deq = K.rng_uniform(torch.empty(B, d, device='cuda'), 2024, 5, ctr, 0.0, 1. / 128)
+    real = K.real_prep(xi, deq, 256.0)
+    alpha = K.rng_uniform(torch.empty(B, 1, device='cuda'), 2024, 6, ctr)
+    assert relerr(rf[:B], real) < 1e-7 and torch.equal(rf[B:], fake)
+    assert relerr(interp, K.interpolate(real, fake, alpha)) < 1e-6
+    h = cl(torch.randn(10, 128, 8, 8, generator=g))
+    for keep in (0.8, 1.0):
+        y = K.rows_cat_dropout(h, 4, keep, 77, 3, ctr)
+        cat = K.to_channels_last(torch.cat([h, h[:4]], 0))
+        ref = K.dropout_rng(cat, keep, 77, 3, ctr) if keep < 1 else cat
+        assert y.shape == ref.shape and torch.equal(y, ref)
+    gy = cl(torch.randn(14, 128, 8, 8, generator=g))
+    gh = K.rows_cat_bwd(gy, 10, 4)
+    ref = gy[:10].clone(); ref[:4] += gy[10:]
+    assert torch.equal(gh, ref)
+
+
 @pytest.mark.parametrize('B,nf,H,with_a', [(16, 128, 8, True), (5, 32, 4, True), (7, 64, 8, False), (3, 256, 2, True)])
 def test_fused_critic_tail_heads(K, B, nf, H, with_a):
     """F.critic_tail_heads (reduce_mean + both Linear heads + loss heads, TF/CT_gan_cifar_resnet.py:179-186,244-248,288-291)
