@@ -158,6 +158,52 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     return gw, gb
 
 
+# ---- forward tape: one set of forward launches for several row ranges of a batch ---------------------------------
+# The samples of a critic batch are independent (no normalisation across the batch), so passes over different inputs that
+# use the same weights - the dropout passes on [real ; fake] and the gradient-penalty pass on x_hat - can share their
+# forward launches: run the layer sequence ONCE on the concatenated rows under `tape_record()`, then build each pass's own
+# autograd graph by running the same layer sequence under `tape_replay(tape, r0, r1)`: every conv / pool forward then
+# returns rows [r0, r1) of the recorded result instead of launching.  The backward passes stay separate (they have
+# different needs: weight gradients only vs. a differentiable data gradient).
+_TAPE = {'mode': None, 'items': None, 'pos': 0, 'rows': None}
+
+
+def _taped(launch):
+    mode = _TAPE['mode']
+    if mode is None:
+        return launch()
+    if mode == 'record':
+        y = launch()
+        _TAPE['items'].append(y)
+        return y
+    y = _TAPE['items'][_TAPE['pos']]
+    _TAPE['pos'] += 1
+    r0, r1 = _TAPE['rows']
+    return y[r0:r1]
+
+
+@contextlib.contextmanager
+def tape_record():
+    assert _TAPE['mode'] is None
+    items = []
+    _TAPE.update(mode='record', items=items, pos=0, rows=None)
+    try:
+        yield items
+    finally:
+        _TAPE.update(mode=None, items=None)
+
+
+@contextlib.contextmanager
+def tape_replay(items, r0, r1):
+    assert _TAPE['mode'] is None
+    _TAPE.update(mode='replay', items=items, pos=0, rows=(int(r0), int(r1)))
+    try:
+        yield
+        assert _TAPE['pos'] == len(items), 'replayed layer sequence differs from the recorded one'
+    finally:
+        _TAPE.update(mode=None, items=None)
+
+
 # --------------------------------------------------------------------------------- conv family
 class ConvFn(Function):
     """y = conv(x, w) [+ b] [+ resid]; relu_in: y = conv(relu(x), w) ... without materialising relu(x)
@@ -183,8 +229,8 @@ class ConvFn(Function):
         ctx.fork = bool(fork)
         if fork:
             ctx.set_materialize_grads(False)       # an unused shortcut branch must not cost a zero-filled add
-        y = K.conv_fwd(x, w, b, g, resid=resid, relu=ctx.out_relu, out_strides=out_strides, relu_in=relu_in, drop=ctx.out_drop,
-                       resid_up=ctx.resid_up)
+        y = _taped(lambda: K.conv_fwd(x, w, b, g, resid=resid, relu=ctx.out_relu, out_strides=out_strides, relu_in=relu_in,
+                                      drop=ctx.out_drop, resid_up=ctx.resid_up))
         if ctx.out_relu:
             ctx.save_for_backward(x, w, y)         # y > 0  <=>  pre-activation > 0 and the element survived the dropout
         else:
@@ -777,7 +823,7 @@ class Pool2Fn(Function):
     @staticmethod
     def forward(ctx, x, scale):
         ctx.scale = scale
-        return K.pool2(x, scale)
+        return _taped(lambda: K.pool2(x, scale))
 
     @staticmethod
     def backward(ctx, gy):

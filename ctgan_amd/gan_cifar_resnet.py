@@ -310,6 +310,9 @@ RESID_UP_FUSION = _os.environ.get('CTGAN_RESID_UP', '1') != '0'
 HEAD_FUSION = _os.environ.get('CTGAN_HEAD_FUSION', '1') != '0'
 
 
+# A/B switch: blocks 1-2 of the critic run once on [real ; fake ; x_hat]; the dropout passes and the gradient-penalty pass
+# build their autograd graphs on row ranges of that one forward (functional.tape_record / tape_replay)
+TRUNK_SHARE = _os.environ.get('CTGAN_TRUNK_SHARE', '1') != '0'
 # A/B switch: dequantisation, interpolation and the [real ; fake] concat of a critic step in one launch
 PREP_FUSION = _os.environ.get('CTGAN_PREP_FUSION', '1') != '0'
 
@@ -323,13 +326,18 @@ def _heads_fusable(rnd, rng):
             and cfg.DIM_D % 4 == 0 and cfg.DIM_D <= 1024)
 
 
-def gradient_penalty_branch(interp, labels, rng, rnd=None):
+def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None):
     """GP = lambda * mean((||dD(x_hat)/dx_hat||_2 - 1)^2) with its own dropout masks (:277-286): critic forward on x_hat,
     data gradient back to x_hat under create_graph.  -> (gp, slopes, dD/dx_hat).  interp must require grad."""
     fuse_heads = _heads_fusable(rnd, rng)
     with F.weight_grads(not _critic_piecewise_linear()):
         if fuse_heads:
-            y_gp = DiscriminatorTailBody(DiscriminatorTrunk(interp), 0.8, 0.5, 0.5, rng=rng, mask_done=True)
+            if trunk_tape is not None:       # the trunk's forward launches were shared with the dropout passes (F.tape_record)
+                with F.tape_replay(*trunk_tape):
+                    h_gp = DiscriminatorTrunk(interp)
+            else:
+                h_gp = DiscriminatorTrunk(interp)
+            y_gp = DiscriminatorTailBody(h_gp, 0.8, 0.5, 0.5, rng=rng, mask_done=True)
         else:
             u_gp = rnd['u_gp'] if rnd is not None else None
             d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng, heads=('wgan',))[0]
@@ -372,14 +380,19 @@ class Trainer:
         oracle/steps.make_rnd_resnet_d for the keys and shapes."""
         B = cfg.BATCH_SIZE
         rng = self.rng
+        tape = None
         with torch.no_grad():
             if fake is None:      # `fake`: samples drawn earlier from the SAME generator weights (generate_fakes)
                 z = torch.cat(rnd['z'], 0) if rnd is not None else None
                 fake = Generator(B, labels, noise=z, groups=2, rng=rng)
             if PREP_FUSION and rnd is None and cfg.OUTPUT_DIM % 4 == 0 and real_int.is_contiguous() and fake.is_contiguous():
                 # dequantised reals, x_hat and the [real ; fake] batch in one launch (same Philox call sites as below)
-                rf, interp = K.critic_prep(real_int, fake, rng.seed, rng._sid(), rng._sid(), rng.ctr, 0.0, 1. / 128, 256.0)
+                rf, interp, both = K.critic_prep(real_int, fake, rng.seed, rng._sid(), rng._sid(), rng.ctr, 0.0, 1. / 128, 256.0)
                 real = rf[:B]
+                if TRUNK_SHARE and not cfg.NORMALIZATION_D and _heads_fusable(rnd, rng):
+                    # blocks 1-2 once for [real ; fake ; x_hat]: the two passes below replay rows of it (F.tape_record)
+                    with F.tape_record() as tape:
+                        DiscriminatorTrunk(both)
             else:
                 deq = rnd['dequant'] if rnd is not None else rng.uniform(B, cfg.OUTPUT_DIM, lo=0.0, hi=1. / 128)
                 real = K.real_prep(real_int, deq, 256.0)
@@ -399,10 +412,14 @@ class Trainer:
             side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side) if side is not None else _nullctx():
             fuse_heads = _heads_fusable(rnd, rng)
-            gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd)
+            gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None)
 
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
-        h = DiscriminatorTrunk(rf)
+        if tape is not None:
+            with F.tape_replay(tape, 0, 2 * B):
+                h = DiscriminatorTrunk(rf)
+        else:
+            h = DiscriminatorTrunk(rf)
         if rnd is not None:
             u = [_cat_rows(a, b[:B]) for a, b in zip(rnd['u_pass1'], rnd['u_pass2'])]
         else:

@@ -944,17 +944,18 @@ def rng_labels(out, nlab, seed, stream_id, ctr):
 
 
 def critic_prep(x_int, fake, seed, sid_deq, sid_alpha, ctr, lo, hi, denom):
-    """-> (rf [2B,d] = [real ; fake], interp [B,d]) in one launch: dequantised reals, x_hat and the batch of the two dropout
-    passes; the draws are those of rng_uniform on [B,d] (stream sid_deq) and [B,1] (stream sid_alpha)."""
+    """-> (rf [2B,d] = [real ; fake], interp [B,d], both) in one launch: dequantised reals, x_hat and the batch of the two dropout
+    passes, and `both` [3B,d] = the buffer they are adjacent views of; the draws are those of rng_uniform on [B,d] (stream sid_deq) and
+    [B,1] (stream sid_alpha)."""
     _need_dev(x_int, fake)
     B, d = x_int.shape
     assert x_int.dtype == torch.int32 and x_int.is_contiguous() and fake.is_contiguous() and tuple(fake.shape) == (B, d)
     assert ctr.is_cuda and ctr.dtype == torch.int64
-    rf = torch.empty(2 * B, d, dtype=torch.float32, device=x_int.device)
-    interp = torch.empty(B, d, dtype=torch.float32, device=x_int.device)
+    both = torch.empty(3 * B, d, dtype=torch.float32, device=x_int.device)      # one buffer: [real ; fake ; x_hat] is also a batch
+    rf, interp = both[:2 * B], both[2 * B:]
     check(lib.ctgan_critic_prep(_ptr(x_int), _ptr(fake), B, d, seed, sid_deq, sid_alpha, _ptr(ctr), lo, hi, denom, _ptr(rf), _ptr(interp),
                                 _stream()), 'critic_prep')
-    return rf, interp
+    return rf, interp, both
 
 
 def rows_cat_dropout(x, n_extra, keep, seed, stream_id, ctr):

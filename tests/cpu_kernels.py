@@ -604,7 +604,8 @@ def critic_prep(x_int, fake, seed, sid_deq, sid_alpha, ctr, lo, hi, denom):
     deq = rng_uniform(torch.empty(B, d), seed, sid_deq, ctr, lo, hi)
     real = real_prep(x_int, deq, denom)
     alpha = rng_uniform(torch.empty(B, 1), seed, sid_alpha, ctr)
-    return torch.cat([real, fake], 0), interpolate(real, fake, alpha)
+    both = torch.cat([real, fake, interpolate(real, fake, alpha)], 0)
+    return both[:2 * B], both[2 * B:], both
 
 
 @_export

@@ -667,7 +667,8 @@ def test_critic_prep_and_rows_cat_dropout_equal_their_compositions(K):
     B, d = 7, 3072
     xi = dev(torch.randint(0, 256, (B, d), generator=g, dtype=torch.int32)); fake = dev(torch.rand(B, d, generator=g) * 2 - 1)
     ctr = torch.full((1,), 9, dtype=torch.int64, device='cuda')
-    rf, interp = K.critic_prep(xi, fake, 2024, 5, 6, ctr, 0.0, 1. / 128, 256.0)
+    rf, interp, both = K.critic_prep(xi, fake, 2024, 5, 6, ctr, 0.0, 1. / 128, 256.0)
+    assert both.shape == (3 * B, d) and both.data_ptr() == rf.data_ptr()
     deq = K.rng_uniform(torch.empty(B, d, device='cuda'), 2024, 5, ctr, 0.0, 1. / 128)
     real = K.real_prep(xi, deq, 256.0)
     alpha = K.rng_uniform(torch.empty(B, 1, device='cuda'), 2024, 6, ctr)
