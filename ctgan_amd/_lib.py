@@ -43,10 +43,16 @@ class WgradGroup(ctypes.Structure):
                 ('xs', ctypes.c_void_p * 3), ('dys', ctypes.c_void_p * 3), ('dw', ctypes.c_void_p), ('db', ctypes.c_void_p)]
 
 
+class RowSegment(ctypes.Structure):
+    """struct ctgan_row_segment (include/ctgan_hip.h)."""
+    _fields_ = [('src_row0', c_int64), ('rows', c_int64), ('keep', ctypes.c_float), ('stream_id', ctypes.c_uint64), ('index_row0', c_int64)]
+
+
 class EpilogueExt(ctypes.Structure):
     """struct ctgan_epilogue_ext (include/ctgan_hip.h)."""
     _fields_ = [('drop_keep', ctypes.c_float), ('drop_seed', ctypes.c_uint64), ('drop_stream_id', ctypes.c_uint64),
-                ('drop_ctr', ctypes.c_void_p)]
+                ('drop_ctr', ctypes.c_void_p), ('n_ranges', c_int32), ('range_end', c_int32 * 3), ('range_keep', ctypes.c_float * 3),
+                ('range_stream_id', ctypes.c_uint64 * 3)]
 
 
 I64x4 = c_int64 * 4
@@ -134,6 +140,7 @@ SIGNATURES = {
     'ctgan_critic_prep': (c_int, [_p, _p, c_int32, c_int32, c_uint64, c_uint64, c_uint64, _p, c_float, c_float, c_float, _p, _p, _p]),
     'ctgan_rows_cat_dropout': (c_int, [_p, c_int64, c_int64, c_int64, c_float, c_uint64, c_uint64, _p, _p, _p]),
     'ctgan_rows_cat_bwd': (c_int, [_p, c_int64, c_int64, c_int64, _p, _p]),
+    'ctgan_rows_gather_dropout': (c_int, [_p, POINTER(RowSegment), c_int32, c_int64, c_uint64, _p, _p, _p]),
 }
 
 

@@ -70,6 +70,11 @@ struct FwdParams {
     // applied to y would compute.  Used for the dropout that follows a conv (forward) and for the mask a data
     // gradient has to be multiplied with (backward).
     int drop; float drop_keep; unsigned long long drop_seed; unsigned drop_sid; const unsigned long long* drop_ctr;
+    // row ranges with their own dropout (forward launches shared by several passes, functional.tape_record): rows
+    // m < drop_mend[0] use range 0, ... ; keep >= 1 = no dropout in that range; the Philox element index is relative to the
+    // range's first element (drop_roff), i.e. what a dropout on the range's own tensor would draw.  drop_nr = 0: one spec.
+    int drop_nr; int drop_mend[CTGAN_DROP_RANGES]; float drop_rkeep[CTGAN_DROP_RANGES]; unsigned drop_rsid[CTGAN_DROP_RANGES];
+    long long drop_roff[CTGAN_DROP_RANGES];
     int phases, ph_tiles_m;
     int ph_pad_t[2], ph_pad_l[2];              // top pad of row parity a / left pad of column parity b
     long long ph_b_stride;                     // filter elements per phase
@@ -375,8 +380,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
 //   * WAVES_K > 1 splits each slice between wave groups (for small M: more waves than output
 //     tiles), partial accumulators are combined through LDS at the end;
 //   * XCD-aware tile order: consecutive M tiles (which share halo rows) land on the same XCD / L2.
+// occupancy the register allocator must keep (waves per SIMD): the 64x128 tile (2 accumulators per wave) sits at the edge of
+// 3 - a few VGPRs more in the epilogue cost a whole wave (measured: -2 % on the step).  Only the 4-phase variant needs the
+// hint; with it the allocator moves the accumulators out of the AGPRs, which costs the plain variant 4 %.
+constexpr int fwd_pipe_min_waves(int waves_k, int tm, int tn, int ksub) { return 1; }
 template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN, int RD, bool RELU_IN, int KSUB>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pipe_kernel(const FwdParams p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, fwd_pipe_min_waves(WAVES_K, TM, TN, KSUB)) void igemm_fwd_pipe_kernel(const FwdParams p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32, BKE = 32 * WAVES_K * KSUB, LDAE = BKE + 4;   // KSUB 32-deep slices per wave per stage
     constexpr int STAGE = BM * LDAE + BKE * BN;
@@ -603,6 +612,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
         const int c4 = tid % C4, r0 = tid / C4;
         const int col = n0 + c4 * 4;
         const uint64_t drop_step = p.drop ? (p.drop_ctr ? p.drop_ctr[0] : 0) : 0;
+        // dropout row ranges start at multiples of the largest M tile (checked by the host), so the range is workgroup-uniform
+        float dkeep = p.drop_keep;
+        unsigned dsid = p.drop_sid;
+        unsigned doff4 = 0;                                  // first float4 index of the range (the counter is 32 bits wide anyway)
+        if (p.drop_nr) {                                     // scalar selects, no dynamic indexing of the argument arrays
+            const bool r1 = p.drop_nr > 1 && m0 >= p.drop_mend[0], r2 = p.drop_nr > 2 && m0 >= p.drop_mend[1];
+            dkeep = r2 ? p.drop_rkeep[2] : (r1 ? p.drop_rkeep[1] : p.drop_rkeep[0]);
+            dsid = r2 ? p.drop_rsid[2] : (r1 ? p.drop_rsid[1] : p.drop_rsid[0]);
+            doff4 = (unsigned)((r2 ? p.drop_roff[2] : (r1 ? p.drop_roff[1] : p.drop_roff[0])) >> 2);
+        }
+        const bool do_drop = p.drop && dkeep < 1.f;
         if (col < p.Ng) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
@@ -644,12 +664,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void igemm_fwd_pi
                     }
                     if (p.resid) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
                     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (p.drop) {
+                    if (do_drop) {
                         uint32_t c[4];
-                        ctgan_philox::draw4(p.drop_seed, p.drop_sid, drop_step, (uint32_t)(off[u] >> 2), c);
-                        const float inv = 1.f / p.drop_keep;
-                        v.x *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[0])); v.y *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[1]));
-                        v.z *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[2])); v.w *= inv * floorf(p.drop_keep + ctgan_philox::u01(c[3]));
+                        ctgan_philox::draw4(p.drop_seed, dsid, drop_step, (uint32_t)(off[u] >> 2) - doff4, c);
+                        const float inv = 1.f / dkeep;
+                        v.x *= inv * floorf(dkeep + ctgan_philox::u01(c[0])); v.y *= inv * floorf(dkeep + ctgan_philox::u01(c[1]));
+                        v.z *= inv * floorf(dkeep + ctgan_philox::u01(c[2])); v.w *= inv * floorf(dkeep + ctgan_philox::u01(c[3]));
                     }
                     *reinterpret_cast<float4*>(p.D + off[u]) = v;
                 }
@@ -1511,18 +1531,41 @@ int ctgan_conv2d_fwd(const ctgan_conv_desc* d, const float* x, const float* w, c
     return ctgan_conv2d_fwd_ex(d, x, w, bias, resid, y, flags, nullptr, stream);
 }
 
-static void set_drop(FwdParams& p, const ctgan_epilogue_ext* ext) {
-    p.drop = 0; p.drop_keep = 1.f; p.drop_seed = 0; p.drop_sid = 0; p.drop_ctr = nullptr;
-    if (ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f) {
-        p.drop = 1; p.drop_keep = ext->drop_keep; p.drop_seed = ext->drop_seed; p.drop_sid = (unsigned)ext->drop_stream_id;
-        p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
+static bool ext_wants_drop(const ctgan_epilogue_ext* ext) {
+    if (!ext) return false;
+    if (ext->n_ranges > 0) {
+        for (int i = 0; i < ext->n_ranges && i < CTGAN_DROP_RANGES; ++i)
+            if (ext->range_keep[i] > 0.f && ext->range_keep[i] < 1.f) return true;
+        return false;
+    }
+    return ext->drop_keep > 0.f && ext->drop_keep < 1.f;
+}
+// rows_per_sample = output pixels per sample (P*Q), sample_elems = elements of one sample of the (dense) output
+static void set_drop(FwdParams& p, const ctgan_epilogue_ext* ext, int rows_per_sample = 0, long long sample_elems = 0) {
+    p.drop = 0; p.drop_keep = 1.f; p.drop_seed = 0; p.drop_sid = 0; p.drop_ctr = nullptr; p.drop_nr = 0;
+    for (int i = 0; i < CTGAN_DROP_RANGES; ++i) { p.drop_mend[i] = 0x7fffffff; p.drop_rkeep[i] = 1.f; p.drop_rsid[i] = 0; p.drop_roff[i] = 0; }
+    if (!ext_wants_drop(ext)) return;
+    p.drop = 1; p.drop_seed = ext->drop_seed;
+    p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
+    if (ext->n_ranges > 0) {
+        p.drop_nr = ext->n_ranges < CTGAN_DROP_RANGES ? ext->n_ranges : CTGAN_DROP_RANGES;
+        long long start = 0;
+        for (int i = 0; i < p.drop_nr; ++i) {
+            p.drop_mend[i] = (int)(ext->range_end[i] * rows_per_sample);
+            p.drop_rkeep[i] = (ext->range_keep[i] > 0.f && ext->range_keep[i] < 1.f) ? ext->range_keep[i] : 1.f;
+            p.drop_rsid[i] = (unsigned)ext->range_stream_id[i];
+            p.drop_roff[i] = start * sample_elems;
+            start = ext->range_end[i];
+        }
+    } else {
+        p.drop_keep = ext->drop_keep; p.drop_sid = (unsigned)ext->drop_stream_id;
     }
 }
 
 int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                         float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_fwd");
-    const bool want_drop = ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f;
+    const bool want_drop = ext_wants_drop(ext);
     if (rc) return rc;
     if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
     if (ctgan_is_small_linear(d) && !resid && !(flags & CTGAN_IN_RELU) && !g_force_generic && !want_drop) {
@@ -1546,7 +1589,13 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
     p.phases = 1;
     p.resid_up = (resid && (flags & CTGAN_RESID_UP)) ? 1 : 0;
     if (p.resid_up && ((d->P | d->Q) & 1)) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: CTGAN_RESID_UP needs even P, Q");
-    set_drop(p, ext);
+    if (ext && ext->n_ranges > 0 && (ext->n_ranges > CTGAN_DROP_RANGES || d->ys[1] != 1 || d->ys[0] != (long long)d->P * d->Q * d->K))
+        return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: dropout row ranges need a dense channels-last result and <= %d ranges", CTGAN_DROP_RANGES);
+    if (ext && ext->n_ranges > 0)
+        for (int i = 0; i + 1 < ext->n_ranges; ++i)
+            if (((long long)ext->range_end[i] * d->P * d->Q) % 128)      // a range boundary inside an M tile: caller drops per range
+                return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_fwd: dropout row ranges must start at multiples of 128 output pixels");
+    set_drop(p, ext, d->P * d->Q, (long long)d->P * d->Q * d->K);
     return run_fwd(p, static_cast<hipStream_t>(stream));
 }
 
@@ -1572,7 +1621,7 @@ int ctgan_conv2d_dgrad_ex(const ctgan_conv_desc* d, const float* dy, const float
                           const float* resid, float* dx, void* ws, size_t ws_bytes, int flags, const ctgan_epilogue_ext* ext,
                           ctgan_stream_t stream) {
     int rc = check_desc(d, "conv2d_dgrad");
-    const bool want_drop = ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f;
+    const bool want_drop = ext_wants_drop(ext);
     if (rc) return rc;
     if (!dy || !w || !dx) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: null pointer");
     if (d->x_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: x_up (pool the result instead)");
@@ -1597,6 +1646,7 @@ int ctgan_conv2d_dgrad_ex(const ctgan_conv_desc* d, const float* dy, const float
     p.relu = 0;
     p.phases = 1;
     p.resid_up = 0;
+    if (ext && ext->n_ranges > 0) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: dropout row ranges are a forward-only option");
     set_drop(p, ext);
     const size_t need = dgrad_filter_elems(d) * sizeof(float);
     const bool pre = (flags & CTGAN_DGRAD_W_REPACKED) != 0;

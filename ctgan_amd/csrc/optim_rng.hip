@@ -170,6 +170,32 @@ __global__ void rows_cat_dropout_kernel(const float* __restrict__ src, long long
     *reinterpret_cast<float4*>(dst + q * 4) = v;
     (void)row4;
 }
+// General form: dst = concatenation of row segments of src, each with its own dropout (or none); the Philox element index
+// of a dst element is taken relative to dst row `index_row0` of its segment - so a group of segments can reproduce exactly the
+// dropout of "its own" concatenated tensor.  One launch builds the input of every critic tail of a step.
+struct RowSegs { int n; long long dst_end4[CTGAN_ROW_SEGMENTS]; long long src_off4[CTGAN_ROW_SEGMENTS]; long long idx_off4[CTGAN_ROW_SEGMENTS];
+                 float keep[CTGAN_ROW_SEGMENTS]; unsigned sid[CTGAN_ROW_SEGMENTS]; };
+__global__ void rows_gather_dropout_kernel(const float* __restrict__ src, const RowSegs t, long long n4_dst, uint64_t seed,
+                                           const uint64_t* __restrict__ ctr, float* __restrict__ dst) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4_dst) return;
+    int sg = 0;
+#pragma unroll
+    for (int i = 1; i < CTGAN_ROW_SEGMENTS; ++i)
+        if (i < t.n && q >= t.dst_end4[i - 1]) sg = i;
+    const long long dst0 = sg ? t.dst_end4[sg - 1] : 0;
+    float4 v = *reinterpret_cast<const float4*>(src + (t.src_off4[sg] + (q - dst0)) * 4);
+    const float keep = t.keep[sg];
+    if (keep < 1.f) {
+        uint32_t c[4];
+        draw4(seed, t.sid[sg], step, (uint32_t)(q - t.idx_off4[sg]), c);
+        const float inv = 1.f / keep;
+        v.x = v.x * inv * floorf(keep + u01(c[0])); v.y = v.y * inv * floorf(keep + u01(c[1]));
+        v.z = v.z * inv * floorf(keep + u01(c[2])); v.w = v.w * inv * floorf(keep + u01(c[3]));
+    }
+    *reinterpret_cast<float4*>(dst + q * 4) = v;
+}
 // adjoint of the concat: gsrc[r] = g[r] + (r < n_extra ? g[n_src + r] : 0)
 __global__ void rows_cat_bwd_kernel(const float* __restrict__ g, long long n4_src, long long n4_extra, float* __restrict__ gsrc) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,6 +298,34 @@ int ctgan_rows_cat_dropout(const float* src, int64_t n_src, int64_t n_extra, int
     hipLaunchKernelGGL(rows_cat_dropout_kernel, dim3(ctgan_blocks(n4_dst, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(s), src,
                        (long long)row_elems / 4, n4_src, n4_dst, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr, dst);
     return ctgan_check_launch("rows_cat_dropout");
+}
+int ctgan_rows_gather_dropout(const float* src, const ctgan_row_segment* segs, int32_t nseg, int64_t row_elems, uint64_t seed,
+                              const uint64_t* ctr, float* dst, ctgan_stream_t s) {
+    if (!src || !segs || !dst || nseg < 1 || nseg > CTGAN_ROW_SEGMENTS || row_elems <= 0 || (row_elems & 3) ||
+        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "rows_gather_dropout: bad argument");
+    RowSegs t;
+    t.n = nseg;
+    const long long r4 = row_elems / 4;
+    long long row = 0;
+    for (int i = 0; i < CTGAN_ROW_SEGMENTS; ++i) {
+        if (i < nseg) {
+            const ctgan_row_segment& g = segs[i];
+            if (g.rows <= 0 || g.src_row0 < 0 || g.index_row0 < 0 || g.index_row0 > row || !(g.keep > 0.f))
+                return ctgan_fail(CTGAN_E_BADARG, "rows_gather_dropout: bad segment %d", i);
+            t.src_off4[i] = g.src_row0 * r4; t.idx_off4[i] = g.index_row0 * r4;
+            t.keep[i] = g.keep < 1.f ? g.keep : 1.f; t.sid[i] = (unsigned)g.stream_id;
+            row += g.rows;
+        } else {
+            t.src_off4[i] = 0; t.idx_off4[i] = 0; t.keep[i] = 1.f; t.sid[i] = 0;
+        }
+        t.dst_end4[i] = row * r4;
+    }
+    const long long n4 = row * r4;
+    if (n4 * 4 >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "rows_gather_dropout: too large");
+    hipLaunchKernelGGL(rows_gather_dropout_kernel, dim3(ctgan_blocks(n4, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(s), src, t, n4,
+                       seed, ctr, dst);
+    return ctgan_check_launch("rows_gather_dropout");
 }
 int ctgan_rows_cat_bwd(const float* g, int64_t n_src, int64_t n_extra, int64_t row_elems, float* gsrc, ctgan_stream_t s) {
     if (!g || !gsrc || n_src <= 0 || n_extra < 0 || n_extra > n_src || row_elems <= 0 || (row_elems & 3) ||

@@ -765,7 +765,7 @@ class DropoutRngFn(Function):
             x = K.copy4d(x, torch.empty_strided(x.shape, strides, dtype=x.dtype, device=x.device))   # same physical order as the forward
         ctx.cfg = (keep, seed, sid, ctr, tuple(x.stride()))
         ctx.bwd_fused = bool(bwd_fused)       # the consumer's data gradient already carries this mask (conv dgrad epilogue)
-        return K.dropout_rng(x, keep, seed, sid, ctr)
+        return _taped(lambda: K.dropout_rng(x, keep, seed, sid, ctr))
 
     @staticmethod
     def backward(ctx, gy):
@@ -782,7 +782,7 @@ class RowsCatDropFn(Function):
     @staticmethod
     def forward(ctx, x, n_extra, keep, seed, sid, ctr):
         ctx.cfg = (x.shape[0], n_extra)
-        return K.rows_cat_dropout(x, n_extra, keep, seed, sid, ctr)
+        return _taped(lambda: K.rows_cat_dropout(x, n_extra, keep, seed, sid, ctr))
 
     @staticmethod
     def backward(ctx, g):

@@ -222,7 +222,7 @@ def _tail_fusable(kp1, kp2, kp3, u, rng):
             and max(kp1, kp2, kp3) < 1.0)
 
 
-def DiscriminatorTailBody(h, kp1, kp2, kp3, u=None, rng=None, mask_done=False, cat_extra=0):
+def DiscriminatorTailBody(h, kp1, kp2, kp3, u=None, rng=None, mask_done=False, cat_extra=0, specs=None):
     """dropout -> block 3 -> dropout -> block 4 -> dropout -> relu (:173-179).  mask_done (fused path only): the consumer
     of the result returns the gradient w.r.t. the last conv's result, relu/dropout mask included (F.critic_tail_heads,
     F.gp_head_grad)."""
@@ -230,7 +230,7 @@ def DiscriminatorTailBody(h, kp1, kp2, kp3, u=None, rng=None, mask_done=False, c
     if _tail_fusable(kp1, kp2, kp3, u, rng):
         # dropout -> block 3 -> dropout -> block 4 -> dropout -> relu with the masks inside the conv kernels: forward in the
         # epilogue of the conv that produces the tensor, backward in the dgrad epilogue of the conv that consumed it
-        s1, s2, s3 = F.drop_spec(rng, kp1), F.drop_spec(rng, kp2), F.drop_spec(rng, kp3)
+        s1, s2, s3 = specs if specs is not None else (F.drop_spec(rng, kp1), F.drop_spec(rng, kp2), F.drop_spec(rng, kp3))
         if cat_extra:       # the tail's input is [h ; h[:cat_extra]] (pass 2 on the real half): concat + dropout in one launch
             out = F.rows_cat_dropout(h, cat_extra, s1)
         else:
@@ -313,6 +313,9 @@ HEAD_FUSION = _os.environ.get('CTGAN_HEAD_FUSION', '1') != '0'
 # A/B switch: blocks 1-2 of the critic run once on [real ; fake ; x_hat]; the dropout passes and the gradient-penalty pass
 # build their autograd graphs on row ranges of that one forward (functional.tape_record / tape_replay)
 TRUNK_SHARE = _os.environ.get('CTGAN_TRUNK_SHARE', '1') != '0'
+# A/B switch: blocks 3-4 of every pass of a critic step (dropout passes, clean pass, GP pass) in one set of forward launches
+# with per-row-range dropout (shared_tail_forward); needs TRUNK_SHARE
+TAIL_SHARE = _os.environ.get('CTGAN_TAIL_SHARE', '1') != '0'
 # A/B switch: dequantisation, interpolation and the [real ; fake] concat of a critic step in one launch
 PREP_FUSION = _os.environ.get('CTGAN_PREP_FUSION', '1') != '0'
 
@@ -326,7 +329,39 @@ def _heads_fusable(rnd, rng):
             and cfg.DIM_D % 4 == 0 and cfg.DIM_D <= 1024)
 
 
-def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None):
+def shared_tail_forward(h_all, B, rng, with_clean):
+    """Blocks 3-4 of the critic for every pass of a critic step in ONE set of forward launches (F.tape_record): rows of the
+    result are [real, fake, real' (dropout passes, specs `main`) | real, fake (clean pass, no dropout) | x_hat (gradient-penalty
+    pass, specs `gp`)], h_all = the shared trunk output [real ; fake ; x_hat].  Each range's dropout masks are those of its own
+    tensor (ctgan_epilogue_ext row ranges), so the passes replay rows of this forward and keep their separate backward graphs.
+    -> (tape, gp_specs, main_specs, ranges = {'main': (r0, r1), 'clean': ..., 'gp': ...})"""
+    D = cfg.DIM_D
+    kps = (0.8, 0.5, 0.5)
+    gp_specs = tuple(F.drop_spec(rng, kp) for kp in kps)            # call-site order of the unshared step: GP pass first
+    main_specs = tuple(F.drop_spec(rng, kp) for kp in kps)
+    n_main, n_clean = 3 * B, (2 * B if with_clean else 0)
+    r_gp = n_main + n_clean
+    segs = [(0, 2 * B, kps[0], main_specs[0][2], 0), (0, B, kps[0], main_specs[0][2], 0)]
+    if with_clean:
+        segs.append((0, 2 * B, 1.0, 0, n_main))
+    segs.append((2 * B, B, kps[0], gp_specs[0][2], r_gp))
+
+    def ranged(i):
+        rs = [(n_main, main_specs[i])]
+        if with_clean:
+            rs.append((r_gp, None))
+        rs.append((r_gp + B, gp_specs[i]))
+        return {'ranges': rs}
+
+    with torch.no_grad(), F.tape_record() as tape:
+        tin = K.rows_gather_dropout(h_all, segs, rng.seed, rng.ctr)
+        tape.append(tin)
+        out = ResidualBlock('Discriminator.3', D, D, 3, tin, resample=None, out_epi={'out_drop': ranged(1)})
+        ResidualBlock('Discriminator.4', D, D, 3, out, resample=None, out_epi={'out_drop': ranged(2), 'out_relu': True})
+    return tape, gp_specs, main_specs, {'main': (0, n_main), 'clean': (n_main, r_gp), 'gp': (r_gp, r_gp + B)}
+
+
+def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None, tail_tape=None, specs=None):
     """GP = lambda * mean((||dD(x_hat)/dx_hat||_2 - 1)^2) with its own dropout masks (:277-286): critic forward on x_hat,
     data gradient back to x_hat under create_graph.  -> (gp, slopes, dD/dx_hat).  interp must require grad."""
     fuse_heads = _heads_fusable(rnd, rng)
@@ -337,7 +372,11 @@ def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None):
                     h_gp = DiscriminatorTrunk(interp)
             else:
                 h_gp = DiscriminatorTrunk(interp)
-            y_gp = DiscriminatorTailBody(h_gp, 0.8, 0.5, 0.5, rng=rng, mask_done=True)
+            if tail_tape is not None:
+                with F.tape_replay(*tail_tape):
+                    y_gp = DiscriminatorTailBody(h_gp, 0.8, 0.5, 0.5, rng=rng, mask_done=True, specs=specs)
+            else:
+                y_gp = DiscriminatorTailBody(h_gp, 0.8, 0.5, 0.5, rng=rng, mask_done=True)
         else:
             u_gp = rnd['u_gp'] if rnd is not None else None
             d_gp = Discriminator(interp, labels, 0.8, 0.5, 0.5, u=u_gp, rng=rng, heads=('wgan',))[0]
@@ -412,7 +451,13 @@ class Trainer:
             side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side) if side is not None else _nullctx():
             fuse_heads = _heads_fusable(rnd, rng)
-            gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None)
+            use_ac = cfg.CONDITIONAL and cfg.ACGAN
+            tail = None
+            if TAIL_SHARE and tape is not None and fuse_heads:
+                tail = shared_tail_forward(tape[-1], B, rng, with_clean=use_ac)
+            gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None,
+                                                        tail_tape=(tail[0],) + tail[3]['gp'] if tail is not None else None,
+                                                        specs=tail[1] if tail is not None else None)
 
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
         if tape is not None:
@@ -429,7 +474,11 @@ class Trainer:
         if fuse_heads:
             # mean + both Linear heads + every loss head: two launches forward, one backward (gradient w.r.t. the last conv's
             # result and the head weights)
-            y = DiscriminatorTailBody(h, 0.8, 0.5, 0.5, rng=rng, mask_done=True, cat_extra=B)
+            if tail is not None:
+                with F.tape_replay(tail[0], *tail[3]['main']):
+                    y = DiscriminatorTailBody(h, 0.8, 0.5, 0.5, rng=rng, mask_done=True, cat_extra=B, specs=tail[2])
+            else:
+                y = DiscriminatorTailBody(h, 0.8, 0.5, 0.5, rng=rng, mask_done=True, cat_extra=B)
             P = lib.param
             cost, wgan, ct, acgan, disc_wgan, d_all = F.critic_tail_heads(
                 y, P('Discriminator.Output.W'), P('Discriminator.Output.b'),
@@ -443,7 +492,11 @@ class Trainer:
                                                               cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp if side is None else None)
         if use_ac:
             with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
-                if fuse_heads:       # relu + mean + Linear in one launch
+                if tail is not None:       # rows of the shared tail forward (ReLU already applied, no dropout in this range)
+                    c0, c1 = tail[3]['clean']
+                    _, _, a_clean = K.tail_heads_fwd(tail[0][-1][c0:c1], None, None, lib.param('Discriminator.ACGANOutput.W'),
+                                                     lib.param('Discriminator.ACGANOutput.b'), relu=False)
+                elif fuse_heads:       # relu + mean + Linear in one launch
                     D = cfg.DIM_D
                     yc = ResidualBlock('Discriminator.4', D, D, 3, ResidualBlock('Discriminator.3', D, D, 3, h.detach(), resample=None),
                                        resample=None)

@@ -155,13 +155,36 @@ def _x_phys_shape(g, N):
 
 
 def _ext(drop):
-    """drop = (keep, seed, stream_id, ctr) -> ctgan_epilogue_ext*, or None."""
+    """drop = (keep, seed, stream_id, ctr) -> ctgan_epilogue_ext*, or None.  Ranged form (forward launches shared by several
+    passes): {'ranges': [(end_sample, spec or None), ...]} - consecutive sample ranges with their own dropout."""
     if drop is None:
         return None
     from ._lib import EpilogueExt
+    if isinstance(drop, dict):
+        rs = drop['ranges']
+        assert 1 <= len(rs) <= 3
+        spec0 = next(sp for _, sp in rs if sp is not None)
+        e = EpilogueExt(1.0, spec0[1], 0, spec0[3].data_ptr())
+        e.n_ranges = len(rs)
+        for i, (end, sp) in enumerate(rs):
+            assert sp is None or (sp[1] == spec0[1] and sp[3].data_ptr() == spec0[3].data_ptr())
+            e.range_end[i] = int(end)
+            e.range_keep[i] = float(sp[0]) if sp is not None else 1.0
+            e.range_stream_id[i] = int(sp[2]) if sp is not None else 0
+        return ctypes.byref(e)
     keep, seed, sid, ctr = drop
     assert ctr.is_cuda and ctr.dtype == torch.int64
     return ctypes.byref(EpilogueExt(keep, seed, sid, ctr.data_ptr()))
+
+
+def _dropout_ranges(y, drop):
+    """Fallback of the ranged epilogue dropout: one dropout pass per range, on the range's own rows."""
+    r0 = 0
+    for end, sp in drop['ranges']:
+        if sp is not None and sp[0] < 1.0:
+            y[r0:end].copy_(dropout_rng(y[r0:end], *sp))
+        r0 = end
+    return y
 
 
 def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False):
@@ -195,7 +218,9 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
         except NotImplementedError:          # no vector epilogue for this call: dropout as its own pass
             pass
     _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y), fl, _stream()), 'conv2d_fwd'))
-    return y if drop is None else dropout_rng(y, *drop)
+    if drop is None:
+        return y
+    return _dropout_ranges(y, drop) if isinstance(drop, dict) else dropout_rng(y, *drop)
 
 
 def repack_filter(w, g):
@@ -971,6 +996,28 @@ def rows_cat_dropout(x, n_extra, keep, seed, stream_id, ctr):
         assert x.is_contiguous()
         out = torch.empty((n + n_extra,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
     check(lib.ctgan_rows_cat_dropout(_ptr(x), n, n_extra, row, keep, seed, stream_id, _ptr(ctr), _ptr(out), _stream()), 'rows_cat_dropout')
+    return out
+
+
+def rows_gather_dropout(src, segs, seed, ctr):
+    """dst = concatenation of row segments of src (dense, rows contiguous), each with its own dropout: segs = [(src_row0, rows,
+    keep, stream_id, index_row0), ...] (csrc: ctgan_rows_gather_dropout).  One launch."""
+    from ._lib import RowSegment
+    _need_dev(src)
+    assert is_dense(src) and ctr.is_cuda and ctr.dtype == torch.int64 and 1 <= len(segs) <= 6
+    n_dst = sum(sg[1] for sg in segs)
+    row = src.numel() // src.shape[0]
+    if src.dim() == 4 and not src.is_contiguous():
+        assert src.permute(0, 2, 3, 1).is_contiguous()
+        out = empty_cl(n_dst, src.shape[1], src.shape[2], src.shape[3], src.device)
+    else:
+        assert src.is_contiguous()
+        out = torch.empty((n_dst,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device)
+    arr = (RowSegment * len(segs))()
+    for i, (r0, rows, keep, sid, idx0) in enumerate(segs):
+        assert 0 <= r0 and r0 + rows <= src.shape[0]
+        arr[i] = RowSegment(r0, rows, keep, sid, idx0)
+    check(lib.ctgan_rows_gather_dropout(_ptr(src), arr, len(segs), row, seed, _ptr(ctr), _ptr(out), _stream()), 'rows_gather_dropout')
     return out
 
 

@@ -73,11 +73,21 @@ void ctgan_debug_force_generic(int on);
  * writes at the same physical offset (i.e. exactly ctgan_dropout_rng of the result, without the extra pass).  The
  * forward uses it for a dropout that follows a conv; the backward for the dropout mask a data gradient is multiplied
  * with.  drop_keep outside (0,1) = no dropout.  CTGAN_E_UNSUPPORTED unless the pipelined kernel with the 16-B
- * epilogue serves the call (caller then applies ctgan_dropout_rng itself).                                    */
+ * epilogue serves the call (caller then applies ctgan_dropout_rng itself).
+ * Row ranges (forward only, dense channels-last result): n_ranges > 0 splits the batch into consecutive sample ranges
+ * [0, range_end[0]), [range_end[0], range_end[1]), ... each with its own keep probability (outside (0,1) = none) and
+ * stream id, the draws indexed from the range's first element - exactly the dropout each range would get as a tensor of
+ * its own.  Lets several passes that use the same weights (dropout passes, clean pass, gradient-penalty pass) share one
+ * launch per layer.                                                                                                      */
+#define CTGAN_DROP_RANGES 3
 typedef struct ctgan_epilogue_ext {
     float drop_keep;
     uint64_t drop_seed, drop_stream_id;
     const uint64_t* drop_ctr;
+    int32_t n_ranges;
+    int32_t range_end[CTGAN_DROP_RANGES];
+    float range_keep[CTGAN_DROP_RANGES];
+    uint64_t range_stream_id[CTGAN_DROP_RANGES];
 } ctgan_epilogue_ext;
 int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                         float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream);
@@ -378,6 +388,21 @@ int ctgan_critic_prep(const int32_t* x_int, const float* fake, int32_t b, int32_
 int ctgan_rows_cat_dropout(const float* src, int64_t n_src, int64_t n_extra, int64_t row_elems, float keep, uint64_t seed,
                            uint64_t stream_id, const uint64_t* ctr, float* dst, ctgan_stream_t stream);
 int ctgan_rows_cat_bwd(const float* g, int64_t n_src, int64_t n_extra, int64_t row_elems, float* gsrc, ctgan_stream_t stream);
+/* General form: dst = concatenation of up to CTGAN_ROW_SEGMENTS row segments of src (segment i = rows [src_row0,
+ * src_row0 + rows)), each with its own tf.nn.dropout (keep >= 1: none) whose Philox element index is counted from dst row
+ * index_row0 (<= the segment's first dst row): segments that share index_row0 and stream_id reproduce the dropout of their
+ * own concatenated tensor.  Builds the inputs of all critic tails of a step (dropout passes, clean pass, gradient-penalty
+ * pass) in one launch.                                                                                                     */
+#define CTGAN_ROW_SEGMENTS 6
+typedef struct ctgan_row_segment {
+    int64_t src_row0, rows;
+    float keep;
+    uint64_t stream_id;
+    int64_t index_row0;
+} ctgan_row_segment;
+int ctgan_rows_gather_dropout(const float* src, const ctgan_row_segment* segs, int32_t nseg, int64_t row_elems, uint64_t seed,
+                              const uint64_t* ctr, float* dst, ctgan_stream_t stream);
+
 
 
 #ifdef __cplusplus

@@ -49,6 +49,14 @@ def _xin(x, g):
 def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False):
     if resid is not None and resid_up:
         resid = upsample2(resid, 1.0)
+    if isinstance(drop, dict):
+        y = conv_fwd(x, w, bias, g, resid, relu, out_strides, relu_in)
+        r0 = 0
+        for end, sp in drop['ranges']:
+            if sp is not None and sp[0] < 1.0:
+                y[r0:end] = dropout_rng(y[r0:end], *sp)
+            r0 = end
+        return y
     if drop is not None:
         return dropout_rng(conv_fwd(x, w, bias, g, resid, relu, out_strides, relu_in), *drop)
     if relu_in:
@@ -614,6 +622,24 @@ def rows_cat_dropout(x, n_extra, keep, seed, stream_id, ctr):
     if x.dim() == 4:
         y = y.contiguous(memory_format=torch.channels_last)
     return dropout_rng(y, keep, seed, stream_id, ctr) if keep < 1.0 else y
+
+
+@_export
+def rows_gather_dropout(src, segs, seed, ctr):
+    parts, groups = [], {}
+    row = 0
+    for r0, rows, keep, sid, idx0 in segs:
+        parts.append(src[r0:r0 + rows])
+        groups.setdefault((idx0, keep, sid), []).append((row, rows))
+        row += rows
+    y = torch.cat(parts, 0)
+    if src.dim() == 4:
+        y = y.contiguous(memory_format=torch.channels_last)
+    for (idx0, keep, sid), rs in groups.items():
+        if keep < 1.0:
+            end = max(a + b for a, b in rs)
+            y[idx0:end] = dropout_rng(y[idx0:end], keep, seed, sid, ctr)     # segments of a group are adjacent
+    return y
 
 
 @_export

@@ -686,6 +686,30 @@ def test_critic_prep_and_rows_cat_dropout_equal_their_compositions(K):
     assert torch.equal(gh, ref)
 
 
+def test_row_range_dropout_in_conv_epilogue_and_row_gather(K):
+    """ctgan_epilogue_ext row ranges: each sample range of one conv launch gets the dropout its own tensor would get
+    (bit-identical to dropout_rng on the range's rows); ctgan_rows_gather_dropout builds [x ; x[:k] | x | x[j:]] with
+    per-group dropout in one launch."""
+    g = torch.Generator().manual_seed(31)
+    ctr = torch.full((1,), 4, dtype=torch.int64, device='cuda')
+    geom = K.ConvGeom(128, 8, 8, 128, 3, 3, 1, False)
+    x = cl(torch.randn(40, 128, 8, 8, generator=g)); w = dev(torch.randn(3, 3, 128, 128, generator=g) * 0.03); b = dev(torch.randn(128, generator=g))
+    r = cl(torch.randn(40, 128, 8, 8, generator=g))
+    s_a, s_b = (0.5, 99, 7, ctr), (0.8, 99, 11, ctr)
+    for relu in (False, True):
+        y0 = K.conv_fwd(x, w, b, geom, resid=r, relu=relu, relu_in=True)
+        y = K.conv_fwd(x, w, b, geom, resid=r, relu=relu, relu_in=True, drop={'ranges': [(18, s_a), (30, None), (40, s_b)]})
+        assert 'igemm_fwd_pipe' in K.last_kernel()
+        assert torch.equal(y[:18], K.dropout_rng(y0[:18], *s_a))
+        assert torch.equal(y[18:30], y0[18:30])
+        assert torch.equal(y[30:], K.dropout_rng(y0[30:], *s_b))
+    h = cl(torch.randn(12, 128, 8, 8, generator=g))
+    out = K.rows_gather_dropout(h, [(0, 8, 0.8, 7, 0), (0, 4, 0.8, 7, 0), (0, 8, 1.0, 0, 12), (8, 4, 0.8, 11, 20)], 99, ctr)
+    main = K.dropout_rng(K.to_channels_last(torch.cat([h[:8], h[:4]], 0)), 0.8, 99, 7, ctr)
+    assert out.shape[0] == 24 and torch.equal(out[:12], main) and torch.equal(out[12:20], h[:8])
+    assert torch.equal(out[20:], K.dropout_rng(h[8:], 0.8, 99, 11, ctr))
+
+
 @pytest.mark.parametrize('B,nf,H,with_a', [(16, 128, 8, True), (5, 32, 4, True), (7, 64, 8, False), (3, 256, 2, True)])
 def test_fused_critic_tail_heads(K, B, nf, H, with_a):
     """F.critic_tail_heads (reduce_mean + both Linear heads + loss heads, TF/CT_gan_cifar_resnet.py:179-186,244-248,288-291)

@@ -259,7 +259,7 @@ def test_fused_critic_heads_equal_separate_head_kernels(setup, dim, B):
     fake = tr.generate_fakes(lab)[0]
     res = {}
     for mode in (False, True):
-        R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = mode            # also: input preparation / concat+dropout in single launches
+        R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = mode            # also: input preparation / concat+dropout in single launches
         try:
             tr.rng.begin_step()
             out = tr.d_losses(real, lab, fake=fake)
@@ -269,7 +269,7 @@ def test_fused_critic_heads_equal_separate_head_kernels(setup, dim, B):
                                                                'acc_real', 'acc_fake')},
                          [None if t is None else t.detach().clone() for t in grads])
         finally:
-            R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = True
+            R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = True
     for k, v in res[True][0].items():
         assert _rel_l2(v, res[False][0][k]) < 2e-5, k
     gmax = max(float(b_.abs().max()) for b_ in res[False][1] if b_ is not None)

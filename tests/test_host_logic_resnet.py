@@ -262,7 +262,7 @@ def test_fused_critic_heads_equal_separate_heads(small):
     fake = tr.generate_fakes(lab)[0]
     res = {}
     for mode in (False, True):
-        R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = mode            # also: input preparation / concat+dropout in single launches
+        R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = mode            # also: input preparation / concat+dropout in single launches
         try:
             tr.rng.begin_step()
             out = tr.d_losses(real, lab, fake=fake)
@@ -270,7 +270,7 @@ def test_fused_critic_heads_equal_separate_heads(small):
             res[mode] = ({k: out[k].detach().clone() for k in ('cost', 'wgan', 'ct', 'acgan', 'gp', 'd_real', 'd_fake', 'gp_grads')},
                          [None if t is None else t.detach().clone() for t in grads])
         finally:
-            R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = True
+            R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = True
     for k, v in res[True][0].items():
         _cmp(v, res[False][0][k], 1e-5, k)
     for (n, _), a_, b_ in zip(tr.d_named, res[True][1], res[False][1]):
