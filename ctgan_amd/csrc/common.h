@@ -39,3 +39,5 @@ int ctgan_fewch_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w,
 size_t ctgan_fewch_wgrad_workspace(const ctgan_conv_desc* d);
 int ctgan_fewch_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
                       int relu_x, hipStream_t st);
+int ctgan_fewch_wgrad2(const ctgan_conv_desc* d, const float* x, const float* dy, int N0, int relu_x, int bias0, const float* x1,
+                       const float* dy1, int N1, int relu_x1, int bias1, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st);

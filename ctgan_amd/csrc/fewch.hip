@@ -332,6 +332,8 @@ struct FWParams {
     int off_r[5], off_s[5];
     float* slab;                                                       // [workgroups][n_out]
     int N, band, bands, total, relu_many, relu_few, few_in, with_bias, n_out, n_main;
+    // optional second (x, dy) pair of the same geometry and strides (another pass's use of the filter): images [N0, N) come from it
+    const float* many2; const float* few2; int N0, relu_many2, relu_few2, bias1, bias2;
 };
 
 // few_in  (C small): many = dy, few = x:   dW[(tap*JS + j)*CM + c]   bias (sum of dy) at n_main + c
@@ -358,7 +360,14 @@ __global__ __launch_bounds__(NT) void fw_wgrad_kernel(const FWParams p) {
     float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (int task = blockIdx.x; task < p.total; task += gridDim.x) {
-        const int n = task / p.bands, b = task - n * p.bands;
+        int n = task / p.bands;
+        const int b = task - n * p.bands;
+        const bool sg2 = n >= p.N0;
+        const float* __restrict__ many = sg2 ? p.many2 : p.many;
+        const float* __restrict__ few = sg2 ? p.few2 : p.few;
+        const int relu_many = sg2 ? p.relu_many2 : p.relu_many, relu_few = sg2 ? p.relu_few2 : p.relu_few;
+        const int seg_bias = sg2 ? p.bias2 : p.bias1;
+        if (sg2) n -= p.N0;
         const int h0 = b * p.band, nh = min(p.band, p.MH - h0);
         const int tr0 = h0 * p.fst + rmin, TR = (nh - 1) * p.fst + rmax - rmin + 1;
         __syncthreads();                                                 // previous band fully consumed
@@ -369,21 +378,21 @@ __global__ __launch_bounds__(NT) void fw_wgrad_kernel(const FWParams p) {
             if ((unsigned)fh < (unsigned)p.FH && (unsigned)fw < (unsigned)p.FW) {
 #pragma unroll
                 for (int j = 0; j < JS; ++j) {
-                    const float t = p.few[n * p.fs_n + j * p.fs_c + fh * p.fs_h + fw * p.fs_w];
-                    v[j] = p.relu_few ? fmaxf(t, 0.f) : t;
+                    const float t = few[n * p.fs_n + j * p.fs_c + fh * p.fs_h + fw * p.fs_w];
+                    v[j] = relu_few ? fmaxf(t, 0.f) : t;
                 }
             }
             tile[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
         for (int hr = grp; hr < nh; hr += GROUPS) {
-            const float* mrow = p.many + n * p.ms_n + (long long)(h0 + hr) * p.ms_h + l * 4;
+            const float* mrow = many + n * p.ms_n + (long long)(h0 + hr) * p.ms_h + l * 4;
             float4 mv = *reinterpret_cast<const float4*>(mrow);
             for (int w = 0; w < p.MW; ++w) {
                 float4 cur = mv;
                 if (w + 1 < p.MW) mv = *reinterpret_cast<const float4*>(mrow + (long long)(w + 1) * p.ms_w);
-                if (p.relu_many) { cur.x = fmaxf(cur.x, 0.f); cur.y = fmaxf(cur.y, 0.f); cur.z = fmaxf(cur.z, 0.f); cur.w = fmaxf(cur.w, 0.f); }
-                if (p.few_in) { accb.x += cur.x; accb.y += cur.y; accb.z += cur.z; accb.w += cur.w; }
+                if (relu_many) { cur.x = fmaxf(cur.x, 0.f); cur.y = fmaxf(cur.y, 0.f); cur.z = fmaxf(cur.z, 0.f); cur.w = fmaxf(cur.w, 0.f); }
+                if (p.few_in && seg_bias) { accb.x += cur.x; accb.y += cur.y; accb.z += cur.z; accb.w += cur.w; }
                 const Acc4 cm = to_acc(cur);
                 const float4* trow = tile + (hr * p.fst - rmin) * TW + (w * p.fst - smin);
 #pragma unroll
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(NT) void fw_wgrad_kernel(const FWParams p) {
 #pragma unroll
                         for (int j = 0; j < JS; ++j) fma4(f[j], cm, acc[(r * S + s) * JS + j]);
                     }
-                if (!p.few_in) {                                         // bias of the few-channel dy: the pixel itself (tap offset 0)
+                if (!p.few_in && seg_bias) {                             // bias of the few-channel dy: the pixel itself (tap offset 0)
                     const float4 fv = trow[0];
                     accb.x += fv.x; accb.y += fv.y; accb.z += fv.z; accb.w += fv.w;
                 }
@@ -662,9 +671,22 @@ size_t ctgan_fewch_wgrad_workspace(const ctgan_conv_desc* d) {
 
 int ctgan_fewch_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
                       int relu_x, hipStream_t st) {
+    return ctgan_fewch_wgrad2(d, x, dy, d->N, relu_x, db ? 1 : 0, nullptr, nullptr, 0, 0, 0, dw, db, ws, ws_bytes, st);
+}
+
+// two (x, dy) pairs of the same geometry and strides summed in one launch (d->N is ignored: N0 + N1 images)
+int ctgan_fewch_wgrad2(const ctgan_conv_desc* d0, const float* x, const float* dy, int N0, int relu_x, int bias0, const float* x1,
+                       const float* dy1, int N1, int relu_x1, int bias1, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st) {
+    ctgan_conv_desc dd = *d0;
+    dd.N = N0 + N1;
+    const ctgan_conv_desc* d = &dd;
     if (!ctgan_fewch_handles(d)) return 0;
+    if (N1 > 0 && (!x1 || !dy1 || !al16(x1) || !al16(dy1))) return 0;
     const bool few_in = d->C <= 4;
     FWParams p;
+    p.N0 = N0; p.bias1 = bias0; p.bias2 = bias1;
+    p.many2 = few_in ? dy1 : x1; p.few2 = few_in ? x1 : dy1;
+    p.relu_many2 = few_in ? 0 : relu_x1; p.relu_few2 = few_in ? relu_x1 : 0;
     if (few_in) {
         if (d->ys[1] != 1 || (d->ys[0] | d->ys[2] | d->ys[3]) % 4 || !al16(dy)) return 0;
         p.many = dy; p.ms_n = d->ys[0]; p.ms_h = d->ys[2]; p.ms_w = d->ys[3]; p.MH = d->P; p.MW = d->Q; p.CM = d->K;

@@ -1771,6 +1771,12 @@ MultiPlan multi_plan(const ctgan_conv_desc* d, int nseg, const int32_t* Ns) {
 
 extern "C" size_t ctgan_conv2d_wgrad_multi_workspace_bytes(const ctgan_conv_desc* d, int32_t nseg, const int32_t* Ns) {
     if (!d || !Ns || nseg < 1 || nseg > CTGAN_WGRAD_MAX_SEGS) return 0;
+    if (!g_force_generic && ctgan_fewch_handles(d)) {        // few-channel convs: up to two segments in the direct kernel
+        ctgan_conv_desc dd = *d;
+        dd.N = 0;
+        for (int i = 0; i < nseg; ++i) dd.N += Ns[i];
+        return nseg <= 2 ? ctgan_fewch_wgrad_workspace(&dd) : 0;
+    }
     const MultiPlan m = multi_plan(d, nseg, Ns);
     return (size_t)m.splits * ((size_t)d->R * d->S * d->C + 1) * d->K * sizeof(float);
 }
@@ -1839,6 +1845,16 @@ int launch_wgrad_pipe_group(const WgradGroupParams& gp, hipStream_t st) {
 extern "C" int ctgan_conv2d_wgrad_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs, const float* const* dys,
                                         const int32_t* Ns, const int32_t* seg_flags, float* dw, float* db, void* ws, size_t ws_bytes,
                                         ctgan_stream_t stream) {
+    if (d && xs && dys && Ns && seg_flags && dw && nseg >= 1 && nseg <= 2 && !g_force_generic && ctgan_fewch_handles(d)) {
+        const int b0 = (seg_flags[0] & CTGAN_WGRAD_SEG_BIAS) ? 1 : 0, b1 = (nseg > 1 && (seg_flags[1] & CTGAN_WGRAD_SEG_BIAS)) ? 1 : 0;
+        if ((b0 || b1) != (db != nullptr)) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_multi: db must be given iff a segment carries the bias flag");
+        const int r = ctgan_fewch_wgrad2(d, xs[0], dys[0], Ns[0], (seg_flags[0] & CTGAN_IN_RELU) ? 1 : 0, b0, nseg > 1 ? xs[1] : nullptr,
+                                         nseg > 1 ? dys[1] : nullptr, nseg > 1 ? Ns[1] : 0, (nseg > 1 && (seg_flags[1] & CTGAN_IN_RELU)) ? 1 : 0, b1,
+                                         dw, db, ws, ws_bytes, static_cast<hipStream_t>(stream));
+        if (r < 0) return r;
+        if (r == 1) return CTGAN_OK;
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_wgrad_multi: the few-channel kernel declined these operands");
+    }
     WgradParams p;
     MultiPlan m;
     int rc = prepare_multi(d, nseg, xs, dys, Ns, seg_flags, dw, db, p, m, "conv2d_wgrad_multi");

@@ -57,6 +57,8 @@ def weight_grads(enabled):
 # double backward - instead of one wgrad + reduction per use and an autograd `add` per extra use.
 _DEFER = {'on': False, 'groups': None, 'post': None}
 DEFER_WGRADS = _os.environ.get('CTGAN_DEFER_WGRADS', '1') != '0'
+# A/B switch: the few-channel weight gradients (first critic conv / shortcut) are queued too: both uses of a filter in one launch
+FEWCH_DEFER = _os.environ.get('CTGAN_FEWCH_DEFER', '1') != '0'
 # A/B switch: all queued weight gradients in one launch per tile configuration + one launch for their reductions
 WGRAD_GROUPED = _os.environ.get('CTGAN_WGRAD_GROUPED', '1') != '0'
 
@@ -84,7 +86,7 @@ def deferred_wgrads():
 def _flush_groups(grps):
     """All queued weight gradients: one grouped launch per tile configuration + one reduction launch when every group
     fits the pipelined kernel (K.conv_wgrad_group), else group by group."""
-    simple = [g for g in grps if len(g.segs) <= K.WGRAD_MAX_SEGS]
+    simple = [g for g in grps if len(g.segs) <= K.WGRAD_MAX_SEGS and not K.fewch_handles(g.g)]
     if WGRAD_GROUPED and len(simple) > 1 and K.PROFILE is None:
         for g in simple:                                   # a queued bias buffer no segment contributes to
             if g.db is not None and not any(sg[3] for sg in g.segs):
@@ -94,7 +96,7 @@ def _flush_groups(grps):
             for i in range(0, len(todo), K.WGRAD_GROUP_LIMIT):
                 K.conv_wgrad_group([(g.segs, g.g, g.dw, g.db if any(sg[3] for sg in g.segs) else None)
                                     for g in todo[i:i + K.WGRAD_GROUP_LIMIT]])
-            grps = [g for g in grps if len(g.segs) > K.WGRAD_MAX_SEGS]
+            grps = [g for g in grps if g not in simple]
         except NotImplementedError:
             pass                                           # nothing was launched: fall back below
     for grp in grps:
@@ -104,8 +106,9 @@ def _flush_groups(grps):
 def _flush_group(grp):
     segs = grp.segs
     try:
-        for i in range(0, len(segs), K.WGRAD_MAX_SEGS):
-            chunk = segs[i:i + K.WGRAD_MAX_SEGS]
+        per = 2 if K.fewch_handles(grp.g) else K.WGRAD_MAX_SEGS
+        for i in range(0, len(segs), per):
+            chunk = segs[i:i + per]
             if i == 0:
                 K.conv_wgrad_multi(chunk, grp.g, grp.dw, grp.db if any(sg[3] for sg in chunk) else None)
                 if grp.db is not None and not any(sg[3] for sg in chunk):
@@ -132,13 +135,14 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     """Weight (and bias) gradient of one use of filter `w`: launched now, or queued (see deferred_wgrads).
     Returns (gw, gb); either may be None when another request of the same filter already owns the result."""
     stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _SPREAD_BUFS     # same identity in every pass of the step
+    fewch = K.fewch_handles(g)                    # few-channel convs: the direct kernel sums two uses in one launch
     defer = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
-             and g.C % 32 == 0 and g.K % 4 == 0 and not K.fewch_handles(g) and not (g.R == 1 and g.H == 1 and g.W == 1))
+             and ((g.C % 32 == 0 and g.K % 4 == 0) or (fewch and FEWCH_DEFER)) and not (g.R == 1 and g.H == 1 and g.W == 1))
     if not defer:
         if with_bias:
             return K.conv_wgrad(x, gy, g, with_bias=True, relu_x=relu_x)
         return K.conv_wgrad(x, gy, g, relu_x=relu_x), None
-    if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous():
+    if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous() and not fewch:
         gy = K.to_channels_last(gy)
     gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     key = (w.data_ptr(), gk)

@@ -794,6 +794,33 @@ def test_multi_segment_wgrad(K, C, H, Ko, k, st, Ns):
     assert torch.equal(dw, dw2)                                    # deterministic
 
 
+@pytest.mark.parametrize('C,Ko,k', [(3, 128, 3), (3, 128, 1), (128, 3, 3)])
+def test_few_channel_wgrad_two_segments(K, C, Ko, k):
+    """ctgan_conv2d_wgrad_multi on a few-channel conv: both uses of the filter (two passes of a step) in one launch of the
+    direct kernel = the sum of the separate weight gradients; per-segment relu-on-load and bias flags."""
+    g = torch.Generator().manual_seed(C * 7 + k)
+    geom = K.ConvGeom(C, 32, 32, Ko, k, k, 1, False)
+    assert K.fewch_handles(geom)
+    segs, ref_w, ref_b = [], 0, 0
+    for i, n in enumerate((12, 5)):
+        x = dev(torch.randn(n, C, 32, 32, generator=g)) if C <= 4 else cl(torch.randn(n, C, 32, 32, generator=g))
+        gy = cl(torch.randn(n, Ko, 32, 32, generator=g)) if Ko > 4 else dev(torch.randn(n, Ko, 32, 32, generator=g))
+        relu_x, with_bias = (i == 1), (i == 0)
+        segs.append((x, gy, relu_x, with_bias))
+        r = K.conv_wgrad(x, gy, geom, with_bias=with_bias, relu_x=relu_x)
+        ref_w = ref_w + (r[0] if with_bias else r).double()
+        if with_bias:
+            ref_b = ref_b + r[1].double()
+    dw = torch.empty(k, k, C, Ko, device='cuda'); db = torch.empty(Ko, device='cuda')
+    K.conv_wgrad_multi(segs, geom, dw, db)
+    assert 'fewch_wgrad' in K.last_kernel()
+    assert relerr(dw, ref_w) < 1e-5 and relerr(db, ref_b) < 1e-5
+    dw1 = torch.empty_like(dw)
+    K.conv_wgrad_multi(segs[:1], geom, dw1, db)
+    r0 = K.conv_wgrad(segs[0][0], segs[0][1], geom, with_bias=True, relu_x=False)
+    assert torch.equal(dw1, r0[0]) and torch.equal(db, r0[1])
+
+
 def test_grouped_wgrad_equals_separate_launches(K):
     """ctgan_conv2d_wgrad_group: the queued weight gradients of a step (different filters, geometries and tile
     configurations, several segments each) from one launch per tile configuration + one reduction launch are
