@@ -383,6 +383,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_fwd_kernel(const
 // occupancy the register allocator must keep (waves per SIMD): the 64x128 tile (2 accumulators per wave) sits at the edge of
 // 3 - a few VGPRs more in the epilogue cost a whole wave (measured: -2 % on the step).  Only the 4-phase variant needs the
 // hint; with it the allocator moves the accumulators out of the AGPRs, which costs the plain variant 4 %.
+#ifndef CTGAN_B_DIRECT
+#define CTGAN_B_DIRECT 0
+#endif
+// EXPERIMENT (off: -DCTGAN_B_DIRECT=1 to build it; parity tests pass).  Measured on the step: the 128x128 / 64x128 tiles do not
+// change (118.6 vs 118.7, 105.6 vs 106.2 TFLOP/s - their pipe-busy gap is not the register staging of B), the K-split tiles of the
+// small layers lose 3-6 % (one slice of latency slack less than the register ring).
+// B operand (filter slices) straight into LDS: buffer_load_dwordx4 ... lds writes lane l's 16 bytes at M0 + 16*l, which is
+// exactly the row-major [BK][BN] layout of the B stage when a wave covers 64/BC consecutive rows - no VGPR staging, no
+// ds_write.  Inline asm: the compiler's waitcnt insertion must not see it (it would drain vmcnt before every ds_read);
+// completion is awaited by hand before the slice barrier (loads retire in order: vmcnt(A loads issued after it)).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void buffer_load16_to_lds(u32x4_t rsrc, unsigned voff, unsigned soff, unsigned lds_byte_off /* wave-uniform */) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte_off)
+                 : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() {
+    static_assert(N >= 0 && N < 16, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt(0xF70 | N);          // lgkmcnt / expcnt untouched, vmcnt <= N (N < 16: low field only)
+}
 constexpr int fwd_pipe_min_waves(int waves_k, int tm, int tn, int ksub) { return 1; }
 template <int WAVES_M, int WAVES_N, int WAVES_K, int TM, int TN, int RD, bool RELU_IN, int KSUB>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, fwd_pipe_min_waves(WAVES_K, TM, TN, KSUB)) void igemm_fwd_pipe_kernel(const FwdParams p) {
@@ -445,6 +468,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, fwd_pipe_min_wave
 
     float4 ra[RD][A_PER], rb[RD][B_PER];                                // register ring: slices are loaded RD iterations ahead
     int ld_r = 0, ld_s = 0, ld_c = 0;                                   // tap / channel-chunk of the NEXT slice to load
+#if CTGAN_B_DIRECT
+    int lb_r = 0, lb_s = 0, lb_c = 0;                                   // ... and of the next B slice sent straight to LDS
+    u32x4_t b_desc;
+    {
+        const unsigned long long ba = reinterpret_cast<unsigned long long>(p.B);
+        b_desc.x = (unsigned)ba; b_desc.y = (unsigned)(ba >> 32); b_desc.z = p.b_bytes; b_desc.w = 0x00020000u;
+    }
+    const unsigned b_lds_wave = (unsigned)__builtin_amdgcn_readfirstlane((wave * (64 / BC)) * BN * 4);
+    auto issue_b_direct = [&](float* Bs) {
+        const unsigned bsoff = (unsigned)__builtin_amdgcn_readfirstlane((int)((ph.b_off + n0 + lb_r * p.bs_r + lb_s * p.bs_s + (long long)(lb_c * BKE) * p.bs_c) * 4));
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)Bs + b_lds_wave;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
+            buffer_load16_to_lds(b_desc, b_voff[i], bsoff, __builtin_amdgcn_readfirstlane(base + (unsigned)(i * (NT / BC) * BN * 4)));
+        if (++lb_c == cpt) { lb_c = 0; if (++lb_s == g.S) { lb_s = 0; ++lb_r; } }
+    };
+#endif
 
     auto load_tile = [&](float4 (&ra)[A_PER], float4 (&rb)[B_PER]) {
         const int c0 = ld_c * BKE;
@@ -468,12 +508,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, fwd_pipe_min_wave
                 ra[i] = __builtin_bit_cast(float4, v);
             }
         }
+#if !CTGAN_B_DIRECT
         const unsigned bsoff = (unsigned)((ph.b_off + n0 + ld_r * p.bs_r + ld_s * p.bs_s + (long long)c0 * p.bs_c) * 4);
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_voff[i], bsoff, 0);
             rb[i] = __builtin_bit_cast(float4, v);
         }
+#endif
         if (++ld_c == cpt) { ld_c = 0; if (++ld_s == g.S) { ld_s = 0; ++ld_r; } }
     };
     auto store_tile = [&](const float4 (&ra)[A_PER], const float4 (&rb)[B_PER], float* As, float* Bs) {
@@ -483,9 +525,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, fwd_pipe_min_wave
             if constexpr (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(&As[(a_row0 + i * (NT / AC)) * LDAE + a_chunk * 4]) = v;
         }
+#if !CTGAN_B_DIRECT
 #pragma unroll
         for (int i = 0; i < B_PER; ++i)
             *reinterpret_cast<float4*>(&Bs[(b_k0 + i * (NT / BC)) * BN + b_j4 * 4]) = rb[i];
+#endif
     };
 
     f32x16 acc[TM][TN];
@@ -497,11 +541,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, fwd_pipe_min_wave
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // prologue: slice 0 -> stage 0; slices 1..RD -> ring slots (slice t lives in slot t % RD)
+#if CTGAN_B_DIRECT
+    issue_b_direct(smem + BM * LDAE);
+#endif
     load_tile(ra[0], rb[0]);
     store_tile(ra[0], rb[0], smem, smem + BM * LDAE);
 #pragma unroll
     for (int t = 1; t <= RD; ++t)
         if (t < nk) load_tile(ra[t % RD], rb[t % RD]);
+#if CTGAN_B_DIRECT
+    wait_vmcnt_le<0>();
+#endif
     __syncthreads();
 
     const int h = lane >> 5, l31 = lane & 31;
@@ -549,13 +599,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, fwd_pipe_min_wave
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, b[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
                 }
                 // slot (u+1)%RD holds slice kt+1 (loaded RD iterations ago): stage it, then refill the slot
-                if (sub == 0 && s == 0 && kt + 1 < nk && !(p.dbg & 1)) store_tile(ra[(u + 1) % RD], rb[(u + 1) % RD], Asn, Bsn);
+                if (sub == 0 && s == 0 && kt + 1 < nk && !(p.dbg & 1)) {
+                    store_tile(ra[(u + 1) % RD], rb[(u + 1) % RD], Asn, Bsn);
+#if CTGAN_B_DIRECT
+                    issue_b_direct(Bsn);      // after the A store: its compiler-inserted vmcnt(0) must not cover these loads
+#endif
+                }
                 if (sub == 0 && s == 1 && kt + 1 + RD < nk && !(p.dbg & 2)) load_tile(ra[(u + 1) % RD], rb[(u + 1) % RD]);
                 // waves that are in their MFMA stretch win arbitration over a co-resident wave that is staging
                 if (sub == 0 && s == 1) __builtin_amdgcn_s_setprio(1);
                 if (sub == KSUB - 1 && s == 15) __builtin_amdgcn_s_setprio(0);
             }
             }
+#if CTGAN_B_DIRECT
+            if (kt + 1 + RD < nk) wait_vmcnt_le<(A_PER < 15 ? A_PER : 0)>(); else wait_vmcnt_le<0>();   // the B slice landed; A registers may still fly
+#endif
             if (!(p.dbg & 4)) __syncthreads();
         }
     }
