@@ -454,6 +454,150 @@ __global__ __launch_bounds__(NT) void fw_wgrad_kernel(const FWParams p) {
     }
 }
 
+// ---- the same weight gradient on the matrix cores (CM = 128) ------------------------------------------------------------------
+// dW[m][c] = sum_px F[px][m] * G[px][c] with m = (tap, few channel) <= 27 rows (padded to the 32 of v_mfma_f32_32x32x2_f32),
+// c = the 128 channels of the wide operand, two pixels per MFMA step.  Per step a lane fetches ONE float4 of the wide operand
+// (channels 4*l31 .. 4*l31+3 of pixel w + h: a half-wave reads the pixel's 512 contiguous bytes) and uses its four components
+// as the B operands of four MFMAs - accumulator t then holds the channels 4*j + t - and ONE value of the zero-padded
+// few-channel LDS tile as the A operand (row m of lane l31 = its tap / channel).  Row 31 of A is the constant 1 when the
+// segment contributes to the bias of a few_in conv, so the column sums of the wide operand ride along; the few_out bias (sum of
+// the few-channel dy) is the sum of the centre-tap A values a lane sees.  The direct-FMA kernel above is VALU-bound at ~2.5x
+// this kernel's HBM floor.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int R, int S, int JS>
+__global__ __launch_bounds__(NT) void fw_wgrad_mfma_kernel(const FWParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* tile = reinterpret_cast<float4*>(smem);
+    const float* tile_f = smem;
+    constexpr int M = R * S * JS;
+    static_assert(M <= 31, "taps x channels must leave row 31 for the bias");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    int rmin = p.off_r[0], rmax = p.off_r[0], smin = p.off_s[0], smax = p.off_s[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) { rmin = min(rmin, p.off_r[r]); rmax = max(rmax, p.off_r[r]); }
+#pragma unroll
+    for (int s = 1; s < S; ++s) { smin = min(smin, p.off_s[s]); smax = max(smax, p.off_s[s]); }
+    const int tw0 = smin, TW = (p.MW - 1) * p.fst + smax - smin + 1;
+    // this lane's A row: tap (ar, as) and few channel aj; rows M..30 are zero, row 31 is the bias row
+    const int am = l31;
+    const int atap = am / JS, aj = am - atap * JS, ar = atap / S, as_ = atap - ar * S;
+    const bool a_live = am < M;
+    const int a_off = a_live ? ((p.off_r[ar] - rmin) * TW + (p.off_s[as_] - smin)) * 4 + aj : 0;
+    const bool a_centre = a_live && !p.few_in && p.off_r[ar] == 0 && p.off_s[as_] == 0;   // few_out bias: the pixel itself
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum = 0.f;
+
+    for (int task = blockIdx.x; task < p.total; task += gridDim.x) {
+        int n = task / p.bands;
+        const int b = task - n * p.bands;
+        const bool sg2 = n >= p.N0;
+        const float* __restrict__ many = sg2 ? p.many2 : p.many;
+        const float* __restrict__ few = sg2 ? p.few2 : p.few;
+        const int relu_many = sg2 ? p.relu_many2 : p.relu_many, relu_few = sg2 ? p.relu_few2 : p.relu_few;
+        const int seg_bias = sg2 ? p.bias2 : p.bias1;
+        if (sg2) n -= p.N0;
+        const int h0 = b * p.band, nh = min(p.band, p.MH - h0);
+        const int tr0 = h0 * p.fst + rmin, TR = (nh - 1) * p.fst + rmax - rmin + 1;
+        __syncthreads();                                                 // previous band fully consumed
+        for (int i = tid; i < TR * TW; i += NT) {
+            const int tr = i / TW, tw = i - tr * TW;
+            const int fh = tr0 + tr, fw = tw0 + tw;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)fh < (unsigned)p.FH && (unsigned)fw < (unsigned)p.FW) {
+#pragma unroll
+                for (int j = 0; j < JS; ++j) {
+                    const float t = few[n * p.fs_n + j * p.fs_c + fh * p.fs_h + fw * p.fs_w];
+                    v[j] = relu_few ? fmaxf(t, 0.f) : t;
+                }
+            }
+            tile[i] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        __syncthreads();
+        const float a_bias = (am == 31 && p.few_in && seg_bias) ? 1.f : 0.f;
+        const float c_flag = (a_centre && seg_bias) ? 1.f : 0.f;
+        for (int hr = wave; hr < nh; hr += 4) {
+            const float* mrow = many + n * p.ms_n + (long long)(h0 + hr) * p.ms_h + l31 * 4 + (long long)h * p.ms_w;
+            const float* arow = tile_f + (hr * p.fst * TW + h * p.fst) * 4 + a_off;
+            const int npair = p.MW >> 1;                                 // MW even (checked by the host)
+            constexpr int UQ = 8;                                        // pixel pairs per batch: 8 float4 loads in flight per lane
+            for (int q0 = 0; q0 < npair; q0 += UQ) {
+                float4 gv[UQ];
+                float av[UQ];
+#pragma unroll
+                for (int u = 0; u < UQ; ++u) {
+                    const int q = q0 + u;
+                    gv[u] = q < npair ? *reinterpret_cast<const float4*>(mrow + (long long)(2 * q) * p.ms_w) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < UQ; ++u) {
+                    const int q = q0 + u;
+                    av[u] = q < npair ? (a_live ? arow[q * 2 * p.fst * 4] : a_bias) : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < UQ; ++u) {
+                    float4 cur = gv[u];
+                    if (relu_many) { cur.x = fmaxf(cur.x, 0.f); cur.y = fmaxf(cur.y, 0.f); cur.z = fmaxf(cur.z, 0.f); cur.w = fmaxf(cur.w, 0.f); }
+                    const float a = av[u];
+                    bsum += a * c_flag;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur.z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur.w, acc[3], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // combine the four waves through LDS in a fixed order, then one wave writes the slab
+    __syncthreads();
+    float* red = smem;                                                   // [3][64 regs][64 lanes]
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[((wave - 1) * 64 + t * 16 + e) * 64 + lane] = acc[t][e];
+        red[3 * 64 * 64 + (wave - 1) * 64 + lane] = bsum;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] += red[((w - 1) * 64 + t * 16 + e) * 64 + lane];
+        bsum += red[3 * 64 * 64 + (w - 1) * 64 + lane];
+    }
+    float* out = p.slab + (long long)blockIdx.x * p.n_out;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = (e & 3) + 8 * (e >> 2) + 4 * h;                    // accumulator row of register e in lane half h
+        const float4 v = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);      // channels 4*l31 .. 4*l31+3
+        if (m < M) {
+            if (p.few_in) {
+                *reinterpret_cast<float4*>(out + (long long)m * p.CM + l31 * 4) = v;
+            } else {
+                const int tap = m / JS, j = m - tap * JS;
+                float* o = out + ((long long)tap * p.CM + l31 * 4) * JS + j;
+                o[0] = v.x; o[JS] = v.y; o[2 * JS] = v.z; o[3 * JS] = v.w;
+            }
+        } else if (m == 31 && p.few_in && p.with_bias) {
+            *reinterpret_cast<float4*>(out + p.n_main + l31 * 4) = v;
+        }
+    }
+    if (!p.few_in && p.with_bias) {                                      // few_out bias: lanes of the centre tap hold sum of dy[., j]
+        const float other = __shfl_xor(bsum, 32, 64);                    // the two pixel halves
+        const float tot = bsum + other;
+        if (a_centre && h == 0) out[p.n_main + aj] = tot;
+        if (lane == 0 && JS < 4) for (int j = JS; j < 4; ++j) out[p.n_main + j] = 0.f;
+    }
+}
+
 // dw = sum over workgroup slabs, fixed order: 16 slab lanes x 16 column groups (float4) per workgroup, then a
 // 16-way LDS combine.  n_tot (filter + bias section) is a multiple of 4; db receives the first nb bias values.
 __global__ __launch_bounds__(NT) void fw_reduce_kernel(const float* __restrict__ slab, int stride, int blocks, float* __restrict__ dw,
@@ -722,6 +866,36 @@ int ctgan_fewch_wgrad2(const ctgan_conv_desc* d0, const float* x, const float* d
     if (smem > 150 * 1024) return 0;
     int rc = 0;
     const dim3 grid(blocks), blk(NT);
+    static const int use_mfma = [] { const char* e = getenv("CTGAN_FW_MFMA"); return e ? atoi(e) : 1; }();
+    const size_t red_mfma = (size_t)(3 * 64 * 64 + 3 * 64) * sizeof(float);
+    const size_t smem_m = tile_b > red_mfma ? tile_b : red_mfma;
+    if (use_mfma && p.CM == 128 && (p.MW & 1) == 0 && smem_m <= 150 * 1024) {
+        bool done = true;
+        // two workgroups per CU: the loop is a latency-bound stream (one float4 per lane per two pixels), registers are few
+        static const int cap = [] { const char* e = getenv("CTGAN_FW_BLOCKS"); return e ? atoi(e) : 512; }();
+        int blocks_m = p.total < cap ? p.total : cap;
+        if ((size_t)blocks_m * p.n_out * sizeof(float) > ws_bytes) blocks_m = blocks;
+        const dim3 grid(blocks_m);
+        const int blocks = blocks_m;
+        switch (tap_case(d->R, d->S, JS)) {
+            case 1: rc = set_smem(&fw_wgrad_mfma_kernel<3, 3, 3>, smem_m); if (!rc) hipLaunchKernelGGL((fw_wgrad_mfma_kernel<3, 3, 3>), grid, blk, smem_m, st, p); break;
+            case 2: rc = set_smem(&fw_wgrad_mfma_kernel<1, 1, 3>, smem_m); if (!rc) hipLaunchKernelGGL((fw_wgrad_mfma_kernel<1, 1, 3>), grid, blk, smem_m, st, p); break;
+            case 3: rc = set_smem(&fw_wgrad_mfma_kernel<5, 5, 1>, smem_m); if (!rc) hipLaunchKernelGGL((fw_wgrad_mfma_kernel<5, 5, 1>), grid, blk, smem_m, st, p); break;
+            case 4: rc = set_smem(&fw_wgrad_mfma_kernel<3, 3, 1>, smem_m); if (!rc) hipLaunchKernelGGL((fw_wgrad_mfma_kernel<3, 3, 1>), grid, blk, smem_m, st, p); break;
+            default: done = false;
+        }
+        if (done) {
+            if (rc) return rc;
+            rc = ctgan_check_launch("fewch_wgrad_mfma");
+            if (rc) return rc;
+            ctgan_set_last_kernel(few_in ? "fewch_wgrad(few_in)" : "fewch_wgrad(few_out)");
+            const int nb = db ? d->K : 0;
+            const int n_tot = db ? p.n_out : p.n_main;
+            hipLaunchKernelGGL(fw_reduce_kernel, dim3((n_tot + 63) / 64), dim3(NT), 0, st, p.slab, p.n_out, blocks, dw, p.n_main, db, nb, n_tot);
+            rc = ctgan_check_launch("fewch_reduce");
+            return rc ? rc : 1;
+        }
+    }
     switch (tap_case(d->R, d->S, JS)) {
         case 1: rc = set_smem(&fw_wgrad_kernel<3, 3, 3>, smem); if (!rc) hipLaunchKernelGGL((fw_wgrad_kernel<3, 3, 3>), grid, blk, smem, st, p); break;
         case 2: rc = set_smem(&fw_wgrad_kernel<1, 1, 3>, smem); if (!rc) hipLaunchKernelGGL((fw_wgrad_kernel<1, 1, 3>), grid, blk, smem, st, p); break;
