@@ -12,11 +12,11 @@ namespace {
 
 constexpr int CB = 64;      // channels per workgroup (one 256-byte row segment per wave load)
 constexpr int RL = 4;       // row lanes per workgroup
-constexpr int POS = 64;     // spatial positions per workgroup
+// spatial positions per workgroup of the partial reductions (one partial row each) = BnShape::pos: 256 when that still
+// leaves >= 512 workgroups (fewer rows for the finalisation), else 64
 
-struct BnShape { int n, hw, c, groups, hc; };
+struct BnShape { int n, hw, c, groups, hc, pos; };
 
-__device__ __forceinline__ int chunk_count(int hw) { return (hw + POS - 1) / POS; }
 
 // part[(sample*hc + chunk)][2][c] (double): sum x, sum x^2 over the chunk's positions
 __global__ __launch_bounds__(CB * RL) void bn_stats_partial_kernel(const float* __restrict__ x, BnShape s,
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(CB * RL) void bn_stats_partial_kernel(const float* 
     const int cl = threadIdx.x % CB, rl = threadIdx.x / CB;
     const int c = blockIdx.y * CB + cl;
     const int sample = blockIdx.x / s.hc, chunk = blockIdx.x - sample * s.hc;
-    const int p0 = chunk * POS, p1 = min(s.hw, p0 + POS);
+    const int p0 = chunk * s.pos, p1 = min(s.hw, p0 + s.pos);
     double a = 0., b = 0.;
     if (c < s.c) {
         const float* base = x + ((long long)sample * s.hw) * s.c + c;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(CB * RL) void bn_bwd_partial_kernel(
     const int cl = threadIdx.x % CB, rl = threadIdx.x / CB;
     const int c = blockIdx.y * CB + cl;
     const int sample = blockIdx.x / s.hc, chunk = blockIdx.x - sample * s.hc;
-    const int p0 = chunk * POS, p1 = min(s.hw, p0 + POS);
+    const int p0 = chunk * s.pos, p1 = min(s.hw, p0 + s.pos);
     double a = 0., b = 0.;
     if (c < s.c) {
         const int g = sample / (s.n / s.groups);
@@ -269,6 +269,81 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
         *reinterpret_cast<float4*>(gx + o) = r;
     }
 }
+// Vector partial reductions (same layout of `part`): 16-B loads, each thread sums <= pos*c4n/256 positions of its 4 channels
+// in fp32 (a few dozen values), the row lanes are then combined in fp64.  blockDim = 256 = (c/4) channel lanes x row lanes.
+__global__ __launch_bounds__(256) void bn_stats_partial_vec_kernel(const float* __restrict__ x, BnShape s, double* __restrict__ part) {
+    __shared__ double red[2][256][4];
+    const int c4n = s.c >> 2, rls = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    const int sample = blockIdx.x / s.hc, chunk = blockIdx.x - sample * s.hc;
+    const int p0 = chunk * s.pos, p1 = min(s.hw, p0 + s.pos);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    const float* base = x + ((long long)sample * s.hw) * s.c + c4 * 4;
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += rls) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (long long)p * s.c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        b.x += v.x * v.x; b.y += v.y * v.y; b.z += v.z * v.z; b.w += v.w * v.w;
+    }
+    double* ra = red[0][threadIdx.x]; double* rb = red[1][threadIdx.x];
+    ra[0] = a.x; ra[1] = a.y; ra[2] = a.z; ra[3] = a.w;
+    rb[0] = b.x; rb[1] = b.y; rb[2] = b.z; rb[3] = b.w;
+    __syncthreads();
+    if (rl == 0) {
+        double sa[4] = {0., 0., 0., 0.}, sb[4] = {0., 0., 0., 0.};
+        for (int r = 0; r < rls; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sa[k] += red[0][r * c4n + c4][k]; sb[k] += red[1][r * c4n + c4][k]; }
+        double* o = part + (long long)blockIdx.x * 2 * s.c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[c4 * 4 + k] = sa[k]; o[s.c + c4 * 4 + k] = sb[k]; }
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_partial_vec_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ scale, const float* __restrict__ offset, const int32_t* __restrict__ labels, BnShape s, int relu,
+    double* __restrict__ part) {
+    __shared__ double red[2][256][4];
+    const int c4n = s.c >> 2, rls = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    const int sample = blockIdx.x / s.hc, chunk = blockIdx.x - sample * s.hc;
+    const int p0 = chunk * s.pos, p1 = min(s.hw, p0 + s.pos);
+    const int g = sample / (s.n / s.groups);
+    const int lab = labels ? labels[sample] : 0;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + g * s.c + c4 * 4), rs = *reinterpret_cast<const float4*>(rstd + g * s.c + c4 * 4);
+    const float4 ga = *reinterpret_cast<const float4*>(scale + lab * s.c + c4 * 4), be = *reinterpret_cast<const float4*>(offset + lab * s.c + c4 * 4);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    const long long base = ((long long)sample * s.hw) * s.c + c4 * 4;
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += rls) {
+        const long long o = base + (long long)p * s.c;
+        const float4 xv = *reinterpret_cast<const float4*>(x + o);
+        float4 gg = *reinterpret_cast<const float4*>(gy + o);
+        const float hx = (xv.x - mu.x) * rs.x, hy = (xv.y - mu.y) * rs.y, hz = (xv.z - mu.z) * rs.z, hw_ = (xv.w - mu.w) * rs.w;
+        if (relu) {
+            if (!(hx * ga.x + be.x > 0.f)) gg.x = 0.f;
+            if (!(hy * ga.y + be.y > 0.f)) gg.y = 0.f;
+            if (!(hz * ga.z + be.z > 0.f)) gg.z = 0.f;
+            if (!(hw_ * ga.w + be.w > 0.f)) gg.w = 0.f;
+        }
+        a.x += gg.x; a.y += gg.y; a.z += gg.z; a.w += gg.w;
+        b.x += gg.x * hx; b.y += gg.y * hy; b.z += gg.z * hz; b.w += gg.w * hw_;
+    }
+    double* ra = red[0][threadIdx.x]; double* rb = red[1][threadIdx.x];
+    ra[0] = a.x; ra[1] = a.y; ra[2] = a.z; ra[3] = a.w;
+    rb[0] = b.x; rb[1] = b.y; rb[2] = b.z; rb[3] = b.w;
+    __syncthreads();
+    if (rl == 0) {
+        double sa[4] = {0., 0., 0., 0.}, sb[4] = {0., 0., 0., 0.};
+        for (int r = 0; r < rls; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sa[k] += red[0][r * c4n + c4][k]; sb[k] += red[1][r * c4n + c4][k]; }
+        double* o = part + (long long)blockIdx.x * 2 * s.c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[c4 * 4 + k] = sa[k]; o[s.c + c4 * 4 + k] = sb[k]; }
+    }
+}
+
 inline bool bn_vec_ok(const BnShape& s, const void* a, const void* b, const void* c) {
     const int c4n = s.c >> 2;
     return (s.c % 4 == 0) && c4n >= 1 && c4n <= 256 && (256 % c4n == 0) && s.hw >= 8 &&
@@ -279,7 +354,10 @@ int check_shape(int n, int hw, int c, int groups, const char* who) {
     if (n <= 0 || hw <= 0 || c <= 0 || groups <= 0 || n % groups) return ctgan_fail(CTGAN_E_BADARG, "%s: bad shape", who);
     return 0;
 }
-BnShape mk(int n, int hw, int c, int groups) { return BnShape{n, hw, c, groups, (hw + POS - 1) / POS}; }
+BnShape mk(int n, int hw, int c, int groups) {
+    const int pos = (long long)n * ((hw + 255) / 256) >= 512 ? 256 : 64;
+    return BnShape{n, hw, c, groups, (hw + pos - 1) / pos, pos};
+}
 size_t part_bytes(const BnShape& s) { return (size_t)s.n * s.hc * 2 * s.c * sizeof(double); }
 size_t tot_bytes(const BnShape& s) { return (size_t)s.n * 2 * s.c * sizeof(double); }
 size_t bins_bytes(const BnShape& s, int n_labels) { return (size_t)n_labels * 2 * s.c * sizeof(double); }
@@ -303,8 +381,11 @@ int ctgan_bn_stats(const float* x, int32_t n, int32_t hw, int32_t c, int32_t gro
     const BnShape s = mk(n, hw, c, groups);
     if (ws_bytes < part_bytes(s)) return ctgan_fail(CTGAN_E_BADARG, "bn_stats: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(n * s.hc, (c + CB - 1) / CB), dim3(CB * RL), 0, st, x, s,
-                       static_cast<double*>(ws));
+    if (bn_vec_ok(s, x, x, x))
+        hipLaunchKernelGGL(bn_stats_partial_vec_kernel, dim3(n * s.hc), dim3(256), 0, st, x, s, static_cast<double*>(ws));
+    else
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(n * s.hc, (c + CB - 1) / CB), dim3(CB * RL), 0, st, x, s,
+                           static_cast<double*>(ws));
     rc = ctgan_check_launch("bn_stats_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((c + CB - 1) / CB, groups), dim3(CB * FL), 0, st,
@@ -346,8 +427,11 @@ int ctgan_bn_bwd(const float* gy, const float* x, const float* mean, const float
     double* tot = reinterpret_cast<double*>(wsb + part_bytes(s));
     double* bins = reinterpret_cast<double*>(wsb + part_bytes(s) + tot_bytes(s));
     float* s12 = reinterpret_cast<float*>(wsb + part_bytes(s) + tot_bytes(s) + bins_bytes(s, n_labels));
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(n * s.hc, (c + CB - 1) / CB), dim3(CB * RL), 0, st, gy, x, mean, rstd,
-                       scale, offset, labels, s, relu, part);
+    if (bn_vec_ok(s, gy, x, mean) && bn_vec_ok(s, rstd, scale, offset))
+        hipLaunchKernelGGL(bn_bwd_partial_vec_kernel, dim3(n * s.hc), dim3(256), 0, st, gy, x, mean, rstd, scale, offset, labels, s, relu, part);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(n * s.hc, (c + CB - 1) / CB), dim3(CB * RL), 0, st, gy, x, mean, rstd,
+                           scale, offset, labels, s, relu, part);
     rc = ctgan_check_launch("bn_bwd_partial");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_sample_kernel, dim3(n, (c + CB - 1) / CB), dim3(CB * RL), 0, st, part, s, tot);
