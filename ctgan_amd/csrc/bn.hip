@@ -54,11 +54,24 @@ __global__ __launch_bounds__(CB * FL) void bn_stats_final_kernel(const double* _
     const int g = blockIdx.y;
     const int per = s.n / s.groups;
     double a = 0., b = 0.;
-    if (c < s.c)
-        for (int i = g * per * s.hc + fl; i < (g + 1) * per * s.hc; i += FL) {
+    if (c < s.c) {
+        int i = g * per * s.hc + fl;
+        const int i1 = (g + 1) * per * s.hc;
+        for (; i + 3 * FL < i1; i += 4 * FL) {                 // four independent row loads in flight, summed in the same fixed order
+            double va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                va[u] = part[(long long)(i + u * FL) * 2 * s.c + c];
+                vb[u] = part[(long long)(i + u * FL) * 2 * s.c + s.c + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; i < i1; i += FL) {
             a += part[(long long)i * 2 * s.c + c];
             b += part[(long long)i * 2 * s.c + s.c + c];
         }
+    }
     red[0][fl][cl] = a; red[1][fl][cl] = b;
     __syncthreads();
     if (fl != 0 || c >= s.c) return;

@@ -176,8 +176,17 @@ __global__ __launch_bounds__(CS_COLS * CS_LANES) void colsum_stage_kernel(const 
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(rows, r0 + rows_per_block);
     float s = 0.f;
-    if (j < cols)
-        for (long long r = r0 + rl; r < r1; r += CS_LANES) s += x[r * ld + j];
+    if (j < cols) {
+        long long r = r0 + rl;
+        for (; r + 7 * CS_LANES < r1; r += 8 * CS_LANES) {          // 8 independent loads in flight, summed in the same fixed order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(r + u * CS_LANES) * ld + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < r1; r += CS_LANES) s += x[r * ld + j];
+    }
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && j < cols) out[(long long)blockIdx.x * cols + j] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
@@ -276,6 +285,41 @@ __global__ __launch_bounds__(256) void filter_batch_kernel(const FilterJobs t) {
     // E of a flipped spread is the rotated, I/O-swapped spread: tap (u,v) of E = transpose of spread tap (R-u, S-v)
     bool transpose = (kind != -1);                                // the dgrad layouts are [k][c] of E
     if (pre == CTGAN_FILTER_SPREAD_FLIP) { transpose = !transpose; if (u >= 0) { u = R - u; v = S - v; } }
+    if (((C | K) & 3) == 0) {                                     // 16-byte path: one float4 per thread each way
+        const int row = threadIdx.x >> 3, q4 = threadIdx.x & 7;   // 32 rows x 8 float4
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = c0 + row, k = k0 + q4 * 4;
+        if (u >= 0 && c < C && k < K) {
+            if (pre) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int rr = u - a, ss = v - bb;
+                        if (rr >= 0 && rr < R && ss >= 0 && ss < S) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(jb.src + (((long long)rr * S + ss) * C + c) * K + k);
+                            acc.x += w4.x; acc.y += w4.y; acc.z += w4.z; acc.w += w4.w;
+                        }
+                    }
+                acc.x = sc * acc.x; acc.y = sc * acc.y; acc.z = sc * acc.z; acc.w = sc * acc.w;
+            } else {
+                acc = *reinterpret_cast<const float4*>(jb.src + (((long long)u * S + v) * C + c) * K + k);
+            }
+        }
+        float* out4 = jb.dst + (long long)plane * C * K;
+        if (!transpose) {
+            if (c < C && k < K) *reinterpret_cast<float4*>(out4 + (long long)c * K + k) = acc;
+        } else {
+            __shared__ float tl4[32][33];
+            tl4[row][q4 * 4 + 0] = acc.x; tl4[row][q4 * 4 + 1] = acc.y; tl4[row][q4 * 4 + 2] = acc.z; tl4[row][q4 * 4 + 3] = acc.w;
+            __syncthreads();
+            const int kk = k0 + row, cc = c0 + q4 * 4;            // now: row = k within the tile, q4 = float4 of c
+            if (kk < K && cc < C)
+                *reinterpret_cast<float4*>(out4 + (long long)kk * C + cc) =
+                    make_float4(tl4[q4 * 4 + 0][row], tl4[q4 * 4 + 1][row], tl4[q4 * 4 + 2][row], tl4[q4 * 4 + 3][row]);
+        }
+        return;
+    }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
     float val[4];
 #pragma unroll
