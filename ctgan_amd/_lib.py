@@ -48,6 +48,12 @@ class RowSegment(ctypes.Structure):
     _fields_ = [('src_row0', c_int64), ('rows', c_int64), ('keep', ctypes.c_float), ('stream_id', ctypes.c_uint64), ('index_row0', c_int64)]
 
 
+class FoldJob(ctypes.Structure):
+    """struct ctgan_fold_job (include/ctgan_hip.h)."""
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('R', c_int32), ('S', c_int32), ('C', c_int32), ('K', c_int32),
+                ('scale', ctypes.c_float), ('flip', c_int32)]
+
+
 class EpilogueExt(ctypes.Structure):
     """struct ctgan_epilogue_ext (include/ctgan_hip.h)."""
     _fields_ = [('drop_keep', ctypes.c_float), ('drop_seed', ctypes.c_uint64), ('drop_stream_id', ctypes.c_uint64),
@@ -97,6 +103,7 @@ SIGNATURES = {
     'ctgan_filter_spread': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
     'ctgan_filter_fold': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _p]),
     'ctgan_filter_batch': (c_int, [_p, c_int32, _p]),
+    'ctgan_filter_fold_batch': (c_int, [POINTER(FoldJob), c_int32, _p]),
     'ctgan_mul': (c_int, [_p, _p, _p, c_int64, _p]),
     'ctgan_rsqrt': (c_int, [_p, _p, c_int64, c_float, _p]),
     'ctgan_sample_sum': (c_int, [_p, _p, c_int32, c_int64, c_float, _p]),

@@ -249,6 +249,32 @@ __global__ void filter_fold_kernel(const float* __restrict__ w4, float* __restri
     }
 }
 
+// several folds in one launch (blockIdx.y = job): the spread-filter gradients of a step are folded after its queued weight
+// gradients have been flushed
+struct FoldJobs { ctgan_fold_job j[CTGAN_FOLD_BATCH]; };
+__global__ void filter_fold_batch_kernel(const FoldJobs t) {
+    const ctgan_fold_job& jb = t.j[blockIdx.y];
+    const int R = jb.R, S = jb.S, C = jb.C, K = jb.K, flip = jb.flip;
+    const float* __restrict__ w4 = jb.src;
+    float* __restrict__ out = jb.dst;
+    const long long n = (long long)R * S * C * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K); long long r = i / K;
+        const int c = (int)(r % C); r /= C;
+        const int ss = (int)(r % S), rr = (int)(r / S);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int u = rr + a, v = ss + b;
+                acc += flip ? w4[(((long long)(R - u) * (S + 1) + (S - v)) * K + k) * C + c]
+                            : w4[(((long long)u * (S + 1) + v) * C + c) * K + k];
+            }
+        out[i] = jb.scale * acc;
+    }
+}
+
 // All derived filters of a weight update in one launch (blockIdx.y = job): the rotated / phase-major layouts the
 // data-gradient kernels multiply with, the spread filters of the resampled convs, and the data-gradient layouts OF the
 // spread filters straight from the parameter (job.pre) - so nothing in the launch depends on another job's output.
@@ -478,6 +504,25 @@ int ctgan_filter_fold(const float* w4, float* out, int32_t R, int32_t S, int32_t
     hipLaunchKernelGGL(filter_fold_kernel, dim3(ctgan_blocks(n, TPB)), dim3(TPB), 0, static_cast<hipStream_t>(s), w4, out, R, S, C,
                        K, scale, flip);
     return ctgan_check_launch("filter_fold");
+}
+
+int ctgan_filter_fold_batch(const ctgan_fold_job* jobs, int32_t n, ctgan_stream_t s) {
+    if (!jobs || n < 0) return ctgan_fail(CTGAN_E_BADARG, "filter_fold_batch: bad argument");
+    for (int32_t base = 0; base < n; base += CTGAN_FOLD_BATCH) {
+        FoldJobs t;
+        const int m = n - base < CTGAN_FOLD_BATCH ? n - base : CTGAN_FOLD_BATCH;
+        long long nmax = 0;
+        for (int i = 0; i < m; ++i) {
+            const ctgan_fold_job& j = t.j[i] = jobs[base + i];
+            if (!j.src || !j.dst || j.R <= 0 || j.S <= 0 || j.C <= 0 || j.K <= 0) return ctgan_fail(CTGAN_E_BADARG, "filter_fold_batch: bad job %d", base + i);
+            const long long e = (long long)j.R * j.S * j.C * j.K;
+            if (e > nmax) nmax = e;
+        }
+        hipLaunchKernelGGL(filter_fold_batch_kernel, dim3(ctgan_blocks(nmax, TPB, 1024), m), dim3(TPB), 0, static_cast<hipStream_t>(s), t);
+        const int rc = ctgan_check_launch("filter_fold_batch");
+        if (rc) return rc;
+    }
+    return CTGAN_OK;
 }
 
 int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t s) {

@@ -79,8 +79,12 @@ def deferred_wgrads():
         groups, post = _DEFER['groups'], _DEFER['post']
         _DEFER.update(on=False, groups=None, post=None)
         _flush_groups(list(groups.values()))
+        folds = [e[1:] for e in post if isinstance(e, tuple) and e[0] == 'fold']
+        if folds:
+            K.filter_fold_batch(folds)               # every spread-filter gradient of the step folded in one launch
         for fn in post:
-            fn()
+            if not isinstance(fn, tuple):
+                fn()
 
 
 def _flush_groups(grps):
@@ -662,7 +666,7 @@ class FilterSpreadFn(Function):
             C, Ko = (g.shape[3], g.shape[2]) if ctx.flip else (g.shape[2], g.shape[3])
             out = torch.empty((R, S, C, Ko), dtype=torch.float32, device=g.device)
             scale, flip = ctx.scale, ctx.flip
-            _DEFER['post'].append(lambda: K.filter_fold(g, scale, flip, out=out))
+            _DEFER['post'].append(('fold', g, scale, flip, out))
             return out, None, None
         return FilterFoldFn.apply(g, ctx.scale, ctx.flip), None, None
 

@@ -605,6 +605,22 @@ def filter_fold(w4, scale, flip, out=None):
     return out
 
 
+def filter_fold_batch(jobs):
+    """jobs = [(w4, scale, flip, out), ...]: every fold in one launch (csrc: ctgan_filter_fold_batch)."""
+    from ._lib import FoldJob
+    if not jobs:
+        return
+    arr = (FoldJob * len(jobs))()
+    for i, (w4, scale, flip, out) in enumerate(jobs):
+        _need_dev(w4, out)
+        assert w4.is_contiguous() and out.is_contiguous()
+        R, S = w4.shape[0] - 1, w4.shape[1] - 1
+        C, Ko = (w4.shape[3], w4.shape[2]) if flip else (w4.shape[2], w4.shape[3])
+        assert tuple(out.shape) == (R, S, C, Ko)
+        arr[i] = FoldJob(w4.data_ptr(), out.data_ptr(), R, S, C, Ko, scale, 1 if flip else 0)
+    check(lib.ctgan_filter_fold_batch(arr, len(jobs), _stream()), 'filter_fold_batch')
+
+
 def mul(x, y):
     """Elementwise product of two dense tensors of the same shape and layout."""
     _need_dev(x, y)

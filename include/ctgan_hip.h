@@ -230,6 +230,16 @@ typedef struct ctgan_filter_job {
     float pre_scale;
 } ctgan_filter_job;
 int ctgan_filter_batch(const ctgan_filter_job* jobs, int32_t n, ctgan_stream_t stream);
+/* Several ctgan_filter_fold calls in one launch: dst[R,S,C,K] = scale * fold(src [(R+1),(S+1),C,K] or, flip, [(R+1),(S+1),K,C]). */
+#define CTGAN_FOLD_BATCH 16
+typedef struct ctgan_fold_job {
+    const float* src;
+    float* dst;
+    int32_t R, S, C, K;
+    float scale;
+    int32_t flip;
+} ctgan_fold_job;
+int ctgan_filter_fold_batch(const ctgan_fold_job* jobs, int32_t n, ctgan_stream_t stream);
 /* ---- Layernorm primitives (TF/tflib/ops/layernorm.py:6-20: tf.nn.moments over (C,H,W) per sample +
  *      tf.nn.batch_normalization with per-channel scale/offset).  The operator is composed of these linear /
  *      elementwise maps so that its first AND second derivatives (gradient penalty through a layer-normalised

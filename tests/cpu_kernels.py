@@ -302,6 +302,12 @@ def filter_batch(jobs):
 
 
 @_export
+def filter_fold_batch(jobs):
+    for w4, scale, flip, out in jobs:
+        filter_fold(w4, scale, flip, out=out)
+
+
+@_export
 def filter_fold(w4, scale, flip, out=None):
     if flip:
         w4 = torch.flip(w4, (0, 1)).permute(0, 1, 3, 2)

@@ -593,6 +593,19 @@ def test_filter_batch_matches_single_kernels(K):
                     assert torch.equal(ref, K.repack_filter(sp, gs).reshape(-1))
 
 
+def test_filter_fold_batch_matches_single_folds(K):
+    """ctgan_filter_fold_batch: every fold of a step in one launch = the stand-alone fold kernel, job by job."""
+    g = torch.Generator().manual_seed(19)
+    jobs, refs = [], []
+    for (R, S, C, Ko, flip) in ((3, 3, 128, 128, False), (3, 3, 128, 128, True), (1, 1, 128, 64, False), (3, 3, 40, 24, True)) * 5:
+        w4 = dev(torch.randn(*((R + 1, S + 1, Ko, C) if flip else (R + 1, S + 1, C, Ko)), generator=g))
+        out = torch.empty(R, S, C, Ko, device='cuda')
+        jobs.append((w4, 0.25, flip, out)); refs.append(K.filter_fold(w4, 0.25, flip))
+    K.filter_fold_batch(jobs)                       # 20 jobs: two launches
+    for (w4, sc, flip, out), ref in zip(jobs, refs):
+        assert torch.equal(out, ref)
+
+
 def test_fused_philox_dropout_equals_draw_then_dropout(K):
     """ctgan_dropout_rng regenerates the mask from (seed, site, device counter): bit-identical to drawing the
     uniform tensor first; backward and double backward reuse the same mask."""
