@@ -445,6 +445,61 @@ __global__ __launch_bounds__(256) void tail_heads_bwd_kernel(const float* __rest
     }
 }
 
+// ---- generator-step loss on the critic's outputs (TF/CT_gan_cifar_resnet.py:321-330): cost = -mean(d) + scale * CE(a, labels) ---------
+// forward: one workgroup (batch means; the softmax probabilities are kept for the backward)
+__global__ __launch_bounds__(256) void gen_heads_loss_kernel(const float* __restrict__ d, const float* __restrict__ a,
+                                                             const int32_t* __restrict__ labels, int n, int ncls, float scale,
+                                                             float* __restrict__ probs, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float sd = 0.f, sl = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        sd += d[i];
+        if (a) {
+            const float* z = a + (long long)i * ncls;
+            float mx = z[0];
+            for (int k = 1; k < ncls; ++k) mx = fmaxf(mx, z[k]);
+            float se = 0.f;
+            for (int k = 0; k < ncls; ++k) se += expf(z[k] - mx);
+            const float lse = logf(se);
+            for (int k = 0; k < ncls; ++k) probs[(long long)i * ncls + k] = expf(z[k] - mx - lse);
+            sl += (mx + lse) - z[labels[i]];
+        }
+    }
+    sd = block_sum(sd, sh); sl = block_sum(sl, sh);
+    if (threadIdx.x == 0) out[0] = -(sd / (float)n) + (a ? scale * (sl / (float)n) : 0.f);
+}
+// backward, one workgroup per sample: gradient w.r.t. the last conv's result through both Linear layers, the spatial mean and
+// the relu/dropout mask:  gy[row,hw,j] = y > 0 ? gout * (-w_out[j] + scale * sum_k (p_k - 1[k = label]) w_ac[j,k]) / n / hw * mask_scale : 0
+__global__ __launch_bounds__(256) void gen_heads_bwd_kernel(const float* __restrict__ y, const float* __restrict__ probs,
+                                                            const int32_t* __restrict__ labels, const float* __restrict__ gout, int n,
+                                                            int hw, int nf, int ncls, float scale, float mask_scale,
+                                                            const float* __restrict__ w_out, const float* __restrict__ w_ac,
+                                                            float* __restrict__ gy) {
+    extern __shared__ float sm[];                          // t [nf]
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float g0 = gout[0] / (float)n;
+    for (int j = tid; j < nf; j += 256) {
+        float v = -g0 * w_out[j];
+        if (w_ac) {
+            const int lab = labels[row];
+            for (int k = 0; k < ncls; ++k)
+                v += g0 * scale * (probs[(long long)row * ncls + k] - (lab == k ? 1.f : 0.f)) * w_ac[(long long)j * ncls + k];
+        }
+        sm[j] = v * (1.f / (float)hw);
+    }
+    __syncthreads();
+    const long long base = (long long)row * hw * nf;
+    const int n4 = (hw * nf) >> 2;
+    for (int q = tid; q < n4; q += 256) {
+        const int j = (q * 4) % nf;
+        const float4 yv = *reinterpret_cast<const float4*>(y + base + (long long)q * 4);
+        float4 o;
+        o.x = yv.x > 0.f ? sm[j] * mask_scale : 0.f;     o.y = yv.y > 0.f ? sm[j + 1] * mask_scale : 0.f;
+        o.z = yv.z > 0.f ? sm[j + 2] * mask_scale : 0.f; o.w = yv.w > 0.f ? sm[j + 3] * mask_scale : 0.f;
+        *reinterpret_cast<float4*>(gy + base + (long long)q * 4) = o;
+    }
+}
+
 // Gradient-penalty branch: dD/dy of D = mean_hw(y) . w_out for the last block's output y = relu(dropout(z)), taken w.r.t. z:
 //   gz[row,hw,j] = y > 0 ? w_out[j] / hw * mask_scale : 0      (the value D(x_hat) itself is never needed, :284)
 __global__ void gp_head_grad_kernel(const float* __restrict__ y, const float* __restrict__ w_out, long long n4, int nf, float s,
@@ -596,6 +651,29 @@ int ctgan_tail_heads_bwd(const float* y, const float* d, const float* f, const f
     hipLaunchKernelGGL(tail_heads_bwd_kernel, dim3(3 * B + wblocks), dim3(256), sh, static_cast<hipStream_t>(s), y, d, f, probs, labels, ct_i,
                        gout, n_gout, B, hw, nf, ncls, lambda2, M, acgan_scale, mask_scale, w_out, w_ac, gy, gw_out, gb_out, gw_ac, gb_ac);
     return ctgan_check_launch("tail_heads_bwd");
+}
+int ctgan_gen_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, const float* w_out, const float* b_out, const float* w_ac,
+                        const float* b_ac, int32_t ncls, const int32_t* labels, float ac_scale, float* f, float* d, float* a, float* probs,
+                        float* out, ctgan_stream_t s) {
+    if (!y || !f || !d || !w_out || !out || n <= 0 || hw <= 0 || nf <= 0 || (nf & 3) || nf > 1024 ||
+        (w_ac && (!a || !labels || !probs || ncls <= 0)) || (reinterpret_cast<uintptr_t>(y) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "gen_heads_fwd: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    hipLaunchKernelGGL(tail_heads_rows_kernel, dim3(n), dim3(256), 0, st, y, hw, nf, 0, w_out, b_out, w_ac, b_ac, ncls, f, d,
+                       w_ac ? a : (float*)nullptr, 0, (const int32_t*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    int rc = ctgan_check_launch("tail_heads_rows");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gen_heads_loss_kernel, dim3(1), dim3(256), 0, st, d, w_ac ? a : (const float*)nullptr, labels, n, ncls, ac_scale, probs, out);
+    return ctgan_check_launch("gen_heads_loss");
+}
+int ctgan_gen_heads_bwd(const float* y, const float* probs, const int32_t* labels, const float* gout, int32_t n, int32_t hw, int32_t nf,
+                        int32_t ncls, float ac_scale, float mask_scale, const float* w_out, const float* w_ac, float* gy, ctgan_stream_t s) {
+    if (!y || !gout || !w_out || !gy || n <= 0 || hw <= 0 || nf <= 0 || (nf & 3) || (w_ac && (!probs || !labels || ncls <= 0)) ||
+        ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gy)) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "gen_heads_bwd: bad argument");
+    hipLaunchKernelGGL(gen_heads_bwd_kernel, dim3(n), dim3(256), (size_t)nf * sizeof(float), static_cast<hipStream_t>(s), y, probs, labels, gout,
+                       n, hw, nf, ncls, ac_scale, mask_scale, w_out, w_ac, gy);
+    return ctgan_check_launch("gen_heads_bwd");
 }
 int ctgan_gp_head_grad(const float* y, const float* w_out, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gz,
                        ctgan_stream_t s) {

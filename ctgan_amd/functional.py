@@ -1282,6 +1282,43 @@ def critic_tail_heads(y, w_out, b_out, w_ac, b_ac, labels, B, lam2=2.0, M=0.0, a
                                    float(mask_scale), gp)
 
 
+class GenTailHeadsFn(Function):
+    """Generator-step loss from the last critic block's relu(dropout(.)) output y (produced with epi['mask_done']): mean + both
+    Linear heads + (-mean D + scale * CE) in two launches, the gradient w.r.t. the conv result in one (:321-330).  The critic's
+    weights get no gradient in this step.  First-order only."""
+
+    @staticmethod
+    def forward(ctx, y, w_out, b_out, w_ac, b_ac, labels, ac_scale, mask_scale):
+        out, probs, d = K.gen_heads_fwd(y, w_out, b_out, w_ac, b_ac, labels, ac_scale)
+        ctx.cfg = (ac_scale, mask_scale)
+        ctx.labels = labels
+        ctx.has_a = w_ac is not None
+        if ctx.has_a:
+            ctx.save_for_backward(y, w_out, w_ac, probs)
+        else:
+            ctx.save_for_backward(y, w_out)
+        ctx.mark_non_differentiable(d)
+        return out.reshape(()), d
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g0, _gd=None):
+        ac_scale, mask_scale = ctx.cfg
+        if ctx.has_a:
+            y, w_out, w_ac, probs = ctx.saved_tensors
+        else:
+            (y, w_out), w_ac, probs = ctx.saved_tensors, None, None
+        gy = K.gen_heads_bwd(y, probs, ctx.labels, g0.reshape(1).contiguous(), ac_scale, mask_scale, w_out, w_ac)
+        return gy, None, None, None, None, None, None, None
+
+
+def gen_tail_heads(y, w_out, b_out, w_ac, b_ac, labels, ac_scale, mask_scale):
+    """-> (cost, d [n])"""
+    return GenTailHeadsFn.apply(y, w_out.detach(), b_out.detach() if b_out is not None else None,
+                                w_ac.detach() if w_ac is not None else None, b_ac.detach() if b_ac is not None else None, labels,
+                                float(ac_scale), float(mask_scale))
+
+
 class GpHeadGradFn(Function):
     """dD/dz at the last block of the critic for the gradient-penalty branch (:284): D = mean_hw(relu(dropout(z))) . w_out, so
     gz = (y > 0) * w_out / hw / keep with y = relu(dropout(z)) - one launch instead of head forward + ones + Linear data

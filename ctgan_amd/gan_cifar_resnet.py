@@ -535,10 +535,19 @@ class Trainer:
             fake_labels = rng.labels(n, 10)
             z, u = None, None
         x = Generator(n, fake_labels, noise=z, groups=2, rng=rng)
+        use_ac = cfg.CONDITIONAL and cfg.ACGAN
         with F.weight_grads(False):                      # only dD/dx is needed from the critic
+            if _heads_fusable(rnd, rng):
+                # mean + both Linear heads + the loss: two launches forward, one backward (F.gen_tail_heads)
+                y = DiscriminatorTailBody(DiscriminatorTrunk(x), 0.8, 0.5, 0.5, rng=rng, mask_done=True)
+                cost, _ = F.gen_tail_heads(y, lib.param('Discriminator.Output.W'), lib.param('Discriminator.Output.b'),
+                                           lib.param('Discriminator.ACGANOutput.W') if use_ac else None,
+                                           lib.param('Discriminator.ACGANOutput.b') if use_ac else None, fake_labels,
+                                           cfg.ACGAN_SCALE_G if use_ac else 0.0, 1.0 / 0.5)
+                return {'cost': cost, 'samples': x}
             d, _, a = Discriminator(x, fake_labels, 0.8, 0.5, 0.5, u=u, rng=rng)
         cost = F.mean_diff(d, n, 0, -1.0, 0.0)
-        if cfg.CONDITIONAL and cfg.ACGAN:
+        if use_ac:
             ce, _ = F.softmax_cross_entropy(a, fake_labels)
             cost = cost + cfg.ACGAN_SCALE_G * ce
         return {'cost': cost, 'samples': x}

@@ -931,6 +931,32 @@ def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_s
     return gy, gw_out, gb_out, gw_ac, gb_ac
 
 
+def gen_heads_fwd(y, w_out, b_out, w_ac, b_ac, labels, ac_scale):
+    """-> (cost [1] = -mean(d) + ac_scale * CE(a, labels), probs [n,ncls] or None, d [n]) from the last critic block's output."""
+    _need_dev(y, w_out, b_out, w_ac, b_ac, labels)
+    n, hw, nf = _cl_rows(y)
+    dev = y.device
+    f = torch.empty(n, nf, dtype=torch.float32, device=dev); d = torch.empty(n, dtype=torch.float32, device=dev)
+    ncls = w_ac.shape[1] if w_ac is not None else 0
+    a = torch.empty(n, ncls, dtype=torch.float32, device=dev) if w_ac is not None else None
+    probs = torch.empty(n, ncls, dtype=torch.float32, device=dev) if w_ac is not None else None
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    check(lib.ctgan_gen_heads_fwd(_ptr(y), n, hw, nf, _ptr(w_out), _ptr(b_out), _ptr(w_ac), _ptr(b_ac), ncls, _ptr(labels), ac_scale, _ptr(f),
+                                  _ptr(d), _ptr(a), _ptr(probs), _ptr(out), _stream()), 'gen_heads_fwd')
+    return out, probs, d
+
+
+def gen_heads_bwd(y, probs, labels, gout, ac_scale, mask_scale, w_out, w_ac):
+    """gradient of that cost w.r.t. the last critic conv's result (mask and 1/keep included), one launch."""
+    _need_dev(y, probs, labels, gout, w_out, w_ac)
+    n, hw, nf = _cl_rows(y)
+    gy = empty_cl(n, nf, y.shape[2], y.shape[3], y.device)
+    ncls = w_ac.shape[1] if w_ac is not None else 0
+    check(lib.ctgan_gen_heads_bwd(_ptr(y), _ptr(probs), _ptr(labels), _ptr(gout), n, hw, nf, ncls, ac_scale, mask_scale, _ptr(w_out), _ptr(w_ac),
+                                  _ptr(gy), _stream()), 'gen_heads_bwd')
+    return gy
+
+
 def gp_head_grad(y, w_out, mask_scale):
     """gz = (y > 0) * w_out / hw * mask_scale  (dD/dz of D = mean_hw(relu(dropout(z))) . w_out)."""
     _need_dev(y, w_out)

@@ -347,6 +347,16 @@ int ctgan_tail_heads_bwd(const float* y, const float* d, const float* f, const f
                          int32_t ncls, float lambda2, float M, float acgan_scale, float mask_scale, const float* w_out,
                          const float* w_ac, float* gy, float* gw_out, float* gb_out, float* gw_ac, float* gb_ac,
                          ctgan_stream_t stream);
+/* Generator-step loss on the critic's output head (TF/CT_gan_cifar_resnet.py:321-330): cost = -mean(d) + ac_scale * CE(a, labels)
+ * with f, d, a as in ctgan_tail_heads_fwd (two launches), and its backward straight to the gradient w.r.t. the last critic
+ * conv's result (both Linear data gradients, the mean's broadcast, the relu/dropout mask) in one launch; the critic's weights
+ * get no gradient in the generator step.                                                                                    */
+int ctgan_gen_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, const float* w_out, const float* b_out,
+                        const float* w_ac, const float* b_ac, int32_t ncls, const int32_t* labels, float ac_scale, float* f,
+                        float* d, float* a, float* probs, float* out, ctgan_stream_t stream);
+int ctgan_gen_heads_bwd(const float* y, const float* probs, const int32_t* labels, const float* gout, int32_t n, int32_t hw,
+                        int32_t nf, int32_t ncls, float ac_scale, float mask_scale, const float* w_out, const float* w_ac,
+                        float* gy, ctgan_stream_t stream);
 int ctgan_gp_head_grad(const float* y, const float* w_out, int32_t n, int32_t hw, int32_t nf, float mask_scale,
                        float* gz, ctgan_stream_t stream);
 int ctgan_gp_head_wgrad(const float* gg, const float* y, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gw,

@@ -531,6 +531,29 @@ def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_s
 
 
 @_export
+def gen_heads_fwd(y, w_out, b_out, w_ac, b_ac, labels, ac_scale):
+    f, d, a = tail_heads_fwd(y, w_out, b_out, w_ac, b_ac)
+    cost = -d.mean()
+    probs = None
+    if a is not None:
+        probs = torch.softmax(a, dim=1)
+        cost = cost + ac_scale * (-torch.log(probs[torch.arange(a.shape[0]), labels.long()]).mean())
+    return cost.reshape(1).float(), probs, d
+
+
+@_export
+def gen_heads_bwd(y, probs, labels, gout, ac_scale, mask_scale, w_out, w_ac):
+    n = y.shape[0]; hw = y.shape[2] * y.shape[3]
+    g0 = gout.reshape(()) / n
+    t = (-g0 * w_out.reshape(1, -1)).expand(n, -1)
+    if w_ac is not None:
+        oh = torch.zeros_like(probs); oh[torch.arange(n), labels.long()] = 1
+        t = t + (g0 * ac_scale * (probs - oh)) @ w_ac.t()
+    gy = (t / hw)[:, :, None, None] * (y > 0).to(y.dtype) * mask_scale
+    return gy.contiguous(memory_format=torch.channels_last)
+
+
+@_export
 def gp_head_grad(y, w_out, mask_scale):
     hw = y.shape[2] * y.shape[3]
     return ((y > 0).to(y.dtype) * (w_out.reshape(1, -1, 1, 1) / hw * mask_scale)).contiguous(memory_format=torch.channels_last)

@@ -279,6 +279,32 @@ def test_fused_critic_heads_equal_separate_head_kernels(setup, dim, B):
             assert float((a_ - b_).norm()) <= 5e-5 * float(b_.norm()) + 1e-6 * gmax, n
 
 
+@pytest.mark.parametrize('dim,B', [(32, 6), (128, 64)])
+def test_fused_generator_heads_equal_separate_head_kernels(setup, dim, B):
+    """HEAD_FUSION in the generator step (F.gen_tail_heads) against the op-by-op head on identical Philox streams: the cost and
+    every generator parameter gradient."""
+    import ctgan_amd.functional as F
+    R, lib = setup(dim, B)
+    tr = R.Trainer(seed=13)
+    res = {}
+    for mode in (False, True):
+        R.HEAD_FUSION = mode
+        try:
+            tr.rng.begin_step()
+            out = tr.g_losses()
+            with F.deferred_wgrads():
+                grads = torch.autograd.grad(out['cost'], tr.g_params, allow_unused=True)
+            res[mode] = (out['cost'].detach().clone(), out['samples'].detach().clone(), [None if t is None else t.detach().clone() for t in grads])
+        finally:
+            R.HEAD_FUSION = True
+    assert _rel_l2(res[True][0], res[False][0]) < 1e-5 and torch.equal(res[True][1], res[False][1])
+    gmax = max(float(b_.abs().max()) for b_ in res[False][2] if b_ is not None)
+    for (n, _), a_, b_ in zip(tr.g_named, res[True][2], res[False][2]):
+        assert (a_ is None) == (b_ is None), n
+        if a_ is not None:
+            assert float((a_ - b_).norm()) <= 5e-5 * float(b_.norm()) + 1e-6 * gmax, n
+
+
 def test_layernorm_critic_d_step_on_gpu(setup):
     """NORMALIZATION_D=True: the gradient penalty differentiates Layernorm twice (functional.layer_norm primitives)."""
     import ctgan_amd.gan_cifar_resnet as R0

@@ -279,6 +279,27 @@ def test_fused_critic_heads_equal_separate_heads(small):
             _cmp(a_, b_, 2e-5, n)
 
 
+def test_fused_generator_heads_equal_separate_heads(small):
+    """Host wiring of GenTailHeadsFn against the op-by-op generator loss on the CPU stand-ins and identical random streams."""
+    R, lib = small
+    tr = R.Trainer(seed=6)
+    res = {}
+    for mode in (False, True):
+        R.HEAD_FUSION = mode
+        try:
+            tr.rng.begin_step()
+            out = tr.g_losses()
+            grads = torch.autograd.grad(out['cost'], tr.g_params, allow_unused=True)
+            res[mode] = (out['cost'].detach().clone(), [None if t is None else t.detach().clone() for t in grads])
+        finally:
+            R.HEAD_FUSION = True
+    _cmp(res[True][0], res[False][0], 1e-5, 'cost')
+    for (n, _), a_, b_ in zip(tr.g_named, res[True][1], res[False][1]):
+        assert (a_ is None) == (b_ is None), n
+        if a_ is not None:
+            _cmp(a_, b_, 5e-5, n, atol=1e-6)
+
+
 def test_layernorm_critic_step_matches_oracle(cpu_kernels):
     """NORMALIZATION_D=True (TF/CT_gan_cifar_resnet.py:76-77: Layernorm after every critic conv input): the critic is no
     longer piecewise linear, so the gradient penalty differentiates Layernorm twice - forward, losses and every critic
