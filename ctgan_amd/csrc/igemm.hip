@@ -791,6 +791,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_kernel(con
     const int nk = (k_end - k_begin + BK - 1) / BK;
     const int PQ = g.P * g.Q;
 
+    const bool pow2 = ((PQ & (PQ - 1)) | (g.Q & (g.Q - 1))) == 0;      // the per-pixel table is filled by one wave: keep it short
+    const int pq_sh = __builtin_ctz(PQ), q_sh = __builtin_ctz(g.Q);
     auto fill_ptab = [&](int kt) {
         if (tid < BK) {
             const int buf = kt & 1, px = k_begin + kt * BK + tid;
@@ -985,12 +987,16 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgradParams& p, const int 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xp), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DYp), 0, dy_bytes, 0x00020000);
 
+    const bool pow2 = ((PQ & (PQ - 1)) | (g.Q & (g.Q - 1))) == 0;      // the per-pixel table is filled by one wave: keep it short
+    const int pq_sh = __builtin_ctz(PQ), q_sh = __builtin_ctz(g.Q);
     auto fill_ptab = [&](int kt) {
         if (tid < BK) {
             const int px = k_begin + kt * BK + tid;
             unsigned xo = 0xFFFFFFFFu, yo = 0xFFFFFFFFu;
             if (px < k_end) {
-                const int n = px / PQ, rem = px - n * PQ, pp = rem / g.Q, qq = rem - pp * g.Q;
+                int n, rem, pp, qq;
+                if (pow2) { n = px >> pq_sh; rem = px & (PQ - 1); pp = rem >> q_sh; qq = rem & (g.Q - 1); }     // no integer divisions
+                else { n = px / PQ; rem = px - n * PQ; pp = rem / g.Q; qq = rem - pp * g.Q; }
                 int ih, iw;
                 const bool ok = src_index(pp * g.stride - g.pad_t + ar, g.shift, g.mask, g.H, ih) &
                                 src_index(qq * g.stride - g.pad_l + as_, g.shift, g.mask, g.W, iw);
@@ -1087,7 +1093,7 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgradParams& p, const int 
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s % (PD + 1)][i], b[s % (PD + 1)][j], acc[i][j], 0, 0, 0);
             if (s == 3 && kt + 1 < nk) store_tile(Asn, Bsn);
-            if (s == 7 && kt + 2 < nk) load_tile(kt + 2);
+            if (s == 4 && kt + 2 < nk) load_tile(kt + 2);      // right after the store freed the registers: the longest latency budget
             if (s == 9 && kt + 3 < nk) fill_ptab(kt + 3);
             if (s == 11 && do_bias) {
                 float t = 0.f;
