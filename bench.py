@@ -167,14 +167,18 @@ def measure_roofline(trainer, next_batch, K, torch):
     name, (cnt, fl, tt) = max(agg.items(), key=lambda kv: kv[1][2])
     achieved = fl / tt / 1e12
     traffic = None
-    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json), scaled by flops
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-        if pmc['kernel'] == name:
-            traffic = {'hbm_bytes_per_launch': round(pmc['hbm_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
-                       'algorithmic_bytes_per_launch': round(pmc['algorithmic_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
-                       'source': 'profiles/r01_pmc_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, scaled to this launch mix)'}
-    except Exception:
-        traffic = None
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of the same kernel (profiles/r01_pmc_traffic*.json: separate
+    # --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), scaled by flops to this launch mix
+    for fn in ('r01_pmc_traffic_64x128.json', 'r01_pmc_traffic.json'):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+            if pmc['kernel'] == name:
+                traffic = {'hbm_bytes_per_launch': round(pmc['hbm_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
+                           'algorithmic_bytes_per_launch': round(pmc['algorithmic_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
+                           'source': 'profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, scaled to this launch mix)' % fn}
+                break
+        except Exception:
+            pass
     return {
         'bound': 'mfma', 'kernel': name, 'launches': cnt,
         'flops_per_launch': round(fl / cnt / 1e9, 3), 'avg_launch_us': round(tt / cnt * 1e6, 2),
