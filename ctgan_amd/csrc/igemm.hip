@@ -1292,7 +1292,7 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
     static const int force = [] { const char* e = getenv("CTGAN_FWD_CFG"); return e ? atoi(e) : 0; }();
     int cfg = force;
     if (!cfg) {
-        // measured on MI355X (tools_cfg_sweep.py, 128->128 3x3): the best tile shrinks with the number of
+        // measured on MI355X (tools/cfg_sweep.py, 128->128 3x3): the best tile shrinks with the number of
         // output rows so that >= ~1024 waves exist; the register ring depth RD bought nothing (kept at 1)
         const long long rows = M * (p.phases > 1 ? p.phases : 1) * ((p.Ng + 127) / 128);
         if (rows >= 65536) {
@@ -1303,7 +1303,7 @@ int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
             const double e1 = (double)t1 / (double)(((t1 + 511) / 512) * 512), e2 = 0.95 * (double)t2 / (double)(((t2 + 767) / 768) * 768);
             cfg = e1 >= e2 ? 1 : 2;
             // the 4-phase data gradient has only 16 K slices per tile: three resident 64x128 workgroups per CU cover the
-            // per-tile prologue / epilogue better than two 128x128 ones once there are several rounds (tools_ph4_sweep.py)
+            // per-tile prologue / epilogue better than two 128x128 ones once there are several rounds (tools/ph4_sweep.py)
             if (p.phases > 1 && rows >= 131072) cfg = 2;
         }
         else if (rows > 24576) cfg = 2;
@@ -1403,7 +1403,7 @@ WPlan wgrad_plan(int C, int Mtot, int Ng, int Kg) {
     if (C % 32 == 0) {           // vector-capable: the M tile must lie inside one filter tap
         if (Ng > 64) {
             // few pixels => prefer smaller tiles: more output tiles, fewer split-K slabs to reduce
-            // measured (tools_wgrad_sweep.py): ~2 workgroups per CU with the largest tile that still leaves
+            // measured (tools/wgrad_sweep.py): ~2 workgroups per CU with the largest tile that still leaves
             // >= ~16 K slices per split
             if (C % 128 == 0 && Kg >= 32768) w.tile = W128x128;
             else if (C % 64 == 0 && Kg >= 8192) w.tile = W64x128;
@@ -1544,7 +1544,7 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
     const int max_splits = (Kg + 4 * BK - 1) / (4 * BK);
     int best = 1;
     // one or two output tiles (few-channel / skinny weight gradients): a streaming reduction over the pixel axis,
-    // bound by load latency.  Measured (tools_skinny_w.py): ~384 pixels per workgroup, at most one workgroup per CU;
+    // bound by load latency.  Measured (tools/skinny_w.py): ~384 pixels per workgroup, at most one workgroup per CU;
     // more splits only add slab traffic and pipeline fill/drain.
     static const int force_k = [] { const char* e = getenv("CTGAN_WGRAD_K"); return e ? atoi(e) : 0; }();
     if (tiles <= 2 && !force_k) {

@@ -60,7 +60,7 @@ class Config:
 cfg = Config()
 import os as _os
 # A/B switch: fold the critic's ReLUs into the conv gathers / dgrad epilogues (relu(x) never materialised).
-# Measured on MI355X (tools_fuse_bench.py): the forward gather and the wgrad relu-on-load are free (the relu(x)
+# Measured on MI355X (tools/fuse_bench.py): the forward gather and the wgrad relu-on-load are free (the relu(x)
 # tensor is never written or re-read); the mask in the dgrad EPILOGUE is not (it lengthens the un-overlapped tail of
 # an MFMA kernel by as much as the stand-alone mask kernel costs), so the backward keeps the stand-alone kernel
 # (functional.MASK_IN_DGRAD_EPILOGUE = False).

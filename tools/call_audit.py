@@ -4,6 +4,8 @@ gradient / weight gradient the host issues, with rows and geometry, and the FLOP
 SURVEY 8(d) (D step B*(13 F_D - 3 f1) without the generator forward, G step 128*(3 F_G + 2 F_D))."""
 import collections
 import torch
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctgan_amd.kernels as K
 import ctgan_amd.gan_cifar_resnet as R
 import ctgan_amd.tflib as lib

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Sweep the pipelined-conv tile configurations over the small/medium shapes (run per config via env)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 SHAPES = [(192, 8), (128, 8), (64, 8), (256, 8), (128, 4), (64, 4), (128, 16), (64, 16), (192, 16), (32, 16), (64, 32), (192, 32)]

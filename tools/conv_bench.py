@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Micro-benchmark of the conv kernel family on the shapes of the ResNet CT-WGAN step.
-usage: python tools_conv_bench.py [reps]   (GPU box)"""
+usage: python tools/conv_bench.py [reps]   (GPU box)"""
 import sys
 import os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 

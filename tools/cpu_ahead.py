@@ -5,6 +5,8 @@ GraphedTrainer.train_iteration (no device syncs inside the loop), next to the GP
 import time
 import numpy as np
 import torch
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctgan_amd.gan_cifar_resnet as R
 import ctgan_amd.tflib as lib
 from ctgan_amd.engine import GraphedTrainer

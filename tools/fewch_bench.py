@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Micro-benchmark of the few-channel direct kernels (csrc/fewch.hip) on the CT-WGAN shapes, with the HBM floor
-(bytes of the wide tensor / 4 TB/s) beside each time.   usage: python tools_fewch_bench.py   (GPU box)"""
+(bytes of the wide tensor / 4 TB/s) beside each time.   usage: python tools/fewch_bench.py   (GPU box)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 

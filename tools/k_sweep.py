@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Where does igemm_fwd_pipe<128x128> lose time: per tile (prologue/epilogue) or per K slice?
-usage: python tools_k_sweep.py   (GPU box)"""
+usage: python tools/k_sweep.py   (GPU box)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Which Python call sites launch the torch plumbing kernels (add / fill / copy / cat) of one eager D and G step.
-usage: python tools_op_sources.py   (GPU box)"""
+usage: python tools/op_sources.py   (GPU box)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from collections import Counter
 import torch
 from torch.profiler import profile, ProfilerActivity

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Tile-config sweep (env CTGAN_FWD_CFG) on the 4-phase stride-2 data gradient and the 4x4 stride-2 forward conv of the
-resampled layers.   usage: CTGAN_FWD_CFG=k python tools_ph4_sweep.py"""
+resampled layers.   usage: CTGAN_FWD_CFG=k python tools/ph4_sweep.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 def timeit(fn, reps=30):

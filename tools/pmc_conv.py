@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Run ONE conv shape/op repeatedly (for rocprofv3 --pmc passes).  usage: tools_pmc_conv.py op N H reps"""
+"""Run ONE conv shape/op repeatedly (for rocprofv3 --pmc passes).  usage: tools/pmc_conv.py op N H reps"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 op, N, H, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])

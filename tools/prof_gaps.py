@@ -2,7 +2,7 @@
 """Steady-state analysis of a rocprofv3 kernel trace (rocpd SQLite) of `bench.py --no-roofline --no-cpu-baseline`:
 the window of the last `iters` training iterations (delimited by adam_kernel launches: 6 per iteration),
 its busy time, idle gaps, and the per-kernel table inside that window.
-usage: python tools_prof_gaps.py results.db [iters=8] [top=40]"""
+usage: python tools/prof_gaps.py results.db [iters=8] [top=40]"""
 import sqlite3
 import sys
 from collections import defaultdict

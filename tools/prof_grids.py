@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Grid-size histogram of the kernels whose name contains a pattern, inside the steady-state window of a rocprofv3
-kernel trace (see tools_prof_gaps.py): identifies WHICH tensors the torch plumbing kernels (add / fill / copy) touch.
-usage: python tools_prof_grids.py results.db pattern [iters=8]"""
+kernel trace (see tools/prof_gaps.py): identifies WHICH tensors the torch plumbing kernels (add / fill / copy) touch.
+usage: python tools/prof_grids.py results.db pattern [iters=8]"""
 import sqlite3, sys
 from collections import Counter
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Ordered launch sequence of the LAST unit in a rocprofv3 kernel trace (rocpd SQLite), the unit being delimited by a
 marker kernel (default gp_mean_kernel: one per `bench.py --gp-unit-only` replay), with per-launch durations averaged
-over the last `reps` units.  usage: python tools_prof_seq.py results.db [marker=gp_mean_kernel] [reps=10] [back=0]
+over the last `reps` units.  usage: python tools/prof_seq.py results.db [marker=gp_mean_kernel] [reps=10] [back=0]
 (back = k: show the unit k markers before the last one instead, e.g. marker adam_kernel, reps 1, back 5 = the generator
 step of the last iteration of a `bench.py --no-roofline` trace)"""
 import re

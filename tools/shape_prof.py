@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Per (kernel variant, conv geometry) time table of one eager training iteration (4 launches per event bracket).
-usage: python tools_shape_prof.py [top]   (GPU box)"""
+usage: python tools/shape_prof.py [top]   (GPU box)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 import ctgan_amd.gan_cifar_resnet as R

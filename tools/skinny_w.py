@@ -1,5 +1,6 @@
 import sys, os
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 def timeit(fn, reps=20):

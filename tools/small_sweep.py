@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""fwd tile config sweep on the small-M conv shapes (env CTGAN_FWD_CFG).  usage: CTGAN_FWD_CFG=k python tools_small_sweep.py"""
+"""fwd tile config sweep on the small-M conv shapes (env CTGAN_FWD_CFG).  usage: CTGAN_FWD_CFG=k python tools/small_sweep.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
 def timeit(fn, reps=50):
