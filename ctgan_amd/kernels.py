@@ -973,7 +973,8 @@ def gp_head_wgrad(gg, y, mask_scale, like):
     n, hw, nf = _cl_rows(y)
     assert tuple(gg.shape) == tuple(y.shape) and gg.permute(0, 2, 3, 1).is_contiguous()
     gw = torch.empty_like(like)
-    check(lib.ctgan_gp_head_wgrad(_ptr(gg), _ptr(y), n, hw, nf, mask_scale, _ptr(gw), _stream()), 'gp_head_wgrad')
+    ws = torch.empty(64 * nf, dtype=torch.float32, device=y.device)
+    check(lib.ctgan_gp_head_wgrad(_ptr(gg), _ptr(y), n, hw, nf, mask_scale, _ptr(gw), _ptr(ws), _stream()), 'gp_head_wgrad')
     return gw
 
 

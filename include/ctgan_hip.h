@@ -360,7 +360,7 @@ int ctgan_gen_heads_bwd(const float* y, const float* probs, const int32_t* label
 int ctgan_gp_head_grad(const float* y, const float* w_out, int32_t n, int32_t hw, int32_t nf, float mask_scale,
                        float* gz, ctgan_stream_t stream);
 int ctgan_gp_head_wgrad(const float* gg, const float* y, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gw,
-                        ctgan_stream_t stream);
+                        float* ws /* 64 * nf floats */, ctgan_stream_t stream);
 /* ACGAN accuracies of the clean critic pass (:249-266): logits [2B,ncls] (real rows, then fake rows); acc[2]   */
 int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32_t ncls, float* acc,
                     ctgan_stream_t stream);
