@@ -363,6 +363,33 @@ def test_fused_relu_in_and_mask_epilogue(K, N, C, H, Ko, k):
     assert torch.equal(dw, dw2) and torch.equal(db, db2), K.last_kernel()
 
 
+@pytest.mark.parametrize('N,C,H,Ko,k,st', [(128, 128, 32, 128, 3, 1), (192, 128, 32, 128, 4, 2), (320, 128, 16, 128, 3, 1),
+                                           (192, 3, 32, 128, 3, 1), (128, 128, 32, 3, 3, 1), (384, 128, 8, 128, 3, 1)])
+def test_full_size_conv_properties(K, N, C, H, Ko, k, st):
+    """Size-independent properties at the sizes the step runs (too large for the fp64 oracle in seconds): the data gradient
+    is the adjoint of the forward, <conv(x,w), gy> = <x, dgrad(gy,w)> = <w, wgrad(x,gy)>; linearity in x; and batch-split
+    invariance (rows of a batch are independent: the forward of the whole batch equals the forwards of its halves)."""
+    g = torch.Generator().manual_seed(N + C + H + Ko + k)
+    geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+    mk_x = (lambda n: dev(torch.randn(n, C, H, H, generator=g))) if C <= 4 else (lambda n: cl(torch.randn(n, C, H, H, generator=g)))
+    mk_y = (lambda n: dev(torch.randn(n, Ko, geom.P, geom.Q, generator=g))) if Ko <= 4 else (lambda n: cl(torch.randn(n, Ko, geom.P, geom.Q, generator=g)))
+    x, x2, gy = mk_x(N), mk_x(N), mk_y(N)
+    w = dev(torch.randn(k, k, C, Ko, generator=g) * 0.05)
+    y = K.conv_fwd(x, w, None, geom)
+    gx = K.conv_dgrad(gy, w, geom, N)
+    gw = K.conv_wgrad(x, gy, geom)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    lhs = dot(y, gy)
+    scale = float(y.double().norm() * gy.double().norm())
+    assert abs(lhs - dot(x, gx)) < 1e-5 * scale and abs(lhs - dot(w, gw)) < 1e-5 * scale
+    y12 = K.conv_fwd(K.axpby(x, x2, 0.75, -1.5), w, None, geom)
+    y2 = K.conv_fwd(x2, w, None, geom)
+    assert relerr(y12, 0.75 * y.double() - 1.5 * y2.double()) < 2e-5
+    h = N // 2
+    # (another batch size may pick another tile / K-split configuration: same sums in another fp32 order)
+    assert relerr(K.conv_fwd(x[:h], w, None, geom), y[:h]) < 1e-5 and relerr(K.conv_fwd(x[h:], w, None, geom), y[h:]) < 1e-5
+
+
 def test_conv_is_deterministic(K):
     g = torch.Generator().manual_seed(8)
     x = cl(torch.randn(32, 128, 16, 16, generator=g)); gy = cl(torch.randn(32, 128, 16, 16, generator=g))
