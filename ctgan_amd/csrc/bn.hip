@@ -181,14 +181,20 @@ __global__ __launch_bounds__(64 * 16) void bn_bwd_final_kernel(const double* __r
             for (int sample = sl; sample < s.n; sample += 16) {
                 const int lab = labels ? labels[sample] : 0;
                 if (lab != job) continue;
-                a += tot[(long long)sample * 2 * s.c + c]; b += tot[(long long)sample * 2 * s.c + s.c + c];
+                for (int k = 0; k < s.hc; ++k) {          // `tot` = the per-chunk partials: hc (<= 4 on this path) rows per sample
+                    const long long i = (long long)(sample * s.hc + k) * 2 * s.c;
+                    a += tot[i + c]; b += tot[i + s.c + c];
+                }
             }
         } else {
             const int g = job - n_labels;
             for (int sample = g * per + sl; sample < (g + 1) * per; sample += 16) {
                 const int lab = labels ? labels[sample] : 0;
                 const double ga = scale[lab * s.c + c];
-                a += tot[(long long)sample * 2 * s.c + c] * ga; b += tot[(long long)sample * 2 * s.c + s.c + c] * ga;
+                for (int k = 0; k < s.hc; ++k) {
+                    const long long i = (long long)(sample * s.hc + k) * 2 * s.c;
+                    a += tot[i + c] * ga; b += tot[i + s.c + c] * ga;
+                }
             }
         }
     }
@@ -447,11 +453,9 @@ int ctgan_bn_bwd(const float* gy, const float* x, const float* mean, const float
                            scale, offset, labels, s, relu, part);
     rc = ctgan_check_launch("bn_bwd_partial");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_sample_kernel, dim3(n, (c + CB - 1) / CB), dim3(CB * RL), 0, st, part, s, tot);
-    rc = ctgan_check_launch("bn_bwd_sample");
-    if (rc) return rc;
-    (void)bins;
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 63) / 64, n_labels + groups), dim3(64 * 16), 0, st, tot, scale, labels, s,
+    (void)bins; (void)tot;
+    // the finalisation sums the (<= 4) chunk partials of a sample itself: no per-sample totals pass
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((c + 63) / 64, n_labels + groups), dim3(64 * 16), 0, st, part, scale, labels, s,
                        n_labels, gscale, goffset, s12);
     rc = ctgan_check_launch("bn_bwd_final");
     if (rc) return rc;
