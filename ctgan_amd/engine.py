@@ -74,35 +74,51 @@ class GraphedTrainer:
         return {'cost': out['cost'].detach()}
 
     def _capture(self, warmup):
+        """Warm-up + capture of the three graphs.  Everything a body changes besides its outputs is restored afterwards
+        (also when capture fails): Adam slots and step counts, the Philox step counter - so a captured trainer continues
+        exactly where the eager one would (checkpoint resume, graph-vs-eager parity tests).
+
+        Each graph owns a PRIVATE memory pool.  The graphs are replayed in an order other than the capture order
+        (g, f, then d x N_CRITIC) and their outputs outlive other graphs' replays - `fake_all` is read by all N_CRITIC
+        critic replays.  With one shared pool a block freed while capturing graph A is handed to graph B as storage of a
+        live OUTPUT, and A's next replay scribbles over it (round 1: the fake batches of critic steps 2..5 were whatever the
+        first critic replay left in that memory, hence a critic cost of -6e18).  A private pool costs ~3 GB per graph of
+        the 288 GB and makes an output valid until its own graph is replayed again."""
         t = self.t
-        t.d_opt.set_lr(0.0)       # warm-up / capture passes must not move the weights
-        t.g_opt.set_lr(0.0)
-        snap = [b.clone() for b in (t.d_opt.m, t.d_opt.v, t.d_opt.state, t.g_opt.m, t.g_opt.v, t.g_opt.state)]
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                if self.batch_fakes:
-                    self._f_body()
-                self._d_body()
-                self._g_body()
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        self.d_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.d_graph):
-            self.d_out = self._d_body()
-        self.g_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_graph, pool=self.d_graph.pool()):
-            self.g_out = self._g_body()
-        if self.batch_fakes:
-            self.f_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.f_graph, pool=self.d_graph.pool()):
-                self.fake_all = self._f_body()
-        torch.cuda.synchronize()
-        # undo the side effects of the warm-up passes on the optimizer slots
-        for b, sn in zip((t.d_opt.m, t.d_opt.v, t.d_opt.state, t.g_opt.m, t.g_opt.v, t.g_opt.state), snap):
-            b.copy_(sn)
-        t.d_opt.t = t.g_opt.t = 0
+        opts = (t.d_opt, t.g_opt)
+        bufs = [b for o in opts for b in (o.m, o.v, o.state)] + [t.rng.ctr]
+        snap = [b.clone() for b in bufs]
+        steps = [o.t for o in opts]
+        for o in opts:
+            o.set_lr(0.0)       # warm-up / capture passes must not move the weights
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    if self.batch_fakes:
+                        self._f_body()
+                    self._d_body()
+                    self._g_body()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.d_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.d_graph):
+                self.d_out = self._d_body()
+            self.g_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_graph):
+                self.g_out = self._g_body()
+            if self.batch_fakes:
+                self.f_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.f_graph):
+                    self.fake_all = self._f_body()
+        finally:
+            torch.cuda.synchronize()
+            for b, sn in zip(bufs, snap):
+                b.copy_(sn)
+            for o, n in zip(opts, steps):
+                o.t, o._lr_last = n, None
+            torch.cuda.synchronize()
 
     @property
     def graphed(self):

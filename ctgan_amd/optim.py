@@ -36,15 +36,20 @@ class FlatAdam:
                 off += n
         # {lr, beta1^t, beta2^t, unused}; TF initialises the power accumulators to beta (t = 1)
         self.state = torch.tensor([0.0, self.beta1, self.beta2, 0.0], dtype=torch.float32, device=dev)
-        self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == 'cuda' else torch.zeros(1)
+        self._lr_last = None      # value currently in state[0] if written by set_lr (None = unknown)
         self.t = 0
         self._keepalive = []
         self.offsets = [sum(self.sizes[:i]) for i in range(len(self.sizes))]
 
     def set_lr(self, lr):
-        """Host -> device copy of the scalar learning rate (outside any captured graph)."""
-        self._lr_host[0] = float(lr)
-        self.state[0:1].copy_(self._lr_host, non_blocking=True)
+        """Write the scalar learning rate into the device-resident state (outside any captured graph).  The value rides in
+        the fill kernel's ARGUMENTS - no host staging buffer a later call could overwrite before an asynchronous copy of it
+        has run - and the launch is skipped while the rate does not change (the N_CRITIC critic steps of an iteration)."""
+        lr = float(lr)
+        if self._lr_last == lr:
+            return
+        self.state[0:1].fill_(lr)
+        self._lr_last = lr
 
     def gather_grads(self, grads):
         """Pack per-parameter gradients (None = zero) into the flat bucket with ONE kernel (the pointer table rides
@@ -86,3 +91,4 @@ class FlatAdam:
 
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.state.copy_(sd['state']); self.t = int(sd['t'])
+        self._lr_last = None

@@ -1,0 +1,140 @@
+"""The BENCHMARKED loop - hipGraph replay of the fused critic / generator steps in the reference's order
+([G] + N_CRITIC x D, TF/CT_gan_cifar_resnet.py:393-404) - checked value by value over several iterations.
+
+Round 1 timed a loop whose critic cost ran to -6e18: the three graphs shared one memory pool and were replayed in an order
+other than the capture order, so the fake batches of critic steps 2..5 were overwritten by the first critic replay
+(engine.GraphedTrainer._capture).  No test looked at a VALUE of the graphed loop.  These do:
+  * every loss term of every critic step of the replayed loop equals the eager loop on the same Philox streams (same kernels
+    in the same order - the comparison is tight), and stays in a sane band;
+  * the fake batches the critic replays read are tanh outputs (|x| <= 1) - the direct symptom of the round-1 aliasing;
+  * the all-switches-off op-by-op eager loop agrees with the default fused loop (free-running drift tolerance);
+  * a GraphedTrainer resumed from a checkpoint continues bit-exactly (capture leaves no trace in optimizer / RNG state).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TERMS = ('cost', 'wgan', 'ct', 'gp', 'acgan')
+
+
+def _batches(B, n=16, seed=1234):
+    import numpy as np
+    nrng = np.random.default_rng(seed)
+    return [(torch.from_numpy(nrng.integers(0, 256, (B, 3072), dtype=np.int32)).cuda(),
+             torch.from_numpy(nrng.integers(0, 10, (B,), dtype=np.int32)).cuda()) for _ in range(n)]
+
+
+def _run_loop(dim, B, iters, graphs, batches, seed=0, start=1):
+    """bench.py's loop, recording every critic step.  -> (records, final critic theta, final generator theta)"""
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.engine import GraphedTrainer
+    lib.delete_all_params(); lib.set_device(None); lib.set_seed(seed)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    R.build_params()
+    tr = R.Trainer(seed=2024)
+    eng = GraphedTrainer(tr, use_graphs=graphs)
+    assert eng.graphed == graphs, eng.graph_error
+    cur = [0]
+
+    def nb():
+        cur[0] = (cur[0] + 1) % len(batches)
+        return batches[cur[0]]
+    recs = []
+    for it in range(start, start + iters):
+        eng.g_step(it)
+        bs = [nb() for _ in range(R.cfg.N_CRITIC)]
+        if eng.graphed:
+            for i, (_, lab) in enumerate(bs):
+                eng.labels_all[i * B:(i + 1) * B].copy_(lab)
+            eng.f_graph.replay()
+            fakes = eng.fake_all
+        else:
+            fakes = tr.generate_fakes(torch.cat([lab for _, lab in bs], 0))
+        for i, (x, lab) in enumerate(bs):
+            out = eng.d_step(x, lab, it, fake=fakes[i])
+            rec = {k: float(out[k].item()) for k in TERMS}
+            rec['fake_max'] = float(fakes[i].abs().max().item())      # read AFTER the replay that could clobber it
+            recs.append(rec)
+    th = (tr.d_opt.theta.clone(), tr.g_opt.theta.clone())
+    lib.delete_all_params(); R.configure()
+    return recs, th[0], th[1]
+
+
+@pytest.mark.parametrize('dim,B,iters', [(32, 8, 12), (128, 64, 8)])
+def test_graph_replay_loop_equals_eager_loop(dim, B, iters):
+    batches = _batches(B)
+    g_recs, g_d, g_g = _run_loop(dim, B, iters, True, batches)
+    e_recs, e_d, e_g = _run_loop(dim, B, iters, False, batches)
+    assert len(g_recs) == len(e_recs) == 5 * iters
+    for n, (a, b) in enumerate(zip(g_recs, e_recs)):
+        assert a['fake_max'] <= 1.0 and b['fake_max'] <= 1.0, 'critic step %d read a fake batch that is not a tanh output: %r' % (n, a)
+        for k in TERMS:
+            assert math.isfinite(a[k]) and abs(a[k]) < 1e3, 'step %d %s = %r' % (n, k, a[k])
+            # identical kernels, launch order and Philox streams: anything beyond round-off of the printed scalars is a bug
+            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(b[k])), 'step %d %s: graph %r eager %r' % (n, k, a[k], b[k])
+    assert torch.equal(g_d, e_d) and torch.equal(g_g, e_g)              # the weights after the loop are the same bits
+
+
+def test_fused_loop_tracks_op_by_op_loop(monkeypatch):
+    """Default switches (tape, shared tail, fused heads, grouped weight gradients) vs every switch off, both eager, free
+    running over 6 iterations at reduced width: same Philox streams, different kernels/summation orders."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    B, dim, iters = 8, 32, 6
+    batches = _batches(B)
+    fused, _, _ = _run_loop(dim, B, iters, False, batches)
+    for mod, names in ((R, ('HEAD_FUSION', 'TRUNK_SHARE', 'TAIL_SHARE', 'PREP_FUSION', 'DROP_FUSION')),
+                       (F, ('WGRAD_GROUPED', 'FEWCH_DEFER', 'DEFER_WGRADS'))):
+        for n in names:
+            monkeypatch.setattr(mod, n, False)
+    plain, _, _ = _run_loop(dim, B, iters, False, batches)
+    for n, (a, b) in enumerate(zip(fused, plain)):
+        for k in TERMS:
+            # free-running drift over 30 critic updates (Adam's early steps are sign-like, so round-off differences move
+            # weights by whole steps): the WGAN / ACGAN terms stay within 5e-3; the penalty terms are means of squared small
+            # differences ((|grad| - 1)^2, (D - D')^2) and amplify it - measured 6e-3 on gp at step 15
+            tol = 3e-2 if k in ('gp', 'ct') else 5e-3
+            assert abs(a[k] - b[k]) <= tol * max(1.0, abs(b[k])), 'step %d %s: fused %r op-by-op %r' % (n, k, a[k], b[k])
+
+
+def test_graphed_trainer_resumes_bit_exactly(tmp_path):
+    """checkpoint.load ran before GraphedTrainer._capture, whose warm-up advanced the Philox counter and zeroed the
+    optimizers' step counts.  Capture now restores all of it: 2 iterations + save + 1 iteration == load + 1 iteration."""
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    from ctgan_amd import checkpoint
+    from ctgan_amd.engine import GraphedTrainer
+    B, dim = 8, 16
+    batches = _batches(B, n=4, seed=7)
+
+    def run(n_iters, resume_from=None, save_at=None):
+        lib.delete_all_params(); lib.set_device(None); lib.set_seed(4)
+        R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+        R.build_params()
+        tr = R.Trainer(seed=9)
+        start = checkpoint.load(resume_from, tr) if resume_from else 0
+        eng = GraphedTrainer(tr)
+        assert eng.graphed, eng.graph_error
+        k = [start * 5]
+
+        def nxt():
+            k[0] += 1
+            return batches[k[0] % 4]
+        for it in range(start, n_iters):
+            eng.train_iteration(it, nxt)
+            if save_at is not None and it + 1 == save_at:
+                checkpoint.save(str(tmp_path / 'ck.pt'), tr, iteration=it + 1)
+        return (tr.d_opt.theta.clone(), tr.g_opt.theta.clone(), tr.d_opt.m.clone(), tr.d_opt.v.clone(), tr.rng.ctr.clone(),
+                tr.d_opt.t, tr.g_opt.t)
+    try:
+        a = run(3, save_at=2)
+        b = run(3, resume_from=str(tmp_path / 'ck.pt'))
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y)
+        assert a[5:] == b[5:] == (15, 2)
+    finally:
+        lib.delete_all_params(); R.configure()
