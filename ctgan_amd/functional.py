@@ -135,6 +135,15 @@ def _flush_group(grp):
             first = False
 
 
+def _like_first(t, ref):
+    """t with the per-sample strides of `ref` (same C,H,W; the batch sizes may differ)."""
+    if t.stride()[1:] == ref.stride()[1:]:
+        return t
+    assert t.shape[1:] == ref.shape[1:]
+    per_sample = t.shape[1] * t.shape[2] * t.shape[3]
+    return K.copy4d(t, torch.empty_strided(t.shape, (per_sample,) + tuple(ref.stride()[1:]), dtype=t.dtype, device=t.device))
+
+
 def _wgrad(x, gy, w, g, relu_x, with_bias):
     """Weight (and bias) gradient of one use of filter `w`: launched now, or queued (see deferred_wgrads).
     Returns (gw, gb); either may be None when another request of the same filter already owns the result."""
@@ -151,9 +160,11 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     key = (w.data_ptr(), gk)
     grp = _DEFER['groups'].get(key)
-    if grp is not None and (grp.segs[0][0].stride()[1:] != x.stride()[1:] or grp.segs[0][1].stride()[1:] != gy.stride()[1:]):
-        key = (w.data_ptr(), gk, x.stride(), gy.stride())       # another memory layout of the same filter's operands
-        grp = _DEFER['groups'].get(key)
+    if grp is not None:
+        # A later use whose operands have another memory layout is repacked into the first use's layout.  It must NOT open a
+        # second queue: that would hand autograd a second, still unfilled, buffer for the same parameter, and the engine
+        # sums the two the moment the second arrives - before the flush has written either.
+        x, gy = _like_first(x, grp.segs[0][0]), _like_first(gy, grp.segs[0][1])
     gw = gb = None
     if grp is None:
         grp = _WgradGroup()

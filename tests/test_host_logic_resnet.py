@@ -331,3 +331,36 @@ def test_layernorm_critic_step_matches_oracle(cpu_kernels):
             _cmp(out['grads'][n], ref['grads'][n], 2e-3, 'dgrad ' + n, atol=1e-6)
     finally:
         R.configure()
+
+
+def test_deferred_wgrads_mixed_operand_layouts_stay_one_queue(cpu_kernels, monkeypatch):
+    """Two uses of ONE filter whose operands have different memory layouts (channels-last vs plain NCHW) under
+    deferred_wgrads: the second use joins the first one's queue (repacked), so autograd receives exactly one gradient
+    buffer for the parameter and it is filled by the flush.  Every torch.empty* is NaN-poisoned: a gradient that was summed
+    before the flush wrote it would be NaN."""
+    import ctgan_amd.functional as F
+    from ctgan_amd.kernels import ConvGeom
+    for name in ('empty', 'empty_like', 'empty_strided'):
+        real = getattr(torch, name)
+
+        def poisoned(*a, _real=real, **k):
+            t = _real(*a, **k)
+            return t.fill_(float('nan')) if t.is_floating_point() else t
+        monkeypatch.setattr(torch, name, poisoned)
+    g = torch.Generator().manual_seed(3)
+    C, K_, H = 32, 32, 6
+    w = torch.nn.Parameter(torch.randn(3, 3, C, K_, generator=g) * 0.1)
+    x_cl = torch.randn(2, H, H, C, generator=g).permute(0, 3, 1, 2)                 # channels-last
+    x_nchw = torch.randn(3, C, H, H, generator=g)                                    # plain NCHW, another batch size
+    geom = ConvGeom(C, H, H, K_, 3, 3, 1, False)
+
+    def loss():
+        ya = F.ConvFn.apply(x_cl, w, None, None, geom, None)
+        yb = F.ConvFn.apply(x_nchw, w, None, None, geom, (K_ * H * H, H * H, H, 1))    # NCHW result: its gradient is NCHW too
+        return (ya * ya).sum() + (yb * yb).sum()
+    (ref,) = torch.autograd.grad(loss(), [w])
+    with F.deferred_wgrads():
+        (got,) = torch.autograd.grad(loss(), [w])
+        assert len(F._DEFER['groups']) == 1 and len(next(iter(F._DEFER['groups'].values())).segs) == 2
+    assert torch.isfinite(got).all()
+    _cmp(got, ref, 1e-5, 'mixed-layout deferred wgrad', atol=1e-6)
