@@ -608,30 +608,36 @@ def adam_advance(state, beta1, beta2):
     state[2] *= beta2
 
 
-_gen = torch.Generator().manual_seed(0)
+def _step_of(ctr):
+    return int(ctr.reshape(-1)[0]) if torch.is_tensor(ctr) else int(ctr or 0)
 
 
-def _gen_for(seed, stream_id, ctr):
-    """Counter-based like the device streams: the draw depends on (seed, call site, step counter) only."""
-    step = int(ctr.reshape(-1)[0]) if torch.is_tensor(ctr) else int(ctr or 0)
-    return torch.Generator().manual_seed((int(seed) * 1000003 + int(stream_id) * 7919 + step * 104729) % (1 << 62))
+def _storage_order(out):
+    """1-D view of a dense tensor in physical (storage) order: the device streams are indexed by the physical element."""
+    assert is_dense(out)
+    return out.as_strided((out.numel(),), (1,))
 
 
+# The stand-ins draw the SAME Philox4x32-10 streams as the device kernels (oracle/philox.py restates them in numpy), so the
+# CPU suite can compare the fused perf-mode step with the oracle on identical draws.
 @_export
 def rng_uniform(out, seed, stream_id, ctr, lo=0.0, hi=1.0):
-    out.copy_(lo + (hi - lo) * torch.rand(out.shape, generator=_gen_for(seed, stream_id, ctr)))
+    from oracle import philox
+    _storage_order(out).copy_(torch.from_numpy(philox.uniform(int(seed), int(stream_id), _step_of(ctr), out.numel(), lo, hi)))
     return out
 
 
 @_export
 def rng_normal(out, seed, stream_id, ctr):
-    out.copy_(torch.randn(out.shape, generator=_gen_for(seed, stream_id, ctr)))
+    from oracle import philox
+    _storage_order(out).copy_(torch.from_numpy(philox.normal(int(seed), int(stream_id), _step_of(ctr), out.numel()).copy()))
     return out
 
 
 @_export
 def rng_labels(out, nlab, seed, stream_id, ctr):
-    out.copy_((torch.rand(out.shape, generator=_gen_for(seed, stream_id, ctr)) * nlab).to(torch.int32))
+    from oracle import philox
+    _storage_order(out).copy_(torch.from_numpy(philox.labels(int(seed), int(stream_id), _step_of(ctr), out.numel(), nlab)))
     return out
 
 

@@ -134,10 +134,40 @@ def resnet_fixture(dim=8, B=4, iters=2):
     np.savez_compressed(os.path.join(HERE, 'resnet_trace.npz'), **out)
 
 
+def loop_trace_fixture(dim=32, B=8, iters=1000, seed=2024, init_seed=0, fname='resnet_loop_trace.npz'):
+    """Free-running trace of the reference LOOP (TF/CT_gan_cifar_resnet.py:393-404: [G step if it > 0] + 5 x (batch, D
+    step), LR decay) over `iters` iterations in fp64.  Seeds, not tensors: the initial weights are the registry's per-name
+    init streams (`init_seed`; the product's lib.set_seed draws the same values), the 16 cycled synthetic batches are
+    numpy default_rng(1234) exactly as bench.py builds them, and every random draw is a Philox stream of (seed, step)
+    (oracle/philox.py, oracle/loop.py).  Stored: every loss term of every critic step and every generator cost."""
+    from oracle import loop
+    reg = ops.Registry(dtype=F64, seed=init_seed)
+    cfg = nets.ResnetCfg(DIM_G=dim, DIM_D=dim)
+    lab0 = torch.zeros(2, dtype=torch.int32)
+    nets.resnet_discriminator(reg, cfg, nets.resnet_generator(reg, cfg, 2, lab0, torch.zeros(2, 128, dtype=F64)), lab0, 1., 1., 1.)
+    nrng = np.random.default_rng(1234)
+    batches = [(torch.from_numpy(nrng.integers(0, 256, (B, 3072), dtype=np.int32)),
+                torch.from_numpy(nrng.integers(0, 10, (B,), dtype=np.int32))) for _ in range(16)]
+    cur = [0]
+
+    def next_batch():
+        cur[0] = (cur[0] + 1) % len(batches)
+        return batches[cur[0]]
+    d_recs, g_recs, _, _, pos = loop.resnet_train_loop(reg, cfg, next_batch, iters, B, seed, start_iteration=1)
+    keys = ('cost', 'wgan', 'acgan', 'ct', 'gp', 'wgan_only')
+    np.savez_compressed(os.path.join(HERE, fname), cfg=np.array([dim, B, iters, seed, init_seed]), keys=np.array(keys),
+                        d=np.array([[r[k] for k in keys] for r in d_recs]), g=np.array(g_recs), stream_pos=np.array(pos))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
-    ops_fixture()
-    resnet_fixture()
+    which = sys.argv[1:] or ['ops', 'resnet', 'loop']
+    if 'ops' in which:
+        ops_fixture()
+    if 'resnet' in which:
+        resnet_fixture()
+    if 'loop' in which:
+        loop_trace_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -85,9 +85,16 @@ def _teacher_force(lib, reg, opt, oopt):
     opt.load_named_slots(oopt.m, oopt.v, oopt.t)
 
 
-@pytest.mark.parametrize('dim,B,steps', [(16, 8, 3), (128, 64, 1)])
-def test_d_and_g_step_parity_teacher_forced(setup, dim, B, steps):
+@pytest.mark.parametrize('dim,B,steps,streams', [(16, 8, 3, False), (128, 64, 1, False),
+                                                 (16, 8, 3, True), (32, 8, 2, True), (128, 64, 2, True)])
+def test_d_and_g_step_parity_teacher_forced(setup, dim, B, steps, streams):
+    """streams=False: every random tensor is injected into both sides (`rnd=`), which switches the product to its op-by-op
+    path.  streams=True: the product runs its DEFAULT path (rnd=None: in-kernel Philox dropout, shared trunk / tail forward,
+    fused heads and input preparation, grouped weight gradients) and the oracle is fed the same Philox streams regenerated in
+    numpy (oracle/philox.py) - the benchmarked step against the reference graph as written."""
+    from oracle import philox
     R, lib = setup(dim, B)
+    pos = [0]                    # stream position = number of steps executed (DeviceRNG.ctr)
     reg = _oracle_from_product(lib)
     cfg = onets.ResnetCfg(DIM_G=dim, DIM_D=dim)
     g = torch.Generator().manual_seed(11)
@@ -97,11 +104,13 @@ def test_d_and_g_step_parity_teacher_forced(setup, dim, B, steps):
     for it in range(steps):
         real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
         labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
-        rnd = osteps.make_rnd_resnet_d(B, dim, g)
+        rnd = philox.rnd_resnet_d(tr.rng.seed, 0, pos[0], B, dim) if streams else osteps.make_rnd_resnet_d(B, dim, g)
         # fp32 twin of the oracle on the same inputs: how far ANY fp32 evaluation of this graph sits
         # from the fp64 truth (ReLU masks of pre-activations within round-off of zero flip)
         twin = _twin_d_grads(reg, cfg, real, labels, rnd, B)
-        out = tr.d_step(real.cuda(), labels.cuda(), {k: _to_dev(v) for k, v in rnd.items()}, iteration=it)
+        out = tr.d_step(real.cuda(), labels.cuda(), None if streams else {k: _to_dev(v) for k, v in rnd.items()}, iteration=it)
+        pos[0] += 1
+        assert tr.rng.ctr.item() == pos[0]
         ref = osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd, iteration=it, B=B)
         # north-star tolerance: losses within 1e-3 relative; measured fp32-vs-fp64 error is ~1e-5
         for k in ('cost', 'wgan', 'acgan', 'ct', 'gp', 'wgan_only'):
@@ -136,9 +145,10 @@ def test_d_and_g_step_parity_teacher_forced(setup, dim, B, steps):
             _cmp_l2(lib._params[n].detach().cpu().double().reshape(-1)[keep], reg[n].detach().double().reshape(-1)[keep], 1e-3,
                     'theta(L2) ' + n, atol=0.02 * 2e-4 * reg[n].numel() ** 0.5)
         _teacher_force(lib, reg, tr.d_opt, optD)
-        rg = osteps.make_rnd_resnet_g(B, dim, g)
-        out = tr.g_step({'z': _to_dev(rg['z']), 'label_u': _to_dev(rg['label_u']), 'u': _to_dev(rg['u'])},
+        rg = philox.rnd_resnet_g(tr.rng.seed, 0, pos[0], B, dim) if streams else osteps.make_rnd_resnet_g(B, dim, g)
+        out = tr.g_step(None if streams else {'z': _to_dev(rg['z']), 'label_u': _to_dev(rg['label_u']), 'u': _to_dev(rg['u'])},
                         iteration=it + 1)
+        pos[0] += 1
         ref = osteps.resnet_g_step(reg, cfg, optG, rg, iteration=it + 1, B=B)
         _cmp(out['cost'], ref['cost'], 2e-4, 'g cost', atol=1e-6)
         _cmp(out['samples'], torch.cat(ref['samples']), 1e-4, 'g samples')

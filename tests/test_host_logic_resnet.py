@@ -364,3 +364,45 @@ def test_deferred_wgrads_mixed_operand_layouts_stay_one_queue(cpu_kernels, monke
         assert len(F._DEFER['groups']) == 1 and len(next(iter(F._DEFER['groups'].values())).segs) == 2
     assert torch.isfinite(got).all()
     _cmp(got, ref, 1e-5, 'mixed-layout deferred wgrad', atol=1e-6)
+
+
+def test_default_fused_step_matches_oracle_on_identical_philox_streams(cpu_kernels):
+    """The DEFAULT path (rnd=None: shared trunk / tail forward on the tape, per-row-range dropout, fused heads and input
+    preparation, grouped deferred weight gradients) against the oracle fed the same Philox streams (oracle/philox.py): the
+    host logic of the benchmarked step, not of the op-by-op parity mode.  (The stand-ins draw the device's streams.)"""
+    from oracle import philox
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    B, dim = 4, 32
+    lib.set_seed(5)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    try:
+        R.build_params('cpu')
+        reg = _oracle_from_product(lib)
+        cfg = onets.ResnetCfg(DIM_G=dim, DIM_D=dim)
+        g = torch.Generator().manual_seed(1)
+        tr = R.Trainer(seed=77)
+        assert R._heads_fusable(None, tr.rng) and R.TRUNK_SHARE and R.TAIL_SHARE
+        optD = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+        optG = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Generator')], 0.0, 0.9)
+        pos = 0
+        for it in range(2):
+            real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+            labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+            out = tr.d_step(real, labels, None, iteration=it)
+            ref = osteps.resnet_d_step(reg, cfg, optD, real, labels, philox.rnd_resnet_d(77, 0, pos, B, dim), iteration=it, B=B)
+            pos += 1
+            for k in ('cost', 'wgan', 'acgan', 'ct', 'gp', 'wgan_only', 'acc_real', 'acc_fake'):
+                _cmp(out[k], ref[k], 2e-4, 'd_step[%d].%s' % (it, k), atol=1e-6)
+            _cmp(out['gp_grads'], ref['gp_grads'], 5e-4, 'gp grads')
+            assert set(out['grads']) == set(ref['grads'])
+            for n in ref['grads']:
+                _cmp(out['grads'][n], ref['grads'][n], 1e-3, 'dgrad ' + n, atol=1e-6)
+        out = tr.g_step(None, iteration=1)
+        ref = osteps.resnet_g_step(reg, cfg, optG, philox.rnd_resnet_g(77, 0, pos, B, dim), iteration=1, B=B)
+        _cmp(out['cost'], ref['cost'], 2e-4, 'g cost')
+        _cmp(out['samples'], torch.cat(ref['samples']), 1e-4, 'g samples')
+        for n in ref['grads']:
+            _cmp(out['grads'][n], ref['grads'][n], 2e-3, 'ggrad ' + n, atol=1e-6)
+    finally:
+        R.configure()
