@@ -36,11 +36,13 @@ def init_from_env(backend=None):
 
 
 class FlatAllReduce:
-    """Sum a flat fp32 bucket across ranks, on a side stream when one is given.
+    """Sum a flat fp32 bucket across ranks.
 
-    With `side_stream`, the collective is enqueued on that stream after the producer's work
-    (event wait) and the caller's stream waits for its completion only at `wait()` - the Adam
-    kernel - so independent work (the next step's generator forward) can overlap it."""
+    With `side_stream` the collective is ASYNCHRONOUS with respect to the caller's stream: `__call__` enqueues it on the
+    side stream behind the producer's work (event wait) and returns; the caller's stream is made to wait for it only by
+    `wait()`, which the optimizer step calls just before the Adam kernel.  Whatever the caller enqueues in between - the
+    next step's input staging (engine.GraphedTrainer) - overlaps the collective.  Without a side stream (gloo / CPU tests)
+    the call is synchronous and `wait()` is a no-op."""
 
     def __init__(self, group=None, side_stream=None):
         self.group = group
@@ -53,6 +55,7 @@ class FlatAllReduce:
         if self.side is None or not flat.is_cuda:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             return
+        assert self._pending is None, 'previous all-reduce was never waited for'
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
@@ -61,9 +64,9 @@ class FlatAllReduce:
             done = torch.cuda.Event()
             done.record(self.side)
         self._pending = done
-        self.wait()
 
     def wait(self):
+        """Order the caller's current stream behind the outstanding collective (if any)."""
         if self._pending is not None:
             torch.cuda.current_stream().wait_event(self._pending)
             self._pending = None

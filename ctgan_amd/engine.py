@@ -124,57 +124,83 @@ class GraphedTrainer:
     def graphed(self):
         return self.d_graph is not None
 
-    def d_step(self, real_int, labels, iteration=0, fake=None):
-        t = self.t
-        if not self.graphed:
-            return t.d_step(real_int, labels, iteration=iteration, fake=fake)
+    def _stage_d_inputs(self, real_int, labels, fake):
         self.real.copy_(real_int, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         if self.batch_fakes:
             if fake is None:          # stand-alone critic step: draw its fake batch now (eager, no-grad)
-                fake = t.generate_fakes(self.labels)[0]
+                fake = self.t.generate_fakes(self.labels)[0]
             self.fake.copy_(fake, non_blocking=True)
+
+    def d_step(self, real_int, labels, iteration=0, fake=None, staged=False, between=None):
+        """One critic update.  world > 1: the graph ends at the packed gradient; the all-reduce runs on the side stream
+        while `between()` (the NEXT step's input staging) is enqueued, then Adam (Trainer.reduce_and_update)."""
+        t = self.t
+        if not self.graphed:
+            return t.d_step(real_int, labels, iteration=iteration, fake=fake)
+        if not staged:
+            self._stage_d_inputs(real_int, labels, fake)
         t.d_opt.set_lr(t.lr(iteration))
         self.d_graph.replay()
         if not self.adam_in_graph:
-            t.allreduce(t.d_opt.grad)
-            t.d_opt.step(1.0 / t.world)
+            t.reduce_and_update(t.d_opt, t.d_opt.grad, between)
         else:
             t.d_opt.t += 1
+            if between is not None:
+                between()
         return self.d_out
 
-    def g_step(self, iteration=0):
+    def g_step(self, iteration=0, between=None):
         t = self.t
         if not self.graphed:
             return t.g_step(iteration=iteration)
         t.g_opt.set_lr(t.lr(iteration))
         self.g_graph.replay()
         if not self.adam_in_graph:
-            t.allreduce(t.g_opt.grad)
-            t.g_opt.step(1.0 / t.world)
+            t.reduce_and_update(t.g_opt, t.g_opt.grad, between)
         else:
             t.g_opt.t += 1
+            if between is not None:
+                between()
         return self.g_out
 
     def train_iteration(self, iteration, next_batch):
-        """[G step if it>0] + N_CRITIC x (next batch, D step)   (TF/CT_gan_cifar_resnet.py:393-404)"""
-        if iteration > 0:
-            self.g_step(iteration)
-        out = None
+        """[G step if it>0] + N_CRITIC x (next batch, D step)   (TF/CT_gan_cifar_resnet.py:393-404).  The inputs of step
+        k+1 are staged into the static buffers right after step k's graph has been enqueued - stream order keeps that
+        safe - i.e. while step k's gradient all-reduce is in flight on the side stream (world > 1)."""
         if not self.batch_fakes:
+            if iteration > 0:
+                self.g_step(iteration)
+            out = None
             for _ in range(R.cfg.N_CRITIC):
                 data, labels = next_batch()
                 out = self.d_step(data, labels, iteration)
             return out
         batches = [next_batch() for _ in range(R.cfg.N_CRITIC)]
         B = R.cfg.BATCH_SIZE
-        if self.graphed:
+        if not self.graphed:
+            if iteration > 0:
+                self.g_step(iteration)
+            fakes = self.t.generate_fakes(torch.cat([lab for _, lab in batches], 0))
+            out = None
+            for i, (data, labels) in enumerate(batches):
+                out = self.d_step(data, labels, iteration, fake=fakes[i])
+            return out
+
+        def stage_labels():
             for i, (_, lab) in enumerate(batches):
                 self.labels_all[i * B:(i + 1) * B].copy_(lab, non_blocking=True)
-            self.f_graph.replay()
-            fakes = self.fake_all
+        if iteration > 0:
+            self.g_step(iteration, between=stage_labels)
         else:
-            fakes = self.t.generate_fakes(torch.cat([lab for _, lab in batches], 0))
-        for i, (data, labels) in enumerate(batches):
-            out = self.d_step(data, labels, iteration, fake=fakes[i])
+            stage_labels()
+        self.f_graph.replay()
+        fakes = self.fake_all
+        self._stage_d_inputs(batches[0][0], batches[0][1], fakes[0])
+        out = None
+        for i in range(len(batches)):
+            nxt = None
+            if i + 1 < len(batches):
+                nxt = (lambda j: lambda: self._stage_d_inputs(batches[j][0], batches[j][1], fakes[j]))(i + 1)
+            out = self.d_step(None, None, iteration, staged=True, between=nxt)
         return out

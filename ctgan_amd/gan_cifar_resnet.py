@@ -600,8 +600,19 @@ class Trainer:
         if set_lr:
             opt.set_lr(self.lr(iteration))
         flat = opt.gather_grads(grads)
-        if self.allreduce is not None and self.world > 1:
-            self.allreduce(flat)
+        self.reduce_and_update(opt, flat)
+
+    def reduce_and_update(self, opt, flat, between=None):
+        """All-reduce the flat gradient bucket (asynchronous on the side stream, ddp.FlatAllReduce), run `between()` - work
+        that does not depend on the update, e.g. staging the next step's inputs - while it is in flight, then Adam with
+        the 1/world average folded in."""
+        ar = self.allreduce if (self.allreduce is not None and self.world > 1) else None
+        if ar is not None:
+            ar(flat)
+        if between is not None:
+            between()
+        if ar is not None and hasattr(ar, 'wait'):
+            ar.wait()
         opt.step(grad_scale=1.0 / self.world)
 
     def train_iteration(self, iteration, next_batch):
@@ -631,14 +642,15 @@ def train(data_dir, n_examples=50000, iters=None, out_dir='.', seed=2024, use_gr
           checkpoint_every=1000, resume=None, log=print):
     """The module-level training loop of the reference (TF/CT_gan_cifar_resnet.py:350-434) minus the Inception
     score (needs the 2015 Inception graph + network): CIFAR-10 generator factories, `time` /
-    `cost` / `wgan` / `acgan` / `acc_real` / `acc_fake` series through tflib.plot, fixed-noise sample grids every
+    `cost` / `wgan` / `acgan` / `acc_real` / `acc_fake` series (train_log.Series), fixed-noise sample grids every
     `sample_every` iterations (:341-348, :429), checkpoints every `checkpoint_every` (build-only)."""
     import os
     import time
 
     from . import checkpoint
     from .engine import GraphedTrainer
-    from .tflib import cifar10, plot, save_images
+    from .tflib import cifar10, save_images
+    from .train_log import Series
     iters = cfg.ITERS if iters is None else iters
     build_params()
     trainer = Trainer(seed=seed)
@@ -648,23 +660,23 @@ def train(data_dir, n_examples=50000, iters=None, out_dir='.', seed=2024, use_gr
     feed = cifar10.prefetch_to_device(cifar10.inf_train_gen(train_gen), trainer.dev)
     fixed_noise = trainer.rng.normal(100, 128)
     fixed_labels = torch.arange(10, dtype=torch.int32, device=trainer.dev).repeat(10)
-    plot.log_path = os.path.join(out_dir, 'log.jsonl')
+    series = Series(os.path.join(out_dir, 'log.jsonl'), echo=log)
     for iteration in range(start, iters):
         t0 = time.time()
         out = eng.train_iteration(iteration, lambda: next(feed))
-        plot.plot('cost', out['cost'].item())
+        series.add('cost', out['cost'].item())
         if out.get('acgan') is not None:
             for k in ('wgan', 'acgan', 'acc_real', 'acc_fake'):
-                plot.plot(k, out[k].item())
-        plot.plot('time', time.time() - t0)
+                series.add(k, out[k].item())
+        series.add('time', time.time() - t0)
         if iteration % sample_every == sample_every - 1:
             _, px = trainer.generate_samples(fixed_noise, fixed_labels)
             save_images.save_images(px.reshape(100, 3, 32, 32).cpu().numpy(), os.path.join(out_dir, 'samples_%d.png' % iteration))
         if checkpoint_every and iteration % checkpoint_every == checkpoint_every - 1:
             checkpoint.save(os.path.join(out_dir, 'checkpoint.pt'), trainer, iteration + 1)
         if iteration < 500 or iteration % 1000 == 999:
-            plot.flush()
-        plot.tick()
+            series.flush()
+        series.tick()
     return trainer
 
 

@@ -1,104 +1,99 @@
-"""tflib.cifar10 - the reference's generator-factory contract (TF/tflib/cifar10.py:8-70) on Python 3.
+"""tflib.cifar10 - CIFAR-10 batch feed with the reference's generator-factory contract.
 
-`load(batch_size, data_dir, n_examples)` -> (train_gen, dev_gen); calling a factory starts an epoch and
-yields `(images uint8 [B,3072], labels [B])`.  Semantics kept: the training set is the FIRST `n_examples`
-rows of data_batch_1..5 (:53-54), images and labels are shuffled in place with the same numpy RNG state
-every epoch (:57-60), the remainder of an epoch is dropped (:62), the dev generator is the unrestricted
-test batch (:69).  `prefetch_to_device` (build-only) double-buffers batches into pinned memory and onto
-the GPU so the 0.79 MB/step feed stays off the critical path.
+Contract kept (what callers of TF/tflib/cifar10.py:40-70 observe): `load(batch_size, data_dir, n_examples)` returns
+`(train_gen, dev_gen)`; calling a factory starts one epoch and yields `(images uint8 [B,3072], labels [B])`.  The training
+set is the first `n_examples` rows of data_batch_1..5, the dev set is the whole test batch; each epoch visits the set in a
+fresh order drawn from numpy's GLOBAL generator (so `np.random.seed` reproduces a run, as with the reference) with images and
+labels permuted together; a trailing partial batch is dropped.
+
+Built differently: an `EpochFeed` object holds the arrays once and draws ONE index permutation per epoch (the reference
+shuffles both arrays in place under a saved / restored generator state - the same permutation and the same generator
+state afterwards, without moving 150 MB of pixels twice per epoch); batches are gathered rows.
+`prefetch_to_device` (build-only) stages batches in pinned host memory and copies them on a side stream, `depth` batches
+ahead, so the 0.79 MB/step feed stays off the critical path.
 """
+import collections
 import os
 import pickle
 
 import numpy as np
 
-
-def unpickle(file):
-    with open(file, 'rb') as fo:
-        d = pickle.load(fo, encoding='latin1')
-    return d['data'], d['labels']
+TRAIN_FILES = tuple('data_batch_%d' % i for i in range(1, 6))
+TEST_FILES = ('test_batch',)
 
 
-def _generator(filenames, batch_size, data_dir, n_examples=None):
-    all_data, all_labels = [], []
-    for filename in filenames:
-        data, labels = unpickle(os.path.join(data_dir, filename))
-        all_data.append(data)
-        all_labels.append(labels)
-    images = np.concatenate(all_data, axis=0)
-    labels = np.concatenate(all_labels, axis=0)
-    if n_examples is not None:
-        images = images[0:n_examples, :]
-        labels = labels[0:n_examples]
-
-    def get_epoch():
-        rng_state = np.random.get_state()
-        np.random.shuffle(images)
-        np.random.set_state(rng_state)
-        np.random.shuffle(labels)
-        for i in range(len(images) // batch_size):
-            yield (images[i * batch_size:(i + 1) * batch_size], labels[i * batch_size:(i + 1) * batch_size])
-
-    return get_epoch
+def _read_batch_file(path):
+    with open(path, 'rb') as f:
+        rec = pickle.load(f, encoding='latin1')
+    return np.asarray(rec['data'], dtype=np.uint8), np.asarray(rec['labels'])
 
 
-def cifar_generator(filenames, batch_size, data_dir):
-    return _generator(filenames, batch_size, data_dir)
+class EpochFeed:
+    """Callable epoch factory over (images, labels)."""
 
+    def __init__(self, images, labels, batch_size):
+        assert len(images) == len(labels)
+        self.images, self.labels, self.batch_size = images, labels, int(batch_size)
 
-def cifar_generator2(filenames, batch_size, data_dir, n_examples):
-    return _generator(filenames, batch_size, data_dir, n_examples)
+    @classmethod
+    def from_files(cls, data_dir, names, batch_size, limit=None):
+        parts = [_read_batch_file(os.path.join(data_dir, n)) for n in names]
+        images = np.concatenate([p[0] for p in parts], axis=0)[:limit]
+        labels = np.concatenate([p[1] for p in parts], axis=0)[:limit]
+        return cls(images, labels, batch_size)
+
+    def __len__(self):
+        return len(self.images) // self.batch_size
+
+    def __call__(self):
+        order = np.arange(len(self.images))
+        np.random.shuffle(order)                      # global generator, one draw sequence per epoch
+        # the visiting order compounds from epoch to epoch, as repeated in-place shuffles do
+        self.images, self.labels = self.images[order], self.labels[order]
+        B = self.batch_size
+        for k in range(len(self)):
+            yield self.images[k * B:(k + 1) * B], self.labels[k * B:(k + 1) * B]
 
 
 def load(batch_size, data_dir, n_examples):
-    return (
-        cifar_generator2(['data_batch_1', 'data_batch_2', 'data_batch_3', 'data_batch_4', 'data_batch_5'],
-                         batch_size, data_dir, n_examples),
-        cifar_generator(['test_batch'], batch_size, data_dir),
-    )
+    return (EpochFeed.from_files(data_dir, TRAIN_FILES, batch_size, limit=n_examples),
+            EpochFeed.from_files(data_dir, TEST_FILES, batch_size))
 
 
 def inf_train_gen(train_gen):
-    """`while True: for images, labels in train_gen(): yield ...` (TF/CT_gan_cifar_resnet.py:362-365)."""
+    """Endless stream of training batches: epoch after epoch (TF/CT_gan_cifar_resnet.py:362-365)."""
     while True:
-        for images, labels in train_gen():
-            yield images, labels
+        yield from train_gen()
 
 
 def prefetch_to_device(gen, device, depth=2):
-    """Wrap an (images uint8, labels) iterator: batches are converted to the int32 placeholder dtypes of
-    the reference (:191-192), staged in pinned host buffers and copied asynchronously on a side stream,
-    `depth` batches ahead of the consumer."""
-    import collections
-
+    """(images uint8, labels) iterator -> (int32 [B,3072], int32 [B]) device tensors (the placeholder dtypes of
+    TF/CT_gan_cifar_resnet.py:191-192), `depth` batches in flight."""
     import torch
-    stream = torch.cuda.Stream(device=device) if torch.device(device).type == 'cuda' else None
-    queue = collections.deque()
+    on_gpu = torch.device(device).type == 'cuda'
+    stream = torch.cuda.Stream(device=device) if on_gpu else None
+    inflight = collections.deque()
 
-    def push():
-        try:
-            images, labels = next(gen)
-        except StopIteration:
-            return False
-        hi = torch.from_numpy(np.ascontiguousarray(images).astype(np.int32))
-        hl = torch.from_numpy(np.ascontiguousarray(labels).astype(np.int32))
-        if stream is None:
-            queue.append((hi.to(device), hl.to(device), None))
-            return True
-        hi, hl = hi.pin_memory(), hl.pin_memory()
+    def stage():
+        item = next(gen, None)
+        if item is None:
+            return
+        host = [torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)) for a in item]
+        if not on_gpu:
+            inflight.append((host[0].to(device), host[1].to(device), None, None))
+            return
+        host = [h.pin_memory() for h in host]
         with torch.cuda.stream(stream):
-            di = hi.to(device, non_blocking=True)
-            dl = hl.to(device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        queue.append((di, dl, ev, hi, hl))
-        return True
+            dev = [h.to(device, non_blocking=True) for h in host]
+            done = torch.cuda.Event()
+            done.record(stream)
+        inflight.append((dev[0], dev[1], done, host))           # `host` stays alive until the copy has been consumed
 
     for _ in range(depth):
-        push()
-    while queue:
-        item = queue.popleft()
-        if item[2] is not None:
-            torch.cuda.current_stream().wait_event(item[2])
-        yield item[0], item[1]
-        push()
+        stage()
+    while inflight:
+        images, labels, done, _ = inflight.popleft()
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        yield images, labels
+        stage()

@@ -39,24 +39,24 @@ def test_cifar10_generator_contract(tmp_path):
     assert torch.equal(dev[2][0], torch.from_numpy(batches[2][0].astype(np.int32)))
 
 
-def test_mnist_generator_contract(tmp_path):
-    from ctgan_amd.tflib import mnist
-    rng = np.random.default_rng(1)
-
-    def split(n):
-        x = rng.random((n, 784)).astype('float32'); x[:, 0] = np.arange(n)
-        return x, (np.arange(n) % 10).astype('int64')
-    path = str(tmp_path / 'mnist.pkl.gz')
-    with gzip.open(path, 'wb') as f:
-        pickle.dump((split(120), split(30), split(30)), f, protocol=2)
-    train_gen, dev_gen, test_gen = mnist.load(50, 10, n_examples=100, filepath=path)
-    np.random.seed(0)
-    b = list(train_gen())
-    assert len(b) == 2 and b[0][0].shape == (50, 784) and b[0][0].dtype == np.float32
-    ids = np.concatenate([x[0][:, 0] for x in b])
-    assert set(ids.astype(int).tolist()) == set(range(100))
-    assert np.array_equal(ids.astype(int) % 10, np.concatenate([x[1] for x in b]))
-    assert len(list(dev_gen())) == 3 and len(list(test_gen())) == 3
+def test_cifar10_epoch_order_is_the_in_place_shuffle_order(tmp_path):
+    """The reference shuffles images and labels in place under a saved / restored global generator state
+    (TF/tflib/cifar10.py:57-60); EpochFeed draws one index permutation per epoch.  Same rows in the same order, epoch after
+    epoch, and the same generator state afterwards."""
+    from ctgan_amd.tflib import cifar10
+    _fake_cifar(str(tmp_path))
+    train_gen, _ = cifar10.load(10, str(tmp_path), n_examples=100)
+    ids0 = train_gen.images[:, 0].copy()
+    np.random.seed(11)
+    got = [np.concatenate([b[0][:, 0] for b in train_gen()]) for _ in range(3)]
+    state_after = np.random.get_state()[1].copy()
+    np.random.seed(11)
+    ref = ids0.copy()
+    for e in range(3):
+        st = np.random.get_state(); np.random.shuffle(ref); np.random.set_state(st)
+        np.random.shuffle(np.arange(100))           # the labels' shuffle: advances the generator exactly as much
+        assert np.array_equal(got[e], ref)
+    assert np.array_equal(state_after, np.random.get_state()[1])
 
 
 def test_save_images_grid(tmp_path):

@@ -51,8 +51,22 @@ def _worker(rank, world, port, out_dir):
     real, labels, rnd, rg = _inputs(rank, 4, 8)
     o1 = tr.d_step(real, labels, rnd, iteration=0)
     o2 = tr.g_step(rg, iteration=1)
-    torch.save({'d': tr.d_opt.theta.clone(), 'g': tr.g_opt.theta.clone(), 'dcost': o1['cost'].detach(),
-                'gcost': o2['cost'].detach()}, os.path.join(out_dir, 'rank%d.pt' % rank))
+    snap = {'d': tr.d_opt.theta.clone(), 'g': tr.g_opt.theta.clone(), 'dcost': o1['cost'].detach(), 'gcost': o2['cost'].detach()}
+    # then the loop body in the reference's order through the engine ([G] + 5 x D, default fused path, per-rank Philox
+    # streams and batches): 1 + 5 more all-reduces; the replicas must still hold the same bits afterwards
+    from ctgan_amd.engine import GraphedTrainer
+    eng = GraphedTrainer(tr, use_graphs=False)
+    g = torch.Generator().manual_seed(500 + rank)
+    feed = [(torch.randint(0, 256, (4, 3072), generator=g, dtype=torch.int32), torch.randint(0, 10, (4,), generator=g, dtype=torch.int32))
+            for _ in range(5)]
+    k = [0]
+
+    def nb():
+        k[0] += 1
+        return feed[(k[0] - 1) % 5]
+    o3 = eng.train_iteration(2, nb)
+    snap.update(d_loop=tr.d_opt.theta.clone(), g_loop=tr.g_opt.theta.clone(), loop_cost=o3['cost'].detach(), d_t=tr.d_opt.t, g_t=tr.g_opt.t)
+    torch.save(snap, os.path.join(out_dir, 'rank%d.pt' % rank))
     ddp.barrier()
     torch.distributed.destroy_process_group()
 
@@ -68,6 +82,9 @@ def test_two_rank_step_equals_average_of_rank_gradients(tmp_path):
     res = [torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r)) for r in range(world)]
     assert torch.equal(res[0]['d'], res[1]['d']) and torch.equal(res[0]['g'], res[1]['g'])      # replicas stay in sync
     assert not torch.equal(res[0]['dcost'], res[1]['dcost'])                                     # different shards
+    assert torch.equal(res[0]['d_loop'], res[1]['d_loop']) and torch.equal(res[0]['g_loop'], res[1]['g_loop'])
+    assert not torch.equal(res[0]['d_loop'], res[0]['d']) and not torch.equal(res[0]['loop_cost'], res[1]['loop_cost'])
+    assert (res[0]['d_t'], res[0]['g_t']) == (6, 2)
 
     # single-process reference: rank-0 init, per-rank gradients computed separately, averaged, one Adam step
     lib = _patch_cpu()
