@@ -1,0 +1,726 @@
+// igemm16.hip - implicit-GEMM convolution family on the gfx950 16-bit matrix cores
+// (v_mfma_f32_32x32x16_bf16 / _f16: 16x the rate of the fp32 MFMA the fp32 family in igemm.hip uses).
+//
+// Mixed precision as BASELINE.json configs[1] / [4] name it: operands are rounded to bf16 (or fp16) on their way into
+// LDS, products are accumulated in fp32 by the MFMA, master weights / activations / gradients stay fp32 in HBM.  Filters are
+// packed once per weight version into a 16-bit K-major image (ctgan_conv2d16_pack_filter), so the filter operand is
+// streamed at 2 bytes per element; the pixel operand is read as fp32 and converted while it is staged (v_cvt_pk_*).
+//
+//   FWD   : D[pixel m][kout n] = sum_{k=(r,s,c)}  X(m; r,s,c) * Wp[n][k]
+//   DGRAD : the same kernel on dy: a stride-1 data gradient is ONE correlation with the rotated filter, a stride-2 data
+//           gradient is FOUR (one per parity of the dx pixel) with only the taps of that parity - the phase rides the M-tile
+//           index, every phase has its own tap counts (5x5: 3x3, 3x2, 2x3, 2x2 - no zero taps), pads and packed filter.
+//   WGRAD : dW[(r,s,c)][kout] = sum_pixels X(pixel; r,s,c) * dY[pixel][kout]: both operands are pixel-major in memory but the
+//           MFMA wants 8 consecutive k (= pixels) per lane, so the staging pass transposes: a thread loads the same 4
+//           channels of 4 consecutive pixels and packs (pixel, pixel+1) pairs with the conversion itself - the transpose
+//           costs no extra instruction, only 8-byte instead of 16-byte LDS writes.  Split over the pixel axis into fp32
+//           slabs + fixed-order reduction (deterministic, no float atomics).
+//
+// Orientation: the MFMA "A" operand is always the CHANNEL-indexed one (kout for FWD/DGRAD, c for WGRAD), so a lane's four
+// consecutive accumulator registers are four consecutive channels of one pixel / one filter row.
+// Tiling: 4 waves as 2x2, a wave owns TMxTN 32x32 accumulators, K slices of BK = 64 (or 32) elements, two LDS stages, one
+// barrier per slice, register prefetch of the next slice, buffer loads with hardware range checks for the padding taps.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+template <int MMA> struct Cvt;
+template <> struct Cvt<CTGAN_MMA_BF16> {
+    static __device__ __forceinline__ unsigned pk(float a, float b) {
+        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+        v2 v; v.x = (__bf16)a; v.y = (__bf16)b;
+        return __builtin_bit_cast(unsigned, v);
+    }
+    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Cvt<CTGAN_MMA_F16> {
+    static __device__ __forceinline__ unsigned pk(float a, float b) {
+        typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+        v2 v; v.x = (_Float16)a; v.y = (_Float16)b;
+        return __builtin_bit_cast(unsigned, v);
+    }
+    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- filter packing
+// FWD : wp[n][(r*S + s)*C + c]                       = w[r][s][c][n]                    (n = kout)
+// DGRAD, phase (a,b): wp[off(a,b) + n*Kph + ((t*U + u)*Kout + k)] = w[r][s][n][k]      (n = c: the data gradient's output channel)
+//        r = r0(a) + step*(T(a)-1-t), s = s0(b) + step*(U(b)-1-u)   (rotated: the gather then runs forward)
+struct PhaseGeom { int T[2], U[2], r0[2], s0[2], pad_t[2], pad_l[2]; int nph, step; };
+
+PhaseGeom phase_geom(const ctgan_conv_desc* d) {
+    PhaseGeom g{};
+    if (d->stride == 1) {
+        g.nph = 1; g.step = 1;
+        g.T[0] = d->R; g.U[0] = d->S; g.r0[0] = g.s0[0] = 0;
+        g.pad_t[0] = d->R - 1 - d->pad_t; g.pad_l[0] = d->S - 1 - d->pad_l;
+        return g;
+    }
+    g.nph = 4; g.step = 2;
+    for (int a = 0; a < 2; ++a) {
+        g.r0[a] = (a + d->pad_t) & 1;
+        g.T[a] = (d->R - g.r0[a] + 1) / 2;
+        g.pad_t[a] = g.T[a] - 1 - (a + d->pad_t - g.r0[a]) / 2;
+        g.s0[a] = (a + d->pad_l) & 1;
+        g.U[a] = (d->S - g.s0[a] + 1) / 2;
+        g.pad_l[a] = g.U[a] - 1 - (a + d->pad_l - g.s0[a]) / 2;
+    }
+    return g;
+}
+long long phase_off(const PhaseGeom& g, const ctgan_conv_desc* d, int ph) {     // 16-bit elements before phase `ph`
+    long long o = 0;
+    for (int q = 0; q < ph; ++q) o += (long long)d->C * g.T[q >> 1] * g.U[q & 1] * d->K;
+    return o;
+}
+
+template <int MMA>
+__global__ void pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int RS, int C, int K) {
+    // one thread per (n, tap, pair of c): reads are strided by K (the transpose), writes are 4-byte and coalesced
+    const long long per = (long long)RS * C / 2, total = per * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / per);
+        const long long e = (i - (long long)n * per) * 2;                      // (tap*C + c), c even
+        const float a = w[e * K + n], b = w[(e + 1) * K + n];
+        reinterpret_cast<unsigned*>(wp)[i] = Cvt<MMA>::pk(a, b);
+    }
+}
+struct PackPhases { int T[2], U[2], r0[2], s0[2]; int nph, step, R, S, C, K; long long off[4]; };
+template <int MMA>
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const PackPhases pp) {
+    const int ph = blockIdx.y, a = ph >> 1, b = ph & 1;
+    const int T = pp.T[a], U = pp.U[b];
+    const long long kph = (long long)T * U * pp.K, per = kph / 2, total = per * pp.C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / per);
+        const long long e = (i - (long long)n * per) * 2;                      // (t*U + u)*K + k, k even
+        const int k = (int)(e % pp.K), tu = (int)(e / pp.K), t = tu / U, u = tu - t * U;
+        const int r = pp.r0[a] + pp.step * (T - 1 - t), s = pp.s0[b] + pp.step * (U - 1 - u);
+        const float* src = w + (((long long)r * pp.S + s) * pp.C + n) * pp.K + k;
+        reinterpret_cast<unsigned*>(wp + pp.off[ph])[i] = Cvt<MMA>::pk(src[0], src[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- FWD / DGRAD kernel
+struct P16 {
+    const float* X;                 // pixel operand (fp32, channel stride 1)
+    const unsigned short* Wp;       // packed filter
+    const float* bias; const float* mask; const float* resid;
+    float* D;
+    int H, W;                       // source extent of the gather
+    int P, Q;                       // pixel grid of ONE phase (rows of the GEMM = N*P*Q)
+    int C;                          // channels per tap of the pixel operand (GEMM K per tap)
+    int stride;                     // gather stride (1 for data gradients)
+    long long s_n, s_h, s_w;        // source strides (elements)
+    int M, Ng;                      // rows per phase, output channels
+    long long ds_n, ds_p, ds_q;     // D strides over (n, phase-grid row, phase-grid col); channel stride 1
+    int relu, relu_in;
+    unsigned x_bytes, w_bytes;
+    int nph, ph_tiles_m;
+    int ph_T[2], ph_U[2], ph_pad_t[2], ph_pad_l[2];
+    long long ph_w_off[4];          // packed-filter element offset of a phase
+    long long ph_d_h, ph_d_w;       // D offset of phase (a,b) = a*ph_d_h + b*ph_d_w
+};
+
+template <int MMA, int TM, int TN, int BK, bool RELU_IN>
+__global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
+    // TM: 32-wide kout sub-tiles per wave ("A" operand), TN: 32-wide pixel sub-tiles per wave ("B" operand)
+    constexpr int NT = 256;
+    constexpr int BMP = 2 * TN * 32;                    // pixels per block
+    constexpr int BNC = 2 * TM * 32;                    // kout per block
+    constexpr int LDS_K = BK + 8;                       // 16-bit elements per LDS row: 144 B (BK 64) / 80 B (BK 32): conflict-free b128 reads
+    constexpr int XC = BK / 4;                          // 16-B fp32 chunks per pixel row per slice
+    constexpr int X_PER = BMP * XC / NT;                // fp32 float4 loads per thread per slice
+    constexpr int WC = BK / 8;                          // 16-B packed chunks per filter row per slice
+    constexpr int W_PER = BNC * WC / NT;
+    static_assert(BMP * XC % NT == 0 && BNC * WC % NT == 0 && X_PER >= 1 && W_PER >= 1, "tile / thread mismatch");
+    constexpr int STAGE = (BMP + BNC) * LDS_K;          // 16-bit elements
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;            // wave's kout half / pixel half
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // neighbouring pixel tiles (shared halo rows) on one XCD
+    const int tiles_n = (p.Ng + BNC - 1) / BNC;
+    int tile_m = bid / tiles_n;
+    const int tile_n = bid - tile_m * tiles_n;
+    int pa = 0, pb = 0, ph = 0;
+    if (p.nph > 1) { ph = tile_m / p.ph_tiles_m; tile_m -= ph * p.ph_tiles_m; pa = ph >> 1; pb = ph & 1; }
+    const int T = p.ph_T[pa], U = p.ph_U[pb], pad_t = p.ph_pad_t[pa], pad_l = p.ph_pad_l[pb];
+    const long long w_off = p.ph_w_off[ph];
+    const long long d_off = pa * p.ph_d_h + pb * p.ph_d_w;
+    const int m0 = tile_m * BMP, n0 = tile_n * BNC;
+    const int cpt = p.C / BK;                            // slices per tap
+    const int nk = T * U * cpt;
+    const long long kph = (long long)T * U * p.C;        // packed-filter row length of this phase
+    const int PQ = p.P * p.Q;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
+
+    // pixel-operand loader: thread -> (row, 16-B chunk); the row's byte offset at tap (0,0) is fixed for the whole kernel
+    const int x_chunk = tid % XC, x_row0 = tid / XC;
+    unsigned x_voff[X_PER];
+    int x_ih0[X_PER], x_iw0[X_PER];
+    bool x_valid[X_PER];
+#pragma unroll
+    for (int i = 0; i < X_PER; ++i) {
+        const int m = m0 + x_row0 + i * (NT / XC);
+        x_valid[i] = m < p.M;
+        const int mm = x_valid[i] ? m : 0;
+        const int n = mm / PQ, rem = mm - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+        x_ih0[i] = pp * p.stride - pad_t;
+        x_iw0[i] = qq * p.stride - pad_l;
+        const long long o = (long long)n * p.s_n + (long long)x_ih0[i] * p.s_h + (long long)x_iw0[i] * p.s_w + x_chunk * 4;
+        x_voff[i] = (unsigned)(o * 4);                   // may be "negative": wraps consistently mod 2^32
+    }
+    const int w_chunk = tid % WC, w_row0 = tid / WC;
+    unsigned w_voff[W_PER];
+#pragma unroll
+    for (int i = 0; i < W_PER; ++i) {
+        const int n = n0 + w_row0 + i * (NT / WC);
+        w_voff[i] = n < p.Ng ? (unsigned)((w_off + (long long)n * kph + w_chunk * 8) * 2) : 0xFFFFFFFFu;
+    }
+
+    float4 rx[X_PER];
+    u32x4 rw[W_PER];
+    int ld_t = 0, ld_u = 0, ld_c = 0, ld_k = 0;          // tap / channel chunk / linear slice index of the NEXT slice to load
+    auto load_slice = [&]() {
+        const unsigned xs = (unsigned)(((long long)ld_t * p.s_h + (long long)ld_u * p.s_w + ld_c * BK) * 4);
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i) {
+            const bool ok = x_valid[i] & ((unsigned)(x_ih0[i] + ld_t) < (unsigned)p.H) & ((unsigned)(x_iw0[i] + ld_u) < (unsigned)p.W);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? x_voff[i] + xs : 0xFFFFFFFFu, 0, 0);
+            rx[i] = __builtin_bit_cast(float4, v);
+        }
+        const unsigned ws = (unsigned)((long long)ld_k * BK * 2);
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], ws, 0);
+            rw[i] = __builtin_bit_cast(u32x4, v);
+        }
+        ++ld_k;
+        if (++ld_c == cpt) { ld_c = 0; if (++ld_u == U) { ld_u = 0; ++ld_t; } }
+    };
+    auto store_slice = [&](unsigned short* st) {
+        unsigned short* Xs = st;
+        unsigned short* Ws = st + BMP * LDS_K;
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i) {
+            float4 v = rx[i];
+            if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            u32x2 o = {Cvt<MMA>::pk(v.x, v.y), Cvt<MMA>::pk(v.z, v.w)};
+            *reinterpret_cast<u32x2*>(&Xs[(x_row0 + i * (NT / XC)) * LDS_K + x_chunk * 4]) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i)
+            *reinterpret_cast<u32x4*>(&Ws[(w_row0 + i * (NT / WC)) * LDS_K + w_chunk * 8]) = rw[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int h = lane >> 5, l31 = lane & 31;
+    load_slice();
+    store_slice(smem);
+    if (nk > 1) load_slice();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned short* Xs = smem + (kt & 1) * STAGE;
+        const unsigned short* Ws = Xs + BMP * LDS_K;
+        if (kt + 1 < nk) store_slice(smem + ((kt + 1) & 1) * STAGE);     // the other stage: its readers passed the last barrier
+        if (kt + 2 < nk) load_slice();
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            u32x4 fw[TM], fx[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fw[i] = *reinterpret_cast<const u32x4*>(&Ws[(wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fx[j] = *reinterpret_cast<const u32x4*>(&Xs[(wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fw[i], fx[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue through LDS: acc[i][j][4g + e] = D(pixel j*32 + l31, kout i*32 + 8g + 4h + e); every wave transposes its own
+    // (TN*32 pixels) x (TM*32 kout) block so that a lane then owns 4 consecutive channels of a pixel and a wave instruction
+    // stores whole rows (16-B per lane, mask / residual / bias operands as 16-B loads).
+    constexpr int LDE = TM * 32 + 4;          // the launcher sizes the LDS for max(two stages, this staging area)
+    float* es = reinterpret_cast<float*>(smem) + wave * (TN * 32 * LDE);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<float4*>(&es[(j * 32 + l31) * LDE + i * 32 + 8 * g + 4 * h]) = v;
+            }
+    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the wave reads back what its own lanes wrote (no cross-wave traffic)
+    __builtin_amdgcn_wave_barrier();
+    constexpr int C4 = TM * 8;                // float4 per pixel row of the wave's block
+    constexpr int ROWS_PER = 64 / C4;
+#pragma unroll
+    for (int it = 0; it < TN * 32 / ROWS_PER; ++it) {
+        const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
+        const int m = m0 + wn * TN * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
+        if (m >= p.M || col >= p.Ng) continue;
+        float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+        const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+        const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (p.mask) {
+            const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+            v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+        }
+        if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(p.D + off) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- WGRAD kernel
+struct W16 {
+    const float* X; const float* DY;
+    float* OUT;                      // [splits][Mtot][Ng] fp32 slabs (the final dw when splits == 1)
+    int H, W, P, Q, C, R, S, stride, pad_t, pad_l;
+    long long s_n, s_h, s_w;         // x strides (channel stride 1)
+    int Mtot, Ng, Kg;                // R*S*C, kout, N*P*Q
+    int chunk;                       // pixels per split (multiple of 64)
+    int relu_x;
+    unsigned x_bytes, dy_bytes;
+};
+
+template <int MMA, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
+    // block tile: (2*TM*32) channels of ONE tap  x  (2*TN*32) kout, K slices of 64 pixels
+    constexpr int NT = 256, BKP = 64;
+    constexpr int BMC = 2 * TM * 32, BNK = 2 * TN * 32;
+    constexpr int LDS_K = BKP + 8;
+    constexpr int STAGE = (BMC + BNK) * LDS_K;
+    constexpr int XG = BMC / 4;                         // 4-channel groups of the x tile
+    constexpr int X_PER = XG * (BKP / 4) / NT;          // (4 pixels x 4 channels) blocks per thread per slice
+    constexpr int YG = BNK / 4;
+    constexpr int Y_PER = YG * (BKP / 4) / NT;
+    static_assert(XG * (BKP / 4) % NT == 0 && YG * (BKP / 4) % NT == 0 && X_PER >= 1 && Y_PER >= 1, "tile / thread mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.Ng + BNK - 1) / BNK;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int cblocks = p.C / BMC;                       // M tiles per tap
+    const int tap = tile_m / cblocks, c0 = (tile_m - tap * cblocks) * BMC;
+    const int r = tap / p.S, s = tap - r * p.S;
+    const int n0 = tile_n * BNK;
+    const int k_begin = blockIdx.y * p.chunk;
+    const int k_end = min(k_begin + p.chunk, p.Kg);
+    const int nk = (k_end - k_begin + BKP - 1) / BKP;
+    const int PQ = p.P * p.Q;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.dy_bytes, 0x00020000);
+
+    // staging map: lane -> (pixel group of 4 = lane % 8 [+ 8 per extra block], channel group of 4 = lane / 8 + 8 * wave [+ 32 ...]):
+    // a wave load instruction touches 8 pixel groups x 128 B of channels; its LDS writes land 2-way = the minimum for 512 B.
+    float4 rxv[X_PER][4], ryv[Y_PER][4];
+    auto load_slice = [&](int kt) {
+        const int kbase = k_begin + kt * BKP;
+#pragma unroll
+        for (int b = 0; b < X_PER; ++b) {
+            const int blk = b * NT + tid;                // 0 .. XG*16-1
+            const int pg = blk % 16, cg = blk / 16;      // 16 pixel groups, XG channel groups
+            const int pix = kbase + pg * 4;              // 4 consecutive pixels: same image row (Q % 4 == 0)
+            const bool inr = pix < k_end;
+            const int pc = inr ? pix : 0;
+            const int n = pc / PQ, rem = pc - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+            const int ih = pp * p.stride - p.pad_t + r;
+            const bool rowok = inr & ((unsigned)ih < (unsigned)p.H);
+            const long long base = (long long)n * p.s_n + (long long)ih * p.s_h + c0 + cg * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int iw = (qq + e) * p.stride - p.pad_l + s;
+                const bool ok = rowok & ((unsigned)iw < (unsigned)p.W);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)((base + (long long)iw * p.s_w) * 4) : 0xFFFFFFFFu, 0, 0);
+                rxv[b][e] = __builtin_bit_cast(float4, v);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < Y_PER; ++b) {
+            const int blk = b * NT + tid;
+            const int pg = blk % 16, cg = blk / 16;
+            const int pix = kbase + pg * 4;
+            const bool colok = (n0 + cg * 4) < p.Ng;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = colok & (pix + e < k_end);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? (unsigned)(((long long)(pix + e) * p.Ng + n0 + cg * 4) * 4) : 0xFFFFFFFFu, 0, 0);
+                ryv[b][e] = __builtin_bit_cast(float4, v);
+            }
+        }
+    };
+    auto store_slice = [&](unsigned short* st) {
+        unsigned short* Xs = st;
+        unsigned short* Ys = st + BMC * LDS_K;
+#pragma unroll
+        for (int b = 0; b < X_PER; ++b) {
+            const int blk = b * NT + tid;
+            const int pg = blk % 16, cg = blk / 16;
+            float4 (&v)[4] = rxv[b];
+            if (p.relu_x) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e].x = fmaxf(v[e].x, 0.f); v[e].y = fmaxf(v[e].y, 0.f); v[e].z = fmaxf(v[e].z, 0.f); v[e].w = fmaxf(v[e].w, 0.f); }
+            }
+            // transpose by register naming: channel j of pixels 0..3 -> two packed dwords
+            u32x2 o0 = {Cvt<MMA>::pk(v[0].x, v[1].x), Cvt<MMA>::pk(v[2].x, v[3].x)};
+            u32x2 o1 = {Cvt<MMA>::pk(v[0].y, v[1].y), Cvt<MMA>::pk(v[2].y, v[3].y)};
+            u32x2 o2 = {Cvt<MMA>::pk(v[0].z, v[1].z), Cvt<MMA>::pk(v[2].z, v[3].z)};
+            u32x2 o3 = {Cvt<MMA>::pk(v[0].w, v[1].w), Cvt<MMA>::pk(v[2].w, v[3].w)};
+            unsigned short* dst = &Xs[(cg * 4) * LDS_K + pg * 4];
+            *reinterpret_cast<u32x2*>(dst) = o0;
+            *reinterpret_cast<u32x2*>(dst + LDS_K) = o1;
+            *reinterpret_cast<u32x2*>(dst + 2 * LDS_K) = o2;
+            *reinterpret_cast<u32x2*>(dst + 3 * LDS_K) = o3;
+        }
+#pragma unroll
+        for (int b = 0; b < Y_PER; ++b) {
+            const int blk = b * NT + tid;
+            const int pg = blk % 16, cg = blk / 16;
+            const float4 (&v)[4] = ryv[b];
+            u32x2 o0 = {Cvt<MMA>::pk(v[0].x, v[1].x), Cvt<MMA>::pk(v[2].x, v[3].x)};
+            u32x2 o1 = {Cvt<MMA>::pk(v[0].y, v[1].y), Cvt<MMA>::pk(v[2].y, v[3].y)};
+            u32x2 o2 = {Cvt<MMA>::pk(v[0].z, v[1].z), Cvt<MMA>::pk(v[2].z, v[3].z)};
+            u32x2 o3 = {Cvt<MMA>::pk(v[0].w, v[1].w), Cvt<MMA>::pk(v[2].w, v[3].w)};
+            unsigned short* dst = &Ys[(cg * 4) * LDS_K + pg * 4];
+            *reinterpret_cast<u32x2*>(dst) = o0;
+            *reinterpret_cast<u32x2*>(dst + LDS_K) = o1;
+            *reinterpret_cast<u32x2*>(dst + 2 * LDS_K) = o2;
+            *reinterpret_cast<u32x2*>(dst + 3 * LDS_K) = o3;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int h = lane >> 5, l31 = lane & 31;
+    if (nk > 0) {
+        load_slice(0);
+        store_slice(smem);
+        if (nk > 1) load_slice(1);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned short* Xs = smem + (kt & 1) * STAGE;
+        const unsigned short* Ys = Xs + BMC * LDS_K;
+        if (kt + 1 < nk) store_slice(smem + ((kt + 1) & 1) * STAGE);
+        if (kt + 2 < nk) load_slice(kt + 2);
+#pragma unroll
+        for (int ks = 0; ks < BKP / 16; ++ks) {
+            u32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const u32x4*>(&Xs[(wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const u32x4*>(&Ys[(wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fa[i], fb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    // acc[i][j][4g + e] = dW(channel c0 + wm*TM*32 + i*32 + 8g + 4h + e, kout n0 + wn*TN*32 + j*32 + l31): 32 lanes = 128 B rows
+    float* out = p.OUT + (long long)blockIdx.y * p.Mtot * p.Ng;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + l31;
+            if (col >= p.Ng) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = c0 + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[((long long)tap * p.C + c) * p.Ng + col] = acc[i][j][e];
+            }
+        }
+}
+
+__global__ void reduce16_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int splits) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int k = 0;
+    for (; k + 2 <= splits; k += 2) {                                  // fixed order: deterministic
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
+        const float4 v1 = *reinterpret_cast<const float4*>(part + (long long)(k + 1) * n + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    }
+    if (k < splits) {
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+bool mma_ok(int mma) { return mma == CTGAN_MMA_BF16 || mma == CTGAN_MMA_F16; }
+
+bool shape_ok_fwd(const ctgan_conv_desc* d) {
+    return !d->x_up && d->C % 32 == 0 && d->K % 4 == 0 && d->xs[1] == 1 && d->ys[1] == 1 &&
+           d->xs[0] % 4 == 0 && d->xs[2] % 4 == 0 && d->xs[3] % 4 == 0 && d->ys[0] % 4 == 0 && d->ys[2] % 4 == 0 && d->ys[3] % 4 == 0;
+}
+bool shape_ok_dgrad(const ctgan_conv_desc* d) {
+    if (d->x_up || d->K % 32 != 0 || d->C % 4 != 0 || d->xs[1] != 1 || d->ys[1] != 1) return false;
+    if (d->xs[0] % 4 || d->xs[2] % 4 || d->xs[3] % 4 || d->ys[0] % 4 || d->ys[2] % 4 || d->ys[3] % 4) return false;
+    if (d->stride == 2) return !(d->H & 1) && !(d->W & 1) && d->P * 2 == d->H && d->Q * 2 == d->W;
+    return d->stride == 1;
+}
+bool shape_ok_wgrad(const ctgan_conv_desc* d) {
+    return !d->x_up && d->C % 64 == 0 && d->K % 4 == 0 && d->Q % 4 == 0 && d->xs[1] == 1 && d->xs[0] % 4 == 0 && d->xs[2] % 4 == 0 &&
+           d->xs[3] % 4 == 0 && d->ys[1] == 1 && d->ys[3] == d->K && d->ys[2] == (int64_t)d->Q * d->K && d->ys[0] == (int64_t)d->P * d->Q * d->K;
+}
+
+template <int MMA, int TM, int TN, int BK>
+int launch_conv16(const P16& p, hipStream_t st, const char* name) {
+    constexpr int BMP = 2 * TN * 32, BNC = 2 * TM * 32;
+    constexpr size_t lds_stages = (size_t)2 * (BMP + BNC) * (BK + 8) * 2, lds_epi = (size_t)4 * TN * 32 * (TM * 32 + 4) * 4;
+    constexpr size_t lds = lds_stages > lds_epi ? lds_stages : lds_epi;
+    auto kern = p.relu_in ? conv16_kernel<MMA, TM, TN, BK, true> : conv16_kernel<MMA, TM, TN, BK, false>;
+    static bool attr[2] = {false, false};
+    if (!attr[p.relu_in ? 1 : 0]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "conv16: cannot reserve %zu B of LDS", lds);
+        attr[p.relu_in ? 1 : 0] = true;
+    }
+    const int tiles_m = (p.M + BMP - 1) / BMP, tiles_n = (p.Ng + BNC - 1) / BNC;
+    P16 q = p;
+    q.ph_tiles_m = tiles_m;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n)), dim3(256), lds, st, q);
+    ctgan_set_last_kernel(name);
+    return ctgan_check_launch(name);
+}
+
+template <int MMA>
+int dispatch_conv16(const P16& p, hipStream_t st) {
+    // small pixel grids (8x8 / 4x4 layers at batch 64): 64x64 tiles expose 4x the workgroups
+    const long long big_tiles = (long long)p.nph * ((p.M + 127) / 128) * ((p.Ng + 127) / 128);
+    const bool small = big_tiles < 192 || p.Ng % 128 != 0;
+    if (p.C % 64 == 0) {
+        if (small) return launch_conv16<MMA, 1, 1, 64>(p, st, "conv16<64x64,k64>");
+        return launch_conv16<MMA, 2, 2, 64>(p, st, "conv16<128x128,k64>");
+    }
+    if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, "conv16<64x64,k32>");
+    return launch_conv16<MMA, 2, 2, 32>(p, st, "conv16<128x128,k32>");
+}
+
+template <int MMA, int TM, int TN>
+int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
+    constexpr int BMC = 2 * TM * 32, BNK = 2 * TN * 32;
+    constexpr size_t lds = (size_t)2 * (BMC + BNK) * (64 + 8) * 2;
+    auto kern = wgrad16_kernel<MMA, TM, TN>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16: cannot reserve %zu B of LDS", lds);
+        attr = true;
+    }
+    const int tiles_m = p.R * p.S * (p.C / BMC), tiles_n = (p.Ng + BNK - 1) / BNK;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), dim3(256), lds, st, p);
+    ctgan_set_last_kernel(name);
+    return ctgan_check_launch(name);
+}
+
+struct WPlan16 { int bmc, bnk, tiles, splits, chunk; };
+WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
+    WPlan16 w;
+    w.bmc = d->C % 128 == 0 ? 128 : 64;
+    w.bnk = d->K % 128 == 0 ? 128 : 64;
+    w.tiles = d->R * d->S * (d->C / w.bmc) * ((d->K + w.bnk - 1) / w.bnk);
+    const int Kg = d->N * d->P * d->Q;
+    // ~2 waves of workgroups over the 256 CUs, at least 4 slices (256 pixels) per split
+    int s = (512 + w.tiles - 1) / w.tiles;
+    const int max_s = (Kg + 255) / 256;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    int ch = (Kg + s - 1) / s;
+    ch = ((ch + 63) / 64) * 64;
+    w.splits = (Kg + ch - 1) / ch;
+    w.chunk = ch;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op) {
+    if (!d) return 0;
+    if (op == CTGAN_CONV_FWD) return shape_ok_fwd(d) ? 1 : 0;
+    if (op == CTGAN_CONV_DGRAD) return shape_ok_dgrad(d) ? 1 : 0;
+    if (op == CTGAN_CONV_WGRAD) return shape_ok_wgrad(d) ? 1 : 0;
+    return 0;
+}
+
+size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op) {
+    if (!d) return 0;
+    return (size_t)d->R * d->S * d->C * d->K;          // both layouts hold every tap exactly once (no zero-padded phases)
+}
+
+int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream) {
+    if (!d || !w || !wp || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_filter: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* out = (unsigned short*)wp;
+    if (op == CTGAN_CONV_FWD) {
+        if (d->C % 2) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_filter: odd channel count");
+        const long long total = (long long)d->R * d->S * d->C / 2 * d->K;
+        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K);
+        else hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K);
+        return ctgan_check_launch("pack16_fwd");
+    }
+    if (op == CTGAN_CONV_DGRAD) {
+        if (!shape_ok_dgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_filter: data-gradient shape outside the 16-bit family");
+        const PhaseGeom g = phase_geom(d);
+        PackPhases pp{};
+        for (int a = 0; a < 2; ++a) { pp.T[a] = g.T[a]; pp.U[a] = g.U[a]; pp.r0[a] = g.r0[a]; pp.s0[a] = g.s0[a]; }
+        pp.nph = g.nph; pp.step = g.step; pp.R = d->R; pp.S = d->S; pp.C = d->C; pp.K = d->K;
+        long long most = 0;
+        for (int ph = 0; ph < g.nph; ++ph) {
+            pp.off[ph] = phase_off(g, d, ph);
+            const long long n = (long long)d->C * g.T[ph >> 1] * g.U[ph & 1] * d->K / 2;
+            if (n > most) most = n;
+        }
+        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_dgrad_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(most, 256), g.nph), dim3(256), 0, st, w, out, pp);
+        else hipLaunchKernelGGL(pack_dgrad_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(most, 256), g.nph), dim3(256), 0, st, w, out, pp);
+        return ctgan_check_launch("pack16_dgrad");
+    }
+    return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_filter: op %d", op);
+}
+
+int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
+                       float* y, int flags, ctgan_stream_t stream) {
+    if (!d || !x || !wp || !y || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_fwd: bad argument");
+    if (!shape_ok_fwd(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: shape outside the 16-bit family");
+    const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
+    if (x_extent * 4 >= (1LL << 32) || (long long)d->R * d->S * d->C * d->K * 2 >= (1LL << 32))
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: operand exceeds the 4 GiB buffer range");
+    P16 p{};
+    p.X = x; p.Wp = (const unsigned short*)wp; p.bias = bias; p.resid = resid; p.mask = nullptr; p.D = y;
+    p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.C = d->C; p.stride = d->stride;
+    p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
+    p.M = d->N * d->P * d->Q; p.Ng = d->K;
+    p.ds_n = d->ys[0]; p.ds_p = d->ys[2]; p.ds_q = d->ys[3];
+    p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
+    p.x_bytes = (unsigned)(x_extent * 4); p.w_bytes = (unsigned)((long long)d->R * d->S * d->C * d->K * 2);
+    p.nph = 1;
+    p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
+    p.ph_T[1] = d->R; p.ph_U[1] = d->S; p.ph_pad_t[1] = d->pad_t; p.ph_pad_l[1] = d->pad_l;
+    hipStream_t st = (hipStream_t)stream;
+    return mma == CTGAN_MMA_BF16 ? dispatch_conv16<CTGAN_MMA_BF16>(p, st) : dispatch_conv16<CTGAN_MMA_F16>(p, st);
+}
+
+int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias, const float* mask,
+                         const float* resid, float* dx, int flags, ctgan_stream_t stream) {
+    if (!d || !dy || !wp || !dx || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_dgrad: bad argument");
+    if (!shape_ok_dgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad: shape outside the 16-bit family");
+    const long long y_extent = (long long)(d->N - 1) * d->ys[0] + (long long)(d->P - 1) * d->ys[2] + (long long)(d->Q - 1) * d->ys[3] + d->K;
+    if (y_extent * 4 >= (1LL << 32) || (long long)d->R * d->S * d->C * d->K * 2 >= (1LL << 32))
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad: operand exceeds the 4 GiB buffer range");
+    const PhaseGeom g = phase_geom(d);
+    P16 p{};
+    p.X = dy; p.Wp = (const unsigned short*)wp; p.bias = bias; p.mask = mask; p.resid = resid; p.D = dx;
+    p.H = d->P; p.W = d->Q;                                  // the gather runs over dy
+    p.C = d->K; p.stride = 1;
+    p.s_n = d->ys[0]; p.s_h = d->ys[2]; p.s_w = d->ys[3];
+    p.Ng = d->C;
+    p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = 0;
+    p.x_bytes = (unsigned)(y_extent * 4); p.w_bytes = (unsigned)((long long)d->R * d->S * d->C * d->K * 2);
+    p.nph = g.nph;
+    for (int a = 0; a < 2; ++a) { p.ph_T[a] = g.T[a]; p.ph_U[a] = g.U[a]; p.ph_pad_t[a] = g.pad_t[a]; p.ph_pad_l[a] = g.pad_l[a]; }
+    for (int ph = 0; ph < 4; ++ph) p.ph_w_off[ph] = ph < g.nph ? phase_off(g, d, ph) : 0;
+    if (g.nph == 4) {
+        p.P = d->H / 2; p.Q = d->W / 2;
+        p.ds_n = d->xs[0]; p.ds_p = 2 * d->xs[2]; p.ds_q = 2 * d->xs[3];
+        p.ph_d_h = d->xs[2]; p.ph_d_w = d->xs[3];
+    } else {
+        p.P = d->H; p.Q = d->W;
+        p.ds_n = d->xs[0]; p.ds_p = d->xs[2]; p.ds_q = d->xs[3];
+        p.ph_T[1] = p.ph_T[0]; p.ph_U[1] = p.ph_U[0]; p.ph_pad_t[1] = p.ph_pad_t[0]; p.ph_pad_l[1] = p.ph_pad_l[0];
+    }
+    p.M = d->N * p.P * p.Q;
+    hipStream_t st = (hipStream_t)stream;
+    return mma == CTGAN_MMA_BF16 ? dispatch_conv16<CTGAN_MMA_BF16>(p, st) : dispatch_conv16<CTGAN_MMA_F16>(p, st);
+}
+
+size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d) {
+    if (!d || !shape_ok_wgrad(d)) return 0;
+    const WPlan16 w = wgrad16_plan(d);
+    return w.splits > 1 ? (size_t)w.splits * d->R * d->S * d->C * d->K * sizeof(float) : 0;
+}
+
+int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                         int flags, ctgan_stream_t stream) {
+    if (!d || !x || !dy || !dw || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad: bad argument");
+    if (!shape_ok_wgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: shape outside the 16-bit family");
+    const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
+    const long long y_extent = (long long)d->N * d->P * d->Q * d->K;
+    if (x_extent * 4 >= (1LL << 32) || y_extent * 4 >= (1LL << 32))
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: operand exceeds the 4 GiB buffer range");
+    const WPlan16 w = wgrad16_plan(d);
+    const size_t need = ctgan_conv2d16_wgrad_workspace_bytes(d);
+    if (need > ws_bytes || (need && !ws)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad: workspace %zu B < %zu B", ws_bytes, need);
+    W16 p{};
+    p.X = x; p.DY = dy; p.OUT = w.splits > 1 ? (float*)ws : dw;
+    p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.C = d->C; p.R = d->R; p.S = d->S; p.stride = d->stride;
+    p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
+    p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
+    p.chunk = w.chunk; p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0;
+    p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)(y_extent * 4);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const bool bf = mma == CTGAN_MMA_BF16;
+    if (w.bmc == 128 && w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 2>(p, w.splits, st, "wgrad16<128x128>") : launch_wgrad16<CTGAN_MMA_F16, 2, 2>(p, w.splits, st, "wgrad16<128x128>");
+    else if (w.bmc == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 1>(p, w.splits, st, "wgrad16<128x64>") : launch_wgrad16<CTGAN_MMA_F16, 2, 1>(p, w.splits, st, "wgrad16<128x64>");
+    else if (w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 2>(p, w.splits, st, "wgrad16<64x128>") : launch_wgrad16<CTGAN_MMA_F16, 1, 2>(p, w.splits, st, "wgrad16<64x128>");
+    else rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 1>(p, w.splits, st, "wgrad16<64x64>") : launch_wgrad16<CTGAN_MMA_F16, 1, 1>(p, w.splits, st, "wgrad16<64x64>");
+    if (rc) return rc;
+    if (w.splits > 1) {
+        const long long n = (long long)p.Mtot * p.Ng;
+        hipLaunchKernelGGL(reduce16_kernel, dim3(ctgan_blocks(n / 4, 256, 1 << 20)), dim3(256), 0, st, (const float*)ws, dw, n, w.splits);
+        return ctgan_check_launch("reduce16");
+    }
+    return 0;
+}
+
+}  // extern "C"

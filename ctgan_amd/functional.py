@@ -150,6 +150,7 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _SPREAD_BUFS     # same identity in every pass of the step
     fewch = K.fewch_handles(g)                    # few-channel convs: the direct kernel sums two uses in one launch
     defer = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
+             and K.MMA_DTYPE is None        # the multi-segment / grouped launches exist in the fp32 family only
              and ((g.C % 32 == 0 and g.K % 4 == 0) or (fewch and FEWCH_DEFER)) and not (g.R == 1 and g.H == 1 and g.W == 1))
     if not defer:
         if with_bias:
@@ -446,6 +447,7 @@ def _cached_filter(src, kind, pad=(0, 0), scale=1.0):
         _FCACHE[key] = e
         if kind in (K.FILTER_SPREAD, K.FILTER_SPREAD_FLIP):
             _SPREAD_BUFS[e.buf.data_ptr()] = e
+            K._STABLE_PTRS.add(e.buf.data_ptr())       # the 16-bit family may cache its packed image per registry epoch
     if e.epoch != lib.epoch(e.group):
         K.filter_batch([e.job()])
         _mark_built([e])

@@ -55,6 +55,65 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# ---- 16-bit matrix-core mode (csrc/igemm16.hip) ---------------------------------------------------------------------------
+# None: every conv runs on the exact-fp32 MFMA family.  'bf16' / 'f16': the layers the 16-bit family takes (channel counts that
+# are multiples of 32 / 64, even extents for stride-2 data gradients) multiply in bf16 / fp16 with fp32 accumulation; tensors
+# stay fp32 in HBM, filters are packed to 16 bits once per weight version.  Few-channel layers and everything else stay fp32.
+MMA_DTYPE = None
+_MMA_CODE = {'bf16': 1, 'f16': 2}
+_STABLE_PTRS = set()      # data_ptr of derived fp32 filters (spread filters) whose contents only change with the registry epoch
+_pack16 = {}              # (data_ptr, op, dtype, geometry) -> [packed int16 buffer, registry epoch it was built for]
+
+
+def set_mma_dtype(name):
+    """name: None | 'bf16' | 'f16'.  Returns the previous setting."""
+    global MMA_DTYPE
+    if name not in (None, 'bf16', 'f16'):
+        raise ValueError("mma dtype must be None, 'bf16' or 'f16'")
+    old, MMA_DTYPE = MMA_DTYPE, name
+    return old
+
+
+class mma_dtype:
+    """with kernels.mma_dtype('bf16'): ..."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.old = set_mma_dtype(self.name)
+
+    def __exit__(self, *a):
+        set_mma_dtype(self.old)
+        return False
+
+
+def clear_pack16_cache():
+    _pack16.clear()
+
+
+def _packed16(w, d, op, g):
+    """The 16-bit packed image of filter `w` for op (0 fwd, 1 dgrad) - cached per registry epoch for parameters and for derived
+    filters registered in _STABLE_PTRS; packed per call for any other tensor."""
+    from . import tflib
+    n = lib.ctgan_conv2d16_filter_elems(ctypes.byref(d), op)
+    stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _STABLE_PTRS
+    key = (w.data_ptr(), op, MMA_DTYPE, g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
+    ver = tflib.epoch()
+    ent = _pack16.get(key) if stable else None
+    if ent is not None and ent[1] == ver:
+        return ent[0]
+    if ent is None:
+        if not _pack16:
+            tflib.on_delete_all_params(clear_pack16_cache)
+        ent = [torch.empty(n, dtype=torch.int16, device=w.device), None]
+        if stable:
+            _pack16[key] = ent
+    check(lib.ctgan_conv2d16_pack_filter(ctypes.byref(d), op, _MMA_CODE[MMA_DTYPE], _ptr(w), _ptr(ent[0]), _stream()), 'conv2d16_pack_filter')
+    ent[1] = ver
+    return ent[0]
+
+
 def _need_dev(*ts):
     for t in ts:
         if t is None:
@@ -62,7 +121,7 @@ def _need_dev(*ts):
         if not t.is_cuda:
             raise RuntimeError('ctgan_amd kernels need HIP device tensors (got %s); there is no CPU fallback'
                                % t.device)
-        if t.dtype not in (torch.float32, torch.int32):
+        if t.dtype not in (torch.float32, torch.int32, torch.int16):
             raise TypeError('ctgan_amd kernels are fp32/int32 (got %s)' % t.dtype)
 
 
@@ -204,6 +263,12 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
         assert is_dense_like(resid, y)
     d = g.desc(N, x.stride(), y.stride())
     fl = (1 if relu else 0) | (2 if relu_in else 0) | (8 if (resid_up and resid is not None) else 0)
+    if (MMA_DTYPE is not None and drop is None and not (fl & 8) and not fewch_handles(g)
+            and lib.ctgan_conv2d16_supported(ctypes.byref(d), 0)):
+        wp = _packed16(w, d, 0, g)
+        code = _MMA_CODE[MMA_DTYPE]
+        _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd(ctypes.byref(d), code, _ptr(x), _ptr(wp), _ptr(bias), _ptr(resid), _ptr(y), fl, _stream()), 'conv2d16_fwd'))
+        return y
     if fl & 8:
         try:
             _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(resid), _ptr(y), fl, _ext(drop), _stream()), 'conv2d_fwd'))
@@ -257,6 +322,11 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
         mask = match_layout(mask, dx)
     if resid is not None:
         resid = match_layout(resid, dx)
+    if (MMA_DTYPE is not None and drop is None and not fewch_handles(g) and lib.ctgan_conv2d16_supported(ctypes.byref(d), 1)):
+        wp = _packed16(w, d, 1, g)
+        code = _MMA_CODE[MMA_DTYPE]
+        _timed(g, N, lambda: check(lib.ctgan_conv2d16_dgrad(ctypes.byref(d), code, _ptr(gy), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), 0, _stream()), 'conv2d16_dgrad'))
+        return dx
     if wt is not None:
         assert wt.numel() * 4 == lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)
         filt, ws_p, ws_n, fl = wt, None, 0, 1
@@ -284,6 +354,16 @@ def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
     if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous():
         gy = to_channels_last(gy)
     d = g.desc(N, x.stride(), gy.stride())
+    if MMA_DTYPE is not None and not fewch_handles(g):
+        gy16 = gy if gy.permute(0, 2, 3, 1).is_contiguous() else to_channels_last(gy)
+        d16 = g.desc(N, x.stride(), gy16.stride())
+        if lib.ctgan_conv2d16_supported(ctypes.byref(d16), 2):
+            ws = workspace(lib.ctgan_conv2d16_wgrad_workspace_bytes(ctypes.byref(d16)), x.device)
+            code = _MMA_CODE[MMA_DTYPE]
+            _timed(g, N, lambda: check(lib.ctgan_conv2d16_wgrad(ctypes.byref(d16), code, _ptr(x), _ptr(gy16), _ptr(dw), _ptr(ws), ws.numel(), 2 if relu_x else 0, _stream()), 'conv2d16_wgrad'))
+            if with_bias:
+                return dw, colsum_channels(gy16)
+            return dw
     nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 2)
     ws = workspace(nb, x.device)
     _timed(g, N, lambda: check(lib.ctgan_conv2d_wgrad(ctypes.byref(d), _ptr(x), _ptr(gy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), 2 if relu_x else 0, _stream()), 'conv2d_wgrad'))

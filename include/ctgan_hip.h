@@ -145,6 +145,28 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
  * with.  Callers that run several dgrads per weight update repack once and pass
  * CTGAN_DGRAD_W_REPACKED (then `w` is wt and no workspace is needed).                            */
 int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* wt, ctgan_stream_t stream);
+/* ---- 16-bit matrix-core family (csrc/igemm16.hip): BASELINE.json configs[1] "bf16" and configs[4] "fp16 MFMA conv" ----
+ * The same three operators (tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112, tf.nn.conv2d_transpose / the data gradient
+ * TF/tflib/ops/deconv2d.py:91-103, the filter gradient tf.gradients derives) computed as mixed precision: operands rounded
+ * (nearest-even) to bf16 or fp16 on their way into LDS, v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulation; activations,
+ * gradients and master weights stay fp32 in caller memory.  The filter operand is a packed 16-bit image built once per
+ * weight version by ctgan_conv2d16_pack_filter (FWD: [K][(r,s,c)]; DGRAD: per output-parity phase [C][(t,u,k)] with the taps
+ * of that phase only, rotated).  `mma` = CTGAN_MMA_BF16 | CTGAN_MMA_F16.  Shapes outside the family (few-channel layers, odd
+ * extents, x_up) return CTGAN_E_UNSUPPORTED: the caller uses the fp32 entry points above for those layers.
+ * Epilogues as the fp32 family: fwd  y = [relu](conv(x | relu(x)) + bias + resid);  dgrad  dx = (conv^T(dy) + bias)
+ * [kept where mask > 0] [+ resid].  flags = CTGAN_EPI_RELU | CTGAN_IN_RELU.  The bias gradient is not fused here
+ * (ctgan_colsum).                                                                                                     */
+enum { CTGAN_MMA_BF16 = 1, CTGAN_MMA_F16 = 2 };
+int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op);                 /* op = CTGAN_CONV_{FWD,DGRAD,WGRAD}; 1 / 0 */
+size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op);           /* 16-bit elements of the packed filter     */
+int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream);
+int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
+                       float* y, int flags, ctgan_stream_t stream);
+int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias,
+                         const float* mask, const float* resid, float* dx, int flags, ctgan_stream_t stream);
+size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d);
+int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws,
+                         size_t ws_bytes, int flags, ctgan_stream_t stream);
 /* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K);
  * db[k] = sum_{n,p,q} dy[n,k,p,q] when db != NULL (tf.nn.bias_add gradient, fused when possible) */
 int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,

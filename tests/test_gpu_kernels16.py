@@ -1,0 +1,230 @@
+"""The 16-bit matrix-core conv family (csrc/igemm16.hip: bf16 / fp16 operands, fp32 accumulation) through the C-ABI.
+
+Two kinds of checks per geometry and operator (forward, data gradient, weight gradient):
+  * EXACT-PRODUCT check: with operands that are representable in the 16-bit format the products are exact in fp32, so the
+    16-bit kernels must agree with the fp64 oracle to fp32 summation error (2e-5) - any indexing / packing / phase /
+    transposition mistake shows at full size of the error, rounding plays no part;
+  * ROUNDING check: with generic fp32 operands the result must sit within the format's rounding model of the fp64 truth:
+    relative L2 error <= 2 * 2^-(mantissa bits + 1) (two rounded operands per product; errors average over K).
+BASELINE.json configs[1] (DCGAN 5x5 stride-2 convs / transposed convs) and configs[4] (3x3, 3x3 stride 2, 4x4 stride-2
+resampling convs at 64..1024 channels) geometries.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tf_ops  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def K():
+    import ctgan_amd.kernels as K
+    yield K
+    K.set_mma_dtype(None)
+
+
+def cl(t):
+    d = t.to('cuda')
+    out = torch.empty((d.shape[0], d.shape[2], d.shape[3], d.shape[1]), device='cuda', dtype=d.dtype).permute(0, 3, 1, 2)
+    out.copy_(d)
+    return out
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rel_l2(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def q16(t, dt):
+    return t.to(torch.bfloat16 if dt == 'bf16' else torch.float16).float()
+
+
+EPS = {'bf16': 2.0 ** -9, 'f16': 2.0 ** -12}
+
+# (N, C, H, W, K, k, stride)
+CASES = [
+    (4, 128, 16, 16, 256, 5, 2),      # DCGAN critic layer 2 (:92); its data gradient = Deconv2D 256->128 of the generator (:70)
+    (8, 256, 8, 8, 512, 5, 2),        # DCGAN critic layer 3 / Deconv2D 512->256
+    (64, 128, 16, 16, 256, 5, 2),     # the same at batch 64: 128x128 tiles
+    (4, 64, 16, 16, 128, 3, 1),       # 3x3 stride 1, C = 64
+    (3, 32, 8, 8, 32, 3, 1),          # C = 32: the 32-deep K slice variant; K = 32: partial kout tile
+    (2, 96, 8, 12, 160, 3, 1),        # C = 96 (32-deep slices), K = 160 (partial tiles), H != W
+    (2, 64, 16, 16, 64, 1, 1),        # 1x1 shortcut
+    (6, 128, 8, 8, 128, 4, 2),        # 4x4 stride 2 = fused ConvMeanPool / UpsampleConv filter; data gradient: 4 phases of 2x2 taps
+    (2, 128, 32, 32, 256, 3, 2),      # 3x3 stride 2, SAME pad (0,1): config[4] critic 'down' conv2 (LS/wgan_LSUN_Bedrooms128.py:126-131)
+    (2, 1024, 8, 8, 1024, 3, 1),      # config[4] critic 1024-channel block
+    (70, 128, 1, 1, 2048, 1, 1),      # Linear 128 -> 2048 (1x1 conv on a 1x1 image)
+]
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d' % c)
+def test_conv16_fwd_dgrad_wgrad(K, case, dt):
+    N, C, H, W, Ko, k, st = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 1000)
+    geom = K.ConvGeom(C, H, W, Ko, k, k, st, False)
+    for exact in (True, False):
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
+        b = torch.randn(Ko, generator=g)
+        gy = torch.randn(N, Ko, geom.P, geom.Q, generator=g)
+        if exact:
+            x, w, gy = q16(x, dt), q16(w, dt), q16(gy, dt)
+        xr = x.double().requires_grad_(True)
+        wr = w.double().requires_grad_(True)
+        ref = tf_ops.bias_add_nchw(tf_ops.conv2d_same(xr, wr, st), b.double())
+        gx_ref, gw_ref = torch.autograd.grad(ref, [xr, wr], gy.double())
+        tol = (lambda got, want, what: (relerr(got, want) < 2e-5, relerr(got, want), what)) if exact else \
+              (lambda got, want, what: (rel_l2(got, want) < 2 * EPS[dt], rel_l2(got, want), what))
+        xd, wd, bd, gyd = cl(x), w.cuda(), b.cuda(), cl(gy)
+        with K.mma_dtype(dt):
+            y = K.conv_fwd(xd, wd, bd, geom)
+            assert K.last_kernel().startswith('conv16'), K.last_kernel()
+            ok, e, what = tol(y, ref, 'fwd'); assert ok, (what, e, K.last_kernel())
+            # epilogue: relu(conv(relu(x)) + b + resid)
+            r = torch.randn(ref.shape, generator=g)
+            y2 = K.conv_fwd(xd, wd, bd, geom, resid=cl(r), relu=True, relu_in=True)
+            ref2 = torch.relu(tf_ops.bias_add_nchw(tf_ops.conv2d_same(torch.relu(x.double()), w.double(), st), b.double()) + r.double())
+            ok, e, what = tol(y2, ref2, 'fwd+epilogue'); assert ok, (what, e)
+            gx = K.conv_dgrad(gyd, wd, geom, N)
+            assert K.last_kernel().startswith('conv16'), K.last_kernel()
+            ok, e, what = tol(gx, gx_ref, 'dgrad'); assert ok, (what, e, K.last_kernel())
+            # dgrad epilogue: (conv^T + bias) masked + resid  (bias has the data gradient's channel count)
+            bc = torch.randn(C, generator=g); m = torch.randn(N, C, H, W, generator=g); rr = torch.randn(N, C, H, W, generator=g)
+            gx2 = K.conv_dgrad(gyd, wd, geom, N, bias=bc.cuda(), mask=cl(m), resid=cl(rr))
+            ref_gx2 = torch.where(m.double() > 0, gx_ref + bc.double().view(1, -1, 1, 1), torch.zeros_like(gx_ref)) + rr.double()
+            ok, e, what = tol(gx2, ref_gx2, 'dgrad+epilogue'); assert ok, (what, e)
+            if C % 64 == 0 and geom.Q % 4 == 0:
+                gw, gb = K.conv_wgrad(xd, gyd, geom, with_bias=True)
+                ok, e, what = tol(gw, gw_ref, 'wgrad'); assert ok, (what, e)
+                assert relerr(gb, gy.double().sum(dim=(0, 2, 3))) < 2e-5
+                gw2 = K.conv_wgrad(xd, gyd, geom, relu_x=True)
+                xr2 = x.double()
+                wr2 = w.double().requires_grad_(True)
+                (gw2_ref,) = torch.autograd.grad(tf_ops.conv2d_same(torch.relu(xr2), wr2, st), [wr2], gy.double())
+                ok, e, what = tol(gw2, gw2_ref, 'wgrad relu_x'); assert ok, (what, e)
+
+
+def test_conv16_wgrad_runs_on_the_16bit_kernel_and_is_deterministic(K):
+    N, C, H, Ko = 16, 128, 16, 256
+    geom = K.ConvGeom(C, H, H, Ko, 5, 5, 2, False)
+    g = torch.Generator().manual_seed(5)
+    x, gy = cl(torch.randn(N, C, H, H, generator=g)), cl(torch.randn(N, Ko, 8, 8, generator=g))
+    with K.mma_dtype('bf16'):
+        a = K.conv_wgrad(x, gy, geom)
+        assert K.last_kernel().startswith('wgrad16'), K.last_kernel()
+        b = K.conv_wgrad(x, gy, geom)
+    assert torch.equal(a, b)                                   # fixed-order split-K reduction
+
+
+def test_packed_filter_cache_follows_the_registry_epoch(K):
+    """Parameters are packed once per weight version (tflib.epoch); any other tensor is packed on every call."""
+    import ctgan_amd.tflib as lib
+    lib.delete_all_params(); lib.set_device(None)
+    try:
+        g = torch.Generator().manual_seed(1)
+        w = lib.param('T.Filters', (torch.randn(3, 3, 64, 64, generator=g) * 0.05).numpy())
+        geom = K.ConvGeom(64, 8, 8, 64, 3, 3, 1, False)
+        x = cl(torch.randn(2, 64, 8, 8, generator=g))
+        with K.mma_dtype('bf16'):
+            y0 = K.conv_fwd(x, w, None, geom)
+            with torch.no_grad():
+                w.mul_(2.0)                                    # values change WITHOUT an epoch bump: the cached image is used
+            y1 = K.conv_fwd(x, w, None, geom)
+            assert torch.equal(y0, y1)
+            lib.bump_epoch()
+            y2 = K.conv_fwd(x, w, None, geom)
+            assert relerr(y2, 2 * y0) < 1e-6
+            t = w.detach().clone()                             # not a registry parameter: packed per call
+            y3 = K.conv_fwd(x, t, None, geom)
+            t.mul_(0.5)
+            y4 = K.conv_fwd(x, t, None, geom)
+            assert relerr(y3, y2) < 1e-6 and relerr(y4, y0) < 1e-6
+    finally:
+        lib.delete_all_params()
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_dcgan_cifar_step_in_16bit_mode_matches_oracle(K, dt):
+    """BASELINE.json configs[1]: CT_gan_cifar.py DCGAN 32x32, BATCH 64, DIM 128, the 5x5 stride-2 convs and transposed convs
+    on the 16-bit matrix cores (first / last layer: 3 channels, fp32 few-channel kernels).  One teacher-forced critic step
+    and generator step against the fp64 oracle on injected randomness.  Stated tolerance for bf16 (8-bit mantissa): loss
+    terms 2e-2 relative (fp16: 4e-3); parameter gradients 1e-1 relative L2 (fp16: 1.5e-2) - measured 5.8e-2 on the first
+    critic layer, whose gradient has passed three 16-bit layers twice (the gradient penalty's double backward) - and a cosine
+    similarity >= 0.995 with the fp64 gradient (the update DIRECTION is what Adam consumes).  Measured errors are written to
+    gpurun_out/dcgan16_<dtype>.json."""
+    import ctgan_amd.gan_cifar as M
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    from oracle import nets as onets, steps as osteps, tflib_ref as oref
+    B, dim = 64, 128
+    ltol, gtol = (2e-2, 1e-1) if dt == 'bf16' else (4e-3, 1.5e-2)
+    report = {}
+    lib.delete_all_params(); lib.set_device(None); lib.set_seed(3)
+    M.configure(DIM=dim, BATCH_SIZE=B)
+    try:
+        with torch.no_grad():
+            M.Discriminator(M.Generator(2, noise=torch.zeros(2, 128, device='cuda')), u=[torch.ones(2, *s, device='cuda') for s in M.feat_shapes()])
+        reg = oref.Registry(dtype=torch.float64)
+        for n, p in lib._params.items():
+            tr_ = n not in lib._non_trainable
+            reg[n] = p.detach().cpu().double().requires_grad_(tr_)
+            if not tr_:
+                reg.non_trainable.add(n)
+        g = torch.Generator().manual_seed(7)
+        real_int = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
+        G = lambda r, n, z: onets.cifar_generator(r, n, z, DIM=dim)
+        D = lambda r, x, u: onets.cifar_discriminator(r, x, u, DIM=dim)
+        real = 2. * ((real_int.double() / 255.) - .5)
+        ref = osteps.dcgan_d_losses(reg, G, D, real, rnd)
+        gref = osteps.grads_of(ref['cost'], reg, 'Discriminator')
+        tr = DCGANTrainer(M, seed=1)
+        dv = lambda o: [dv(t) for t in o] if isinstance(o, list) else o.float().cuda()
+        with K.mma_dtype(dt):
+            out = tr.d_step(real_int.cuda(), {k: dv(v) for k, v in rnd.items()})
+        for k in ('cost', 'wgan_only', 'ct', 'gp'):
+            a, b = out[k].item(), ref[k].item() * (M.cfg.LAMBDA if k == 'gp' else 1.0)     # the product's gp carries LAMBDA
+            assert abs(a - b) <= ltol * max(1.0, abs(b)), (k, a, b)
+        for k in ('cost', 'wgan_only', 'ct', 'gp'):
+            report['d.' + k] = [out[k].item(), ref[k].item() * (M.cfg.LAMBDA if k == 'gp' else 1.0)]
+        cos = lambda a, b: torch.nn.functional.cosine_similarity(a.detach().cpu().double().reshape(1, -1), b.detach().double().reshape(1, -1)).item()
+        for n in gref:
+            report['dgrad.' + n] = [rel_l2(out['grads'][n], gref[n]), cos(out['grads'][n], gref[n])]
+        for n in gref:
+            assert report['dgrad.' + n][0] <= gtol and report['dgrad.' + n][1] >= 0.995, (n, report)
+        rg = osteps.make_rnd_dcgan_g(B, M.feat_shapes(), g)
+        reg2 = oref.Registry(dtype=torch.float64)              # the generator step starts from the product's updated critic
+        for n, p in lib._params.items():
+            tr_ = n not in lib._non_trainable
+            reg2[n] = p.detach().cpu().double().requires_grad_(tr_)
+            if not tr_:
+                reg2.non_trainable.add(n)
+        refg = osteps.dcgan_g_losses(reg2, G, D, B, rg)
+        ggref = osteps.grads_of(refg['cost'], reg2, 'Generator')
+        with K.mma_dtype(dt):
+            outg = tr.g_step({k: dv(v) for k, v in rg.items()})
+        a, b = outg['cost'].item(), refg['cost'].item()
+        assert abs(a - b) <= ltol * max(1.0, abs(b)), ('g cost', a, b)
+        report['g.cost'] = [a, b]
+        for n in ggref:
+            if ggref[n].abs().max() < 1e-12:
+                continue
+            report['ggrad.' + n] = [rel_l2(outg['grads'][n], ggref[n]), cos(outg['grads'][n], ggref[n])]
+        import json, os
+        os.makedirs('gpurun_out', exist_ok=True)
+        json.dump(report, open('gpurun_out/dcgan16_%s.json' % dt, 'w'), indent=1)
+        for n, v in report.items():
+            if n.startswith('ggrad.'):
+                assert v[0] <= gtol and v[1] >= 0.995, (n, report)
+    finally:
+        lib.delete_all_params(); M.configure()
