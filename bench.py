@@ -25,6 +25,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_16BIT_MFMA_TFLOPS = 2500.0       # dense bf16 / fp16 MFMA (same guide); never the 2:1-sparsity figure
+# --config name -> (module under ctgan_amd, kernels.mma_dtype, workload description)
+ALT_CONFIGS = {
+    'cifar_dcgan_bf16': ('gan_cifar', 'bf16', 'CT_gan_cifar.py DCGAN 32x32 CT-WGAN, batch 64, DIM 128, 5x5 stride-2 convs / transposed convs on bf16 MFMA (fp32 accumulate, fp32 master weights)'),
+    'cifar_dcgan_f32': ('gan_cifar', None, 'CT_gan_cifar.py DCGAN 32x32 CT-WGAN, batch 64, DIM 128, fp32 MFMA'),
+    'lsun128_f16': ('gan_lsun128', 'f16', '128x128 ResNet CT-WGAN (LS/wgan_LSUN_Bedrooms128.py nets), batch 64/GPU, convs on fp16 MFMA (fp32 accumulate, fp32 master weights)'),
+    'lsun128_bf16': ('gan_lsun128', 'bf16', '128x128 ResNet CT-WGAN (LS/wgan_LSUN_Bedrooms128.py nets), batch 64/GPU, convs on bf16 MFMA'),
+    'lsun128_f32': ('gan_lsun128', None, '128x128 ResNet CT-WGAN (LS/wgan_LSUN_Bedrooms128.py nets), batch 64/GPU, fp32 MFMA'),
+}
 ITER_GFLOP = 2990.5                   # algorithmic GFLOP per GPU per iteration
 
 
@@ -37,6 +46,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--gp-unit-only', action='store_true', help='run only the critic-forward + GP-backward sub-benchmark')
+    ap.add_argument('--config', default='resnet', choices=['resnet'] + sorted(ALT_CONFIGS),
+                    help='resnet = the headline (BASELINE.json configs[2]/[3], fp32); the others: configs[1] / configs[4] on the '
+                         '16-bit matrix cores (or their fp32 twins for comparison)')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets the\n'
                     'multi-rank code path be exercised on a single-GPU box (all ranks share cuda:0)')
     args = ap.parse_args()
@@ -46,6 +58,8 @@ def main():
     import torch.distributed as dist
 
     from ctgan_amd import ddp
+    if args.config != 'resnet':
+        return run_unconditional(args)
     rank, world, local = ddp.init_from_env(backend=args.backend)
     if local >= torch.cuda.device_count():
         if world > 1 and dist.get_backend() != 'gloo':
@@ -156,6 +170,117 @@ def main():
         dist.destroy_process_group()
     if not sane:
         print('bench: critic loss terms out of band %r - the timed loop is not computing the reference step' % (last,), file=sys.stderr)
+        sys.exit(3)
+
+
+def run_unconditional(args):
+    """BASELINE.json configs[1] / configs[4]: the unconditional CT-WGAN step (dcgan_step.DCGANTrainer) under hipGraph replay,
+    same timing contract and JSON line as the headline config."""
+    import importlib
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd import ddp
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    from ctgan_amd.engine import GraphedDCGANTrainer
+    modname, dtype, workload = ALT_CONFIGS[args.config]
+    rank, world, local = ddp.init_from_env(backend=args.backend)
+    if local >= torch.cuda.device_count():
+        if world > 1 and dist.get_backend() != 'gloo':
+            raise SystemExit('two RCCL ranks cannot share a GPU')
+        local = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    M = importlib.import_module('ctgan_amd.' + modname)
+    lib.delete_all_params(); lib.set_seed(0); lib.set_device(None)
+    M.configure()
+    B = M.cfg.BATCH_SIZE
+    if hasattr(M, 'build_params'):
+        M.build_params(dev)
+    else:
+        with torch.no_grad():
+            M.Discriminator(M.Generator(2, noise=torch.zeros(2, 128, device=dev)), u=[torch.ones(2, *s, device=dev) for s in M.feat_shapes()])
+    K.set_mma_dtype(dtype)
+    side = torch.cuda.Stream() if world > 1 else None
+    tr = DCGANTrainer(M, seed=2024, rank=rank, world_size=world, allreduce=ddp.FlatAllReduce(side_stream=side))
+    ddp.broadcast_params([tr.d_opt.theta, tr.g_opt.theta])
+    nrng = np.random.default_rng(1234 + rank)
+    batches = [torch.from_numpy(nrng.integers(0, 256, (B, M.cfg.OUTPUT_DIM), dtype=np.int32)).to(dev) for _ in range(8)]
+    cursor = [0]
+
+    def next_batch():
+        cursor[0] = (cursor[0] + 1) % len(batches)
+        return batches[cursor[0]]
+    eng = GraphedDCGANTrainer(tr, (B, M.cfg.OUTPUT_DIM), torch.int32, use_graphs=not args.no_graph)
+    if eng.graph_error and rank == 0:
+        print('hipGraph capture failed, running eager: ' + eng.graph_error, file=sys.stderr)
+    it = 1
+    for _ in range(args.warmup):
+        eng.train_iteration(it, next_batch); it += 1
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ddp.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for k in range(args.steps):
+        out = eng.train_iteration(it, next_batch); it += 1
+        marks[k + 1].record()
+    torch.cuda.synchronize(); ddp.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    last = {k: float(out[k].item()) for k in ('cost', 'wgan_only', 'ct', 'gp') if out.get(k) is not None}
+    sane = all(v == v and abs(v) < 1e4 for v in last.values())
+    ms_per_step = 1e3 * dt / args.steps
+    n_crit = M.cfg.CRITIC_ITERS
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        peak = PEAK_16BIT_MFMA_TFLOPS if dtype else PEAK_F32_MFMA_TFLOPS
+        saved_world, tr.world = tr.world, 1
+        try:
+            tr.train_iteration(1, next_batch)
+            torch.cuda.synchronize()
+            K.PROFILE, K.PROFILE_REPS = [], 4
+            try:
+                tr.train_iteration(1, next_batch)
+                torch.cuda.synchronize()
+                prof = K.PROFILE
+            finally:
+                K.PROFILE, K.PROFILE_REPS = None, 1
+        finally:
+            tr.world = saved_world
+        agg = {}
+        for name, flops, e0, e1, reps, _shape in prof:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
+        total_t = sum(a[2] for a in agg.values()); total_f = sum(a[1] for a in agg.values())
+        mm = {k: v for k, v in agg.items() if ('16' in k) == bool(dtype)} or agg     # the dominant kernel of the family this config is about
+        name, (cnt, fl, tt) = max(mm.items(), key=lambda kv: kv[1][2])
+        roofline = {'bound': 'mfma', 'kernel': name, 'launches': cnt, 'flops_per_launch': round(fl / cnt / 1e9, 3),
+                    'avg_launch_us': round(tt / cnt * 1e6, 2), 'achieved': round(fl / tt / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(fl / tt / 1e12 / peak, 4), 'traffic': None,
+                    'all_conv_kernels': {'time_ms': round(total_t * 1e3, 3), 'gflop_executed': round(total_f / 1e9, 2), 'launches': len(prof)},
+                    'by_kernel': {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3)}
+                                  for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'img/s per (n_critic D + 1 G) step', 'value': round(n_crit * B * world * args.steps / dt, 2), 'unit': 'img/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'ms_per_step_p50': round(per_step[len(per_step) // 2], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': dtype or 'f32', 'data': 'synthetic',
+            'config': {'workload': workload, 'name': args.config, 'global_batch': B * world, 'images_per_step': n_crit * B * world,
+                       'parallelism': 'dp%d' % world, 'hipgraph': bool(eng.graphed), 'last_d_terms': last, 'loss_sane': sane},
+            'roofline': roofline, 'cpu_baseline': None}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    if not sane:
+        print('bench: critic loss terms out of band %r' % (last,), file=sys.stderr)
         sys.exit(3)
 
 

@@ -80,6 +80,8 @@ class DCGANTrainer:
         flat = opt.gather_grads(grads)
         if self.allreduce is not None and self.world > 1:
             self.allreduce(flat)
+            if hasattr(self.allreduce, 'wait'):
+                self.allreduce.wait()
         opt.step(grad_scale=1.0 / self.world)
 
     def d_step(self, real_in, rnd=None):

@@ -204,3 +204,124 @@ class GraphedTrainer:
                 nxt = (lambda j: lambda: self._stage_d_inputs(batches[j][0], batches[j][1], fakes[j]))(i + 1)
             out = self.d_step(None, None, iteration, staged=True, between=nxt)
         return out
+
+
+class GraphedDCGANTrainer:
+    """hipGraph replay of the shared unconditional CT-WGAN step (dcgan_step.DCGANTrainer: the DCGAN scripts, the 64x64 and
+    128x128 ResNets).  Same rules as GraphedTrainer: one private memory pool per graph, the Philox step counter / Adam state
+    live in device memory, capture leaves no trace in them, Adam inside the graph when world == 1."""
+
+    def __init__(self, trainer, real_shape, real_dtype, use_graphs=True, warmup=2):
+        self.t = trainer
+        self.real = torch.zeros(real_shape, dtype=real_dtype, device=trainer.dev)
+        self.adam_in_graph = trainer.world == 1
+        self.d_graph = self.g_graph = None
+        self.d_out = self.g_out = None
+        self.graph_error = None
+        if use_graphs:
+            try:
+                self._capture(warmup)
+            except Exception as e:
+                self.graph_error = '%s: %s' % (type(e).__name__, e)
+                self.d_graph = self.g_graph = None
+                torch.cuda.synchronize()
+
+    def _body(self, which):
+        t = self.t
+        lib.bump_epoch()                 # weights changed since the last replay: derived / packed filters are rebuilt in-graph
+        F.prepare_filters()
+        t.rng.begin_step()
+        if which == 'd':
+            out = t.d_losses(self.real)
+            params, opt = t.d_params, t.d_opt
+        else:
+            out = t.g_losses()
+            params, opt = t.g_params, t.g_opt
+        grads = torch.autograd.grad(out['cost'], params, allow_unused=True)
+        opt.gather_grads(grads)
+        if self.adam_in_graph:
+            opt.step(1.0)
+        t.rng.end_step()
+        return {k: out[k].detach() for k in ('cost', 'wgan_only', 'ct', 'gp') if out.get(k) is not None}
+
+    def _capture(self, warmup):
+        t = self.t
+        opts = (t.d_opt, t.g_opt)
+        bufs = [b for o in opts for b in (o.m, o.v, o.state)] + [t.rng.ctr]
+        snap = [b.clone() for b in bufs]
+        steps = [o.t for o in opts]
+        for o in opts:
+            o.set_lr(0.0)
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    self._body('d')
+                    self._body('g')
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.d_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.d_graph):
+                self.d_out = self._body('d')
+            self.g_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_graph):
+                self.g_out = self._body('g')
+        finally:
+            torch.cuda.synchronize()
+            for b, sn in zip(bufs, snap):
+                b.copy_(sn)
+            for o, n in zip(opts, steps):
+                o.t, o._lr_last = n, None
+            torch.cuda.synchronize()
+
+    @property
+    def graphed(self):
+        return self.d_graph is not None
+
+    def _lr(self):
+        m = self.t.mod
+        return m.lr(self.t.iteration) if hasattr(m, 'lr') else m.cfg.LR
+
+    def d_step(self, real_in):
+        t = self.t
+        if not self.graphed:
+            return t.d_step(real_in)
+        self.real.copy_(real_in, non_blocking=True)
+        t.d_opt.set_lr(self._lr())
+        self.d_graph.replay()
+        if self.adam_in_graph:
+            t.d_opt.t += 1
+        else:
+            self._reduce_update(t.d_opt)
+        return self.d_out
+
+    def g_step(self):
+        t = self.t
+        if not self.graphed:
+            return t.g_step()
+        t.g_opt.set_lr(self._lr())
+        self.g_graph.replay()
+        if self.adam_in_graph:
+            t.g_opt.t += 1
+        else:
+            self._reduce_update(t.g_opt)
+        return self.g_out
+
+    def _reduce_update(self, opt):
+        t = self.t
+        if t.allreduce is not None and t.world > 1:
+            t.allreduce(opt.grad)
+            if hasattr(t.allreduce, 'wait'):
+                t.allreduce.wait()
+        opt.step(1.0 / t.world)
+
+    def train_iteration(self, iteration, next_batch):
+        """[G step if it > 0] + CRITIC_ITERS x (batch, D step)  (TF/CT_gan_cifar.py:190-204)."""
+        self.t.iteration = iteration
+        if iteration > 0:
+            self.g_step()
+        out = None
+        for _ in range(self.t.mod.cfg.CRITIC_ITERS):
+            out = self.d_step(next_batch())
+        return out
