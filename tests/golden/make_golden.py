@@ -134,17 +134,17 @@ def resnet_fixture(dim=8, B=4, iters=2):
     np.savez_compressed(os.path.join(HERE, 'resnet_trace.npz'), **out)
 
 
-def loop_trace_fixture(dim=32, B=8, iters=1000, seed=2024, init_seed=0, fname='resnet_loop_trace.npz'):
+def loop_trace_fixture(dim=32, B=8, iters=1000, seed=2024, init_seed=0, fname='resnet_loop_trace.npz', dtype=F64):
     """Free-running trace of the reference LOOP (TF/CT_gan_cifar_resnet.py:393-404: [G step if it > 0] + 5 x (batch, D
     step), LR decay) over `iters` iterations in fp64.  Seeds, not tensors: the initial weights are the registry's per-name
     init streams (`init_seed`; the product's lib.set_seed draws the same values), the 16 cycled synthetic batches are
     numpy default_rng(1234) exactly as bench.py builds them, and every random draw is a Philox stream of (seed, step)
     (oracle/philox.py, oracle/loop.py).  Stored: every loss term of every critic step and every generator cost."""
     from oracle import loop
-    reg = ops.Registry(dtype=F64, seed=init_seed)
+    reg = ops.Registry(dtype=dtype, seed=init_seed)
     cfg = nets.ResnetCfg(DIM_G=dim, DIM_D=dim)
     lab0 = torch.zeros(2, dtype=torch.int32)
-    nets.resnet_discriminator(reg, cfg, nets.resnet_generator(reg, cfg, 2, lab0, torch.zeros(2, 128, dtype=F64)), lab0, 1., 1., 1.)
+    nets.resnet_discriminator(reg, cfg, nets.resnet_generator(reg, cfg, 2, lab0, torch.zeros(2, 128, dtype=dtype)), lab0, 1., 1., 1.)
     nrng = np.random.default_rng(1234)
     batches = [(torch.from_numpy(nrng.integers(0, 256, (B, 3072), dtype=np.int32)),
                 torch.from_numpy(nrng.integers(0, 10, (B,), dtype=np.int32))) for _ in range(16)]
@@ -153,7 +153,7 @@ def loop_trace_fixture(dim=32, B=8, iters=1000, seed=2024, init_seed=0, fname='r
     def next_batch():
         cur[0] = (cur[0] + 1) % len(batches)
         return batches[cur[0]]
-    d_recs, g_recs, _, _, pos = loop.resnet_train_loop(reg, cfg, next_batch, iters, B, seed, start_iteration=1)
+    d_recs, g_recs, _, _, pos = loop.resnet_train_loop(reg, cfg, next_batch, iters, B, seed, start_iteration=1, dtype=dtype)
     keys = ('cost', 'wgan', 'acgan', 'ct', 'gp', 'wgan_only')
     np.savez_compressed(os.path.join(HERE, fname), cfg=np.array([dim, B, iters, seed, init_seed]), keys=np.array(keys),
                         d=np.array([[r[k] for k in keys] for r in d_recs]), g=np.array(g_recs), stream_pos=np.array(pos))
@@ -168,6 +168,8 @@ if __name__ == '__main__':
         resnet_fixture()
     if 'loop' in which:
         loop_trace_fixture()
+    if 'loop32' in which:       # the oracle's own fp32 twin on the same streams: how far ANY fp32 evaluation drifts from the fp64 trace
+        loop_trace_fixture(fname='resnet_loop_trace_f32twin.npz', dtype=torch.float32)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
