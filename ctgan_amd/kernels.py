@@ -747,6 +747,66 @@ def channel_affine(x, scale, offset=None):
     return y
 
 
+# ---- fused Layernorm (csrc/layernorm.hip) ------------------------------------------------------------------------------------
+def _ln_dims(x):
+    """(N, D, C) of a dense channel-fastest tensor ([N,C,H,W] channels-last or [N,C] contiguous), or None."""
+    if x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous():
+        return x.shape[0], x.shape[1] * x.shape[2] * x.shape[3], x.shape[1]
+    if x.dim() == 2 and x.is_contiguous():
+        return x.shape[0], x.shape[1], x.shape[1]
+    return None
+
+
+def layernorm_supported(x):
+    d = _ln_dims(x)
+    return d is not None and bool(lib.ctgan_layernorm_supported(d[1], d[2]))
+
+
+def _ln_ws(N, D, C, dev):
+    return workspace(lib.ctgan_layernorm_workspace_bytes(N, D, C), dev)
+
+
+def layernorm_fwd(x, scale, offset, eps):
+    """-> (y, mean [N], rstd [N])   (TF/tflib/ops/layernorm.py:6-20)"""
+    _need_dev(x, scale, offset)
+    N, D, C = _ln_dims(x)
+    y = _ew_out(x)
+    mean = torch.empty(N, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = _ln_ws(N, D, C, x.device)
+    check(lib.ctgan_layernorm_fwd(_ptr(x), _ptr(scale), _ptr(offset), _ptr(y), _ptr(mean), _ptr(rstd), N, D, C, float(eps), _ptr(ws), ws.numel(),
+                                  _stream()), 'layernorm_fwd')
+    return y, mean, rstd
+
+
+def layernorm_bwd(gy, x, scale, mean, rstd, want_params):
+    """-> (gx, gscale | None, goffset | None)"""
+    _need_dev(gy, x, scale, mean, rstd)
+    N, D, C = _ln_dims(x)
+    gy = match_layout(gy, x)
+    gx = _ew_out(x)
+    gs = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
+    go = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
+    ws = _ln_ws(N, D, C, x.device)
+    check(lib.ctgan_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(gs), _ptr(go), N, D, C, _ptr(ws), ws.numel(),
+                                  _stream()), 'layernorm_bwd')
+    return gx, gs, go
+
+
+def layernorm_bwd2(u, gy, x, scale, mean, rstd, want_gy=True, want_x=True, want_scale=True):
+    """Adjoint of layernorm_bwd: cotangent u of gx -> (cot_gy, cot_x, cot_scale), None where not wanted."""
+    _need_dev(u, gy, x, scale, mean, rstd)
+    N, D, C = _ln_dims(x)
+    u, gy = match_layout(u, x), match_layout(gy, x)
+    cg = _ew_out(x) if want_gy else None
+    cx = _ew_out(x) if want_x else None
+    cs = torch.empty(C, dtype=torch.float32, device=x.device) if want_scale else None
+    ws = _ln_ws(N, D, C, x.device)
+    check(lib.ctgan_layernorm_bwd2(_ptr(u), _ptr(gy), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(cg), _ptr(cx), _ptr(cs), N, D, C, _ptr(ws),
+                                   ws.numel(), _stream()), 'layernorm_bwd2')
+    return cg, cx, cs
+
+
 def spatial_sum(x, scale):
     """[N,C,H,W] channels-last -> [N,C], scale * sum over (h,w)."""
     _need_dev(x)

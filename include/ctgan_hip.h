@@ -145,6 +145,26 @@ int ctgan_conv2d_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w
  * with.  Callers that run several dgrads per weight update repack once and pass
  * CTGAN_DGRAD_W_REPACKED (then `w` is wt and no workspace is needed).                            */
 int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* wt, ctgan_stream_t stream);
+/* ---- Layernorm, fused (csrc/layernorm.hip) ----------------------------------------------------------------------------------
+ * TF/tflib/ops/layernorm.py:6-20 (tf.nn.moments over the non-batch axes + tf.nn.batch_normalization, eps 1e-5) for dense
+ * tensors with the channel axis fastest ([N,H,W,C] or [N,C]); D = elements per sample, C = channels (scale / offset size).
+ *   fwd : y = (x - mean) * rstd * scale[c] + offset[c]; mean / rstd [N] are returned for the backward passes
+ *   bwd : gx (and, when gscale / goffset != NULL, the parameter gradients) from the gradient gy of y
+ *   bwd2: the adjoint of bwd - the gradient penalty differentiates the critic twice (LS/wgan_LSUN_Bedrooms128.py:256-262):
+ *         given the cotangent u of gx returns the cotangents of gy, x and scale (NULL = not wanted)
+ * Supported when C % 4 == 0 and 1024 % C == 0 (ctgan_layernorm_supported); otherwise CTGAN_E_UNSUPPORTED and the caller
+ * composes the operator from ctgan_sample_sum / ctgan_mul / ctgan_rsqrt / ctgan_channel_affine.  ws: scratch of
+ * ctgan_layernorm_workspace_bytes(N, D, C) bytes.                                                                       */
+int ctgan_layernorm_supported(int64_t D, int32_t C);
+size_t ctgan_layernorm_workspace_bytes(int32_t N, int64_t D, int32_t C);
+int ctgan_layernorm_fwd(const float* x, const float* scale, const float* offset, float* y, float* mean, float* rstd, int32_t N,
+                        int64_t D, int32_t C, float eps, void* ws, size_t ws_bytes, ctgan_stream_t stream);
+int ctgan_layernorm_bwd(const float* gy, const float* x, const float* scale, const float* mean, const float* rstd, float* gx,
+                        float* gscale, float* goffset, int32_t N, int64_t D, int32_t C, void* ws, size_t ws_bytes,
+                        ctgan_stream_t stream);
+int ctgan_layernorm_bwd2(const float* u, const float* gy, const float* x, const float* scale, const float* mean,
+                         const float* rstd, float* cot_gy, float* cot_x, float* cot_scale, int32_t N, int64_t D, int32_t C,
+                         void* ws, size_t ws_bytes, ctgan_stream_t stream);
 /* ---- 16-bit matrix-core family (csrc/igemm16.hip): BASELINE.json configs[1] "bf16" and configs[4] "fp16 MFMA conv" ----
  * The same three operators (tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112, tf.nn.conv2d_transpose / the data gradient
  * TF/tflib/ops/deconv2d.py:91-103, the filter gradient tf.gradients derives) computed as mixed precision: operands rounded

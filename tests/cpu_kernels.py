@@ -349,6 +349,59 @@ def channel_affine(x, scale, offset=None):
 
 
 @_export
+def layernorm_supported(x):
+    C = x.shape[1]
+    return C % 4 == 0 and 1024 % C == 0 and ((x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()) or (x.dim() == 2 and x.is_contiguous()))
+
+
+def _ln_parts(x, scale, mean, rstd):
+    shp = [-1] + [1] * (x.dim() - 1)
+    cshp = [1, -1] + [1] * (x.dim() - 2)
+    xh = (x.double() - mean.double().reshape(shp)) * rstd.double().reshape(shp)
+    return xh, scale.double().reshape(cshp), shp, tuple(range(1, x.dim())), tuple(d for d in range(x.dim()) if d != 1)
+
+
+@_export
+def layernorm_fwd(x, scale, offset, eps):
+    dims = tuple(range(1, x.dim()))
+    xd = x.double()
+    mean = xd.mean(dim=dims)
+    var = xd.var(dim=dims, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    xh, s, shp, _, _ = _ln_parts(x, scale, mean, rstd)
+    y = xh * s + offset.double().reshape([1, -1] + [1] * (x.dim() - 2))
+    return _like(y.float(), x), mean.float(), rstd.float()
+
+
+@_export
+def layernorm_bwd(gy, x, scale, mean, rstd, want_params):
+    xh, s, shp, sd, cd = _ln_parts(x, scale, mean, rstd)
+    g = gy.double() * s
+    a = g.mean(dim=sd, keepdim=True); b = (g * xh).mean(dim=sd, keepdim=True)
+    gx = rstd.double().reshape(shp) * (g - a - xh * b)
+    if not want_params:
+        return _like(gx.float(), x), None, None
+    return _like(gx.float(), x), (gy.double() * xh).sum(dim=cd).float(), gy.double().sum(dim=cd).float()
+
+
+@_export
+def layernorm_bwd2(u, gy, x, scale, mean, rstd, want_gy=True, want_x=True, want_scale=True):
+    # autograd through the double-precision restatement of layernorm_bwd as a function of (gy, x, scale)
+    dims = tuple(range(1, x.dim()))
+    cshp = [1, -1] + [1] * (x.dim() - 2)
+    eps = (1.0 / rstd.double() ** 2 - x.double().var(dim=dims, unbiased=False)).mean().item()
+    with torch.enable_grad():
+        gy_, x_, s_ = (t.detach().double().requires_grad_(True) for t in (gy, x, scale))
+        m = x_.mean(dim=dims, keepdim=True)
+        r = 1.0 / torch.sqrt(x_.var(dim=dims, unbiased=False, keepdim=True) + eps)
+        xh = (x_ - m) * r
+        g = gy_ * s_.reshape(cshp)
+        gx = r * (g - g.mean(dim=dims, keepdim=True) - xh * (g * xh).mean(dim=dims, keepdim=True))
+        cg, cx, cs = torch.autograd.grad(gx, [gy_, x_, s_], u.double())
+    return (_like(cg.float(), x) if want_gy else None, _like(cx.float(), x) if want_x else None, cs.float() if want_scale else None)
+
+
+@_export
 def spatial_sum(x, scale):
     return (x.sum(dim=(2, 3)) * scale).contiguous()
 

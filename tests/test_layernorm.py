@@ -55,7 +55,7 @@ def test_layernorm_values_gradients_and_double_backward(cpu_kernels, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(6, 128, 8, 8), (3, 64, 16, 16), (9, 40)])
+@pytest.mark.parametrize('shape', [(6, 128, 8, 8), (3, 64, 16, 16), (9, 40), (2, 128, 32, 32), (3, 1024, 8, 8), (5, 256)])
 def test_layernorm_on_gpu(shape):
     import ctgan_amd.tflib as lib
     lib.delete_all_params(); lib.set_device(None)
