@@ -133,6 +133,7 @@ struct P16 {
     int ph_T[2], ph_U[2], ph_pad_t[2], ph_pad_l[2];
     long long ph_w_off[4];          // packed-filter element offset of a phase
     long long ph_d_h, ph_d_w;       // D offset of phase (a,b) = a*ph_d_h + b*ph_d_w
+    int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier, 8 no MFMA
 };
 
 template <int MMA, int TM, int TN, int BK, bool RELU_IN>
@@ -247,8 +248,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned short* Xs = smem + (kt & 1) * STAGE;
         const unsigned short* Ws = Xs + BMP * LDS_K;
-        if (kt + 1 < nk) store_slice(smem + ((kt + 1) & 1) * STAGE);     // the other stage: its readers passed the last barrier
-        if (kt + 2 < nk) load_slice();
+        if (kt + 1 < nk && !(p.dbg & 1)) store_slice(smem + ((kt + 1) & 1) * STAGE);     // the other stage: its readers passed the last barrier
+        if (kt + 2 < nk && !(p.dbg & 2)) load_slice();
+        if (!(p.dbg & 8))
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             u32x4 fw[TM], fx[TN];
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fw[i], fx[j], acc[i][j]);
         }
-        __syncthreads();
+        if (!(p.dbg & 4)) __syncthreads();
     }
 
     // epilogue through LDS: acc[i][j][4g + e] = D(pixel j*32 + l31, kout i*32 + 8g + 4h + e); every wave transposes its own
@@ -313,6 +315,7 @@ struct W16 {
     int chunk;                       // pixels per split (multiple of 64)
     int relu_x;
     unsigned x_bytes, dy_bytes;
+    int dbg;
 };
 
 template <int MMA, int TM, int TN>
@@ -441,8 +444,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned short* Xs = smem + (kt & 1) * STAGE;
         const unsigned short* Ys = Xs + BMC * LDS_K;
-        if (kt + 1 < nk) store_slice(smem + ((kt + 1) & 1) * STAGE);
-        if (kt + 2 < nk) load_slice(kt + 2);
+        if (kt + 1 < nk && !(p.dbg & 1)) store_slice(smem + ((kt + 1) & 1) * STAGE);
+        if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2);
+        if (!(p.dbg & 8))
 #pragma unroll
         for (int ks = 0; ks < BKP / 16; ++ks) {
             u32x4 fa[TM], fb[TN];
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fa[i], fb[j], acc[i][j]);
         }
-        __syncthreads();
+        if (!(p.dbg & 4)) __syncthreads();
     }
     // acc[i][j][4g + e] = dW(channel c0 + wm*TM*32 + i*32 + 8g + 4h + e, kout n0 + wn*TN*32 + j*32 + l31): 32 lanes = 128 B rows
     float* out = p.OUT + (long long)blockIdx.y * p.Mtot * p.Ng;
@@ -495,6 +499,7 @@ __global__ void reduce16_kernel(const float* __restrict__ part, float* __restric
 
 // ---------------------------------------------------------------------------------------------- host side
 bool mma_ok(int mma) { return mma == CTGAN_MMA_BF16 || mma == CTGAN_MMA_F16; }
+int dbg16() { static const int v = [] { const char* e = getenv("CTGAN_DBG16"); return e ? atoi(e) : 0; }(); return v; }
 
 bool shape_ok_fwd(const ctgan_conv_desc* d) {
     return !d->x_up && d->C % 32 == 0 && d->K % 4 == 0 && d->xs[1] == 1 && d->ys[1] == 1 &&
@@ -526,6 +531,7 @@ int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     const int tiles_m = (p.M + BMP - 1) / BMP, tiles_n = (p.Ng + BNC - 1) / BNC;
     P16 q = p;
     q.ph_tiles_m = tiles_m;
+    q.dbg = dbg16();
     hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n)), dim3(256), lds, st, q);
     ctgan_set_last_kernel(name);
     return ctgan_check_launch(name);
@@ -568,11 +574,18 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
     w.bnk = d->K % 128 == 0 ? 128 : 64;
     w.tiles = d->R * d->S * (d->C / w.bmc) * ((d->K + w.bnk - 1) / w.bnk);
     const int Kg = d->N * d->P * d->Q;
-    // ~2 waves of workgroups over the 256 CUs, at least 4 slices (256 pixels) per split
-    int s = (512 + w.tiles - 1) / w.tiles;
+    // 512 workgroups are resident at a time (2 per CU: 73 KB of LDS each).  Pick the split count whose LAST round of workgroups
+    // is the fullest (576 tiles unsplit would run as 512 + 64: 44 % of the second round idle), preferring fewer splits (less
+    // slab traffic) among equals; at least 4 slices (256 pixels) per split.
     const int max_s = (Kg + 255) / 256;
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
+    int s = 1;
+    double best = -1.;
+    for (int cand = 1; cand <= max_s && cand <= 64 && (long long)cand * w.tiles <= 4096; ++cand) {
+        const long long blocks = (long long)cand * w.tiles;
+        const long long rounds = (blocks + 511) / 512;
+        const double eff = (double)blocks / (double)(rounds * 512);
+        if (eff > best + 0.03) { best = eff; s = cand; }
+    }
     int ch = (Kg + s - 1) / s;
     ch = ((ch + 63) / 64) * 64;
     w.splits = (Kg + ch - 1) / ch;
@@ -705,7 +718,7 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
     p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
-    p.chunk = w.chunk; p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0;
+    p.chunk = w.chunk; p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0; p.dbg = dbg16();
     p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)(y_extent * 4);
     hipStream_t st = (hipStream_t)stream;
     int rc;

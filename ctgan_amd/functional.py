@@ -602,6 +602,10 @@ def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_
         return out if resid is None else add(out, resid)
     if x_up and fusable and R > 1 and resid is None and not relu_in and not out_nchw:
         return upsample_conv2d(x, w, b)
+    if (x_up and FEWCH_DECONV and RESAMPLE_FUSION and Kout <= 4 and C % 32 == 0 and R % 2 == 1 and S % 2 == 1 and R > 1 and stride == 1
+            and resid is None and not relu_in and not pool and not fork):
+        y = upsample_conv2d(x, w, b)                              # image-producing UpsampleConv (LS/wgan_LSUN_Bedrooms128.py:160)
+        return to_nchw(y) if out_nchw else y
     if C <= 4 and not x_up and stride == 1 and K.fewch_handles(ConvGeom(C, H, W, Kout, R, S, stride, False)):
         pass          # direct few-channel kernels (csrc/fewch.hip) behind the ordinary conv entry points
     elif C <= 4 and not x_up and Kout % 4 == 0:
@@ -626,6 +630,10 @@ def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_
     return ConvFn.apply(x, w, b, resid, g, out_strides, relu_in, False, epi)
 
 
+# A/B switch: transposed convs with <= 4 output channels as one 1x1 conv onto (tap, channel) columns + col2im
+FEWCH_DECONV = _os.environ.get('CTGAN_FEWCH_DECONV', '1') != '0'
+
+
 def conv2d_transpose(x, w_hwoi, b=None, stride=2):
     """tf.nn.conv2d_transpose 'SAME' with filter [k,k,out,in]: the dgrad of the strided conv whose
     HWIO filter is `w_hwoi` (I = out, O = in)."""
@@ -634,6 +642,21 @@ def conv2d_transpose(x, w_hwoi, b=None, stride=2):
     assert Cx == Cin
     g = ConvGeom(Cout, H * stride, W * stride, Cin, R, S, stride, False)
     assert (g.P, g.Q) == (H, W)
+    if FEWCH_DECONV and Cout <= 4 and Cin % 32 == 0:
+        # many -> few channels (the image-producing layer, Deconv2D(DIM, 3, 5) TF/CT_gan_cifar.py:76): as a data gradient the
+        # GEMM would have 3 useful output columns of a 32-wide tile.  Transposed: every input pixel emits its contribution
+        # to all R*S*Cout (tap, channel) outputs - ONE dense 1x1 conv Cin -> R*S*Cout on the pipelined kernels - and the
+        # adjoint of im2col (col2im) sums the overlapping taps: no wasted MACs, no dilation zeros.
+        rsc = R * S * Cout
+        cpad = -(-rsc // 32) * 32
+        w2 = w_hwoi.reshape(rsc, Cin).t()
+        if cpad > rsc:
+            w2 = torch.cat([w2, w2.new_zeros(Cin, cpad - rsc)], 1)
+        cols = conv2d(x, w2.contiguous().view(1, 1, Cin, cpad))
+        y = Col2imFn.apply(cols, g, N, None)
+        if b is not None:
+            y = ChannelAffineFn.apply(y, torch.ones_like(b), b)
+        return y
     return ConvDgradFn.apply(x, w_hwoi, b, g, N, None, None)
 
 
@@ -712,6 +735,8 @@ def upsample_conv2d(x, w, b=None):
     N, Cx, H, W = x.shape
     assert Cx == C and R % 2 == 1 and S % 2 == 1
     w4 = FilterSpreadFn.apply(w, 1.0, True)                       # [R+1,S+1,Kout,C]: HWIO filter of the adjoint conv
+    if Kout <= 4:
+        return conv2d_transpose(x, w4, b, stride=2)               # many -> few channels: 1x1 conv onto columns + col2im
     g = ConvGeom(Kout, 2 * H, 2 * W, C, R + 1, S + 1, 2, False)    # the strided conv whose data gradient this is
     assert (g.P, g.Q) == (H, W) and (g.pad_t, g.pad_l) == ((R - 1) // 2, (S - 1) // 2)
     return ConvDgradFn.apply(x, w4, b, g, N, None, None)

