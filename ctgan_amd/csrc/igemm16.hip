@@ -133,7 +133,7 @@ struct P16 {
     int ph_T[2], ph_U[2], ph_pad_t[2], ph_pad_l[2];
     long long ph_w_off[4];          // packed-filter element offset of a phase
     long long ph_d_h, ph_d_w;       // D offset of phase (a,b) = a*ph_d_h + b*ph_d_w
-    int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier, 8 no MFMA
+    int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier (a branch around the MFMAs would move the accumulators out of the AGPRs)
 };
 
 template <int MMA, int TM, int TN, int BK, bool RELU_IN>
@@ -250,7 +250,6 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
         const unsigned short* Ws = Xs + BMP * LDS_K;
         if (kt + 1 < nk && !(p.dbg & 1)) store_slice(smem + ((kt + 1) & 1) * STAGE);     // the other stage: its readers passed the last barrier
         if (kt + 2 < nk && !(p.dbg & 2)) load_slice();
-        if (!(p.dbg & 8))
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             u32x4 fw[TM], fx[TN];
@@ -316,9 +315,10 @@ struct W16 {
     int relu_x;
     unsigned x_bytes, dy_bytes;
     int dbg;
+    int pq_shift, q_shift;           // log2(P*Q), log2(Q) when both are powers of two, else -1: pixel -> (n,p,q) without integer division
 };
 
-template <int MMA, int TM, int TN>
+template <int MMA, int TM, int TN, bool RELU_X>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     // block tile: (2*TM*32) channels of ONE tap  x  (2*TN*32) kout, K slices of 64 pixels
     constexpr int NT = 256, BKP = 64;
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     constexpr int XG = BMC / 4;                         // 4-channel groups of the x tile
     constexpr int X_PER = XG * (BKP / 4) / NT;          // (4 pixels x 4 channels) blocks per thread per slice
     constexpr int YG = BNK / 4;
+    constexpr int XPG = XG >= 32 ? 8 : 16, YPG = YG >= 32 ? 8 : 16;      // pixel groups a wave's load instruction spans (see the staging map)
     constexpr int Y_PER = YG * (BKP / 4) / NT;
     static_assert(XG * (BKP / 4) % NT == 0 && YG * (BKP / 4) % NT == 0 && X_PER >= 1 && Y_PER >= 1, "tile / thread mismatch");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -348,40 +349,53 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.dy_bytes, 0x00020000);
 
-    // staging map: lane -> (pixel group of 4 = lane % 8 [+ 8 per extra block], channel group of 4 = lane / 8 + 8 * wave [+ 32 ...]):
-    // a wave load instruction touches 8 pixel groups x 128 B of channels; its LDS writes land 2-way = the minimum for 512 B.
+    // staging map: thread -> (pixel group of 4 = tid % 8 [+ 8 for odd b], channel group of 4 = tid / 8 [+ 32 per pair of b]):
+    // a wave load instruction touches 8 pixels x 128 B - whole cache lines (16 pixel groups x 64 B per wave moves half-used
+    // lines over the L2 -> L1 path); its LDS writes land 2-way = the minimum for 512 B.  64-wide tiles keep the 16 x 64 B map.
     float4 rxv[X_PER][4], ryv[Y_PER][4];
+    const unsigned x_wstep = (unsigned)p.s_w * 4u, x_estep = (unsigned)p.stride * x_wstep;
     auto load_slice = [&](int kt) {
         const int kbase = k_begin + kt * BKP;
 #pragma unroll
         for (int b = 0; b < X_PER; ++b) {
-            const int blk = b * NT + tid;                // 0 .. XG*16-1
-            const int pg = blk % 16, cg = blk / 16;      // 16 pixel groups, XG channel groups
+            const int pg = tid % XPG + XPG * (b % (16 / XPG)), cg = tid / XPG + (NT / XPG) * (b / (16 / XPG));      // 16 pixel groups, XG channel groups
             const int pix = kbase + pg * 4;              // 4 consecutive pixels: same image row (Q % 4 == 0)
             const bool inr = pix < k_end;
             const int pc = inr ? pix : 0;
-            const int n = pc / PQ, rem = pc - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+            int n, pp, qq;
+            if (p.pq_shift >= 0) {           // workgroup-uniform branch: the staging pass is VALU-bound on this address math
+                n = pc >> p.pq_shift;
+                const int rem = pc & (PQ - 1);
+                pp = rem >> p.q_shift; qq = rem & (p.Q - 1);
+            } else {
+                n = pc / PQ;
+                const int rem = pc - n * PQ;
+                pp = rem / p.Q; qq = rem - pp * p.Q;
+            }
             const int ih = pp * p.stride - p.pad_t + r;
             const bool rowok = inr & ((unsigned)ih < (unsigned)p.H);
-            const long long base = (long long)n * p.s_n + (long long)ih * p.s_h + c0 + cg * 4;
+            // 32-bit byte offsets (the launcher checks that the tensor spans < 4 GiB)
+            const unsigned base = ((unsigned)n * (unsigned)p.s_n + (unsigned)ih * (unsigned)p.s_h + (unsigned)(c0 + cg * 4)) * 4u;
+            const int iw0 = qq * p.stride - p.pad_l + s;
+            const unsigned w0 = base + (unsigned)iw0 * x_wstep;          // one multiply per block; the 4 pixels step by a kernel constant
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int iw = (qq + e) * p.stride - p.pad_l + s;
-                const bool ok = rowok & ((unsigned)iw < (unsigned)p.W);
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)((base + (long long)iw * p.s_w) * 4) : 0xFFFFFFFFu, 0, 0);
+                const bool ok = rowok & ((unsigned)(iw0 + e * p.stride) < (unsigned)p.W);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? w0 + e * x_estep : 0xFFFFFFFFu, 0, 0);
                 rxv[b][e] = __builtin_bit_cast(float4, v);
             }
         }
 #pragma unroll
         for (int b = 0; b < Y_PER; ++b) {
-            const int blk = b * NT + tid;
-            const int pg = blk % 16, cg = blk / 16;
+            const int pg = tid % YPG + YPG * (b % (16 / YPG)), cg = tid / YPG + (NT / YPG) * (b / (16 / YPG));
             const int pix = kbase + pg * 4;
             const bool colok = (n0 + cg * 4) < p.Ng;
+            const unsigned ybase = ((unsigned)pix * (unsigned)p.Ng + (unsigned)(n0 + cg * 4)) * 4u;
+            const unsigned ystep = (unsigned)p.Ng * 4u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool ok = colok & (pix + e < k_end);
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? (unsigned)(((long long)(pix + e) * p.Ng + n0 + cg * 4) * 4) : 0xFFFFFFFFu, 0, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? ybase + e * ystep : 0xFFFFFFFFu, 0, 0);
                 ryv[b][e] = __builtin_bit_cast(float4, v);
             }
         }
@@ -391,10 +405,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         unsigned short* Ys = st + BMC * LDS_K;
 #pragma unroll
         for (int b = 0; b < X_PER; ++b) {
-            const int blk = b * NT + tid;
-            const int pg = blk % 16, cg = blk / 16;
+            const int pg = tid % XPG + XPG * (b % (16 / XPG)), cg = tid / XPG + (NT / XPG) * (b / (16 / XPG));
             float4 (&v)[4] = rxv[b];
-            if (p.relu_x) {
+            if (RELU_X) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e].x = fmaxf(v[e].x, 0.f); v[e].y = fmaxf(v[e].y, 0.f); v[e].z = fmaxf(v[e].z, 0.f); v[e].w = fmaxf(v[e].w, 0.f); }
             }
@@ -411,8 +424,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         }
 #pragma unroll
         for (int b = 0; b < Y_PER; ++b) {
-            const int blk = b * NT + tid;
-            const int pg = blk % 16, cg = blk / 16;
+            const int pg = tid % YPG + YPG * (b % (16 / YPG)), cg = tid / YPG + (NT / YPG) * (b / (16 / YPG));
             const float4 (&v)[4] = ryv[b];
             u32x2 o0 = {Cvt<MMA>::pk(v[0].x, v[1].x), Cvt<MMA>::pk(v[2].x, v[3].x)};
             u32x2 o1 = {Cvt<MMA>::pk(v[0].y, v[1].y), Cvt<MMA>::pk(v[2].y, v[3].y)};
@@ -446,7 +458,6 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         const unsigned short* Ys = Xs + BMC * LDS_K;
         if (kt + 1 < nk && !(p.dbg & 1)) store_slice(smem + ((kt + 1) & 1) * STAGE);
         if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2);
-        if (!(p.dbg & 8))
 #pragma unroll
         for (int ks = 0; ks < BKP / 16; ++ks) {
             u32x4 fa[TM], fb[TN];
@@ -554,8 +565,9 @@ template <int MMA, int TM, int TN>
 int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
     constexpr int BMC = 2 * TM * 32, BNK = 2 * TN * 32;
     constexpr size_t lds = (size_t)2 * (BMC + BNK) * (64 + 8) * 2;
-    auto kern = wgrad16_kernel<MMA, TM, TN>;
-    static bool attr = false;
+    auto kern = p.relu_x ? wgrad16_kernel<MMA, TM, TN, true> : wgrad16_kernel<MMA, TM, TN, false>;
+    static bool attrs[2] = {false, false};
+    bool& attr = attrs[p.relu_x ? 1 : 0];
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16: cannot reserve %zu B of LDS", lds);
@@ -719,6 +731,12 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
     p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.chunk = w.chunk; p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0; p.dbg = dbg16();
+    {
+        const int pq = d->P * d->Q;
+        const bool pow2 = !(pq & (pq - 1)) && !(d->Q & (d->Q - 1));
+        p.pq_shift = pow2 ? __builtin_ctz(pq) : -1;
+        p.q_shift = pow2 ? __builtin_ctz(d->Q) : -1;
+    }
     p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)(y_extent * 4);
     hipStream_t st = (hipStream_t)stream;
     int rc;
