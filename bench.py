@@ -162,7 +162,7 @@ def main():
             'step': step_exec,
             'step_effective_frac': round(ITER_GFLOP * 1e9 / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             'step_effective_frac_note': 'EFFECTIVE rate, not a roofline fraction: FLOPs of the REFERENCE formulation (SURVEY 8(d), 2990.5 GFLOP / iteration) / time / fp32 MFMA peak; the executed count is lower (resampled convs run as stride-2 convs with the spread filter): see step.frac_executed',
-            'roofline': roofline, 'gp_unit': gp_unit, 'cpu_baseline': cpu,
+            'roofline': roofline, 'gp_unit': gp_unit, 'cpu_baseline': cpu, 'build': build_provenance(),
         }
         print(json.dumps(rec))
     if world > 1:
@@ -276,7 +276,7 @@ def run_unconditional(args):
             'dtype': dtype or 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'name': args.config, 'global_batch': B * world, 'images_per_step': n_crit * B * world,
                        'parallelism': 'dp%d' % world, 'hipgraph': bool(eng.graphed), 'last_d_terms': last, 'loss_sane': sane},
-            'roofline': roofline, 'cpu_baseline': None}))
+            'roofline': roofline, 'cpu_baseline': None, 'build': build_provenance()}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
     if not sane:
@@ -399,6 +399,17 @@ def measure_gp_unit(trainer, batch, torch):
             'effective_frac': round(gflop / ms / PEAK_F32_MFMA_TFLOPS, 4), 'target_frac': 0.60,
             'note': 'frac_executed = FLOPs launched (ConvMeanPool runs as a 4x4 stride-2 conv: 2.25x fewer MACs on 69 % of F_D) / time / '
                     'peak - the roofline fraction; effective_frac prices the same time with the reference formulation\'s 139.3 GFLOP'}
+
+
+def build_provenance():
+    """Which sources the loaded libctgan_hip.so was built from (stamp written by __graft_entry__.build) and whether they are the
+    sources in this tree."""
+    try:
+        import __graft_entry__ as ge
+        stamp = json.load(open(os.path.join(ROOT, 'ctgan_amd', 'libctgan_hip.build.json')))
+        return {'sources_sha256': stamp['sources_sha256'][:16], 'built_at': stamp['built_at'], 'matches_tree': stamp['sources_sha256'] == ge.source_digest()}
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e)}
 
 
 def host_cores():

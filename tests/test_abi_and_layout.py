@@ -82,3 +82,17 @@ def test_reference_error_behaviour_is_kept(cpu_kernels):
         linear.Linear('l', 4, 4, torch.zeros(1, 4), initialization='nope')
     with pytest.raises(Exception, match='invalid resample value'):
         R.ResidualBlock('r', 4, 4, 3, x, resample='sideways')
+
+
+def test_shared_library_was_built_from_the_sources_in_this_tree():
+    """Provenance: __graft_entry__.build() stamps the library with the sha256 of the sources it compiled; a stale prebuilt
+    library (sources edited, library not rebuilt) fails here and shows as `build.matches_tree: false` in the bench line."""
+    import json
+    import os
+    import __graft_entry__ as ge
+    stamp_path = os.path.join(ge.ROOT, 'ctgan_amd', 'libctgan_hip.build.json')
+    if not os.path.exists(stamp_path):
+        import pytest
+        pytest.skip('library not built through __graft_entry__.build()')
+    stamp = json.load(open(stamp_path))
+    assert stamp['sources_sha256'] == ge.source_digest(), 'libctgan_hip.so is older than the kernel sources: run python __graft_entry__.py'
