@@ -13,6 +13,11 @@ from . import gan_cifar_resnet as R
 from . import tflib as lib
 
 
+import os as _os
+# A/B switch: the whole iteration (G step + fake batches + N_CRITIC critic steps) as ONE hipGraph when world == 1
+ITERATION_GRAPH = _os.environ.get('CTGAN_ITERATION_GRAPH', '1') != '0'
+
+
 class GraphedTrainer:
     def __init__(self, trainer, use_graphs=True, warmup=2):
         self.t = trainer
@@ -26,6 +31,9 @@ class GraphedTrainer:
         self.fake = torch.zeros(B, R.cfg.OUTPUT_DIM, dtype=torch.float32, device=dev) if self.batch_fakes else None
         self.f_graph = None
         self.fake_all = None
+        self.it_graph = None          # ONE graph for a whole iteration (G step + fake batches + N_CRITIC critic steps), world == 1
+        self.it_out = None
+        self.real_all = torch.zeros(R.cfg.N_CRITIC, B, R.cfg.OUTPUT_DIM, dtype=torch.int32, device=dev) if self.batch_fakes else None
         self.adam_in_graph = trainer.world == 1
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
@@ -39,14 +47,17 @@ class GraphedTrainer:
                 torch.cuda.synchronize()
 
     # -- the region that is captured (everything between input copy and all-reduce / Adam)
-    def _d_body(self):
+    def _d_body(self, real=None, labels=None, fake=None):
         t = self.t
+        real = self.real if real is None else real
+        labels = self.labels if labels is None else labels
+        fake = self.fake if fake is None else fake
         # the critic's weights change between replays (its Adam step): its derived filter layouts must be rebuilt INSIDE
         # this graph - all of them in one or two launches.  The generator's are not used here (fake batches are inputs).
         lib.bump_epoch('Discriminator' if self.batch_fakes else None)
         F.prepare_filters()
         t.rng.begin_step()
-        out = t.d_losses(self.real, self.labels, fake=self.fake)
+        out = t.d_losses(real, labels, fake=fake)
         with F.deferred_wgrads():
             grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
         t.d_opt.gather_grads(grads)
@@ -54,6 +65,15 @@ class GraphedTrainer:
             t.d_opt.step(1.0)
         t.rng.end_step()
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
+
+    def _it_body(self):
+        """A whole iteration of the loop body (TF/CT_gan_cifar_resnet.py:393-404) with it > 0: generator step, the fake batches
+        of the N_CRITIC critic steps, then the critic steps on rows of the static batch buffers."""
+        B = R.cfg.BATCH_SIZE
+        g_out = self._g_body()
+        fakes = self._f_body()
+        d_outs = [self._d_body(self.real_all[i], self.labels_all[i * B:(i + 1) * B], fakes[i]) for i in range(R.cfg.N_CRITIC)]
+        return {'g': g_out, 'd': d_outs}
 
     def _f_body(self):
         lib.bump_epoch('Generator')      # runs after the generator update of the iteration
@@ -112,6 +132,12 @@ class GraphedTrainer:
                 self.f_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.f_graph):
                     self.fake_all = self._f_body()
+                if self.adam_in_graph and ITERATION_GRAPH:
+                    # Seven graph launches per iteration leave ~150 us of idle GPU at each boundary (profiles/
+                    # r02_steady_state_resnet_v2.txt: 1.07 ms of 20.5 ms); one graph per iteration has one boundary.
+                    self.it_graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.it_graph):
+                        self.it_out = self._it_body()
         finally:
             torch.cuda.synchronize()
             for b, sn in zip(bufs, snap):
@@ -190,6 +216,18 @@ class GraphedTrainer:
         def stage_labels():
             for i, (_, lab) in enumerate(batches):
                 self.labels_all[i * B:(i + 1) * B].copy_(lab, non_blocking=True)
+        if self.it_graph is not None and iteration > 0:
+            t = self.t
+            stage_labels()
+            for i, (data, _) in enumerate(batches):
+                self.real_all[i].copy_(data, non_blocking=True)
+            t.g_opt.set_lr(t.lr(iteration))
+            t.d_opt.set_lr(t.lr(iteration))
+            self.it_graph.replay()
+            t.g_opt.t += 1
+            t.d_opt.t += len(batches)
+            self.g_out = self.it_out['g']
+            return self.it_out['d'][-1]
         if iteration > 0:
             self.g_step(iteration, between=stage_labels)
         else:

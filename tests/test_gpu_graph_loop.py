@@ -252,3 +252,43 @@ def test_thousand_iteration_trace_against_oracle_fixture():
     for j, n in enumerate(names):
         bound = 0.2 if twin_w is None else max(0.2, 2.0 * float(twin_w[:, j].max()))
         assert wrel[:, j].max() <= bound, (n, float(wrel[:, j].max()), bound)
+
+
+@pytest.mark.parametrize('dim,B,iters', [(32, 8, 6), (128, 64, 4)])
+def test_whole_iteration_graph_equals_eager_loop(dim, B, iters):
+    """engine.GraphedTrainer.train_iteration replays ONE hipGraph per iteration (generator step + the fake batches + N_CRITIC
+    critic steps; world == 1) - what bench.py times.  Against the eager Trainer.train_iteration on the same batches and Philox
+    streams: the last critic step's loss terms of every iteration and the final weights are the same bits."""
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.engine import GraphedTrainer
+    batches = _batches(B)
+
+    def run(graphs):
+        lib.delete_all_params(); lib.set_device(None); lib.set_seed(0)
+        R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+        R.build_params()
+        tr = R.Trainer(seed=2024)
+        eng = GraphedTrainer(tr, use_graphs=graphs)
+        assert eng.graphed == graphs, eng.graph_error
+        if graphs:
+            assert eng.it_graph is not None
+        cur = [0]
+
+        def nb():
+            cur[0] = (cur[0] + 1) % len(batches)
+            return batches[cur[0]]
+        recs = []
+        for it in range(0, iters):                   # iteration 0 has no generator step: per-step graphs; then the iteration graph
+            out = eng.train_iteration(it, nb)
+            recs.append({k: float(out[k].item()) for k in TERMS})
+        res = (recs, tr.d_opt.theta.clone(), tr.g_opt.theta.clone(), tr.d_opt.t, tr.g_opt.t, int(tr.rng.ctr.item()))
+        lib.delete_all_params(); R.configure()
+        return res
+    g, e = run(True), run(False)
+    assert g[3:] == e[3:] == (5 * iters, iters - 1, 7 * iters - 1)
+    for n, (a, b) in enumerate(zip(g[0], e[0])):
+        for k in TERMS:
+            assert math.isfinite(a[k]) and abs(a[k]) < 1e3
+            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(b[k])), 'iteration %d %s: graph %r eager %r' % (n, k, a[k], b[k])
+    assert torch.equal(g[1], e[1]) and torch.equal(g[2], e[2])
