@@ -136,7 +136,7 @@ struct P16 {
     int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier (a branch around the MFMAs would move the accumulators out of the AGPRs)
 };
 
-template <int MMA, int TM, int TN, int BK, bool RELU_IN>
+template <int MMA, int TM, int TN, int BK, bool RELU_IN, bool SCHED = (TM * TN >= 8)>
 __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     // TM: 32-wide kout sub-tiles per wave ("A" operand), TN: 32-wide pixel sub-tiles per wave ("B" operand)
     constexpr int NT = 256;
@@ -215,7 +215,15 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
             rw[i] = __builtin_bit_cast(u32x4, v);
         }
         ++ld_k;
-        if (++ld_c == cpt) { ld_c = 0; if (++ld_u == U) { ld_u = 0; ++ld_t; } }
+        // branch-free advance (scalar selects): a branch here would split the slice's basic block and the scheduler could not
+        // weave the staging instructions between the MFMAs
+        ++ld_c;
+        const bool wc = ld_c == cpt;
+        ld_c = wc ? 0 : ld_c;
+        ld_u += wc ? 1 : 0;
+        const bool wu = ld_u == U;
+        ld_u = wu ? 0 : ld_u;
+        ld_t += wu ? 1 : 0;
     };
     auto store_slice = [&](unsigned short* st) {
         unsigned short* Xs = st;
@@ -241,15 +249,8 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int h = lane >> 5, l31 = lane & 31;
-    load_slice();
-    store_slice(smem);
-    if (nk > 1) load_slice();
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned short* Xs = smem + (kt & 1) * STAGE;
+    auto mma_slice = [&](const unsigned short* Xs) {
         const unsigned short* Ws = Xs + BMP * LDS_K;
-        if (kt + 1 < nk && !(p.dbg & 1)) store_slice(smem + ((kt + 1) & 1) * STAGE);     // the other stage: its readers passed the last barrier
-        if (kt + 2 < nk && !(p.dbg & 2)) load_slice();
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             u32x4 fw[TM], fx[TN];
@@ -264,7 +265,36 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fw[i], fx[j], acc[i][j]);
         }
-        if (!(p.dbg & 4)) __syncthreads();
+    };
+    load_slice();
+    store_slice(smem);
+    if (nk > 1) load_slice();
+    __syncthreads();
+    // steady state (slices kt+1 and kt+2 exist): ONE basic block per slice - stage slice kt+1 into the other LDS buffer, issue
+    // the loads of slice kt+2, multiply slice kt - so that the scheduler can weave the staging instructions between the MFMAs
+    // (with a single wave per SIMD nothing else fills the 32-cycle MFMA gaps).  The scheduling groups ask for that order:
+    // per MFMA a few VALU (conversions / addresses), one LDS access and one buffer load.
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        store_slice(smem + ((kt + 1) & 1) * STAGE);       // the other stage: its readers passed the last barrier
+        load_slice();
+        mma_slice(smem + (kt & 1) * STAGE);
+        if (SCHED) {
+#pragma unroll
+            for (int g = 0; g < TM * TN * (BK / 16); ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // 3 VALU
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+            }
+        }
+        __syncthreads();
+    }
+    for (; kt < nk; ++kt) {                                // the last two slices
+        if (kt + 1 < nk) store_slice(smem + ((kt + 1) & 1) * STAGE);
+        mma_slice(smem + (kt & 1) * STAGE);
+        __syncthreads();
     }
 
     // epilogue through LDS: acc[i][j][4g + e] = D(pixel j*32 + l31, kout i*32 + 8g + 4h + e); every wave transposes its own
@@ -555,6 +585,15 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
     const bool small = big_tiles < 192 || p.Ng % 128 != 0;
     if (p.C % 64 == 0) {
         if (small) return launch_conv16<MMA, 1, 1, 64>(p, st, "conv16<64x64,k64>");
+        // EXPERIMENT, off by default (CTGAN_CONV16_WIDE=1): 2x4 accumulators per wave (128 kout x 256 pixels per workgroup, one wave
+        // per SIMD, 0.75 fragment reads per MFMA).  Measured SLOWER than the 2x2 tile at two waves per SIMD (373-458 vs 500-610
+        // TFLOP/s): with one wave per SIMD the staging instructions must be woven between the MFMAs, and although the slice is one
+        // basic block with scheduling groups, the LDS stores of the next slice may not be hoisted above the fragment reads of the
+        // current one (may-alias: both index the same dynamic LDS array) - they stay serial.  Needs restrict-qualified stage
+        // pointers (or hand-placed asm) before it pays.
+        static const int wide = [] { const char* e = getenv("CTGAN_CONV16_WIDE"); return e ? atoi(e) : 0; }();
+        if (wide && (long long)p.nph * ((p.M + 255) / 256) * (p.Ng / 128) >= 224)
+            return launch_conv16<MMA, 2, 4, 64>(p, st, "conv16<128x256,k64>");
         return launch_conv16<MMA, 2, 2, 64>(p, st, "conv16<128x128,k64>");
     }
     if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, "conv16<64x64,k32>");
@@ -584,6 +623,8 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
     WPlan16 w;
     w.bmc = d->C % 128 == 0 ? 128 : 64;
     w.bnk = d->K % 128 == 0 ? 128 : 64;
+    static const int wide = [] { const char* e = getenv("CTGAN_WGRAD16_WIDE"); return e ? atoi(e) : 1; }();
+    if (wide && d->C % 256 == 0 && d->K % 128 == 0) w.bmc = 256;      // 4x2 accumulators per wave: 0.75 operand bytes per MFMA of the 128x128 tile
     w.tiles = d->R * d->S * (d->C / w.bmc) * ((d->K + w.bnk - 1) / w.bnk);
     const int Kg = d->N * d->P * d->Q;
     // 512 workgroups are resident at a time (2 per CU: 73 KB of LDS each).  Pick the split count whose LAST round of workgroups
@@ -592,10 +633,11 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
     const int max_s = (Kg + 255) / 256;
     int s = 1;
     double best = -1.;
-    for (int cand = 1; cand <= max_s && cand <= 64 && (long long)cand * w.tiles <= 4096; ++cand) {
+    const int resident = w.bmc == 256 ? 256 : 512;      // the 110 KB wide tile: one workgroup per CU
+    for (int cand = 1; cand <= max_s && cand <= 64 && (long long)cand * w.tiles <= 8 * resident; ++cand) {
         const long long blocks = (long long)cand * w.tiles;
-        const long long rounds = (blocks + 511) / 512;
-        const double eff = (double)blocks / (double)(rounds * 512);
+        const long long rounds = (blocks + resident - 1) / resident;
+        const double eff = (double)blocks / (double)(rounds * resident);
         if (eff > best + 0.03) { best = eff; s = cand; }
     }
     int ch = (Kg + s - 1) / s;
@@ -741,7 +783,8 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool bf = mma == CTGAN_MMA_BF16;
-    if (w.bmc == 128 && w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 2>(p, w.splits, st, "wgrad16<128x128>") : launch_wgrad16<CTGAN_MMA_F16, 2, 2>(p, w.splits, st, "wgrad16<128x128>");
+    if (w.bmc == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 2>(p, w.splits, st, "wgrad16<256x128>") : launch_wgrad16<CTGAN_MMA_F16, 4, 2>(p, w.splits, st, "wgrad16<256x128>");
+    else if (w.bmc == 128 && w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 2>(p, w.splits, st, "wgrad16<128x128>") : launch_wgrad16<CTGAN_MMA_F16, 2, 2>(p, w.splits, st, "wgrad16<128x128>");
     else if (w.bmc == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 1>(p, w.splits, st, "wgrad16<128x64>") : launch_wgrad16<CTGAN_MMA_F16, 2, 1>(p, w.splits, st, "wgrad16<128x64>");
     else if (w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 2>(p, w.splits, st, "wgrad16<64x128>") : launch_wgrad16<CTGAN_MMA_F16, 1, 2>(p, w.splits, st, "wgrad16<64x128>");
     else rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 1>(p, w.splits, st, "wgrad16<64x64>") : launch_wgrad16<CTGAN_MMA_F16, 1, 1>(p, w.splits, st, "wgrad16<64x64>");
