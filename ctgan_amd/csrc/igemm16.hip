@@ -136,7 +136,7 @@ struct P16 {
     int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier (a branch around the MFMAs would move the accumulators out of the AGPRs)
 };
 
-template <int MMA, int TM, int TN, int BK, bool RELU_IN, bool SCHED = (TM * TN >= 8)>
+template <int MMA, int TM, int TN, int BK, bool RELU_IN, bool SPLIT = (TM * TN >= 8)>
 __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     // TM: 32-wide kout sub-tiles per wave ("A" operand), TN: 32-wide pixel sub-tiles per wave ("B" operand)
     constexpr int NT = 256;
@@ -149,7 +149,13 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     constexpr int W_PER = BNC * WC / NT;
     static_assert(BMP * XC % NT == 0 && BNC * WC % NT == 0 && X_PER >= 1 && W_PER >= 1, "tile / thread mismatch");
     constexpr int STAGE = (BMP + BNC) * LDS_K;          // 16-bit elements
+    // SPLIT (the one-wave-per-SIMD tile): the two LDS stages are two DIFFERENT objects - a static array and the dynamic region -
+    // so the compiler knows that the stores staging slice t+1 cannot alias the fragment reads of slice t and may weave them
+    // between the MFMAs (with both stages inside one dynamic array every store has to stay behind every earlier read).
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    __shared__ __attribute__((aligned(16))) unsigned short stage0_static[SPLIT ? STAGE : 8];
+    unsigned short* const S0 = SPLIT ? stage0_static : smem;
+    unsigned short* const S1 = SPLIT ? smem : smem + STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;            // wave's kout half / pixel half
@@ -267,70 +273,79 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
         }
     };
     load_slice();
-    store_slice(smem);
+    store_slice(S0);
     if (nk > 1) load_slice();
     __syncthreads();
     // steady state (slices kt+1 and kt+2 exist): ONE basic block per slice - stage slice kt+1 into the other LDS buffer, issue
-    // the loads of slice kt+2, multiply slice kt - so that the scheduler can weave the staging instructions between the MFMAs
-    // (with a single wave per SIMD nothing else fills the 32-cycle MFMA gaps).  The scheduling groups ask for that order:
-    // per MFMA a few VALU (conversions / addresses), one LDS access and one buffer load.
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) {
-        store_slice(smem + ((kt + 1) & 1) * STAGE);       // the other stage: its readers passed the last barrier
+    // the loads of slice kt+2, multiply slice kt.  SPLIT: scheduling groups ask for the staging instructions to be woven between
+    // the MFMAs (one wave per SIMD: nothing else fills the 32-cycle MFMA gaps): first the fragments of the first k step, then
+    // per MFMA a few VALU (conversions / addresses), one LDS read, one LDS write, one buffer load.
+    auto slice = [&](unsigned short* wr, const unsigned short* rd) {
+        store_slice(wr);                                   // the other stage: its readers passed the last barrier
         load_slice();
-        mma_slice(smem + (kt & 1) * STAGE);
-        if (SCHED) {
+        mma_slice(rd);
+        if (SPLIT) {
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
             for (int g = 0; g < TM * TN * (BK / 16); ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // 3 VALU
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
             }
         }
         __syncthreads();
-    }
-    for (; kt < nk; ++kt) {                                // the last two slices
-        if (kt + 1 < nk) store_slice(smem + ((kt + 1) & 1) * STAGE);
-        mma_slice(smem + (kt & 1) * STAGE);
+    };
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) { slice(S1, S0); slice(S0, S1); }      // kt even: slice kt lives in S0
+    for (; kt < nk; ++kt) {                                // the last slices
+        if (kt + 1 < nk) store_slice((kt + 1) & 1 ? S1 : S0);
+        if (kt + 2 < nk) load_slice();
+        mma_slice(kt & 1 ? S1 : S0);
         __syncthreads();
     }
 
     // epilogue through LDS: acc[i][j][4g + e] = D(pixel j*32 + l31, kout i*32 + 8g + 4h + e); every wave transposes its own
     // (TN*32 pixels) x (TM*32 kout) block so that a lane then owns 4 consecutive channels of a pixel and a wave instruction
     // stores whole rows (16-B per lane, mask / residual / bias operands as 16-B loads).
-    constexpr int LDE = TM * 32 + 4;          // the launcher sizes the LDS for max(two stages, this staging area)
-    float* es = reinterpret_cast<float*>(smem) + wave * (TN * 32 * LDE);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *reinterpret_cast<float4*>(&es[(j * 32 + l31) * LDE + i * 32 + 8 * g + 4 * h]) = v;
-            }
-    __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): the wave reads back what its own lanes wrote (no cross-wave traffic)
-    __builtin_amdgcn_wave_barrier();
+    constexpr int LDE = TM * 32 + 4;          // the launcher sizes the dynamic LDS for max(stage(s), this staging area)
+    constexpr int JE = TN > 2 ? 2 : TN;       // pixel sub-tiles per epilogue pass (the wide tile takes two passes: 70 KB, not 139)
+    float* es = reinterpret_cast<float*>(smem) + wave * (JE * 32 * LDE);
     constexpr int C4 = TM * 8;                // float4 per pixel row of the wave's block
     constexpr int ROWS_PER = 64 / C4;
 #pragma unroll
-    for (int it = 0; it < TN * 32 / ROWS_PER; ++it) {
-        const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
-        const int m = m0 + wn * TN * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
-        if (m >= p.M || col >= p.Ng) continue;
-        float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
-        const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
-        const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
-        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        if (p.mask) {
-            const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
-            v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    for (int jh = 0; jh < TN; jh += JE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < JE; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v = {acc[i][jh + j][4 * g], acc[i][jh + j][4 * g + 1], acc[i][jh + j][4 * g + 2], acc[i][jh + j][4 * g + 3]};
+                    *reinterpret_cast<float4*>(&es[(j * 32 + l31) * LDE + i * 32 + 8 * g + 4 * h]) = v;
+                }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave reads back what its own lanes wrote (no cross-wave traffic)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < JE * 32 / ROWS_PER; ++it) {
+            const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
+            const int m = m0 + wn * TN * 32 + jh * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
+            if (m >= p.M || col >= p.Ng) continue;
+            float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+            const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+            const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.mask) {
+                const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+                v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+            }
+            if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(p.D + off) = v;
         }
-        if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(p.D + off) = v;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();      // the next pass overwrites the staging rows this pass has just read
     }
 }
 
@@ -560,7 +575,9 @@ bool shape_ok_wgrad(const ctgan_conv_desc* d) {
 template <int MMA, int TM, int TN, int BK>
 int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     constexpr int BMP = 2 * TN * 32, BNC = 2 * TM * 32;
-    constexpr size_t lds_stages = (size_t)2 * (BMP + BNC) * (BK + 8) * 2, lds_epi = (size_t)4 * TN * 32 * (TM * 32 + 4) * 4;
+    constexpr bool split = TM * TN >= 8;            // one stage is a static array (see the kernel)
+    constexpr size_t lds_stages = (size_t)(split ? 1 : 2) * (BMP + BNC) * (BK + 8) * 2;
+    constexpr size_t lds_epi = (size_t)4 * (TN > 2 ? 2 : TN) * 32 * (TM * 32 + 4) * 4;
     constexpr size_t lds = lds_stages > lds_epi ? lds_stages : lds_epi;
     auto kern = p.relu_in ? conv16_kernel<MMA, TM, TN, BK, true> : conv16_kernel<MMA, TM, TN, BK, false>;
     static bool attr[2] = {false, false};
