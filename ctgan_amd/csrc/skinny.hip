@@ -4,6 +4,8 @@
 //   forward = one wave per row with a shuffle reduction, data gradient = one thread per input
 //   element, weight/bias gradient = one thread per weight walking the rows in order (deterministic).
 //   These are latency-bound (a few KB); the point is a ~3 us launch instead of a ~30 us GEMM tile.
+#include <stdint.h>
+
 #include "common.h"
 
 namespace {
@@ -39,6 +41,30 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __re
             if (relu) v = fmaxf(v, 0.f);
             y[(long long)row * ys_n + j * ys_k] = v;
         }
+    }
+}
+
+// Long single-output rows (the DCGAN critic head [n,8192] x [8192,1], TF/CT_gan_cifar.py:98): one WORKGROUP per row, every thread
+// keeps C/1024 independent 16-B loads of x and w in flight (the wave-per-row kernel above walks 128 dependent steps: 57 us for
+// 6 MB).  Fixed-order reduction (lane tree, then the 4 wave partials in order).
+__global__ __launch_bounds__(256) void linear_gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int C, long long xs_n, long long ys_n, int relu) {
+    __shared__ float red[4];
+    const float* xr = x + (long long)blockIdx.x * xs_n;
+    float acc = 0.f;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + c);
+        const float4 b = *reinterpret_cast<const float4*>(w + c);
+        acc = fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, acc))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = ((red[0] + red[1]) + (red[2] + red[3])) + (bias ? bias[0] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        y[(long long)blockIdx.x * ys_n] = v;
     }
 }
 
@@ -95,6 +121,11 @@ bool ctgan_is_small_linear(const ctgan_conv_desc* d) {
 
 int ctgan_small_linear_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu,
                            hipStream_t st) {
+    if (d->K == 1 && d->xs[1] == 1 && d->C % 4 == 0 && d->C >= 1024 && d->xs[0] % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        hipLaunchKernelGGL(linear_gemv_fwd_kernel, dim3(d->N), dim3(256), 0, st, x, w, bias, y, d->C, (long long)d->xs[0], (long long)d->ys[0], relu);
+        return ctgan_check_launch("linear_gemv_fwd");
+    }
     hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((d->N + 3) / 4), dim3(256), 0, st, x, w, bias, y, d->N, d->C, d->K,
                        (long long)d->xs[0], (long long)d->xs[1], (long long)d->ys[0], (long long)d->ys[1], relu);
     return ctgan_check_launch("linear_small_fwd");

@@ -50,14 +50,14 @@ class DCGANTrainer:
             x3 = torch.cat([real, real, fake], 0)
         if rnd is not None:
             u = [torch.cat([a, b, c], 0) for a, b, c in zip(rnd['u_real'], rnd['u_real_'], rnd['u_fake'])]
+            d, f = m.Discriminator(x3, u=u)
         else:
-            u = self._masks(3 * B, None, None)
-        d, f = m.Discriminator(x3, u=u)
+            d, f = m.Discriminator(x3, rng=self.rng)      # masks regenerated from the Philox stream inside the dropout kernels: no uniform tensors
         wgan = F.mean_diff(d[B:], B, B, 0.0, 1.0) + F.mean_diff(d[:B], B, 0, -1.0, 0.0)   # mean(fake) - mean(real)
         ct = F.consistency_term(d[:B], d[B:2 * B], f[:B], f[B:2 * B], cfg.LAMBDA_2, cfg.Factor_M)
         interp.requires_grad_(True)
         with F.weight_grads(not self.piecewise):     # a LeakyReLU + dropout critic is piecewise linear; a layer-normalised one is not
-            d_gp = m.Discriminator(interp, u=self._masks(B, 'u_gp', rnd))[0]
+            d_gp = (m.Discriminator(interp, u=rnd['u_gp']) if rnd is not None else m.Discriminator(interp, rng=self.rng))[0]
         (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=torch.ones_like(d_gp), create_graph=True)
         gp, slopes = F.gradient_penalty(grads, cfg.LAMBDA)
         return {'cost': wgan + ct + gp, 'wgan_only': wgan, 'ct': ct, 'gp': gp, 'fake': fake, 'slopes': slopes,
@@ -72,7 +72,7 @@ class DCGANTrainer:
         m, B = self.mod, self.mod.cfg.BATCH_SIZE
         x = self._gen(B, rnd['z'] if rnd is not None else None)
         with F.weight_grads(False):
-            d, _ = m.Discriminator(x, u=self._masks(B, 'u_fake', rnd))
+            d, _ = m.Discriminator(x, u=rnd['u_fake']) if rnd is not None else m.Discriminator(x, rng=self.rng)
         return {'cost': F.mean_diff(d, B, 0, -1.0, 0.0), 'samples': x}
 
     def _apply(self, opt, grads):
