@@ -87,8 +87,9 @@ SIGNATURES = {
     'ctgan_conv2d16_supported': (c_int, [_D, c_int]),
     'ctgan_conv2d16_filter_elems': (c_size_t, [_D, c_int]),
     'ctgan_conv2d16_pack_filter': (c_int, [_D, c_int, c_int, _p, _p, _p]),
-    'ctgan_conv2d16_fwd': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_int, _p]),
-    'ctgan_conv2d16_dgrad': (c_int, [_D, c_int, _p, _p, _p, _p, _p, _p, c_int, _p]),
+    'ctgan_conv2d16_workspace_bytes': (c_size_t, [_D, c_int]),
+    'ctgan_conv2d16_fwd': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
+    'ctgan_conv2d16_dgrad': (c_int, [_D, c_int, _p, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
     'ctgan_conv2d16_wgrad_workspace_bytes': (c_size_t, [_D]),
     'ctgan_conv2d16_wgrad': (c_int, [_D, c_int, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_layernorm_supported': (c_int, [c_int64, c_int32]),

@@ -133,6 +133,8 @@ struct P16 {
     int ph_T[2], ph_U[2], ph_pad_t[2], ph_pad_l[2];
     long long ph_w_off[4];          // packed-filter element offset of a phase
     long long ph_d_h, ph_d_w;       // D offset of phase (a,b) = a*ph_d_h + b*ph_d_w
+    int ksplit;                     // > 1: blockIdx.y handles slices [y*nk/ksplit, (y+1)*nk/ksplit) and writes raw sums to slab[y][phase row][n]
+    float* slab; size_t slab_bytes;
     int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier (a branch around the MFMAs would move the accumulators out of the AGPRs)
 };
 
@@ -172,7 +174,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     const long long d_off = pa * p.ph_d_h + pb * p.ph_d_w;
     const int m0 = tile_m * BMP, n0 = tile_n * BNC;
     const int cpt = p.C / BK;                            // slices per tap
-    const int nk = T * U * cpt;
+    const int nk_all = T * U * cpt;
+    const int k_first = p.ksplit > 1 ? (int)((long long)nk_all * blockIdx.y / p.ksplit) : 0;
+    const int nk = (p.ksplit > 1 ? (int)((long long)nk_all * (blockIdx.y + 1) / p.ksplit) : nk_all) - k_first;
     const long long kph = (long long)T * U * p.C;        // packed-filter row length of this phase
     const int PQ = p.P * p.Q;
 
@@ -205,7 +209,8 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
 
     float4 rx[X_PER];
     u32x4 rw[W_PER];
-    int ld_t = 0, ld_u = 0, ld_c = 0, ld_k = 0;          // tap / channel chunk / linear slice index of the NEXT slice to load
+    // tap / channel chunk / linear slice index of the NEXT slice to load (a K split starts in the middle of the filter)
+    int ld_k = k_first, ld_c = k_first % cpt, ld_u = (k_first / cpt) % U, ld_t = (k_first / cpt) / U;
     auto load_slice = [&]() {
         const unsigned xs = (unsigned)(((long long)ld_t * p.s_h + (long long)ld_u * p.s_w + ld_c * BK) * 4);
 #pragma unroll
@@ -333,6 +338,10 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
             const int m = m0 + wn * TN * 32 + jh * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
             if (m >= p.M || col >= p.Ng) continue;
             float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+            if (p.ksplit > 1) {               // partial sums: the reduction kernel applies the epilogue
+                *reinterpret_cast<float4*>(p.slab + (((long long)blockIdx.y * p.nph + ph) * p.M + m) * p.Ng + col) = v;
+                continue;
+            }
             const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
             const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
             if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
@@ -572,6 +581,44 @@ bool shape_ok_wgrad(const ctgan_conv_desc* d) {
            d->xs[3] % 4 == 0 && d->ys[1] == 1 && d->ys[3] == d->K && d->ys[2] == (int64_t)d->Q * d->K && d->ys[0] == (int64_t)d->P * d->Q * d->K;
 }
 
+// D = epilogue(sum over K splits of slab[s][phase row][n]): fixed order, 16-B accesses
+__global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const P16 p) {
+    const long long rows = (long long)p.nph * p.M;
+    const int n4 = p.Ng / 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n4) return;
+    const long long rowi = i / n4;
+    const int col = (int)(i - rowi * n4) * 4;
+    const int ph = (int)(rowi / p.M), m = (int)(rowi - (long long)ph * p.M);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < p.ksplit; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(p.slab + ((long long)s * rows + rowi) * p.Ng + col);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    const int PQ = p.P * p.Q;
+    const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+    const long long off = (ph >> 1) * p.ph_d_h + (ph & 1) * p.ph_d_w + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+    if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (p.mask) {
+        const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+        v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    }
+    if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(p.D + off) = v;
+}
+
+// K split of a forward / data-gradient launch whose pixel x kout tiles cannot fill the chip (8x8 / 4x4 layers at batch 64:
+// 1024 pixels x 512 kout = 128 tiles of 64x64 for K = 6400).  Returns the split count for `blocks` tiles and `nk` slices.
+int conv16_ksplit(long long blocks, int nk) {
+    static const int off = [] { const char* e = getenv("CTGAN_CONV16_KSPLIT"); return e && atoi(e) == 0; }();
+    if (off || blocks >= 256 || nk < 32) return 1;
+    int s = (int)(512 / blocks);
+    if (s > 8) s = 8;
+    while (s > 1 && nk / s < 12) --s;
+    return s < 2 ? 1 : s;
+}
+
 template <int MMA, int TM, int TN, int BK>
 int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     constexpr int BMP = 2 * TN * 32, BNC = 2 * TM * 32;
@@ -590,18 +637,42 @@ int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     P16 q = p;
     q.ph_tiles_m = tiles_m;
     q.dbg = dbg16();
-    hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n)), dim3(256), lds, st, q);
+    if (!(q.ksplit > 1 && q.slab)) { q.ksplit = 1; q.slab = nullptr; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n), (unsigned)q.ksplit), dim3(256), lds, st, q);
     ctgan_set_last_kernel(name);
-    return ctgan_check_launch(name);
+    int rc = ctgan_check_launch(name);
+    if (rc || q.ksplit == 1) return rc;
+    const long long n = (long long)q.nph * q.M * (q.Ng / 4);
+    hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q);
+    return ctgan_check_launch("conv16_splitk_epilogue");
 }
+
+template <int MMA>
+int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st);
 
 template <int MMA>
 int dispatch_conv16(const P16& p, hipStream_t st) {
     // small pixel grids (8x8 / 4x4 layers at batch 64): 64x64 tiles expose 4x the workgroups
     const long long big_tiles = (long long)p.nph * ((p.M + 127) / 128) * ((p.Ng + 127) / 128);
     const bool small = big_tiles < 192 || p.Ng % 128 != 0;
+    P16 q = p;
+    q.ksplit = 1;
+    if (small && p.slab) {
+        const int bk = p.C % 64 == 0 ? 64 : 32;
+        int nk_min = 1 << 30;
+        for (int ph = 0; ph < p.nph; ++ph) { const int nk = p.ph_T[ph >> 1] * p.ph_U[ph & 1] * (p.C / bk); if (nk < nk_min) nk_min = nk; }
+        const long long blocks = (long long)p.nph * ((p.M + 63) / 64) * ((p.Ng + 63) / 64);
+        q.ksplit = conv16_ksplit(blocks, nk_min);
+        if ((size_t)q.ksplit * p.nph * p.M * p.Ng * sizeof(float) > p.slab_bytes) q.ksplit = 1;
+    }
+    if (q.ksplit == 1) q.slab = nullptr;
+    return dispatch_conv16_tiles<MMA>(q, small, st);
+}
+
+template <int MMA>
+int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
     if (p.C % 64 == 0) {
-        if (small) return launch_conv16<MMA, 1, 1, 64>(p, st, "conv16<64x64,k64>");
+        if (small) return launch_conv16<MMA, 1, 1, 64>(p, st, p.ksplit > 1 ? "conv16<64x64,k64,ksplit>" : "conv16<64x64,k64>");
         // EXPERIMENT, off by default (CTGAN_CONV16_WIDE=1): 2x4 accumulators per wave (128 kout x 256 pixels per workgroup, one wave
         // per SIMD, 0.75 fragment reads per MFMA).  Measured SLOWER than the 2x2 tile at two waves per SIMD (373-458 vs 500-610
         // TFLOP/s): with one wave per SIMD the staging instructions must be woven between the MFMAs, and although the slice is one
@@ -613,7 +684,7 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
             return launch_conv16<MMA, 2, 4, 64>(p, st, "conv16<128x256,k64>");
         return launch_conv16<MMA, 2, 2, 64>(p, st, "conv16<128x128,k64>");
     }
-    if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, "conv16<64x64,k32>");
+    if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16<64x64,k32,ksplit>" : "conv16<64x64,k32>");
     return launch_conv16<MMA, 2, 2, 32>(p, st, "conv16<128x128,k32>");
 }
 
@@ -711,8 +782,17 @@ int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const 
     return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_filter: op %d", op);
 }
 
+size_t ctgan_conv2d16_workspace_bytes(const ctgan_conv_desc* d, int op) {
+    // K-split slabs of the forward / data gradient (only launches whose tiles cannot fill the chip use them): 8 splits at most
+    if (!d || (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD)) return 0;
+    const long long rows = op == CTGAN_CONV_FWD ? (long long)d->N * d->P * d->Q : (long long)d->N * d->H * d->W;
+    const long long cols = op == CTGAN_CONV_FWD ? d->K : d->C;
+    if (rows * cols > (1LL << 22)) return 0;                 // >= 256 tiles of 128x128: never split
+    return (size_t)8 * rows * cols * sizeof(float);
+}
+
 int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
-                       float* y, int flags, ctgan_stream_t stream) {
+                       float* y, int flags, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     if (!d || !x || !wp || !y || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_fwd: bad argument");
     if (!shape_ok_fwd(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: shape outside the 16-bit family");
     const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
@@ -727,6 +807,7 @@ int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const 
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
     p.x_bytes = (unsigned)(x_extent * 4); p.w_bytes = (unsigned)((long long)d->R * d->S * d->C * d->K * 2);
     p.nph = 1;
+    p.slab = (float*)ws; p.slab_bytes = ws ? ws_bytes : 0;
     p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
     p.ph_T[1] = d->R; p.ph_U[1] = d->S; p.ph_pad_t[1] = d->pad_t; p.ph_pad_l[1] = d->pad_l;
     hipStream_t st = (hipStream_t)stream;
@@ -734,7 +815,7 @@ int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const 
 }
 
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias, const float* mask,
-                         const float* resid, float* dx, int flags, ctgan_stream_t stream) {
+                         const float* resid, float* dx, int flags, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     if (!d || !dy || !wp || !dx || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_dgrad: bad argument");
     if (!shape_ok_dgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad: shape outside the 16-bit family");
     const long long y_extent = (long long)(d->N - 1) * d->ys[0] + (long long)(d->P - 1) * d->ys[2] + (long long)(d->Q - 1) * d->ys[3] + d->K;
@@ -750,6 +831,7 @@ int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, con
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = 0;
     p.x_bytes = (unsigned)(y_extent * 4); p.w_bytes = (unsigned)((long long)d->R * d->S * d->C * d->K * 2);
     p.nph = g.nph;
+    p.slab = (float*)ws; p.slab_bytes = ws ? ws_bytes : 0;
     for (int a = 0; a < 2; ++a) { p.ph_T[a] = g.T[a]; p.ph_U[a] = g.U[a]; p.ph_pad_t[a] = g.pad_t[a]; p.ph_pad_l[a] = g.pad_l[a]; }
     for (int ph = 0; ph < 4; ++ph) p.ph_w_off[ph] = ph < g.nph ? phase_off(g, d, ph) : 0;
     if (g.nph == 4) {

@@ -267,7 +267,9 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
             and lib.ctgan_conv2d16_supported(ctypes.byref(d), 0)):
         wp = _packed16(w, d, 0, g)
         code = _MMA_CODE[MMA_DTYPE]
-        _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd(ctypes.byref(d), code, _ptr(x), _ptr(wp), _ptr(bias), _ptr(resid), _ptr(y), fl, _stream()), 'conv2d16_fwd'))
+        nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), 0)
+        ws = workspace(nb, x.device) if nb else None
+        _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd(ctypes.byref(d), code, _ptr(x), _ptr(wp), _ptr(bias), _ptr(resid), _ptr(y), fl, _ptr(ws), nb, _stream()), 'conv2d16_fwd'))
         return y
     if fl & 8:
         try:
@@ -325,7 +327,9 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
     if (MMA_DTYPE is not None and drop is None and not fewch_handles(g) and lib.ctgan_conv2d16_supported(ctypes.byref(d), 1)):
         wp = _packed16(w, d, 1, g)
         code = _MMA_CODE[MMA_DTYPE]
-        _timed(g, N, lambda: check(lib.ctgan_conv2d16_dgrad(ctypes.byref(d), code, _ptr(gy), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), 0, _stream()), 'conv2d16_dgrad'))
+        nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), 1)
+        ws = workspace(nb, gy.device) if nb else None
+        _timed(g, N, lambda: check(lib.ctgan_conv2d16_dgrad(ctypes.byref(d), code, _ptr(gy), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), 0, _ptr(ws), nb, _stream()), 'conv2d16_dgrad'))
         return dx
     if wt is not None:
         assert wt.numel() * 4 == lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 1)

@@ -180,10 +180,14 @@ enum { CTGAN_MMA_BF16 = 1, CTGAN_MMA_F16 = 2 };
 int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op);                 /* op = CTGAN_CONV_{FWD,DGRAD,WGRAD}; 1 / 0 */
 size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op);           /* 16-bit elements of the packed filter     */
 int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream);
+/* ws (optional, ctgan_conv2d16_workspace_bytes(d, op) bytes): slabs for a K split of launches whose pixel x channel tiles cannot
+ * fill the chip (8x8 / 4x4 layers at batch 64); NULL = never split.                                                      */
+size_t ctgan_conv2d16_workspace_bytes(const ctgan_conv_desc* d, int op);
 int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
-                       float* y, int flags, ctgan_stream_t stream);
+                       float* y, int flags, void* ws, size_t ws_bytes, ctgan_stream_t stream);
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias,
-                         const float* mask, const float* resid, float* dx, int flags, ctgan_stream_t stream);
+                         const float* mask, const float* resid, float* dx, int flags, void* ws, size_t ws_bytes,
+                         ctgan_stream_t stream);
 size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d);
 int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws,
                          size_t ws_bytes, int flags, ctgan_stream_t stream);
