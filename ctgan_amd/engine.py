@@ -105,6 +105,8 @@ class GraphedTrainer:
         first critic replay left in that memory, hence a critic cost of -6e18).  A private pool costs ~3 GB per graph of
         the 288 GB and makes an output valid until its own graph is replayed again."""
         t = self.t
+        from . import kernels as K
+        K.reset_capture_workspaces()
         opts = (t.d_opt, t.g_opt)
         bufs = [b for o in opts for b in (o.m, o.v, o.state)] + [t.rng.ctr]
         snap = [b.clone() for b in bufs]
@@ -284,6 +286,8 @@ class GraphedDCGANTrainer:
 
     def _capture(self, warmup):
         t = self.t
+        from . import kernels as K
+        K.reset_capture_workspaces()
         opts = (t.d_opt, t.g_opt)
         bufs = [b for o in opts for b in (o.m, o.v, o.state)] + [t.rng.ctr]
         snap = [b.clone() for b in bufs]

@@ -127,13 +127,24 @@ def _need_dev(*ts):
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream): reuse is ordered by the stream it belongs to, so
-    branches of a step that run on different streams never share split-K slabs."""
+    branches of a step that run on different streams never share split-K slabs.  Buffers requested while a hipGraph is being
+    captured live in that graph's private pool: they are kept in a separate table that `reset_capture_workspaces()` empties
+    before the next set of graphs is captured (a buffer from the pool of a destroyed graph must not be baked into another)."""
+    capturing = device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+    cache = _ws_capture_cache if capturing else _ws_cache
     key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == 'cuda' else 0)
-    buf = _ws_cache.get(key)
+    buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+        cache[key] = buf
     return buf
+
+
+_ws_capture_cache = {}
+
+
+def reset_capture_workspaces():
+    _ws_capture_cache.clear()
 
 
 def empty_cl(n, c, h, w, device, dtype=torch.float32):

@@ -103,3 +103,59 @@ def test_dcgan_d_and_g_step(which, dim, B):
         assert torch.isfinite(o['cost']).item()
     finally:
         M.configure(); lib.delete_all_params()
+
+
+@pytest.mark.parametrize('which,dtype', [('cifar', None), ('cifar', 'bf16'), ('lsun128', 'f16')])
+def test_graphed_unconditional_trainer_equals_eager(which, dtype):
+    """engine.GraphedDCGANTrainer (what `bench.py --config ...` times: hipGraph replay of the shared unconditional CT-WGAN step,
+    in-kernel Philox dropout, packed 16-bit filters rebuilt inside the graphs) against the eager DCGANTrainer on the same batches
+    and Philox streams: same loss terms at every iteration, same weights afterwards (bit-identical: same kernels, same order)."""
+    import numpy as np
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    from ctgan_amd.engine import GraphedDCGANTrainer
+    if which == 'cifar':
+        import ctgan_amd.gan_cifar as M
+        cfgkw = dict(DIM=32, BATCH_SIZE=8)
+    else:
+        import ctgan_amd.gan_lsun128 as M
+        cfgkw = dict(BATCH_SIZE=4, DIM_G_64=32, DIM_G_32=32, DIM_G_16=64, DIM_G_8=64, DIM_G_4=64, DIM_D_64=32, DIM_D_32=64, DIM_D_16=64, DIM_D_8=128)
+    nrng = np.random.default_rng(5)
+
+    def run(graphs):
+        lib.delete_all_params(); lib.set_device(None); lib.set_seed(3)
+        M.configure(**cfgkw)
+        B = M.cfg.BATCH_SIZE
+        if hasattr(M, 'build_params'):
+            M.build_params('cuda')
+        else:
+            with torch.no_grad():
+                M.Discriminator(M.Generator(2, noise=torch.zeros(2, 128, device='cuda')), u=[torch.ones(2, *s, device='cuda') for s in M.feat_shapes()])
+        tr = DCGANTrainer(M, seed=11)
+        eng = GraphedDCGANTrainer(tr, (B, M.cfg.OUTPUT_DIM), torch.int32, use_graphs=graphs)
+        assert eng.graphed == graphs, eng.graph_error
+        k = [0]
+
+        def nb():
+            k[0] += 1
+            return batches[k[0] % len(batches)]
+        recs = []
+        for it in range(3):
+            out = eng.train_iteration(it, nb)
+            recs.append({n: float(out[n].item()) for n in ('cost', 'wgan_only', 'ct', 'gp')})
+        return recs, tr.d_opt.theta.clone(), tr.g_opt.theta.clone(), int(tr.rng.ctr.item())
+    try:
+        K.set_mma_dtype(dtype)
+        M.configure(**cfgkw)
+        batches = [torch.from_numpy(nrng.integers(0, 256, (M.cfg.BATCH_SIZE, M.cfg.OUTPUT_DIM), dtype=np.int32)).cuda() for _ in range(4)]
+        g = run(True)
+        e = run(False)
+        assert g[3] == e[3] == 3 * M.cfg.CRITIC_ITERS + 2
+        for a, b in zip(g[0], e[0]):
+            for n in a:
+                assert abs(a[n]) < 1e4 and abs(a[n] - b[n]) <= 1e-5 * max(1.0, abs(b[n])), (n, a, b)
+        assert torch.equal(g[1], e[1]) and torch.equal(g[2], e[2])
+    finally:
+        K.set_mma_dtype(None)
+        M.configure(); lib.delete_all_params()
