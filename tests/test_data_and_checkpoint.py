@@ -96,3 +96,30 @@ def test_checkpoint_roundtrip(cpu_kernels, tmp_path):
         assert tr.d_params[0].data_ptr() == tr.d_opt.theta.data_ptr()     # still views into the flat buffer
     finally:
         R.configure()
+
+
+def test_inception_score_statistic():
+    """tflib.inception_score: the score formula on known distributions - uniform predictions score 1, one-hot
+    predictions spread evenly over k classes score k; the classifier is an argument (no Inception weights offline)."""
+    from ctgan_amd.tflib import inception_score as isc
+    rng = np.random.default_rng(0)
+    n, k = 1000, 10
+    m, s = isc.score_from_probabilities(np.full((n, k), 1.0 / k))
+    assert abs(m - 1.0) < 1e-12 and s < 1e-12
+    onehot = np.full((n, k), 1e-12); onehot[np.arange(n), np.arange(n) % k] = 1.0
+    onehot /= onehot.sum(1, keepdims=True)
+    m, s = isc.score_from_probabilities(onehot)
+    assert abs(m - k) < 1e-6
+    p = rng.dirichlet(np.ones(k), size=n)
+    ref = []
+    for i in range(10):                      # the statistic written out independently
+        part = p[i * n // 10:(i + 1) * n // 10]
+        py = part.mean(0)
+        ref.append(np.exp(np.mean([(row * np.log(row / py)).sum() for row in part])))
+    m, s = isc.score_from_probabilities(p, 10)
+    assert abs(m - np.mean(ref)) < 1e-12 and abs(s - np.std(ref)) < 1e-12
+    imgs = [rng.integers(0, 256, (32, 32, 3)).astype(np.float64) for _ in range(250)]
+    m2, _ = isc.get_inception_score(imgs, splits=5, classifier=lambda b: np.full((b.shape[0], k), 1.0 / k))
+    assert abs(m2 - 1.0) < 1e-12
+    with pytest.raises(RuntimeError):
+        isc.get_inception_score(imgs)
