@@ -94,9 +94,9 @@ SIGNATURES = {
     'ctgan_conv2d16_wgrad': (c_int, [_D, c_int, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_layernorm_supported': (c_int, [c_int64, c_int32]),
     'ctgan_layernorm_workspace_bytes': (c_size_t, [c_int32, c_int64, c_int32]),
-    'ctgan_layernorm_fwd': (c_int, [_p, _p, _p, _p, _p, _p, c_int32, c_int64, c_int32, c_float, _p, c_size_t, _p]),
-    'ctgan_layernorm_bwd': (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, c_int32, c_int64, c_int32, _p, c_size_t, _p]),
-    'ctgan_layernorm_bwd2': (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, c_int32, c_int64, c_int32, _p, c_size_t, _p]),
+    'ctgan_layernorm_fwd': (c_int, [_p, _p, _p, _p, _p, _p, c_int32, c_int64, c_int32, c_float, c_int32, _p, c_size_t, _p]),
+    'ctgan_layernorm_bwd': (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, c_int32, c_int64, c_int32, _p, c_size_t, _p]),
+    'ctgan_layernorm_bwd2': (c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int32, c_int64, c_int32, _p, c_size_t, _p]),
     'ctgan_im2col': (c_int, [_D, _p, c_int32, _p, _p]),
     'ctgan_col2im': (c_int, [_D, _p, c_int32, _p, _p]),
     'ctgan_colsum': (c_int, [_p, c_int64, c_int32, c_int64, _p, _p, c_size_t, _p]),

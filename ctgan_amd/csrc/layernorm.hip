@@ -3,7 +3,8 @@
 // TF/tflib/ops/layernorm.py:6-20 (LSUN copy: LS/tflib/ops/layernorm.py): per-sample moments over (C,H,W) (tf.nn.moments,
 // biased variance), y = (x - mean) * rsqrt(var + 1e-5) * scale[c] + offset[c].  The layer-normalised critics (config[4],
 // the 64x64 GoodDiscriminator) are differentiated TWICE through it by the gradient penalty, so three maps are needed:
-//   fwd : y  = xh * scale + offset,                     xh = (x - mean) * r,  r = rsqrt(var + eps)
+//   fwd : y  = xh * scale + offset [then ReLU: `relu`; the backward maps then take y as `ymask` and treat gy as gy * (y > 0)],
+//                                                       xh = (x - mean) * r,  r = rsqrt(var + eps)
 //   bwd : gx = r * (g - mean(g) - xh * mean(g * xh)),   g = gy * scale;  gscale[c] = sum gy * xh,  goffset[c] = sum gy
 //   bwd2: the adjoint of bwd with respect to (gy, x, scale), given the cotangent u of gx.  bwd is linear and SYMMETRIC in g,
 //         so  cot_g = r * (u - mean(u) - xh * mean(u * xh)),  cot_gy = cot_g * scale,  cot_scale[c] = sum gy * cot_g;
@@ -39,7 +40,8 @@ __device__ __forceinline__ double block_sum(double v, double* red /* [NT/64] */)
 template <int MODE>
 __global__ __launch_bounds__(NT) void ln_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy, const float* __restrict__ u,
                                                         const float* __restrict__ scale, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, long long D, int C, double* __restrict__ part) {
+                                                        const float* __restrict__ rstd, const float* __restrict__ ymask, long long D, int C,
+                                                        double* __restrict__ part) {
     constexpr int NS = MODE == 2 ? 5 : 2;
     __shared__ double red[NT / 64];
     const int n = blockIdx.y, chunk = blockIdx.x;
@@ -61,7 +63,11 @@ __global__ __launch_bounds__(NT) void ln_partial_kernel(const float* __restrict_
         } else {
             const float4 gv = *reinterpret_cast<const float4*>(gs + e);
             const float4 sv = *reinterpret_cast<const float4*>(scale + (int)(e % C));
-            const float ga[4] = {gv.x * sv.x, gv.y * sv.y, gv.z * sv.z, gv.w * sv.w};
+            float ga[4] = {gv.x * sv.x, gv.y * sv.y, gv.z * sv.z, gv.w * sv.w};
+            if (ymask) {                      // fused ReLU: the gradient only passes where the forward result is positive
+                const float4 yv = *reinterpret_cast<const float4*>(ymask + (long long)n * D + e);
+                ga[0] = yv.x > 0.f ? ga[0] : 0.f; ga[1] = yv.y > 0.f ? ga[1] : 0.f; ga[2] = yv.z > 0.f ? ga[2] : 0.f; ga[3] = yv.w > 0.f ? ga[3] : 0.f;
+            }
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const float xh = (xa[j] - mu) * r; s[0] += ga[j]; s[1] += ga[j] * xh; }
@@ -95,7 +101,7 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ part, i
 }
 
 __global__ __launch_bounds__(NT) void ln_fwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
-                                                          const double* __restrict__ part, long long D, int C, float eps,
+                                                          const double* __restrict__ part, long long D, int C, float eps, int relu,
                                                           float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     double t[2];
@@ -116,6 +122,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_apply_kernel(const float* __restric
         float4 o;
         o.x = (xv.x - mu) * r * sv.x + ov.x; o.y = (xv.y - mu) * r * sv.y + ov.y;
         o.z = (xv.z - mu) * r * sv.z + ov.z; o.w = (xv.w - mu) * r * sv.w + ov.w;
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         *reinterpret_cast<float4*>(ys + e) = o;
     }
 }
@@ -143,7 +150,7 @@ __device__ __forceinline__ void channel_rows(const float (&acc)[NV][4], int C, f
 }
 
 __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ ymask,
                                                           const double* __restrict__ part, long long D, int C, float* __restrict__ gx,
                                                           float* __restrict__ rows /* [2][N*chunks][C] or null */) {
     __shared__ float lds[2 * NT * 4];
@@ -161,7 +168,12 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restric
         const float4 xv = *reinterpret_cast<const float4*>(xs + e);
         const float4 gv = *reinterpret_cast<const float4*>(gs + e);
         const float4 sv = *reinterpret_cast<const float4*>(scale + (int)(e % C));
-        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, gya[4] = {gv.x, gv.y, gv.z, gv.w}, sa[4] = {sv.x, sv.y, sv.z, sv.w};
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, sa[4] = {sv.x, sv.y, sv.z, sv.w};
+        float gya[4] = {gv.x, gv.y, gv.z, gv.w};
+        if (ymask) {
+            const float4 yv = *reinterpret_cast<const float4*>(ymask + (long long)n * D + e);
+            gya[0] = yv.x > 0.f ? gya[0] : 0.f; gya[1] = yv.y > 0.f ? gya[1] : 0.f; gya[2] = yv.z > 0.f ? gya[2] : 0.f; gya[3] = yv.w > 0.f ? gya[3] : 0.f;
+        }
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -176,7 +188,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const float* __restric
 
 __global__ __launch_bounds__(NT) void ln_bwd2_apply_kernel(const float* __restrict__ u, const float* __restrict__ gy, const float* __restrict__ x,
                                                            const float* __restrict__ scale, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const double* __restrict__ part, long long D, int C,
+                                                           const float* __restrict__ rstd, const float* __restrict__ ymask,
+                                                           const double* __restrict__ part, long long D, int C,
                                                            float* __restrict__ cot_gy, float* __restrict__ cot_x,
                                                            float* __restrict__ rows /* [1][N*chunks][C] or null */) {
     __shared__ float lds[NT * 4];
@@ -198,14 +211,21 @@ __global__ __launch_bounds__(NT) void ln_bwd2_apply_kernel(const float* __restri
         const float4 gv = *reinterpret_cast<const float4*>(gs + e);
         const float4 uv = *reinterpret_cast<const float4*>(us + e);
         const float4 sv = *reinterpret_cast<const float4*>(scale + (int)(e % C));
-        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, gya[4] = {gv.x, gv.y, gv.z, gv.w}, ua[4] = {uv.x, uv.y, uv.z, uv.w}, sa[4] = {sv.x, sv.y, sv.z, sv.w};
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, ua[4] = {uv.x, uv.y, uv.z, uv.w}, sa[4] = {sv.x, sv.y, sv.z, sv.w};
+        float gya[4] = {gv.x, gv.y, gv.z, gv.w}, mk[4] = {1.f, 1.f, 1.f, 1.f};
+        if (ymask) {
+            const float4 yv = *reinterpret_cast<const float4*>(ymask + (long long)n * D + e);
+            mk[0] = yv.x > 0.f ? 1.f : 0.f; mk[1] = yv.y > 0.f ? 1.f : 0.f; mk[2] = yv.z > 0.f ? 1.f : 0.f; mk[3] = yv.w > 0.f ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gya[j] *= mk[j];
+        }
         float og[4], ox[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float xh = (xa[j] - mu) * r;
             const float g = gya[j] * sa[j];
             const float cg = r * (ua[j] - mu_u - xh * m);
-            og[j] = cg * sa[j];
+            og[j] = cg * sa[j] * mk[j];
             acc[0][j] += gya[j] * cg;
             const float q = -r * (b * ua[j] + m * g);
             ox[j] = r * (q - mean_q) - xh * k_xh;
@@ -260,20 +280,21 @@ size_t ctgan_layernorm_workspace_bytes(int32_t N, int64_t D, int32_t C) {
 }
 
 int ctgan_layernorm_fwd(const float* x, const float* scale, const float* offset, float* y, float* mean, float* rstd, int32_t N,
-                        int64_t D, int32_t C, float eps, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+                        int64_t D, int32_t C, float eps, int32_t relu, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     if (!x || !scale || !offset || !y || !mean || !rstd || N <= 0) return ctgan_fail(CTGAN_E_BADARG, "layernorm_fwd: bad argument");
     if (!ln_ok(D, C)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "layernorm_fwd: D=%lld C=%d outside the fused kernels", (long long)D, C);
     if (ws_bytes < ctgan_layernorm_workspace_bytes(N, D, C)) return ctgan_fail(CTGAN_E_BADARG, "layernorm_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(chunks_of(D), N);
     double* part = (double*)ws;
-    hipLaunchKernelGGL(ln_partial_kernel<0>, grid, dim3(NT), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, (long long)D, C, part);
-    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(NT), 0, st, x, scale, offset, part, (long long)D, C, eps, y, mean, rstd);
+    hipLaunchKernelGGL(ln_partial_kernel<0>, grid, dim3(NT), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (long long)D, C, part);
+    hipLaunchKernelGGL(ln_fwd_apply_kernel, grid, dim3(NT), 0, st, x, scale, offset, part, (long long)D, C, eps, (int)relu, y, mean, rstd);
     return ctgan_check_launch("layernorm_fwd");
 }
 
-int ctgan_layernorm_bwd(const float* gy, const float* x, const float* scale, const float* mean, const float* rstd, float* gx,
-                        float* gscale, float* goffset, int32_t N, int64_t D, int32_t C, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+int ctgan_layernorm_bwd(const float* gy, const float* x, const float* scale, const float* mean, const float* rstd, const float* ymask,
+                        float* gx, float* gscale, float* goffset, int32_t N, int64_t D, int32_t C, void* ws, size_t ws_bytes,
+                        ctgan_stream_t stream) {
     if (!gy || !x || !scale || !mean || !rstd || !gx || N <= 0 || (!gscale) != (!goffset)) return ctgan_fail(CTGAN_E_BADARG, "layernorm_bwd: bad argument");
     if (!ln_ok(D, C)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "layernorm_bwd: D=%lld C=%d outside the fused kernels", (long long)D, C);
     if (ws_bytes < ctgan_layernorm_workspace_bytes(N, D, C)) return ctgan_fail(CTGAN_E_BADARG, "layernorm_bwd: workspace too small");
@@ -282,15 +303,15 @@ int ctgan_layernorm_bwd(const float* gy, const float* x, const float* scale, con
     const dim3 grid(ch, N);
     double* part = (double*)ws;
     float* rows = gscale ? (float*)(part + (size_t)N * ch * 5) : nullptr;
-    hipLaunchKernelGGL(ln_partial_kernel<1>, grid, dim3(NT), 0, st, x, gy, nullptr, scale, mean, rstd, (long long)D, C, part);
-    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(NT), 0, st, gy, x, scale, mean, rstd, part, (long long)D, C, gx, rows);
+    hipLaunchKernelGGL(ln_partial_kernel<1>, grid, dim3(NT), 0, st, x, gy, nullptr, scale, mean, rstd, ymask, (long long)D, C, part);
+    hipLaunchKernelGGL(ln_bwd_apply_kernel, grid, dim3(NT), 0, st, gy, x, scale, mean, rstd, ymask, part, (long long)D, C, gx, rows);
     if (rows) hipLaunchKernelGGL(ln_rows_reduce_kernel, dim3((C + RC - 1) / RC, 2), dim3(RC * RLN), 0, st, rows, (long long)N * ch, C, gscale, goffset);
     return ctgan_check_launch("layernorm_bwd");
 }
 
 int ctgan_layernorm_bwd2(const float* u, const float* gy, const float* x, const float* scale, const float* mean, const float* rstd,
-                         float* cot_gy, float* cot_x, float* cot_scale, int32_t N, int64_t D, int32_t C, void* ws, size_t ws_bytes,
-                         ctgan_stream_t stream) {
+                         const float* ymask, float* cot_gy, float* cot_x, float* cot_scale, int32_t N, int64_t D, int32_t C, void* ws,
+                         size_t ws_bytes, ctgan_stream_t stream) {
     if (!u || !gy || !x || !scale || !mean || !rstd || N <= 0) return ctgan_fail(CTGAN_E_BADARG, "layernorm_bwd2: bad argument");
     if (!ln_ok(D, C)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "layernorm_bwd2: D=%lld C=%d outside the fused kernels", (long long)D, C);
     if (ws_bytes < ctgan_layernorm_workspace_bytes(N, D, C)) return ctgan_fail(CTGAN_E_BADARG, "layernorm_bwd2: workspace too small");
@@ -299,8 +320,8 @@ int ctgan_layernorm_bwd2(const float* u, const float* gy, const float* x, const 
     const dim3 grid(ch, N);
     double* part = (double*)ws;
     float* rows = cot_scale ? (float*)(part + (size_t)N * ch * 5) : nullptr;
-    hipLaunchKernelGGL(ln_partial_kernel<2>, grid, dim3(NT), 0, st, x, gy, u, scale, mean, rstd, (long long)D, C, part);
-    hipLaunchKernelGGL(ln_bwd2_apply_kernel, grid, dim3(NT), 0, st, u, gy, x, scale, mean, rstd, part, (long long)D, C, cot_gy, cot_x, rows);
+    hipLaunchKernelGGL(ln_partial_kernel<2>, grid, dim3(NT), 0, st, x, gy, u, scale, mean, rstd, ymask, (long long)D, C, part);
+    hipLaunchKernelGGL(ln_bwd2_apply_kernel, grid, dim3(NT), 0, st, u, gy, x, scale, mean, rstd, ymask, part, (long long)D, C, cot_gy, cot_x, rows);
     if (rows) hipLaunchKernelGGL(ln_rows_reduce_kernel, dim3((C + RC - 1) / RC, 1), dim3(RC * RLN), 0, st, rows, (long long)N * ch, C, cot_scale, cot_scale);
     return ctgan_check_launch("layernorm_bwd2");
 }

@@ -1168,36 +1168,42 @@ LN_FUSED = _os.environ.get('CTGAN_LN_FUSED', '1') != '0'
 
 
 class LayerNormFn(Function):
-    """y = Layernorm(x) * scale + offset with fused forward / backward / double-backward kernels.  The backward is itself a
-    Function (LayerNormBwdFn) whose backward is the bwd2 kernel: the gradient penalty differentiates the critic twice."""
+    """y = [relu](Layernorm(x) * scale + offset) with fused forward / backward / double-backward kernels.  The backward is itself a
+    Function (LayerNormBwdFn) whose backward is the bwd2 kernel: the gradient penalty differentiates the critic twice.  With
+    relu the result doubles as the mask of the backward maps (y > 0): no separate ReLU / ReLU-backward passes."""
 
     @staticmethod
-    def forward(ctx, x, scale, offset, eps):
-        y, mean, rstd = K.layernorm_fwd(x, scale, offset, eps)
-        ctx.save_for_backward(x, scale, mean, rstd)
+    def forward(ctx, x, scale, offset, eps, relu):
+        y, mean, rstd = K.layernorm_fwd(x, scale, offset, eps, relu)
+        ctx.relu = bool(relu)
+        if relu:
+            ctx.save_for_backward(x, scale, mean, rstd, y)
+        else:
+            ctx.save_for_backward(x, scale, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, scale, mean, rstd = ctx.saved_tensors
-        want_params = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and _WEIGHT_GRADS_LN()
+        x, scale, mean, rstd = ctx.saved_tensors[:4]
+        ymask = ctx.saved_tensors[4].detach() if ctx.relu else None       # a constant of every derivative order
+        want_params = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         if want_params:
-            gx, gs, go = LayerNormBwdFn.apply(gy, x, scale, mean, rstd, True)
-            return gx, gs, go, None
-        return LayerNormBwdFn.apply(gy, x, scale, mean, rstd, False), None, None, None
-
-
-def _WEIGHT_GRADS_LN():
-    return True      # a normalised critic is not piecewise linear: its forward always records parameter gradients (weight_grads(True))
+            gx, gs, go = LayerNormBwdFn.apply(gy, x, scale, mean, rstd, ymask, True)
+            return gx, gs, go, None, None
+        return LayerNormBwdFn.apply(gy, x, scale, mean, rstd, ymask, False), None, None, None, None
 
 
 class LayerNormBwdFn(Function):
     """(gy, x, scale) -> gx [, gscale, goffset]; mean / rstd are functions of x that the bwd2 formula differentiates through."""
 
     @staticmethod
-    def forward(ctx, gy, x, scale, mean, rstd, want_params):
-        gx, gs, go = K.layernorm_bwd(gy, x, scale, mean, rstd, want_params)
-        ctx.save_for_backward(gy, x, scale, mean, rstd)
+    def forward(ctx, gy, x, scale, mean, rstd, ymask, want_params):
+        gx, gs, go = K.layernorm_bwd(gy, x, scale, mean, rstd, want_params, ymask)
+        ctx.has_mask = ymask is not None
+        if ymask is not None:
+            ctx.save_for_backward(gy, x, scale, mean, rstd, ymask)
+        else:
+            ctx.save_for_backward(gy, x, scale, mean, rstd)
         ctx.set_materialize_grads(False)
         if want_params:
             return gx, gs, go
@@ -1208,23 +1214,26 @@ class LayerNormBwdFn(Function):
         if u_s is not None or u_o is not None:
             raise NotImplementedError('derivatives of the Layernorm parameter gradients (third order) are not used by any loss')
         if u is None:
-            return None, None, None, None, None, None
-        gy, x, scale, mean, rstd = ctx.saved_tensors
+            return None, None, None, None, None, None, None
         if torch.is_grad_enabled():
             raise NotImplementedError('third-order derivatives through Layernorm')
-        cg, cx, cs = K.layernorm_bwd2(u, gy, x, scale, mean, rstd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
-        return cg, cx, cs, None, None, None
+        gy, x, scale, mean, rstd = ctx.saved_tensors[:5]
+        ymask = ctx.saved_tensors[5] if ctx.has_mask else None
+        cg, cx, cs = K.layernorm_bwd2(u, gy, x, scale, mean, rstd, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ymask)
+        return cg, cx, cs, None, None, None, None
 
 
-def layer_norm(x, scale, offset, eps=1e-5):
-    """Per-sample normalisation over all non-batch axes, then per-channel scale / offset (TF/tflib/ops/layernorm.py)."""
+def layer_norm(x, scale, offset, eps=1e-5, relu=False):
+    """Per-sample normalisation over all non-batch axes, then per-channel scale / offset (TF/tflib/ops/layernorm.py);
+    relu=True also applies the nonlinearity that follows it in the critics' blocks (fused kernels: same pass)."""
     if x.dim() == 4 and not x.permute(0, 2, 3, 1).is_contiguous():
         x = to_channels_last(x)
     elif x.dim() == 2:
         x = x.contiguous()
     if LN_FUSED and K.layernorm_supported(x):
-        return LayerNormFn.apply(x, scale, offset, float(eps))
-    return layer_norm_composed(x, scale, offset, eps)
+        return LayerNormFn.apply(x, scale, offset, float(eps), bool(relu))
+    y = layer_norm_composed(x, scale, offset, eps)
+    return globals()['relu'](y) if relu else y
 
 
 def layer_norm_composed(x, scale, offset, eps=1e-5):

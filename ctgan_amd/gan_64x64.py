@@ -58,8 +58,7 @@ def Normalize(name, axes, inputs, relu=False):
     if ('Discriminator' in name) and (cfg.MODE == 'wgan-ct'):
         if axes != [0, 2, 3]:
             raise Exception('Layernorm over non-standard axes is unsupported')
-        out = _ln.Layernorm(name, [1, 2, 3], inputs)
-        return F.relu(out) if relu else out
+        return _ln.Layernorm(name, [1, 2, 3], inputs, relu=relu)      # ReLU fused into the Layernorm kernels
     return _bn.Batchnorm(name, axes, inputs, fused=True, relu=relu)
 
 

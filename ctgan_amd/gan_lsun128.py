@@ -74,8 +74,7 @@ def nonlinearity(x):
 def Normalize(name, inputs, groups=1, relu=False):
     """:70-74"""
     if ('Discriminator' in name) and cfg.NORMALIZATION_D:
-        out = _ln.Layernorm(name, [1, 2, 3], inputs)
-        return F.relu(out) if relu else out
+        return _ln.Layernorm(name, [1, 2, 3], inputs, relu=relu)      # ReLU fused into the Layernorm kernels
     if ('Generator' in name) and cfg.NORMALIZATION_G:
         return _bn.Batchnorm(name, [0, 2, 3], inputs, fused=True, groups=groups, relu=relu)
     return F.relu(inputs) if relu else inputs        # (the reference returns None here; never reached with both flags on)

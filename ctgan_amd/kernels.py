@@ -781,43 +781,43 @@ def _ln_ws(N, D, C, dev):
     return workspace(lib.ctgan_layernorm_workspace_bytes(N, D, C), dev)
 
 
-def layernorm_fwd(x, scale, offset, eps):
-    """-> (y, mean [N], rstd [N])   (TF/tflib/ops/layernorm.py:6-20)"""
+def layernorm_fwd(x, scale, offset, eps, relu=False):
+    """-> (y, mean [N], rstd [N])   (TF/tflib/ops/layernorm.py:6-20); relu: y = relu(Layernorm(x)) in the same pass"""
     _need_dev(x, scale, offset)
     N, D, C = _ln_dims(x)
     y = _ew_out(x)
     mean = torch.empty(N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(N, dtype=torch.float32, device=x.device)
     ws = _ln_ws(N, D, C, x.device)
-    check(lib.ctgan_layernorm_fwd(_ptr(x), _ptr(scale), _ptr(offset), _ptr(y), _ptr(mean), _ptr(rstd), N, D, C, float(eps), _ptr(ws), ws.numel(),
-                                  _stream()), 'layernorm_fwd')
+    check(lib.ctgan_layernorm_fwd(_ptr(x), _ptr(scale), _ptr(offset), _ptr(y), _ptr(mean), _ptr(rstd), N, D, C, float(eps), 1 if relu else 0, _ptr(ws),
+                                  ws.numel(), _stream()), 'layernorm_fwd')
     return y, mean, rstd
 
 
-def layernorm_bwd(gy, x, scale, mean, rstd, want_params):
-    """-> (gx, gscale | None, goffset | None)"""
-    _need_dev(gy, x, scale, mean, rstd)
+def layernorm_bwd(gy, x, scale, mean, rstd, want_params, ymask=None):
+    """-> (gx, gscale | None, goffset | None); ymask = the fused-ReLU forward result (gy counts where it is positive)"""
+    _need_dev(gy, x, scale, mean, rstd, ymask)
     N, D, C = _ln_dims(x)
     gy = match_layout(gy, x)
     gx = _ew_out(x)
     gs = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
     go = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
     ws = _ln_ws(N, D, C, x.device)
-    check(lib.ctgan_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(gx), _ptr(gs), _ptr(go), N, D, C, _ptr(ws), ws.numel(),
+    check(lib.ctgan_layernorm_bwd(_ptr(gy), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(ymask), _ptr(gx), _ptr(gs), _ptr(go), N, D, C, _ptr(ws), ws.numel(),
                                   _stream()), 'layernorm_bwd')
     return gx, gs, go
 
 
-def layernorm_bwd2(u, gy, x, scale, mean, rstd, want_gy=True, want_x=True, want_scale=True):
+def layernorm_bwd2(u, gy, x, scale, mean, rstd, want_gy=True, want_x=True, want_scale=True, ymask=None):
     """Adjoint of layernorm_bwd: cotangent u of gx -> (cot_gy, cot_x, cot_scale), None where not wanted."""
-    _need_dev(u, gy, x, scale, mean, rstd)
+    _need_dev(u, gy, x, scale, mean, rstd, ymask)
     N, D, C = _ln_dims(x)
     u, gy = match_layout(u, x), match_layout(gy, x)
     cg = _ew_out(x) if want_gy else None
     cx = _ew_out(x) if want_x else None
     cs = torch.empty(C, dtype=torch.float32, device=x.device) if want_scale else None
     ws = _ln_ws(N, D, C, x.device)
-    check(lib.ctgan_layernorm_bwd2(_ptr(u), _ptr(gy), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(cg), _ptr(cx), _ptr(cs), N, D, C, _ptr(ws),
+    check(lib.ctgan_layernorm_bwd2(_ptr(u), _ptr(gy), _ptr(x), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(ymask), _ptr(cg), _ptr(cx), _ptr(cs), N, D, C, _ptr(ws),
                                    ws.numel(), _stream()), 'layernorm_bwd2')
     return cg, cx, cs
 

@@ -10,9 +10,10 @@ from ... import functional as F
 from .. import param as _param
 
 
-def Layernorm(name, norm_axes, inputs):
+def Layernorm(name, norm_axes, inputs, relu=False):
     """inputs [N,C,H,W] (norm_axes [1,2,3]) or [N,C] (norm_axes [1]): per-sample moments over norm_axes, then
-    `name.scale` / `name.offset` of size C (the first normalised axis, :10-13), eps 1e-5."""
+    `name.scale` / `name.offset` of size C (the first normalised axis, :10-13), eps 1e-5.  `relu` (build-only): also apply the
+    ReLU that follows the normalisation in the critics' blocks, in the same kernels."""
     norm_axes = list(norm_axes)
     if norm_axes != list(range(1, inputs.dim())):
         raise NotImplementedError('Layernorm over axes %s of a %d-D tensor (the CT scripts use all non-batch axes)'
@@ -20,4 +21,4 @@ def Layernorm(name, norm_axes, inputs):
     n_neurons = inputs.shape[norm_axes[0]]
     offset = _param(name + '.offset', lambda rng: np.zeros(n_neurons, dtype='float32'))
     scale = _param(name + '.scale', lambda rng: np.ones(n_neurons, dtype='float32'))
-    return F.layer_norm(inputs, scale, offset, 1e-5)
+    return F.layer_norm(inputs, scale, offset, 1e-5, relu=relu)

@@ -157,14 +157,16 @@ int ctgan_conv2d_repack_filter(const ctgan_conv_desc* d, const float* w, float* 
  * ctgan_layernorm_workspace_bytes(N, D, C) bytes.                                                                       */
 int ctgan_layernorm_supported(int64_t D, int32_t C);
 size_t ctgan_layernorm_workspace_bytes(int32_t N, int64_t D, int32_t C);
+/* relu != 0: y = relu(Layernorm(x)) (the critics' Normalize -> nonlinearity, LS/wgan_LSUN_Bedrooms128.py:122-128) in the same
+ * pass; the backward maps then take that y as `ymask` (NULL = no fused ReLU) and read gy as gy * (y > 0).                   */
 int ctgan_layernorm_fwd(const float* x, const float* scale, const float* offset, float* y, float* mean, float* rstd, int32_t N,
-                        int64_t D, int32_t C, float eps, void* ws, size_t ws_bytes, ctgan_stream_t stream);
-int ctgan_layernorm_bwd(const float* gy, const float* x, const float* scale, const float* mean, const float* rstd, float* gx,
-                        float* gscale, float* goffset, int32_t N, int64_t D, int32_t C, void* ws, size_t ws_bytes,
-                        ctgan_stream_t stream);
+                        int64_t D, int32_t C, float eps, int32_t relu, void* ws, size_t ws_bytes, ctgan_stream_t stream);
+int ctgan_layernorm_bwd(const float* gy, const float* x, const float* scale, const float* mean, const float* rstd,
+                        const float* ymask, float* gx, float* gscale, float* goffset, int32_t N, int64_t D, int32_t C, void* ws,
+                        size_t ws_bytes, ctgan_stream_t stream);
 int ctgan_layernorm_bwd2(const float* u, const float* gy, const float* x, const float* scale, const float* mean,
-                         const float* rstd, float* cot_gy, float* cot_x, float* cot_scale, int32_t N, int64_t D, int32_t C,
-                         void* ws, size_t ws_bytes, ctgan_stream_t stream);
+                         const float* rstd, const float* ymask, float* cot_gy, float* cot_x, float* cot_scale, int32_t N,
+                         int64_t D, int32_t C, void* ws, size_t ws_bytes, ctgan_stream_t stream);
 /* ---- 16-bit matrix-core family (csrc/igemm16.hip): BASELINE.json configs[1] "bf16" and configs[4] "fp16 MFMA conv" ----
  * The same three operators (tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112, tf.nn.conv2d_transpose / the data gradient
  * TF/tflib/ops/deconv2d.py:91-103, the filter gradient tf.gradients derives) computed as mixed precision: operands rounded

@@ -362,7 +362,7 @@ def _ln_parts(x, scale, mean, rstd):
 
 
 @_export
-def layernorm_fwd(x, scale, offset, eps):
+def layernorm_fwd(x, scale, offset, eps, relu=False):
     dims = tuple(range(1, x.dim()))
     xd = x.double()
     mean = xd.mean(dim=dims)
@@ -370,12 +370,16 @@ def layernorm_fwd(x, scale, offset, eps):
     rstd = 1.0 / torch.sqrt(var + eps)
     xh, s, shp, _, _ = _ln_parts(x, scale, mean, rstd)
     y = xh * s + offset.double().reshape([1, -1] + [1] * (x.dim() - 2))
+    if relu:
+        y = torch.relu(y)
     return _like(y.float(), x), mean.float(), rstd.float()
 
 
 @_export
-def layernorm_bwd(gy, x, scale, mean, rstd, want_params):
+def layernorm_bwd(gy, x, scale, mean, rstd, want_params, ymask=None):
     xh, s, shp, sd, cd = _ln_parts(x, scale, mean, rstd)
+    if ymask is not None:
+        gy = gy * (ymask > 0).to(gy.dtype)
     g = gy.double() * s
     a = g.mean(dim=sd, keepdim=True); b = (g * xh).mean(dim=sd, keepdim=True)
     gx = rstd.double().reshape(shp) * (g - a - xh * b)
@@ -385,7 +389,7 @@ def layernorm_bwd(gy, x, scale, mean, rstd, want_params):
 
 
 @_export
-def layernorm_bwd2(u, gy, x, scale, mean, rstd, want_gy=True, want_x=True, want_scale=True):
+def layernorm_bwd2(u, gy, x, scale, mean, rstd, want_gy=True, want_x=True, want_scale=True, ymask=None):
     # autograd through the double-precision restatement of layernorm_bwd as a function of (gy, x, scale)
     dims = tuple(range(1, x.dim()))
     cshp = [1, -1] + [1] * (x.dim() - 2)
@@ -396,6 +400,8 @@ def layernorm_bwd2(u, gy, x, scale, mean, rstd, want_gy=True, want_x=True, want_
         r = 1.0 / torch.sqrt(x_.var(dim=dims, unbiased=False, keepdim=True) + eps)
         xh = (x_ - m) * r
         g = gy_ * s_.reshape(cshp)
+        if ymask is not None:
+            g = g * (ymask > 0).double()
         gx = r * (g - g.mean(dim=dims, keepdim=True) - xh * (g * xh).mean(dim=dims, keepdim=True))
         cg, cx, cs = torch.autograd.grad(gx, [gy_, x_, s_], u.double())
     return (_like(cg.float(), x) if want_gy else None, _like(cx.float(), x) if want_x else None, cs.float() if want_scale else None)

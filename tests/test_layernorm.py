@@ -13,7 +13,7 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def _check(lib, dev, shape, tol):
+def _check(lib, dev, shape, tol, relu=False):
     from ctgan_amd.tflib.ops import layernorm as ln
     g = torch.Generator().manual_seed(3)
     x = torch.randn(*shape, generator=g) * 1.7 + 0.3
@@ -21,12 +21,14 @@ def _check(lib, dev, shape, tol):
     lib.param('L.scale', (torch.rand(C, generator=g) + 0.5).numpy())
     lib.param('L.offset', torch.randn(C, generator=g).numpy())
     xd = x.to(dev).requires_grad_(True)
-    y = ln.Layernorm('L', list(range(1, len(shape))), xd)
+    y = ln.Layernorm('L', list(range(1, len(shape))), xd, relu=relu)
     reg = oref.Registry(dtype=torch.float64)
     for n in ('L.scale', 'L.offset'):
         reg[n] = lib._params[n].detach().cpu().double().requires_grad_(True)
     xr = x.double().requires_grad_(True)
     yr = oref.Layernorm(reg, 'L', list(range(1, len(shape))), xr)
+    if relu:
+        yr = torch.relu(yr)          # Normalize -> nonlinearity of the critics' blocks, fused into the Layernorm kernels
     assert tuple(y.shape) == tuple(yr.shape) and _rel(y.cpu(), yr) < tol
     sc, of = lib._params['L.scale'], lib._params['L.offset']
     gy = torch.randn(*shape, generator=g)
@@ -48,18 +50,20 @@ def _check(lib, dev, shape, tol):
         assert _rel(a.cpu(), b) < 20 * tol
 
 
+@pytest.mark.parametrize('relu', [False, True])
 @pytest.mark.parametrize('shape', [(5, 8, 4, 4), (3, 16, 8, 8), (7, 24)])
-def test_layernorm_values_gradients_and_double_backward(cpu_kernels, shape):
+def test_layernorm_values_gradients_and_double_backward(cpu_kernels, shape, relu):
     import ctgan_amd.tflib as lib
-    _check(lib, 'cpu', shape, 2e-5)
+    _check(lib, 'cpu', shape, 2e-5, relu)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(6, 128, 8, 8), (3, 64, 16, 16), (9, 40), (2, 128, 32, 32), (3, 1024, 8, 8), (5, 256)])
-def test_layernorm_on_gpu(shape):
+@pytest.mark.parametrize('relu', [False, True])
+def test_layernorm_on_gpu(shape, relu):
     import ctgan_amd.tflib as lib
     lib.delete_all_params(); lib.set_device(None)
     try:
-        _check(lib, 'cuda', shape, 3e-5)
+        _check(lib, 'cuda', shape, 3e-5, relu)
     finally:
         lib.delete_all_params()
