@@ -15,6 +15,12 @@ from .optim import FlatAdam
 from .rng import DeviceRNG
 
 
+import os as _os
+# A/B switch: the two dropout passes over the real batch share the critic's layers before the first dropout (modules that expose
+# DiscriminatorTrunk / DiscriminatorTail: the layer-normalised ResNet critics, whose dropouts sit after the 16x16 blocks)
+TRUNK_SHARE = _os.environ.get('CTGAN_UNCOND_TRUNK_SHARE', '1') != '0'
+
+
 class DCGANTrainer:
     def __init__(self, module, seed=2024, rank=0, world_size=1, allreduce=None):
         """`module` = ctgan_amd.gan_cifar or ctgan_amd.gan_mnist (provides cfg, Generator, Discriminator,
@@ -47,12 +53,17 @@ class DCGANTrainer:
             real = m.real_prep(real_in)
             alpha = rnd['alpha'] if rnd is not None else self.rng.uniform(B, 1)
             interp = K.interpolate(real, fake, alpha)
-            x3 = torch.cat([real, real, fake], 0)
-        if rnd is not None:
-            u = [torch.cat([a, b, c], 0) for a, b, c in zip(rnd['u_real'], rnd['u_real_'], rnd['u_fake'])]
-            d, f = m.Discriminator(x3, u=u)
+        u = [torch.cat([a, b, c], 0) for a, b, c in zip(rnd['u_real'], rnd['u_real_'], rnd['u_fake'])] if rnd is not None else None
+        if TRUNK_SHARE and hasattr(m, 'DiscriminatorTrunk'):
+            # the critic's layers before its first dropout are deterministic and per-sample: the two dropout passes over the real
+            # batch share ONE evaluation of them - rows [real ; fake] through the trunk, rows [real, real, fake] through the tail
+            h = m.DiscriminatorTrunk(torch.cat([real, fake], 0))
+            h3 = F.rows_select(h, [(0, B), (0, B), (B, 2 * B)])
+            d, f = m.DiscriminatorTail(h3, u=u, rng=None if rnd is not None else self.rng)
         else:
-            d, f = m.Discriminator(x3, rng=self.rng)      # masks regenerated from the Philox stream inside the dropout kernels: no uniform tensors
+            x3 = torch.cat([real, real, fake], 0)
+            # masks regenerated from the Philox stream inside the dropout kernels when none are injected: no uniform tensors
+            d, f = m.Discriminator(x3, u=u) if rnd is not None else m.Discriminator(x3, rng=self.rng)
         wgan = F.mean_diff(d[B:], B, B, 0.0, 1.0) + F.mean_diff(d[:B], B, 0, -1.0, 0.0)   # mean(fake) - mean(real)
         ct = F.consistency_term(d[:B], d[B:2 * B], f[:B], f[B:2 * B], cfg.LAMBDA_2, cfg.Factor_M)
         interp.requires_grad_(True)

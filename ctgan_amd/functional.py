@@ -838,6 +838,51 @@ class RowsCatDropFn(Function):
         return K.rows_cat_bwd(g, n, n_extra), None, None, None, None, None
 
 
+class RowsSelectFn(Function):
+    """Concatenation of row ranges of x (ranges may repeat rows); adjoint = per-range accumulation into the rows."""
+
+    @staticmethod
+    def forward(ctx, x, ranges):
+        ctx.ranges, ctx.n = ranges, x.shape[0]
+        parts = [x[a:b] for a, b in ranges]
+        y = torch.cat(parts, 0)
+        if x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous() and not y.permute(0, 2, 3, 1).is_contiguous():
+            y = K.to_channels_last(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.dim() == 4 and not g.permute(0, 2, 3, 1).is_contiguous():
+            g = K.to_channels_last(g)
+        out = None
+        r0 = 0
+        pieces = []
+        for a, b in ctx.ranges:
+            pieces.append((a, b, g[r0:r0 + (b - a)]))
+            r0 += b - a
+        # rows covered once are copied, rows covered several times are summed (axpby kernel)
+        acc = {}
+        order = []
+        for a, b, piece in pieces:
+            if (a, b) in acc:
+                acc[(a, b)] = add(acc[(a, b)], piece) if torch.is_grad_enabled() else K.axpby(acc[(a, b)], piece, 1.0, 1.0)
+            else:
+                acc[(a, b)] = piece
+                order.append((a, b))
+        order.sort()
+        assert order[0][0] == 0 and order[-1][1] == ctx.n and all(order[i][1] == order[i + 1][0] for i in range(len(order) - 1)), \
+            'row ranges must tile the input (possibly repeated)'
+        gx = torch.cat([acc[k] for k in order], 0)
+        if g.dim() == 4 and not gx.permute(0, 2, 3, 1).is_contiguous():
+            gx = K.to_channels_last(gx)
+        return gx, None
+
+
+def rows_select(x, ranges):
+    """cat([x[a:b] for (a, b) in ranges]); the ranges must tile x's rows, repeats allowed (a shared trunk feeding several passes)."""
+    return RowsSelectFn.apply(x, tuple((int(a), int(b)) for a, b in ranges))
+
+
 def rows_cat_dropout(x, n_extra, spec):
     """spec = drop_spec(...): (keep, seed, site, ctr).  The consumer must apply the mask in its backward (in_drop=spec)."""
     return RowsCatDropFn.apply(x, int(n_extra), spec[0], spec[1], spec[2], spec[3])
