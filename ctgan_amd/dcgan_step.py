@@ -54,7 +54,7 @@ class DCGANTrainer:
             alpha = rnd['alpha'] if rnd is not None else self.rng.uniform(B, 1)
             interp = K.interpolate(real, fake, alpha)
         u = [torch.cat([a, b, c], 0) for a, b, c in zip(rnd['u_real'], rnd['u_real_'], rnd['u_fake'])] if rnd is not None else None
-        if TRUNK_SHARE and hasattr(m, 'DiscriminatorTrunk'):
+        if TRUNK_SHARE and hasattr(m, 'DiscriminatorTrunk') and getattr(m, 'critic_is_per_sample', lambda: True)():
             # the critic's layers before its first dropout are deterministic and per-sample: the two dropout passes over the real
             # batch share ONE evaluation of them - rows [real ; fake] through the trunk, rows [real, real, fake] through the tail
             h = m.DiscriminatorTrunk(torch.cat([real, fake], 0))

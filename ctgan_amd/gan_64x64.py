@@ -118,19 +118,30 @@ def Generator(n_samples, noise=None, rng=None):
     return out.reshape(-1, cfg.OUTPUT_DIM)
 
 
-def Discriminator(inputs, kp1=0.8, kp2=0.5, kp3=0.5, u=None, rng=None):
-    """GoodDiscriminator :357-373 -> (D [n], D_ [n, 4*4*8*DIM])."""
+def critic_is_per_sample():
+    """Layernorm (MODE 'wgan-ct') normalises each sample on its own; a batch-normalised critic couples the rows of a batch."""
+    return cfg.MODE == 'wgan-ct'
+
+
+def DiscriminatorTrunk(inputs):
+    """Input conv + Res1 + Res2: everything before the first dropout (:358-363); deterministic and per-sample, shared by the two
+    dropout passes over the real batch of a critic step (dcgan_step.DCGANTrainer.d_losses)."""
+    dim = cfg.DIM
+    out = inputs.reshape(-1, 3, 64, 64)
+    out = _conv2d.Conv2D('Discriminator.Input', 3, dim, 3, out, he_init=False)
+    out = ResidualBlock('Discriminator.Res1', dim, 2 * dim, 3, out, resample='down')
+    return ResidualBlock('Discriminator.Res2', 2 * dim, 4 * dim, 3, out, resample='down')
+
+
+def DiscriminatorTail(h, kp1=0.8, kp2=0.5, kp3=0.5, u=None, rng=None):
+    """dropout -> Res3 -> dropout -> Res4 -> dropout -> Linear (:364-373)."""
     dim = cfg.DIM
 
     def drop(i, x, kp):
         if kp == 1.0:
             return x
         return F.dropout(x, kp, u[i]) if u is not None else F.dropout(x, kp, rng=rng)
-    out = inputs.reshape(-1, 3, 64, 64)
-    out = _conv2d.Conv2D('Discriminator.Input', 3, dim, 3, out, he_init=False)
-    out = ResidualBlock('Discriminator.Res1', dim, 2 * dim, 3, out, resample='down')
-    out = ResidualBlock('Discriminator.Res2', 2 * dim, 4 * dim, 3, out, resample='down')
-    out = drop(0, out, kp1)
+    out = drop(0, h, kp1)
     out = ResidualBlock('Discriminator.Res3', 4 * dim, 8 * dim, 3, out, resample='down')
     out = drop(1, out, kp2)
     out = ResidualBlock('Discriminator.Res4', 8 * dim, 8 * dim, 3, out, resample='down')
@@ -138,6 +149,11 @@ def Discriminator(inputs, kp1=0.8, kp2=0.5, kp3=0.5, u=None, rng=None):
     output2 = F.to_nchw(out).reshape(-1, 4 * 4 * 8 * dim)
     out = _linear.Linear('Discriminator.Output', 4 * 4 * 8 * dim, 1, output2)
     return out.reshape(-1), output2
+
+
+def Discriminator(inputs, kp1=0.8, kp2=0.5, kp3=0.5, u=None, rng=None):
+    """GoodDiscriminator :357-373 -> (D [n], D_ [n, 4*4*8*DIM])."""
+    return DiscriminatorTail(DiscriminatorTrunk(inputs), kp1, kp2, kp3, u=u, rng=rng)
 
 
 def build_params(device=None):
