@@ -372,7 +372,7 @@ struct W16 {
     int pq_shift, q_shift;           // log2(P*Q), log2(Q) when both are powers of two, else -1: pixel -> (n,p,q) without integer division
 };
 
-template <int MMA, int TM, int TN, bool RELU_X>
+template <int MMA, int TM, int TN, bool RELU_X, bool SPLIT = (TM * TN >= 8)>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     // block tile: (2*TM*32) channels of ONE tap  x  (2*TN*32) kout, K slices of 64 pixels
     constexpr int NT = 256, BKP = 64;
@@ -385,7 +385,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     constexpr int XPG = XG >= 32 ? 8 : 16, YPG = YG >= 32 ? 8 : 16;      // pixel groups a wave's load instruction spans (see the staging map)
     constexpr int Y_PER = YG * (BKP / 4) / NT;
     static_assert(XG * (BKP / 4) % NT == 0 && YG * (BKP / 4) % NT == 0 && X_PER >= 1 && Y_PER >= 1, "tile / thread mismatch");
+    // SPLIT (the one-wave-per-SIMD tile): two DIFFERENT LDS objects for the two stages, see conv16_kernel
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    __shared__ __attribute__((aligned(16))) unsigned short stage0_static[SPLIT ? STAGE : 8];
+    unsigned short* const S0 = SPLIT ? stage0_static : smem;
+    unsigned short* const S1 = SPLIT ? smem : smem + STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
             const bool inr = pix < k_end;
             const int pc = inr ? pix : 0;
             int n, pp, qq;
-            if (p.pq_shift >= 0) {           // workgroup-uniform branch: the staging pass is VALU-bound on this address math
+            if (SPLIT || p.pq_shift >= 0) {  // (the wide tile is only planned for power-of-two grids: no branch inside its slice)
                 n = pc >> p.pq_shift;
                 const int rem = pc & (PQ - 1);
                 pp = rem >> p.q_shift; qq = rem & (p.Q - 1);
@@ -501,17 +505,8 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int h = lane >> 5, l31 = lane & 31;
-    if (nk > 0) {
-        load_slice(0);
-        store_slice(smem);
-        if (nk > 1) load_slice(1);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned short* Xs = smem + (kt & 1) * STAGE;
+    auto mma_slice = [&](const unsigned short* Xs) {
         const unsigned short* Ys = Xs + BMC * LDS_K;
-        if (kt + 1 < nk && !(p.dbg & 1)) store_slice(smem + ((kt + 1) & 1) * STAGE);
-        if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2);
 #pragma unroll
         for (int ks = 0; ks < BKP / 16; ++ks) {
             u32x4 fa[TM], fb[TN];
@@ -526,6 +521,38 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fa[i], fb[j], acc[i][j]);
         }
+    };
+    if (nk > 0) {
+        load_slice(0);
+        store_slice(S0);
+        if (nk > 1) load_slice(1);
+    }
+    __syncthreads();
+    int kt = 0;
+    if (SPLIT) {
+        // steady state, two slices per trip so that each names its LDS objects: stage slice kt+1, load slice kt+2, multiply slice
+        // kt - one basic block, woven by the scheduling groups (one wave per SIMD: nothing else fills the MFMA gaps)
+        auto slice = [&](unsigned short* wr, const unsigned short* rd, int k) {
+            store_slice(wr);
+            load_slice(k + 2);
+            mma_slice(rd);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+            for (int g = 0; g < TM * TN * (BKP / 16); ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // VALU (conversions, addresses, halo checks)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+            }
+            __syncthreads();
+        };
+        for (; kt + 3 < nk; kt += 2) { slice(S1, S0, kt); slice(S0, S1, kt + 1); }
+    }
+    for (; kt < nk; ++kt) {
+        if (kt + 1 < nk && !(p.dbg & 1)) store_slice((kt + 1) & 1 ? S1 : S0);
+        if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2);
+        mma_slice(kt & 1 ? S1 : S0);
         if (!(p.dbg & 4)) __syncthreads();
     }
     // acc[i][j][4g + e] = dW(channel c0 + wm*TM*32 + i*32 + 8g + 4h + e, kout n0 + wn*TN*32 + j*32 + l31): 32 lanes = 128 B rows
@@ -691,7 +718,7 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
 template <int MMA, int TM, int TN>
 int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
     constexpr int BMC = 2 * TM * 32, BNK = 2 * TN * 32;
-    constexpr size_t lds = (size_t)2 * (BMC + BNK) * (64 + 8) * 2;
+    constexpr size_t lds = (size_t)(TM * TN >= 8 ? 1 : 2) * (BMC + BNK) * (64 + 8) * 2;      // the wide tile keeps one stage in a static array
     auto kern = p.relu_x ? wgrad16_kernel<MMA, TM, TN, true> : wgrad16_kernel<MMA, TM, TN, false>;
     static bool attrs[2] = {false, false};
     bool& attr = attrs[p.relu_x ? 1 : 0];
@@ -712,7 +739,8 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
     w.bmc = d->C % 128 == 0 ? 128 : 64;
     w.bnk = d->K % 128 == 0 ? 128 : 64;
     static const int wide = [] { const char* e = getenv("CTGAN_WGRAD16_WIDE"); return e ? atoi(e) : 1; }();
-    if (wide && d->C % 256 == 0 && d->K % 128 == 0) w.bmc = 256;      // 4x2 accumulators per wave: 0.75 operand bytes per MFMA of the 128x128 tile
+    const int pq = d->P * d->Q;
+    if (wide && d->C % 256 == 0 && d->K % 128 == 0 && !(pq & (pq - 1)) && !(d->Q & (d->Q - 1))) w.bmc = 256;      // 4x2 accumulators per wave: 0.75 operand bytes per MFMA of the 128x128 tile
     w.tiles = d->R * d->S * (d->C / w.bmc) * ((d->K + w.bnk - 1) / w.bnk);
     const int Kg = d->N * d->P * d->Q;
     // 512 workgroups are resident at a time (2 per CU: 73 KB of LDS each).  Pick the split count whose LAST round of workgroups
