@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -410,9 +411,13 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     // staging map: thread -> (pixel group of 4 = tid % 8 [+ 8 for odd b], channel group of 4 = tid / 8 [+ 32 per pair of b]):
     // a wave load instruction touches 8 pixels x 128 B - whole cache lines (16 pixel groups x 64 B per wave moves half-used
     // lines over the L2 -> L1 path); its LDS writes land 2-way = the minimum for 512 B.  64-wide tiles keep the 16 x 64 B map.
-    float4 rxv[X_PER][4], ryv[Y_PER][4];
+    // operand registers: the wide tile (one wave per SIMD, 512 registers) keeps TWO slices in flight - its waves spend most of
+    // their time waiting for operand loads, and a second set doubles the bytes in flight per CU
+    constexpr int NSET = SPLIT ? 2 : 1;
+    float4 rxv[NSET][X_PER][4], ryv[NSET][Y_PER][4];
     const unsigned x_wstep = (unsigned)p.s_w * 4u, x_estep = (unsigned)p.stride * x_wstep;
-    auto load_slice = [&](int kt) {
+    auto load_slice = [&](int kt, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
         const int kbase = k_begin + kt * BKP;
 #pragma unroll
         for (int b = 0; b < X_PER; ++b) {
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
             for (int e = 0; e < 4; ++e) {
                 const bool ok = rowok & ((unsigned)(iw0 + e * p.stride) < (unsigned)p.W);
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? w0 + e * x_estep : 0xFFFFFFFFu, 0, 0);
-                rxv[b][e] = __builtin_bit_cast(float4, v);
+                rxv[SET][b][e] = __builtin_bit_cast(float4, v);
             }
         }
 #pragma unroll
@@ -454,17 +459,18 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
             for (int e = 0; e < 4; ++e) {
                 const bool ok = colok & (pix + e < k_end);
                 const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? ybase + e * ystep : 0xFFFFFFFFu, 0, 0);
-                ryv[b][e] = __builtin_bit_cast(float4, v);
+                ryv[SET][b][e] = __builtin_bit_cast(float4, v);
             }
         }
     };
-    auto store_slice = [&](unsigned short* st) {
+    auto store_slice = [&](unsigned short* st, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
         unsigned short* Xs = st;
         unsigned short* Ys = st + BMC * LDS_K;
 #pragma unroll
         for (int b = 0; b < X_PER; ++b) {
             const int pg = tid % XPG + XPG * (b % (16 / XPG)), cg = tid / XPG + (NT / XPG) * (b / (16 / XPG));
-            float4 (&v)[4] = rxv[b];
+            float4 (&v)[4] = rxv[SET][b];
             if (RELU_X) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e].x = fmaxf(v[e].x, 0.f); v[e].y = fmaxf(v[e].y, 0.f); v[e].z = fmaxf(v[e].z, 0.f); v[e].w = fmaxf(v[e].w, 0.f); }
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
 #pragma unroll
         for (int b = 0; b < Y_PER; ++b) {
             const int pg = tid % YPG + YPG * (b % (16 / YPG)), cg = tid / YPG + (NT / YPG) * (b / (16 / YPG));
-            const float4 (&v)[4] = ryv[b];
+            const float4 (&v)[4] = ryv[SET][b];
             u32x2 o0 = {Cvt<MMA>::pk(v[0].x, v[1].x), Cvt<MMA>::pk(v[2].x, v[3].x)};
             u32x2 o1 = {Cvt<MMA>::pk(v[0].y, v[1].y), Cvt<MMA>::pk(v[2].y, v[3].y)};
             u32x2 o2 = {Cvt<MMA>::pk(v[0].z, v[1].z), Cvt<MMA>::pk(v[2].z, v[3].z)};
@@ -522,19 +528,19 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fa[i], fb[j], acc[i][j]);
         }
     };
-    if (nk > 0) {
-        load_slice(0);
-        store_slice(S0);
-        if (nk > 1) load_slice(1);
-    }
-    __syncthreads();
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, NSET - 1>;
     int kt = 0;
     if (SPLIT) {
-        // steady state, two slices per trip so that each names its LDS objects: stage slice kt+1, load slice kt+2, multiply slice
-        // kt - one basic block, woven by the scheduling groups (one wave per SIMD: nothing else fills the MFMA gaps)
-        auto slice = [&](unsigned short* wr, const unsigned short* rd, int k) {
-            store_slice(wr);
-            load_slice(k + 2);
+        // Two register sets: slice k's operands live in set (k & 1).  Steady state per slice k: stage slice k+1 from its set
+        // into the other LDS object, refill that set with slice k+3 (two slices of latency slack), multiply slice k.
+        if (nk > 0) { load_slice(0, set0{}); store_slice(S0, set0{}); }
+        if (nk > 1) load_slice(1, set1{});
+        if (nk > 2) load_slice(2, set0{});
+        __syncthreads();
+        auto slice = [&](unsigned short* wr, const unsigned short* rd, int k, auto set_c) {
+            store_slice(wr, set_c);                       // slice k+1
+            load_slice(k + 3, set_c);                     // slice k+3 into the registers just drained (out-of-range rows read as zeros)
             mma_slice(rd);
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
@@ -547,13 +553,26 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
             }
             __syncthreads();
         };
-        for (; kt + 3 < nk; kt += 2) { slice(S1, S0, kt); slice(S0, S1, kt + 1); }
-    }
-    for (; kt < nk; ++kt) {
-        if (kt + 1 < nk && !(p.dbg & 1)) store_slice((kt + 1) & 1 ? S1 : S0);
-        if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2);
-        mma_slice(kt & 1 ? S1 : S0);
-        if (!(p.dbg & 4)) __syncthreads();
+        // slice k+1 is staged while slice k is multiplied; both must exist.  Loads past the chunk return zeros and are never staged.
+        for (; kt + 2 < nk; kt += 2) { slice(S1, S0, kt, set1{}); slice(S0, S1, kt + 1, set0{}); }
+        // here slices kt (in S0) and, if it exists, kt+1 (registers of set 1) remain
+        if (kt + 1 < nk) store_slice(S1, set1{});
+        if (kt < nk) mma_slice(S0);
+        __syncthreads();
+        if (kt + 1 < nk) mma_slice(S1);
+    } else {
+        if (nk > 0) {
+            load_slice(0, set0{});
+            store_slice(S0, set0{});
+            if (nk > 1) load_slice(1, set0{});
+        }
+        __syncthreads();
+        for (; kt < nk; ++kt) {
+            if (kt + 1 < nk && !(p.dbg & 1)) store_slice((kt + 1) & 1 ? S1 : S0, set0{});
+            if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2, set0{});
+            mma_slice(kt & 1 ? S1 : S0);
+            if (!(p.dbg & 4)) __syncthreads();
+        }
     }
     // acc[i][j][4g + e] = dW(channel c0 + wm*TM*32 + i*32 + 8g + 4h + e, kout n0 + wn*TN*32 + j*32 + l31): 32 lanes = 128 B rows
     float* out = p.OUT + (long long)blockIdx.y * p.Mtot * p.Ng;
