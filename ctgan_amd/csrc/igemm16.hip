@@ -411,8 +411,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     // staging map: thread -> (pixel group of 4 = tid % 8 [+ 8 for odd b], channel group of 4 = tid / 8 [+ 32 per pair of b]):
     // a wave load instruction touches 8 pixels x 128 B - whole cache lines (16 pixel groups x 64 B per wave moves half-used
     // lines over the L2 -> L1 path); its LDS writes land 2-way = the minimum for 512 B.  64-wide tiles keep the 16 x 64 B map.
-    // operand registers: the wide tile (one wave per SIMD, 512 registers) keeps TWO slices in flight - its waves spend most of
-    // their time waiting for operand loads, and a second set doubles the bytes in flight per CU
+    // operand registers: the wide tile (one wave per SIMD, 512 registers) keeps TWO slices in flight.  Measured neutral (339 vs 337
+    // TFLOP/s at 1024 channels): the waves' 61 % wait share (tools/pmc_run16b.sh) is not a latency x bytes-in-flight limit; kept
+    // because it costs nothing at one wave per SIMD and removes the load latency from the list of suspects.
     constexpr int NSET = SPLIT ? 2 : 1;
     float4 rxv[NSET][X_PER][4], ryv[NSET][Y_PER][4];
     const unsigned x_wstep = (unsigned)p.s_w * 4u, x_estep = (unsigned)p.stride * x_wstep;
