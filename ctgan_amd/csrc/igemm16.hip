@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     // (TN*32 pixels) x (TM*32 kout) block so that a lane then owns 4 consecutive channels of a pixel and a wave instruction
     // stores whole rows (16-B per lane, mask / residual / bias operands as 16-B loads).
     constexpr int LDE = TM * 32 + 4;          // the launcher sizes the dynamic LDS for max(stage(s), this staging area)
-    constexpr int JE = TN > 2 ? 2 : TN;       // pixel sub-tiles per epilogue pass (the wide tile takes two passes: 70 KB, not 139)
+    constexpr int JE = TM >= 4 ? 1 : (TN > 2 ? 2 : TN);       // pixel sub-tiles per epilogue pass (the wide tiles take several passes: <= 70 KB of staging)
     float* es = reinterpret_cast<float*>(smem) + wave * (JE * 32 * LDE);
     constexpr int C4 = TM * 8;                // float4 per pixel row of the wave's block
     constexpr int ROWS_PER = 64 / C4;
@@ -373,7 +373,7 @@ struct W16 {
     int pq_shift, q_shift;           // log2(P*Q), log2(Q) when both are powers of two, else -1: pixel -> (n,p,q) without integer division
 };
 
-template <int MMA, int TM, int TN, bool RELU_X, bool SPLIT = (TM * TN >= 8)>
+template <int MMA, int TM, int TN, bool RELU_X, bool SPLIT = (TM * TN == 8)>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     // block tile: (2*TM*32) channels of ONE tap  x  (2*TN*32) kout, K slices of 64 pixels
     constexpr int NT = 256, BKP = 64;
@@ -671,7 +671,7 @@ int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     constexpr int BMP = 2 * TN * 32, BNC = 2 * TM * 32;
     constexpr bool split = TM * TN >= 8;            // one stage is a static array (see the kernel)
     constexpr size_t lds_stages = (size_t)(split ? 1 : 2) * (BMP + BNC) * (BK + 8) * 2;
-    constexpr size_t lds_epi = (size_t)4 * (TN > 2 ? 2 : TN) * 32 * (TM * 32 + 4) * 4;
+    constexpr size_t lds_epi = (size_t)4 * (TM >= 4 ? 1 : (TN > 2 ? 2 : TN)) * 32 * (TM * 32 + 4) * 4;
     constexpr size_t lds = lds_stages > lds_epi ? lds_stages : lds_epi;
     auto kern = p.relu_in ? conv16_kernel<MMA, TM, TN, BK, true> : conv16_kernel<MMA, TM, TN, BK, false>;
     static bool attr[2] = {false, false};
@@ -727,8 +727,12 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
         // current one (may-alias: both index the same dynamic LDS array) - they stay serial.  Needs restrict-qualified stage
         // pointers (or hand-placed asm) before it pays.
         static const int wide = [] { const char* e = getenv("CTGAN_CONV16_WIDE"); return e ? atoi(e) : 0; }();
-        if (wide && (long long)p.nph * ((p.M + 255) / 256) * (p.Ng / 128) >= 224)
+        if (wide == 1 && (long long)p.nph * ((p.M + 255) / 256) * (p.Ng / 128) >= 224)
             return launch_conv16<MMA, 2, 4, 64>(p, st, "conv16<128x256,k64>");
+        // 4x2 accumulators per wave: 256 kout x 128 pixels per workgroup - 15 operand bytes per kFLOP instead of 23 (the fp32 pixel
+        // operand is the expensive one, so the tile grows along kout)
+        if (wide == 2 && p.Ng % 256 == 0 && (long long)p.nph * ((p.M + 127) / 128) * (p.Ng / 256) >= 224)
+            return launch_conv16<MMA, 4, 2, 64>(p, st, "conv16<256x128,k64>");
         return launch_conv16<MMA, 2, 2, 64>(p, st, "conv16<128x128,k64>");
     }
     if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16<64x64,k32,ksplit>" : "conv16<64x64,k32>");
@@ -738,7 +742,7 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
 template <int MMA, int TM, int TN>
 int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
     constexpr int BMC = 2 * TM * 32, BNK = 2 * TN * 32;
-    constexpr size_t lds = (size_t)(TM * TN >= 8 ? 1 : 2) * (BMC + BNK) * (64 + 8) * 2;      // the wide tile keeps one stage in a static array
+    constexpr size_t lds = (size_t)(TM * TN == 8 ? 1 : 2) * (BMC + BNK) * (64 + 8) * 2;      // the 256x128 tile keeps one stage in a static array
     auto kern = p.relu_x ? wgrad16_kernel<MMA, TM, TN, true> : wgrad16_kernel<MMA, TM, TN, false>;
     static bool attrs[2] = {false, false};
     bool& attr = attrs[p.relu_x ? 1 : 0];
@@ -758,9 +762,13 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
     WPlan16 w;
     w.bmc = d->C % 128 == 0 ? 128 : 64;
     w.bnk = d->K % 128 == 0 ? 128 : 64;
-    static const int wide = [] { const char* e = getenv("CTGAN_WGRAD16_WIDE"); return e ? atoi(e) : 1; }();
+    static const int wide = [] { const char* e = getenv("CTGAN_WGRAD16_WIDE"); return e ? atoi(e) : 2; }();
     const int pq = d->P * d->Q;
-    if (wide && d->C % 256 == 0 && d->K % 128 == 0 && !(pq & (pq - 1)) && !(d->Q & (d->Q - 1))) w.bmc = 256;      // 4x2 accumulators per wave: 0.75 operand bytes per MFMA of the 128x128 tile
+    // 4x2 accumulators per wave (256 x 128): 0.75 operand bytes per MFMA of the 128x128 tile
+    if (wide && d->C % 256 == 0 && d->K % 128 == 0 && !(pq & (pq - 1)) && !(d->Q & (d->Q - 1))) w.bmc = 256;
+    // 4x4 accumulators per wave (256 x 256 per workgroup): the kernel is bound by the bytes each CU can pull through its L1 miss
+    // path (~35 GB/s per CU, ~9 TB/s chip-wide, whatever the tile): 15 B per kFLOP instead of 23 (256x128) / 30 (128x128)
+    if (wide >= 2 && w.bmc == 256 && d->K % 256 == 0) w.bnk = 256;
     w.tiles = d->R * d->S * (d->C / w.bmc) * ((d->K + w.bnk - 1) / w.bnk);
     const int Kg = d->N * d->P * d->Q;
     // 512 workgroups are resident at a time (2 per CU: 73 KB of LDS each).  Pick the split count whose LAST round of workgroups
@@ -930,7 +938,8 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool bf = mma == CTGAN_MMA_BF16;
-    if (w.bmc == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 2>(p, w.splits, st, "wgrad16<256x128>") : launch_wgrad16<CTGAN_MMA_F16, 4, 2>(p, w.splits, st, "wgrad16<256x128>");
+    if (w.bmc == 256 && w.bnk == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 4>(p, w.splits, st, "wgrad16<256x256>") : launch_wgrad16<CTGAN_MMA_F16, 4, 4>(p, w.splits, st, "wgrad16<256x256>");
+    else if (w.bmc == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 2>(p, w.splits, st, "wgrad16<256x128>") : launch_wgrad16<CTGAN_MMA_F16, 4, 2>(p, w.splits, st, "wgrad16<256x128>");
     else if (w.bmc == 128 && w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 2>(p, w.splits, st, "wgrad16<128x128>") : launch_wgrad16<CTGAN_MMA_F16, 2, 2>(p, w.splits, st, "wgrad16<128x128>");
     else if (w.bmc == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 1>(p, w.splits, st, "wgrad16<128x64>") : launch_wgrad16<CTGAN_MMA_F16, 2, 1>(p, w.splits, st, "wgrad16<128x64>");
     else if (w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 2>(p, w.splits, st, "wgrad16<64x128>") : launch_wgrad16<CTGAN_MMA_F16, 1, 2>(p, w.splits, st, "wgrad16<64x128>");
