@@ -262,9 +262,18 @@ def run_unconditional(args):
         total_t = sum(a[2] for a in agg.values()); total_f = sum(a[1] for a in agg.values())
         mm = {k: v for k, v in agg.items() if ('16' in k) == bool(dtype)} or agg     # the dominant kernel of the family this config is about
         name, (cnt, fl, tt) = max(mm.items(), key=lambda kv: kv[1][2])
+        traffic = None
+        try:        # HBM-side bytes of this kernel from the committed PMC passes (tools/pmc_run16.sh), scaled by FLOPs to this launch mix
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_conv16.json'))).get(name)
+            if pmc:
+                k = (fl / cnt) / pmc['flops_per_launch']
+                traffic = {'hbm_bytes_per_launch': round(pmc['hbm_bytes_per_launch'] * k), 'algorithmic_bytes_per_launch': round(pmc['algorithmic_bytes_per_launch'] * k),
+                           'source': 'profiles/r02_pmc_traffic_conv16.json (%s; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, scaled to this launch mix)' % pmc['geometry']}
+        except Exception:
+            pass
         roofline = {'bound': 'mfma', 'kernel': name, 'launches': cnt, 'flops_per_launch': round(fl / cnt / 1e9, 3),
                     'avg_launch_us': round(tt / cnt * 1e6, 2), 'achieved': round(fl / tt / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(fl / tt / 1e12 / peak, 4), 'traffic': None,
+                    'frac': round(fl / tt / 1e12 / peak, 4), 'traffic': traffic,
                     'all_conv_kernels': {'time_ms': round(total_t * 1e3, 3), 'gflop_executed': round(total_f / 1e9, 2), 'launches': len(prof)},
                     'by_kernel': {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3)}
                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}}
