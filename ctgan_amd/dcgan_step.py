@@ -2,9 +2,13 @@
 TF/CT_gan_mnist.py:110-179,232-249.  Loss = WGAN + consistency term (two dropout passes over the
 real batch) + LAMBDA * gradient penalty; Adam(1e-4, beta1=.5, beta2=.9), no LR decay.
 
-Exact restructuring: the three live critic calls of the reference (real with masks A, real with masks
+Exact restructurings: the three live critic calls of the reference (real with masks A, real with masks
 B, fake with masks C) are evaluated as ONE batch of 3B rows (dropout is elementwise, the critic has no
-batch-coupled op); the dead 4th call `disc_fake_2` and the extra generators are not executed.
+batch-coupled op); where the module exposes `DiscriminatorTrunk` / `DiscriminatorTail` (the layer-normalised
+ResNet critics, whose first dropout sits after the 16x16 blocks) the deterministic trunk runs once on [real ; fake]
+and the two dropout passes over the real batch share it; the dead 4th call `disc_fake_2` and the extra
+generators are not executed.  Without injected draws (`rnd=None`) the dropout masks are regenerated from the
+Philox streams inside the kernels.
 """
 import torch
 
@@ -39,11 +43,6 @@ class DCGANTrainer:
         self.iteration = 0
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
-
-    def _masks(self, n, rnd_key, rnd):
-        if rnd is not None:
-            return rnd[rnd_key]
-        return [self.rng.uniform(n, *s, channels_last=True) for s in self.mod.feat_shapes()]
 
     def d_losses(self, real_in, rnd=None):
         m, cfg = self.mod, self.mod.cfg
