@@ -146,14 +146,34 @@ __global__ void mean_diff_bwd_kernel(const float* __restrict__ gout, int na, int
 //   CT_i  = l2*(d_i - d_{2B+i})^2 + 0.1*l2*mean_j (f_ij - f_{2B+i,j})^2;  ct = mean_i max(CT_i - M, 0)   (:288-291)
 //   acgan = mean_i softmax-CE(a[i], labels[i]),  i < B                                  (:246-248)
 //   out = {wgan + ct + scale*acgan, wgan, ct, acgan}
+// CT_i for wide feature rows (the DCGAN critics' 8192 features): one workgroup per sample, float4 loads
+__global__ __launch_bounds__(256) void critic_heads_ct_rows_kernel(const float* __restrict__ d, const float* __restrict__ f, int B, int nf,
+                                                                   float l2, float* __restrict__ ct_i) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x;
+    const float* fa = f + (long long)i * nf;
+    const float* fb = f + (long long)(2 * B + i) * nf;
+    float s = 0.f;
+    if ((nf & 3) == 0) {
+        for (int j = threadIdx.x * 4; j < nf; j += 1024) {
+            const float4 p = *reinterpret_cast<const float4*>(fa + j), q = *reinterpret_cast<const float4*>(fb + j);
+            const float t0 = p.x - q.x, t1 = p.y - q.y, t2 = p.z - q.z, t3 = p.w - q.w;
+            s += (t0 * t0 + t1 * t1) + (t2 * t2 + t3 * t3);
+        }
+    } else {
+        for (int j = threadIdx.x; j < nf; j += 256) { const float t = fa[j] - fb[j]; s += t * t; }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) { const float t = d[i] - d[2 * B + i]; ct_i[i] = l2 * t * t + l2 * 0.1f * (s / (float)nf); }
+}
 __global__ __launch_bounds__(256) void critic_heads_fwd_kernel(const float* __restrict__ d, const float* __restrict__ f,
                                                                const float* __restrict__ a, const int32_t* __restrict__ labels,
                                                                const float* __restrict__ gp, int B, int nf, int ncls, float l2,
-                                                               float M, float scale, float* __restrict__ ct_i,
+                                                               float M, float scale, int have_ct, float* __restrict__ ct_i,
                                                                float* __restrict__ probs, float* __restrict__ out) {
     __shared__ float sh[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int i = w; i < B; i += 4) {                       // one wave per row
+    for (int i = w; i < B && !have_ct; i += 4) {           // one wave per row
         float s = 0.f;
         for (int j = lane; j < nf; j += 64) { const float t = f[(long long)i * nf + j] - f[(long long)(2 * B + i) * nf + j]; s += t * t; }
         s = wave_sum(s);
@@ -617,8 +637,11 @@ int ctgan_critic_heads_fwd(const float* d, const float* f, const float* a, const
                            float* out, ctgan_stream_t s) {
     if (!d || !f || !ct_i || !out || B <= 0 || nf <= 0 || (a && (!labels || !probs || ncls <= 0)))
         return ctgan_fail(CTGAN_E_BADARG, "critic_heads_fwd: bad argument");
+    const int wide = (long long)B * nf >= 65536 && !(reinterpret_cast<uintptr_t>(f) & 15);     // wide rows: CT_i by one workgroup per sample
+    if (wide)
+        hipLaunchKernelGGL(critic_heads_ct_rows_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(s), d, f, B, nf, lambda2, ct_i);
     hipLaunchKernelGGL(critic_heads_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(s), d, f, a, labels, gp, B, nf, ncls,
-                       lambda2, M, acgan_scale, ct_i, probs, out);
+                       lambda2, M, acgan_scale, wide, ct_i, probs, out);
     return ctgan_check_launch("critic_heads_fwd");
 }
 int ctgan_critic_heads_bwd(const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,

@@ -6,7 +6,8 @@ Exact restructurings: the three live critic calls of the reference (real with ma
 B, fake with masks C) are evaluated as ONE batch of 3B rows (dropout is elementwise, the critic has no
 batch-coupled op); where the module exposes `DiscriminatorTrunk` / `DiscriminatorTail` (the layer-normalised
 ResNet critics, whose first dropout sits after the 16x16 blocks) the deterministic trunk runs once on [real ; fake]
-and the two dropout passes over the real batch share it; the dead 4th call `disc_fake_2` and the extra
+and the two dropout passes over the real batch share it; the WGAN difference, the consistency term and the sum with the
+gradient penalty are one fused loss-heads launch each way (rows ordered real, fake, real); the dead 4th call `disc_fake_2` and the extra
 generators are not executed.  Without injected draws (`rnd=None`) the dropout masks are regenerated from the
 Philox streams inside the kernels.
 """
@@ -52,26 +53,26 @@ class DCGANTrainer:
             real = m.real_prep(real_in)
             alpha = rnd['alpha'] if rnd is not None else self.rng.uniform(B, 1)
             interp = K.interpolate(real, fake, alpha)
-        u = [torch.cat([a, b, c], 0) for a, b, c in zip(rnd['u_real'], rnd['u_real_'], rnd['u_fake'])] if rnd is not None else None
+        # rows of the batched passes: real (masks A), fake (masks C), real (masks B) - the order the fused loss heads read
+        u = [torch.cat([a, c, b], 0) for a, b, c in zip(rnd['u_real'], rnd['u_real_'], rnd['u_fake'])] if rnd is not None else None
         if TRUNK_SHARE and hasattr(m, 'DiscriminatorTrunk') and getattr(m, 'critic_is_per_sample', lambda: True)():
             # the critic's layers before its first dropout are deterministic and per-sample: the two dropout passes over the real
-            # batch share ONE evaluation of them - rows [real ; fake] through the trunk, rows [real, real, fake] through the tail
+            # batch share ONE evaluation of them - rows [real ; fake] through the trunk, rows [real, fake, real] through the tail
             h = m.DiscriminatorTrunk(torch.cat([real, fake], 0))
-            h3 = F.rows_select(h, [(0, B), (0, B), (B, 2 * B)])
+            h3 = F.rows_select(h, [(0, B), (B, 2 * B), (0, B)])
             d, f = m.DiscriminatorTail(h3, u=u, rng=None if rnd is not None else self.rng)
         else:
-            x3 = torch.cat([real, real, fake], 0)
+            x3 = torch.cat([real, fake, real], 0)
             # masks regenerated from the Philox stream inside the dropout kernels when none are injected: no uniform tensors
             d, f = m.Discriminator(x3, u=u) if rnd is not None else m.Discriminator(x3, rng=self.rng)
-        wgan = F.mean_diff(d[B:], B, B, 0.0, 1.0) + F.mean_diff(d[:B], B, 0, -1.0, 0.0)   # mean(fake) - mean(real)
-        ct = F.consistency_term(d[:B], d[B:2 * B], f[:B], f[B:2 * B], cfg.LAMBDA_2, cfg.Factor_M)
         interp.requires_grad_(True)
         with F.weight_grads(not self.piecewise):     # a LeakyReLU + dropout critic is piecewise linear; a layer-normalised one is not
             d_gp = (m.Discriminator(interp, u=rnd['u_gp']) if rnd is not None else m.Discriminator(interp, rng=self.rng))[0]
         (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=torch.ones_like(d_gp), create_graph=True)
         gp, slopes = F.gradient_penalty(grads, cfg.LAMBDA)
-        return {'cost': wgan + ct + gp, 'wgan_only': wgan, 'ct': ct, 'gp': gp, 'fake': fake, 'slopes': slopes,
-                'gp_grads': grads}
+        # mean(fake) - mean(real), the consistency term over the two real passes and the sum with gp: one launch each way
+        cost, wgan, ct, _, _ = F.critic_heads(d, f, None, None, B, cfg.LAMBDA_2, cfg.Factor_M, 0.0, gp)
+        return {'cost': cost, 'wgan_only': wgan, 'ct': ct, 'gp': gp, 'fake': fake, 'slopes': slopes, 'gp_grads': grads}
 
     def _gen(self, n, z):
         if self.towers > 1:
