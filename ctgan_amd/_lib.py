@@ -14,7 +14,7 @@ import torch  # noqa: F401  (also the device-memory / stream provider of every w
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libctgan_hip.so')
+LIB_PATH = os.environ.get('CTGAN_LIB') or os.path.join(_HERE, 'libctgan_hip.so')      # CTGAN_LIB: A/B builds (tools only)
 
 
 class ConvDesc(ctypes.Structure):
@@ -84,13 +84,13 @@ SIGNATURES = {
     'ctgan_conv2d_dgrad': (c_int, [_D, _p, _p, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_conv2d_repack_filter': (c_int, [_D, _p, _p, _p]),
     'ctgan_conv2d_wgrad': (c_int, [_D, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),
-    'ctgan_conv2d16_supported': (c_int, [_D, c_int]),
-    'ctgan_conv2d16_filter_elems': (c_size_t, [_D, c_int]),
+    'ctgan_conv2d16_supported': (c_int, [_D, c_int, c_int]),
+    'ctgan_conv2d16_filter_elems': (c_size_t, [_D, c_int, c_int]),
     'ctgan_conv2d16_pack_filter': (c_int, [_D, c_int, c_int, _p, _p, _p]),
     'ctgan_conv2d16_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d16_fwd': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
     'ctgan_conv2d16_dgrad': (c_int, [_D, c_int, _p, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
-    'ctgan_conv2d16_wgrad_workspace_bytes': (c_size_t, [_D]),
+    'ctgan_conv2d16_wgrad_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d16_wgrad': (c_int, [_D, c_int, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_layernorm_supported': (c_int, [c_int64, c_int32]),
     'ctgan_layernorm_workspace_bytes': (c_size_t, [c_int32, c_int64, c_int32]),

@@ -46,6 +46,10 @@ template <> struct Cvt<CTGAN_MMA_BF16> {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
 };
+// fp32 values as three bf16 terms (x = h + m + l, each the nearest-even bf16 of what the previous ones left: 24 significand bits):
+// the product x*w = hh + hm + mh + mm + hl + lh (+ terms below 2^-24 relative that are dropped) - six bf16 MFMAs that accumulate in
+// fp32 reproduce an fp32 multiply-accumulate to fp32 rounding accuracy at 6/16 of the fp32 MFMA's cycle cost.
+template <> struct Cvt<CTGAN_MMA_F32X3> : Cvt<CTGAN_MMA_BF16> {};
 template <> struct Cvt<CTGAN_MMA_F16> {
     static __device__ __forceinline__ unsigned pk(float a, float b) {
         typedef _Float16 v2 __attribute__((ext_vector_type(2)));
@@ -57,7 +61,42 @@ template <> struct Cvt<CTGAN_MMA_F16> {
     }
 };
 
+template <int MMA> constexpr int planes() { return MMA == CTGAN_MMA_F32X3 ? 3 : 1; }
+// the 16-bit pieces of the pair (a, b), packed (a low, b high): one rounded piece, or the three terms of the split
+template <int MMA>
+__device__ __forceinline__ void split_pk(float a, float b, unsigned (&o)[planes<MMA>()]) {
+    if constexpr (planes<MMA>() == 1) {
+        o[0] = Cvt<MMA>::pk(a, b);
+    } else {
+        // remainder of an element = x - piece: v_dot2c_f32_bf16 with the packed constants (-1, 0) / (0, -1) subtracts the low / high
+        // piece of the pair in ONE instruction (no unpacking); the difference is exactly representable, so the result is exact
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        // (the constants are made opaque: folded into the instruction, (-1, 0) becomes the inline operand "-1.0", which the hardware
+        // does not read as that bf16 pair - tools/dot2_check.hip)
+        unsigned klo = 0x0000BF80u, khi = 0xBF800000u;
+        asm("" : "+s"(klo));
+        asm("" : "+s"(khi));
+        const bf2 lo = __builtin_bit_cast(bf2, klo), hi = __builtin_bit_cast(bf2, khi);
+#ifdef CTGAN_SPLIT_SUB
+        const unsigned h0 = Cvt<MMA>::pk(a, b);
+        const float ra0 = a - __builtin_bit_cast(float, h0 << 16), rb0 = b - __builtin_bit_cast(float, h0 & 0xFFFF0000u);
+        const unsigned m0 = Cvt<MMA>::pk(ra0, rb0);
+        const float sa0 = ra0 - __builtin_bit_cast(float, m0 << 16), sb0 = rb0 - __builtin_bit_cast(float, m0 & 0xFFFF0000u);
+        o[0] = h0; o[1] = m0; o[2] = Cvt<MMA>::pk(sa0, sb0);
+        return;
+#endif
+        const unsigned h = Cvt<MMA>::pk(a, b);
+        const float ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, h), lo, a, false);
+        const float rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, h), hi, b, false);
+        const unsigned m = Cvt<MMA>::pk(ra, rb);
+        const float sa = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, m), lo, ra, false);
+        const float sb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, m), hi, rb, false);
+        o[0] = h; o[1] = m; o[2] = Cvt<MMA>::pk(sa, sb);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- filter packing
+// (the three planes of the split mode follow each other, `plane` 16-bit elements apart)
 // FWD : wp[n][(r*S + s)*C + c]                       = w[r][s][c][n]                    (n = kout)
 // DGRAD, phase (a,b): wp[off(a,b) + n*Kph + ((t*U + u)*Kout + k)] = w[r][s][n][k]      (n = c: the data gradient's output channel)
 //        r = r0(a) + step*(T(a)-1-t), s = s0(b) + step*(U(b)-1-u)   (rotated: the gather then runs forward)
@@ -89,19 +128,22 @@ long long phase_off(const PhaseGeom& g, const ctgan_conv_desc* d, int ph) {     
 }
 
 template <int MMA>
-__global__ void pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int RS, int C, int K) {
+__global__ void pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int RS, int C, int K, long long plane) {
     // one thread per (n, tap, pair of c): reads are strided by K (the transpose), writes are 4-byte and coalesced
     const long long per = (long long)RS * C / 2, total = per * K;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i / per);
         const long long e = (i - (long long)n * per) * 2;                      // (tap*C + c), c even
         const float a = w[e * K + n], b = w[(e + 1) * K + n];
-        reinterpret_cast<unsigned*>(wp)[i] = Cvt<MMA>::pk(a, b);
+        unsigned o[planes<MMA>()];
+        split_pk<MMA>(a, b, o);
+#pragma unroll
+        for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane)[i] = o[q];
     }
 }
 struct PackPhases { int T[2], U[2], r0[2], s0[2]; int nph, step, R, S, C, K; long long off[4]; };
 template <int MMA>
-__global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const PackPhases pp) {
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const PackPhases pp, long long plane) {
     const int ph = blockIdx.y, a = ph >> 1, b = ph & 1;
     const int T = pp.T[a], U = pp.U[b];
     const long long kph = (long long)T * U * pp.K, per = kph / 2, total = per * pp.C;
@@ -111,7 +153,10 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* _
         const int k = (int)(e % pp.K), tu = (int)(e / pp.K), t = tu / U, u = tu - t * U;
         const int r = pp.r0[a] + pp.step * (T - 1 - t), s = pp.s0[b] + pp.step * (U - 1 - u);
         const float* src = w + (((long long)r * pp.S + s) * pp.C + n) * pp.K + k;
-        reinterpret_cast<unsigned*>(wp + pp.off[ph])[i] = Cvt<MMA>::pk(src[0], src[1]);
+        unsigned o[planes<MMA>()];
+        split_pk<MMA>(src[0], src[1], o);
+#pragma unroll
+        for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane + pp.off[ph])[i] = o[q];
     }
 }
 
@@ -129,7 +174,8 @@ struct P16 {
     int M, Ng;                      // rows per phase, output channels
     long long ds_n, ds_p, ds_q;     // D strides over (n, phase-grid row, phase-grid col); channel stride 1
     int relu, relu_in;
-    unsigned x_bytes, w_bytes;
+    unsigned x_bytes, w_bytes;      // w_bytes covers every plane
+    unsigned w_plane_bytes;         // split mode: byte distance between the filter's planes
     int nph, ph_tiles_m;
     int ph_T[2], ph_U[2], ph_pad_t[2], ph_pad_l[2];
     long long ph_w_off[4];          // packed-filter element offset of a phase
@@ -139,8 +185,22 @@ struct P16 {
     int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier (a branch around the MFMAs would move the accumulators out of the AGPRs)
 };
 
-template <int MMA, int TM, int TN, int BK, bool RELU_IN, bool SPLIT = (TM * TN >= 8)>
-__global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
+// one workgroup per CU (the staging must be woven between the MFMAs): the 8-accumulator tiles
+template <int MMA, int TM, int TN> constexpr bool conv16_one_wave() { return TM * TN >= 8; }
+// ONE LDS stage (two barriers per slice), two workgroups per CU: an alternative for the split mode's 128x128 tile, measured
+// 149-178 TFLOP/s against 126 for the double-buffered one-workgroup form whose staging the scheduler does not weave between
+// the MFMAs; superseded by the producer / consumer form below
+template <int MMA, int TM, int TN> constexpr bool conv16_single_stage() { return false; }
+// PRODUCER / CONSUMER waves (split mode, 128x128 tile): 8 waves per workgroup, one workgroup per CU, two 60 KB LDS stages.  Waves
+// 0-3 only read fragments and issue MFMAs; waves 4-7 load the next slices, split the fp32 pixel values into their three bf16
+// terms and write the LDS planes.  Each SIMD then holds one wave of either kind and the hardware interleaves the producer's
+// VALU / memory instructions with the consumer's 32-cycle MFMAs - no reliance on the compiler weaving one wave's instruction stream.
+template <int MMA, int TM, int TN> constexpr bool conv16_ws() { return planes<MMA>() == 3 && TM * TN >= 4; }
+// pixel sub-tiles per epilogue pass (the wide tiles take several passes: <= 70 KB of staging)
+template <int MMA, int TM, int TN> constexpr int conv16_je() { return TM >= 4 ? 1 : (TN > 2 ? 2 : TN); }
+
+template <int MMA, int TM, int TN, int BK, bool RELU_IN, bool SPLIT = conv16_one_wave<MMA, TM, TN>(), bool WS = conv16_ws<MMA, TM, TN>()>
+__global__ __launch_bounds__(WS ? 512 : 256) void conv16_kernel(const P16 p) {
     // TM: 32-wide kout sub-tiles per wave ("A" operand), TN: 32-wide pixel sub-tiles per wave ("B" operand)
     constexpr int NT = 256;
     constexpr int BMP = 2 * TN * 32;                    // pixels per block
@@ -151,16 +211,20 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     constexpr int WC = BK / 8;                          // 16-B packed chunks per filter row per slice
     constexpr int W_PER = BNC * WC / NT;
     static_assert(BMP * XC % NT == 0 && BNC * WC % NT == 0 && X_PER >= 1 && W_PER >= 1, "tile / thread mismatch");
-    constexpr int STAGE = (BMP + BNC) * LDS_K;          // 16-bit elements
+    constexpr int NP = planes<MMA>();                   // operand planes (split mode: h, m, l)
+    constexpr int XPLANE = BMP * LDS_K, WPLANE = BNC * LDS_K;
+    constexpr int STAGE = NP * (XPLANE + WPLANE);       // 16-bit elements: X planes, then W planes
     // SPLIT (the one-wave-per-SIMD tile): the two LDS stages are two DIFFERENT objects - a static array and the dynamic region -
     // so the compiler knows that the stores staging slice t+1 cannot alias the fragment reads of slice t and may weave them
     // between the MFMAs (with both stages inside one dynamic array every store has to stay behind every earlier read).
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     __shared__ __attribute__((aligned(16))) unsigned short stage0_static[SPLIT ? STAGE : 8];
+    constexpr bool SINGLE = conv16_single_stage<MMA, TM, TN>();
     unsigned short* const S0 = SPLIT ? stage0_static : smem;
-    unsigned short* const S1 = SPLIT ? smem : smem + STAGE;
+    unsigned short* const S1 = SPLIT ? smem : (SINGLE ? smem : smem + STAGE);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = WS && threadIdx.x >= 256;     // wave-uniform role
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;            // wave's kout half / pixel half
     int bid = blockIdx.x;
     const int nb = gridDim.x;
@@ -185,7 +249,10 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
 
     // pixel-operand loader: thread -> (row, 16-B chunk); the row's byte offset at tap (0,0) is fixed for the whole kernel
-    const int x_chunk = tid % XC, x_row0 = tid / XC;
+    // BK 32 (80-B LDS rows): the two rows a store instruction's 16 lanes (b64) / 8 lanes (b128) cover are 4 rows apart (320 B = 64 mod
+    // 128: disjoint banks); consecutive rows would overlap in 16 of their 64 bytes
+    auto spread = [](int g) { return BK == 32 ? ((g & 1) * 4 + ((g >> 1) & 3) + (g >> 3) * 8) : g; };
+    const int x_chunk = tid % XC, x_row0 = spread(tid / XC);
     unsigned x_voff[X_PER];
     int x_ih0[X_PER], x_iw0[X_PER];
     bool x_valid[X_PER];
@@ -200,7 +267,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
         const long long o = (long long)n * p.s_n + (long long)x_ih0[i] * p.s_h + (long long)x_iw0[i] * p.s_w + x_chunk * 4;
         x_voff[i] = (unsigned)(o * 4);                   // may be "negative": wraps consistently mod 2^32
     }
-    const int w_chunk = tid % WC, w_row0 = tid / WC;
+    const int w_chunk = tid % WC, w_row0 = spread(tid / WC);
     unsigned w_voff[W_PER];
 #pragma unroll
     for (int i = 0; i < W_PER; ++i) {
@@ -209,7 +276,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     }
 
     float4 rx[X_PER];
-    u32x4 rw[W_PER];
+    u32x4 rw[NP][W_PER];
     // tap / channel chunk / linear slice index of the NEXT slice to load (a K split starts in the middle of the filter)
     int ld_k = k_first, ld_c = k_first % cpt, ld_u = (k_first / cpt) % U, ld_t = (k_first / cpt) / U;
     auto load_slice = [&]() {
@@ -222,10 +289,12 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
         }
         const unsigned ws = (unsigned)((long long)ld_k * BK * 2);
 #pragma unroll
-        for (int i = 0; i < W_PER; ++i) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], ws, 0);
-            rw[i] = __builtin_bit_cast(u32x4, v);
-        }
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int i = 0; i < W_PER; ++i) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], ws + q * p.w_plane_bytes, 0);
+                rw[q][i] = __builtin_bit_cast(u32x4, v);
+            }
         ++ld_k;
         // branch-free advance (scalar selects): a branch here would split the slice's basic block and the scheduler could not
         // weave the staging instructions between the MFMAs
@@ -239,48 +308,113 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     };
     auto store_slice = [&](unsigned short* st) {
         unsigned short* Xs = st;
-        unsigned short* Ws = st + BMP * LDS_K;
+        unsigned short* Ws = st + NP * XPLANE;
 #pragma unroll
         for (int i = 0; i < X_PER; ++i) {
             float4 v = rx[i];
             if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            u32x2 o = {Cvt<MMA>::pk(v.x, v.y), Cvt<MMA>::pk(v.z, v.w)};
-            *reinterpret_cast<u32x2*>(&Xs[(x_row0 + i * (NT / XC)) * LDS_K + x_chunk * 4]) = o;
+            unsigned o0[NP], o1[NP];
+            split_pk<MMA>(v.x, v.y, o0);
+            split_pk<MMA>(v.z, v.w, o1);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const u32x2 o = {o0[q], o1[q]};
+                *reinterpret_cast<u32x2*>(&Xs[q * XPLANE + (x_row0 + i * (NT / XC)) * LDS_K + x_chunk * 4]) = o;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < W_PER; ++i)
-            *reinterpret_cast<u32x4*>(&Ws[(w_row0 + i * (NT / WC)) * LDS_K + w_chunk * 8]) = rw[i];
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int i = 0; i < W_PER; ++i)
+                *reinterpret_cast<u32x4*>(&Ws[q * WPLANE + (w_row0 + i * (NT / WC)) * LDS_K + w_chunk * 8]) = rw[q][i];
     };
 
-    f32x16 acc[TM][TN];
+    // split mode, one accumulator per wave: its six products alternate between two accumulators (no back-to-back dependent MFMAs)
+    constexpr int NACC = (NP == 3 && TM * TN == 1) ? 2 : 1;
+    f32x16 acc[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][i][j][e] = 0.f;
 
     const int h = lane >> 5, l31 = lane & 31;
     auto mma_slice = [&](const unsigned short* Xs) {
-        const unsigned short* Ws = Xs + BMP * LDS_K;
+        const unsigned short* Ws = Xs + NP * XPLANE;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            u32x4 fw[TM], fx[TN];
+            u32x4 fw[NP][TM], fx[NP][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fw[i] = *reinterpret_cast<const u32x4*>(&Ws[(wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fx[j] = *reinterpret_cast<const u32x4*>(&Xs[(wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+                for (int i = 0; i < TM; ++i)
+                    fw[q][i] = *reinterpret_cast<const u32x4*>(&Ws[q * WPLANE + (wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j)
+                    fx[q][j] = *reinterpret_cast<const u32x4*>(&Xs[q * XPLANE + (wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+            }
+            if constexpr (NP == 1) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fw[i], fx[j], acc[i][j]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[0][i][j] = Cvt<MMA>::mma(fw[0][i], fx[0][j], acc[0][i][j]);
+            } else {
+                // (filter piece, pixel piece), the small products first: l*h, h*l, m*m, m*h, h*m, h*h
+                constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[c % NACC][i][j] = Cvt<MMA>::mma(fw[QW[c]][i], fx[QX[c]][j], acc[c % NACC][i][j]);
+            }
         }
     };
-    load_slice();
-    store_slice(S0);
-    if (nk > 1) load_slice();
+    // consumer waves of the producer / consumer form.  The instruction order is pinned (scheduling barriers): left alone, the
+    // scheduler groups the six products of one accumulator - ten dependent MFMAs back to back, each waiting for the previous
+    // result (measured 55 % MFMA occupancy with nothing else in the loop).  Products are issued class by class (four MFMAs on four
+    // different accumulators), the fragment reads in the order the classes consume them, the second k step's reads between the
+    // MFMAs of the first.
+    auto mma_slice_ws = [&](const unsigned short* Xs) {
+        if constexpr (NP == 3 && BK == 32) {
+            const unsigned short* Ws = Xs + NP * XPLANE;
+            constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};
+            u32x4 fw[2][NP][TM], fx[2][NP][TN];
+            auto rd = [&](int ks, int qw, int qx) {        // the fragments product class (qw, qx) is the first to need
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fw[ks][qw][i] = *reinterpret_cast<const u32x4*>(&Ws[qw * WPLANE + (wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fx[ks][qx][j] = *reinterpret_cast<const u32x4*>(&Xs[qx * XPLANE + (wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mm = [&](int ks, int c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[0][i][j] = Cvt<MMA>::mma(fw[ks][QW[c]][i], fx[ks][QX[c]][j], acc[0][i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            rd(0, 2, 0); rd(0, 0, 2);
+            mm(0, 0); rd(0, 1, 1);
+            mm(0, 1); rd(1, 2, 0);
+            mm(0, 2); rd(1, 0, 2);
+            mm(0, 3); rd(1, 1, 1);
+            mm(0, 4); mm(0, 5);
+            mm(1, 0); mm(1, 1); mm(1, 2); mm(1, 3); mm(1, 4); mm(1, 5);
+        }
+    };
+    if (!WS || producer) {
+        load_slice();
+        store_slice(S0);
+        if (nk > 1) load_slice();
+    }
     __syncthreads();
     // steady state (slices kt+1 and kt+2 exist): ONE basic block per slice - stage slice kt+1 into the other LDS buffer, issue
     // the loads of slice kt+2, multiply slice kt.  SPLIT: scheduling groups ask for the staging instructions to be woven between
@@ -291,9 +425,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
         load_slice();
         mma_slice(rd);
         if (SPLIT) {
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NP * (TM + TN), 0);
 #pragma unroll
-            for (int g = 0; g < TM * TN * (BK / 16); ++g) {
+            for (int g = 0; g < (NP == 3 ? 6 : 1) * TM * TN * (BK / 16); ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
@@ -304,19 +438,46 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
         __syncthreads();
     };
     int kt = 0;
-    for (; kt + 3 < nk; kt += 2) { slice(S1, S0); slice(S0, S1); }      // kt even: slice kt lives in S0
-    for (; kt < nk; ++kt) {                                // the last slices
-        if (kt + 1 < nk) store_slice((kt + 1) & 1 ? S1 : S0);
-        if (kt + 2 < nk) load_slice();
-        mma_slice(kt & 1 ? S1 : S0);
-        __syncthreads();
+    if constexpr (WS) {
+        for (; kt < nk; ++kt) {
+            if (!producer) {
+                mma_slice_ws(kt & 1 ? S1 : S0);
+            } else {
+                if (kt + 1 < nk && !(p.dbg & 1)) store_slice((kt + 1) & 1 ? S1 : S0);
+                if (kt + 2 < nk && !(p.dbg & 2)) load_slice();
+            }
+            __syncthreads();
+        }
+        if (producer) return;                              // the epilogue is the consumers' (wave-level synchronisation only)
+    } else if constexpr (SINGLE) {
+        for (; kt < nk; ++kt) {
+            mma_slice(S0);
+            __syncthreads();                               // every wave has read slice kt
+            if (kt + 1 < nk) {
+                if (!(p.dbg & 1)) store_slice(S0);
+                if (kt + 2 < nk && !(p.dbg & 2)) load_slice();
+                __syncthreads();
+            }
+        }
+    } else {
+        for (; kt + 3 < nk; kt += 2) { slice(S1, S0); slice(S0, S1); }      // kt even: slice kt lives in S0
+        for (; kt < nk; ++kt) {                                // the last slices
+            if (kt + 1 < nk) store_slice((kt + 1) & 1 ? S1 : S0);
+            if (kt + 2 < nk) load_slice();
+            mma_slice(kt & 1 ? S1 : S0);
+            __syncthreads();
+        }
     }
 
     // epilogue through LDS: acc[i][j][4g + e] = D(pixel j*32 + l31, kout i*32 + 8g + 4h + e); every wave transposes its own
     // (TN*32 pixels) x (TM*32 kout) block so that a lane then owns 4 consecutive channels of a pixel and a wave instruction
     // stores whole rows (16-B per lane, mask / residual / bias operands as 16-B loads).
+    if constexpr (NACC == 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][0][e] += acc[1][0][0][e];
+    }
     constexpr int LDE = TM * 32 + 4;          // the launcher sizes the dynamic LDS for max(stage(s), this staging area)
-    constexpr int JE = TM >= 4 ? 1 : (TN > 2 ? 2 : TN);       // pixel sub-tiles per epilogue pass (the wide tiles take several passes: <= 70 KB of staging)
+    constexpr int JE = conv16_je<MMA, TM, TN>();
     float* es = reinterpret_cast<float*>(smem) + wave * (JE * 32 * LDE);
     constexpr int C4 = TM * 8;                // float4 per pixel row of the wave's block
     constexpr int ROWS_PER = 64 / C4;
@@ -328,7 +489,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
             for (int j = 0; j < JE; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 v = {acc[i][jh + j][4 * g], acc[i][jh + j][4 * g + 1], acc[i][jh + j][4 * g + 2], acc[i][jh + j][4 * g + 3]};
+                    float4 v = {acc[0][i][jh + j][4 * g], acc[0][i][jh + j][4 * g + 1], acc[0][i][jh + j][4 * g + 2], acc[0][i][jh + j][4 * g + 3]};
                     *reinterpret_cast<float4*>(&es[(j * 32 + l31) * LDE + i * 32 + 8 * g + 4 * h]) = v;
                 }
         __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave reads back what its own lanes wrote (no cross-wave traffic)
@@ -359,6 +520,243 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- split mode, persistent form
+// conv16x3p: the split mode's 128 kout x 128 pixel tile as a PERSISTENT producer / consumer kernel - one workgroup of 8 waves per
+// CU walks the tiles b, b + grid, b + 2 grid, ...  Waves 0-3 (consumers, one per SIMD) only read fragments and issue MFMAs, and
+// write a finished tile through their own LDS staging area; waves 4-7 (producers) stream the slices of the tile sequence - fp32
+// pixel values split into three bf16 terms, the three packed filter planes - into two 60 KB LDS stages, two slices of loads in
+// flight, and run ahead across tile boundaries: the first slices of the next tile are staged while the consumers finish and
+// store the current one.  Measured on the one-tile-per-workgroup form: 10-16 us of prologue + epilogue + dispatch per tile
+// against 30 us of MFMAs for a 3x3x128 filter - that is what the persistence hides; one barrier per slice for all 8 waves.
+template <bool RELU_IN>
+__global__ __launch_bounds__(512) void conv16x3p_kernel(const P16 p) {
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, TM = 2, TN = 2, BK = 32, NT = 256;
+    constexpr int BMP = 128, BNC = 128, LDS_K = BK + 8;
+    constexpr int XC = BK / 4, X_PER = BMP * XC / NT, WC = BK / 8, W_PER = BNC * WC / NT;
+    constexpr int XPLANE = BMP * LDS_K, WPLANE = BNC * LDS_K, STAGE = NP * (XPLANE + WPLANE);
+    constexpr int LDE = TM * 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short* const S0 = smem;
+    unsigned short* const S1 = smem + STAGE;
+    float* const epi = reinterpret_cast<float*>(smem + 2 * STAGE);      // 4 waves x 32 pixels x LDE floats
+
+    const bool producer = threadIdx.x >= 256;            // wave-uniform role
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.Ng + BNC - 1) / BNC;
+    const int per_phase = p.ph_tiles_m * tiles_n;
+    const int total = p.nph * per_phase;
+    const int G = gridDim.x;
+    const int cpt = p.C / BK;
+    const int PQ = p.P * p.Q;
+    // tile L -> (phase, pixel tile, kout tile); neighbouring pixel tiles (shared halo rows) stay on one XCD
+    auto locate = [&](int L, int& ph, int& tile_m, int& tile_n) {
+        int b = L;
+        if ((total & 7) == 0) b = (L & 7) * (total >> 3) + (L >> 3);
+        tile_m = b / tiles_n; tile_n = b - tile_m * tiles_n;
+        ph = 0;
+        if (p.nph > 1) { ph = tile_m / p.ph_tiles_m; tile_m -= ph * p.ph_tiles_m; }
+    };
+    auto slices_of = [&](int ph) { return p.ph_T[ph >> 1] * p.ph_U[ph & 1] * cpt; };
+    int n_total = 0;                                     // slices this workgroup walks
+    for (int L = blockIdx.x; L < total; L += G) { int ph, tm, tn; locate(L, ph, tm, tn); n_total += slices_of(ph); }
+
+    if (producer) {
+        // the second-dispatched half of a workgroup loses the per-SIMD issue arbitration (priority, then age): without a static
+        // priority the producers' VALU / LDS instructions only issue once the consumer on their SIMD runs out of MFMAs, and the two
+        // roles serialise (measured 1.4-1.6 us per slice against 0.82 us of MFMAs)
+        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
+        auto spread = [](int g) { return (g & 1) * 4 + ((g >> 1) & 3) + (g >> 3) * 8; };      // conflict-free row pairs, see conv16_kernel
+        const int x_chunk = tid % XC, x_row0 = spread(tid / XC);
+        const int w_chunk = tid % WC, w_row0 = spread(tid / WC);
+        // loader state: the tile whose slices are being read, and the position inside it
+        int L = blockIdx.x, U = 1, nk = 0;
+        unsigned x_voff[X_PER], w_voff[W_PER];
+        int x_ih0[X_PER], x_iw0[X_PER];
+        bool x_valid[X_PER];
+        int ld_k = 0, ld_c = 0, ld_u = 0, ld_t = 0;
+        auto setup = [&]() {
+            int ph, tile_m, tile_n;
+            locate(L, ph, tile_m, tile_n);
+            const int pa = ph >> 1, pb = ph & 1;
+            const int T = p.ph_T[pa];
+            U = p.ph_U[pb];
+            nk = T * U * cpt;
+            const long long kph = (long long)T * U * p.C;
+#pragma unroll
+            for (int i = 0; i < X_PER; ++i) {
+                const int m = tile_m * BMP + x_row0 + i * (NT / XC);
+                x_valid[i] = m < p.M;
+                const int mm = x_valid[i] ? m : 0;
+                const int n = mm / PQ, rem = mm - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+                x_ih0[i] = pp * p.stride - p.ph_pad_t[pa];
+                x_iw0[i] = qq * p.stride - p.ph_pad_l[pb];
+                const long long o = (long long)n * p.s_n + (long long)x_ih0[i] * p.s_h + (long long)x_iw0[i] * p.s_w + x_chunk * 4;
+                x_voff[i] = (unsigned)(o * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < W_PER; ++i) {
+                const int n = tile_n * BNC + w_row0 + i * (NT / WC);
+                w_voff[i] = n < p.Ng ? (unsigned)((p.ph_w_off[ph] + (long long)n * kph + w_chunk * 8) * 2) : 0xFFFFFFFFu;
+            }
+            ld_k = ld_c = ld_u = ld_t = 0;
+        };
+        float4 rx[2][X_PER];
+        u32x4 rw[2][NP][W_PER];
+        auto load_slice = [&](auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+            const unsigned xs = (unsigned)(((long long)ld_t * p.s_h + (long long)ld_u * p.s_w + ld_c * BK) * 4);
+#pragma unroll
+            for (int i = 0; i < X_PER; ++i) {
+                const bool ok = x_valid[i] & ((unsigned)(x_ih0[i] + ld_t) < (unsigned)p.H) & ((unsigned)(x_iw0[i] + ld_u) < (unsigned)p.W);
+                rx[SET][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? x_voff[i] + xs : 0xFFFFFFFFu, 0, 0));
+            }
+            const unsigned ws = (unsigned)((long long)ld_k * BK * 2);
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int i = 0; i < W_PER; ++i)
+                    rw[SET][q][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], ws + q * p.w_plane_bytes, 0));
+            ++ld_k; ++ld_c;
+            if (ld_c == cpt) { ld_c = 0; if (++ld_u == U) { ld_u = 0; ++ld_t; } }
+            if (ld_k == nk) { L += G; if (L < total) setup(); }      // the loader moves on to the next tile
+        };
+        auto store_slice = [&](unsigned short* st, auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+            unsigned short* Xs = st;
+            unsigned short* Ws = st + NP * XPLANE;
+#pragma unroll
+            for (int i = 0; i < X_PER; ++i) {
+                float4 v = rx[SET][i];
+                if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                unsigned o0[NP], o1[NP];
+                split_pk<MMA>(v.x, v.y, o0);
+                split_pk<MMA>(v.z, v.w, o1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const u32x2 o = {o0[q], o1[q]};
+                    *reinterpret_cast<u32x2*>(&Xs[q * XPLANE + (x_row0 + i * (NT / XC)) * LDS_K + x_chunk * 4]) = o;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int i = 0; i < W_PER; ++i)
+                    *reinterpret_cast<u32x4*>(&Ws[q * WPLANE + (w_row0 + i * (NT / WC)) * LDS_K + w_chunk * 8]) = rw[SET][q][i];
+        };
+        using set0 = std::integral_constant<int, 0>;
+        using set1 = std::integral_constant<int, 1>;
+        // slice g lives in register set (g & 1) and LDS stage (g & 1); steady state at step g: stage slice g + 1, refill its set with g + 3
+        setup();
+        load_slice(set0{});
+        store_slice(S0, set0{});
+        if (n_total > 1) load_slice(set1{});
+        if (n_total > 2) load_slice(set0{});
+        __syncthreads();
+        int g = 0;
+        for (; g + 1 < n_total; g += 2) {
+            store_slice(S1, set1{});                                   // slice g + 1
+            if (g + 3 < n_total && !(p.dbg & 2)) load_slice(set1{});
+            __syncthreads();
+            if (g + 2 < n_total) store_slice(S0, set0{});              // slice g + 2
+            if (g + 4 < n_total && !(p.dbg & 2)) load_slice(set0{});
+            __syncthreads();
+        }
+        if (g < n_total) __syncthreads();                              // odd count: the consumers' last slice
+        return;
+    }
+
+    // ---- consumers
+    const int h = lane >> 5, l31 = lane & 31;
+    float* const es = epi + wave * (32 * LDE);
+    constexpr int C4 = TM * 8, ROWS_PER = 64 / C4;
+    __syncthreads();                                       // slice 0 is staged
+    int g = 0;
+    for (int L = blockIdx.x; L < total; L += G) {
+        int ph, tile_m, tile_n;
+        locate(L, ph, tile_m, tile_n);
+        const int nk = slices_of(ph);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            const unsigned short* Xs = (g & 1) ? S1 : S0;
+            const unsigned short* Ws = Xs + NP * XPLANE;
+            // pinned order (scheduling barriers): products class by class - four MFMAs on four different accumulators - fragment
+            // reads in the order the classes consume them, the second k step's reads between the MFMAs of the first.  Left alone the
+            // scheduler groups the six products of one accumulator: ten dependent MFMAs back to back.
+            constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
+            u32x4 fw[2][NP][TM], fx[2][NP][TN];
+            auto rd = [&](int ks, int qw, int qx) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fw[ks][qw][i] = *reinterpret_cast<const u32x4*>(&Ws[qw * WPLANE + (wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fx[ks][qx][j] = *reinterpret_cast<const u32x4*>(&Xs[qx * XPLANE + (wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mm = [&](int ks, int c) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = Cvt<MMA>::mma(fw[ks][QW[c]][i], fx[ks][QX[c]][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            rd(0, 2, 0); rd(0, 0, 2);
+            mm(0, 0); rd(0, 1, 1);
+            mm(0, 1); rd(1, 2, 0);
+            mm(0, 2); rd(1, 0, 2);
+            mm(0, 3); rd(1, 1, 1);
+            mm(0, 4); mm(0, 5);
+            mm(1, 0); mm(1, 1); mm(1, 2); mm(1, 3); mm(1, 4); mm(1, 5);
+            __syncthreads();
+        }
+        // epilogue through the wave's own LDS area (as conv16_kernel): the producers keep staging the next tile meanwhile
+        const int m0 = tile_m * BMP, n0 = tile_n * BNC;
+        const long long d_off = (ph >> 1) * p.ph_d_h + (ph & 1) * p.ph_d_w;
+        if (p.dbg & 8) continue;
+#pragma unroll
+        for (int jh = 0; jh < TN; ++jh) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = {acc[i][jh][4 * q], acc[i][jh][4 * q + 1], acc[i][jh][4 * q + 2], acc[i][jh][4 * q + 3]};
+                    *reinterpret_cast<float4*>(&es[l31 * LDE + i * 32 + 8 * q + 4 * h]) = v;
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 32 / ROWS_PER; ++it) {
+                const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
+                const int m = m0 + wn * TN * 32 + jh * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
+                if (m >= p.M || col >= p.Ng) continue;
+                float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+                const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+                const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if (p.mask) {
+                    const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+                    v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+                }
+                if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(p.D + off) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- WGRAD kernel
 struct W16 {
     const float* X; const float* DY;
@@ -373,24 +771,33 @@ struct W16 {
     int pq_shift, q_shift;           // log2(P*Q), log2(Q) when both are powers of two, else -1: pixel -> (n,p,q) without integer division
 };
 
-template <int MMA, int TM, int TN, bool RELU_X, bool SPLIT = (TM * TN == 8)>
+// one workgroup per CU, staging woven between the MFMAs: the 256x128 tile
+template <int MMA, int TM, int TN> constexpr bool wgrad16_one_wave() { return TM * TN == 8; }
+// one LDS stage, two workgroups per CU: the 128x128 tile of the split mode (see conv16_single_stage)
+template <int MMA, int TM, int TN> constexpr bool wgrad16_single_stage() { return planes<MMA>() == 3 && TM * TN == 4; }
+
+template <int MMA, int TM, int TN, bool RELU_X, bool SPLIT = wgrad16_one_wave<MMA, TM, TN>()>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
-    // block tile: (2*TM*32) channels of ONE tap  x  (2*TN*32) kout, K slices of 64 pixels
-    constexpr int NT = 256, BKP = 64;
+    // block tile: (2*TM*32) channels of ONE tap  x  (2*TN*32) kout, K slices of 64 pixels (32 in the split mode: three planes per operand)
+    constexpr int NP = planes<MMA>();
+    constexpr int NT = 256, BKP = NP == 3 ? 32 : 64;
+    constexpr int PGS = BKP / 4;                        // groups of 4 pixels per slice
     constexpr int BMC = 2 * TM * 32, BNK = 2 * TN * 32;
     constexpr int LDS_K = BKP + 8;
-    constexpr int STAGE = (BMC + BNK) * LDS_K;
+    constexpr int XPLANE = BMC * LDS_K, YPLANE = BNK * LDS_K;
+    constexpr int STAGE = NP * (XPLANE + YPLANE);       // X planes, then dY planes
     constexpr int XG = BMC / 4;                         // 4-channel groups of the x tile
-    constexpr int X_PER = XG * (BKP / 4) / NT;          // (4 pixels x 4 channels) blocks per thread per slice
+    constexpr int X_PER = XG * PGS / NT;                // (4 pixels x 4 channels) blocks per thread per slice
     constexpr int YG = BNK / 4;
     constexpr int XPG = XG >= 32 ? 8 : 16, YPG = YG >= 32 ? 8 : 16;      // pixel groups a wave's load instruction spans (see the staging map)
-    constexpr int Y_PER = YG * (BKP / 4) / NT;
-    static_assert(XG * (BKP / 4) % NT == 0 && YG * (BKP / 4) % NT == 0 && X_PER >= 1 && Y_PER >= 1, "tile / thread mismatch");
+    constexpr int Y_PER = YG * PGS / NT;
+    static_assert(XG * PGS % NT == 0 && YG * PGS % NT == 0 && X_PER >= 1 && Y_PER >= 1 && XPG <= PGS && YPG <= PGS, "tile / thread mismatch");
     // SPLIT (the one-wave-per-SIMD tile): two DIFFERENT LDS objects for the two stages, see conv16_kernel
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     __shared__ __attribute__((aligned(16))) unsigned short stage0_static[SPLIT ? STAGE : 8];
+    constexpr bool SINGLE = wgrad16_single_stage<MMA, TM, TN>();
     unsigned short* const S0 = SPLIT ? stage0_static : smem;
-    unsigned short* const S1 = SPLIT ? smem : smem + STAGE;
+    unsigned short* const S1 = SPLIT ? smem : (SINGLE ? smem : smem + STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -422,7 +829,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         const int kbase = k_begin + kt * BKP;
 #pragma unroll
         for (int b = 0; b < X_PER; ++b) {
-            const int pg = tid % XPG + XPG * (b % (16 / XPG)), cg = tid / XPG + (NT / XPG) * (b / (16 / XPG));      // 16 pixel groups, XG channel groups
+            const int pg = tid % XPG + XPG * (b % (PGS / XPG)), cg = tid / XPG + (NT / XPG) * (b / (PGS / XPG));      // 16 pixel groups, XG channel groups
             const int pix = kbase + pg * 4;              // 4 consecutive pixels: same image row (Q % 4 == 0)
             const bool inr = pix < k_end;
             const int pc = inr ? pix : 0;
@@ -451,7 +858,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         }
 #pragma unroll
         for (int b = 0; b < Y_PER; ++b) {
-            const int pg = tid % YPG + YPG * (b % (16 / YPG)), cg = tid / YPG + (NT / YPG) * (b / (16 / YPG));
+            const int pg = tid % YPG + YPG * (b % (PGS / YPG)), cg = tid / YPG + (NT / YPG) * (b / (PGS / YPG));
             const int pix = kbase + pg * 4;
             const bool colok = (n0 + cg * 4) < p.Ng;
             const unsigned ybase = ((unsigned)pix * (unsigned)p.Ng + (unsigned)(n0 + cg * 4)) * 4u;
@@ -467,39 +874,38 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     auto store_slice = [&](unsigned short* st, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
         unsigned short* Xs = st;
-        unsigned short* Ys = st + BMC * LDS_K;
+        unsigned short* Ys = st + NP * XPLANE;
+        // transpose by register naming: channel j of pixels 0..3 -> two packed dwords (per plane)
+        auto put = [&](unsigned short* dst, int plane, float a0, float a1, float a2, float a3) {
+            unsigned o0[NP], o1[NP];
+            split_pk<MMA>(a0, a1, o0);
+            split_pk<MMA>(a2, a3, o1);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { const u32x2 o = {o0[q], o1[q]}; *reinterpret_cast<u32x2*>(dst + q * plane) = o; }
+        };
 #pragma unroll
         for (int b = 0; b < X_PER; ++b) {
-            const int pg = tid % XPG + XPG * (b % (16 / XPG)), cg = tid / XPG + (NT / XPG) * (b / (16 / XPG));
+            const int pg = tid % XPG + XPG * (b % (PGS / XPG)), cg = tid / XPG + (NT / XPG) * (b / (PGS / XPG));
             float4 (&v)[4] = rxv[SET][b];
             if (RELU_X) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e].x = fmaxf(v[e].x, 0.f); v[e].y = fmaxf(v[e].y, 0.f); v[e].z = fmaxf(v[e].z, 0.f); v[e].w = fmaxf(v[e].w, 0.f); }
             }
-            // transpose by register naming: channel j of pixels 0..3 -> two packed dwords
-            u32x2 o0 = {Cvt<MMA>::pk(v[0].x, v[1].x), Cvt<MMA>::pk(v[2].x, v[3].x)};
-            u32x2 o1 = {Cvt<MMA>::pk(v[0].y, v[1].y), Cvt<MMA>::pk(v[2].y, v[3].y)};
-            u32x2 o2 = {Cvt<MMA>::pk(v[0].z, v[1].z), Cvt<MMA>::pk(v[2].z, v[3].z)};
-            u32x2 o3 = {Cvt<MMA>::pk(v[0].w, v[1].w), Cvt<MMA>::pk(v[2].w, v[3].w)};
             unsigned short* dst = &Xs[(cg * 4) * LDS_K + pg * 4];
-            *reinterpret_cast<u32x2*>(dst) = o0;
-            *reinterpret_cast<u32x2*>(dst + LDS_K) = o1;
-            *reinterpret_cast<u32x2*>(dst + 2 * LDS_K) = o2;
-            *reinterpret_cast<u32x2*>(dst + 3 * LDS_K) = o3;
+            put(dst, XPLANE, v[0].x, v[1].x, v[2].x, v[3].x);
+            put(dst + LDS_K, XPLANE, v[0].y, v[1].y, v[2].y, v[3].y);
+            put(dst + 2 * LDS_K, XPLANE, v[0].z, v[1].z, v[2].z, v[3].z);
+            put(dst + 3 * LDS_K, XPLANE, v[0].w, v[1].w, v[2].w, v[3].w);
         }
 #pragma unroll
         for (int b = 0; b < Y_PER; ++b) {
-            const int pg = tid % YPG + YPG * (b % (16 / YPG)), cg = tid / YPG + (NT / YPG) * (b / (16 / YPG));
+            const int pg = tid % YPG + YPG * (b % (PGS / YPG)), cg = tid / YPG + (NT / YPG) * (b / (PGS / YPG));
             const float4 (&v)[4] = ryv[SET][b];
-            u32x2 o0 = {Cvt<MMA>::pk(v[0].x, v[1].x), Cvt<MMA>::pk(v[2].x, v[3].x)};
-            u32x2 o1 = {Cvt<MMA>::pk(v[0].y, v[1].y), Cvt<MMA>::pk(v[2].y, v[3].y)};
-            u32x2 o2 = {Cvt<MMA>::pk(v[0].z, v[1].z), Cvt<MMA>::pk(v[2].z, v[3].z)};
-            u32x2 o3 = {Cvt<MMA>::pk(v[0].w, v[1].w), Cvt<MMA>::pk(v[2].w, v[3].w)};
             unsigned short* dst = &Ys[(cg * 4) * LDS_K + pg * 4];
-            *reinterpret_cast<u32x2*>(dst) = o0;
-            *reinterpret_cast<u32x2*>(dst + LDS_K) = o1;
-            *reinterpret_cast<u32x2*>(dst + 2 * LDS_K) = o2;
-            *reinterpret_cast<u32x2*>(dst + 3 * LDS_K) = o3;
+            put(dst, YPLANE, v[0].x, v[1].x, v[2].x, v[3].x);
+            put(dst + LDS_K, YPLANE, v[0].y, v[1].y, v[2].y, v[3].y);
+            put(dst + 2 * LDS_K, YPLANE, v[0].z, v[1].z, v[2].z, v[3].z);
+            put(dst + 3 * LDS_K, YPLANE, v[0].w, v[1].w, v[2].w, v[3].w);
         }
     };
 
@@ -513,20 +919,33 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
 
     const int h = lane >> 5, l31 = lane & 31;
     auto mma_slice = [&](const unsigned short* Xs) {
-        const unsigned short* Ys = Xs + BMC * LDS_K;
+        const unsigned short* Ys = Xs + NP * XPLANE;
 #pragma unroll
         for (int ks = 0; ks < BKP / 16; ++ks) {
-            u32x4 fa[TM], fb[TN];
+            u32x4 fa[NP][TM], fb[NP][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const u32x4*>(&Xs[(wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const u32x4*>(&Ys[(wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+                for (int i = 0; i < TM; ++i)
+                    fa[q][i] = *reinterpret_cast<const u32x4*>(&Xs[q * XPLANE + (wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j)
+                    fb[q][j] = *reinterpret_cast<const u32x4*>(&Ys[q * YPLANE + (wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+            }
+            if constexpr (NP == 1) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fa[i], fb[j], acc[i][j]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fa[0][i], fb[0][j], acc[i][j]);
+            } else {
+                constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // small products first (see conv16_kernel)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = Cvt<MMA>::mma(fa[QA[c]][i], fb[QB[c]][j], acc[i][j]);
+            }
         }
     };
     using set0 = std::integral_constant<int, 0>;
@@ -543,9 +962,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
             store_slice(wr, set_c);                       // slice k+1
             load_slice(k + 3, set_c);                     // slice k+3 into the registers just drained (out-of-range rows read as zeros)
             mma_slice(rd);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NP * (TM + TN), 0);
 #pragma unroll
-            for (int g = 0; g < TM * TN * (BKP / 16); ++g) {
+            for (int g = 0; g < (NP == 3 ? 6 : 1) * TM * TN * (BKP / 16); ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // VALU (conversions, addresses, halo checks)
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
@@ -568,11 +987,23 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
             if (nk > 1) load_slice(1, set0{});
         }
         __syncthreads();
-        for (; kt < nk; ++kt) {
-            if (kt + 1 < nk && !(p.dbg & 1)) store_slice((kt + 1) & 1 ? S1 : S0, set0{});
-            if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2, set0{});
-            mma_slice(kt & 1 ? S1 : S0);
-            if (!(p.dbg & 4)) __syncthreads();
+        if constexpr (SINGLE) {
+            for (; kt < nk; ++kt) {
+                mma_slice(S0);
+                if (kt + 1 < nk) {
+                    __syncthreads();                       // every wave has read slice kt
+                    store_slice(S0, set0{});
+                    if (kt + 2 < nk) load_slice(kt + 2, set0{});
+                    __syncthreads();
+                }
+            }
+        } else {
+            for (; kt < nk; ++kt) {
+                if (kt + 1 < nk && !(p.dbg & 1)) store_slice((kt + 1) & 1 ? S1 : S0, set0{});
+                if (kt + 2 < nk && !(p.dbg & 2)) load_slice(kt + 2, set0{});
+                mma_slice(kt & 1 ? S1 : S0);
+                if (!(p.dbg & 4)) __syncthreads();
+            }
         }
     }
     // acc[i][j][4g + e] = dW(channel c0 + wm*TM*32 + i*32 + 8g + 4h + e, kout n0 + wn*TN*32 + j*32 + l31): 32 lanes = 128 B rows
@@ -610,7 +1041,8 @@ __global__ void reduce16_kernel(const float* __restrict__ part, float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------- host side
-bool mma_ok(int mma) { return mma == CTGAN_MMA_BF16 || mma == CTGAN_MMA_F16; }
+bool mma_ok(int mma) { return mma == CTGAN_MMA_BF16 || mma == CTGAN_MMA_F16 || mma == CTGAN_MMA_F32X3; }
+int mma_planes(int mma) { return mma == CTGAN_MMA_F32X3 ? 3 : 1; }
 int dbg16() { static const int v = [] { const char* e = getenv("CTGAN_DBG16"); return e ? atoi(e) : 0; }(); return v; }
 
 bool shape_ok_fwd(const ctgan_conv_desc* d) {
@@ -669,9 +1101,9 @@ int conv16_ksplit(long long blocks, int nk) {
 template <int MMA, int TM, int TN, int BK>
 int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     constexpr int BMP = 2 * TN * 32, BNC = 2 * TM * 32;
-    constexpr bool split = TM * TN >= 8;            // one stage is a static array (see the kernel)
-    constexpr size_t lds_stages = (size_t)(split ? 1 : 2) * (BMP + BNC) * (BK + 8) * 2;
-    constexpr size_t lds_epi = (size_t)4 * (TM >= 4 ? 1 : (TN > 2 ? 2 : TN)) * 32 * (TM * 32 + 4) * 4;
+    constexpr bool split = conv16_one_wave<MMA, TM, TN>();            // one stage is a static array (see the kernel)
+    constexpr size_t lds_stages = (size_t)((split || conv16_single_stage<MMA, TM, TN>()) ? 1 : 2) * planes<MMA>() * (BMP + BNC) * (BK + 8) * 2;
+    constexpr size_t lds_epi = (size_t)4 * conv16_je<MMA, TM, TN>() * 32 * (TM * 32 + 4) * 4;
     constexpr size_t lds = lds_stages > lds_epi ? lds_stages : lds_epi;
     auto kern = p.relu_in ? conv16_kernel<MMA, TM, TN, BK, true> : conv16_kernel<MMA, TM, TN, BK, false>;
     static bool attr[2] = {false, false};
@@ -685,13 +1117,33 @@ int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     q.ph_tiles_m = tiles_m;
     q.dbg = dbg16();
     if (!(q.ksplit > 1 && q.slab)) { q.ksplit = 1; q.slab = nullptr; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n), (unsigned)q.ksplit), dim3(256), lds, st, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n), (unsigned)q.ksplit), dim3(conv16_ws<MMA, TM, TN>() ? 512 : 256), lds, st, q);
     ctgan_set_last_kernel(name);
     int rc = ctgan_check_launch(name);
     if (rc || q.ksplit == 1) return rc;
     const long long n = (long long)q.nph * q.M * (q.Ng / 4);
     hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q);
     return ctgan_check_launch("conv16_splitk_epilogue");
+}
+
+int launch_conv16x3p(const P16& p, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * 3 * (128 + 128) * (32 + 8) * 2 + (size_t)4 * 32 * (64 + 4) * 4;      // two stages + the consumers' epilogue areas
+    auto kern = p.relu_in ? conv16x3p_kernel<true> : conv16x3p_kernel<false>;
+    static bool attr[2] = {false, false};
+    if (!attr[p.relu_in ? 1 : 0]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3p: cannot reserve %zu B of LDS", lds);
+        attr[p.relu_in ? 1 : 0] = true;
+    }
+    P16 q = p;
+    q.ph_tiles_m = (p.M + 127) / 128;
+    q.dbg = dbg16();
+    q.ksplit = 1; q.slab = nullptr;
+    const long long total = (long long)q.nph * q.ph_tiles_m * ((p.Ng + 127) / 128);
+    static const int cus = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, q);
+    ctgan_set_last_kernel("conv16x3p<128x128,k32>");
+    return ctgan_check_launch("conv16x3p<128x128,k32>");
 }
 
 template <int MMA>
@@ -705,7 +1157,7 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
     P16 q = p;
     q.ksplit = 1;
     if (small && p.slab) {
-        const int bk = p.C % 64 == 0 ? 64 : 32;
+        const int bk = (p.C % 64 == 0 && planes<MMA>() == 1) ? 64 : 32;
         int nk_min = 1 << 30;
         for (int ph = 0; ph < p.nph; ++ph) { const int nk = p.ph_T[ph >> 1] * p.ph_U[ph & 1] * (p.C / bk); if (nk < nk_min) nk_min = nk; }
         const long long blocks = (long long)p.nph * ((p.M + 63) / 64) * ((p.Ng + 63) / 64);
@@ -718,6 +1170,13 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
 
 template <int MMA>
 int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
+    if constexpr (planes<MMA>() == 3) {
+        // split mode: three planes per operand in LDS - 32-deep slices; the 128x128 tile keeps ONE 60 KB stage (two workgroups per CU)
+        if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16x3<64x64,k32,ksplit>" : "conv16x3<64x64,k32>");
+        static const int persist = [] { const char* e = getenv("CTGAN_X3_PERSIST"); return e ? atoi(e) : 1; }();
+        if (persist) return launch_conv16x3p(p, st);
+        return launch_conv16<MMA, 2, 2, 32>(p, st, "conv16x3<128x128,k32>");
+    } else
     if (p.C % 64 == 0) {
         if (small) return launch_conv16<MMA, 1, 1, 64>(p, st, p.ksplit > 1 ? "conv16<64x64,k64,ksplit>" : "conv16<64x64,k64>");
         // EXPERIMENT, off by default (CTGAN_CONV16_WIDE=1): 2x4 accumulators per wave (128 kout x 256 pixels per workgroup, one wave
@@ -739,10 +1198,17 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
     return launch_conv16<MMA, 2, 2, 32>(p, st, "conv16<128x128,k32>");
 }
 
+int run_conv16(int mma, const P16& p, hipStream_t st) {
+    if (mma == CTGAN_MMA_BF16) return dispatch_conv16<CTGAN_MMA_BF16>(p, st);
+    if (mma == CTGAN_MMA_F16) return dispatch_conv16<CTGAN_MMA_F16>(p, st);
+    return dispatch_conv16<CTGAN_MMA_F32X3>(p, st);
+}
+
 template <int MMA, int TM, int TN>
 int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
     constexpr int BMC = 2 * TM * 32, BNK = 2 * TN * 32;
-    constexpr size_t lds = (size_t)(TM * TN == 8 ? 1 : 2) * (BMC + BNK) * (64 + 8) * 2;      // the 256x128 tile keeps one stage in a static array
+    constexpr int bkp = planes<MMA>() == 3 ? 32 : 64;
+    constexpr size_t lds = (size_t)((wgrad16_one_wave<MMA, TM, TN>() || wgrad16_single_stage<MMA, TM, TN>()) ? 1 : 2) * planes<MMA>() * (BMC + BNK) * (bkp + 8) * 2;      // the one-wave tiles keep one stage in a static array
     auto kern = p.relu_x ? wgrad16_kernel<MMA, TM, TN, true> : wgrad16_kernel<MMA, TM, TN, false>;
     static bool attrs[2] = {false, false};
     bool& attr = attrs[p.relu_x ? 1 : 0];
@@ -758,11 +1224,16 @@ int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
 }
 
 struct WPlan16 { int bmc, bnk, tiles, splits, chunk; };
-WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
+bool pow2_grid(const ctgan_conv_desc* d) { const int pq = d->P * d->Q; return !(pq & (pq - 1)) && !(d->Q & (d->Q - 1)); }
+// the split mode has the 128x128 tile only (three planes per operand: one 60 KB stage), for power-of-two pixel grids
+bool shape_ok_wgrad_x3(const ctgan_conv_desc* d) { return d->C % 128 == 0 && d->K % 128 == 0 && pow2_grid(d); }
+
+WPlan16 wgrad16_plan(const ctgan_conv_desc* d, int mma) {
     WPlan16 w;
     w.bmc = d->C % 128 == 0 ? 128 : 64;
     w.bnk = d->K % 128 == 0 ? 128 : 64;
-    static const int wide = [] { const char* e = getenv("CTGAN_WGRAD16_WIDE"); return e ? atoi(e) : 2; }();
+    static const int wide_env = [] { const char* e = getenv("CTGAN_WGRAD16_WIDE"); return e ? atoi(e) : 2; }();
+    const int wide = mma == CTGAN_MMA_F32X3 ? 0 : wide_env;
     const int pq = d->P * d->Q;
     // 4x2 accumulators per wave (256 x 128): 0.75 operand bytes per MFMA of the 128x128 tile
     if (wide && d->C % 256 == 0 && d->K % 128 == 0 && !(pq & (pq - 1)) && !(d->Q & (d->Q - 1))) w.bmc = 256;
@@ -795,28 +1266,30 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d) {
 
 extern "C" {
 
-int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op) {
-    if (!d) return 0;
+int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
+    if (!d || !mma_ok(mma)) return 0;
     if (op == CTGAN_CONV_FWD) return shape_ok_fwd(d) ? 1 : 0;
     if (op == CTGAN_CONV_DGRAD) return shape_ok_dgrad(d) ? 1 : 0;
-    if (op == CTGAN_CONV_WGRAD) return shape_ok_wgrad(d) ? 1 : 0;
+    if (op == CTGAN_CONV_WGRAD) return (shape_ok_wgrad(d) && (mma != CTGAN_MMA_F32X3 || shape_ok_wgrad_x3(d))) ? 1 : 0;
     return 0;
 }
 
-size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op) {
-    if (!d) return 0;
-    return (size_t)d->R * d->S * d->C * d->K;          // both layouts hold every tap exactly once (no zero-padded phases)
+size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op, int mma) {
+    if (!d || !mma_ok(mma)) return 0;
+    return (size_t)mma_planes(mma) * d->R * d->S * d->C * d->K;          // both layouts hold every tap exactly once (no zero-padded phases)
 }
 
 int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream) {
     if (!d || !w || !wp || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_filter: bad argument");
     hipStream_t st = (hipStream_t)stream;
     unsigned short* out = (unsigned short*)wp;
+    const long long plane = (long long)d->R * d->S * d->C * d->K;
     if (op == CTGAN_CONV_FWD) {
         if (d->C % 2) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_filter: odd channel count");
         const long long total = (long long)d->R * d->S * d->C / 2 * d->K;
-        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K);
-        else hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K);
+        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane);
+        else if (mma == CTGAN_MMA_F16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane);
+        else hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F32X3>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane);
         return ctgan_check_launch("pack16_fwd");
     }
     if (op == CTGAN_CONV_DGRAD) {
@@ -831,8 +1304,9 @@ int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const 
             const long long n = (long long)d->C * g.T[ph >> 1] * g.U[ph & 1] * d->K / 2;
             if (n > most) most = n;
         }
-        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_dgrad_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(most, 256), g.nph), dim3(256), 0, st, w, out, pp);
-        else hipLaunchKernelGGL(pack_dgrad_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(most, 256), g.nph), dim3(256), 0, st, w, out, pp);
+        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_dgrad_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(most, 256), g.nph), dim3(256), 0, st, w, out, pp, plane);
+        else if (mma == CTGAN_MMA_F16) hipLaunchKernelGGL(pack_dgrad_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(most, 256), g.nph), dim3(256), 0, st, w, out, pp, plane);
+        else hipLaunchKernelGGL(pack_dgrad_kernel<CTGAN_MMA_F32X3>, dim3(ctgan_blocks(most, 256), g.nph), dim3(256), 0, st, w, out, pp, plane);
         return ctgan_check_launch("pack16_dgrad");
     }
     return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_filter: op %d", op);
@@ -852,7 +1326,8 @@ int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const 
     if (!d || !x || !wp || !y || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_fwd: bad argument");
     if (!shape_ok_fwd(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: shape outside the 16-bit family");
     const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
-    if (x_extent * 4 >= (1LL << 32) || (long long)d->R * d->S * d->C * d->K * 2 >= (1LL << 32))
+    const long long w_plane = (long long)d->R * d->S * d->C * d->K * 2;
+    if (x_extent * 4 >= (1LL << 32) || w_plane * mma_planes(mma) >= (1LL << 32))
         return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: operand exceeds the 4 GiB buffer range");
     P16 p{};
     p.X = x; p.Wp = (const unsigned short*)wp; p.bias = bias; p.resid = resid; p.mask = nullptr; p.D = y;
@@ -861,13 +1336,13 @@ int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const 
     p.M = d->N * d->P * d->Q; p.Ng = d->K;
     p.ds_n = d->ys[0]; p.ds_p = d->ys[2]; p.ds_q = d->ys[3];
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
-    p.x_bytes = (unsigned)(x_extent * 4); p.w_bytes = (unsigned)((long long)d->R * d->S * d->C * d->K * 2);
+    p.x_bytes = (unsigned)(x_extent * 4); p.w_plane_bytes = (unsigned)w_plane; p.w_bytes = (unsigned)(w_plane * mma_planes(mma));
     p.nph = 1;
     p.slab = (float*)ws; p.slab_bytes = ws ? ws_bytes : 0;
     p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
     p.ph_T[1] = d->R; p.ph_U[1] = d->S; p.ph_pad_t[1] = d->pad_t; p.ph_pad_l[1] = d->pad_l;
     hipStream_t st = (hipStream_t)stream;
-    return mma == CTGAN_MMA_BF16 ? dispatch_conv16<CTGAN_MMA_BF16>(p, st) : dispatch_conv16<CTGAN_MMA_F16>(p, st);
+    return run_conv16(mma, p, st);
 }
 
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias, const float* mask,
@@ -875,7 +1350,8 @@ int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, con
     if (!d || !dy || !wp || !dx || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_dgrad: bad argument");
     if (!shape_ok_dgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad: shape outside the 16-bit family");
     const long long y_extent = (long long)(d->N - 1) * d->ys[0] + (long long)(d->P - 1) * d->ys[2] + (long long)(d->Q - 1) * d->ys[3] + d->K;
-    if (y_extent * 4 >= (1LL << 32) || (long long)d->R * d->S * d->C * d->K * 2 >= (1LL << 32))
+    const long long w_plane = (long long)d->R * d->S * d->C * d->K * 2;
+    if (y_extent * 4 >= (1LL << 32) || w_plane * mma_planes(mma) >= (1LL << 32))
         return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad: operand exceeds the 4 GiB buffer range");
     const PhaseGeom g = phase_geom(d);
     P16 p{};
@@ -885,7 +1361,7 @@ int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, con
     p.s_n = d->ys[0]; p.s_h = d->ys[2]; p.s_w = d->ys[3];
     p.Ng = d->C;
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = 0;
-    p.x_bytes = (unsigned)(y_extent * 4); p.w_bytes = (unsigned)((long long)d->R * d->S * d->C * d->K * 2);
+    p.x_bytes = (unsigned)(y_extent * 4); p.w_plane_bytes = (unsigned)w_plane; p.w_bytes = (unsigned)(w_plane * mma_planes(mma));
     p.nph = g.nph;
     p.slab = (float*)ws; p.slab_bytes = ws ? ws_bytes : 0;
     for (int a = 0; a < 2; ++a) { p.ph_T[a] = g.T[a]; p.ph_U[a] = g.U[a]; p.ph_pad_t[a] = g.pad_t[a]; p.ph_pad_l[a] = g.pad_l[a]; }
@@ -901,25 +1377,25 @@ int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, con
     }
     p.M = d->N * p.P * p.Q;
     hipStream_t st = (hipStream_t)stream;
-    return mma == CTGAN_MMA_BF16 ? dispatch_conv16<CTGAN_MMA_BF16>(p, st) : dispatch_conv16<CTGAN_MMA_F16>(p, st);
+    return run_conv16(mma, p, st);
 }
 
-size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d) {
-    if (!d || !shape_ok_wgrad(d)) return 0;
-    const WPlan16 w = wgrad16_plan(d);
+size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d, int mma) {
+    if (!d || !ctgan_conv2d16_supported(d, CTGAN_CONV_WGRAD, mma)) return 0;
+    const WPlan16 w = wgrad16_plan(d, mma);
     return w.splits > 1 ? (size_t)w.splits * d->R * d->S * d->C * d->K * sizeof(float) : 0;
 }
 
 int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
                          int flags, ctgan_stream_t stream) {
     if (!d || !x || !dy || !dw || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad: bad argument");
-    if (!shape_ok_wgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: shape outside the 16-bit family");
+    if (!ctgan_conv2d16_supported(d, CTGAN_CONV_WGRAD, mma)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: shape outside the 16-bit family");
     const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
     const long long y_extent = (long long)d->N * d->P * d->Q * d->K;
     if (x_extent * 4 >= (1LL << 32) || y_extent * 4 >= (1LL << 32))
         return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: operand exceeds the 4 GiB buffer range");
-    const WPlan16 w = wgrad16_plan(d);
-    const size_t need = ctgan_conv2d16_wgrad_workspace_bytes(d);
+    const WPlan16 w = wgrad16_plan(d, mma);
+    const size_t need = ctgan_conv2d16_wgrad_workspace_bytes(d, mma);
     if (need > ws_bytes || (need && !ws)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad: workspace %zu B < %zu B", ws_bytes, need);
     W16 p{};
     p.X = x; p.DY = dy; p.OUT = w.splits > 1 ? (float*)ws : dw;
@@ -938,7 +1414,8 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const bool bf = mma == CTGAN_MMA_BF16;
-    if (w.bmc == 256 && w.bnk == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 4>(p, w.splits, st, "wgrad16<256x256>") : launch_wgrad16<CTGAN_MMA_F16, 4, 4>(p, w.splits, st, "wgrad16<256x256>");
+    if (mma == CTGAN_MMA_F32X3) rc = launch_wgrad16<CTGAN_MMA_F32X3, 2, 2>(p, w.splits, st, "wgrad16x3<128x128>");
+    else if (w.bmc == 256 && w.bnk == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 4>(p, w.splits, st, "wgrad16<256x256>") : launch_wgrad16<CTGAN_MMA_F16, 4, 4>(p, w.splits, st, "wgrad16<256x256>");
     else if (w.bmc == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 2>(p, w.splits, st, "wgrad16<256x128>") : launch_wgrad16<CTGAN_MMA_F16, 4, 2>(p, w.splits, st, "wgrad16<256x128>");
     else if (w.bmc == 128 && w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 2>(p, w.splits, st, "wgrad16<128x128>") : launch_wgrad16<CTGAN_MMA_F16, 2, 2>(p, w.splits, st, "wgrad16<128x128>");
     else if (w.bmc == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 2, 1>(p, w.splits, st, "wgrad16<128x64>") : launch_wgrad16<CTGAN_MMA_F16, 2, 1>(p, w.splits, st, "wgrad16<128x64>");

@@ -9,6 +9,7 @@ No CPU fallback: every wrapper raises on a non-HIP tensor.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -59,17 +60,17 @@ def _ptr(t):
 # None: every conv runs on the exact-fp32 MFMA family.  'bf16' / 'f16': the layers the 16-bit family takes (channel counts that
 # are multiples of 32 / 64, even extents for stride-2 data gradients) multiply in bf16 / fp16 with fp32 accumulation; tensors
 # stay fp32 in HBM, filters are packed to 16 bits once per weight version.  Few-channel layers and everything else stay fp32.
-MMA_DTYPE = None
-_MMA_CODE = {'bf16': 1, 'f16': 2}
+MMA_DTYPE = os.environ.get('CTGAN_MMA') or None      # experiments: start in a 16-bit mode without touching the caller
+_MMA_CODE = {'bf16': 1, 'f16': 2, 'f32x3': 3}
 _STABLE_PTRS = set()      # data_ptr of derived fp32 filters (spread filters) whose contents only change with the registry epoch
 _pack16 = {}              # (data_ptr, op, dtype, geometry) -> [packed int16 buffer, registry epoch it was built for]
 
 
 def set_mma_dtype(name):
-    """name: None | 'bf16' | 'f16'.  Returns the previous setting."""
+    """name: None | 'bf16' | 'f16' | 'f32x3'.  Returns the previous setting."""
     global MMA_DTYPE
-    if name not in (None, 'bf16', 'f16'):
-        raise ValueError("mma dtype must be None, 'bf16' or 'f16'")
+    if name is not None and name not in _MMA_CODE:
+        raise ValueError("mma dtype must be None, 'bf16', 'f16' or 'f32x3'")
     old, MMA_DTYPE = MMA_DTYPE, name
     return old
 
@@ -96,7 +97,7 @@ def _packed16(w, d, op, g):
     """The 16-bit packed image of filter `w` for op (0 fwd, 1 dgrad) - cached per registry epoch for parameters and for derived
     filters registered in _STABLE_PTRS; packed per call for any other tensor."""
     from . import tflib
-    n = lib.ctgan_conv2d16_filter_elems(ctypes.byref(d), op)
+    n = lib.ctgan_conv2d16_filter_elems(ctypes.byref(d), op, _MMA_CODE[MMA_DTYPE])
     stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _STABLE_PTRS
     key = (w.data_ptr(), op, MMA_DTYPE, g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     ver = tflib.epoch()
@@ -275,7 +276,7 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
     d = g.desc(N, x.stride(), y.stride())
     fl = (1 if relu else 0) | (2 if relu_in else 0) | (8 if (resid_up and resid is not None) else 0)
     if (MMA_DTYPE is not None and drop is None and not (fl & 8) and not fewch_handles(g)
-            and lib.ctgan_conv2d16_supported(ctypes.byref(d), 0)):
+            and lib.ctgan_conv2d16_supported(ctypes.byref(d), 0, _MMA_CODE[MMA_DTYPE])):
         wp = _packed16(w, d, 0, g)
         code = _MMA_CODE[MMA_DTYPE]
         nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), 0)
@@ -335,7 +336,7 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
         mask = match_layout(mask, dx)
     if resid is not None:
         resid = match_layout(resid, dx)
-    if (MMA_DTYPE is not None and drop is None and not fewch_handles(g) and lib.ctgan_conv2d16_supported(ctypes.byref(d), 1)):
+    if (MMA_DTYPE is not None and drop is None and not fewch_handles(g) and lib.ctgan_conv2d16_supported(ctypes.byref(d), 1, _MMA_CODE[MMA_DTYPE])):
         wp = _packed16(w, d, 1, g)
         code = _MMA_CODE[MMA_DTYPE]
         nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), 1)
@@ -372,8 +373,8 @@ def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
     if MMA_DTYPE is not None and not fewch_handles(g):
         gy16 = gy if gy.permute(0, 2, 3, 1).is_contiguous() else to_channels_last(gy)
         d16 = g.desc(N, x.stride(), gy16.stride())
-        if lib.ctgan_conv2d16_supported(ctypes.byref(d16), 2):
-            ws = workspace(lib.ctgan_conv2d16_wgrad_workspace_bytes(ctypes.byref(d16)), x.device)
+        if lib.ctgan_conv2d16_supported(ctypes.byref(d16), 2, _MMA_CODE[MMA_DTYPE]):
+            ws = workspace(lib.ctgan_conv2d16_wgrad_workspace_bytes(ctypes.byref(d16), _MMA_CODE[MMA_DTYPE]), x.device)
             code = _MMA_CODE[MMA_DTYPE]
             _timed(g, N, lambda: check(lib.ctgan_conv2d16_wgrad(ctypes.byref(d16), code, _ptr(x), _ptr(gy16), _ptr(dw), _ptr(ws), ws.numel(), 2 if relu_x else 0, _stream()), 'conv2d16_wgrad'))
             if with_bias:

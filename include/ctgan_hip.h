@@ -178,9 +178,14 @@ int ctgan_layernorm_bwd2(const float* u, const float* gy, const float* x, const 
  * Epilogues as the fp32 family: fwd  y = [relu](conv(x | relu(x)) + bias + resid);  dgrad  dx = (conv^T(dy) + bias)
  * [kept where mask > 0] [+ resid].  flags = CTGAN_EPI_RELU | CTGAN_IN_RELU.  The bias gradient is not fused here
  * (ctgan_colsum).                                                                                                     */
-enum { CTGAN_MMA_BF16 = 1, CTGAN_MMA_F16 = 2 };
-int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op);                 /* op = CTGAN_CONV_{FWD,DGRAD,WGRAD}; 1 / 0 */
-size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op);           /* 16-bit elements of the packed filter     */
+/* CTGAN_MMA_F32X3: fp32 arithmetic on the bf16 matrix cores.  Every fp32 operand is split exactly into three bf16 terms
+ * (x = h + m + l, nearest-even at each level: 24 significand bits) while it is staged, and a product is the six bf16 MFMAs
+ * hh + hm + mh + mm + hl + lh accumulated in fp32 - the dropped terms are below 2^-24 relative, i.e. the result carries fp32
+ * rounding accuracy (measured against an fp64 reference it is as close as the fp32 MFMA family), at 6/16 of the fp32 MFMA's
+ * cycle cost.  The packed filter holds the three planes one after the other.                                               */
+enum { CTGAN_MMA_BF16 = 1, CTGAN_MMA_F16 = 2, CTGAN_MMA_F32X3 = 3 };
+int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma);        /* op = CTGAN_CONV_{FWD,DGRAD,WGRAD}; 1 / 0 */
+size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op, int mma);  /* 16-bit elements of the packed filter     */
 int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream);
 /* ws (optional, ctgan_conv2d16_workspace_bytes(d, op) bytes): slabs for a K split of launches whose pixel x channel tiles cannot
  * fill the chip (8x8 / 4x4 layers at batch 64); NULL = never split.                                                      */
@@ -190,7 +195,7 @@ int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const 
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias,
                          const float* mask, const float* resid, float* dx, int flags, void* ws, size_t ws_bytes,
                          ctgan_stream_t stream);
-size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d);
+size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d, int mma);
 int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws,
                          size_t ws_bytes, int flags, ctgan_stream_t stream);
 /* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K);

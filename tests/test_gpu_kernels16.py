@@ -114,6 +114,53 @@ def test_conv16_fwd_dgrad_wgrad(K, case, dt):
                 ok, e, what = tol(gw2, gw2_ref, 'wgrad relu_x'); assert ok, (what, e)
 
 
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d' % c)
+def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
+    """'f32x3': every fp32 operand split exactly into three bf16 terms, six bf16 MFMAs per product, fp32 accumulation.  With generic
+    fp32 operands its distance to the fp64 truth must be fp32 rounding noise - no larger than twice that of the fp32 MFMA family on
+    the same inputs (floor 3e-7: both sit at a few 1e-8 .. 1e-7) - forward, data gradient (with epilogues) and weight gradient."""
+    N, C, H, W, Ko, k, st = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 1000 + 7)
+    geom = K.ConvGeom(C, H, W, Ko, k, k, st, False)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)
+    b = torch.randn(Ko, generator=g)
+    gy = torch.randn(N, Ko, geom.P, geom.Q, generator=g)
+    r = torch.randn(N, Ko, geom.P, geom.Q, generator=g)
+    bc = torch.randn(C, generator=g); m = torch.randn(N, C, H, W, generator=g); rr = torch.randn(N, C, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    ref = tf_ops.bias_add_nchw(tf_ops.conv2d_same(xr, wr, st), b.double())
+    gx_ref, gw_ref = torch.autograd.grad(ref, [xr, wr], gy.double())
+    ref2 = torch.relu(tf_ops.bias_add_nchw(tf_ops.conv2d_same(torch.relu(x.double()), w.double(), st), b.double()) + r.double())
+    ref_gx2 = torch.where(m.double() > 0, gx_ref + bc.double().view(1, -1, 1, 1), torch.zeros_like(gx_ref)) + rr.double()
+    xd, wd, bd, gyd = cl(x), w.cuda(), b.cuda(), cl(gy)
+
+    def run():
+        out = {'fwd': K.conv_fwd(xd, wd, bd, geom)}
+        kern = {'fwd': K.last_kernel()}
+        out['fwd+epi'] = K.conv_fwd(xd, wd, bd, geom, resid=cl(r), relu=True, relu_in=True)
+        out['dgrad'] = K.conv_dgrad(gyd, wd, geom, N)
+        kern['dgrad'] = K.last_kernel()
+        out['dgrad+epi'] = K.conv_dgrad(gyd, wd, geom, N, bias=bc.cuda(), mask=cl(m), resid=cl(rr))
+        out['wgrad'] = K.conv_wgrad(xd, gyd, geom)
+        kern['wgrad'] = K.last_kernel()
+        return out, kern
+    want = {'fwd': ref, 'fwd+epi': ref2, 'dgrad': gx_ref, 'dgrad+epi': ref_gx2, 'wgrad': gw_ref}
+    with K.mma_dtype('f32x3'):
+        got3, kern3 = run()
+    got1, _ = run()
+    assert kern3['fwd'].startswith('conv16x3') and kern3['dgrad'].startswith('conv16x3'), kern3
+    pq = geom.P * geom.Q
+    if C % 128 == 0 and Ko % 128 == 0 and geom.Q % 4 == 0 and not (pq & (pq - 1)) and not (geom.Q & (geom.Q - 1)):
+        assert kern3['wgrad'].startswith('wgrad16x3') or kern3['wgrad'].startswith('reduce16'), kern3
+    for what in want:
+        e3, e1 = rel_l2(got3[what], want[what]), rel_l2(got1[what], want[what])
+        assert e3 <= max(2.0 * e1, 3e-7), (what, e3, e1)
+        m3, m1 = relerr(got3[what], want[what]), relerr(got1[what], want[what])
+        assert m3 <= max(3.0 * m1, 1e-6), (what, m3, m1)
+
+
 def test_conv16_wgrad_runs_on_the_16bit_kernel_and_is_deterministic(K):
     N, C, H, Ko = 16, 128, 16, 256
     geom = K.ConvGeom(C, H, H, Ko, 5, 5, 2, False)

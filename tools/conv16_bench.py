@@ -9,7 +9,14 @@ import ctgan_amd.kernels as K
 
 SHAPES = [(192, 1024, 8, 8, 1024, 3, 1), (192, 128, 64, 64, 128, 3, 1), (192, 256, 32, 32, 256, 3, 1), (192, 128, 64, 64, 256, 3, 2),
           (64, 256, 8, 8, 512, 5, 2), (192, 128, 16, 16, 256, 5, 2), (64, 1024, 8, 8, 1024, 3, 1)]
+# the headline's layers (CIFAR ResNet critic over 3B = 192 rows / GP pass over 64, DIM 128; 4x4 stride 2 = the folded ConvMeanPool)
+RESNET = [(192, 128, 32, 32, 128, 3, 1), (192, 128, 32, 32, 128, 4, 2), (192, 128, 16, 16, 128, 3, 1), (192, 128, 16, 16, 128, 4, 2),
+          (192, 128, 8, 8, 128, 3, 1), (64, 128, 32, 32, 128, 3, 1), (64, 128, 16, 16, 128, 3, 1), (64, 128, 8, 8, 128, 3, 1)]
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f16'
+if len(sys.argv) > 2 and sys.argv[2] == 'resnet':
+    SHAPES = RESNET
+if dt == 'f32':
+    dt = None
 
 
 def timed(fn, reps=20):
@@ -28,6 +35,7 @@ for N, C, H, W, Ko, R, st in SHAPES:
     g = K.ConvGeom(C, H, W, Ko, R, R, st, False)
     x = K.empty_cl(N, C, H, W, 'cuda').normal_()
     w = (torch.randn(R, R, C, Ko, device='cuda') * 0.02)
+    K._STABLE_PTRS.add(w.data_ptr())          # packed once, as a parameter would be
     gy = K.empty_cl(N, Ko, g.P, g.Q, 'cuda').normal_()
     fl = 2.0 * N * g.P * g.Q * Ko * R * R * C
     with K.mma_dtype(dt):

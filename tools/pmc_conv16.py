@@ -12,6 +12,7 @@ dt = sys.argv[9] if len(sys.argv) > 9 else 'f16'
 g = K.ConvGeom(C, H, H, Ko, R, R, st, False)
 x = K.empty_cl(N, C, H, H, 'cuda').normal_()
 w = torch.randn(R, R, C, Ko, device='cuda') * 0.02
+K._STABLE_PTRS.add(w.data_ptr())
 gy = K.empty_cl(N, Ko, g.P, g.Q, 'cuda').normal_()
 with K.mma_dtype(dt if dt != 'f32' else None):
     for _ in range(reps):
