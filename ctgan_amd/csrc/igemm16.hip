@@ -757,6 +757,287 @@ __global__ __launch_bounds__(512) void conv16x3p_kernel(const P16 p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- split mode, halo-patch form
+// conv16x3h: stride-1 R x S convolutions (forward, and the data gradient of a stride-1 conv) on 128 kout x 128 pixel tiles that are
+// whole image rows (128 / Q rows of a Q-wide image).  In the slice-per-(tap, channel chunk) kernels every pixel value is loaded,
+// split into its three bf16 terms and written to LDS once PER TAP - R*S times - and that staging work (VALU + LDS stores issued
+// beside the MFMAs, tools/mfma_loop_probe.hip: 100 VALU + 18 stores per 48 MFMAs cost 35 % of the MFMA rate) is what holds those
+// kernels at half the matrix rate.  Here the producers stage, per 16-channel chunk, the tile's pixels PLUS THEIR HALO once - a
+// (rows + R - 1) x (Q + S - 1) patch in split form - and the consumers run all R*S taps from that patch by shifting their
+// fragment row; per tap only the 12 KB filter slice moves.  Pixel-operand loads, split VALU and LDS stores drop by
+// R*S * 128 / patch pixels (5.6x for 3x3 on 32-wide images).  Persistent producer / consumer form as conv16x3p: the producers
+// run ahead across chunk and tile boundaries, one barrier per (tap, chunk) slice of 24 MFMAs per consumer wave.
+struct PatchGeom { int TR, PW, NPX, n_iters; };           // tile rows, patch width, patch pixels, 256-thread float4 batches per patch
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(512) void conv16x3h_kernel(const P16 p, const PatchGeom pg) {
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, TM = 2, TN = 2, CH = 16;
+    constexpr int LDS_K = CH + 8;                         // 48-B rows: conflict-free b128 fragment reads
+    constexpr int WPLANE = 128 * LDS_K, WSTAGE = NP * WPLANE;
+    constexpr int LDE = TM * 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int PPLANE = pg.NPX * LDS_K, PATCH = NP * PPLANE;               // 16-bit elements
+    unsigned short* const W0 = smem;                                     // THREE filter stages (slice g lives in stage g % 3)
+    unsigned short* const P0 = smem + 3 * WSTAGE;                        // two patch buffers (chunk sequence index & 1)
+    float* const epi = reinterpret_cast<float*>(P0 + 2 * PATCH);         // consumers' epilogue areas (PATCH * 2 B is a multiple of 16)
+
+    const bool producer = threadIdx.x >= 256;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
+    const int tiles_n = p.Ng / 128;
+    const int total = p.ph_tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int nch = p.C / CH;
+    const int PQ = p.P * p.Q;
+    auto locate = [&](int L, int& tile_m, int& tile_n) {
+        int b = L;
+        if ((total & 7) == 0) b = (L & 7) * (total >> 3) + (L >> 3);
+        tile_m = b / tiles_n; tile_n = b - tile_m * tiles_n;
+    };
+    int my_tiles = 0;
+    for (int L = blockIdx.x; L < total; L += G) ++my_tiles;
+    const int n_chunks = my_tiles * nch;                  // chunk sequence of this workgroup
+    const int n_slices = n_chunks * RS;
+
+    // Pipeline (one barrier per slice = per (tap, chunk), 24 MFMAs per consumer wave).  At step g the consumers multiply slice g
+    // from fragment registers they read during step g - 1 and read the fragments of slice g + 1; the producers stage filter slice
+    // g + 2.  The matrix pipe therefore never drains at a barrier (with fragments read AFTER the barrier it idles ~200 cycles of
+    // every 768: measured 1.0 us per 48 MFMAs against 0.82).
+    if (producer) {
+        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
+        // ---- filter loader: slice = (chunk sequence index, tap); thread -> (kout row, 8-element half)
+        const int w_row = tid >> 1, w_half = tid & 1;
+        const long long kph = (long long)RS * p.C;
+        int wl_L = blockIdx.x, wl_chunk = 0, wl_tap = 0, wl_tile_n = 0;
+        { int tm; locate(wl_L, tm, wl_tile_n); }
+        u32x4 rw[2][NP];
+        auto load_w = [&](auto set_c) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_c)::value;
+            const unsigned off = (unsigned)((((long long)(wl_tile_n * 128 + w_row)) * kph + (long long)wl_tap * p.C + wl_chunk * CH + w_half * 8) * 2);
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                rw[SET][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, q * p.w_plane_bytes, 0));
+            if (++wl_tap == RS) {
+                wl_tap = 0;
+                if (++wl_chunk == nch) { wl_chunk = 0; wl_L += G; if (wl_L < total) { int tm; locate(wl_L, tm, wl_tile_n); } }
+            }
+        };
+        auto store_w = [&](unsigned short* st, auto set_c) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                *reinterpret_cast<u32x4*>(&st[q * WPLANE + w_row * LDS_K + w_half * 8]) = rw[SET][q];
+        };
+        // ---- patch loader: chunk sequence index -> (tile, chunk); batch b covers patch float4 items [256 b, 256 b + 256): item -> (patch pixel, 4-channel group)
+        int pl_L = blockIdx.x, pl_chunk = 0, pl_n = 0, pl_row0 = 0;
+        auto pl_setup = [&]() __attribute__((always_inline)) {
+            int tile_m, tile_n;
+            locate(pl_L, tile_m, tile_n);
+            const int m0 = tile_m * 128;
+            pl_n = m0 / PQ;
+            pl_row0 = (m0 - pl_n * PQ) / p.Q;
+        };
+        pl_setup();
+        float4 rp;
+        bool rp_live = false;
+        int rp_px = 0;
+        auto load_patch = [&](int b) __attribute__((always_inline)) {
+            const int item = b * 256 + tid;
+            rp_px = item >> 2;
+            rp_live = rp_px < pg.NPX;
+            unsigned off = 0xFFFFFFFFu;
+            if (rp_live) {
+                const int prow = rp_px / pg.PW, pcol = rp_px - prow * pg.PW;
+                const int ih = pl_row0 + prow - p.ph_pad_t[0], iw = pcol - p.ph_pad_l[0];
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                    off = (unsigned)(((long long)pl_n * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + pl_chunk * CH + (item & 3) * 4) * 4);
+            }
+            rp = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
+        };
+        auto store_patch = [&](unsigned short* pb) __attribute__((always_inline)) {
+            if (!rp_live) return;
+            float4 v = rp;
+            if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            unsigned o0[NP], o1[NP];
+            split_pk<MMA>(v.x, v.y, o0);
+            split_pk<MMA>(v.z, v.w, o1);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const u32x2 o = {o0[q], o1[q]};
+                *reinterpret_cast<u32x2*>(&pb[q * PPLANE + rp_px * LDS_K + (tid & 3) * 4]) = o;
+            }
+        };
+        auto pl_advance = [&]() __attribute__((always_inline)) {                            // the patch loader moves on to the next chunk of the sequence
+            if (++pl_chunk == nch) { pl_chunk = 0; pl_L += G; if (pl_L < total) pl_setup(); }
+        };
+        using set0 = std::integral_constant<int, 0>;
+        using set1 = std::integral_constant<int, 1>;
+        // prologue: the first patch and filter slices 0 and 1 synchronously, slices 2 and 3 in flight
+        for (int b = 0; b < pg.n_iters; ++b) { load_patch(b); store_patch(P0); }
+        pl_advance();
+        load_w(set0{});
+        store_w(W0, set0{});
+        if (n_slices > 1) { load_w(set1{}); store_w(W0 + WSTAGE, set1{}); }
+        if (n_slices > 2) load_w(set0{});
+        if (n_slices > 3) load_w(set1{});
+        __syncthreads();
+        // step g: stage filter slice g + 2 (register set g & 1, stage (g + 2) % 3), refill the set with slice g + 4; taps 0 .. n_iters of
+        // a chunk also carry the NEXT chunk's patch: batch t is loaded at tap t and split + stored at tap t + 1.  The consumers read
+        // the first fragments of a chunk during the previous chunk's last tap, so the patch must be complete one tap earlier:
+        // n_iters + 2 <= R*S (checked by the launcher).
+        int t = 0, gc = 0;                                   // tap and chunk sequence index of slice g
+        auto patch_work = [&]() __attribute__((always_inline)) {
+            if (gc + 1 < n_chunks) {
+                unsigned short* pb = P0 + ((gc + 1) & 1) * PATCH;
+                if (t >= 1 && t <= pg.n_iters) store_patch(pb);
+                if (t < pg.n_iters) load_patch(t);
+                if (t == pg.n_iters) pl_advance();
+            }
+            if (++t == RS) { t = 0; ++gc; }
+        };
+        int st = 2;                                          // stage of slice g + 2
+        for (int g = 0; g < n_slices; g += 2) {
+            if (g + 2 < n_slices && !(p.dbg & 1)) store_w(W0 + st * WSTAGE, set0{});
+            if (g + 4 < n_slices && !(p.dbg & 2)) load_w(set0{});
+            if (!(p.dbg & 4)) patch_work();
+            st = st == 2 ? 0 : st + 1;
+            __syncthreads();
+            if (g + 1 >= n_slices) break;
+            if (g + 3 < n_slices && !(p.dbg & 1)) store_w(W0 + st * WSTAGE, set1{});
+            if (g + 5 < n_slices && !(p.dbg & 2)) load_w(set1{});
+            if (!(p.dbg & 4)) patch_work();
+            st = st == 2 ? 0 : st + 1;
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumers
+    const int h = lane >> 5, l31 = lane & 31;
+    float* const es = epi + wave * (32 * LDE);
+    constexpr int C4 = TM * 8, ROWS_PER = 64 / C4;
+    // patch index (tap (0,0)) of this lane's pixel in fragment j: tile pixel t = wn*64 + j*32 + l31 -> (t / Q, t % Q)
+    int pix[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int tp = wn * 64 + j * 32 + l31; pix[j] = (tp / p.Q) * pg.PW + (tp % p.Q); }
+    constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
+    u32x4 fw[2][NP][TM], fx[2][NP][TN];                    // fragment registers of the slice being multiplied / the next one
+    // read cursor: the slice whose fragments are read next
+    int r_g = 0, r_gc = 0, r_tap_off = 0, r_s = 0, r_t = 0, r_st = 0;
+    auto read_frags = [&](auto set_c) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_c)::value;
+        const unsigned short* Ws = W0 + r_st * WSTAGE;
+        const unsigned short* Xs = P0 + (r_gc & 1) * PATCH;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            constexpr int ORD[3] = {2, 0, 1}, ORDX[3] = {0, 2, 1};      // the order the product classes consume them
+            const int qw = ORD[q], qx = ORDX[q];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fw[SET][qw][i] = *reinterpret_cast<const u32x4*>(&Ws[qw * WPLANE + (wm * 64 + i * 32 + l31) * LDS_K + h * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fx[SET][qx][j] = *reinterpret_cast<const u32x4*>(&Xs[qx * PPLANE + (pix[j] + r_tap_off) * LDS_K + h * 8]);
+        }
+        // advance the cursor (stays on the last slice once the sequence is exhausted: harmless re-reads)
+        if (r_g + 1 < n_slices) {
+            ++r_g;
+            r_st = r_st == 2 ? 0 : r_st + 1;
+            if (++r_t == RS) { r_t = 0; r_s = 0; r_tap_off = 0; ++r_gc; }
+            else if (++r_s == S) { r_s = 0; r_tap_off += pg.PW - (S - 1); }
+            else ++r_tap_off;
+        }
+    };
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    __syncthreads();                                       // patch 0 and filter slices 0, 1 are staged
+    read_frags(set0{});
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    // multiply the slice held in register set CUR; read the next slice's fragments (staged before the previous barrier) into the other set
+    auto step = [&](auto cur_c, auto nxt_c) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_c)::value;
+        auto mm = [&](int cl) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = Cvt<MMA>::mma(fw[CUR][QW[cl]][i], fx[CUR][QX[cl]][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        mm(0);
+        read_frags(nxt_c);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1); mm(2); mm(3); mm(4); mm(5);
+        __syncthreads();
+    };
+    int L = blockIdx.x, tile_m, tile_n;
+    // epilogue through the wave's own LDS area (as conv16_kernel); the producers keep staging the next tile meanwhile
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int m0 = tile_m * 128, n0 = tile_n * 128;
+        if (p.dbg & 8) return;
+#pragma unroll
+        for (int jh = 0; jh < TN; ++jh) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = {acc[i][jh][4 * q], acc[i][jh][4 * q + 1], acc[i][jh][4 * q + 2], acc[i][jh][4 * q + 3]};
+                    *reinterpret_cast<float4*>(&es[l31 * LDE + i * 32 + 8 * q + 4 * h]) = v;
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 32 / ROWS_PER; ++it) {
+                const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
+                const int m = m0 + wn * TN * 32 + jh * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
+                float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+                const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+                const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                if (p.mask) {
+                    const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+                    v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+                }
+                if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(p.D + off) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    // a tile's last slice may fall on either register set: the tile-end handling follows both half-steps (no parity-dependent paths
+    // with different register assignments - the compiler answers those with 64 accumulator moves per slice and spills)
+    auto tile_end = [&]() __attribute__((always_inline)) -> bool {
+        epilogue();
+        L += G;
+        if (L >= total) return true;
+        locate(L, tile_m, tile_n);
+        zero_acc();
+        return false;
+    };
+    locate(L, tile_m, tile_n);
+    zero_acc();
+    const int per_tile = nch * RS;
+    int left = per_tile;
+    for (;;) {
+        step(set0{}, set1{});
+        if (--left == 0) { if (tile_end()) break; left = per_tile; }
+        step(set1{}, set0{});
+        if (--left == 0) { if (tile_end()) break; left = per_tile; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- WGRAD kernel
 struct W16 {
     const float* X; const float* DY;
@@ -1140,10 +1421,47 @@ int launch_conv16x3p(const P16& p, hipStream_t st) {
     q.dbg = dbg16();
     q.ksplit = 1; q.slab = nullptr;
     const long long total = (long long)q.nph * q.ph_tiles_m * ((p.Ng + 127) / 128);
-    static const int cus = [] { int dev = 0, n = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, q);
     ctgan_set_last_kernel("conv16x3p<128x128,k32>");
     return ctgan_check_launch("conv16x3p<128x128,k32>");
+}
+
+// the halo-patch form takes: one phase, gather stride 1, whole-row tiles inside one image (128 % Q == 0, P*Q % 128 == 0), kout a multiple of
+// 128, 16-channel chunks, and enough taps to carry the next patch's batches (n_iters + 2 <= R*S: not 1x1 convs)
+bool conv16x3h_ok(const P16& p, PatchGeom* out) {
+    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 16 || p.Q <= 0 || 128 % p.Q || (p.P * p.Q) % 128 || p.M % 128) return false;
+    const int R = p.ph_T[0], S = p.ph_U[0];
+    PatchGeom g;
+    g.TR = 128 / p.Q; g.PW = p.Q + S - 1; g.NPX = (g.TR + R - 1) * g.PW;
+    g.n_iters = (g.NPX * 4 + 255) / 256;
+    if (g.n_iters + 2 > R * S) return false;
+    const size_t lds = (size_t)3 * 3 * 128 * 24 * 2 + (size_t)2 * 3 * g.NPX * 24 * 2 + (size_t)4 * 32 * 68 * 4;
+    if (lds > 160 * 1024) return false;
+    if (out) *out = g;
+    return true;
+}
+int launch_conv16x3h(const P16& p, hipStream_t st) {
+    PatchGeom pg;
+    if (!conv16x3h_ok(p, &pg)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv16x3h: shape outside the halo-patch form");
+    const size_t lds = (size_t)3 * 3 * 128 * 24 * 2 + (size_t)2 * 3 * pg.NPX * 24 * 2 + (size_t)4 * 32 * 68 * 4;
+    auto kern = p.relu_in ? conv16x3h_kernel<true> : conv16x3h_kernel<false>;
+    static size_t reserved[2] = {0, 0};
+    size_t& have = reserved[p.relu_in ? 1 : 0];
+    if (have < lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3h: cannot reserve %zu B of LDS", lds);
+        have = lds;
+    }
+    P16 q = p;
+    q.ph_tiles_m = p.M / 128;
+    q.dbg = dbg16();
+    q.ksplit = 1; q.slab = nullptr;
+    const long long total = (long long)q.ph_tiles_m * (p.Ng / 128);
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, q, pg);
+    ctgan_set_last_kernel("conv16x3h<128x128,c16>");
+    return ctgan_check_launch("conv16x3h<128x128,c16>");
 }
 
 template <int MMA>
@@ -1172,6 +1490,8 @@ template <int MMA>
 int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
     if constexpr (planes<MMA>() == 3) {
         // split mode: three planes per operand in LDS - 32-deep slices; the 128x128 tile keeps ONE 60 KB stage (two workgroups per CU)
+        static const int halo = [] { const char* e = getenv("CTGAN_X3_HALO"); return e ? atoi(e) : 1; }();      // 2: also for launches of few tiles (tests)
+        if (halo && (!small || halo == 2) && conv16x3h_ok(p, nullptr)) return launch_conv16x3h(p, st);
         if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16x3<64x64,k32,ksplit>" : "conv16x3<64x64,k32>");
         static const int persist = [] { const char* e = getenv("CTGAN_X3_PERSIST"); return e ? atoi(e) : 1; }();
         if (persist) return launch_conv16x3p(p, st);
