@@ -85,6 +85,7 @@ SIGNATURES = {
     'ctgan_conv2d_repack_filter': (c_int, [_D, _p, _p, _p]),
     'ctgan_conv2d_wgrad': (c_int, [_D, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_conv2d16_supported': (c_int, [_D, c_int, c_int]),
+    'ctgan_conv2d16_x3_prefers': (c_int, [_D, c_int]),
     'ctgan_conv2d16_filter_elems': (c_size_t, [_D, c_int, c_int]),
     'ctgan_conv2d16_pack_filter': (c_int, [_D, c_int, c_int, _p, _p, _p]),
     'ctgan_conv2d16_workspace_bytes': (c_size_t, [_D, c_int]),

@@ -187,20 +187,18 @@ struct P16 {
 
 // one workgroup per CU (the staging must be woven between the MFMAs): the 8-accumulator tiles
 template <int MMA, int TM, int TN> constexpr bool conv16_one_wave() { return TM * TN >= 8; }
-// ONE LDS stage (two barriers per slice), two workgroups per CU: an alternative for the split mode's 128x128 tile, measured
-// 149-178 TFLOP/s against 126 for the double-buffered one-workgroup form whose staging the scheduler does not weave between
-// the MFMAs; superseded by the producer / consumer form below
-template <int MMA, int TM, int TN> constexpr bool conv16_single_stage() { return false; }
-// PRODUCER / CONSUMER waves (split mode, 128x128 tile): 8 waves per workgroup, one workgroup per CU, two 60 KB LDS stages.  Waves
-// 0-3 only read fragments and issue MFMAs; waves 4-7 load the next slices, split the fp32 pixel values into their three bf16
-// terms and write the LDS planes.  Each SIMD then holds one wave of either kind and the hardware interleaves the producer's
-// VALU / memory instructions with the consumer's 32-cycle MFMAs - no reliance on the compiler weaving one wave's instruction stream.
-template <int MMA, int TM, int TN> constexpr bool conv16_ws() { return planes<MMA>() == 3 && TM * TN >= 4; }
-// pixel sub-tiles per epilogue pass (the wide tiles take several passes: <= 70 KB of staging)
-template <int MMA, int TM, int TN> constexpr int conv16_je() { return TM >= 4 ? 1 : (TN > 2 ? 2 : TN); }
+// ONE LDS stage (two barriers per slice), two workgroups per CU: the split mode's 128x128 tile (three planes per operand: 60 KB per
+// stage).  A wave of the other workgroup multiplies while this one splits and stages.  Measured on the headline's layers
+// (tools/conv16_bench.py f32x3 resnet): 149-178 TFLOP/s, against 126 for one double-buffered workgroup per CU (the scheduler does
+// not weave the staging between the MFMAs), 120-143 for 4 producer + 4 consumer waves per workgroup and 128-150 for the same as a
+// persistent kernel: VALU and LDS stores issued beside a saturated MFMA stream on the same SIMD are not free
+// (tools/mfma_loop_probe.hip: 100 VALU + 18 stores per 48 MFMAs cost 35 % of the matrix rate), whichever wave issues them.
+template <int MMA, int TM, int TN> constexpr bool conv16_single_stage() { return planes<MMA>() == 3 && TM * TN >= 4; }
+// pixel sub-tiles per epilogue pass (the wide tiles take several passes: <= 70 KB of staging; the single-stage tile: 35 KB)
+template <int MMA, int TM, int TN> constexpr int conv16_je() { return TM >= 4 ? 1 : (TN > 2 ? 2 : (conv16_single_stage<MMA, TM, TN>() ? 1 : TN)); }
 
-template <int MMA, int TM, int TN, int BK, bool RELU_IN, bool SPLIT = conv16_one_wave<MMA, TM, TN>(), bool WS = conv16_ws<MMA, TM, TN>()>
-__global__ __launch_bounds__(WS ? 512 : 256) void conv16_kernel(const P16 p) {
+template <int MMA, int TM, int TN, int BK, bool RELU_IN, bool SPLIT = conv16_one_wave<MMA, TM, TN>()>
+__global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
     // TM: 32-wide kout sub-tiles per wave ("A" operand), TN: 32-wide pixel sub-tiles per wave ("B" operand)
     constexpr int NT = 256;
     constexpr int BMP = 2 * TN * 32;                    // pixels per block
@@ -223,8 +221,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv16_kernel(const P16 p) {
     unsigned short* const S0 = SPLIT ? stage0_static : smem;
     unsigned short* const S1 = SPLIT ? smem : (SINGLE ? smem : smem + STAGE);
 
-    const bool producer = WS && threadIdx.x >= 256;     // wave-uniform role
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;            // wave's kout half / pixel half
     int bid = blockIdx.x;
     const int nb = gridDim.x;
@@ -374,47 +371,9 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv16_kernel(const P16 p) {
             }
         }
     };
-    // consumer waves of the producer / consumer form.  The instruction order is pinned (scheduling barriers): left alone, the
-    // scheduler groups the six products of one accumulator - ten dependent MFMAs back to back, each waiting for the previous
-    // result (measured 55 % MFMA occupancy with nothing else in the loop).  Products are issued class by class (four MFMAs on four
-    // different accumulators), the fragment reads in the order the classes consume them, the second k step's reads between the
-    // MFMAs of the first.
-    auto mma_slice_ws = [&](const unsigned short* Xs) {
-        if constexpr (NP == 3 && BK == 32) {
-            const unsigned short* Ws = Xs + NP * XPLANE;
-            constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};
-            u32x4 fw[2][NP][TM], fx[2][NP][TN];
-            auto rd = [&](int ks, int qw, int qx) {        // the fragments product class (qw, qx) is the first to need
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    fw[ks][qw][i] = *reinterpret_cast<const u32x4*>(&Ws[qw * WPLANE + (wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fx[ks][qx][j] = *reinterpret_cast<const u32x4*>(&Xs[qx * XPLANE + (wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            auto mm = [&](int ks, int c) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[0][i][j] = Cvt<MMA>::mma(fw[ks][QW[c]][i], fx[ks][QX[c]][j], acc[0][i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            rd(0, 2, 0); rd(0, 0, 2);
-            mm(0, 0); rd(0, 1, 1);
-            mm(0, 1); rd(1, 2, 0);
-            mm(0, 2); rd(1, 0, 2);
-            mm(0, 3); rd(1, 1, 1);
-            mm(0, 4); mm(0, 5);
-            mm(1, 0); mm(1, 1); mm(1, 2); mm(1, 3); mm(1, 4); mm(1, 5);
-        }
-    };
-    if (!WS || producer) {
-        load_slice();
-        store_slice(S0);
-        if (nk > 1) load_slice();
-    }
+    load_slice();
+    store_slice(S0);
+    if (nk > 1) load_slice();
     __syncthreads();
     // steady state (slices kt+1 and kt+2 exist): ONE basic block per slice - stage slice kt+1 into the other LDS buffer, issue
     // the loads of slice kt+2, multiply slice kt.  SPLIT: scheduling groups ask for the staging instructions to be woven between
@@ -438,24 +397,13 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv16_kernel(const P16 p) {
         __syncthreads();
     };
     int kt = 0;
-    if constexpr (WS) {
-        for (; kt < nk; ++kt) {
-            if (!producer) {
-                mma_slice_ws(kt & 1 ? S1 : S0);
-            } else {
-                if (kt + 1 < nk && !(p.dbg & 1)) store_slice((kt + 1) & 1 ? S1 : S0);
-                if (kt + 2 < nk && !(p.dbg & 2)) load_slice();
-            }
-            __syncthreads();
-        }
-        if (producer) return;                              // the epilogue is the consumers' (wave-level synchronisation only)
-    } else if constexpr (SINGLE) {
+    if constexpr (SINGLE) {
         for (; kt < nk; ++kt) {
             mma_slice(S0);
             __syncthreads();                               // every wave has read slice kt
             if (kt + 1 < nk) {
-                if (!(p.dbg & 1)) store_slice(S0);
-                if (kt + 2 < nk && !(p.dbg & 2)) load_slice();
+                store_slice(S0);
+                if (kt + 2 < nk) load_slice();
                 __syncthreads();
             }
         }
@@ -520,116 +468,95 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv16_kernel(const P16 p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------- split mode, persistent form
-// conv16x3p: the split mode's 128 kout x 128 pixel tile as a PERSISTENT producer / consumer kernel - one workgroup of 8 waves per
-// CU walks the tiles b, b + grid, b + 2 grid, ...  Waves 0-3 (consumers, one per SIMD) only read fragments and issue MFMAs, and
-// write a finished tile through their own LDS staging area; waves 4-7 (producers) stream the slices of the tile sequence - fp32
-// pixel values split into three bf16 terms, the three packed filter planes - into two 60 KB LDS stages, two slices of loads in
-// flight, and run ahead across tile boundaries: the first slices of the next tile are staged while the consumers finish and
-// store the current one.  Measured on the one-tile-per-workgroup form: 10-16 us of prologue + epilogue + dispatch per tile
-// against 30 us of MFMAs for a 3x3x128 filter - that is what the persistence hides; one barrier per slice for all 8 waves.
+// ---------------------------------------------------------------------------------------------- split mode, halo-patch form
+// conv16x3h: stride-1 R x S convolutions (forward, and the data gradient of a stride-1 conv) on 128 kout x 128 pixel tiles that are
+// whole image rows (128 / Q rows of a Q-wide image).  In the slice-per-(tap, channel chunk) kernel every pixel value is loaded,
+// split into its three bf16 terms and written to LDS once PER TAP - R*S times - and that staging work (VALU + LDS stores issued
+// beside the MFMAs; tools/mfma_loop_probe.hip: 100 VALU + 18 stores per 48 MFMAs cost 35 % of the matrix rate) is what holds it
+// at half the matrix rate.  Here a workgroup stages, per 32-channel chunk, the tile's pixels PLUS THEIR HALO once - a
+// (rows + R - 1) x (Q + S - 1) patch in split form - and runs all R*S taps from that patch by shifting the fragment row; per tap
+// only the 24 KB filter slice moves.  Pixel-operand loads, split VALU and LDS stores drop by R*S * 128 / patch pixels (5.6x for
+// 3x3 on 32-wide images).  Single LDS stage, two workgroups of 4 waves per CU (80 KB each) as conv16_single_stage: the other
+// workgroup multiplies while this one stages.
+struct PatchGeom { int TR, PW, NPX, n_it; };              // tile rows, patch width, patch pixels, float4 items per thread per patch
+
 template <bool RELU_IN>
-__global__ __launch_bounds__(512) void conv16x3p_kernel(const P16 p) {
-    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, TM = 2, TN = 2, BK = 32, NT = 256;
-    constexpr int BMP = 128, BNC = 128, LDS_K = BK + 8;
-    constexpr int XC = BK / 4, X_PER = BMP * XC / NT, WC = BK / 8, W_PER = BNC * WC / NT;
-    constexpr int XPLANE = BMP * LDS_K, WPLANE = BNC * LDS_K, STAGE = NP * (XPLANE + WPLANE);
+__global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const PatchGeom pg) {
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, TM = 2, TN = 2, BK = 32, NT = 256, MAXIT = 8;
+    constexpr int LDS_K = BK + 8, WC = BK / 8, W_PER = 128 * WC / NT;
+    constexpr int WPLANE = 128 * LDS_K;
     constexpr int LDE = TM * 32 + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    unsigned short* const S0 = smem;
-    unsigned short* const S1 = smem + STAGE;
-    float* const epi = reinterpret_cast<float*>(smem + 2 * STAGE);      // 4 waves x 32 pixels x LDE floats
+    const int PPLANE = pg.NPX * LDS_K;
+    unsigned short* const Ws = smem;                      // filter stage: 3 planes x 128 kout rows
+    unsigned short* const Xs = smem + NP * WPLANE;        // patch: 3 planes x NPX pixel rows
 
-    const bool producer = threadIdx.x >= 256;            // wave-uniform role
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.Ng + BNC - 1) / BNC;
-    const int per_phase = p.ph_tiles_m * tiles_n;
-    const int total = p.nph * per_phase;
-    const int G = gridDim.x;
-    const int cpt = p.C / BK;
+    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
+    const int tiles_n = p.Ng / 128;
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // neighbouring pixel tiles (shared halo rows) on one XCD
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int nch = p.C / BK;
     const int PQ = p.P * p.Q;
-    // tile L -> (phase, pixel tile, kout tile); neighbouring pixel tiles (shared halo rows) stay on one XCD
-    auto locate = [&](int L, int& ph, int& tile_m, int& tile_n) {
-        int b = L;
-        if ((total & 7) == 0) b = (L & 7) * (total >> 3) + (L >> 3);
-        tile_m = b / tiles_n; tile_n = b - tile_m * tiles_n;
-        ph = 0;
-        if (p.nph > 1) { ph = tile_m / p.ph_tiles_m; tile_m -= ph * p.ph_tiles_m; }
-    };
-    auto slices_of = [&](int ph) { return p.ph_T[ph >> 1] * p.ph_U[ph & 1] * cpt; };
-    int n_total = 0;                                     // slices this workgroup walks
-    for (int L = blockIdx.x; L < total; L += G) { int ph, tm, tn; locate(L, ph, tm, tn); n_total += slices_of(ph); }
+    const int img = m0 / PQ, row0 = (m0 - img * PQ) / p.Q;
 
-    if (producer) {
-        // the second-dispatched half of a workgroup loses the per-SIMD issue arbitration (priority, then age): without a static
-        // priority the producers' VALU / LDS instructions only issue once the consumer on their SIMD runs out of MFMAs, and the two
-        // roles serialise (measured 1.4-1.6 us per slice against 0.82 us of MFMAs)
-        if (!(p.dbg & 16)) __builtin_amdgcn_s_setprio(3);
-        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
-        auto spread = [](int g) { return (g & 1) * 4 + ((g >> 1) & 3) + (g >> 3) * 8; };      // conflict-free row pairs, see conv16_kernel
-        const int x_chunk = tid % XC, x_row0 = spread(tid / XC);
-        const int w_chunk = tid % WC, w_row0 = spread(tid / WC);
-        // loader state: the tile whose slices are being read, and the position inside it
-        int L = blockIdx.x, U = 1, nk = 0;
-        unsigned x_voff[X_PER], w_voff[W_PER];
-        int x_ih0[X_PER], x_iw0[X_PER];
-        bool x_valid[X_PER];
-        int ld_k = 0, ld_c = 0, ld_u = 0, ld_t = 0;
-        auto setup = [&]() {
-            int ph, tile_m, tile_n;
-            locate(L, ph, tile_m, tile_n);
-            const int pa = ph >> 1, pb = ph & 1;
-            const int T = p.ph_T[pa];
-            U = p.ph_U[pb];
-            nk = T * U * cpt;
-            const long long kph = (long long)T * U * p.C;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
+    // ---- filter loader (as conv16_kernel: rows 4 apart per 8 lanes - disjoint LDS banks)
+    auto spread = [](int g) { return (g & 1) * 4 + ((g >> 1) & 3) + (g >> 3) * 8; };
+    const int w_chunk = tid % WC, w_row0 = spread(tid / WC);
+    const long long kph = (long long)RS * p.C;
+    unsigned w_voff[W_PER];
 #pragma unroll
-            for (int i = 0; i < X_PER; ++i) {
-                const int m = tile_m * BMP + x_row0 + i * (NT / XC);
-                x_valid[i] = m < p.M;
-                const int mm = x_valid[i] ? m : 0;
-                const int n = mm / PQ, rem = mm - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
-                x_ih0[i] = pp * p.stride - p.ph_pad_t[pa];
-                x_iw0[i] = qq * p.stride - p.ph_pad_l[pb];
-                const long long o = (long long)n * p.s_n + (long long)x_ih0[i] * p.s_h + (long long)x_iw0[i] * p.s_w + x_chunk * 4;
-                x_voff[i] = (unsigned)(o * 4);
-            }
+    for (int i = 0; i < W_PER; ++i) w_voff[i] = (unsigned)(((long long)(n0 + w_row0 + i * (NT / WC)) * kph + w_chunk * 8) * 2);
+    u32x4 rw[NP][W_PER];
+    int wl_tap = 0, wl_chunk = 0;                         // next filter slice to load
+    auto load_w = [&]() __attribute__((always_inline)) {
+        const unsigned ws = (unsigned)(((long long)wl_tap * p.C + wl_chunk * BK) * 2);
 #pragma unroll
-            for (int i = 0; i < W_PER; ++i) {
-                const int n = tile_n * BNC + w_row0 + i * (NT / WC);
-                w_voff[i] = n < p.Ng ? (unsigned)((p.ph_w_off[ph] + (long long)n * kph + w_chunk * 8) * 2) : 0xFFFFFFFFu;
-            }
-            ld_k = ld_c = ld_u = ld_t = 0;
-        };
-        float4 rx[2][X_PER];
-        u32x4 rw[2][NP][W_PER];
-        auto load_slice = [&](auto set_c) {
-            constexpr int SET = decltype(set_c)::value;
-            const unsigned xs = (unsigned)(((long long)ld_t * p.s_h + (long long)ld_u * p.s_w + ld_c * BK) * 4);
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int i = 0; i < X_PER; ++i) {
-                const bool ok = x_valid[i] & ((unsigned)(x_ih0[i] + ld_t) < (unsigned)p.H) & ((unsigned)(x_iw0[i] + ld_u) < (unsigned)p.W);
-                rx[SET][i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? x_voff[i] + xs : 0xFFFFFFFFu, 0, 0));
-            }
-            const unsigned ws = (unsigned)((long long)ld_k * BK * 2);
+            for (int i = 0; i < W_PER; ++i)
+                rw[q][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], ws + q * p.w_plane_bytes, 0));
+        if (++wl_tap == RS) { wl_tap = 0; ++wl_chunk; }
+    };
+    auto store_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q)
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-                for (int i = 0; i < W_PER; ++i)
-                    rw[SET][q][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], ws + q * p.w_plane_bytes, 0));
-            ++ld_k; ++ld_c;
-            if (ld_c == cpt) { ld_c = 0; if (++ld_u == U) { ld_u = 0; ++ld_t; } }
-            if (ld_k == nk) { L += G; if (L < total) setup(); }      // the loader moves on to the next tile
-        };
-        auto store_slice = [&](unsigned short* st, auto set_c) {
-            constexpr int SET = decltype(set_c)::value;
-            unsigned short* Xs = st;
-            unsigned short* Ws = st + NP * XPLANE;
+            for (int i = 0; i < W_PER; ++i)
+                *reinterpret_cast<u32x4*>(&Ws[q * WPLANE + (w_row0 + i * (NT / WC)) * LDS_K + w_chunk * 8]) = rw[q][i];
+    };
+    // ---- patch loader: item = it * 256 + tid -> (patch pixel = item / 8, 4-channel group = item % 8): 8 lanes read one pixel's 128 B
+    float4 rp[MAXIT];
+    unsigned p_voff[MAXIT];                               // byte offset of the item at chunk 0 (0xFFFFFFFF: outside the image / the patch)
 #pragma unroll
-            for (int i = 0; i < X_PER; ++i) {
-                float4 v = rx[SET][i];
+    for (int it = 0; it < MAXIT; ++it) {
+        const int item = it * NT + tid, px = item >> 3;
+        p_voff[it] = 0xFFFFFFFFu;
+        if (it < pg.n_it && px < pg.NPX) {
+            const int prow = px / pg.PW, pcol = px - prow * pg.PW;
+            const int ih = row0 + prow - p.ph_pad_t[0], iw = pcol - p.ph_pad_l[0];
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                p_voff[it] = (unsigned)(((long long)img * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + (item & 7) * 4) * 4);
+        }
+    }
+    auto load_patch = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+            if (it < pg.n_it)
+                rp[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, p_voff[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : p_voff[it] + chunk * (BK * 4), 0, 0));
+    };
+    auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int item = it * NT + tid, px = item >> 3;
+            if (it < pg.n_it && px < pg.NPX) {
+                float4 v = rp[it];
                 if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 unsigned o0[NP], o1[NP];
                 split_pk<MMA>(v.x, v.y, o0);
@@ -637,77 +564,54 @@ __global__ __launch_bounds__(512) void conv16x3p_kernel(const P16 p) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
                     const u32x2 o = {o0[q], o1[q]};
-                    *reinterpret_cast<u32x2*>(&Xs[q * XPLANE + (x_row0 + i * (NT / XC)) * LDS_K + x_chunk * 4]) = o;
+                    *reinterpret_cast<u32x2*>(&Xs[q * PPLANE + px * LDS_K + (item & 7) * 4]) = o;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-#pragma unroll
-                for (int i = 0; i < W_PER; ++i)
-                    *reinterpret_cast<u32x4*>(&Ws[q * WPLANE + (w_row0 + i * (NT / WC)) * LDS_K + w_chunk * 8]) = rw[SET][q][i];
-        };
-        using set0 = std::integral_constant<int, 0>;
-        using set1 = std::integral_constant<int, 1>;
-        // slice g lives in register set (g & 1) and LDS stage (g & 1); steady state at step g: stage slice g + 1, refill its set with g + 3
-        setup();
-        load_slice(set0{});
-        store_slice(S0, set0{});
-        if (n_total > 1) load_slice(set1{});
-        if (n_total > 2) load_slice(set0{});
-        __syncthreads();
-        int g = 0;
-        for (; g + 1 < n_total; g += 2) {
-            store_slice(S1, set1{});                                   // slice g + 1
-            if (g + 3 < n_total && !(p.dbg & 2)) load_slice(set1{});
-            __syncthreads();
-            if (g + 2 < n_total) store_slice(S0, set0{});              // slice g + 2
-            if (g + 4 < n_total && !(p.dbg & 2)) load_slice(set0{});
-            __syncthreads();
         }
-        if (g < n_total) __syncthreads();                              // odd count: the consumers' last slice
-        return;
-    }
+    };
 
-    // ---- consumers
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int h = lane >> 5, l31 = lane & 31;
-    float* const es = epi + wave * (32 * LDE);
-    constexpr int C4 = TM * 8, ROWS_PER = 64 / C4;
-    __syncthreads();                                       // slice 0 is staged
-    int g = 0;
-    for (int L = blockIdx.x; L < total; L += G) {
-        int ph, tile_m, tile_n;
-        locate(L, ph, tile_m, tile_n);
-        const int nk = slices_of(ph);
-        f32x16 acc[TM][TN];
+    // patch index (tap (0,0)) of this lane's pixel in fragment j: tile pixel t = wn*64 + j*32 + l31 -> (t / Q, t % Q)
+    int pix[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            const unsigned short* Xs = (g & 1) ? S1 : S0;
-            const unsigned short* Ws = Xs + NP * XPLANE;
-            // pinned order (scheduling barriers): products class by class - four MFMAs on four different accumulators - fragment
-            // reads in the order the classes consume them, the second k step's reads between the MFMAs of the first.  Left alone the
-            // scheduler groups the six products of one accumulator: ten dependent MFMAs back to back.
-            constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
+    for (int j = 0; j < TN; ++j) { const int tp = wn * 64 + j * 32 + l31; pix[j] = (tp / p.Q) * pg.PW + (tp % p.Q); }
+    constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
+
+    load_patch(0);
+    load_w();
+    for (int c = 0; c < nch; ++c) {
+        store_patch();                                     // every wave passed the barrier behind the previous chunk's last MFMAs
+        if (c + 1 < nch) load_patch(c + 1);                // in flight during this chunk's taps
+        int tap_off = 0, s_cnt = 0;
+        for (int tp = 0; tp < RS; ++tp) {
+            store_w();
+            if (tp + 1 < RS || c + 1 < nch) load_w();
+            __syncthreads();
+            // pinned order (scheduling barriers): products class by class - four MFMAs on four different accumulators - fragment reads in
+            // the order the classes consume them, the second k step's reads between the MFMAs of the first
             u32x4 fw[2][NP][TM], fx[2][NP][TN];
-            auto rd = [&](int ks, int qw, int qx) {
+            auto rd = [&](int ks, int qw, int qx) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fw[ks][qw][i] = *reinterpret_cast<const u32x4*>(&Ws[qw * WPLANE + (wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+                    fw[ks][qw][i] = *reinterpret_cast<const u32x4*>(&Ws[qw * WPLANE + (wm * 64 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fx[ks][qx][j] = *reinterpret_cast<const u32x4*>(&Xs[qx * XPLANE + (wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+                    fx[ks][qx][j] = *reinterpret_cast<const u32x4*>(&Xs[qx * PPLANE + (pix[j] + tap_off) * LDS_K + ks * 16 + h * 8]);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto mm = [&](int ks, int c) {
+            auto mm = [&](int ks, int cl) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = Cvt<MMA>::mma(fw[ks][QW[c]][i], fx[ks][QX[c]][j], acc[i][j]);
+                        acc[i][j] = Cvt<MMA>::mma(fw[ks][QW[cl]][i], fx[ks][QX[cl]][j], acc[i][j]);
                 __builtin_amdgcn_sched_barrier(0);
             };
             rd(0, 2, 0); rd(0, 0, 2);
@@ -717,324 +621,43 @@ __global__ __launch_bounds__(512) void conv16x3p_kernel(const P16 p) {
             mm(0, 3); rd(1, 1, 1);
             mm(0, 4); mm(0, 5);
             mm(1, 0); mm(1, 1); mm(1, 2); mm(1, 3); mm(1, 4); mm(1, 5);
-            __syncthreads();
-        }
-        // epilogue through the wave's own LDS area (as conv16_kernel): the producers keep staging the next tile meanwhile
-        const int m0 = tile_m * BMP, n0 = tile_n * BNC;
-        const long long d_off = (ph >> 1) * p.ph_d_h + (ph & 1) * p.ph_d_w;
-        if (p.dbg & 8) continue;
-#pragma unroll
-        for (int jh = 0; jh < TN; ++jh) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = {acc[i][jh][4 * q], acc[i][jh][4 * q + 1], acc[i][jh][4 * q + 2], acc[i][jh][4 * q + 3]};
-                    *reinterpret_cast<float4*>(&es[l31 * LDE + i * 32 + 8 * q + 4 * h]) = v;
-                }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < 32 / ROWS_PER; ++it) {
-                const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
-                const int m = m0 + wn * TN * 32 + jh * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
-                if (m >= p.M || col >= p.Ng) continue;
-                float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
-                const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
-                const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                if (p.mask) {
-                    const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
-                    v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
-                }
-                if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(p.D + off) = v;
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
+            __syncthreads();                               // the filter stage (and, after the last tap, the patch) may be overwritten
+            if (++s_cnt == S) { s_cnt = 0; tap_off += pg.PW - (S - 1); } else ++tap_off;      // next tap: one pixel right, or the next patch row
         }
     }
-}
 
-// ---------------------------------------------------------------------------------------------- split mode, halo-patch form
-// conv16x3h: stride-1 R x S convolutions (forward, and the data gradient of a stride-1 conv) on 128 kout x 128 pixel tiles that are
-// whole image rows (128 / Q rows of a Q-wide image).  In the slice-per-(tap, channel chunk) kernels every pixel value is loaded,
-// split into its three bf16 terms and written to LDS once PER TAP - R*S times - and that staging work (VALU + LDS stores issued
-// beside the MFMAs, tools/mfma_loop_probe.hip: 100 VALU + 18 stores per 48 MFMAs cost 35 % of the MFMA rate) is what holds those
-// kernels at half the matrix rate.  Here the producers stage, per 16-channel chunk, the tile's pixels PLUS THEIR HALO once - a
-// (rows + R - 1) x (Q + S - 1) patch in split form - and the consumers run all R*S taps from that patch by shifting their
-// fragment row; per tap only the 12 KB filter slice moves.  Pixel-operand loads, split VALU and LDS stores drop by
-// R*S * 128 / patch pixels (5.6x for 3x3 on 32-wide images).  Persistent producer / consumer form as conv16x3p: the producers
-// run ahead across chunk and tile boundaries, one barrier per (tap, chunk) slice of 24 MFMAs per consumer wave.
-struct PatchGeom { int TR, PW, NPX, n_iters; };           // tile rows, patch width, patch pixels, 256-thread float4 batches per patch
-
-template <bool RELU_IN>
-__global__ __launch_bounds__(512) void conv16x3h_kernel(const P16 p, const PatchGeom pg) {
-    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, TM = 2, TN = 2, CH = 16;
-    constexpr int LDS_K = CH + 8;                         // 48-B rows: conflict-free b128 fragment reads
-    constexpr int WPLANE = 128 * LDS_K, WSTAGE = NP * WPLANE;
-    constexpr int LDE = TM * 32 + 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-    const int PPLANE = pg.NPX * LDS_K, PATCH = NP * PPLANE;               // 16-bit elements
-    unsigned short* const W0 = smem;                                     // THREE filter stages (slice g lives in stage g % 3)
-    unsigned short* const P0 = smem + 3 * WSTAGE;                        // two patch buffers (chunk sequence index & 1)
-    float* const epi = reinterpret_cast<float*>(P0 + 2 * PATCH);         // consumers' epilogue areas (PATCH * 2 B is a multiple of 16)
-
-    const bool producer = threadIdx.x >= 256;
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
-    const int tiles_n = p.Ng / 128;
-    const int total = p.ph_tiles_m * tiles_n;
-    const int G = gridDim.x;
-    const int nch = p.C / CH;
-    const int PQ = p.P * p.Q;
-    auto locate = [&](int L, int& tile_m, int& tile_n) {
-        int b = L;
-        if ((total & 7) == 0) b = (L & 7) * (total >> 3) + (L >> 3);
-        tile_m = b / tiles_n; tile_n = b - tile_m * tiles_n;
-    };
-    int my_tiles = 0;
-    for (int L = blockIdx.x; L < total; L += G) ++my_tiles;
-    const int n_chunks = my_tiles * nch;                  // chunk sequence of this workgroup
-    const int n_slices = n_chunks * RS;
-
-    // Pipeline (one barrier per slice = per (tap, chunk), 24 MFMAs per consumer wave).  At step g the consumers multiply slice g
-    // from fragment registers they read during step g - 1 and read the fragments of slice g + 1; the producers stage filter slice
-    // g + 2.  The matrix pipe therefore never drains at a barrier (with fragments read AFTER the barrier it idles ~200 cycles of
-    // every 768: measured 1.0 us per 48 MFMAs against 0.82).
-    if (producer) {
-        const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
-        // ---- filter loader: slice = (chunk sequence index, tap); thread -> (kout row, 8-element half)
-        const int w_row = tid >> 1, w_half = tid & 1;
-        const long long kph = (long long)RS * p.C;
-        int wl_L = blockIdx.x, wl_chunk = 0, wl_tap = 0, wl_tile_n = 0;
-        { int tm; locate(wl_L, tm, wl_tile_n); }
-        u32x4 rw[2][NP];
-        auto load_w = [&](auto set_c) __attribute__((always_inline)) {
-            constexpr int SET = decltype(set_c)::value;
-            const unsigned off = (unsigned)((((long long)(wl_tile_n * 128 + w_row)) * kph + (long long)wl_tap * p.C + wl_chunk * CH + w_half * 8) * 2);
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-                rw[SET][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, off, q * p.w_plane_bytes, 0));
-            if (++wl_tap == RS) {
-                wl_tap = 0;
-                if (++wl_chunk == nch) { wl_chunk = 0; wl_L += G; if (wl_L < total) { int tm; locate(wl_L, tm, wl_tile_n); } }
-            }
-        };
-        auto store_w = [&](unsigned short* st, auto set_c) __attribute__((always_inline)) {
-            constexpr int SET = decltype(set_c)::value;
-#pragma unroll
-            for (int q = 0; q < NP; ++q)
-                *reinterpret_cast<u32x4*>(&st[q * WPLANE + w_row * LDS_K + w_half * 8]) = rw[SET][q];
-        };
-        // ---- patch loader: chunk sequence index -> (tile, chunk); batch b covers patch float4 items [256 b, 256 b + 256): item -> (patch pixel, 4-channel group)
-        int pl_L = blockIdx.x, pl_chunk = 0, pl_n = 0, pl_row0 = 0;
-        auto pl_setup = [&]() __attribute__((always_inline)) {
-            int tile_m, tile_n;
-            locate(pl_L, tile_m, tile_n);
-            const int m0 = tile_m * 128;
-            pl_n = m0 / PQ;
-            pl_row0 = (m0 - pl_n * PQ) / p.Q;
-        };
-        pl_setup();
-        float4 rp;
-        bool rp_live = false;
-        int rp_px = 0;
-        auto load_patch = [&](int b) __attribute__((always_inline)) {
-            const int item = b * 256 + tid;
-            rp_px = item >> 2;
-            rp_live = rp_px < pg.NPX;
-            unsigned off = 0xFFFFFFFFu;
-            if (rp_live) {
-                const int prow = rp_px / pg.PW, pcol = rp_px - prow * pg.PW;
-                const int ih = pl_row0 + prow - p.ph_pad_t[0], iw = pcol - p.ph_pad_l[0];
-                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                    off = (unsigned)(((long long)pl_n * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + pl_chunk * CH + (item & 3) * 4) * 4);
-            }
-            rp = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, off, 0, 0));
-        };
-        auto store_patch = [&](unsigned short* pb) __attribute__((always_inline)) {
-            if (!rp_live) return;
-            float4 v = rp;
-            if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            unsigned o0[NP], o1[NP];
-            split_pk<MMA>(v.x, v.y, o0);
-            split_pk<MMA>(v.z, v.w, o1);
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const u32x2 o = {o0[q], o1[q]};
-                *reinterpret_cast<u32x2*>(&pb[q * PPLANE + rp_px * LDS_K + (tid & 3) * 4]) = o;
-            }
-        };
-        auto pl_advance = [&]() __attribute__((always_inline)) {                            // the patch loader moves on to the next chunk of the sequence
-            if (++pl_chunk == nch) { pl_chunk = 0; pl_L += G; if (pl_L < total) pl_setup(); }
-        };
-        using set0 = std::integral_constant<int, 0>;
-        using set1 = std::integral_constant<int, 1>;
-        // prologue: the first patch and filter slices 0 and 1 synchronously, slices 2 and 3 in flight
-        for (int b = 0; b < pg.n_iters; ++b) { load_patch(b); store_patch(P0); }
-        pl_advance();
-        load_w(set0{});
-        store_w(W0, set0{});
-        if (n_slices > 1) { load_w(set1{}); store_w(W0 + WSTAGE, set1{}); }
-        if (n_slices > 2) load_w(set0{});
-        if (n_slices > 3) load_w(set1{});
-        __syncthreads();
-        // step g: stage filter slice g + 2 (register set g & 1, stage (g + 2) % 3), refill the set with slice g + 4; taps 0 .. n_iters of
-        // a chunk also carry the NEXT chunk's patch: batch t is loaded at tap t and split + stored at tap t + 1.  The consumers read
-        // the first fragments of a chunk during the previous chunk's last tap, so the patch must be complete one tap earlier:
-        // n_iters + 2 <= R*S (checked by the launcher).
-        int t = 0, gc = 0;                                   // tap and chunk sequence index of slice g
-        auto patch_work = [&]() __attribute__((always_inline)) {
-            if (gc + 1 < n_chunks) {
-                unsigned short* pb = P0 + ((gc + 1) & 1) * PATCH;
-                if (t >= 1 && t <= pg.n_iters) store_patch(pb);
-                if (t < pg.n_iters) load_patch(t);
-                if (t == pg.n_iters) pl_advance();
-            }
-            if (++t == RS) { t = 0; ++gc; }
-        };
-        int st = 2;                                          // stage of slice g + 2
-        for (int g = 0; g < n_slices; g += 2) {
-            if (g + 2 < n_slices && !(p.dbg & 1)) store_w(W0 + st * WSTAGE, set0{});
-            if (g + 4 < n_slices && !(p.dbg & 2)) load_w(set0{});
-            if (!(p.dbg & 4)) patch_work();
-            st = st == 2 ? 0 : st + 1;
-            __syncthreads();
-            if (g + 1 >= n_slices) break;
-            if (g + 3 < n_slices && !(p.dbg & 1)) store_w(W0 + st * WSTAGE, set1{});
-            if (g + 5 < n_slices && !(p.dbg & 2)) load_w(set1{});
-            if (!(p.dbg & 4)) patch_work();
-            st = st == 2 ? 0 : st + 1;
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---- consumers
-    const int h = lane >> 5, l31 = lane & 31;
-    float* const es = epi + wave * (32 * LDE);
+    // epilogue through LDS (as conv16_kernel, one 32-pixel sub-tile per pass)
+    float* es = reinterpret_cast<float*>(smem) + wave * (32 * LDE);
     constexpr int C4 = TM * 8, ROWS_PER = 64 / C4;
-    // patch index (tap (0,0)) of this lane's pixel in fragment j: tile pixel t = wn*64 + j*32 + l31 -> (t / Q, t % Q)
-    int pix[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { const int tp = wn * 64 + j * 32 + l31; pix[j] = (tp / p.Q) * pg.PW + (tp % p.Q); }
-    constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
-    u32x4 fw[2][NP][TM], fx[2][NP][TN];                    // fragment registers of the slice being multiplied / the next one
-    // read cursor: the slice whose fragments are read next
-    int r_g = 0, r_gc = 0, r_tap_off = 0, r_s = 0, r_t = 0, r_st = 0;
-    auto read_frags = [&](auto set_c) __attribute__((always_inline)) {
-        constexpr int SET = decltype(set_c)::value;
-        const unsigned short* Ws = W0 + r_st * WSTAGE;
-        const unsigned short* Xs = P0 + (r_gc & 1) * PATCH;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            constexpr int ORD[3] = {2, 0, 1}, ORDX[3] = {0, 2, 1};      // the order the product classes consume them
-            const int qw = ORD[q], qx = ORDX[q];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fw[SET][qw][i] = *reinterpret_cast<const u32x4*>(&Ws[qw * WPLANE + (wm * 64 + i * 32 + l31) * LDS_K + h * 8]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fx[SET][qx][j] = *reinterpret_cast<const u32x4*>(&Xs[qx * PPLANE + (pix[j] + r_tap_off) * LDS_K + h * 8]);
-        }
-        // advance the cursor (stays on the last slice once the sequence is exhausted: harmless re-reads)
-        if (r_g + 1 < n_slices) {
-            ++r_g;
-            r_st = r_st == 2 ? 0 : r_st + 1;
-            if (++r_t == RS) { r_t = 0; r_s = 0; r_tap_off = 0; ++r_gc; }
-            else if (++r_s == S) { r_s = 0; r_tap_off += pg.PW - (S - 1); }
-            else ++r_tap_off;
-        }
-    };
-    using set0 = std::integral_constant<int, 0>;
-    using set1 = std::integral_constant<int, 1>;
-    __syncthreads();                                       // patch 0 and filter slices 0, 1 are staged
-    read_frags(set0{});
-    f32x16 acc[TM][TN];
-    auto zero_acc = [&]() __attribute__((always_inline)) {
+    for (int jh = 0; jh < TN; ++jh) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    };
-    // multiply the slice held in register set CUR; read the next slice's fragments (staged before the previous barrier) into the other set
-    auto step = [&](auto cur_c, auto nxt_c) __attribute__((always_inline)) {
-        constexpr int CUR = decltype(cur_c)::value;
-        auto mm = [&](int cl) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = Cvt<MMA>::mma(fw[CUR][QW[cl]][i], fx[CUR][QX[cl]][j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        mm(0);
-        read_frags(nxt_c);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(1); mm(2); mm(3); mm(4); mm(5);
-        __syncthreads();
-    };
-    int L = blockIdx.x, tile_m, tile_n;
-    // epilogue through the wave's own LDS area (as conv16_kernel); the producers keep staging the next tile meanwhile
-    auto epilogue = [&]() __attribute__((always_inline)) {
-        const int m0 = tile_m * 128, n0 = tile_n * 128;
-        if (p.dbg & 8) return;
-#pragma unroll
-        for (int jh = 0; jh < TN; ++jh) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = {acc[i][jh][4 * q], acc[i][jh][4 * q + 1], acc[i][jh][4 * q + 2], acc[i][jh][4 * q + 3]};
-                    *reinterpret_cast<float4*>(&es[l31 * LDE + i * 32 + 8 * q + 4 * h]) = v;
-                }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < 32 / ROWS_PER; ++it) {
-                const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
-                const int m = m0 + wn * TN * 32 + jh * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
-                float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
-                const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
-                const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
-                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                if (p.mask) {
-                    const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
-                    v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
-                }
-                if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(p.D + off) = v;
+            for (int q = 0; q < 4; ++q) {
+                float4 v = {acc[i][jh][4 * q], acc[i][jh][4 * q + 1], acc[i][jh][4 * q + 2], acc[i][jh][4 * q + 3]};
+                *reinterpret_cast<float4*>(&es[l31 * LDE + i * 32 + 8 * q + 4 * h]) = v;
             }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / ROWS_PER; ++it) {
+            const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
+            const int m = m0 + wn * TN * 32 + jh * 32 + row, col = n0 + wm * TM * 32 + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+            const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+            const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.mask) {
+                const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+                v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+            }
+            if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(p.D + off) = v;
         }
-    };
-    // a tile's last slice may fall on either register set: the tile-end handling follows both half-steps (no parity-dependent paths
-    // with different register assignments - the compiler answers those with 64 accumulator moves per slice and spills)
-    auto tile_end = [&]() __attribute__((always_inline)) -> bool {
-        epilogue();
-        L += G;
-        if (L >= total) return true;
-        locate(L, tile_m, tile_n);
-        zero_acc();
-        return false;
-    };
-    locate(L, tile_m, tile_n);
-    zero_acc();
-    const int per_tile = nch * RS;
-    int left = per_tile;
-    for (;;) {
-        step(set0{}, set1{});
-        if (--left == 0) { if (tile_end()) break; left = per_tile; }
-        step(set1{}, set0{});
-        if (--left == 0) { if (tile_end()) break; left = per_tile; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1398,7 +1021,7 @@ int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     q.ph_tiles_m = tiles_m;
     q.dbg = dbg16();
     if (!(q.ksplit > 1 && q.slab)) { q.ksplit = 1; q.slab = nullptr; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n), (unsigned)q.ksplit), dim3(conv16_ws<MMA, TM, TN>() ? 512 : 256), lds, st, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n), (unsigned)q.ksplit), dim3(256), lds, st, q);
     ctgan_set_last_kernel(name);
     int rc = ctgan_check_launch(name);
     if (rc || q.ksplit == 1) return rc;
@@ -1407,44 +1030,27 @@ int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     return ctgan_check_launch("conv16_splitk_epilogue");
 }
 
-int launch_conv16x3p(const P16& p, hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * 3 * (128 + 128) * (32 + 8) * 2 + (size_t)4 * 32 * (64 + 4) * 4;      // two stages + the consumers' epilogue areas
-    auto kern = p.relu_in ? conv16x3p_kernel<true> : conv16x3p_kernel<false>;
-    static bool attr[2] = {false, false};
-    if (!attr[p.relu_in ? 1 : 0]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3p: cannot reserve %zu B of LDS", lds);
-        attr[p.relu_in ? 1 : 0] = true;
-    }
-    P16 q = p;
-    q.ph_tiles_m = (p.M + 127) / 128;
-    q.dbg = dbg16();
-    q.ksplit = 1; q.slab = nullptr;
-    const long long total = (long long)q.nph * q.ph_tiles_m * ((p.Ng + 127) / 128);
-    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, q);
-    ctgan_set_last_kernel("conv16x3p<128x128,k32>");
-    return ctgan_check_launch("conv16x3p<128x128,k32>");
-}
-
 // the halo-patch form takes: one phase, gather stride 1, whole-row tiles inside one image (128 % Q == 0, P*Q % 128 == 0), kout a multiple of
-// 128, 16-channel chunks, and enough taps to carry the next patch's batches (n_iters + 2 <= R*S: not 1x1 convs)
+// 128, 32-channel chunks, more than one tap, a patch of at most 256 pixels (8 float4 items per thread)
+size_t conv16x3h_lds(const PatchGeom& g) {
+    const size_t stages = (size_t)3 * (128 + g.NPX) * 40 * 2, epi = (size_t)4 * 32 * 68 * 4;
+    return stages > epi ? stages : epi;
+}
 bool conv16x3h_ok(const P16& p, PatchGeom* out) {
-    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 16 || p.Q <= 0 || 128 % p.Q || (p.P * p.Q) % 128 || p.M % 128) return false;
+    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 32 || p.Q <= 0 || 128 % p.Q || (p.P * p.Q) % 128 || p.M % 128) return false;
     const int R = p.ph_T[0], S = p.ph_U[0];
+    if (R * S < 2) return false;
     PatchGeom g;
     g.TR = 128 / p.Q; g.PW = p.Q + S - 1; g.NPX = (g.TR + R - 1) * g.PW;
-    g.n_iters = (g.NPX * 4 + 255) / 256;
-    if (g.n_iters + 2 > R * S) return false;
-    const size_t lds = (size_t)3 * 3 * 128 * 24 * 2 + (size_t)2 * 3 * g.NPX * 24 * 2 + (size_t)4 * 32 * 68 * 4;
-    if (lds > 160 * 1024) return false;
+    g.n_it = (g.NPX * 8 + 255) / 256;
+    if (g.n_it > 8 || conv16x3h_lds(g) > 80 * 1024) return false;      // two workgroups per CU
     if (out) *out = g;
     return true;
 }
 int launch_conv16x3h(const P16& p, hipStream_t st) {
     PatchGeom pg;
     if (!conv16x3h_ok(p, &pg)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv16x3h: shape outside the halo-patch form");
-    const size_t lds = (size_t)3 * 3 * 128 * 24 * 2 + (size_t)2 * 3 * pg.NPX * 24 * 2 + (size_t)4 * 32 * 68 * 4;
+    const size_t lds = conv16x3h_lds(pg);
     auto kern = p.relu_in ? conv16x3h_kernel<true> : conv16x3h_kernel<false>;
     static size_t reserved[2] = {0, 0};
     size_t& have = reserved[p.relu_in ? 1 : 0];
@@ -1457,11 +1063,9 @@ int launch_conv16x3h(const P16& p, hipStream_t st) {
     q.ph_tiles_m = p.M / 128;
     q.dbg = dbg16();
     q.ksplit = 1; q.slab = nullptr;
-    const long long total = (long long)q.ph_tiles_m * (p.Ng / 128);
-    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    hipLaunchKernelGGL(kern, dim3((unsigned)(total < cus ? total : cus)), dim3(512), lds, st, q, pg);
-    ctgan_set_last_kernel("conv16x3h<128x128,c16>");
-    return ctgan_check_launch("conv16x3h<128x128,c16>");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
+    ctgan_set_last_kernel("conv16x3h<128x128,k32>");
+    return ctgan_check_launch("conv16x3h<128x128,k32>");
 }
 
 template <int MMA>
@@ -1489,12 +1093,11 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
 template <int MMA>
 int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
     if constexpr (planes<MMA>() == 3) {
-        // split mode: three planes per operand in LDS - 32-deep slices; the 128x128 tile keeps ONE 60 KB stage (two workgroups per CU)
+        // split mode: stride-1 whole-row tiles go to the halo-patch kernel; everything else to the slice kernels with three planes per
+        // operand in LDS - 32-deep slices, the 128x128 tile with ONE 60 KB stage (two workgroups per CU)
         static const int halo = [] { const char* e = getenv("CTGAN_X3_HALO"); return e ? atoi(e) : 1; }();      // 2: also for launches of few tiles (tests)
         if (halo && (!small || halo == 2) && conv16x3h_ok(p, nullptr)) return launch_conv16x3h(p, st);
         if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16x3<64x64,k32,ksplit>" : "conv16x3<64x64,k32>");
-        static const int persist = [] { const char* e = getenv("CTGAN_X3_PERSIST"); return e ? atoi(e) : 1; }();
-        if (persist) return launch_conv16x3p(p, st);
         return launch_conv16<MMA, 2, 2, 32>(p, st, "conv16x3<128x128,k32>");
     } else
     if (p.C % 64 == 0) {
@@ -1592,6 +1195,20 @@ int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     if (op == CTGAN_CONV_DGRAD) return shape_ok_dgrad(d) ? 1 : 0;
     if (op == CTGAN_CONV_WGRAD) return (shape_ok_wgrad(d) && (mma != CTGAN_MMA_F32X3 || shape_ok_wgrad_x3(d))) ? 1 : 0;
     return 0;
+}
+
+int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
+    // 1 where the split mode's halo-patch kernel takes the launch AND the launch fills the chip (>= 192 tiles of 128x128): the
+    // layers on which CTGAN_MMA_F32X3 is measured faster than the fp32 MFMA family (tools/conv16_bench.py: 170-200 vs 110-125 TFLOP/s)
+    if (!d || (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD)) return 0;
+    if (op == CTGAN_CONV_FWD ? !shape_ok_fwd(d) : (!shape_ok_dgrad(d) || d->stride != 1)) return 0;
+    P16 p{};
+    p.nph = 1; p.stride = d->stride;
+    p.ph_T[0] = d->R; p.ph_U[0] = d->S;
+    if (op == CTGAN_CONV_FWD) { p.Ng = d->K; p.C = d->C; p.P = d->P; p.Q = d->Q; p.M = d->N * d->P * d->Q; }
+    else { p.Ng = d->C; p.C = d->K; p.P = d->H; p.Q = d->W; p.M = d->N * d->H * d->W; }
+    if (!conv16x3h_ok(p, nullptr)) return 0;
+    return (long long)(p.M / 128) * (p.Ng / 128) >= 192 ? 1 : 0;
 }
 
 size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op, int mma) {

@@ -62,6 +62,23 @@ def _ptr(t):
 # stay fp32 in HBM, filters are packed to 16 bits once per weight version.  Few-channel layers and everything else stay fp32.
 MMA_DTYPE = os.environ.get('CTGAN_MMA') or None      # experiments: start in a 16-bit mode without touching the caller
 _MMA_CODE = {'bf16': 1, 'f16': 2, 'f32x3': 3}
+# Opt-in (CTGAN_X3_HYBRID=1) for the fp32 mode (MMA_DTYPE None): the layers on which the split mode 'f32x3' (fp32 operands as three bf16
+# terms, six bf16 MFMAs per product - fp32 accuracy, tests/test_gpu_kernels16.py) is the faster fp32 path - stride-1 convs / data
+# gradients on whole-row 128x128 tiles that fill the chip (ctgan_conv2d16_x3_prefers) - run on it; every other layer stays on the fp32
+# MFMA family.  Off by default: on the headline only the 14 launches per iteration without a fused dropout / upsample epilogue
+# qualify today (18.61 vs 19.04 ms per iteration, profiles/r02_bench_resnet_x3hybrid.json), so the headline stays on one family.
+X3_HYBRID = os.environ.get('CTGAN_X3_HYBRID', '0') == '1'
+
+
+def _conv_mode(d, op, plain):
+    """The 16-bit-family mode this launch runs in (None: fp32 MFMA family); `plain` = no epilogue the 16-bit family lacks."""
+    if not plain:
+        return None
+    if MMA_DTYPE is not None:
+        return MMA_DTYPE if lib.ctgan_conv2d16_supported(ctypes.byref(d), op, _MMA_CODE[MMA_DTYPE]) else None
+    if X3_HYBRID and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), op):
+        return 'f32x3'
+    return None
 _STABLE_PTRS = set()      # data_ptr of derived fp32 filters (spread filters) whose contents only change with the registry epoch
 _pack16 = {}              # (data_ptr, op, dtype, geometry) -> [packed int16 buffer, registry epoch it was built for]
 
@@ -93,13 +110,13 @@ def clear_pack16_cache():
     _pack16.clear()
 
 
-def _packed16(w, d, op, g):
-    """The 16-bit packed image of filter `w` for op (0 fwd, 1 dgrad) - cached per registry epoch for parameters and for derived
-    filters registered in _STABLE_PTRS; packed per call for any other tensor."""
+def _packed16(w, d, op, g, mode):
+    """The 16-bit packed image of filter `w` for op (0 fwd, 1 dgrad) in `mode` - cached per registry epoch for parameters and for
+    derived filters registered in _STABLE_PTRS; packed per call for any other tensor."""
     from . import tflib
-    n = lib.ctgan_conv2d16_filter_elems(ctypes.byref(d), op, _MMA_CODE[MMA_DTYPE])
+    n = lib.ctgan_conv2d16_filter_elems(ctypes.byref(d), op, _MMA_CODE[mode])
     stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _STABLE_PTRS
-    key = (w.data_ptr(), op, MMA_DTYPE, g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
+    key = (w.data_ptr(), op, mode, g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     ver = tflib.epoch()
     ent = _pack16.get(key) if stable else None
     if ent is not None and ent[1] == ver:
@@ -110,7 +127,7 @@ def _packed16(w, d, op, g):
         ent = [torch.empty(n, dtype=torch.int16, device=w.device), None]
         if stable:
             _pack16[key] = ent
-    check(lib.ctgan_conv2d16_pack_filter(ctypes.byref(d), op, _MMA_CODE[MMA_DTYPE], _ptr(w), _ptr(ent[0]), _stream()), 'conv2d16_pack_filter')
+    check(lib.ctgan_conv2d16_pack_filter(ctypes.byref(d), op, _MMA_CODE[mode], _ptr(w), _ptr(ent[0]), _stream()), 'conv2d16_pack_filter')
     ent[1] = ver
     return ent[0]
 
@@ -275,10 +292,10 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
         assert is_dense_like(resid, y)
     d = g.desc(N, x.stride(), y.stride())
     fl = (1 if relu else 0) | (2 if relu_in else 0) | (8 if (resid_up and resid is not None) else 0)
-    if (MMA_DTYPE is not None and drop is None and not (fl & 8) and not fewch_handles(g)
-            and lib.ctgan_conv2d16_supported(ctypes.byref(d), 0, _MMA_CODE[MMA_DTYPE])):
-        wp = _packed16(w, d, 0, g)
-        code = _MMA_CODE[MMA_DTYPE]
+    mode = _conv_mode(d, 0, drop is None and not (fl & 8) and not fewch_handles(g))
+    if mode is not None:
+        wp = _packed16(w, d, 0, g, mode)
+        code = _MMA_CODE[mode]
         nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), 0)
         ws = workspace(nb, x.device) if nb else None
         _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd(ctypes.byref(d), code, _ptr(x), _ptr(wp), _ptr(bias), _ptr(resid), _ptr(y), fl, _ptr(ws), nb, _stream()), 'conv2d16_fwd'))
@@ -336,9 +353,10 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
         mask = match_layout(mask, dx)
     if resid is not None:
         resid = match_layout(resid, dx)
-    if (MMA_DTYPE is not None and drop is None and not fewch_handles(g) and lib.ctgan_conv2d16_supported(ctypes.byref(d), 1, _MMA_CODE[MMA_DTYPE])):
-        wp = _packed16(w, d, 1, g)
-        code = _MMA_CODE[MMA_DTYPE]
+    mode = _conv_mode(d, 1, drop is None and not fewch_handles(g))
+    if mode is not None:
+        wp = _packed16(w, d, 1, g, mode)
+        code = _MMA_CODE[mode]
         nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), 1)
         ws = workspace(nb, gy.device) if nb else None
         _timed(g, N, lambda: check(lib.ctgan_conv2d16_dgrad(ctypes.byref(d), code, _ptr(gy), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), 0, _ptr(ws), nb, _stream()), 'conv2d16_dgrad'))

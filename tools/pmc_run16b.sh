@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
     k = r.get('Kernel_Name', '')
-    if '16_kernel' not in k: continue
+    if 'conv16' not in k and 'wgrad16' not in k: continue
     agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for c, v in agg.items():
     print('%-40s n=%d mean=%.5g' % (c, len(v), sum(v) / len(v)))
