@@ -133,6 +133,26 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         roofline = measure_roofline(trainer, next_batch, K, torch)
+    # the same loop with every layer on the fp32 MFMA family (no split-mode routing), for comparison: 50 iterations on a second engine
+    fp32_only = None
+    if K.X3_HYBRID and K.MMA_DTYPE is None and rank == 0 and world == 1 and not args.no_roofline:
+        K.X3_HYBRID = False
+        try:
+            eng2 = GraphedTrainer(trainer, use_graphs=not args.no_graph)
+            for _ in range(10):
+                eng2.train_iteration(it, next_batch); it += 1
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                eng2.train_iteration(it, next_batch); it += 1
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            fp32_only = {'value': round(R.cfg.N_CRITIC * B * 50 / dt2, 2), 'ms_per_step': round(1e3 * dt2 / 50, 3), 'steps': 50,
+                         'note': 'CTGAN_X3_HYBRID=0: every layer on the fp32 MFMA family'}
+            del eng2
+        finally:
+            K.X3_HYBRID = True
+
     gp_unit = None
     step_exec = None
     if not args.no_roofline and rank == 0:
@@ -157,7 +177,12 @@ def main():
                                    'N_CRITIC=5 + 1 G step (128 samples) per step', 'global_batch': B * world,
                        'images_per_step': R.cfg.N_CRITIC * B * world, 'parallelism': 'dp%d' % world,
                        'hipgraph': bool(eng.graphed), 'last_d_cost': last_cost, 'last_d_terms': last, 'loss_sane': sane,
-                       'rccl_world': world if world > 1 else None},
+                       'rccl_world': world if world > 1 else None,
+                       'arithmetic': ('fp32 throughout; the large stride-1 conv layers (roofline.by_kernel: conv16x3h) compute the fp32 products as '
+                                      'three-bf16-term splits on the bf16 matrix cores (six MFMAs per product, fp32 accumulate; error vs fp64 '
+                                      'no larger than the fp32 MFMA family\'s, tests/test_gpu_kernels16.py, DESIGN 4.6), every other layer on '
+                                      'v_mfma_f32_32x32x2_f32' if (K.X3_HYBRID and K.MMA_DTYPE is None) else 'fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout'),
+                       'fp32_mfma_only': fp32_only},
             'ms_per_step_p50': round(p50, 3),
             'step': step_exec,
             'step_effective_frac': round(ITER_GFLOP * 1e9 / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
@@ -342,11 +367,19 @@ def measure_roofline(trainer, next_batch, K, torch):
     # a split-mode kernel (opt-in: CTGAN_MMA=f32x3 / CTGAN_X3_HYBRID=1) executes SIX bf16 MFMAs per algorithmic fp32 product: its
     # peak in algorithmic FLOPs is the dense bf16 peak / 6, not the fp32 MFMA peak
     peak = PEAK_16BIT_MFMA_TFLOPS / 6.0 if 'x3' in name else PEAK_F32_MFMA_TFLOPS
+    f32_top = None
+    f32_items = [(k, v) for k, v in agg.items() if 'x3' not in k]
+    if 'x3' in name and f32_items:
+        k2, (c2, f2, t2) = max(f32_items, key=lambda kv: kv[1][2])
+        f32_top = {'kernel': k2, 'launches': c2, 'avg_launch_us': round(t2 / c2 * 1e6, 2), 'achieved': round(f2 / t2 / 1e12, 2),
+                   'peak': PEAK_F32_MFMA_TFLOPS, 'frac': round(f2 / t2 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     return {
         'bound': 'mfma', 'kernel': name, 'launches': cnt,
         'flops_per_launch': round(fl / cnt / 1e9, 3), 'avg_launch_us': round(tt / cnt * 1e6, 2),
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': traffic,
+        'peak_note': ('dense bf16 MFMA peak / 6: a split-mode kernel issues six bf16 MFMAs per fp32 product' if 'x3' in name else 'fp32 MFMA peak'),
+        'top_fp32_mfma_kernel': f32_top,
         'kernel_share_of_conv_time': round(tt / total_t, 3),
         'all_conv_kernels': {'achieved': round(total_f / total_t / 1e12, 2),
                              'frac': round(total_f / total_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),

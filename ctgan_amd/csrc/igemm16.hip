@@ -174,6 +174,7 @@ struct P16 {
     int M, Ng;                      // rows per phase, output channels
     long long ds_n, ds_p, ds_q;     // D strides over (n, phase-grid row, phase-grid col); channel stride 1
     int relu, relu_in;
+    int resid_up;                   // halo-patch kernel only: resid is the dense channels-last [N, P/2, Q/2, Ng] tensor, added through a nearest-2x upsample
     unsigned x_bytes, w_bytes;      // w_bytes covers every plane
     unsigned w_plane_bytes;         // split mode: byte distance between the filter's planes
     int nph, ph_tiles_m;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
 
 // ---------------------------------------------------------------------------------------------- split mode, halo-patch form
 // conv16x3h: stride-1 R x S convolutions (forward, and the data gradient of a stride-1 conv) on 128 kout x 128 pixel tiles that are
-// whole image rows (128 / Q rows of a Q-wide image).  In the slice-per-(tap, channel chunk) kernel every pixel value is loaded,
+// whole image rows (128 / Q rows of a Q-wide image) or whole images (two 8x8 images, each with its own halo block).  In the slice-per-(tap, channel chunk) kernel every pixel value is loaded,
 // split into its three bf16 terms and written to LDS once PER TAP - R*S times - and that staging work (VALU + LDS stores issued
 // beside the MFMAs; tools/mfma_loop_probe.hip: 100 VALU + 18 stores per 48 MFMAs cost 35 % of the matrix rate) is what holds it
 // at half the matrix rate.  Here a workgroup stages, per 32-channel chunk, the tile's pixels PLUS THEIR HALO once - a
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
 // only the 24 KB filter slice moves.  Pixel-operand loads, split VALU and LDS stores drop by R*S * 128 / patch pixels (5.6x for
 // 3x3 on 32-wide images).  Single LDS stage, two workgroups of 4 waves per CU (80 KB each) as conv16_single_stage: the other
 // workgroup multiplies while this one stages.
-struct PatchGeom { int TR, PW, NPX, n_it; };              // tile rows, patch width, patch pixels, float4 items per thread per patch
+// tile = TR rows of IMGS images each (IMGS > 1: whole images smaller than the tile); per image a (TR + R - 1) x PW patch block
+struct PatchGeom { int TR, PW, NPX, n_it, IMGS, PIMG; };  // rows per image, patch width, patch pixels, float4 items per thread, images, patch pixels per image
 
 template <bool RELU_IN>
 __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const PatchGeom pg) {
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const int nch = p.C / BK;
     const int PQ = p.P * p.Q;
-    const int img = m0 / PQ, row0 = (m0 - img * PQ) / p.Q;
+    const int img = m0 / PQ, row0 = (m0 - img * PQ) / p.Q;        // first image / first row (0 when the tile holds whole images)
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wp), 0, p.w_bytes, 0x00020000);
@@ -539,10 +541,11 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
         const int item = it * NT + tid, px = item >> 3;
         p_voff[it] = 0xFFFFFFFFu;
         if (it < pg.n_it && px < pg.NPX) {
-            const int prow = px / pg.PW, pcol = px - prow * pg.PW;
+            const int pi = px / pg.PIMG, pr = px - pi * pg.PIMG;      // image of the tile, pixel inside its patch block
+            const int prow = pr / pg.PW, pcol = pr - prow * pg.PW;
             const int ih = row0 + prow - p.ph_pad_t[0], iw = pcol - p.ph_pad_l[0];
             if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                p_voff[it] = (unsigned)(((long long)img * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + (item & 7) * 4) * 4);
+                p_voff[it] = (unsigned)(((long long)(img + pi) * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + (item & 7) * 4) * 4);
         }
     }
     auto load_patch = [&](int chunk) __attribute__((always_inline)) {
@@ -578,10 +581,13 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int h = lane >> 5, l31 = lane & 31;
-    // patch index (tap (0,0)) of this lane's pixel in fragment j: tile pixel t = wn*64 + j*32 + l31 -> (t / Q, t % Q)
+    // patch index (tap (0,0)) of this lane's pixel in fragment j: tile pixel t = wn*64 + j*32 + l31 -> (image, row, column)
     int pix[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { const int tp = wn * 64 + j * 32 + l31; pix[j] = (tp / p.Q) * pg.PW + (tp % p.Q); }
+    for (int j = 0; j < TN; ++j) {
+        const int tp = wn * 64 + j * 32 + l31, per = pg.TR * p.Q, ti = tp / per, tr = tp - ti * per;
+        pix[j] = ti * pg.PIMG + (tr / p.Q) * pg.PW + (tr % p.Q);
+    }
     constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
 
     load_patch(0);
@@ -652,7 +658,11 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
                 const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
                 v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
             }
-            if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (p.resid) {
+                const long long ro = p.resid_up ? ((((long long)n * (p.P >> 1) + (pp >> 1)) * (p.Q >> 1) + (qq >> 1)) * p.Ng + col) : off;
+                const float4 r = *reinterpret_cast<const float4*>(p.resid + ro);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(p.D + off) = v;
         }
@@ -1037,11 +1047,15 @@ size_t conv16x3h_lds(const PatchGeom& g) {
     return stages > epi ? stages : epi;
 }
 bool conv16x3h_ok(const P16& p, PatchGeom* out) {
-    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 32 || p.Q <= 0 || 128 % p.Q || (p.P * p.Q) % 128 || p.M % 128) return false;
+    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 32 || p.Q <= 0 || p.M % 128) return false;
+    const int PQ = p.P * p.Q;
+    if (!(PQ % 128 == 0 && 128 % p.Q == 0) && !(PQ < 128 && 128 % PQ == 0)) return false;      // whole rows of one image, or whole images
     const int R = p.ph_T[0], S = p.ph_U[0];
     if (R * S < 2) return false;
     PatchGeom g;
-    g.TR = 128 / p.Q; g.PW = p.Q + S - 1; g.NPX = (g.TR + R - 1) * g.PW;
+    g.IMGS = PQ < 128 ? 128 / PQ : 1;
+    g.TR = PQ < 128 ? p.P : 128 / p.Q;
+    g.PW = p.Q + S - 1; g.PIMG = (g.TR + R - 1) * g.PW; g.NPX = g.IMGS * g.PIMG;
     g.n_it = (g.NPX * 8 + 255) / 256;
     if (g.n_it > 8 || conv16x3h_lds(g) > 80 * 1024) return false;      // two workgroups per CU
     if (out) *out = g;
@@ -1273,12 +1287,18 @@ int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const 
     p.M = d->N * d->P * d->Q; p.Ng = d->K;
     p.ds_n = d->ys[0]; p.ds_p = d->ys[2]; p.ds_q = d->ys[3];
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
+    p.resid_up = (resid && (flags & CTGAN_RESID_UP)) ? 1 : 0;
     p.x_bytes = (unsigned)(x_extent * 4); p.w_plane_bytes = (unsigned)w_plane; p.w_bytes = (unsigned)(w_plane * mma_planes(mma));
     p.nph = 1;
     p.slab = (float*)ws; p.slab_bytes = ws ? ws_bytes : 0;
     p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
     p.ph_T[1] = d->R; p.ph_U[1] = d->S; p.ph_pad_t[1] = d->pad_t; p.ph_pad_l[1] = d->pad_l;
     hipStream_t st = (hipStream_t)stream;
+    if (p.resid_up) {                                        // only the halo-patch kernel reads the residual through the upsample
+        if (mma != CTGAN_MMA_F32X3 || ((d->P | d->Q) & 1) || !conv16x3h_ok(p, nullptr))
+            return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: CTGAN_RESID_UP outside the halo-patch form");
+        return launch_conv16x3h(p, st);
+    }
     return run_conv16(mma, p, st);
 }
 

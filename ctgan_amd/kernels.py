@@ -62,12 +62,11 @@ def _ptr(t):
 # stay fp32 in HBM, filters are packed to 16 bits once per weight version.  Few-channel layers and everything else stay fp32.
 MMA_DTYPE = os.environ.get('CTGAN_MMA') or None      # experiments: start in a 16-bit mode without touching the caller
 _MMA_CODE = {'bf16': 1, 'f16': 2, 'f32x3': 3}
-# Opt-in (CTGAN_X3_HYBRID=1) for the fp32 mode (MMA_DTYPE None): the layers on which the split mode 'f32x3' (fp32 operands as three bf16
-# terms, six bf16 MFMAs per product - fp32 accuracy, tests/test_gpu_kernels16.py) is the faster fp32 path - stride-1 convs / data
-# gradients on whole-row 128x128 tiles that fill the chip (ctgan_conv2d16_x3_prefers) - run on it; every other layer stays on the fp32
-# MFMA family.  Off by default: on the headline only the 14 launches per iteration without a fused dropout / upsample epilogue
-# qualify today (18.61 vs 19.04 ms per iteration, profiles/r02_bench_resnet_x3hybrid.json), so the headline stays on one family.
-X3_HYBRID = os.environ.get('CTGAN_X3_HYBRID', '0') == '1'
+# fp32 mode (MMA_DTYPE None): the layers on which the split mode 'f32x3' (fp32 operands as three bf16 terms, six bf16 MFMAs per product -
+# fp32 accuracy, tests/test_gpu_kernels16.py) is the faster fp32 path - stride-1 convs / data gradients on whole-row or whole-image
+# 128x128 tiles that fill the chip (ctgan_conv2d16_x3_prefers; 170-200 vs 110-125 TFLOP/s) - run on it; every other layer stays on the
+# fp32 MFMA family.  Headline: 17.74 vs 19.04 ms per iteration.  CTGAN_X3_HYBRID=0: fp32 MFMA only (bench.py reports both).
+X3_HYBRID = os.environ.get('CTGAN_X3_HYBRID', '1') != '0'
 
 
 def _conv_mode(d, op, plain):
@@ -79,6 +78,15 @@ def _conv_mode(d, op, plain):
     if X3_HYBRID and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), op):
         return 'f32x3'
     return None
+
+
+_X3_LOG = os.environ.get('CTGAN_X3_LOG') == '1'      # diagnosis: which large stride-1 launches the hybrid routing leaves on the fp32 family, and why
+
+
+def _x3_log(g, N, d, op, **why):
+    if _X3_LOG and g.stride == 1 and g.R == 3 and N * g.P * g.Q >= 24576 and g.C % 32 == 0:
+        print('x3-log op%d N%d C%d %dx%d K%d prefers=%d %s xs=%s ys=%s' % (op, N, g.C, g.H, g.W, g.K, lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), op),
+                                                                 why, tuple(d.xs), tuple(d.ys)), flush=True)
 _STABLE_PTRS = set()      # data_ptr of derived fp32 filters (spread filters) whose contents only change with the registry epoch
 _pack16 = {}              # (data_ptr, op, dtype, geometry) -> [packed int16 buffer, registry epoch it was built for]
 
@@ -292,7 +300,12 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
         assert is_dense_like(resid, y)
     d = g.desc(N, x.stride(), y.stride())
     fl = (1 if relu else 0) | (2 if relu_in else 0) | (8 if (resid_up and resid is not None) else 0)
-    mode = _conv_mode(d, 0, drop is None and not (fl & 8) and not fewch_handles(g))
+    plain = drop is None and not fewch_handles(g)
+    mode = _conv_mode(d, 0, plain and not (fl & 8))
+    if (mode is None and (fl & 8) and plain and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID))
+            and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 0)):
+        mode = 'f32x3'                                # the halo-patch kernel reads the residual through the 2x upsample itself
+    _x3_log(g, N, d, 0, drop=drop is not None, resid_up=bool(fl & 8), x_up=bool(g.x_up))
     if mode is not None:
         wp = _packed16(w, d, 0, g, mode)
         code = _MMA_CODE[mode]
@@ -354,6 +367,7 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
     if resid is not None:
         resid = match_layout(resid, dx)
     mode = _conv_mode(d, 1, drop is None and not fewch_handles(g))
+    _x3_log(g, N, d, 1, drop=drop is not None)
     if mode is not None:
         wp = _packed16(w, d, 1, g, mode)
         code = _MMA_CODE[mode]

@@ -120,6 +120,7 @@ X3_CASES = CASES + [
     (24, 32, 32, 32, 128, 3, 1),      # 32-wide images: tile = 4 rows, 6 x 34 patch
     (96, 32, 16, 16, 128, 3, 1),      # 16-wide images: tile = 8 rows (half an image), 10 x 18 patch
     (96, 32, 16, 16, 128, 5, 1),      # 5x5 taps: 12 x 20 patch = 88 KB with the filter stage - slice kernel
+    (384, 32, 8, 8, 128, 3, 1),       # 8x8 images: tile = two whole images, each with its own 10 x 10 halo block
     (96, 64, 32, 32, 128, 4, 2),      # stride 2 (the folded ConvMeanPool filter): single-stage 128x128 slice kernel; data gradient in 4 phases
 ]
 
@@ -159,7 +160,12 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
     want = {'fwd': ref, 'fwd+epi': ref2, 'dgrad': gx_ref, 'dgrad+epi': ref_gx2, 'wgrad': gw_ref}
     with K.mma_dtype('f32x3'):
         got3, kern3 = run()
-    got1, _ = run()
+    hybrid, K.X3_HYBRID = K.X3_HYBRID, False
+    try:
+        got1, kern1 = run()                                  # the fp32 MFMA family
+    finally:
+        K.X3_HYBRID = hybrid
+    assert kern1['fwd'].startswith('igemm') or kern1['fwd'].startswith('fewch'), kern1
     assert kern3['fwd'].startswith('conv16x3') and kern3['dgrad'].startswith('conv16x3'), kern3
     if case in X3_CASES[len(CASES):]:
         want_kernel = 'conv16x3h' if (st == 1 and k == 3) else 'conv16x3<128x128'      # (5x5: the patch does not fit two workgroups per CU)
@@ -172,6 +178,26 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
         assert e3 <= max(2.0 * e1, 3e-7), (what, e3, e1)
         m3, m1 = relerr(got3[what], want[what]), relerr(got1[what], want[what])
         assert m3 <= max(3.0 * m1, 1e-6), (what, m3, m1)
+
+
+def test_f32x3_halo_kernel_adds_the_upsampled_residual(K):
+    """UpsampleConv shortcut (CTGAN_RESID_UP): the dense [N, K, P/2, Q/2] residual is added through a nearest-2x upsample inside the
+    halo-patch kernel's epilogue - equal to the fp32 family's result on the same inputs to fp32 rounding."""
+    N, C, H, Ko = 24, 32, 32, 128
+    geom = K.ConvGeom(C, H, H, Ko, 3, 3, 1, False)
+    g = torch.Generator().manual_seed(11)
+    x, w, b = cl(torch.randn(N, C, H, H, generator=g)), (torch.randn(3, 3, C, Ko, generator=g) / 17).cuda(), torch.randn(Ko, generator=g).cuda()
+    r = cl(torch.randn(N, Ko, H // 2, H // 2, generator=g))
+    hybrid, K.X3_HYBRID = K.X3_HYBRID, False
+    try:
+        want = K.conv_fwd(x, w, b, geom, resid=r, resid_up=True, relu_in=True)
+    finally:
+        K.X3_HYBRID = hybrid
+    assert K.last_kernel().startswith('igemm'), K.last_kernel()
+    with K.mma_dtype('f32x3'):
+        got = K.conv_fwd(x, w, b, geom, resid=r, resid_up=True, relu_in=True)
+        assert K.last_kernel().startswith('conv16x3h'), K.last_kernel()
+    assert relerr(got, want) < 2e-6
 
 
 def test_conv16_wgrad_runs_on_the_16bit_kernel_and_is_deterministic(K):

@@ -261,25 +261,35 @@ def test_fused_critic_heads_equal_separate_head_kernels(setup, dim, B):
     dD/dz of the last block (F.gp_head_grad) against the op-by-op head on identical Philox streams: every loss term, the
     critic outputs, dD/dx_hat and all parameter gradients of a critic step."""
     import ctgan_amd.functional as F
+    import ctgan_amd.kernels as K
     R, lib = setup(dim, B)
     g = torch.Generator().manual_seed(33)
     real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32).cuda()
     lab = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32).cuda()
     tr = R.Trainer(seed=11)
-    fake = tr.generate_fakes(lab)[0]
     res = {}
-    for mode in (False, True):
-        R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = mode            # also: input preparation / concat+dropout in single launches
-        try:
-            tr.rng.begin_step()
-            out = tr.d_losses(real, lab, fake=fake)
-            with F.deferred_wgrads():
-                grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
-            res[mode] = ({k: out[k].detach().clone() for k in ('cost', 'wgan', 'ct', 'acgan', 'gp', 'd_real', 'd_fake', 'gp_grads',
-                                                               'acc_real', 'acc_fake')},
-                         [None if t is None else t.detach().clone() for t in grads])
-        finally:
-            R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = True
+    # The two forms batch the critic's rows differently (384-row shared tail vs separate passes), so with the split-mode routing on
+    # they would not run the same conv kernels (kernels.X3_HYBRID routes by launch size); this equivalence is checked at 2e-5 / 5e-5 on
+    # ONE conv family and on the fake batch that family generates (the tolerance leaves no room for a ReLU mask that flips between
+    # the forms; whether one does depends on the inputs).  The routed path itself is checked against the oracle by the step / loop
+    # parity tests.
+    hybrid, K.X3_HYBRID = K.X3_HYBRID, False
+    try:
+        fake = tr.generate_fakes(lab)[0]
+        for mode in (False, True):
+            R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = mode            # also: input preparation / concat+dropout in single launches
+            try:
+                tr.rng.begin_step()
+                out = tr.d_losses(real, lab, fake=fake)
+                with F.deferred_wgrads():
+                    grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+                res[mode] = ({k: out[k].detach().clone() for k in ('cost', 'wgan', 'ct', 'acgan', 'gp', 'd_real', 'd_fake', 'gp_grads',
+                                                                   'acc_real', 'acc_fake')},
+                             [None if t is None else t.detach().clone() for t in grads])
+            finally:
+                R.HEAD_FUSION = R.PREP_FUSION = R.TRUNK_SHARE = R.TAIL_SHARE = True
+    finally:
+        K.X3_HYBRID = hybrid
     for k, v in res[True][0].items():
         assert _rel_l2(v, res[False][0][k]) < 2e-5, k
     gmax = max(float(b_.abs().max()) for b_ in res[False][1] if b_ is not None)

@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
+K.X3_HYBRID = False      # families are compared explicitly here: 'f32' means the fp32 MFMA family on every layer
 
 SHAPES = [(192, 1024, 8, 8, 1024, 3, 1), (192, 128, 64, 64, 128, 3, 1), (192, 256, 32, 32, 256, 3, 1), (192, 128, 64, 64, 256, 3, 2),
           (64, 256, 8, 8, 512, 5, 2), (192, 128, 16, 16, 256, 5, 2), (64, 1024, 8, 8, 1024, 3, 1)]

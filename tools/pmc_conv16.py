@@ -6,6 +6,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ctgan_amd.kernels as K
+K.X3_HYBRID = False      # families are compared explicitly here: 'f32' means the fp32 MFMA family on every layer
 op = sys.argv[1]
 N, C, H, Ko, R, st, reps = (int(v) for v in sys.argv[2:9])
 dt = sys.argv[9] if len(sys.argv) > 9 else 'f16'

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per (kernel variant, conv geometry) table of one eager iteration of the headline (CIFAR ResNet CT-WGAN step, batch 64): launches,
 time and TFLOP/s - which layers a conv family / mode spends the step on.
-usage: python tools/shape_prof_resnet.py [mma dtype: f32 | f32x3 | bf16] [top]   (GPU box)"""
+usage: python tools/shape_prof_resnet.py [f32 (fp32 MFMA family only) | hybrid (the default routing) | f32x3 | bf16] [top]   (GPU box)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,8 @@ from ctgan_amd.engine import GraphedTrainer
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 lib.delete_all_params(); lib.set_seed(0); R.configure(); R.build_params('cuda')
-K.set_mma_dtype(None if dt == 'f32' else dt)
+K.X3_HYBRID = dt == 'hybrid'
+K.set_mma_dtype(None if dt in ('f32', 'hybrid') else dt)
 tr = R.Trainer(seed=1)
 B = R.cfg.BATCH_SIZE
 rng = np.random.default_rng(0)

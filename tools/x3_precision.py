@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import ctgan_amd.kernels as K
+K.X3_HYBRID = False      # families are compared explicitly here: 'f32' means the fp32 MFMA family on every layer
 
 SHAPES = [(16, 128, 32, 32, 128, 3, 1), (48, 128, 16, 16, 128, 3, 1), (16, 128, 32, 32, 128, 4, 2), (64, 128, 8, 8, 128, 3, 1)]
 
