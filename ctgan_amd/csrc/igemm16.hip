@@ -1212,10 +1212,25 @@ int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
 }
 
 int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
-    // 1 where the split mode's halo-patch kernel takes the launch AND the launch fills the chip (>= 192 tiles of 128x128): the
-    // layers on which CTGAN_MMA_F32X3 is measured faster than the fp32 MFMA family (tools/conv16_bench.py: 170-200 vs 110-125 TFLOP/s)
-    if (!d || (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD)) return 0;
-    if (op == CTGAN_CONV_FWD ? !shape_ok_fwd(d) : (!shape_ok_dgrad(d) || d->stride != 1)) return 0;
+    // 1 for the launches on which CTGAN_MMA_F32X3 is measured faster than the fp32 MFMA family (tools/conv16_bench.py): stride-1 layers
+    // the halo-patch kernel takes (170-200 vs 110-125 TFLOP/s), stride-2 layers on the slice kernel, large weight gradients - each only
+    // when the launch fills the chip
+    if (!d) return 0;
+    if (op == CTGAN_CONV_WGRAD) {
+        // weight gradient (wgrad16x3<128x128>): 145-167 vs 108-122 TFLOP/s from 32k pixels up; below that the fp32 family's grouped
+        // multi-segment launch keeps the layer
+        return (ctgan_conv2d16_supported(d, op, CTGAN_MMA_F32X3) && (long long)d->N * d->P * d->Q >= 32768) ? 1 : 0;
+    }
+    if (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD) return 0;
+    if (op == CTGAN_CONV_FWD ? !shape_ok_fwd(d) : !shape_ok_dgrad(d)) return 0;
+    if (d->stride == 2) {
+        // stride-2 layers (the folded ConvMeanPool / UpsampleConv filters) on the single-stage slice kernel: 145 / 160 vs 125 / 113
+        // TFLOP/s (forward / four-phase data gradient) when the launch has >= 192 tiles of 128x128
+        const long long M = op == CTGAN_CONV_FWD ? (long long)d->N * d->P * d->Q : (long long)d->N * (d->H / 2) * (d->W / 2);
+        const int Ng = op == CTGAN_CONV_FWD ? d->K : d->C, Cg = op == CTGAN_CONV_FWD ? d->C : d->K;
+        const int nph = op == CTGAN_CONV_FWD ? 1 : 4;
+        return (Ng % 128 == 0 && Cg % 32 == 0 && nph * ((M + 127) / 128) * (Ng / 128) >= 192) ? 1 : 0;
+    }
     P16 p{};
     p.nph = 1; p.stride = d->stride;
     p.ph_T[0] = d->R; p.ph_U[0] = d->S;

@@ -64,7 +64,9 @@ WGRAD_GROUPED = _os.environ.get('CTGAN_WGRAD_GROUPED', '1') != '0'
 
 
 class _WgradGroup:
-    __slots__ = ('g', 'segs', 'dw', 'db')
+    # pre: (gw, gb) results already computed for this filter (uses the split-mode kernel took at once, _wgrad): added at the flush,
+    # so that autograd still sees ONE buffer per filter, filled exactly once
+    __slots__ = ('g', 'segs', 'dw', 'db', 'pre')
 
 
 @contextlib.contextmanager
@@ -90,7 +92,8 @@ def deferred_wgrads():
 def _flush_groups(grps):
     """All queued weight gradients: one grouped launch per tile configuration + one reduction launch when every group
     fits the pipelined kernel (K.conv_wgrad_group), else group by group."""
-    simple = [g for g in grps if len(g.segs) <= K.WGRAD_MAX_SEGS and not K.fewch_handles(g.g)]
+    _all = list(grps)
+    simple = [g for g in grps if 1 <= len(g.segs) <= K.WGRAD_MAX_SEGS and not K.fewch_handles(g.g)]
     if WGRAD_GROUPED and len(simple) > 1 and K.PROFILE is None:
         for g in simple:                                   # a queued bias buffer no segment contributes to
             if g.db is not None and not any(sg[3] for sg in g.segs):
@@ -104,7 +107,18 @@ def _flush_groups(grps):
         except NotImplementedError:
             pass                                           # nothing was launched: fall back below
     for grp in grps:
-        _flush_group(grp)
+        if grp.segs:
+            _flush_group(grp)
+    for grp in (g for g in _all if g.pre):                  # results the split-mode kernel produced at request time
+        dw_set, db_set = bool(grp.segs), any(sg[3] for sg in grp.segs)
+        for gw, gb in grp.pre:
+            grp.dw.copy_(K.axpby(grp.dw, gw, 1.0, 1.0) if dw_set else gw)
+            dw_set = True
+            if gb is not None and grp.db is not None:
+                grp.db.copy_(K.axpby(grp.db, gb, 1.0, 1.0) if db_set else gb)
+                db_set = True
+        if grp.db is not None and not db_set:
+            grp.db.zero_()
 
 
 def _flush_group(grp):
@@ -161,7 +175,22 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     key = (w.data_ptr(), gk)
     grp = _DEFER['groups'].get(key)
-    if grp is not None:
+    if x.is_cuda and K.wgrad_prefers_x3(g, x.shape[0]):
+        # a large layer: the split-mode kernel is the faster fp32 path (kernels.X3_HYBRID) - launched now, its result joins the
+        # filter's queue as a finished addend (the filter keeps ONE result buffer, filled once at the flush)
+        r = K.conv_wgrad(x, gy, g, with_bias=with_bias, relu_x=relu_x)
+        now = r if with_bias else (r, None)
+        gw = gb = None
+        if grp is None:
+            grp = _WgradGroup()
+            grp.g, grp.segs, grp.db, grp.pre = g, [], None, []
+            grp.dw = gw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+            _DEFER['groups'][key] = grp
+        if with_bias and grp.db is None:
+            grp.db = gb = torch.empty(g.K, dtype=torch.float32, device=x.device)
+        grp.pre.append(now)
+        return gw, gb
+    if grp is not None and grp.segs:
         # A later use whose operands have another memory layout is repacked into the first use's layout.  It must NOT open a
         # second queue: that would hand autograd a second, still unfilled, buffer for the same parameter, and the engine
         # sums the two the moment the second arrives - before the flush has written either.
@@ -169,7 +198,7 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     gw = gb = None
     if grp is None:
         grp = _WgradGroup()
-        grp.g, grp.segs, grp.db = g, [], None
+        grp.g, grp.segs, grp.db, grp.pre = g, [], None, []
         grp.dw = gw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
         _DEFER['groups'][key] = grp
     if with_bias and grp.db is None:
@@ -408,6 +437,7 @@ _hooked = [False]
 
 
 def clear_filter_cache():
+    K._STABLE_PTRS.difference_update(_SPREAD_BUFS.keys())      # (a freed buffer's address may come back as an unrelated tensor)
     _FCACHE.clear()
     _SPREAD_BUFS.clear()
 

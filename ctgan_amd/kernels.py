@@ -80,6 +80,15 @@ def _conv_mode(d, op, plain):
     return None
 
 
+def wgrad_prefers_x3(g, N):
+    """True when the fp32 mode routes this weight gradient to the split mode (then it is launched at once, not queued for the fp32
+    family's grouped launch).  Needs dense channels-last operands, which the callers of the large layers provide."""
+    if MMA_DTYPE is not None or not X3_HYBRID or g.x_up or fewch_handles(g):
+        return False
+    d = g.desc(N, (g.C * g.H * g.W, 1, g.W * g.C, g.C), (g.K * g.P * g.Q, 1, g.Q * g.K, g.K))
+    return bool(lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 2))
+
+
 _X3_LOG = os.environ.get('CTGAN_X3_LOG') == '1'      # diagnosis: which large stride-1 launches the hybrid routing leaves on the fp32 family, and why
 
 
@@ -402,12 +411,13 @@ def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
     if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous():
         gy = to_channels_last(gy)
     d = g.desc(N, x.stride(), gy.stride())
-    if MMA_DTYPE is not None and not fewch_handles(g):
+    if (MMA_DTYPE is not None or X3_HYBRID) and not fewch_handles(g) and not g.x_up:
         gy16 = gy if gy.permute(0, 2, 3, 1).is_contiguous() else to_channels_last(gy)
         d16 = g.desc(N, x.stride(), gy16.stride())
-        if lib.ctgan_conv2d16_supported(ctypes.byref(d16), 2, _MMA_CODE[MMA_DTYPE]):
-            ws = workspace(lib.ctgan_conv2d16_wgrad_workspace_bytes(ctypes.byref(d16), _MMA_CODE[MMA_DTYPE]), x.device)
-            code = _MMA_CODE[MMA_DTYPE]
+        mode = _conv_mode(d16, 2, True)
+        if mode is not None:
+            ws = workspace(lib.ctgan_conv2d16_wgrad_workspace_bytes(ctypes.byref(d16), _MMA_CODE[mode]), x.device)
+            code = _MMA_CODE[mode]
             _timed(g, N, lambda: check(lib.ctgan_conv2d16_wgrad(ctypes.byref(d16), code, _ptr(x), _ptr(gy16), _ptr(dw), _ptr(ws), ws.numel(), 2 if relu_x else 0, _stream()), 'conv2d16_wgrad'))
             if with_bias:
                 return dw, colsum_channels(gy16)

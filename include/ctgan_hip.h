@@ -185,9 +185,11 @@ int ctgan_layernorm_bwd2(const float* u, const float* gy, const float* x, const 
  * cycle cost.  The packed filter holds the three planes one after the other.                                               */
 enum { CTGAN_MMA_BF16 = 1, CTGAN_MMA_F16 = 2, CTGAN_MMA_F32X3 = 3 };
 int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma);        /* op = CTGAN_CONV_{FWD,DGRAD,WGRAD}; 1 / 0 */
-/* 1 where CTGAN_MMA_F32X3 is the faster fp32 path for this launch (stride-1 convs / data gradients on whole-row 128x128 tiles that
- * fill the chip): the caller may route such layers through ctgan_conv2d16_{fwd,dgrad} with mma = CTGAN_MMA_F32X3 and keep every
- * other layer on the fp32 MFMA entry points - the results carry fp32 accuracy either way.                                   */
+/* 1 where CTGAN_MMA_F32X3 is the faster fp32 path for this launch (stride-1 convs / data gradients on whole-row or whole-image
+ * 128x128 tiles, stride-2 convs / data gradients, weight gradients over >= 32k pixels - each only when the launch fills the chip):
+ * the caller may route such layers through ctgan_conv2d16_{fwd,dgrad,wgrad} with mma = CTGAN_MMA_F32X3 and keep every other layer
+ * on the fp32 MFMA entry points - the results carry fp32 accuracy either way.  A forward launch with prefers = 1 and stride 1 also
+ * accepts CTGAN_RESID_UP.                                                                                                    */
 int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op);
 size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op, int mma);  /* 16-bit elements of the packed filter     */
 int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream);
