@@ -160,6 +160,46 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* _
     }
 }
 
+// all packed images of one weight version in ONE launch (a pack per filter and operator is ~5 us of launch floor each, 57 per
+// iteration on the headline): blockIdx.y = job, grid-stride over the job's pairs; a data-gradient job walks its phases in turn
+struct PackJob { const float* w; unsigned short* wp; PackPhases pp; long long plane; int op; int pad; };
+#define CTGAN_PACK_BATCH 20
+struct PackJobs { PackJob j[CTGAN_PACK_BATCH]; };
+template <int MMA>
+__global__ void pack_batch_kernel(const PackJobs jobs) {
+    const PackJob& jb = jobs.j[blockIdx.y];
+    const PackPhases& pp = jb.pp;
+    const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jb.op == CTGAN_CONV_FWD) {
+        const long long per = (long long)pp.R * pp.S * pp.C / 2, total = per * pp.K;
+        for (long long i = t0; i < total; i += stride) {
+            const int n = (int)(i / per);
+            const long long e = (i - (long long)n * per) * 2;
+            unsigned o[planes<MMA>()];
+            split_pk<MMA>(jb.w[e * pp.K + n], jb.w[(e + 1) * pp.K + n], o);
+#pragma unroll
+            for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane)[i] = o[q];
+        }
+        return;
+    }
+    for (int ph = 0; ph < pp.nph; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        const int T = pp.T[a], U = pp.U[b];
+        const long long kph = (long long)T * U * pp.K, per = kph / 2, total = per * pp.C;
+        for (long long i = t0; i < total; i += stride) {
+            const int n = (int)(i / per);
+            const long long e = (i - (long long)n * per) * 2;
+            const int k = (int)(e % pp.K), tu = (int)(e / pp.K), t = tu / U, u = tu - t * U;
+            const int r = pp.r0[a] + pp.step * (T - 1 - t), sx = pp.s0[b] + pp.step * (U - 1 - u);
+            const float* src = jb.w + (((long long)r * pp.S + sx) * pp.C + n) * pp.K + k;
+            unsigned o[planes<MMA>()];
+            split_pk<MMA>(src[0], src[1], o);
+#pragma unroll
+            for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane + pp.off[ph])[i] = o[q];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- FWD / DGRAD kernel
 struct P16 {
     const float* X;                 // pixel operand (fp32, channel stride 1)
@@ -1276,6 +1316,52 @@ int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const 
         return ctgan_check_launch("pack16_dgrad");
     }
     return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_filter: op %d", op);
+}
+
+int ctgan_conv2d16_pack_batch(const ctgan_conv_desc* descs, const int32_t* ops, int32_t n, int mma, const float* const* ws, void* const* wps,
+                              ctgan_stream_t stream) {
+    if (!descs || !ops || !ws || !wps || n <= 0 || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_batch: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += CTGAN_PACK_BATCH) {
+        PackJobs jobs{};
+        const int cnt = n - base < CTGAN_PACK_BATCH ? n - base : CTGAN_PACK_BATCH;
+        long long most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const ctgan_conv_desc* d = descs + base + i;
+            PackJob& jb = jobs.j[i];
+            jb.w = ws[base + i]; jb.wp = (unsigned short*)wps[base + i]; jb.op = ops[base + i];
+            if (!jb.w || !jb.wp) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_batch: null filter");
+            jb.plane = (long long)d->R * d->S * d->C * d->K;
+            PackPhases& pp = jb.pp;
+            pp.R = d->R; pp.S = d->S; pp.C = d->C; pp.K = d->K;
+            long long work;
+            if (jb.op == CTGAN_CONV_FWD) {
+                if (d->C % 2) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_batch: odd channel count");
+                pp.nph = 1; work = jb.plane / 2;
+            } else if (jb.op == CTGAN_CONV_DGRAD) {
+                if (!shape_ok_dgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_batch: data-gradient shape outside the 16-bit family");
+                const PhaseGeom g = phase_geom(d);
+                for (int a = 0; a < 2; ++a) { pp.T[a] = g.T[a]; pp.U[a] = g.U[a]; pp.r0[a] = g.r0[a]; pp.s0[a] = g.s0[a]; }
+                pp.nph = g.nph; pp.step = g.step;
+                work = 0;
+                for (int ph = 0; ph < g.nph; ++ph) {
+                    pp.off[ph] = phase_off(g, d, ph);
+                    const long long m = (long long)d->C * g.T[ph >> 1] * g.U[ph & 1] * d->K / 2;
+                    if (m > work) work = m;
+                }
+            } else {
+                return ctgan_fail(CTGAN_E_BADARG, "conv2d16_pack_batch: op %d", jb.op);
+            }
+            if (work > most) most = work;
+        }
+        const dim3 grid(ctgan_blocks(most, 256, 64), (unsigned)cnt);
+        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_batch_kernel<CTGAN_MMA_BF16>, grid, dim3(256), 0, st, jobs);
+        else if (mma == CTGAN_MMA_F16) hipLaunchKernelGGL(pack_batch_kernel<CTGAN_MMA_F16>, grid, dim3(256), 0, st, jobs);
+        else hipLaunchKernelGGL(pack_batch_kernel<CTGAN_MMA_F32X3>, grid, dim3(256), 0, st, jobs);
+        const int rc = ctgan_check_launch("pack16_batch");
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 size_t ctgan_conv2d16_workspace_bytes(const ctgan_conv_desc* d, int op) {

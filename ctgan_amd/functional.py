@@ -438,6 +438,8 @@ _hooked = [False]
 
 def clear_filter_cache():
     K._STABLE_PTRS.difference_update(_SPREAD_BUFS.keys())      # (a freed buffer's address may come back as an unrelated tensor)
+    for ptr in _SPREAD_BUFS:
+        K._STABLE_GROUP.pop(ptr, None)
     _FCACHE.clear()
     _SPREAD_BUFS.clear()
 
@@ -478,6 +480,7 @@ def _cached_filter(src, kind, pad=(0, 0), scale=1.0):
         if kind in (K.FILTER_SPREAD, K.FILTER_SPREAD_FLIP):
             _SPREAD_BUFS[e.buf.data_ptr()] = e
             K._STABLE_PTRS.add(e.buf.data_ptr())       # the 16-bit family may cache its packed image per registry epoch
+            K._STABLE_GROUP[e.buf.data_ptr()] = e.group
     if e.epoch != lib.epoch(e.group):
         K.filter_batch([e.job()])
         _mark_built([e])
@@ -494,6 +497,8 @@ def prepare_filters():
     if todo:
         K.filter_batch([e.job() for e in todo])
         _mark_built(todo)
+    if todo or K._pack16:
+        K.prepare_packs()                 # the 16-bit / split-mode images of the parameters and of the filters just rebuilt: one launch
 
 
 def _repacked(w, g):

@@ -97,6 +97,7 @@ def _x3_log(g, N, d, op, **why):
         print('x3-log op%d N%d C%d %dx%d K%d prefers=%d %s xs=%s ys=%s' % (op, N, g.C, g.H, g.W, g.K, lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), op),
                                                                  why, tuple(d.xs), tuple(d.ys)), flush=True)
 _STABLE_PTRS = set()      # data_ptr of derived fp32 filters (spread filters) whose contents only change with the registry epoch
+_STABLE_GROUP = {}        # ... -> the network ('Discriminator', 'Generator') whose updates change them (None: any update)
 _pack16 = {}              # (data_ptr, op, dtype, geometry) -> [packed int16 buffer, registry epoch it was built for]
 
 
@@ -129,24 +130,67 @@ def clear_pack16_cache():
 
 def _packed16(w, d, op, g, mode):
     """The 16-bit packed image of filter `w` for op (0 fwd, 1 dgrad) in `mode` - cached per registry epoch for parameters and for
-    derived filters registered in _STABLE_PTRS; packed per call for any other tensor."""
+    derived filters registered in _STABLE_PTRS (and then refreshed for every known image in ONE launch by prepare_packs, which the
+    step calls right after it rebuilt the derived filters); packed per call for any other tensor."""
     from . import tflib
     n = lib.ctgan_conv2d16_filter_elems(ctypes.byref(d), op, _MMA_CODE[mode])
     stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _STABLE_PTRS
     key = (w.data_ptr(), op, mode, g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
-    ver = tflib.epoch()
     ent = _pack16.get(key) if stable else None
+    if ent is not None:
+        group = ent[6]
+    else:
+        group = (tflib.group_of(w) if isinstance(w, torch.nn.Parameter) else _STABLE_GROUP.get(w.data_ptr())) if stable else None
+    ver = tflib.epoch(group)              # only updates of the filter's own network make its image stale
     if ent is not None and ent[1] == ver:
         return ent[0]
     if ent is None:
         if not _pack16:
             tflib.on_delete_all_params(clear_pack16_cache)
-        ent = [torch.empty(n, dtype=torch.int16, device=w.device), None]
+        # (a strong reference to the filter's storage: the tensor OBJECT a conv wrapper receives is often a temporary - an autograd-saved
+        # view - and while the entry lives the address cannot be reused by an unrelated tensor)
+        ent = [torch.empty(n, dtype=torch.int16, device=w.device), None, w.detach(), g, op, mode, group]
         if stable:
             _pack16[key] = ent
+    if _X3_LOG:
+        print('x3-log pack op%d %s stable=%d cached=%d type=%s shape=%s' % (op, mode, stable, key in _pack16, type(w).__name__, tuple(w.shape)), flush=True)
     check(lib.ctgan_conv2d16_pack_filter(ctypes.byref(d), op, _MMA_CODE[mode], _ptr(w), _ptr(ent[0]), _stream()), 'conv2d16_pack_filter')
     ent[1] = ver
     return ent[0]
+
+
+PACK_BATCH_MAX_ELEMS = 1 << 20      # 16-bit elements per image (all planes)
+
+
+def prepare_packs():
+    """Refresh every cached packed image whose weight version is stale - one launch per mode (ctgan_conv2d16_pack_batch) instead of
+    one per filter and operator at first use.  The caller has already rebuilt the derived (spread) filters on this stream."""
+    from . import tflib
+    if not _pack16:
+        return
+    by_mode = {}
+    for key, ent in list(_pack16.items()):
+        # small images only: a large one (DCGAN 5x5x256x512, config[4] 3x3x1024x1024) costs more to pack than a launch, and a step that
+        # does not use it (the generator's data-gradient images during the critic steps) should not pay for it - those stay lazy
+        if ent[1] == tflib.epoch(ent[6]) or ent[0].numel() > PACK_BATCH_MAX_ELEMS:
+            continue
+        by_mode.setdefault(ent[5], []).append((ent, ent[2]))
+    for mode, items in by_mode.items():
+        n = len(items)
+        descs = (ConvDesc * n)()
+        ops = (ctypes.c_int32 * n)()
+        ws = (ctypes.c_void_p * n)()
+        wps = (ctypes.c_void_p * n)()
+        for i, (ent, w) in enumerate(items):
+            descs[i] = ent[3].desc(1, (0, 0, 0, 0), (0, 0, 0, 0))
+            # the packed layouts depend on channel counts, taps, stride and pads only; the stride checks of the entry points do not apply
+            descs[i].xs = I64x4(4, 1, 4, 4); descs[i].ys = I64x4(4, 1, 4, 4)
+            ops[i] = ent[4]
+            ws[i] = w.data_ptr()
+            wps[i] = ent[0].data_ptr()
+        check(lib.ctgan_conv2d16_pack_batch(descs, ops, n, _MMA_CODE[mode], ws, wps, _stream()), 'conv2d16_pack_batch')
+        for ent, _ in items:
+            ent[1] = tflib.epoch(ent[6])
 
 
 def _need_dev(*ts):

@@ -193,6 +193,9 @@ int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma);        
 int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op);
 size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op, int mma);  /* 16-bit elements of the packed filter     */
 int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream);
+/* n packs in one launch (all images of one weight version): descs[i] / ops[i] (CTGAN_CONV_FWD | CTGAN_CONV_DGRAD) / ws[i] -> wps[i] */
+int ctgan_conv2d16_pack_batch(const ctgan_conv_desc* descs, const int32_t* ops, int32_t n, int mma, const float* const* ws,
+                              void* const* wps, ctgan_stream_t stream);
 /* ws (optional, ctgan_conv2d16_workspace_bytes(d, op) bytes): slabs for a K split of launches whose pixel x channel tiles cannot
  * fill the chip (8x8 / 4x4 layers at batch 64); NULL = never split.                                                      */
 size_t ctgan_conv2d16_workspace_bytes(const ctgan_conv_desc* d, int op);

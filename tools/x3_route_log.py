@@ -18,3 +18,6 @@ batch = (torch.from_numpy(rng.integers(0, 256, (B, 3072), dtype=np.int32)).cuda(
 eng = GraphedTrainer(tr, use_graphs=False)
 eng.train_iteration(1, lambda: batch)
 torch.cuda.synchronize()
+print('x3-log ---- second iteration', flush=True)
+eng.train_iteration(2, lambda: batch)
+torch.cuda.synchronize()
