@@ -91,6 +91,7 @@ SIGNATURES = {
     'ctgan_conv2d16_pack_batch': (c_int, [POINTER(ConvDesc), POINTER(c_int32), c_int32, c_int, POINTER(c_void_p), POINTER(c_void_p), _p]),
     'ctgan_conv2d16_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d16_fwd': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
+    'ctgan_conv2d16_fwd_ex': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_int, POINTER(EpilogueExt), _p, c_size_t, _p]),
     'ctgan_conv2d16_dgrad': (c_int, [_D, c_int, _p, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
     'ctgan_conv2d16_wgrad_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d16_wgrad': (c_int, [_D, c_int, _p, _p, _p, _p, c_size_t, c_int, _p]),

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "philox.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -215,6 +216,12 @@ struct P16 {
     long long ds_n, ds_p, ds_q;     // D strides over (n, phase-grid row, phase-grid col); channel stride 1
     int relu, relu_in;
     int resid_up;                   // halo-patch kernel only: resid is the dense channels-last [N, P/2, Q/2, Ng] tensor, added through a nearest-2x upsample
+    // halo-patch kernel only: tf.nn.dropout of the result inside the epilogue, exactly as the fp32 family's (igemm.hip FwdParams::drop):
+    // y *= floor(keep + u) / keep, u = element (physical offset / 4) of the Philox stream (seed, sid, ctr[0]); up to three sample
+    // ranges with their own keep / stream, draws indexed from the range's first element
+    int drop; float drop_keep; unsigned long long drop_seed; unsigned drop_sid; const unsigned long long* drop_ctr;
+    int drop_nr; int drop_mend[CTGAN_DROP_RANGES]; float drop_rkeep[CTGAN_DROP_RANGES]; unsigned drop_rsid[CTGAN_DROP_RANGES];
+    long long drop_roff[CTGAN_DROP_RANGES];
     unsigned x_bytes, w_bytes;      // w_bytes covers every plane
     unsigned w_plane_bytes;         // split mode: byte distance between the filter's planes
     int nph, ph_tiles_m;
@@ -675,6 +682,17 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
     // epilogue through LDS (as conv16_kernel, one 32-pixel sub-tile per pass)
     float* es = reinterpret_cast<float*>(smem) + wave * (32 * LDE);
     constexpr int C4 = TM * 8, ROWS_PER = 64 / C4;
+    // dropout of the result: the row range is workgroup-uniform (range boundaries are multiples of the 128-pixel tile, checked by the host)
+    const unsigned long long drop_step = p.drop ? (p.drop_ctr ? p.drop_ctr[0] : 0) : 0;
+    float dkeep = p.drop_keep;
+    unsigned dsid = p.drop_sid, doff4 = 0;
+    if (p.drop_nr) {
+        const bool r1 = p.drop_nr > 1 && m0 >= p.drop_mend[0], r2 = p.drop_nr > 2 && m0 >= p.drop_mend[1];
+        dkeep = r2 ? p.drop_rkeep[2] : (r1 ? p.drop_rkeep[1] : p.drop_rkeep[0]);
+        dsid = r2 ? p.drop_rsid[2] : (r1 ? p.drop_rsid[1] : p.drop_rsid[0]);
+        doff4 = (unsigned)((r2 ? p.drop_roff[2] : (r1 ? p.drop_roff[1] : p.drop_roff[0])) >> 2);
+    }
+    const bool do_drop = p.drop && dkeep < 1.f;
 #pragma unroll
     for (int jh = 0; jh < TN; ++jh) {
 #pragma unroll
@@ -704,6 +722,13 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (do_drop) {
+                uint32_t c[4];
+                ctgan_philox::draw4(p.drop_seed, dsid, drop_step, (uint32_t)(off >> 2) - doff4, c);
+                const float inv = 1.f / dkeep;
+                v.x *= inv * floorf(dkeep + ctgan_philox::u01(c[0])); v.y *= inv * floorf(dkeep + ctgan_philox::u01(c[1]));
+                v.z *= inv * floorf(dkeep + ctgan_philox::u01(c[2])); v.w *= inv * floorf(dkeep + ctgan_philox::u01(c[3]));
+            }
             *reinterpret_cast<float4*>(p.D + off) = v;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1373,8 +1398,8 @@ size_t ctgan_conv2d16_workspace_bytes(const ctgan_conv_desc* d, int op) {
     return (size_t)8 * rows * cols * sizeof(float);
 }
 
-int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
-                       float* y, int flags, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
+                             float* y, int flags, const ctgan_epilogue_ext* ext, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     if (!d || !x || !wp || !y || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_fwd: bad argument");
     if (!shape_ok_fwd(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: shape outside the 16-bit family");
     const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
@@ -1395,12 +1420,47 @@ int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const 
     p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
     p.ph_T[1] = d->R; p.ph_U[1] = d->S; p.ph_pad_t[1] = d->pad_t; p.ph_pad_l[1] = d->pad_l;
     hipStream_t st = (hipStream_t)stream;
+    const bool ranged = ext && ext->n_ranges > 0;
+    const bool want_drop = ext && (ranged || (ext->drop_keep > 0.f && ext->drop_keep < 1.f));
+    if (want_drop) {                                         // only the halo-patch kernel has the dropout epilogue
+        const bool dense = d->ys[1] == 1 && d->ys[3] == d->K && d->ys[2] == (int64_t)d->Q * d->K && d->ys[0] == (int64_t)d->P * d->Q * d->K;
+        if (mma != CTGAN_MMA_F32X3 || !conv16x3h_ok(p, nullptr) || (ranged && (!dense || ext->n_ranges > CTGAN_DROP_RANGES)))
+            return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: epilogue dropout outside the halo-patch form");
+        p.drop = 1; p.drop_keep = 1.f; p.drop_seed = ext->drop_seed; p.drop_sid = 0;
+        p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
+        for (int i = 0; i < CTGAN_DROP_RANGES; ++i) { p.drop_mend[i] = 0x7fffffff; p.drop_rkeep[i] = 1.f; p.drop_rsid[i] = 0; p.drop_roff[i] = 0; }
+        if (ranged) {
+            p.drop_nr = ext->n_ranges;
+            long long start = 0;
+            for (int i = 0; i < p.drop_nr; ++i) {
+                if (((long long)ext->range_end[i] * d->P * d->Q) % 128)
+                    return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: dropout row ranges must start at multiples of 128 output pixels");
+                p.drop_mend[i] = (int)((long long)ext->range_end[i] * d->P * d->Q);
+                p.drop_rkeep[i] = (ext->range_keep[i] > 0.f && ext->range_keep[i] < 1.f) ? ext->range_keep[i] : 1.f;
+                p.drop_rsid[i] = (unsigned)ext->range_stream_id[i];
+                p.drop_roff[i] = start * (long long)d->P * d->Q * d->K;
+                start = ext->range_end[i];
+            }
+        } else {
+            p.drop_keep = ext->drop_keep; p.drop_sid = (unsigned)ext->drop_stream_id;
+        }
+        return launch_conv16x3h(p, st);
+    }
     if (p.resid_up) {                                        // only the halo-patch kernel reads the residual through the upsample
         if (mma != CTGAN_MMA_F32X3 || ((d->P | d->Q) & 1) || !conv16x3h_ok(p, nullptr))
             return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: CTGAN_RESID_UP outside the halo-patch form");
         return launch_conv16x3h(p, st);
     }
     return run_conv16(mma, p, st);
+}
+
+int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
+                       float* y, int flags, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+    return conv2d16_fwd_impl(d, mma, x, wp, bias, resid, y, flags, nullptr, ws, ws_bytes, stream);
+}
+int ctgan_conv2d16_fwd_ex(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
+                          float* y, int flags, const ctgan_epilogue_ext* ext, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+    return conv2d16_fwd_impl(d, mma, x, wp, bias, resid, y, flags, ext, ws, ws_bytes, stream);
 }
 
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias, const float* mask,

@@ -112,10 +112,16 @@ def _flush_groups(grps):
     for grp in (g for g in _all if g.pre):                  # results the split-mode kernel produced at request time
         dw_set, db_set = bool(grp.segs), any(sg[3] for sg in grp.segs)
         for gw, gb in grp.pre:
-            grp.dw.copy_(K.axpby(grp.dw, gw, 1.0, 1.0) if dw_set else gw)
+            if dw_set:
+                K.axpby(grp.dw, gw, 1.0, 1.0, out=grp.dw)
+            else:
+                grp.dw.copy_(gw)
             dw_set = True
             if gb is not None and grp.db is not None:
-                grp.db.copy_(K.axpby(grp.db, gb, 1.0, 1.0) if db_set else gb)
+                if db_set:
+                    K.axpby(grp.db, gb, 1.0, 1.0, out=grp.db)
+                else:
+                    grp.db.copy_(gb)
                 db_set = True
         if grp.db is not None and not db_set:
             grp.db.zero_()
@@ -135,15 +141,15 @@ def _flush_group(grp):
                 dw2 = torch.empty_like(grp.dw)
                 db2 = torch.empty_like(grp.db) if (grp.db is not None and any(sg[3] for sg in chunk)) else None
                 K.conv_wgrad_multi(chunk, grp.g, dw2, db2)
-                grp.dw.copy_(K.axpby(grp.dw, dw2, 1.0, 1.0))
+                K.axpby(grp.dw, dw2, 1.0, 1.0, out=grp.dw)
                 if db2 is not None:
-                    grp.db.copy_(K.axpby(grp.db, db2, 1.0, 1.0))
+                    K.axpby(grp.db, db2, 1.0, 1.0, out=grp.db)
     except NotImplementedError:                                 # shape outside the pipelined kernel: one call per use
         first = True
         for x, gy, relu_x, with_bias in segs:
             r = K.conv_wgrad(x, gy, grp.g, with_bias=with_bias, relu_x=relu_x)
             gw, gb = r if with_bias else (r, None)
-            grp.dw.copy_(gw if first else K.axpby(grp.dw, gw, 1.0, 1.0))
+            (grp.dw.copy_(gw) if first else K.axpby(grp.dw, gw, 1.0, 1.0, out=grp.dw))
             if gb is not None:
                 grp.db.copy_(gb)
             first = False

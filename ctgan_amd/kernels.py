@@ -359,6 +359,15 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
             and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 0)):
         mode = 'f32x3'                                # the halo-patch kernel reads the residual through the 2x upsample itself
     _x3_log(g, N, d, 0, drop=drop is not None, resid_up=bool(fl & 8), x_up=bool(g.x_up))
+    if (mode is None and drop is not None and not (fl & 8) and g.stride == 1 and not fewch_handles(g)
+            and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID)) and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 0)):
+        # the halo-patch kernel has the fp32 family's dropout epilogue (same Philox draws at the same offsets)
+        wp = _packed16(w, d, 0, g, 'f32x3')
+        try:
+            _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd_ex(ctypes.byref(d), 3, _ptr(x), _ptr(wp), _ptr(bias), _ptr(resid), _ptr(y), fl, _ext(drop), None, 0, _stream()), 'conv2d16_fwd_ex'))
+            return y
+        except NotImplementedError:
+            pass
     if mode is not None:
         wp = _packed16(w, d, 0, g, mode)
         code = _MMA_CODE[mode]
@@ -660,12 +669,15 @@ def sigmoid_bwd(gy, y):
     return gx
 
 
-def axpby(x, y, a, b):
-    """a*x + b*y (y may be None)."""
-    _need_dev(x, y)
+def axpby(x, y, a, b, out=None):
+    """a*x + b*y (y may be None); out: result buffer with x's layout (may be x itself: elementwise)."""
+    _need_dev(x, y, out)
     if y is not None:
         y = match_layout(y, x)
-    out = _ew_out(x)
+    if out is None:
+        out = _ew_out(x)
+    else:
+        assert out.shape == x.shape and out.stride() == x.stride()
     check(lib.ctgan_axpby(_ptr(x), _ptr(y), _ptr(out), x.numel(), a, b, _stream()), 'axpby')
     return out
 

@@ -201,6 +201,10 @@ int ctgan_conv2d16_pack_batch(const ctgan_conv_desc* descs, const int32_t* ops, 
 size_t ctgan_conv2d16_workspace_bytes(const ctgan_conv_desc* d, int op);
 int ctgan_conv2d16_fwd(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
                        float* y, int flags, void* ws, size_t ws_bytes, ctgan_stream_t stream);
+/* forward with the epilogue dropout of ctgan_conv2d_fwd_ex (same ext, same draws): mma = CTGAN_MMA_F32X3 on launches the halo-patch
+ * kernel takes (ctgan_conv2d16_x3_prefers, stride 1); CTGAN_E_UNSUPPORTED otherwise - the caller then uses ctgan_conv2d_fwd_ex.   */
+int ctgan_conv2d16_fwd_ex(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
+                          float* y, int flags, const ctgan_epilogue_ext* ext, void* ws, size_t ws_bytes, ctgan_stream_t stream);
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias,
                          const float* mask, const float* resid, float* dx, int flags, void* ws, size_t ws_bytes,
                          ctgan_stream_t stream);

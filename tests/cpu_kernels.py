@@ -236,8 +236,12 @@ def sigmoid_bwd(gy, y):
 
 
 @_export
-def axpby(x, y, a, b):
-    return _like(a * x if y is None else a * x + b * y, x)
+def axpby(x, y, a, b, out=None):
+    r = _like(a * x if y is None else a * x + b * y, x)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
 
 
 @_export

@@ -200,6 +200,35 @@ def test_f32x3_halo_kernel_adds_the_upsampled_residual(K):
     assert relerr(got, want) < 2e-6
 
 
+@pytest.mark.parametrize('ranged', [False, True])
+def test_f32x3_halo_kernel_applies_the_epilogue_dropout_of_the_fp32_family(K, ranged):
+    """tf.nn.dropout of the conv result inside the epilogue (one spec, or sample ranges with their own keep / stream as the shared
+    forward launches of a critic step use them): the halo-patch kernel must zero exactly the elements the fp32 family zeroes (same
+    Philox draws at the same physical offsets) and agree on the kept ones to fp32 rounding."""
+    N, C, Hh, Ko = 384, 32, 8, 128                          # 8x8 images: whole-image tiles; 192 tiles
+    geom = K.ConvGeom(C, Hh, Hh, Ko, 3, 3, 1, False)
+    g = torch.Generator().manual_seed(13)
+    x, w, b = cl(torch.randn(N, C, Hh, Hh, generator=g)), (torch.randn(3, 3, C, Ko, generator=g) / 17).cuda(), torch.randn(Ko, generator=g).cuda()
+    ctr = torch.tensor([5], dtype=torch.int64, device='cuda')
+    if ranged:
+        drop = {'ranges': [(128, (0.5, 99, 3, ctr)), (192, None), (384, (0.8, 99, 4, ctr))]}
+    else:
+        drop = (0.5, 99, 3, ctr)
+    hybrid, K.X3_HYBRID = K.X3_HYBRID, False
+    try:
+        want = K.conv_fwd(x, w, b, geom, relu=True, relu_in=True, drop=drop)
+        assert K.last_kernel().startswith('igemm'), K.last_kernel()
+    finally:
+        K.X3_HYBRID = hybrid
+    with K.mma_dtype('f32x3'):
+        got = K.conv_fwd(x, w, b, geom, relu=True, relu_in=True, drop=drop)
+        assert K.last_kernel().startswith('conv16x3h'), K.last_kernel()
+    # kept / dropped pattern: identical wherever the undropped value is not itself ~0 (ReLU zeros are zeros on both sides anyway)
+    assert torch.equal(got == 0, want == 0) or ((got == 0) != (want == 0)).float().mean().item() < 1e-5
+    assert relerr(got, want) < 2e-6
+    assert 0.2 < (want == 0).float().mean().item() < 0.9
+
+
 def test_conv16_wgrad_runs_on_the_16bit_kernel_and_is_deterministic(K):
     N, C, H, Ko = 16, 128, 16, 256
     geom = K.ConvGeom(C, H, H, Ko, 5, 5, 2, False)
