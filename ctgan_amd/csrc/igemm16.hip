@@ -1276,6 +1276,11 @@ int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     return 0;
 }
 
+static long long x3_wgrad_min_pixels() {      // CTGAN_X3_WGRAD_MIN: experiment switch for the routing threshold of weight gradients
+    static const long long v = [] { const char* e = getenv("CTGAN_X3_WGRAD_MIN"); return e ? atoll(e) : 32768LL; }();
+    return v;
+}
+
 int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
     // 1 for the launches on which CTGAN_MMA_F32X3 is measured faster than the fp32 MFMA family (tools/conv16_bench.py): stride-1 layers
     // the halo-patch kernel takes (170-200 vs 110-125 TFLOP/s), stride-2 layers on the slice kernel, large weight gradients - each only
@@ -1284,7 +1289,7 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
     if (op == CTGAN_CONV_WGRAD) {
         // weight gradient (wgrad16x3<128x128>): 145-167 vs 108-122 TFLOP/s from 32k pixels up; below that the fp32 family's grouped
         // multi-segment launch keeps the layer
-        return (ctgan_conv2d16_supported(d, op, CTGAN_MMA_F32X3) && (long long)d->N * d->P * d->Q >= 32768) ? 1 : 0;
+        return (ctgan_conv2d16_supported(d, op, CTGAN_MMA_F32X3) && (long long)d->N * d->P * d->Q >= x3_wgrad_min_pixels()) ? 1 : 0;
     }
     if (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD) return 0;
     if (op == CTGAN_CONV_FWD ? !shape_ok_fwd(d) : !shape_ok_dgrad(d)) return 0;
