@@ -3,16 +3,21 @@
 of CT_gan_cifar_resnet.py on MI355X, synthetic 32x32x3 data, fp32 (the reference's dtype).
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL).  A "step" here is one full
+N > 1: either launched under torch.distributed.run (one rank per GPU, RCCL; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
+the environment), or - when WORLD_SIZE is not set - this process becomes a LAUNCHER: before anything touches the GPU it
+starts N rank processes of itself (127.0.0.1 rendezvous on a free port), relays rank 0's JSON line and exits with the
+first non-zero rank status; it refuses (exit 2) when fewer than N devices are visible (--backend gloo lets N ranks share
+one device to exercise the multi-rank code path).  A "step" here is one full
 iteration of the reference loop body (TF/CT_gan_cifar_resnet.py:393-404): 1 G step + 5 x (batch,
 D step) at BATCH_SIZE=64 per GPU = 320 real images per GPU.  Inputs are resident in HBM before the
 timed region.  Rank 0 prints ONE JSON line including
-  roofline     : the dominant kernel (by GPU time) of the iteration, its algorithmic FLOPs per
-                 launch / average launch duration, measured with HIP events on the launch stream
-                 in an instrumented eager iteration, against the fp32 MFMA peak (157.3 TFLOP/s)
+  roofline     : the dominant kernel (by GPU time, keyed by device symbol) of the iteration, its
+                 algorithmic FLOPs per launch / average launch duration, measured with HIP events on
+                 the launch stream in an instrumented eager iteration of the same launch mix, against
+                 the peak of the matrix pipe it runs on (fp32 MFMA 157.3 TFLOP/s; split mode 2500/6)
   cpu_baseline : the CPU oracle (PyTorch-CPU fp32 restatement of the reference graph AS WRITTEN;
-                 TF1 cannot be installed here) timed on the host cores - 1 D step + 1 G step,
-                 extrapolated to an iteration (N=1 only).
+                 TF1 cannot be installed here) timed on the host cores - 1 warm-up + 2 timed D steps and
+                 G steps, extrapolated to an iteration G + 5 D (N=1 only).
 """
 import argparse
 import json
@@ -51,7 +56,15 @@ def main():
                          '16-bit matrix cores (or their fp32 twins for comparison)')
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL); gloo lets the\n'
                     'multi-rank code path be exercised on a single-GPU box (all ranks share cuda:0)')
+    ap.add_argument('--launcher', default='auto', choices=['auto', 'always', 'never'],
+                    help='auto: start the N rank processes here when --gpus N > 1 and WORLD_SIZE is unset; always: also for N = 1')
+    ap.add_argument('--spawn-check', action='store_true',
+                    help='ranks only join the process group, all-reduce their rank numbers and report (no GPU work): the launcher test')
     args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and (args.launcher == 'always' or (args.launcher == 'auto' and args.gpus > 1)):
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.spawn_check:
+        return spawn_check(args)
 
     import numpy as np
     import torch
@@ -68,8 +81,7 @@ def main():
                              % (rank, local, torch.cuda.device_count()))
         local = local % max(torch.cuda.device_count(), 1)       # gloo test mode only (ranks share a device)
     if world != args.gpus:
-        if rank == 0:
-            print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: the record would not say what ran' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -130,28 +142,56 @@ def main():
     # Round 1 timed a loop whose cost had run to -6e18 (graph outputs aliased in a shared pool) and nothing looked.
     sane = all(v == v and abs(v) < 1e4 for v in last.values())
 
+    # N > 1: what the six gradient all-reduces of an iteration cost on the critical path = the same loop with the collective
+    # switched off on every rank (the replicas drift apart from here on: nothing below compares them)
+    collective = None
+    if world > 1:
+        saved_ar, trainer.allreduce = trainer.allreduce, None
+        try:
+            k2 = max(5, min(20, args.steps))
+            for _ in range(3):
+                eng.train_iteration(it, next_batch); it += 1
+            ddp.barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                eng.train_iteration(it, next_batch); it += 1
+            torch.cuda.synchronize(); ddp.barrier()
+            tl = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            ms_local = 1e3 * tl.item() / k2
+        finally:
+            trainer.allreduce = saved_ar
+        collective = {'all_reduces_per_step': R.cfg.N_CRITIC + 1,
+                      'bucket_bytes': {'critic': 4 * trainer.d_opt.theta.numel(), 'generator': 4 * trainer.g_opt.theta.numel()},
+                      'ms_per_step_without_all_reduce': round(ms_local, 3), 'steps': k2,
+                      'exposed_ms_per_step': round(ms_per_step - ms_local, 3),
+                      'overlap': 'side stream; the next critic step\'s input staging is enqueued while the bucket is in flight (DESIGN 5)'}
+
     roofline = None
     if not args.no_roofline and rank == 0:
-        roofline = measure_roofline(trainer, next_batch, K, torch)
-    # the same loop with every layer on the fp32 MFMA family (no split-mode routing), for comparison: 50 iterations on a second engine
+        roofline = measure_roofline(trainer, next_batch, K, torch, ms_per_step)
+    # the same loop with every layer on the fp32 MFMA family (no split-mode routing), for comparison: a second engine, same warm-up and
+    # step counts, same clock (the comparison used to be 10 / 50 steps on wall clock against 20 / 100 with a p50)
     fp32_only = None
     if K.X3_HYBRID and K.MMA_DTYPE is None and rank == 0 and world == 1 and not args.no_roofline:
         K.X3_HYBRID = False
         try:
+            K.clear_pack16_cache()                 # no split-mode launch can be routed: its packed filter images are not refreshed either
             eng2 = GraphedTrainer(trainer, use_graphs=not args.no_graph)
-            for _ in range(10):
+            for _ in range(args.warmup):
                 eng2.train_iteration(it, next_batch); it += 1
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(50):
+            for _ in range(args.steps):
                 eng2.train_iteration(it, next_batch); it += 1
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
-            fp32_only = {'value': round(R.cfg.N_CRITIC * B * 50 / dt2, 2), 'ms_per_step': round(1e3 * dt2 / 50, 3), 'steps': 50,
-                         'note': 'CTGAN_X3_HYBRID=0: every layer on the fp32 MFMA family'}
+            fp32_only = {'value': round(R.cfg.N_CRITIC * B * args.steps / dt2, 2), 'ms_per_step': round(1e3 * dt2 / args.steps, 3), 'steps': args.steps,
+                         'warmup': args.warmup, 'note': 'CTGAN_X3_HYBRID=0: every layer on the fp32 MFMA family'}
             del eng2
         finally:
             K.X3_HYBRID = True
+            K.clear_pack16_cache()
 
     gp_unit = None
     step_exec = None
@@ -159,10 +199,15 @@ def main():
         gp_unit = measure_gp_unit(trainer, batches[0], torch)
         if roofline is not None:
             gf = roofline['all_conv_kernels']['gflop_executed']
+            ideal_ms = sum(v['gflop_executed'] / v['peak'] for v in roofline['by_pipe'].values())
             step_exec = {'gflop_executed': gf, 'achieved': round(gf / ms_per_step, 2), 'unit': 'TFLOP/s',
-                         'frac_executed': round(gf / ms_per_step / PEAK_F32_MFMA_TFLOPS, 4),
-                         'note': 'conv-family FLOPs actually launched in one iteration (sum of 2*N*P*Q*K*R*S*C over the launches) / '
-                                 'ms_per_step / fp32 MFMA peak'}
+                         'frac_executed': round(ideal_ms / ms_per_step, 4),
+                         'frac_note': 'time the launched conv FLOPs take at the peak of the pipe each kernel runs on / ms_per_step',
+                         'conv_time_share': round(roofline['all_conv_kernels']['time_ms'] / ms_per_step, 3),
+                         'by_pipe': {k: {'frac': v['frac'], 'share_of_step_time': v['share_of_step_time']} for k, v in roofline['by_pipe'].items()},
+                         'note': 'conv-family FLOPs actually launched in one iteration (sum of 2*N*P*Q*K*R*S*C over the launches) / ms_per_step; '
+                                 'the roofline fractions are per matrix pipe and time-weighted (roofline.by_pipe): fp32-pipe kernels against 157.3 '
+                                 'TFLOP/s, split-mode kernels against 2500/6'}
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(lib, torch)
@@ -177,7 +222,7 @@ def main():
                                    'N_CRITIC=5 + 1 G step (128 samples) per step', 'global_batch': B * world,
                        'images_per_step': R.cfg.N_CRITIC * B * world, 'parallelism': 'dp%d' % world,
                        'hipgraph': bool(eng.graphed), 'last_d_cost': last_cost, 'last_d_terms': last, 'loss_sane': sane,
-                       'rccl_world': world if world > 1 else None,
+                       'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1], 'collective': collective,
                        'arithmetic': ('fp32 throughout; the large stride-1 conv layers (roofline.by_kernel: conv16x3h) compute the fp32 products as '
                                       'three-bf16-term splits on the bf16 matrix cores (six MFMAs per product, fp32 accumulate; error vs fp64 '
                                       'no larger than the fp32 MFMA family\'s, tests/test_gpu_kernels16.py, DESIGN 4.6), every other layer on '
@@ -196,6 +241,81 @@ def main():
     if not sane:
         print('bench: critic loss terms out of band %r - the timed loop is not computing the reference step' % (last,), file=sys.stderr)
         sys.exit(3)
+
+
+def launch_ranks(args, argv):
+    """The launcher side of `python bench.py --gpus N`: start N rank processes of this script (one per GPU), relay rank 0's
+    stdout (the JSON line), exit status = the first non-zero rank status.  This process never initialises the GPU: it only counts
+    devices (torch.cuda.device_count() does not create a HIP context on this image) - a process that has touched the GPU must not
+    start other programs in its place, and this one does not exec, it waits for its children."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if n < 1:
+        print('bench: --gpus must be >= 1', file=sys.stderr)
+        return 2
+    backend = args.backend or 'nccl'
+    if not args.spawn_check:
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev < 1 or (backend != 'gloo' and ndev < n):
+            print('bench: --gpus %d but %d device(s) visible - two RCCL ranks cannot share a GPU (use --backend gloo to exercise the '
+                  'multi-rank code path on one device)' % (n, ndev), file=sys.stderr)
+            return 2
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    child_argv = [a for a in argv]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    status = 0
+    try:
+        out, _ = procs[0].communicate()
+        for line in out.decode().splitlines():       # stdout carries the record only; library chatter (gloo prints to stdout) -> stderr
+            print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
+        sys.stdout.flush()
+        for pr in procs:
+            rc = pr.wait()
+            if rc and not status:
+                status = rc
+    finally:
+        for pr in procs:                 # a rank that died leaves the others in a collective: end exactly the processes started here
+            if pr.poll() is None:
+                pr.kill()
+    return status
+
+
+def dist_info(world):
+    """(backend, rccl_world): rccl_world is the world size ONLY when the collectives really are RCCL."""
+    import torch.distributed as dist
+    backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else None
+    return backend, (world if backend == 'nccl' else None)
+
+
+def spawn_check(args):
+    """Launcher self-test (no GPU): every rank joins the group, the ranks' numbers are summed, rank 0 reports."""
+    import torch
+    import torch.distributed as dist
+
+    from ctgan_amd import ddp
+    rank, world, local = ddp.init_from_env(backend=args.backend or 'gloo')
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    backend, rccl = dist_info(world)
+    if rank == 0:
+        print(json.dumps({'spawn_check': True, 'n_gpus': world, 'rank_sum': t.item(), 'backend': backend, 'rccl_world': rccl,
+                          'local_rank': local, 'master_port': os.environ.get('MASTER_PORT')}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def run_unconditional(args):
@@ -218,6 +338,8 @@ def run_unconditional(args):
         if world > 1 and dist.get_backend() != 'gloo':
             raise SystemExit('two RCCL ranks cannot share a GPU')
         local = local % max(torch.cuda.device_count(), 1)
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: the record would not say what ran' % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     M = importlib.import_module('ctgan_amd.' + modname)
@@ -281,7 +403,7 @@ def run_unconditional(args):
         finally:
             tr.world = saved_world
         agg = {}
-        for name, flops, e0, e1, reps, _shape in prof:
+        for name, flops, e0, e1, reps, _shape, _sym in prof:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
         total_t = sum(a[2] for a in agg.values()); total_f = sum(a[1] for a in agg.values())
@@ -309,7 +431,8 @@ def run_unconditional(args):
             'ms_per_step_p50': round(per_step[len(per_step) // 2], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': dtype or 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'name': args.config, 'global_batch': B * world, 'images_per_step': n_crit * B * world,
-                       'parallelism': 'dp%d' % world, 'hipgraph': bool(eng.graphed), 'last_d_terms': last, 'loss_sane': sane},
+                       'parallelism': 'dp%d' % world, 'hipgraph': bool(eng.graphed), 'last_d_terms': last, 'loss_sane': sane,
+                       'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1]},
             'roofline': roofline, 'cpu_baseline': None, 'build': build_provenance()}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -318,12 +441,45 @@ def run_unconditional(args):
         sys.exit(3)
 
 
-def measure_roofline(trainer, next_batch, K, torch):
-    """One instrumented EAGER iteration: every conv-family launch is bracketed by HIP events on its
-    launch stream (4 back-to-back repeats per bracket, time / 4: a single-launch bracket carries ~10 us of
-    event overhead and disagrees with rocprofv3's kernel durations).  The dominant kernel = the variant
-    with the largest summed duration."""
-    import ctgan_amd.gan_cifar_resnet as R
+def pipe_of(variant):
+    """'bf16x6' for the split-mode kernels (fp32 products as six bf16 MFMAs: peak = dense bf16 peak / 6), 'bf16' / 'f16' for the plain
+    16-bit kernels, else 'f32' (v_mfma_f32_32x32x2_f32 or packed-fp32 FMA kernels: priced against the fp32 MFMA peak)."""
+    if 'x3' in variant:
+        return 'bf16x6'
+    if variant.startswith(('conv16', 'wgrad16')):
+        return '16bit'
+    return 'f32'
+
+
+PIPE_PEAK = {'bf16x6': PEAK_16BIT_MFMA_TFLOPS / 6.0, '16bit': PEAK_16BIT_MFMA_TFLOPS, 'f32': PEAK_F32_MFMA_TFLOPS}
+
+
+def load_pmc_traffic():
+    """profiles/r03_pmc_traffic_x3.json (tools/pmc_x3.sh: separate rocprofv3 --pmc passes, gfx950 corrections of the guide) + the
+    round-1 files of the fp32 tiles, keyed by device symbol."""
+    out = {}
+    try:
+        for sym, rec in json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_x3.json'))).items():
+            if isinstance(rec, dict) and 'hbm_bytes_per_launch' in rec:
+                out[sym] = dict(rec, file='profiles/r03_pmc_traffic_x3.json')
+    except Exception:
+        pass
+    for fn, sym in (('r01_pmc_traffic_64x128.json', 'igemm_fwd_pipe_kernel<1, 4, 1, 2, 1, 1, false, 1>'),
+                    ('r01_pmc_traffic.json', 'igemm_fwd_pipe_kernel<2, 2, 1, 2, 2, 1, false, 1>')):
+        try:
+            rec = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+            out.setdefault(sym, dict(rec, file='profiles/' + fn))
+        except Exception:
+            pass
+    return out
+
+
+def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
+    """One instrumented EAGER iteration of the SAME launch mix the graph replays (grouped weight gradients included): every
+    conv-family launch is bracketed by HIP events on its launch stream (4 back-to-back repeats per bracket, time / 4: a
+    single-launch bracket carries ~10 us of event overhead and disagrees with rocprofv3's kernel durations).  Kernels are keyed by
+    their device symbol as rocprofv3 prints it (ctgan_last_symbol), so every row can be looked up in the committed summaries under
+    profiles/.  The dominant kernel = the symbol with the largest summed duration."""
     # rank 0 only: this pass must not enter a collective (the other ranks are not here)
     saved_world, trainer.world = trainer.world, 1
     try:
@@ -341,51 +497,62 @@ def measure_roofline(trainer, next_batch, K, torch):
     finally:
         trainer.world = saved_world
     agg = {}
-    for name, flops, e0, e1, reps, _shape in prof:
-        name = name.replace(',ph4', '')      # the 4-phase dgrad is a launch mode of the same kernel symbol (what rocprofv3 reports)
-        a = agg.setdefault(name, [0, 0.0, 0.0])
+    for name, flops, e0, e1, reps, _shape, sym in prof:
+        a = agg.setdefault(sym, [0, 0.0, 0.0, set()])
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
+        a[3].add(name.replace(',ph4', '').split(',split')[0].rstrip('>') + ('>' if '<' in name else ''))
     if not agg:
         return None
     total_t = sum(a[2] for a in agg.values())
     total_f = sum(a[1] for a in agg.values())
-    name, (cnt, fl, tt) = max(agg.items(), key=lambda kv: kv[1][2])
+    sym, (cnt, fl, tt, variants) = max(agg.items(), key=lambda kv: kv[1][2])
+    pipe = pipe_of(sorted(variants)[0])
+    peak = PIPE_PEAK[pipe]
     achieved = fl / tt / 1e12
-    traffic = None
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of the same kernel (profiles/r01_pmc_traffic*.json: separate
-    # --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), scaled by flops to this launch mix
-    for fn in ('r01_pmc_traffic_64x128.json', 'r01_pmc_traffic.json'):
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
-            if pmc['kernel'] == name:
-                traffic = {'hbm_bytes_per_launch': round(pmc['hbm_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
-                           'algorithmic_bytes_per_launch': round(pmc['algorithmic_bytes_per_launch'] * (fl / cnt) / pmc['flops_per_launch']),
-                           'source': 'profiles/%s (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, scaled to this launch mix)' % fn}
-                break
-        except Exception:
-            pass
-    # a split-mode kernel (opt-in: CTGAN_MMA=f32x3 / CTGAN_X3_HYBRID=1) executes SIX bf16 MFMAs per algorithmic fp32 product: its
-    # peak in algorithmic FLOPs is the dense bf16 peak / 6, not the fp32 MFMA peak
-    peak = PEAK_16BIT_MFMA_TFLOPS / 6.0 if 'x3' in name else PEAK_F32_MFMA_TFLOPS
-    f32_top = None
-    f32_items = [(k, v) for k, v in agg.items() if 'x3' not in k]
-    if 'x3' in name and f32_items:
-        k2, (c2, f2, t2) = max(f32_items, key=lambda kv: kv[1][2])
-        f32_top = {'kernel': k2, 'launches': c2, 'avg_launch_us': round(t2 / c2 * 1e6, 2), 'achieved': round(f2 / t2 / 1e12, 2),
-                   'peak': PEAK_F32_MFMA_TFLOPS, 'frac': round(f2 / t2 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    pmc = load_pmc_traffic()
+
+    def traffic_of(symbol, flops_per_launch):
+        rec = pmc.get(symbol)
+        if not rec:
+            return None
+        k = flops_per_launch / rec['flops_per_launch']
+        out = {'hbm_bytes_per_launch': round(rec['hbm_bytes_per_launch'] * k), 'algorithmic_bytes_per_launch': round(rec['algorithmic_bytes_per_launch'] * k),
+               'traffic_over_algorithmic': round(rec['hbm_bytes_per_launch'] / rec['algorithmic_bytes_per_launch'], 2),
+               'source': '%s (%s; FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes, scaled by FLOPs to this launch mix)'
+                         % (rec['file'], rec.get('geometry', 'geometry in the file'))}
+        for key in ('mfma_busy_frac', 'valu_active_frac', 'lds_wait_frac', 'l2_hit_rate'):
+            if key in rec:
+                out[key] = rec[key]
+        return out
+
+    # time-weighted roofline fractions per matrix pipe (a mixed FLOP sum over one peak is not a fraction of anything)
+    pipes = {}
+    for k, v in agg.items():
+        pp = pipes.setdefault(pipe_of(sorted(v[3])[0]), [0.0, 0.0, 0])
+        pp[0] += v[1]; pp[1] += v[2]; pp[2] += v[0]
+    by_pipe = {k: {'launches': v[2], 'time_ms': round(v[1] * 1e3, 3), 'gflop_executed': round(v[0] / 1e9, 2), 'achieved': round(v[0] / v[1] / 1e12, 2),
+                   'peak': round(PIPE_PEAK[k], 1), 'frac': round(v[0] / v[1] / 1e12 / PIPE_PEAK[k], 4),
+                   'share_of_conv_time': round(v[1] / total_t, 3),
+                   'share_of_step_time': round(v[1] * 1e3 / ms_per_step, 3) if ms_per_step else None}
+               for k, v in sorted(pipes.items(), key=lambda kv: -kv[1][1])}
     return {
-        'bound': 'mfma', 'kernel': name, 'launches': cnt,
+        'bound': 'mfma', 'kernel': sym, 'variant': sorted(variants), 'pipe': pipe, 'launches': cnt,
         'flops_per_launch': round(fl / cnt / 1e9, 3), 'avg_launch_us': round(tt / cnt * 1e6, 2),
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-        'frac': round(achieved / peak, 4), 'traffic': traffic,
-        'peak_note': ('dense bf16 MFMA peak / 6: a split-mode kernel issues six bf16 MFMAs per fp32 product' if 'x3' in name else 'fp32 MFMA peak'),
-        'top_fp32_mfma_kernel': f32_top,
+        'frac': round(achieved / peak, 4), 'traffic': traffic_of(sym, fl / cnt),
+        'peak_note': ('dense bf16 MFMA peak / 6: a split-mode kernel issues six bf16 MFMAs per fp32 product' if pipe == 'bf16x6' else
+                      ('dense 16-bit MFMA peak' if pipe == '16bit' else 'fp32 MFMA peak')),
         'kernel_share_of_conv_time': round(tt / total_t, 3),
-        'all_conv_kernels': {'achieved': round(total_f / total_t / 1e12, 2),
-                             'frac': round(total_f / total_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                             'time_ms': round(total_t * 1e3, 3), 'launches': len(prof), 'gflop_executed': round(total_f / 1e9, 2)},
-        'by_kernel': {k: {'launches': v[0], 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3)}
+        'by_pipe': by_pipe,
+        'all_conv_kernels': {'time_ms': round(total_t * 1e3, 3), 'launches': len(prof), 'gflop_executed': round(total_f / 1e9, 2),
+                             'achieved': round(total_f / total_t / 1e12, 2),
+                             'note': 'mixed pipes: see by_pipe for the roofline fractions'},
+        'by_kernel': {k: {'launches': v[0], 'avg_launch_us': round(v[2] / v[0] * 1e6, 2), 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3),
+                          'frac': round(v[1] / v[2] / 1e12 / PIPE_PEAK[pipe_of(sorted(v[3])[0])], 4), 'pipe': pipe_of(sorted(v[3])[0]),
+                          'variant': sorted(v[3]), 'traffic': traffic_of(k, v[1] / v[0])}
                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
+        'note': 'by_kernel keys are device symbols: look them up in profiles/r03_kernel_stats_resnet_*.txt / r03_steady_state_resnet_*.txt '
+                '(tools/roofline_crosscheck.py prints both side by side)',
     }
 
 
@@ -415,11 +582,14 @@ def measure_gp_unit(trainer, batch, torch):
             unit()
         torch.cuda.synchronize()
         import ctgan_amd.kernels as K
-        K.PROFILE = []                          # one instrumented eager pass: the FLOPs this unit actually launches
+        K.PROFILE = []                          # one instrumented eager pass: the FLOPs this unit actually launches, per matrix pipe
         try:
             unit()
             torch.cuda.synchronize()
             executed = sum(p[1] for p in K.PROFILE) / 1e9
+            by_pipe = {}
+            for p in K.PROFILE:
+                by_pipe[pipe_of(p[0])] = by_pipe.get(pipe_of(p[0]), 0.0) + p[1] / 1e9
         finally:
             K.PROFILE = None
         graph = torch.cuda.CUDAGraph()
@@ -439,11 +609,13 @@ def measure_gp_unit(trainer, batch, torch):
     return {'what': 'critic forward + GP backward (dD/dx_hat, then d(GP)/d(theta)), B=64, hipGraph replay',
             'ms': round(ms, 4), 'target_ms': 1.48,
             'gflop_executed': round(executed, 2), 'achieved': round(executed / ms, 2), 'unit': 'TFLOP/s',
-            'frac_executed': round(executed / ms / PEAK_F32_MFMA_TFLOPS, 4),
+            'frac_executed': round(sum(gf / PIPE_PEAK[pp] for pp, gf in by_pipe.items()) / ms, 4),
+            'gflop_executed_by_pipe': {pp: round(gf, 2) for pp, gf in by_pipe.items()},
             'gflop_reference_formulation': round(gflop, 2), 'effective': round(gflop / ms, 2),
             'effective_frac': round(gflop / ms / PEAK_F32_MFMA_TFLOPS, 4), 'target_frac': 0.60,
-            'note': 'frac_executed = FLOPs launched (ConvMeanPool runs as a 4x4 stride-2 conv: 2.25x fewer MACs on 69 % of F_D) / time / '
-                    'peak - the roofline fraction; effective_frac prices the same time with the reference formulation\'s 139.3 GFLOP'}
+            'note': 'frac_executed = (time the launched FLOPs take at the peak of the pipe each kernel runs on: fp32 MFMA 157.3, split mode '
+                    '2500/6 TFLOP/s) / measured time - the roofline fraction (ConvMeanPool runs as a 4x4 stride-2 conv: 2.25x fewer MACs on '
+                    '69 % of F_D); effective_frac prices the same time with the reference formulation\'s 139.3 GFLOP at the fp32 MFMA peak'}
 
 
 def build_provenance():
@@ -491,17 +663,24 @@ def cpu_baseline(lib, torch):
     optG = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Generator')], 0.0, 0.9)
     rnd = osteps.make_rnd_resnet_d(B, 128, g, dtype=torch.float32)
     rg = osteps.make_rnd_resnet_g(B, 128, g, dtype=torch.float32)
-    t0 = time.perf_counter()
+    # 1 warm-up + 2 timed steps of each kind (the first call of a shape pays for oneDNN primitive creation and the
+    # allocator's first touch; a cold D step measured ~15 % slower than a warm one)
     osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd, iteration=1, B=B)
-    td = time.perf_counter() - t0
-    t0 = time.perf_counter()
     osteps.resnet_g_step(reg, cfg, optG, rg, iteration=1, B=B)
-    tg = time.perf_counter() - t0
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        osteps.resnet_d_step(reg, cfg, optD, real, labels, rnd, iteration=1, B=B)
+    td = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        osteps.resnet_g_step(reg, cfg, optG, rg, iteration=1, B=B)
+    tg = (time.perf_counter() - t0) / reps
     t_iter = tg + 5 * td
     return {'value': round(5 * B / t_iter, 3), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 critic step (%.2f s) + 1 generator step (%.2f s) of the oracle at full width, B=64, '
+            'sample': '1 warm-up + %d timed critic steps (%.2f s each) and generator steps (%.2f s each) of the oracle at full width, B=64, '
                       'torch-CPU fp32 with %d threads; iteration = G + 5*D = %.2f s (TF1 itself is not installable)'
-                      % (td, tg, cores, t_iter)}
+                      % (reps, td, tg, cores, t_iter)}
 
 
 if __name__ == '__main__':

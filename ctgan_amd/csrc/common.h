@@ -29,6 +29,9 @@ int ctgan_small_linear_dgrad(const ctgan_conv_desc* d, const float* gy, const fl
 int ctgan_small_linear_wgrad(const ctgan_conv_desc* d, const float* x, const float* gy, float* gw, float* gb, hipStream_t st);
 // per-thread name of the kernel variant the last conv call dispatched to
 void ctgan_set_last_kernel(const char* name);
+// ... and the device symbol of that launch as rocprofv3 prints it (template arguments spelled the compiler's way), so that
+// bench.py's per-kernel table can be looked up in a committed rocprof summary.  ctgan_set_last_kernel clears it.
+void ctgan_set_last_symbol(const char* fmt, ...);
 
 // fewch.hip: direct kernels for convs with <= 4 channels on one side.  fwd / dgrad / wgrad return 1 when they
 // handled the call, 0 when the caller should fall through to the GEMM kernels, < 0 on error.

@@ -685,6 +685,7 @@ static int launch_f2m(const F2MParams& p, int R, int S, int CS, hipStream_t st) 
         case 4: hipLaunchKernelGGL((f2m_kernel<3, 3, 1>), grid, blk, smem, st, p); break;
         default: return ctgan_fail(CTGAN_E_UNSUPPORTED, "fewch f2m: taps");
     }
+    ctgan_set_last_symbol("f2m_kernel<%d, %d, %d>", R, S, CS);
     return ctgan_check_launch("fewch_f2m");
 }
 
@@ -705,6 +706,7 @@ static int launch_m2f_ring(M2FParams p, hipStream_t st) {
     int rc = set_smem(&m2f_ring_kernel<JS>, smem);
     if (rc) return rc;
     hipLaunchKernelGGL((m2f_ring_kernel<JS>), dim3(p.N * strips), dim3(RING_NT), smem, st, p);
+    ctgan_set_last_symbol("m2f_ring_kernel<%d>", JS);
     return ctgan_check_launch("fewch_m2f_ring");
 }
 
@@ -725,6 +727,7 @@ static int launch_m2f(const M2FParams& p, int R, int S, int JS, hipStream_t st) 
         default: return ctgan_fail(CTGAN_E_UNSUPPORTED, "fewch m2f: taps");
     }
     if (rc) return rc;
+    ctgan_set_last_symbol("m2f_kernel<%d, %d, %d>", R, S, JS);
     return ctgan_check_launch("fewch_m2f");
 }
 
@@ -889,6 +892,7 @@ int ctgan_fewch_wgrad2(const ctgan_conv_desc* d0, const float* x, const float* d
             rc = ctgan_check_launch("fewch_wgrad_mfma");
             if (rc) return rc;
             ctgan_set_last_kernel(few_in ? "fewch_wgrad(few_in)" : "fewch_wgrad(few_out)");
+            ctgan_set_last_symbol("fw_wgrad_mfma_kernel<%d, %d, %d>", d->R, d->S, JS);
             const int nb = db ? d->K : 0;
             const int n_tot = db ? p.n_out : p.n_main;
             hipLaunchKernelGGL(fw_reduce_kernel, dim3((n_tot + 63) / 64), dim3(NT), 0, st, p.slab, p.n_out, blocks, dw, p.n_main, db, nb, n_tot);
@@ -907,6 +911,7 @@ int ctgan_fewch_wgrad2(const ctgan_conv_desc* d0, const float* x, const float* d
     rc = ctgan_check_launch("fewch_wgrad");
     if (rc) return rc;
     ctgan_set_last_kernel(few_in ? "fewch_wgrad(few_in)" : "fewch_wgrad(few_out)");
+    ctgan_set_last_symbol("fw_wgrad_kernel<%d, %d, %d>", d->R, d->S, JS);
     const int nb = db ? d->K : 0;
     const int n_tot = db ? p.n_out : p.n_main;
     hipLaunchKernelGGL(fw_reduce_kernel, dim3((n_tot + 63) / 64), dim3(NT), 0, st, p.slab, p.n_out, blocks, dw, p.n_main, db, nb, n_tot);

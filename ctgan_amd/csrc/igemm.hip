@@ -1233,6 +1233,7 @@ inline size_t dgrad_filter_elems(const ctgan_conv_desc* d) {
 // ------------------------------------------------------------------------------------------
 // host-side dispatch
 thread_local char g_last_kernel[128] = "";
+thread_local char g_last_symbol[160] = "";
 bool g_force_generic = false;   // tests: route vectorisable shapes through the table-driven kernel too
 
 template <bool AVEC, bool BVEC, int WM, int WN, int TM, int TN>
@@ -1243,6 +1244,7 @@ int launch_fwd(const FwdParams& p, hipStream_t st) {
     const int tiles = q.ph_tiles_m * (p.phases > 1 ? p.phases : 1) * ((p.Ng + BN - 1) / BN);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd<%s,%s,%dx%d%s>", AVEC ? "avec" : "agen",
              BVEC ? "bvec" : "bgen", BM, BN, p.phases > 1 ? ",ph4" : "");
+    ctgan_set_last_symbol("igemm_fwd_kernel<%s, %s, %d, %d, %d, %d>", AVEC ? "true" : "false", BVEC ? "true" : "false", WM, WN, TM, TN);
     hipLaunchKernelGGL((igemm_fwd_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(tiles), dim3(64 * WM * WN), 0, st, q);
     return ctgan_check_launch("igemm_fwd");
 }
@@ -1276,6 +1278,7 @@ int launch_fwd_pipe_impl(const FwdParams& p, hipStream_t st) {
     const int tiles = q.ph_tiles_m * (p.phases > 1 ? p.phases : 1) * ((p.Ng + BN - 1) / BN);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_fwd_pipe<%dx%d,k%d%s%s%s>", BM, BN, WK, KSUB > 1 ? ",bk64" : "", RELU_IN ? ",relu" : "",
              p.phases > 1 ? ",ph4" : "");
+    ctgan_set_last_symbol("igemm_fwd_pipe_kernel<%d, %d, %d, %d, %d, %d, %s, %d>", WM, WN, WK, TM, TN, RD, RELU_IN ? "true" : "false", KSUB);
     hipLaunchKernelGGL((igemm_fwd_pipe_kernel<WM, WN, WK, TM, TN, RD, RELU_IN, KSUB>), dim3(tiles), dim3(64 * WM * WN * WK), smem_bytes, st, q);
     return ctgan_check_launch("igemm_fwd_pipe");
 }
@@ -1436,6 +1439,7 @@ int launch_wgrad(WgradParams p, const WPlan& w, float* dw, void* ws, hipStream_t
     p.OUT = w.splits > 1 ? static_cast<float*>(ws) : dw;
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad<%s,%s,%dx%d,split%d>", AVEC ? "avec" : "agen",
              BVEC ? "bvec" : "bgen", w.bm, w.bn, w.splits);
+    ctgan_set_last_symbol("igemm_wgrad_kernel<%s, %s, %d, %d, %d, %d>", AVEC ? "true" : "false", BVEC ? "true" : "false", WM, WN, TM, TN);
     hipLaunchKernelGGL((igemm_wgrad_kernel<AVEC, BVEC, WM, WN, TM, TN>), dim3(w.tiles, w.splits), dim3(64 * WM * WN), 0, st, p);
     int rc = ctgan_check_launch("igemm_wgrad");
     if (rc) return rc;
@@ -1476,6 +1480,7 @@ int launch_wgrad_pipe(WgradParams p, const WPlan& w, float* dw, float* db, void*
     const bool direct = w.splits == 1 && !db;
     p.OUT = direct ? dw : static_cast<float*>(ws);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad_pipe<%dx%d,split%d%s>", BM, BN, w.splits, db ? ",bias" : "");
+    ctgan_set_last_symbol("igemm_wgrad_pipe_kernel<%d, %d, %d, %d>", WM, WN, TM, TN);
     hipLaunchKernelGGL((igemm_wgrad_pipe_kernel<WM, WN, TM, TN>), dim3(w.tiles, w.splits), dim3(64 * WM * WN), smem_bytes, st, p);
     int rc = ctgan_check_launch("igemm_wgrad_pipe");
     if (rc || direct) return rc;
@@ -1569,11 +1574,18 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
     *chunk = ch;
 }
 
-void ctgan_set_last_kernel(const char* name) { snprintf(g_last_kernel, sizeof g_last_kernel, "%s", name); }
+void ctgan_set_last_kernel(const char* name) { snprintf(g_last_kernel, sizeof g_last_kernel, "%s", name); g_last_symbol[0] = 0; }
+void ctgan_set_last_symbol(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_symbol, sizeof g_last_symbol, fmt, ap);
+    va_end(ap);
+}
 
 extern "C" {
 
 const char* ctgan_last_kernel(void) { return g_last_kernel; }
+const char* ctgan_last_symbol(void) { return g_last_symbol[0] ? g_last_symbol : g_last_kernel; }
 void ctgan_debug_force_generic(int on) { g_force_generic = on != 0; }
 
 size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
@@ -1901,6 +1913,7 @@ int launch_wgrad_pipe_group(const WgradGroupParams& gp, hipStream_t st) {
         attr_set = true;
     }
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad_pipe_group<%dx%d,n%d>", BM, BN, gp.n);
+    ctgan_set_last_symbol("igemm_wgrad_pipe_group_kernel<%d, %d, %d, %d>", WM, WN, TM, TN);
     hipLaunchKernelGGL((igemm_wgrad_pipe_group_kernel<WM, WN, TM, TN>), dim3(gp.block0[gp.n]), dim3(64 * WM * WN), smem_bytes, st, gp);
     return ctgan_check_launch("igemm_wgrad_pipe_group");
 }
@@ -1977,6 +1990,11 @@ extern "C" size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_gro
 }
 
 extern "C" int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+    return ctgan_conv2d_wgrad_group_ex(groups, n, ws, ws_bytes, CTGAN_WGRAD_GROUP_GEMM | CTGAN_WGRAD_GROUP_REDUCE, stream);
+}
+
+extern "C" int ctgan_conv2d_wgrad_group_ex(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, int phases,
+                                           ctgan_stream_t stream) {
     if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT) return ctgan_fail(CTGAN_E_BADARG, "conv2d_wgrad_group: bad argument");
     static thread_local MultiPlan M[CTGAN_WGRAD_GROUP_LIMIT];
     static thread_local WgradParams PT[CTGAN_WGRAD_GROUP_LIMIT];
@@ -1995,7 +2013,7 @@ extern "C" int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const WTile order[4] = {W128x128, W64x128, W64x64, W32x128};
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4 && (phases & CTGAN_WGRAD_GROUP_GEMM); ++t) {
         int idx[CTGAN_WGRAD_GROUP_LIMIT], cnt = 0;
         for (int i = 0; i < n; ++i) if (M[i].w.tile == order[t]) idx[cnt++] = i;
         // longest chunk first: the workgroups that run longest start first
@@ -2024,7 +2042,7 @@ extern "C" int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t
             if (rc) return rc;
         }
     }
-    for (int base = 0; base < n; base += CTGAN_REDUCE_BATCH) {
+    for (int base = 0; base < n && (phases & CTGAN_WGRAD_GROUP_REDUCE); base += CTGAN_REDUCE_BATCH) {
         ReduceJobs jobs;
         jobs.n = (n - base) < CTGAN_REDUCE_BATCH ? (n - base) : CTGAN_REDUCE_BATCH;
         jobs.pad = 0;
@@ -2040,6 +2058,7 @@ extern "C" int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t
         int rc = ctgan_check_launch("splitk_reduce_batch");
         if (rc) return rc;
     }
-    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad_pipe_group<n%d>", n);
+    if (phases & CTGAN_WGRAD_GROUP_GEMM)
+        snprintf(g_last_kernel, sizeof g_last_kernel, "igemm_wgrad_pipe_group<n%d>", n);      // (the symbol stays that of the last grouped launch)
     return CTGAN_OK;
 }

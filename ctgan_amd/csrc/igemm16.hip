@@ -1098,6 +1098,7 @@ int launch_conv16(const P16& p, hipStream_t st, const char* name) {
     if (!(q.ksplit > 1 && q.slab)) { q.ksplit = 1; q.slab = nullptr; }
     hipLaunchKernelGGL(kern, dim3((unsigned)(q.nph * tiles_m * tiles_n), (unsigned)q.ksplit), dim3(256), lds, st, q);
     ctgan_set_last_kernel(name);
+    ctgan_set_last_symbol("conv16_kernel<%d, %d, %d, %d, %s, %s>", MMA, TM, TN, BK, p.relu_in ? "true" : "false", conv16_one_wave<MMA, TM, TN>() ? "true" : "false");
     int rc = ctgan_check_launch(name);
     if (rc || q.ksplit == 1) return rc;
     const long long n = (long long)q.nph * q.M * (q.Ng / 4);
@@ -1144,6 +1145,7 @@ int launch_conv16x3h(const P16& p, hipStream_t st) {
     q.ksplit = 1; q.slab = nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
     ctgan_set_last_kernel("conv16x3h<128x128,k32>");
+    ctgan_set_last_symbol("conv16x3h_kernel<%s>", p.relu_in ? "true" : "false");
     return ctgan_check_launch("conv16x3h<128x128,k32>");
 }
 
@@ -1222,6 +1224,7 @@ int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
     const int tiles_m = p.R * p.S * (p.C / BMC), tiles_n = (p.Ng + BNK - 1) / BNK;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), dim3(256), lds, st, p);
     ctgan_set_last_kernel(name);
+    ctgan_set_last_symbol("wgrad16_kernel<%d, %d, %d, %s, %s>", MMA, TM, TN, p.relu_x ? "true" : "false", wgrad16_one_wave<MMA, TM, TN>() ? "true" : "false");
     return ctgan_check_launch(name);
 }
 
@@ -1266,14 +1269,28 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d, int mma) {
 
 }  // namespace
 
+// The kernels address their operands with 32-bit byte offsets through buffer descriptors: every operand a launch gathers from must
+// span < 4 GiB.  Part of the routing predicates (not only of the launchers), so that a caller that asks "does the 16-bit family take
+// this launch" never gets a yes followed by CTGAN_E_UNSUPPORTED.
+static bool extents_ok(const ctgan_conv_desc* d, int op, int mma) {
+    const long long lim = 1LL << 32;
+    const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
+    const long long y_extent = (long long)(d->N - 1) * d->ys[0] + (long long)(d->P - 1) * d->ys[2] + (long long)(d->Q - 1) * d->ys[3] + d->K;
+    const long long w_bytes = (long long)d->R * d->S * d->C * d->K * 2 * mma_planes(mma);
+    if (op == CTGAN_CONV_FWD) return x_extent * 4 < lim && w_bytes < lim;
+    if (op == CTGAN_CONV_DGRAD) return y_extent * 4 < lim && w_bytes < lim;
+    return x_extent * 4 < lim && (long long)d->N * d->P * d->Q * d->K * 4 < lim;
+}
+
 extern "C" {
 
 int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     if (!d || !mma_ok(mma)) return 0;
+    if (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD && op != CTGAN_CONV_WGRAD) return 0;
+    if (!extents_ok(d, op, mma)) return 0;
     if (op == CTGAN_CONV_FWD) return shape_ok_fwd(d) ? 1 : 0;
     if (op == CTGAN_CONV_DGRAD) return shape_ok_dgrad(d) ? 1 : 0;
-    if (op == CTGAN_CONV_WGRAD) return (shape_ok_wgrad(d) && (mma != CTGAN_MMA_F32X3 || shape_ok_wgrad_x3(d))) ? 1 : 0;
-    return 0;
+    return (shape_ok_wgrad(d) && (mma != CTGAN_MMA_F32X3 || shape_ok_wgrad_x3(d))) ? 1 : 0;
 }
 
 static long long x3_wgrad_min_pixels() {      // CTGAN_X3_WGRAD_MIN: experiment switch for the routing threshold of weight gradients
@@ -1293,6 +1310,7 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
     }
     if (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD) return 0;
     if (op == CTGAN_CONV_FWD ? !shape_ok_fwd(d) : !shape_ok_dgrad(d)) return 0;
+    if (!extents_ok(d, op, CTGAN_MMA_F32X3)) return 0;
     if (d->stride == 2) {
         // stride-2 layers (the folded ConvMeanPool / UpsampleConv filters) on the single-stage slice kernel: 145 / 160 vs 125 / 113
         // TFLOP/s (forward / four-phase data gradient) when the launch has >= 192 tiles of 128x128

@@ -43,8 +43,16 @@ class GraphedTrainer:
                 self._capture(warmup)
             except Exception as e:      # fall back to eager launches; bench.py reports it
                 self.graph_error = '%s: %s' % (type(e).__name__, e)
-                self.d_graph = self.g_graph = None
+                self.d_graph = self.g_graph = self.f_graph = self.it_graph = None
+                self.fake_all = self.it_out = None
                 torch.cuda.synchronize()
+
+    def _weights_moved(self, group=None):
+        """A replay with Adam inside the graph changed the weights AFTER the graph's own rebuild of the derived / packed filter
+        images: tell the host-side version counter, so that an eager consumer after the replay (a stand-alone step, bench.py's
+        instrumented passes, sample grids) rebuilds them instead of mixing fresh weights with images one step old."""
+        if self.adam_in_graph:
+            lib.bump_epoch(group)
 
     # -- the region that is captured (everything between input copy and all-reduce / Adam)
     def _d_body(self, real=None, labels=None, fake=None):
@@ -137,9 +145,15 @@ class GraphedTrainer:
                 if self.adam_in_graph and ITERATION_GRAPH:
                     # Seven graph launches per iteration leave ~150 us of idle GPU at each boundary (profiles/
                     # r02_steady_state_resnet_v2.txt: 1.07 ms of 20.5 ms); one graph per iteration has one boundary.
-                    self.it_graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.it_graph):
-                        self.it_out = self._it_body()
+                    # Optional: if only this capture fails (a fourth private pool), the three per-step graphs stay in use.
+                    try:
+                        self.it_graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.it_graph):
+                            self.it_out = self._it_body()
+                    except Exception as e:
+                        self.it_graph = self.it_out = None
+                        self.graph_error = 'iteration graph not captured (per-step graphs in use): %s: %s' % (type(e).__name__, e)
+                        torch.cuda.synchronize()
         finally:
             torch.cuda.synchronize()
             for b, sn in zip(bufs, snap):
@@ -174,6 +188,7 @@ class GraphedTrainer:
             t.reduce_and_update(t.d_opt, t.d_opt.grad, between)
         else:
             t.d_opt.t += 1
+            self._weights_moved('Discriminator')
             if between is not None:
                 between()
         return self.d_out
@@ -188,6 +203,7 @@ class GraphedTrainer:
             t.reduce_and_update(t.g_opt, t.g_opt.grad, between)
         else:
             t.g_opt.t += 1
+            self._weights_moved('Generator')
             if between is not None:
                 between()
         return self.g_out
@@ -228,6 +244,7 @@ class GraphedTrainer:
             self.it_graph.replay()
             t.g_opt.t += 1
             t.d_opt.t += len(batches)
+            self._weights_moved()
             self.g_out = self.it_out['g']
             return self.it_out['d'][-1]
         if iteration > 0:
@@ -334,6 +351,7 @@ class GraphedDCGANTrainer:
         self.d_graph.replay()
         if self.adam_in_graph:
             t.d_opt.t += 1
+            lib.bump_epoch()           # the in-graph Adam step ran after the graph's own filter rebuild (see GraphedTrainer._weights_moved)
         else:
             self._reduce_update(t.d_opt)
         return self.d_out
@@ -346,6 +364,7 @@ class GraphedDCGANTrainer:
         self.g_graph.replay()
         if self.adam_in_graph:
             t.g_opt.t += 1
+            lib.bump_epoch()
         else:
             self._reduce_update(t.g_opt)
         return self.g_out

@@ -94,7 +94,7 @@ def _flush_groups(grps):
     fits the pipelined kernel (K.conv_wgrad_group), else group by group."""
     _all = list(grps)
     simple = [g for g in grps if 1 <= len(g.segs) <= K.WGRAD_MAX_SEGS and not K.fewch_handles(g.g)]
-    if WGRAD_GROUPED and len(simple) > 1 and K.PROFILE is None:
+    if WGRAD_GROUPED and len(simple) > 1:
         for g in simple:                                   # a queued bias buffer no segment contributes to
             if g.db is not None and not any(sg[3] for sg in g.segs):
                 g.db.zero_()
@@ -503,7 +503,7 @@ def prepare_filters():
     if todo:
         K.filter_batch([e.job() for e in todo])
         _mark_built(todo)
-    if todo or K._pack16:
+    if (todo or K._pack16) and (K.MMA_DTYPE is not None or K.X3_HYBRID):       # no 16-bit / split-mode launch can be routed otherwise
         K.prepare_packs()                 # the 16-bit / split-mode images of the parameters and of the filters just rebuilt: one launch
 
 

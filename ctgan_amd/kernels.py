@@ -45,7 +45,7 @@ def _timed(g, N, launch):
     for _ in range(PROFILE_REPS):
         launch()
     e1.record(st)
-    PROFILE.append((last_kernel(), _conv_flops(g, N), e0, e1, PROFILE_REPS, (N, g.C, g.H, g.W, g.K, g.R, g.stride, int(g.x_up))))
+    PROFILE.append((last_kernel(), _conv_flops(g, N), e0, e1, PROFILE_REPS, (N, g.C, g.H, g.W, g.K, g.R, g.stride, int(g.x_up)), last_symbol()))
 
 
 def _stream():
@@ -546,7 +546,21 @@ def conv_wgrad_group(groups):
     if nb == 0:
         raise NotImplementedError('conv2d_wgrad_group: unsupported group')
     ws = workspace(nb, dev)
-    check(lib.ctgan_conv2d_wgrad_group(arr, n, _ptr(ws), ws.numel(), _stream()), 'conv2d_wgrad_group')
+    if PROFILE is None:
+        check(lib.ctgan_conv2d_wgrad_group(arr, n, _ptr(ws), ws.numel(), _stream()), 'conv2d_wgrad_group')
+        return
+    # bench.py's roofline leg: the grouped GEMM launch alone inside the event bracket (what rocprofv3 lists under this symbol), the
+    # batched split-K reduction after it
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream()
+    e0.record(st)
+    for _ in range(PROFILE_REPS):
+        check(lib.ctgan_conv2d_wgrad_group_ex(arr, n, _ptr(ws), ws.numel(), 1, _stream()), 'conv2d_wgrad_group')
+    e1.record(st)
+    flops = sum(_conv_flops(g, sum(sg[0].shape[0] for sg in segs)) for segs, g, _, _ in groups)
+    PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, ('group', n), last_symbol()))
+    check(lib.ctgan_conv2d_wgrad_group_ex(arr, n, _ptr(ws), ws.numel(), 2, _stream()), 'conv2d_wgrad_group')
 
 
 def im2col(x, g, cpad):
@@ -576,6 +590,11 @@ def col2im(cols, g, N, out_strides=None):
 
 def last_kernel():
     return lib.ctgan_last_kernel().decode()
+
+
+def last_symbol():
+    """Device symbol of the last conv launch as rocprofv3 prints it (the variant name where the launcher records none)."""
+    return lib.ctgan_last_symbol().decode()
 
 
 def debug_force_generic(on):

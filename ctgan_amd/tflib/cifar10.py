@@ -94,6 +94,11 @@ def prefetch_to_device(gen, device, depth=2):
     while inflight:
         images, labels, done, _ = inflight.popleft()
         if done is not None:
-            torch.cuda.current_stream().wait_event(done)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)
+            # the tensors were allocated on the copy stream: tell the caching allocator that the consumer's stream uses them too,
+            # or a dropped batch's block can be handed to the next H2D copy while the consumer's (queued) read is still pending
+            images.record_stream(cur)
+            labels.record_stream(cur)
         yield images, labels
         stage()

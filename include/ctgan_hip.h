@@ -65,6 +65,9 @@ int ctgan_version(void);
 const char* ctgan_last_error(void);
 /* which kernel variant the last conv call on this thread dispatched to (for tests/profiles)   */
 const char* ctgan_last_kernel(void);
+/* ... and its device symbol as rocprofv3 prints it (e.g. "conv16_kernel<3, 2, 2, 32, false, false>"); the variant name when the
+   launcher does not record one.  bench.py keys its per-kernel roofline table by it (cross-checked against profiles/).            */
+const char* ctgan_last_symbol(void);
 /* tests only: 1 = route every conv through the table-driven generic kernels                   */
 void ctgan_debug_force_generic(int on);
 
@@ -126,6 +129,11 @@ typedef struct ctgan_wgrad_group {
 size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n);
 int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes,
                              ctgan_stream_t stream);
+/* The two phases of the grouped launch separately (bench.py times the GEMM launches alone, as rocprofv3 reports them): the grouped
+   weight-gradient kernels write the split-K slabs, the batched reduction sums them into dw / db in a fixed order.             */
+enum { CTGAN_WGRAD_GROUP_GEMM = 1, CTGAN_WGRAD_GROUP_REDUCE = 2 };
+int ctgan_conv2d_wgrad_group_ex(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, int phases,
+                                ctgan_stream_t stream);
 /* ---- convolution family  (replaces tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112,
  *      tf.nn.conv2d_transpose TF/tflib/ops/deconv2d.py:97-103, tf.matmul
  *      TF/tflib/ops/linear.py:132-137 (as 1x1 conv on a 1x1 image), and the conv gradient nodes

@@ -1,0 +1,52 @@
+"""`python bench.py --gpus N` without a launcher around it: the script starts its own N rank processes (before anything touches the
+GPU), relays rank 0's record and reports the world it really ran.  CPU-only: `--spawn-check` makes the ranks join
+the group and all-reduce their rank numbers instead of training."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_gpus_2_spawns_two_ranks_and_prints_one_json_line():
+    r = _run('--gpus', '2', '--backend', 'gloo', '--spawn-check')
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                     # library chatter goes to stderr
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['rank_sum'] == 3.0          # both ranks were in the all-reduce
+    assert rec['backend'] == 'gloo' and rec['rccl_world'] is None  # a gloo world is not reported as an RCCL world
+
+
+def test_launcher_always_runs_one_rank_through_the_same_path():
+    r = _run('--gpus', '1', '--launcher', 'always', '--spawn-check')
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec['n_gpus'] == 1 and rec['backend'] is None and rec['rccl_world'] is None
+
+
+def test_more_rccl_ranks_than_devices_is_refused_before_any_rank_starts():
+    import torch
+    if torch.cuda.device_count() >= 3:
+        import pytest
+        pytest.skip('needs a box with fewer than 3 devices')
+    r = _run('--gpus', '3')
+    assert r.returncode == 2 and 'device(s) visible' in r.stderr and r.stdout.strip() == ''
+
+
+def test_world_size_that_contradicts_gpus_is_an_error_not_a_warning():
+    r = _run('--gpus', '2', '--spawn-check', env={'WORLD_SIZE': '1', 'RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr
+
+
+def test_a_failing_rank_fails_the_launcher():
+    # rank processes that cannot rendezvous with the requested backend must surface as a non-zero exit, not as a hang or a 0
+    r = _run('--gpus', '2', '--backend', 'no_such_backend', '--spawn-check')
+    assert r.returncode != 0

@@ -55,10 +55,13 @@ def test_64x64_nets_and_steps_match_oracle(cpu_kernels):
 
 
 @pytest.mark.gpu
-def test_64x64_on_gpu():
+@pytest.mark.parametrize('dim', [32, 64])
+def test_64x64_on_gpu(dim):
+    """GoodGenerator / GoodDiscriminator (TF/CT_gan_64x64.py:166-221,357-373) against the fp64 oracle at half width and at the
+    reference width DIM = 64 (critic 64..512 channels), B = 4."""
     import ctgan_amd.tflib as lib
     lib.delete_all_params(); lib.set_device(None)
     try:
-        _run(lib, 'cuda', 32, 4, 5e-5)
+        _run(lib, 'cuda', dim, 4, 5e-5)
     finally:
         lib.delete_all_params()

@@ -221,6 +221,37 @@ def test_train_iteration_and_samples(setup):
     assert s.shape == (100, 3072) and px.min() >= 0 and px.max() <= 255
 
 
+@pytest.mark.parametrize('dim', [16, 128])
+def test_fixed_noise_sample_tensors_match_oracle(setup, dim):
+    """north_star "sample tensors": generate_image's path (TF/CT_gan_cifar_resnet.py:341-348) - Generator(100, fixed_labels =
+    [0..9] x 10, noise = fixed_noise[100,128]), conditional BN on the statistics of those 100 samples, pixels =
+    ((s + 1) * 255 / 2).astype(int32) - against the fp64 oracle at reduced and FULL width.  Float samples: 1e-4 of the tanh range.
+    Integer pixels: EQUAL, except where the oracle's real-valued pixel lies within 2e-2 of an integer boundary (1e-4 * 127.5 of
+    float error + fp32 rounding of the affine map can move such a value across the truncation); at most 1 level apart there."""
+    import numpy as np
+    R, lib = setup(dim, 8)
+    reg = _oracle_from_product(lib)
+    cfg = onets.ResnetCfg(DIM_G=dim, DIM_D=dim)
+    g = torch.Generator().manual_seed(11)
+    noise = torch.randn(100, 128, generator=g, dtype=torch.float64)
+    labels = torch.arange(10, dtype=torch.int32).repeat(10)
+    tr = R.Trainer(seed=7)
+    s, px = tr.generate_samples(noise.float().cuda(), labels.cuda())
+    with torch.no_grad():
+        ref = onets.resnet_generator(reg, cfg, 100, labels, noise)
+    assert s.shape == (100, 3072) and px.dtype == torch.int32 and px.shape == (100, 3072)
+    _cmp(s, ref, 1e-4, 'fixed-noise samples', atol=1e-6)
+    real_px = ((ref + 1.) * (255. / 2)).numpy()
+    ref_px = real_px.astype(np.int32)                            # numpy's float -> int32 cast truncates, like tf.cast / astype('int32')
+    got = px.cpu().numpy()
+    assert got.min() >= 0 and got.max() <= 255
+    near_boundary = np.abs(real_px - np.round(real_px)) < 2e-2
+    diff = got != ref_px
+    assert not (diff & ~near_boundary).any(), 'integer pixels differ away from a truncation boundary: %d' % int((diff & ~near_boundary).sum())
+    assert np.abs(got - ref_px).max() <= 1
+    assert diff.mean() < 2e-3, 'fraction of boundary flips %.2e' % diff.mean()
+
+
 @pytest.mark.parametrize('dim,B', [(32, 6), (128, 16)])
 def test_dropout_fused_into_conv_epilogues_equals_separate_dropout_kernels(setup, dim, B):
     """DiscriminatorTail with the dropout masks (and the final ReLU) inside the conv kernels - forward in the producing

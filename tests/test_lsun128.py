@@ -156,8 +156,16 @@ def test_lsun128_full_width_16bit_losses(dt):
         rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
         ref = osteps.dcgan_d_losses(reg, G, D, 2 * ((real_in.double() / 255.) - .5), rnd)
         with K.mma_dtype(dt):
-            out = tr.d_step(real_in.cuda(), {k: _to(v, 'cuda') for k, v in rnd.items()})
-            assert any(n.startswith('conv16') or n.startswith('wgrad16') for n in [K.last_kernel()]) or True
+            K.PROFILE = []                 # records the kernel variant of every conv-family launch of the step
+            try:
+                out = tr.d_step(real_in.cuda(), {k: _to(v, 'cuda') for k, v in rnd.items()})
+                ran = [p[0] for p in K.PROFILE]
+            finally:
+                K.PROFILE = None
+        # the step really ran on the 16-bit matrix cores: forward / data-gradient AND weight-gradient kernels of that family, and they
+        # are the majority of its conv launches (the 3-channel layers and the heads stay fp32)
+        n16 = sum(n.startswith('conv16<') for n in ran), sum(n.startswith('wgrad16<') for n in ran)
+        assert n16[0] >= 20 and n16[1] >= 10 and sum(n16) > len(ran) // 2, (n16, len(ran), sorted(set(ran)))
         tol = 1e-2 if dt == 'f16' else 4e-2
         for k in ('cost', 'wgan_only', 'ct', 'gp'):
             a, b = out[k].item(), ref[k].item() * (M.cfg.LAMBDA if k == 'gp' else 1.0)

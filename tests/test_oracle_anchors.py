@@ -191,3 +191,66 @@ def test_resnet_d_and_g_step_run_small():
     assert torch.isfinite(o3['cost']) and set(o3['grads']) == set(optG.names)
     # second D step decreases nothing pathological and Adam t advanced
     assert optD.t == 1 and optG.t == 1
+
+
+# ---- second restatement of the ResNet critic + its loss scalars (oracle/np_critic.py: numpy only, hand-derived gradient) ----------
+def _np_critic_setup(dim=4, B=2, seed=3):
+    from oracle import np_critic
+    cfg = nets.ResnetCfg(DIM_G=dim, DIM_D=dim)
+    reg = ops.Registry(dtype=torch.float64, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    real_int = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+    labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+    rnd = steps.make_rnd_resnet_d(B, dim, g)
+    ref = steps.resnet_d_losses(reg, cfg, real_int, labels, rnd, B=B)           # creates the parameters (reference init)
+    with torch.no_grad():                                                        # biases are zero at init: make them count
+        for n, p in reg.items():
+            if n.endswith('.Biases') or n.endswith('.b'):
+                p.copy_(torch.randn(p.shape, generator=g, dtype=torch.float64) * 0.1)
+    ref = steps.resnet_d_losses(reg, cfg, real_int, labels, rnd, B=B)
+    P = {n: p.detach().numpy() for n, p in reg.items()}
+    nrnd = {k: ([t.numpy() for t in v] if isinstance(v, list) else v.numpy()) for k, v in rnd.items()}
+    return np_critic, cfg, reg, P, ref, nrnd, B
+
+
+def test_numpy_restatement_of_the_critic_agrees_with_the_torch_oracle():
+    """Two restatements written separately from the reference text (torch ops + autograd vs numpy tap loops + a hand-derived
+    backward) must produce the same critic outputs, the same dD/dx_hat and the same WGAN / CT / GP scalars (fp64: 1e-10)."""
+    np_critic, cfg, reg, P, ref, rnd, B = _np_critic_setup()
+    out = np_critic.critic_scalars(P, ref['real'].detach().numpy(), ref['fake'].detach().numpy(), rnd, B)
+    for k in ('wgan_only', 'ct', 'gp'):
+        a, b = out['wgan' if k == 'wgan_only' else k], ref[k].item()
+        assert abs(a - b) <= 1e-10 * max(1.0, abs(b)), (k, a, b)
+    np.testing.assert_allclose(out['d_real'], ref['d_real'].detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(out['d_fake'], ref['d_fake'].detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(out['slopes'], ref['slopes'].detach().numpy(), rtol=1e-9)
+    np.testing.assert_allclose(out['gp_grads'], ref['gp_grads'].detach().numpy(), rtol=1e-8, atol=1e-12)
+    assert out['ct'] > 0 and out['gp'] > 0            # the draws exercise both terms
+
+
+def test_hand_derived_critic_gradient_matches_central_differences():
+    """The numpy backward is pinned by the numpy forward alone: directional derivatives along random directions (ReLU / dropout
+    kinks are measure-zero; h = 1e-6 in fp64)."""
+    np_critic, cfg, reg, P, ref, rnd, B = _np_critic_setup(seed=5)
+    x = (ref['real'] + 0.3 * (ref['fake'] - ref['real'])).detach().numpy()
+    kps = (0.8, 0.5, 0.5)
+    D, _, gx = np_critic.critic(P, x, kps, rnd['u_gp'], want_grad=True)
+    rs = np.random.default_rng(0)
+    for _ in range(4):
+        v = rs.standard_normal(x.shape)
+        h = 1e-6
+        fd = (np_critic.critic(P, x + h * v, kps, rnd['u_gp'])[0] - np_critic.critic(P, x - h * v, kps, rnd['u_gp'])[0]) / (2 * h)
+        an = (gx * v).sum(axis=1)
+        np.testing.assert_allclose(an, fd, rtol=2e-5, atol=1e-9)
+
+
+def test_numpy_critic_clean_pass_and_consistency_anchor():
+    """No dropout (keep 1): both passes coincide, so the consistency term of identical passes is exactly 0 in the second
+    restatement as well, and D of the numpy critic equals the torch oracle's clean pass."""
+    np_critic, cfg, reg, P, ref, rnd, B = _np_critic_setup(seed=9)
+    rf = torch.cat([ref['real'], ref['fake']], 0).detach()
+    with torch.no_grad():
+        dc, fc, _ = nets.resnet_discriminator(reg, cfg, rf, None, 1.0, 1.0, 1.0, None)
+    d, f = np_critic.critic(P, rf.numpy(), (1.0, 1.0, 1.0), None)
+    np.testing.assert_allclose(d, dc.numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(f, fc.numpy(), rtol=1e-10, atol=1e-12)

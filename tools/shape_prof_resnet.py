@@ -29,7 +29,7 @@ K.PROFILE = []; K.PROFILE_REPS = 4
 eng.train_iteration(3, lambda: batch); torch.cuda.synchronize()
 prof, K.PROFILE, K.PROFILE_REPS = K.PROFILE, None, 1
 agg = {}
-for kname, fl, e0, e1, reps, shp in prof:
+for kname, fl, e0, e1, reps, shp, _sym in prof:
     a = agg.setdefault((kname, shp), [0, 0.0, 0.0])
     a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
 tot = sum(a[2] for a in agg.values())
