@@ -73,12 +73,14 @@ SIGNATURES = {
     'ctgan_last_kernel': (c_char_p, []),
     'ctgan_last_symbol': (c_char_p, []),
     'ctgan_debug_force_generic': (None, [c_int]),
+    'ctgan_debug_x3_halo_version': (None, [c_int]),
     'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     'ctgan_conv2d_wgrad_multi': (c_int, [POINTER(ConvDesc), c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), _p, _p, _p,
                                          c_size_t, _p]),
     'ctgan_conv2d_wgrad_group_workspace_bytes': (c_size_t, [POINTER(WgradGroup), c_int32]),
     'ctgan_conv2d_wgrad_group': (c_int, [POINTER(WgradGroup), c_int32, _p, c_size_t, _p]),
     'ctgan_conv2d_wgrad_group_ex': (c_int, [POINTER(WgradGroup), c_int32, _p, c_size_t, c_int, _p]),
+    'ctgan_conv2d_wgrad_group_tile': (c_int, [POINTER(WgradGroup)]),
     'ctgan_conv2d_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d_fwd': (c_int, [_D, _p, _p, _p, _p, _p, c_int, _p]),
     'ctgan_conv2d_fwd_ex': (c_int, [_D, _p, _p, _p, _p, _p, c_int, POINTER(EpilogueExt), _p]),
@@ -95,6 +97,7 @@ SIGNATURES = {
     'ctgan_conv2d16_fwd': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
     'ctgan_conv2d16_fwd_ex': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_int, POINTER(EpilogueExt), _p, c_size_t, _p]),
     'ctgan_conv2d16_dgrad': (c_int, [_D, c_int, _p, _p, _p, _p, _p, _p, c_int, _p, c_size_t, _p]),
+    'ctgan_conv2d16_dgrad_ex': (c_int, [_D, c_int, _p, _p, _p, _p, _p, _p, c_int, POINTER(EpilogueExt), _p, c_size_t, _p]),
     'ctgan_conv2d16_wgrad_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d16_wgrad': (c_int, [_D, c_int, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_layernorm_supported': (c_int, [c_int64, c_int32]),

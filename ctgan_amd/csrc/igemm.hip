@@ -1989,6 +1989,15 @@ extern "C" size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_gro
     return tot;
 }
 
+extern "C" int ctgan_conv2d_wgrad_group_tile(const ctgan_wgrad_group* G) {
+    // which of the (up to four) launches of a grouped call problem G rides in: index into the launch order {128x128, 64x128, 64x64, 32x128}
+    if (!G || G->nseg < 1 || G->nseg > CTGAN_WGRAD_MAX_SEGS) return -1;
+    const MultiPlan m = multi_plan(&G->d, G->nseg, G->Ns);
+    static const WTile order[4] = {W128x128, W64x128, W64x64, W32x128};
+    for (int t = 0; t < 4; ++t) if (m.w.tile == order[t]) return t;
+    return -1;
+}
+
 extern "C" int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     return ctgan_conv2d_wgrad_group_ex(groups, n, ws, ws_bytes, CTGAN_WGRAD_GROUP_GEMM | CTGAN_WGRAD_GROUP_REDUCE, stream);
 }
@@ -2014,6 +2023,7 @@ extern "C" int ctgan_conv2d_wgrad_group_ex(const ctgan_wgrad_group* groups, int3
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const WTile order[4] = {W128x128, W64x128, W64x64, W32x128};
     for (int t = 0; t < 4 && (phases & CTGAN_WGRAD_GROUP_GEMM); ++t) {
+        if ((phases & CTGAN_WGRAD_GROUP_TILE_MASK) && !(phases & (CTGAN_WGRAD_GROUP_TILE0 << t))) continue;      // one tile configuration only
         int idx[CTGAN_WGRAD_GROUP_LIMIT], cnt = 0;
         for (int i = 0; i < n; ++i) if (M[i].w.tile == order[t]) idx[cnt++] = i;
         // longest chunk first: the workgroups that run longest start first

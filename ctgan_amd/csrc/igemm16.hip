@@ -128,8 +128,19 @@ long long phase_off(const PhaseGeom& g, const ctgan_conv_desc* d, int ph) {     
     return o;
 }
 
+// FRAG image of the split mode (stride-1 layers the halo-patch kernel takes; appended behind the three planes): the same 16-bit
+// pieces in MFMA-FRAGMENT order, so that a wave reads the "A" fragment of its 32 output channels with ONE fully coalesced 1 KB load
+// and streams through it linearly - the filter operand never touches LDS (conv16x3hf_kernel):
+//   block (n/32, 32-channel chunk, tap, k step of 16, plane) -> 64 lanes x 16 B, lane = 32*h + n%32 holds k = 8*h .. 8*h+7 of that step
+// u32 index of the pair (k, k+1), k even, of output channel n, reduction index (tap, c = 32*chunk + 16*ks + 8*h + k):
+__device__ __forceinline__ long long frag_u32_index(int n, int tap, int c, int RS, int nch, int q) {
+    const int nt = n >> 5, l31 = n & 31, ch = c >> 5, cc = c & 31, ks = cc >> 4, hh = (cc >> 3) & 1, e2 = (cc & 7) >> 1;
+    const long long blk = ((((long long)nt * nch + ch) * RS + tap) * 2 + ks) * 3 + q;
+    return blk * 256 + (hh * 32 + l31) * 4 + e2;
+}
+
 template <int MMA>
-__global__ void pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int RS, int C, int K, long long plane) {
+__global__ void pack_fwd_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int RS, int C, int K, long long plane, int frag) {
     // one thread per (n, tap, pair of c): reads are strided by K (the transpose), writes are 4-byte and coalesced
     const long long per = (long long)RS * C / 2, total = per * K;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -140,9 +151,16 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, unsigned short* __r
         split_pk<MMA>(a, b, o);
 #pragma unroll
         for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane)[i] = o[q];
+        if constexpr (planes<MMA>() == 3) {
+            if (frag) {
+                const int tap = (int)(e / C), c = (int)(e - (long long)tap * C);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(wp + 3 * plane)[frag_u32_index(n, tap, c, RS, C >> 5, q)] = o[q];
+            }
+        }
     }
 }
-struct PackPhases { int T[2], U[2], r0[2], s0[2]; int nph, step, R, S, C, K; long long off[4]; };
+struct PackPhases { int T[2], U[2], r0[2], s0[2]; int nph, step, R, S, C, K; long long off[4]; int frag; int pad; };
 template <int MMA>
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const PackPhases pp, long long plane) {
     const int ph = blockIdx.y, a = ph >> 1, b = ph & 1;
@@ -158,6 +176,12 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* _
         split_pk<MMA>(src[0], src[1], o);
 #pragma unroll
         for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane + pp.off[ph])[i] = o[q];
+        if constexpr (planes<MMA>() == 3) {
+            if (pp.frag) {                                   // (stride 1: one phase; the reduction channel is k, the output channel n = c)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(wp + 3 * plane)[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
+            }
+        }
     }
 }
 
@@ -180,6 +204,13 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
             split_pk<MMA>(jb.w[e * pp.K + n], jb.w[(e + 1) * pp.K + n], o);
 #pragma unroll
             for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane)[i] = o[q];
+            if constexpr (planes<MMA>() == 3) {
+                if (pp.frag) {
+                    const int tap = (int)(e / pp.C), c = (int)(e - (long long)tap * pp.C);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane)[frag_u32_index(n, tap, c, pp.R * pp.S, pp.C >> 5, q)] = o[q];
+                }
+            }
         }
         return;
     }
@@ -197,6 +228,12 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
             split_pk<MMA>(src[0], src[1], o);
 #pragma unroll
             for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane + pp.off[ph])[i] = o[q];
+            if constexpr (planes<MMA>() == 3) {
+                if (pp.frag) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane)[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
+                }
+            }
         }
     }
 }
@@ -223,6 +260,8 @@ struct P16 {
     int drop_nr; int drop_mend[CTGAN_DROP_RANGES]; float drop_rkeep[CTGAN_DROP_RANGES]; unsigned drop_rsid[CTGAN_DROP_RANGES];
     long long drop_roff[CTGAN_DROP_RANGES];
     unsigned x_bytes, w_bytes;      // w_bytes covers every plane
+    const unsigned short* Wf;       // FRAG image of the filter (fragment order, see frag_u32_index) or null; wf_bytes its size
+    unsigned wf_bytes;
     unsigned w_plane_bytes;         // split mode: byte distance between the filter's planes
     int nph, ph_tiles_m;
     int ph_T[2], ph_U[2], ph_pad_t[2], ph_pad_l[2];
@@ -736,6 +775,201 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
     }
 }
 
+// ---------------------------------------------------------------------------------------------- halo patch, filter from L2
+// conv16x3hf: the halo-patch kernel with the FILTER operand streamed straight from L2 into registers in MFMA-fragment order (FRAG image,
+// frag_u32_index) instead of through an LDS stage.  What changes against conv16x3h_kernel:
+//   * waves split the 128 output channels FOUR ways (a wave: 32 kout x 128 pixels, 1 x 4 accumulators), so every filter fragment is
+//     loaded by exactly one wave (no duplicate L2 traffic): 6 coalesced 1 KB loads per tap per wave, one tap ahead of its MFMAs
+//     (two register sets);
+//   * no filter stage in LDS: no ds_write of filters (a quarter of the LDS port traffic of the old kernel), and the two barriers per
+//     TAP (48 MFMAs) become two per 32-channel CHUNK (R*S*48 MFMAs) - between them the four waves run free;
+//   * LDS holds the patch only (49 KB): fragment reads stay at 0.5 ds_read_b128 per MFMA (pixel fragments are not shared between
+//     accumulators of a 1 x 4 tile; filter fragments are, in registers).
+// Same arithmetic in the same order per accumulator element (chunk-major, tap, k step, the six products small-first): bit-identical
+// results to conv16x3h_kernel (tests/test_gpu_kernels16.py).
+// TN = 32-pixel sub-tiles per workgroup tile (4: 128 pixels; 2 / 1: the 64- / 32-pixel tiles of launches whose 128-pixel tiles
+// could not fill the chip - the 16x16 / 8x8 layers at 64-192 rows; the filter stream per workgroup is the same, so they trade L2
+// bytes per MFMA for workgroups).
+template <bool RELU_IN, int TN>
+__global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const PatchGeom pg) {
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, MAXIT = 8, BMP = TN * 32;
+    constexpr int LDS_K = BK + 8;
+    constexpr int LDE = 32 + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int PPLANE = pg.NPX * LDS_K;
+    unsigned short* const Xs = smem;                      // patch: 3 planes x NPX pixel rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
+    const int tiles_n = p.Ng / 128;
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // neighbouring pixel tiles (shared halo rows) on one XCD
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BMP, n0 = tile_n * 128;
+    const int nch = p.C / BK;
+    const int PQ = p.P * p.Q;
+    const int img = m0 / PQ, row0 = (m0 - img * PQ) / p.Q;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
+    // ---- filter fragment stream of this wave: output channels n0 + 32*wave .. +31; 6 KB per (chunk, tap) step, steps contiguous
+    const unsigned a_voff = (unsigned)lane * 16u;
+    unsigned a_soff = (unsigned)((long long)((n0 >> 5) + wave) * nch * RS * 6144);
+    u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
+    auto loadA = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                fa[SET][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, a_soff + (unsigned)((ks * NP + q) * 1024), 0));
+        a_soff += 6144u;
+    };
+    // ---- patch loader (as conv16x3h_kernel)
+    float4 rp[MAXIT];
+    unsigned p_voff[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int item = it * NT + tid, px = item >> 3;
+        p_voff[it] = 0xFFFFFFFFu;
+        if (it < pg.n_it && px < pg.NPX) {
+            const int pi = px / pg.PIMG, pr = px - pi * pg.PIMG;
+            const int prow = pr / pg.PW, pcol = pr - prow * pg.PW;
+            const int ih = row0 + prow - p.ph_pad_t[0], iw = pcol - p.ph_pad_l[0];
+            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                p_voff[it] = (unsigned)(((long long)(img + pi) * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + (item & 7) * 4) * 4);
+        }
+    }
+    auto load_patch = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+            if (it < pg.n_it)
+                rp[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, p_voff[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : p_voff[it] + chunk * (BK * 4), 0, 0));
+    };
+    auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int item = it * NT + tid, px = item >> 3;
+            if (it < pg.n_it && px < pg.NPX) {
+                float4 v = rp[it];
+                if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                unsigned o0[NP], o1[NP];
+                split_pk<MMA>(v.x, v.y, o0);
+                split_pk<MMA>(v.z, v.w, o1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const u32x2 o = {o0[q], o1[q]};
+                    *reinterpret_cast<u32x2*>(&Xs[q * PPLANE + px * LDS_K + (item & 7) * 4]) = o;
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int h = lane >> 5, l31 = lane & 31;
+    int pix[TN];                                           // patch index (tap (0,0)) of this lane's pixel in fragment j: tile pixel 32*j + l31
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int tp = j * 32 + l31, per = pg.TR * p.Q, ti = tp / per, tr = tp - ti * per;
+        pix[j] = (ti * pg.PIMG + (tr / p.Q) * pg.PW + (tr % p.Q)) * LDS_K + h * 8;
+    }
+    constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
+
+    const int T = nch * RS;
+    int c = 0, tp = 0, tap_off = 0, s_cnt = 0;
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    load_patch(0);
+    loadA(set0{});
+    auto step = [&](auto curc, auto nxtc, bool has_next) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(curc)::value;
+        if (tp == 0) {                                     // chunk prologue (uniform): every wave is past the previous chunk's reads
+            store_patch();
+            if (c + 1 < nch) load_patch(c + 1);            // in flight during this chunk's taps
+            __syncthreads();
+            tap_off = 0; s_cnt = 0;
+        }
+        if (has_next) loadA(nxtc);                         // the next step's filter fragments, one step ahead
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fx[NP][TN];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fx[q][j] = *reinterpret_cast<const u32x4*>(&Xs[q * PPLANE + pix[j] + tap_off * LDS_K + ks * 16]);
+#pragma unroll
+            for (int cl = 0; cl < 6; ++cl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[j] = Cvt<MMA>::mma(fa[CUR][ks][QW[cl]], fx[QX[cl]][j], acc[j]);
+        }
+        if (++s_cnt == S) { s_cnt = 0; tap_off += pg.PW - (S - 1); } else ++tap_off;
+        if (++tp == RS) { tp = 0; ++c; __syncthreads(); }  // the patch may be overwritten
+    };
+    int st = 0;
+    for (; st + 1 < T; st += 2) { step(set0{}, set1{}, true); step(set1{}, set0{}, st + 2 < T); }
+    if (st < T) step(set0{}, set1{}, false);
+
+    // epilogue through LDS: a wave's 32 kout x 32 pixels per pass, transposed so that a lane stores 4 consecutive channels of one pixel
+    float* es = reinterpret_cast<float*>(smem) + wave * (32 * LDE);
+    constexpr int C4 = 8, ROWS_PER = 64 / C4;
+    const unsigned long long drop_step = p.drop ? (p.drop_ctr ? p.drop_ctr[0] : 0) : 0;
+    float dkeep = p.drop_keep;
+    unsigned dsid = p.drop_sid, doff4 = 0;
+    if (p.drop_nr) {
+        const bool r1 = p.drop_nr > 1 && m0 >= p.drop_mend[0], r2 = p.drop_nr > 2 && m0 >= p.drop_mend[1];
+        dkeep = r2 ? p.drop_rkeep[2] : (r1 ? p.drop_rkeep[1] : p.drop_rkeep[0]);
+        dsid = r2 ? p.drop_rsid[2] : (r1 ? p.drop_rsid[1] : p.drop_rsid[0]);
+        doff4 = (unsigned)((r2 ? p.drop_roff[2] : (r1 ? p.drop_roff[1] : p.drop_roff[0])) >> 2);
+    }
+    const bool do_drop = p.drop && dkeep < 1.f;
+#pragma unroll
+    for (int jh = 0; jh < TN; ++jh) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = {acc[jh][4 * q], acc[jh][4 * q + 1], acc[jh][4 * q + 2], acc[jh][4 * q + 3]};
+            *reinterpret_cast<float4*>(&es[l31 * LDE + 8 * q + 4 * h]) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / ROWS_PER; ++it) {
+            const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
+            const int m = m0 + jh * 32 + row, col = n0 + wave * 32 + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+            const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+            const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.mask) {
+                const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+                v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+            }
+            if (p.resid) {
+                const long long ro = p.resid_up ? ((((long long)n * (p.P >> 1) + (pp >> 1)) * (p.Q >> 1) + (qq >> 1)) * p.Ng + col) : off;
+                const float4 r = *reinterpret_cast<const float4*>(p.resid + ro);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (do_drop) {
+                uint32_t cc[4];
+                ctgan_philox::draw4(p.drop_seed, dsid, drop_step, (uint32_t)(off >> 2) - doff4, cc);
+                const float inv = 1.f / dkeep;
+                v.x *= inv * floorf(dkeep + ctgan_philox::u01(cc[0])); v.y *= inv * floorf(dkeep + ctgan_philox::u01(cc[1]));
+                v.z *= inv * floorf(dkeep + ctgan_philox::u01(cc[2])); v.w *= inv * floorf(dkeep + ctgan_philox::u01(cc[3]));
+            }
+            *reinterpret_cast<float4*>(p.D + off) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- WGRAD kernel
 struct W16 {
     const float* X; const float* DY;
@@ -1021,6 +1255,14 @@ __global__ void reduce16_kernel(const float* __restrict__ part, float* __restric
 
 // ---------------------------------------------------------------------------------------------- host side
 bool mma_ok(int mma) { return mma == CTGAN_MMA_BF16 || mma == CTGAN_MMA_F16 || mma == CTGAN_MMA_F32X3; }
+// Does the split-mode packed image of (d, op) carry the FRAG copy (frag_u32_index) behind its planes?  A function of the filter's
+// shape only (never of N, H, W: the image is cached per filter and operator): stride 1, several taps, 32-channel chunks on the
+// reduction side, 128-channel tiles on the output side - the shapes conv16x3hf_kernel takes.
+bool frag_image_shape(const ctgan_conv_desc* d, int op) {
+    if (d->stride != 1 || d->R * d->S < 2) return false;
+    const int nout = op == CTGAN_CONV_FWD ? d->K : d->C, cred = op == CTGAN_CONV_FWD ? d->C : d->K;
+    return (op == CTGAN_CONV_FWD || op == CTGAN_CONV_DGRAD) && nout % 128 == 0 && cred % 32 == 0;
+}
 int mma_planes(int mma) { return mma == CTGAN_MMA_F32X3 ? 3 : 1; }
 int dbg16() { static const int v = [] { const char* e = getenv("CTGAN_DBG16"); return e ? atoi(e) : 0; }(); return v; }
 
@@ -1112,22 +1354,72 @@ size_t conv16x3h_lds(const PatchGeom& g) {
     const size_t stages = (size_t)3 * (128 + g.NPX) * 40 * 2, epi = (size_t)4 * 32 * 68 * 4;
     return stages > epi ? stages : epi;
 }
-bool conv16x3h_ok(const P16& p, PatchGeom* out) {
-    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 32 || p.Q <= 0 || p.M % 128) return false;
+bool conv16x3h_ok(const P16& p, PatchGeom* out, int bmp = 128) {
+    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 32 || p.Q <= 0 || p.M % bmp) return false;
     const int PQ = p.P * p.Q;
-    if (!(PQ % 128 == 0 && 128 % p.Q == 0) && !(PQ < 128 && 128 % PQ == 0)) return false;      // whole rows of one image, or whole images
+    if (!(PQ % bmp == 0 && bmp % p.Q == 0) && !(PQ < bmp && bmp % PQ == 0)) return false;      // whole rows of one image, or whole images
     const int R = p.ph_T[0], S = p.ph_U[0];
     if (R * S < 2) return false;
     PatchGeom g;
-    g.IMGS = PQ < 128 ? 128 / PQ : 1;
-    g.TR = PQ < 128 ? p.P : 128 / p.Q;
+    g.IMGS = PQ < bmp ? bmp / PQ : 1;
+    g.TR = PQ < bmp ? p.P : bmp / p.Q;
     g.PW = p.Q + S - 1; g.PIMG = (g.TR + R - 1) * g.PW; g.NPX = g.IMGS * g.PIMG;
     g.n_it = (g.NPX * 8 + 255) / 256;
     if (g.n_it > 8 || conv16x3h_lds(g) > 80 * 1024) return false;      // two workgroups per CU
     if (out) *out = g;
     return true;
 }
+// Pixels per workgroup tile of the fragment-streaming halo kernel for this launch: the largest of 128 / 64 / 32 whose tiles fill the
+// chip (>= 192 workgroups; the smallest that qualifies otherwise).  0: no tile shape qualifies.
+int conv16x3hf_tile(const P16& p) {
+    static const int force = [] { const char* e = getenv("CTGAN_X3_HF_TILE"); return e ? atoi(e) : 0; }();
+    if (force && conv16x3h_ok(p, nullptr, force)) return force;
+    int last = 0;
+    for (int bmp = 128; bmp >= 32; bmp >>= 1) {
+        if (!conv16x3h_ok(p, nullptr, bmp)) continue;
+        last = bmp;
+        if ((long long)(p.M / bmp) * (p.Ng / 128) >= 192) return bmp;
+    }
+    return last;
+}
+// CTGAN_X3_HALO_V=1: the filter through an LDS stage (conv16x3h_kernel, 128-pixel tiles only); default 2: filter fragments streamed
+// from L2 (conv16x3hf_kernel, 128- / 64- / 32-pixel tiles)
+int g_halo_version_override = 0;      // tests: ctgan_debug_x3_halo_version
+int halo_version() {
+    static const int v = [] { const char* e = getenv("CTGAN_X3_HALO_V"); return e ? atoi(e) : 2; }();
+    return g_halo_version_override ? g_halo_version_override : v;
+}
+bool conv16x3hf_usable(const P16& p) { return halo_version() != 1 && p.Wf != nullptr && conv16x3hf_tile(p) > 0; }
+
+template <bool RELU_IN, int TN>
+int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
+    const size_t epi = (size_t)4 * 32 * 36 * 4, stage = (size_t)3 * pg.NPX * 40 * 2;
+    const size_t lds = stage > epi ? stage : epi;
+    static size_t have = 0;
+    if (have < lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv16x3hf_kernel<RELU_IN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3hf: cannot reserve %zu B of LDS", lds);
+        have = lds;
+    }
+    P16 q = p;
+    q.ph_tiles_m = p.M / (TN * 32);
+    q.dbg = dbg16();
+    q.ksplit = 1; q.slab = nullptr;
+    hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
+    ctgan_set_last_kernel(TN == 4 ? "conv16x3hf<128x128,k32>" : (TN == 2 ? "conv16x3hf<64x128,k32>" : "conv16x3hf<32x128,k32>"));
+    ctgan_set_last_symbol("conv16x3hf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
+    return ctgan_check_launch("conv16x3hf");
+}
+
 int launch_conv16x3h(const P16& p, hipStream_t st) {
+    if (conv16x3hf_usable(p)) {
+        const int bmp = conv16x3hf_tile(p);
+        PatchGeom pg;
+        conv16x3h_ok(p, &pg, bmp);
+        if (bmp == 128) return p.relu_in ? launch_conv16x3hf_t<true, 4>(p, pg, st) : launch_conv16x3hf_t<false, 4>(p, pg, st);
+        if (bmp == 64) return p.relu_in ? launch_conv16x3hf_t<true, 2>(p, pg, st) : launch_conv16x3hf_t<false, 2>(p, pg, st);
+        return p.relu_in ? launch_conv16x3hf_t<true, 1>(p, pg, st) : launch_conv16x3hf_t<false, 1>(p, pg, st);
+    }
     PatchGeom pg;
     if (!conv16x3h_ok(p, &pg)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv16x3h: shape outside the halo-patch form");
     const size_t lds = conv16x3h_lds(pg);
@@ -1148,6 +1440,8 @@ int launch_conv16x3h(const P16& p, hipStream_t st) {
     ctgan_set_last_symbol("conv16x3h_kernel<%s>", p.relu_in ? "true" : "false");
     return ctgan_check_launch("conv16x3h<128x128,k32>");
 }
+// can launch_conv16x3h take this launch (either kernel)?
+bool halo_takes(const P16& p) { return conv16x3hf_usable(p) || conv16x3h_ok(p, nullptr); }
 
 template <int MMA>
 int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st);
@@ -1177,7 +1471,10 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
         // split mode: stride-1 whole-row tiles go to the halo-patch kernel; everything else to the slice kernels with three planes per
         // operand in LDS - 32-deep slices, the 128x128 tile with ONE 60 KB stage (two workgroups per CU)
         static const int halo = [] { const char* e = getenv("CTGAN_X3_HALO"); return e ? atoi(e) : 1; }();      // 2: also for launches of few tiles (tests)
-        if (halo && (!small || halo == 2) && conv16x3h_ok(p, nullptr)) return launch_conv16x3h(p, st);
+        if (halo && halo_takes(p)) {
+            const int bmp = conv16x3hf_usable(p) ? conv16x3hf_tile(p) : 128;
+            if (!small || halo == 2 || (bmp < 128 && (long long)(p.M / bmp) * (p.Ng / 128) >= 96)) return launch_conv16x3h(p, st);
+        }
         if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16x3<64x64,k32,ksplit>" : "conv16x3<64x64,k32>");
         return launch_conv16<MMA, 2, 2, 32>(p, st, "conv16x3<128x128,k32>");
     } else
@@ -1284,6 +1581,8 @@ static bool extents_ok(const ctgan_conv_desc* d, int op, int mma) {
 
 extern "C" {
 
+void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = version; }
+
 int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     if (!d || !mma_ok(mma)) return 0;
     if (op != CTGAN_CONV_FWD && op != CTGAN_CONV_DGRAD && op != CTGAN_CONV_WGRAD) return 0;
@@ -1324,13 +1623,23 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
     p.ph_T[0] = d->R; p.ph_U[0] = d->S;
     if (op == CTGAN_CONV_FWD) { p.Ng = d->K; p.C = d->C; p.P = d->P; p.Q = d->Q; p.M = d->N * d->P * d->Q; }
     else { p.Ng = d->C; p.C = d->K; p.P = d->H; p.Q = d->W; p.M = d->N * d->H * d->W; }
+    if (halo_version() != 1 && frag_image_shape(d, op)) {
+        // the fragment-streaming halo kernel has 64- and 32-pixel tiles: the 16x16 / 8x8 layers at 64-192 rows qualify too
+        P16 q = p;
+        q.Wf = reinterpret_cast<const unsigned short*>(d);      // (any non-null value: only the shape matters here)
+        const int bmp = conv16x3hf_tile(q);
+        return (bmp > 0 && (long long)(p.M / bmp) * (p.Ng / 128) >= (bmp == 128 ? 192 : 96)) ? 1 : 0;
+    }
     if (!conv16x3h_ok(p, nullptr)) return 0;
     return (long long)(p.M / 128) * (p.Ng / 128) >= 192 ? 1 : 0;
 }
 
+static bool frag_image(const ctgan_conv_desc* d, int op, int mma) { return mma == CTGAN_MMA_F32X3 && frag_image_shape(d, op); }
+
 size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op, int mma) {
     if (!d || !mma_ok(mma)) return 0;
-    return (size_t)mma_planes(mma) * d->R * d->S * d->C * d->K;          // both layouts hold every tap exactly once (no zero-padded phases)
+    // both layouts hold every tap exactly once (no zero-padded phases); the FRAG copy doubles the split-mode image of the shapes that have one
+    return (size_t)mma_planes(mma) * d->R * d->S * d->C * d->K * (frag_image(d, op, mma) ? 2 : 1);
 }
 
 int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream) {
@@ -1341,9 +1650,10 @@ int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const 
     if (op == CTGAN_CONV_FWD) {
         if (d->C % 2) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_filter: odd channel count");
         const long long total = (long long)d->R * d->S * d->C / 2 * d->K;
-        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane);
-        else if (mma == CTGAN_MMA_F16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane);
-        else hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F32X3>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane);
+        const int frag = frag_image(d, op, mma) ? 1 : 0;
+        if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane, 0);
+        else if (mma == CTGAN_MMA_F16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane, 0);
+        else hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F32X3>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane, frag);
         return ctgan_check_launch("pack16_fwd");
     }
     if (op == CTGAN_CONV_DGRAD) {
@@ -1352,6 +1662,7 @@ int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const 
         PackPhases pp{};
         for (int a = 0; a < 2; ++a) { pp.T[a] = g.T[a]; pp.U[a] = g.U[a]; pp.r0[a] = g.r0[a]; pp.s0[a] = g.s0[a]; }
         pp.nph = g.nph; pp.step = g.step; pp.R = d->R; pp.S = d->S; pp.C = d->C; pp.K = d->K;
+        pp.frag = frag_image(d, op, mma) ? 1 : 0;
         long long most = 0;
         for (int ph = 0; ph < g.nph; ++ph) {
             pp.off[ph] = phase_off(g, d, ph);
@@ -1382,6 +1693,7 @@ int ctgan_conv2d16_pack_batch(const ctgan_conv_desc* descs, const int32_t* ops, 
             jb.plane = (long long)d->R * d->S * d->C * d->K;
             PackPhases& pp = jb.pp;
             pp.R = d->R; pp.S = d->S; pp.C = d->C; pp.K = d->K;
+            pp.frag = frag_image(d, jb.op, mma) ? 1 : 0;
             long long work;
             if (jb.op == CTGAN_CONV_FWD) {
                 if (d->C % 2) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_batch: odd channel count");
@@ -1438,6 +1750,7 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
     p.resid_up = (resid && (flags & CTGAN_RESID_UP)) ? 1 : 0;
     p.x_bytes = (unsigned)(x_extent * 4); p.w_plane_bytes = (unsigned)w_plane; p.w_bytes = (unsigned)(w_plane * mma_planes(mma));
+    if (frag_image(d, CTGAN_CONV_FWD, mma)) { p.Wf = p.Wp + 3 * (w_plane / 2); p.wf_bytes = (unsigned)(3 * w_plane); }
     p.nph = 1;
     p.slab = (float*)ws; p.slab_bytes = ws ? ws_bytes : 0;
     p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
@@ -1447,7 +1760,7 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
     const bool want_drop = ext && (ranged || (ext->drop_keep > 0.f && ext->drop_keep < 1.f));
     if (want_drop) {                                         // only the halo-patch kernel has the dropout epilogue
         const bool dense = d->ys[1] == 1 && d->ys[3] == d->K && d->ys[2] == (int64_t)d->Q * d->K && d->ys[0] == (int64_t)d->P * d->Q * d->K;
-        if (mma != CTGAN_MMA_F32X3 || !conv16x3h_ok(p, nullptr) || (ranged && (!dense || ext->n_ranges > CTGAN_DROP_RANGES)))
+        if (mma != CTGAN_MMA_F32X3 || !halo_takes(p) || (ranged && (!dense || ext->n_ranges > CTGAN_DROP_RANGES)))
             return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: epilogue dropout outside the halo-patch form");
         p.drop = 1; p.drop_keep = 1.f; p.drop_seed = ext->drop_seed; p.drop_sid = 0;
         p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
@@ -1470,7 +1783,7 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
         return launch_conv16x3h(p, st);
     }
     if (p.resid_up) {                                        // only the halo-patch kernel reads the residual through the upsample
-        if (mma != CTGAN_MMA_F32X3 || ((d->P | d->Q) & 1) || !conv16x3h_ok(p, nullptr))
+        if (mma != CTGAN_MMA_F32X3 || ((d->P | d->Q) & 1) || !halo_takes(p))
             return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: CTGAN_RESID_UP outside the halo-patch form");
         return launch_conv16x3h(p, st);
     }
@@ -1488,6 +1801,12 @@ int ctgan_conv2d16_fwd_ex(const ctgan_conv_desc* d, int mma, const float* x, con
 
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias, const float* mask,
                          const float* resid, float* dx, int flags, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
+    return ctgan_conv2d16_dgrad_ex(d, mma, dy, wp, bias, mask, resid, dx, flags, nullptr, ws, ws_bytes, stream);
+}
+
+int ctgan_conv2d16_dgrad_ex(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias, const float* mask,
+                            const float* resid, float* dx, int flags, const ctgan_epilogue_ext* ext, void* ws, size_t ws_bytes,
+                            ctgan_stream_t stream) {
     if (!d || !dy || !wp || !dx || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_dgrad: bad argument");
     if (!shape_ok_dgrad(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad: shape outside the 16-bit family");
     const long long y_extent = (long long)(d->N - 1) * d->ys[0] + (long long)(d->P - 1) * d->ys[2] + (long long)(d->Q - 1) * d->ys[3] + d->K;
@@ -1503,6 +1822,7 @@ int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, con
     p.Ng = d->C;
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0; p.relu_in = 0;
     p.x_bytes = (unsigned)(y_extent * 4); p.w_plane_bytes = (unsigned)w_plane; p.w_bytes = (unsigned)(w_plane * mma_planes(mma));
+    if (frag_image(d, CTGAN_CONV_DGRAD, mma)) { p.Wf = p.Wp + 3 * (w_plane / 2); p.wf_bytes = (unsigned)(3 * w_plane); }
     p.nph = g.nph;
     p.slab = (float*)ws; p.slab_bytes = ws ? ws_bytes : 0;
     for (int a = 0; a < 2; ++a) { p.ph_T[a] = g.T[a]; p.ph_U[a] = g.U[a]; p.ph_pad_t[a] = g.pad_t[a]; p.ph_pad_l[a] = g.pad_l[a]; }
@@ -1518,6 +1838,19 @@ int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, con
     }
     p.M = d->N * p.P * p.Q;
     hipStream_t st = (hipStream_t)stream;
+    if (ext && ext->n_ranges > 0) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad_ex: sample ranges are a forward-only epilogue");
+    if (ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f) {
+        // the data gradient multiplied by a dropout mask (the mask of the dropout whose result the forward conv consumed), as
+        // ctgan_conv2d_dgrad_ex: only the halo-patch kernels have the dropout epilogue, on a dense channels-last dx
+        const bool dense = d->xs[1] == 1 && d->xs[3] == d->C && d->xs[2] == (int64_t)d->W * d->C && d->xs[0] == (int64_t)d->H * d->W * d->C;
+        if (mma != CTGAN_MMA_F32X3 || g.nph != 1 || !dense || !halo_takes(p))
+            return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad_ex: epilogue dropout outside the halo-patch form");
+        p.drop = 1; p.drop_keep = ext->drop_keep; p.drop_seed = ext->drop_seed; p.drop_sid = (unsigned)ext->drop_stream_id;
+        p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
+        p.drop_nr = 0;
+        for (int i = 0; i < CTGAN_DROP_RANGES; ++i) { p.drop_mend[i] = 0x7fffffff; p.drop_rkeep[i] = 1.f; p.drop_rsid[i] = 0; p.drop_roff[i] = 0; }
+        return launch_conv16x3h(p, st);
+    }
     return run_conv16(mma, p, st);
 }
 

@@ -430,6 +430,16 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
         resid = match_layout(resid, dx)
     mode = _conv_mode(d, 1, drop is None and not fewch_handles(g))
     _x3_log(g, N, d, 1, drop=drop is not None)
+    if (mode is None and drop is not None and not isinstance(drop, dict) and g.stride == 1 and not fewch_handles(g)
+            and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID)) and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 1)):
+        # the halo-patch kernels carry the fp32 family's epilogue dropout (same Philox draws at the same offsets)
+        wp = _packed16(w, d, 1, g, 'f32x3')
+        try:
+            _timed(g, N, lambda: check(lib.ctgan_conv2d16_dgrad_ex(ctypes.byref(d), 3, _ptr(gy), _ptr(wp), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), 0,
+                                                                     _ext(drop), None, 0, _stream()), 'conv2d16_dgrad_ex'))
+            return dx
+        except NotImplementedError:
+            pass
     if mode is not None:
         wp = _packed16(w, d, 1, g, mode)
         code = _MMA_CODE[mode]
@@ -549,17 +559,21 @@ def conv_wgrad_group(groups):
     if PROFILE is None:
         check(lib.ctgan_conv2d_wgrad_group(arr, n, _ptr(ws), ws.numel(), _stream()), 'conv2d_wgrad_group')
         return
-    # bench.py's roofline leg: the grouped GEMM launch alone inside the event bracket (what rocprofv3 lists under this symbol), the
-    # batched split-K reduction after it
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
+    # bench.py's roofline leg: each grouped GEMM launch (one per tile configuration) alone inside its own event bracket (what rocprofv3
+    # lists under that symbol), the batched split-K reduction after them
     st = torch.cuda.current_stream()
-    e0.record(st)
-    for _ in range(PROFILE_REPS):
-        check(lib.ctgan_conv2d_wgrad_group_ex(arr, n, _ptr(ws), ws.numel(), 1, _stream()), 'conv2d_wgrad_group')
-    e1.record(st)
-    flops = sum(_conv_flops(g, sum(sg[0].shape[0] for sg in segs)) for segs, g, _, _ in groups)
-    PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, ('group', n), last_symbol()))
+    for t in range(4):
+        members = [i for i in range(n) if lib.ctgan_conv2d_wgrad_group_tile(ctypes.byref(arr[i])) == t]
+        if not members:
+            continue
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(PROFILE_REPS):
+            check(lib.ctgan_conv2d_wgrad_group_ex(arr, n, _ptr(ws), ws.numel(), 1 | (16 << t), _stream()), 'conv2d_wgrad_group')
+        e1.record(st)
+        flops = sum(_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in members)
+        PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, ('group', len(members)), last_symbol()))
     check(lib.ctgan_conv2d_wgrad_group_ex(arr, n, _ptr(ws), ws.numel(), 2, _stream()), 'conv2d_wgrad_group')
 
 
@@ -600,6 +614,11 @@ def last_symbol():
 def debug_force_generic(on):
     """Tests only: route every conv through the table-driven generic kernels."""
     lib.ctgan_debug_force_generic(1 if on else 0)
+
+
+def debug_x3_halo_version(v):
+    """Tests only: 1 = halo-patch kernel with the filter staged through LDS, 2 = filter fragments streamed from L2, 0 = default."""
+    lib.ctgan_debug_x3_halo_version(int(v))
 
 
 def colsum_channels(gy):

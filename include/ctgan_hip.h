@@ -70,6 +70,9 @@ const char* ctgan_last_kernel(void);
 const char* ctgan_last_symbol(void);
 /* tests only: 1 = route every conv through the table-driven generic kernels                   */
 void ctgan_debug_force_generic(int on);
+/* tests only: which halo-patch kernel of the split mode takes the launches that qualify - 1: filter through an LDS stage
+   (conv16x3h_kernel), 2: filter fragments streamed from L2 (conv16x3hf_kernel), 0: back to the default (env CTGAN_X3_HALO_V, else 2) */
+void ctgan_debug_x3_halo_version(int version);
 
 /* Optional epilogue extension of ctgan_conv2d_fwd / ctgan_conv2d_dgrad: tf.nn.dropout (:173-177) applied to the
  * RESULT inside the kernel, y *= floor(keep + u)/keep, where u is what ctgan_rng_uniform(.., seed, stream_id, ctr)
@@ -131,7 +134,11 @@ int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* w
                              ctgan_stream_t stream);
 /* The two phases of the grouped launch separately (bench.py times the GEMM launches alone, as rocprofv3 reports them): the grouped
    weight-gradient kernels write the split-K slabs, the batched reduction sums them into dw / db in a fixed order.             */
-enum { CTGAN_WGRAD_GROUP_GEMM = 1, CTGAN_WGRAD_GROUP_REDUCE = 2 };
+enum { CTGAN_WGRAD_GROUP_GEMM = 1, CTGAN_WGRAD_GROUP_REDUCE = 2,
+       /* optional: restrict the GEMM phase to the launch of one tile configuration (bit CTGAN_WGRAD_GROUP_TILE0 << t, t = 0..3) */
+       CTGAN_WGRAD_GROUP_TILE0 = 16, CTGAN_WGRAD_GROUP_TILE_MASK = 16 | 32 | 64 | 128 };
+/* the launch (0..3) of a grouped call that problem g rides in; -1 if it does not qualify */
+int ctgan_conv2d_wgrad_group_tile(const ctgan_wgrad_group* g);
 int ctgan_conv2d_wgrad_group_ex(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, int phases,
                                 ctgan_stream_t stream);
 /* ---- convolution family  (replaces tf.nn.conv2d TF/tflib/ops/conv2d.py:106-112,
@@ -216,6 +223,12 @@ int ctgan_conv2d16_fwd_ex(const ctgan_conv_desc* d, int mma, const float* x, con
 int ctgan_conv2d16_dgrad(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias,
                          const float* mask, const float* resid, float* dx, int flags, void* ws, size_t ws_bytes,
                          ctgan_stream_t stream);
+/* data gradient with the epilogue dropout of ctgan_conv2d_dgrad_ex (dx multiplied by the mask of ext's dropout, same draws at the same
+ * physical offsets): mma = CTGAN_MMA_F32X3, stride 1, dense channels-last dx, launches the halo-patch kernels take; CTGAN_E_UNSUPPORTED
+ * otherwise - the caller then uses ctgan_conv2d_dgrad_ex.                                                                          */
+int ctgan_conv2d16_dgrad_ex(const ctgan_conv_desc* d, int mma, const float* dy, const void* wp, const float* bias,
+                            const float* mask, const float* resid, float* dx, int flags, const ctgan_epilogue_ext* ext, void* ws,
+                            size_t ws_bytes, ctgan_stream_t stream);
 size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d, int mma);
 int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws,
                          size_t ws_bytes, int flags, ctgan_stream_t stream);

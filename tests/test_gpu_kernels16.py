@@ -122,7 +122,14 @@ X3_CASES = CASES + [
     (96, 32, 16, 16, 128, 5, 1),      # 5x5 taps: 12 x 20 patch = 88 KB with the filter stage - slice kernel
     (384, 32, 8, 8, 128, 3, 1),       # 8x8 images: tile = two whole images, each with its own 10 x 10 halo block
     (96, 64, 32, 32, 128, 4, 2),      # stride 2 (the folded ConvMeanPool filter): single-stage 128x128 slice kernel; data gradient in 4 phases
+    # launches whose 128-pixel tiles cannot fill the chip: the 64- and 32-pixel tiles of the fragment-streaming halo kernel
+    (64, 32, 16, 16, 128, 3, 1),      # 16-wide, 64-pixel tiles = 4 rows (256 tiles)
+    (12, 64, 32, 32, 128, 3, 1),      # 32-wide, 64-pixel tiles = 2 rows (192 tiles)
+    (48, 32, 8, 8, 128, 3, 1),        # 8x8 images, 32-pixel tiles = half an image (96 tiles)
+    (160, 32, 8, 8, 256, 3, 1),       # 8x8 images, 64-pixel tiles = one image; two kout tiles (320 tiles)
 ]
+X3_SMALL_TILE = {(64, 32, 16, 16, 128, 3, 1): '64x128', (12, 64, 32, 32, 128, 3, 1): '64x128', (48, 32, 8, 8, 128, 3, 1): '32x128',
+                 (160, 32, 8, 8, 256, 3, 1): '64x128'}
 
 
 @pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d' % c)
@@ -169,7 +176,9 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
     assert kern3['fwd'].startswith('conv16x3') and kern3['dgrad'].startswith('conv16x3'), kern3
     if case in X3_CASES[len(CASES):]:
         want_kernel = 'conv16x3h' if (st == 1 and k == 3) else 'conv16x3<128x128'      # (5x5: the patch does not fit two workgroups per CU)
-        assert kern3['fwd'].startswith(want_kernel), kern3
+        if case in X3_SMALL_TILE:
+            want_kernel = 'conv16x3hf<' + X3_SMALL_TILE[case]
+        assert kern3['fwd'].startswith(want_kernel) and kern3['dgrad'].startswith(want_kernel), kern3
     pq = geom.P * geom.Q
     if C % 128 == 0 and Ko % 128 == 0 and geom.Q % 4 == 0 and not (pq & (pq - 1)) and not (geom.Q & (geom.Q - 1)):
         assert kern3['wgrad'].startswith('wgrad16x3') or kern3['wgrad'].startswith('reduce16'), kern3
@@ -178,6 +187,37 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
         assert e3 <= max(2.0 * e1, 3e-7), (what, e3, e1)
         m3, m1 = relerr(got3[what], want[what]), relerr(got1[what], want[what])
         assert m3 <= max(3.0 * m1, 1e-6), (what, m3, m1)
+
+
+@pytest.mark.parametrize('case', [(24, 32, 32, 32, 128, 3, 1), (96, 64, 16, 16, 256, 3, 1), (384, 32, 8, 8, 128, 3, 1)],
+                         ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d' % c)
+def test_f32x3_halo_kernel_with_filter_fragments_from_l2_equals_the_lds_staged_one_bitwise(K, case):
+    """conv16x3hf (filter fragments streamed from L2 in MFMA-fragment order, waves split over kout) performs the same MFMAs in the same
+    order per accumulator element as conv16x3h (filter staged through LDS): forward with every epilogue and the data gradient must be
+    BIT-identical on 128-pixel tiles - any error in the fragment-order packed image or the wave -> channel map shows as a mismatch."""
+    N, C, H, W, Ko, k, st = case
+    g = torch.Generator().manual_seed(5)
+    geom = K.ConvGeom(C, H, W, Ko, k, k, st, False)
+    x, w, b = cl(torch.randn(N, C, H, W, generator=g)), (torch.randn(k, k, C, Ko, generator=g) / 17).cuda(), torch.randn(Ko, generator=g).cuda()
+    r, gy = cl(torch.randn(N, Ko, H, W, generator=g)), cl(torch.randn(N, Ko, H, W, generator=g))
+    m, rr, bc = cl(torch.randn(N, C, H, W, generator=g)), cl(torch.randn(N, C, H, W, generator=g)), torch.randn(C, generator=g).cuda()
+
+    def run(v):
+        K.debug_x3_halo_version(v)
+        try:
+            with K.mma_dtype('f32x3'):
+                a = K.conv_fwd(x, w, b, geom, resid=r, relu=True, relu_in=True)
+                name = K.last_kernel()
+                c = K.conv_fwd(x, w, None, geom)
+                d = K.conv_dgrad(gy, w, geom, N, bias=bc, mask=m, resid=rr)
+                return a, c, d, name, K.last_kernel()
+        finally:
+            K.debug_x3_halo_version(0)
+    a1, c1, d1, n1, nd1 = run(1)
+    a2, c2, d2, n2, nd2 = run(2)
+    assert n1.startswith('conv16x3h<128x128') and nd1.startswith('conv16x3h<128x128'), (n1, nd1)
+    assert n2.startswith('conv16x3hf<128x128') and nd2.startswith('conv16x3hf<128x128'), (n2, nd2)
+    assert torch.equal(a1, a2) and torch.equal(c1, c2) and torch.equal(d1, d2)
 
 
 def test_f32x3_halo_kernel_adds_the_upsampled_residual(K):

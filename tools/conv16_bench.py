@@ -12,7 +12,8 @@ SHAPES = [(192, 1024, 8, 8, 1024, 3, 1), (192, 128, 64, 64, 128, 3, 1), (192, 25
           (64, 256, 8, 8, 512, 5, 2), (192, 128, 16, 16, 256, 5, 2), (64, 1024, 8, 8, 1024, 3, 1)]
 # the headline's layers (CIFAR ResNet critic over 3B = 192 rows / GP pass over 64, DIM 128; 4x4 stride 2 = the folded ConvMeanPool)
 RESNET = [(192, 128, 32, 32, 128, 3, 1), (192, 128, 32, 32, 128, 4, 2), (192, 128, 16, 16, 128, 3, 1), (192, 128, 16, 16, 128, 4, 2),
-          (192, 128, 8, 8, 128, 3, 1), (64, 128, 32, 32, 128, 3, 1), (64, 128, 16, 16, 128, 3, 1), (64, 128, 8, 8, 128, 3, 1)]
+          (192, 128, 8, 8, 128, 3, 1), (64, 128, 32, 32, 128, 3, 1), (64, 128, 16, 16, 128, 3, 1), (64, 128, 8, 8, 128, 3, 1),
+          (384, 128, 8, 8, 128, 3, 1), (128, 128, 8, 8, 128, 3, 1), (128, 128, 16, 16, 128, 3, 1), (320, 128, 32, 32, 128, 3, 1)]
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 if len(sys.argv) > 2 and sys.argv[2] == 'resnet':
     SHAPES = RESNET
