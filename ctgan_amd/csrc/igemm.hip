@@ -112,6 +112,7 @@ struct WgradParams {
     // [split0[s], split0[s+1]) works on segment s only.
     int nseg;
     struct Seg { const float* X; const float* DY; int Kg, split0, relu_x, bias; unsigned x_bytes, dy_bytes; } seg[CTGAN_WGRAD_MAX_SEGS];
+    int xcd;                 // pipelined kernels: XCD-aware workgroup order (xcd_remap)
 };
 
 __device__ __forceinline__ bool src_index(int i, int shift, int mask, int lim, int& o) {
@@ -1122,9 +1123,19 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgradParams& p, const int 
 }
 
 
+// XCD-aware block order (speed only; placement is never assumed for correctness): the hardware deals consecutive workgroup ids round
+// robin over the 8 XCDs, whose L2s are private.  The tiles of ONE pixel chunk (all taps / channel blocks of a split) read the same x
+// and dy rows; dealt round robin they pull those rows into all eight L2s (measured on the split-mode twin of this kernel: L2 hit rate
+// 0.18-0.49, 3.5-8.5x the algorithmic HBM bytes, profiles/r03_pmc_traffic_x3.json).  Remapped, XCD c works on the logical blocks
+// [c*n/8, (c+1)*n/8) - tile-fastest, so a chunk's tiles are neighbours on one XCD and run at the same time.
+__device__ __forceinline__ int xcd_remap(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
+bool wgrad_xcd_remap_on() { static const bool on = [] { const char* e = getenv("CTGAN_WGRAD_XCD"); return !e || atoi(e) != 0; }(); return on; }
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kernel(const WgradParams p) {
-    wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(p, (int)blockIdx.x, (int)blockIdx.y);
+    const int nx = (int)gridDim.x, n = nx * (int)gridDim.y;
+    const int b = p.xcd ? xcd_remap((int)blockIdx.y * nx + (int)blockIdx.x, n) : (int)blockIdx.y * nx + (int)blockIdx.x;
+    wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(p, b % nx, b / nx);
 }
 
 // Several weight gradients of the SAME tile configuration in one launch (the deferred weight gradients of a step are
@@ -1132,8 +1143,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
 // problem like the single-problem grid.  Problems are ordered longest chunk first.
 struct WgradGroupParams {
     int n;
-    int block0[CTGAN_WGRAD_GROUP_MAX + 1];
+    int block0[CTGAN_WGRAD_GROUP_MAX + 1];   // (with the XCD-aware order: every problem's block range is padded to a multiple of 8)
     int tiles[CTGAN_WGRAD_GROUP_MAX];
+    int real[CTGAN_WGRAD_GROUP_MAX];         // workgroups that have work (tiles * splits) inside the problem's padded range
     WgradParams p[CTGAN_WGRAD_GROUP_MAX];
 };
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -1143,7 +1155,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_group
 #pragma unroll
     for (int t = 1; t < CTGAN_WGRAD_GROUP_MAX; ++t)
         if (t < gp.n && b >= gp.block0[t]) i = t;
-    const int r = b - gp.block0[i];
+    int r = b - gp.block0[i];
+    if (gp.p[i].xcd) r = xcd_remap(r, gp.block0[i + 1] - gp.block0[i]);      // per problem: every XCD gets an eighth of each problem
+    if (r >= gp.real[i]) return;                                              // padding
     const int by = r / gp.tiles[i];
     wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(gp.p[i], r - by * gp.tiles[i], by);
 }
@@ -1475,6 +1489,7 @@ int launch_wgrad_pipe(WgradParams p, const WPlan& w, float* dw, float* db, void*
     }
     p.chunk = w.chunk;
     p.with_bias = db ? 1 : 0;
+    p.xcd = wgrad_xcd_remap_on() ? 1 : 0;
     // with a bias row the slab layout is [Mtot+1][Ng]; a single split still goes through the slab so that
     // dw stays exactly [Mtot][Ng]
     const bool direct = w.splits == 1 && !db;
@@ -1796,7 +1811,7 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
     p.X = x; p.DY = dy; p.OUT = dw;
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
-    p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0; p.nseg = 0;
+    p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0; p.nseg = 0; p.xcd = 0;
     p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = run_wgrad(p, dw, db, ws, ws_bytes, st);
@@ -1872,7 +1887,7 @@ int prepare_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs
     p.X = xs[0]; p.DY = dys[0]; p.OUT = nullptr;
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
-    p.relu_x = 0; p.x_bytes = p.dy_bytes = 0;
+    p.relu_x = 0; p.x_bytes = p.dy_bytes = 0; p.xcd = 0;
     m = multi_plan(d, nseg, Ns);
     const WPlan& w = m.w;
     bool ok = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) && p.dy_k == 1 && (p.Ng % 4 == 0) &&
@@ -2037,9 +2052,11 @@ extern "C" int ctgan_conv2d_wgrad_group_ex(const ctgan_wgrad_group* groups, int3
                 if (k < gp.n) {
                     const int i = idx[base + k];
                     gp.block0[k] = b0; gp.tiles[k] = M[i].w.tiles; gp.p[k] = PT[i];
-                    b0 += M[i].w.tiles * M[i].splits;
+                    gp.real[k] = M[i].w.tiles * M[i].splits;
+                    gp.p[k].xcd = wgrad_xcd_remap_on() ? 1 : 0;
+                    b0 += gp.p[k].xcd ? ((gp.real[k] + 7) & ~7) : gp.real[k];
                 } else {
-                    gp.block0[k] = b0; gp.tiles[k] = 1; gp.p[k] = PT[idx[base]];
+                    gp.block0[k] = b0; gp.tiles[k] = 1; gp.real[k] = 0; gp.p[k] = PT[idx[base]];
                 }
             }
             gp.block0[CTGAN_WGRAD_GROUP_MAX] = b0;

@@ -982,6 +982,7 @@ struct W16 {
     unsigned x_bytes, dy_bytes;
     int dbg;
     int pq_shift, q_shift;           // log2(P*Q), log2(Q) when both are powers of two, else -1: pixel -> (n,p,q) without integer division
+    int xcd;                         // XCD-aware workgroup order
 };
 
 // one workgroup per CU, staging woven between the MFMAs: the 256x128 tile
@@ -1015,12 +1016,20 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.Ng + BNK - 1) / BNK;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    // XCD-aware block order (speed only): the tiles of one pixel chunk - all taps / channel blocks - read the same x and dy rows; the
+    // hardware deals consecutive workgroup ids round robin over the 8 XCDs (private L2s), so remap: XCD c works on the logical blocks
+    // [c*n/8, (c+1)*n/8), tile-fastest (measured before: L2 hit rate 0.18-0.49, 3.5-8.5x the algorithmic HBM bytes)
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (p.xcd) {
+        const int nx = (int)gridDim.x, nb = nx * (int)gridDim.y;
+        if ((nb & 7) == 0) { const int b = by * nx + bx, l = (b & 7) * (nb >> 3) + (b >> 3); by = l / nx; bx = l - by * nx; }
+    }
+    const int tile_m = bx / tiles_n, tile_n = bx - tile_m * tiles_n;
     const int cblocks = p.C / BMC;                       // M tiles per tap
     const int tap = tile_m / cblocks, c0 = (tile_m - tap * cblocks) * BMC;
     const int r = tap / p.S, s = tap - r * p.S;
     const int n0 = tile_n * BNK;
-    const int k_begin = blockIdx.y * p.chunk;
+    const int k_begin = by * p.chunk;
     const int k_end = min(k_begin + p.chunk, p.Kg);
     const int nk = (k_end - k_begin + BKP - 1) / BKP;
     const int PQ = p.P * p.Q;
@@ -1220,7 +1229,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         }
     }
     // acc[i][j][4g + e] = dW(channel c0 + wm*TM*32 + i*32 + 8g + 4h + e, kout n0 + wn*TN*32 + j*32 + l31): 32 lanes = 128 B rows
-    float* out = p.OUT + (long long)blockIdx.y * p.Mtot * p.Ng;
+    float* out = p.OUT + (long long)by * p.Mtot * p.Ng;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1878,6 +1887,7 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
     p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.chunk = w.chunk; p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0; p.dbg = dbg16();
+    { static const bool on = [] { const char* e = getenv("CTGAN_WGRAD_XCD"); return !e || atoi(e) != 0; }(); p.xcd = on ? 1 : 0; }
     {
         const int pq = d->P * d->Q;
         const bool pow2 = !(pq & (pq - 1)) && !(d->Q & (d->Q - 1));

@@ -37,6 +37,14 @@ for sym, rec in info.items():
     if hit is not None and miss is not None and hit + miss > 0:
         o['l2_hit_rate'] = round(hit / (hit + miss), 4)
     busy, mf, wave = mean('SQ_BUSY_CYCLES'), mean('SQ_VALU_MFMA_BUSY_CYCLES'), mean('SQ_WAVE_CYCLES')
+    # SQ_BUSY_CYCLES is summed over the 32 SQ instances (shader engines), SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (checked in
+    # round 1 against a kernel of known MFMA count: profiles/r01_pmc_sq_fwd_n128_h32.json): busy fraction of the matrix pipes =
+    # MFMA_BUSY / (1024 * BUSY / 32)
+    if busy:
+        busy = 1024.0 * busy / 32.0
+        o['shader_cycles_per_launch'] = round(busy / 1024.0)
+        n_mfma = rec['flops_per_launch'] * 6 / 32768.0            # six bf16 32x32x16 MFMAs (32,768 FLOP, 32 cycles each) per fp32 product
+        o['mfma_busy_check'] = '%.4g MFMAs x 32 cycles = %.4g vs SQ_VALU_MFMA_BUSY_CYCLES %.4g' % (n_mfma, n_mfma * 32, mf or 0)
     for key, num, den in (('mfma_busy_frac', mf, busy), ('valu_active_frac', mean('SQ_ACTIVE_INST_VALU'), wave),
                           ('lds_wait_frac', mean('SQ_WAIT_INST_LDS'), wave), ('wave_parked_frac', mean('SQ_WAIT_ANY'), wave),
                           ('issue_stall_frac', mean('SQ_WAIT_INST_ANY'), wave), ('inst_active_frac', mean('SQ_ACTIVE_INST_ANY'), wave)):
