@@ -799,7 +799,8 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
     const int PPLANE = pg.NPX * LDS_K;
     unsigned short* const Xs = smem;                      // patch: 3 planes x NPX pixel rows
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the filter stream's offset lives in SGPRs (no waterfall loop around its loads)
     const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
     const int tiles_n = p.Ng / 128;
     int bid = blockIdx.x;
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
     const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
     // ---- filter fragment stream of this wave: output channels n0 + 32*wave .. +31; 6 KB per (chunk, tap) step, steps contiguous
     const unsigned a_voff = (unsigned)lane * 16u;
-    unsigned a_soff = (unsigned)((long long)((n0 >> 5) + wave) * nch * RS * 6144);
+    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((long long)((n0 >> 5) + wave) * nch * RS * 6144));
     u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
     auto loadA = [&](auto setc) __attribute__((always_inline)) {
         constexpr int SET = decltype(setc)::value;
@@ -1391,6 +1392,23 @@ int conv16x3hf_tile(const P16& p) {
     }
     return last;
 }
+// Which launches the hybrid (fp32-mode) routing hands to the fragment-streaming kernel, from tools/conv16_bench.py on the headline's
+// layers (profiles/r03_conv_bench_*.txt; TFLOP/s fp32 family / LDS-staged halo or slice kernel / this kernel):
+//   128-pixel tiles, >= 192 of them, images of >= 128 pixels: 112-129 / 171-217 / 174-224       -> this kernel
+//   128-pixel tiles over whole 8x8 images (384 rows):         104 / 144 / 132                   -> the LDS-staged halo kernel
+//   64-pixel tiles on 16x16 images (64 rows):                 103 / 130 / 137                   -> this kernel
+//   64- / 32-pixel tiles on 8x8 images (64-192 rows):         69-94 / 47-105 / 50-105           -> stay on the fp32 family (its fused
+//                                                                                                  epilogues and K-split tiles win or tie)
+bool conv16x3hf_wins(const P16& p) {
+    const int bmp = conv16x3hf_tile(p);
+    if (!bmp) return false;
+    const long long tiles = (long long)(p.M / bmp) * (p.Ng / 128);
+    const int PQ = p.P * p.Q;
+    static const int small8 = [] { const char* e = getenv("CTGAN_X3_HF_8X8"); return e ? atoi(e) : 0; }();      // experiment: also the 8x8 layers
+    if (bmp == 128) return tiles >= 192 && PQ >= 128;
+    if (bmp == 64) return tiles >= 192 && (PQ >= 256 || small8);
+    return small8 && tiles >= 96;
+}
 // CTGAN_X3_HALO_V=1: the filter through an LDS stage (conv16x3h_kernel, 128-pixel tiles only); default 2: filter fragments streamed
 // from L2 (conv16x3hf_kernel, 128- / 64- / 32-pixel tiles)
 int g_halo_version_override = 0;      // tests: ctgan_debug_x3_halo_version
@@ -1421,7 +1439,9 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
 }
 
 int launch_conv16x3h(const P16& p, hipStream_t st) {
-    if (conv16x3hf_usable(p)) {
+    // whole small images per 128-pixel tile (8x8): the LDS-staged kernel is the faster one when it applies
+    const bool prefer_v1 = !g_halo_version_override && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
+    if (conv16x3hf_usable(p) && !prefer_v1) {
         const int bmp = conv16x3hf_tile(p);
         PatchGeom pg;
         conv16x3h_ok(p, &pg, bmp);
@@ -1636,8 +1656,7 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
         // the fragment-streaming halo kernel has 64- and 32-pixel tiles: the 16x16 / 8x8 layers at 64-192 rows qualify too
         P16 q = p;
         q.Wf = reinterpret_cast<const unsigned short*>(d);      // (any non-null value: only the shape matters here)
-        const int bmp = conv16x3hf_tile(q);
-        return (bmp > 0 && (long long)(p.M / bmp) * (p.Ng / 128) >= (bmp == 128 ? 192 : 96)) ? 1 : 0;
+        if (conv16x3hf_wins(q)) return 1;
     }
     if (!conv16x3h_ok(p, nullptr)) return 0;
     return (long long)(p.M / 128) * (p.Ng / 128) >= 192 ? 1 : 0;
