@@ -40,7 +40,8 @@ class FilterJob(ctypes.Structure):
 class WgradGroup(ctypes.Structure):
     """struct ctgan_wgrad_group (include/ctgan_hip.h)."""
     _fields_ = [('d', ConvDesc), ('nseg', c_int32), ('Ns', c_int32 * 3), ('seg_flags', c_int32 * 3),
-                ('xs', ctypes.c_void_p * 3), ('dys', ctypes.c_void_p * 3), ('dw', ctypes.c_void_p), ('db', ctypes.c_void_p)]
+                ('xs', ctypes.c_void_p * 3), ('dys', ctypes.c_void_p * 3), ('dw', ctypes.c_void_p), ('db', ctypes.c_void_p),
+                ('add_dw', ctypes.c_void_p), ('add_db', ctypes.c_void_p)]
 
 
 class RowSegment(ctypes.Structure):
@@ -100,6 +101,7 @@ SIGNATURES = {
     'ctgan_conv2d16_dgrad_ex': (c_int, [_D, c_int, _p, _p, _p, _p, _p, _p, c_int, POINTER(EpilogueExt), _p, c_size_t, _p]),
     'ctgan_conv2d16_wgrad_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d16_wgrad': (c_int, [_D, c_int, _p, _p, _p, _p, c_size_t, c_int, _p]),
+    'ctgan_conv2d16_wgrad_bias': (c_int, [_D, c_int, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_layernorm_supported': (c_int, [c_int64, c_int32]),
     'ctgan_layernorm_workspace_bytes': (c_size_t, [c_int32, c_int64, c_int32]),
     'ctgan_layernorm_fwd': (c_int, [_p, _p, _p, _p, _p, _p, c_int32, c_int64, c_int32, c_float, c_int32, _p, c_size_t, _p]),

@@ -112,7 +112,6 @@ struct WgradParams {
     // [split0[s], split0[s+1]) works on segment s only.
     int nseg;
     struct Seg { const float* X; const float* DY; int Kg, split0, relu_x, bias; unsigned x_bytes, dy_bytes; } seg[CTGAN_WGRAD_MAX_SEGS];
-    int xcd;                 // pipelined kernels: XCD-aware workgroup order (xcd_remap)
 };
 
 __device__ __forceinline__ bool src_index(int i, int shift, int mask, int lim, int& o) {
@@ -1123,19 +1122,9 @@ __device__ __forceinline__ void wgrad_pipe_body(const WgradParams& p, const int 
 }
 
 
-// XCD-aware block order (speed only; placement is never assumed for correctness): the hardware deals consecutive workgroup ids round
-// robin over the 8 XCDs, whose L2s are private.  The tiles of ONE pixel chunk (all taps / channel blocks of a split) read the same x
-// and dy rows; dealt round robin they pull those rows into all eight L2s (measured on the split-mode twin of this kernel: L2 hit rate
-// 0.18-0.49, 3.5-8.5x the algorithmic HBM bytes, profiles/r03_pmc_traffic_x3.json).  Remapped, XCD c works on the logical blocks
-// [c*n/8, (c+1)*n/8) - tile-fastest, so a chunk's tiles are neighbours on one XCD and run at the same time.
-__device__ __forceinline__ int xcd_remap(int b, int n) { return (n & 7) ? b : (b & 7) * (n >> 3) + (b >> 3); }
-bool wgrad_xcd_remap_on() { static const bool on = [] { const char* e = getenv("CTGAN_WGRAD_XCD"); return !e || atoi(e) != 0; }(); return on; }
-
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kernel(const WgradParams p) {
-    const int nx = (int)gridDim.x, n = nx * (int)gridDim.y;
-    const int b = p.xcd ? xcd_remap((int)blockIdx.y * nx + (int)blockIdx.x, n) : (int)blockIdx.y * nx + (int)blockIdx.x;
-    wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(p, b % nx, b / nx);
+    wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(p, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Several weight gradients of the SAME tile configuration in one launch (the deferred weight gradients of a step are
@@ -1143,9 +1132,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_kerne
 // problem like the single-problem grid.  Problems are ordered longest chunk first.
 struct WgradGroupParams {
     int n;
-    int block0[CTGAN_WGRAD_GROUP_MAX + 1];   // (with the XCD-aware order: every problem's block range is padded to a multiple of 8)
+    int block0[CTGAN_WGRAD_GROUP_MAX + 1];
     int tiles[CTGAN_WGRAD_GROUP_MAX];
-    int real[CTGAN_WGRAD_GROUP_MAX];         // workgroups that have work (tiles * splits) inside the problem's padded range
     WgradParams p[CTGAN_WGRAD_GROUP_MAX];
 };
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -1155,9 +1143,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_pipe_group
 #pragma unroll
     for (int t = 1; t < CTGAN_WGRAD_GROUP_MAX; ++t)
         if (t < gp.n && b >= gp.block0[t]) i = t;
-    int r = b - gp.block0[i];
-    if (gp.p[i].xcd) r = xcd_remap(r, gp.block0[i + 1] - gp.block0[i]);      // per problem: every XCD gets an eighth of each problem
-    if (r >= gp.real[i]) return;                                              // padding
+    const int r = b - gp.block0[i];
     const int by = r / gp.tiles[i];
     wgrad_pipe_body<WAVES_M, WAVES_N, TM, TN>(gp.p[i], r - by * gp.tiles[i], by);
 }
@@ -1381,7 +1367,10 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
 // ---- weight-gradient planning (shared by the launcher and the workspace query) ------------
 enum WTile { W128x128, W64x128, W32x128, W64x64, W128x32 };
 // the split-K reductions of several weight gradients in one launch: blockIdx.y = job
-struct ReduceJob { const float* part; float* out; float* out2; long long n, n_main; int splits, pad; };
+// add / add2 (optional): finished addends of the same shapes as out / out2 - the weight gradient a split-mode launch produced earlier
+// for the same filter; summed AFTER the slabs (r = slabs + add).  They may alias out / out2 (accumulate in place: each thread reads
+// and writes the same four elements).
+struct ReduceJob { const float* part; float* out; float* out2; const float* add; const float* add2; long long n, n_main; int splits, pad; };
 struct ReduceJobs { int n; int pad; ReduceJob j[CTGAN_REDUCE_BATCH]; };
 __global__ void splitk_reduce_batch_kernel(const ReduceJobs jobs) {
     const ReduceJob& jb = jobs.j[blockIdx.y];
@@ -1409,8 +1398,13 @@ __global__ void splitk_reduce_batch_kernel(const ReduceJobs jobs) {
     float4 r;
     r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
     r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
-    if (i < n_main) *reinterpret_cast<float4*>(jb.out + i) = r;
-    else *reinterpret_cast<float4*>(jb.out2 + (i - n_main)) = r;
+    if (i < n_main) {
+        if (jb.add) { const float4 v = *reinterpret_cast<const float4*>(jb.add + i); r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        *reinterpret_cast<float4*>(jb.out + i) = r;
+    } else {
+        if (jb.add2) { const float4 v = *reinterpret_cast<const float4*>(jb.add2 + (i - n_main)); r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        *reinterpret_cast<float4*>(jb.out2 + (i - n_main)) = r;
+    }
 }
 
 struct WPlan { WTile tile; int bm, bn, tiles, splits, chunk; };
@@ -1489,7 +1483,6 @@ int launch_wgrad_pipe(WgradParams p, const WPlan& w, float* dw, float* db, void*
     }
     p.chunk = w.chunk;
     p.with_bias = db ? 1 : 0;
-    p.xcd = wgrad_xcd_remap_on() ? 1 : 0;
     // with a bias row the slab layout is [Mtot+1][Ng]; a single split still goes through the slab so that
     // dw stays exactly [Mtot][Ng]
     const bool direct = w.splits == 1 && !db;
@@ -1811,7 +1804,7 @@ int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy
     p.X = x; p.DY = dy; p.OUT = dw;
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
-    p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0; p.nseg = 0; p.xcd = 0;
+    p.chunk = 0; p.with_bias = 0; p.x_bytes = p.dy_bytes = 0; p.nseg = 0;
     p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = run_wgrad(p, dw, db, ws, ws_bytes, st);
@@ -1887,7 +1880,7 @@ int prepare_multi(const ctgan_conv_desc* d, int32_t nseg, const float* const* xs
     p.X = xs[0]; p.DY = dys[0]; p.OUT = nullptr;
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K;
     p.dy_n = d->ys[0]; p.dy_k = d->ys[1]; p.dy_p = d->ys[2]; p.dy_q = d->ys[3];
-    p.relu_x = 0; p.x_bytes = p.dy_bytes = 0; p.xcd = 0;
+    p.relu_x = 0; p.x_bytes = p.dy_bytes = 0;
     m = multi_plan(d, nseg, Ns);
     const WPlan& w = m.w;
     bool ok = (g.C % 32 == 0) && g.s_c == 1 && (g.s_n % 4 == 0) && (g.s_h % 4 == 0) && (g.s_w % 4 == 0) && p.dy_k == 1 && (p.Ng % 4 == 0) &&
@@ -2052,11 +2045,9 @@ extern "C" int ctgan_conv2d_wgrad_group_ex(const ctgan_wgrad_group* groups, int3
                 if (k < gp.n) {
                     const int i = idx[base + k];
                     gp.block0[k] = b0; gp.tiles[k] = M[i].w.tiles; gp.p[k] = PT[i];
-                    gp.real[k] = M[i].w.tiles * M[i].splits;
-                    gp.p[k].xcd = wgrad_xcd_remap_on() ? 1 : 0;
-                    b0 += gp.p[k].xcd ? ((gp.real[k] + 7) & ~7) : gp.real[k];
+                    b0 += M[i].w.tiles * M[i].splits;
                 } else {
-                    gp.block0[k] = b0; gp.tiles[k] = 1; gp.real[k] = 0; gp.p[k] = PT[idx[base]];
+                    gp.block0[k] = b0; gp.tiles[k] = 1; gp.p[k] = PT[idx[base]];
                 }
             }
             gp.block0[CTGAN_WGRAD_GROUP_MAX] = b0;
@@ -2078,6 +2069,7 @@ extern "C" int ctgan_conv2d_wgrad_group_ex(const ctgan_wgrad_group* groups, int3
             const int i = base + (k < jobs.n ? k : 0);
             const long long n_main = (long long)PT[i].Mtot * PT[i].Ng, nn = n_main + (groups[i].db ? PT[i].Ng : 0);
             jobs.j[k].part = PT[i].OUT; jobs.j[k].out = groups[i].dw; jobs.j[k].out2 = groups[i].db ? groups[i].db : groups[i].dw;
+            jobs.j[k].add = groups[i].add_dw; jobs.j[k].add2 = groups[i].db ? groups[i].add_db : nullptr;
             jobs.j[k].n = nn; jobs.j[k].n_main = n_main; jobs.j[k].splits = M[i].splits; jobs.j[k].pad = 0;
             if (k < jobs.n && nn > max_n) max_n = nn;
         }

@@ -983,7 +983,7 @@ struct W16 {
     unsigned x_bytes, dy_bytes;
     int dbg;
     int pq_shift, q_shift;           // log2(P*Q), log2(Q) when both are powers of two, else -1: pixel -> (n,p,q) without integer division
-    int xcd;                         // XCD-aware workgroup order
+    int with_bias;                   // slab row Mtot receives the column sums of dy (bias gradient), summed by the workgroups of the first M tile
 };
 
 // one workgroup per CU, staging woven between the MFMAs: the 256x128 tile
@@ -1017,14 +1017,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.Ng + BNK - 1) / BNK;
-    // XCD-aware block order (speed only): the tiles of one pixel chunk - all taps / channel blocks - read the same x and dy rows; the
-    // hardware deals consecutive workgroup ids round robin over the 8 XCDs (private L2s), so remap: XCD c works on the logical blocks
-    // [c*n/8, (c+1)*n/8), tile-fastest (measured before: L2 hit rate 0.18-0.49, 3.5-8.5x the algorithmic HBM bytes)
-    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
-    if (p.xcd) {
-        const int nx = (int)gridDim.x, nb = nx * (int)gridDim.y;
-        if ((nb & 7) == 0) { const int b = by * nx + bx, l = (b & 7) * (nb >> 3) + (b >> 3); by = l / nx; bx = l - by * nx; }
-    }
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     const int tile_m = bx / tiles_n, tile_n = bx - tile_m * tiles_n;
     const int cblocks = p.C / BMC;                       // M tiles per tap
     const int tap = tile_m / cblocks, c0 = (tile_m - tap * cblocks) * BMC;
@@ -1046,6 +1039,10 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     // because it costs nothing at one wave per SIMD and removes the load latency from the list of suspects.
     constexpr int NSET = SPLIT ? 2 : 1;
     float4 rxv[NSET][X_PER][4], ryv[NSET][Y_PER][4];
+    const bool bias_wg = p.with_bias && tile_m == 0;
+    float4 bsum[Y_PER];
+#pragma unroll
+    for (int b = 0; b < Y_PER; ++b) bsum[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned x_wstep = (unsigned)p.s_w * 4u, x_estep = (unsigned)p.stride * x_wstep;
     auto load_slice = [&](int kt, auto set_c) {
         constexpr int SET = decltype(set_c)::value;
@@ -1124,6 +1121,10 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         for (int b = 0; b < Y_PER; ++b) {
             const int pg = tid % YPG + YPG * (b % (PGS / YPG)), cg = tid / YPG + (NT / YPG) * (b / (PGS / YPG));
             const float4 (&v)[4] = ryv[SET][b];
+            if (bias_wg) {           // workgroup-uniform: the bias gradient rides the staging of dy (rows past the chunk were loaded as zeros)
+                bsum[b].x += (v[0].x + v[1].x) + (v[2].x + v[3].x); bsum[b].y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+                bsum[b].z += (v[0].z + v[1].z) + (v[2].z + v[3].z); bsum[b].w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+            }
             unsigned short* dst = &Ys[(cg * 4) * LDS_K + pg * 4];
             put(dst, YPLANE, v[0].x, v[1].x, v[2].x, v[3].x);
             put(dst + LDS_K, YPLANE, v[0].y, v[1].y, v[2].y, v[3].y);
@@ -1230,7 +1231,25 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         }
     }
     // acc[i][j][4g + e] = dW(channel c0 + wm*TM*32 + i*32 + 8g + 4h + e, kout n0 + wn*TN*32 + j*32 + l31): 32 lanes = 128 B rows
-    float* out = p.OUT + (long long)by * p.Mtot * p.Ng;
+    float* out = p.OUT + (long long)by * (p.Mtot + (p.with_bias ? 1 : 0)) * p.Ng;
+    if (bias_wg) {
+        // column sums of this chunk's dy tile: a thread holds 4 channels of its pixel groups; fold the pixel groups through LDS in a
+        // fixed order (deterministic), one thread per channel writes slab row Mtot
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(S0);
+#pragma unroll
+        for (int b = 0; b < Y_PER; ++b) {
+            const int pg = tid % YPG + YPG * (b % (PGS / YPG)), cg = tid / YPG + (NT / YPG) * (b / (PGS / YPG));
+            *reinterpret_cast<float4*>(&red[pg * BNK + cg * 4]) = bsum[b];
+        }
+        __syncthreads();
+        if (tid < BNK && n0 + tid < p.Ng) {
+            float t = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < PGS; ++g2) t += red[g2 * BNK + tid];
+            out[(long long)p.Mtot * p.Ng + n0 + tid] = t;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1245,7 +1264,8 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         }
 }
 
-__global__ void reduce16_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int splits) {
+// elements [0, n_main) go to `out`, the trailing n - n_main (the bias row of the slabs) to `out2`; n, n_main multiples of 4
+__global__ void reduce16_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2, long long n, long long n_main, int splits) {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
@@ -1260,7 +1280,9 @@ __global__ void reduce16_kernel(const float* __restrict__ part, float* __restric
         const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
         a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
     }
-    *reinterpret_cast<float4*>(out + i) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    const float4 r = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+    if (i < n_main) *reinterpret_cast<float4*>(out + i) = r;
+    else *reinterpret_cast<float4*>(out2 + (i - n_main)) = r;
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -1883,30 +1905,39 @@ int ctgan_conv2d16_dgrad_ex(const ctgan_conv_desc* d, int mma, const float* dy, 
 }
 
 size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d, int mma) {
+    // (sized for the bias row as well: with db the partial sums always go through the slabs, also when the plan has one split)
     if (!d || !ctgan_conv2d16_supported(d, CTGAN_CONV_WGRAD, mma)) return 0;
     const WPlan16 w = wgrad16_plan(d, mma);
-    return w.splits > 1 ? (size_t)w.splits * d->R * d->S * d->C * d->K * sizeof(float) : 0;
+    return (size_t)w.splits * ((size_t)d->R * d->S * d->C + 1) * d->K * sizeof(float);
 }
 
 int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
                          int flags, ctgan_stream_t stream) {
+    return ctgan_conv2d16_wgrad_bias(d, mma, x, dy, dw, nullptr, ws, ws_bytes, flags, stream);
+}
+
+int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, float* db, void* ws,
+                              size_t ws_bytes, int flags, ctgan_stream_t stream) {
     if (!d || !x || !dy || !dw || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad: bad argument");
+    if (db && (d->K % 4 || (reinterpret_cast<uintptr_t>(db) & 15)))
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: the fused bias gradient needs K %% 4 == 0 and a 16-byte aligned db");
     if (!ctgan_conv2d16_supported(d, CTGAN_CONV_WGRAD, mma)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: shape outside the 16-bit family");
     const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
     const long long y_extent = (long long)d->N * d->P * d->Q * d->K;
     if (x_extent * 4 >= (1LL << 32) || y_extent * 4 >= (1LL << 32))
         return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: operand exceeds the 4 GiB buffer range");
     const WPlan16 w = wgrad16_plan(d, mma);
-    const size_t need = ctgan_conv2d16_wgrad_workspace_bytes(d, mma);
+    const bool slabs = w.splits > 1 || db;
+    const size_t need = slabs ? (size_t)w.splits * ((size_t)d->R * d->S * d->C + (db ? 1 : 0)) * d->K * sizeof(float) : 0;
     if (need > ws_bytes || (need && !ws)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad: workspace %zu B < %zu B", ws_bytes, need);
     W16 p{};
-    p.X = x; p.DY = dy; p.OUT = w.splits > 1 ? (float*)ws : dw;
+    p.X = x; p.DY = dy; p.OUT = slabs ? (float*)ws : dw;
+    p.with_bias = db ? 1 : 0;
     p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.C = d->C; p.R = d->R; p.S = d->S; p.stride = d->stride;
     p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
     p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = d->N * d->P * d->Q;
     p.chunk = w.chunk; p.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0; p.dbg = dbg16();
-    { static const bool on = [] { const char* e = getenv("CTGAN_WGRAD_XCD"); return !e || atoi(e) != 0; }(); p.xcd = on ? 1 : 0; }
     {
         const int pq = d->P * d->Q;
         const bool pow2 = !(pq & (pq - 1)) && !(d->Q & (d->Q - 1));
@@ -1925,9 +1956,9 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
     else if (w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 2>(p, w.splits, st, "wgrad16<64x128>") : launch_wgrad16<CTGAN_MMA_F16, 1, 2>(p, w.splits, st, "wgrad16<64x128>");
     else rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 1>(p, w.splits, st, "wgrad16<64x64>") : launch_wgrad16<CTGAN_MMA_F16, 1, 1>(p, w.splits, st, "wgrad16<64x64>");
     if (rc) return rc;
-    if (w.splits > 1) {
-        const long long n = (long long)p.Mtot * p.Ng;
-        hipLaunchKernelGGL(reduce16_kernel, dim3(ctgan_blocks(n / 4, 256, 1 << 20)), dim3(256), 0, st, (const float*)ws, dw, n, w.splits);
+    if (slabs) {
+        const long long n_main = (long long)p.Mtot * p.Ng, n = n_main + (db ? p.Ng : 0);
+        hipLaunchKernelGGL(reduce16_kernel, dim3(ctgan_blocks(n / 4, 256, 1 << 20)), dim3(256), 0, st, (const float*)ws, dw, db ? db : dw, n, n_main, w.splits);
         return ctgan_check_launch("reduce16");
     }
     return 0;

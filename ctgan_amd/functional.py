@@ -64,9 +64,18 @@ WGRAD_GROUPED = _os.environ.get('CTGAN_WGRAD_GROUPED', '1') != '0'
 
 
 class _WgradGroup:
-    # pre: (gw, gb) results already computed for this filter (uses the split-mode kernel took at once, _wgrad): added at the flush,
-    # so that autograd still sees ONE buffer per filter, filled exactly once
-    __slots__ = ('g', 'segs', 'dw', 'db', 'pre')
+    # inplace / inplace_b: dw / db already HOLD a finished addend - the result of the first use the split-mode kernel took at request
+    # time (_wgrad), written straight into the filter's buffers; the flush then accumulates the queued segments onto it inside the
+    # batched split-K reduction (no axpby / copy launches).  pre: (gw, gb) results of further such uses (rare), added at the flush.
+    # Either way autograd sees ONE buffer per filter, complete when the deferred_wgrads() block exits.
+    __slots__ = ('g', 'segs', 'dw', 'db', 'pre', 'inplace', 'inplace_b')
+
+
+def _new_group(g, device):
+    grp = _WgradGroup()
+    grp.g, grp.segs, grp.db, grp.pre, grp.inplace, grp.inplace_b = g, [], None, [], False, False
+    grp.dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=device)
+    return grp
 
 
 @contextlib.contextmanager
@@ -89,29 +98,34 @@ def deferred_wgrads():
                 fn()
 
 
+def _seg_bias(grp):
+    return any(sg[3] for sg in grp.segs)
+
+
 def _flush_groups(grps):
     """All queued weight gradients: one grouped launch per tile configuration + one reduction launch when every group
     fits the pipelined kernel (K.conv_wgrad_group), else group by group."""
     _all = list(grps)
-    simple = [g for g in grps if 1 <= len(g.segs) <= K.WGRAD_MAX_SEGS and not K.fewch_handles(g.g)]
+    grps = [g for g in grps if g.segs]
+    simple = [g for g in grps if len(g.segs) <= K.WGRAD_MAX_SEGS and not K.fewch_handles(g.g)]
     if WGRAD_GROUPED and len(simple) > 1:
-        for g in simple:                                   # a queued bias buffer no segment contributes to
-            if g.db is not None and not any(sg[3] for sg in g.segs):
+        for g in simple:                                   # a queued bias buffer nothing contributes to
+            if g.db is not None and not _seg_bias(g) and not g.inplace_b:
                 g.db.zero_()
-        todo = simple
         try:
-            for i in range(0, len(todo), K.WGRAD_GROUP_LIMIT):
-                K.conv_wgrad_group([(g.segs, g.g, g.dw, g.db if any(sg[3] for sg in g.segs) else None)
-                                    for g in todo[i:i + K.WGRAD_GROUP_LIMIT]])
+            for i in range(0, len(simple), K.WGRAD_GROUP_LIMIT):
+                K.conv_wgrad_group([(g.segs, g.g, g.dw, g.db if _seg_bias(g) else None,
+                                     g.dw if g.inplace else None, g.db if (g.inplace_b and _seg_bias(g)) else None)
+                                    for g in simple[i:i + K.WGRAD_GROUP_LIMIT]])
             grps = [g for g in grps if g not in simple]
         except NotImplementedError:
             pass                                           # nothing was launched: fall back below
     for grp in grps:
-        if grp.segs:
-            _flush_group(grp)
-    for grp in (g for g in _all if g.pre):                  # results the split-mode kernel produced at request time
-        dw_set, db_set = bool(grp.segs), any(sg[3] for sg in grp.segs)
-        for gw, gb in grp.pre:
+        _flush_group(grp)
+    for grp in _all:
+        dw_set = bool(grp.segs) or grp.inplace
+        db_set = _seg_bias(grp) or grp.inplace_b
+        for gw, gb in grp.pre:                              # further results the split-mode kernel produced at request time
             if dw_set:
                 K.axpby(grp.dw, gw, 1.0, 1.0, out=grp.dw)
             else:
@@ -129,30 +143,38 @@ def _flush_groups(grps):
 
 def _flush_group(grp):
     segs = grp.segs
+    acc_w, acc_b = grp.inplace, grp.inplace_b               # the buffers already hold an addend: accumulate instead of overwriting
+
+    def put(dw2, db2):
+        nonlocal acc_w, acc_b
+        if acc_w:
+            K.axpby(grp.dw, dw2, 1.0, 1.0, out=grp.dw)
+        elif dw2 is not grp.dw:
+            grp.dw.copy_(dw2)
+        acc_w = True
+        if db2 is not None:
+            if acc_b:
+                K.axpby(grp.db, db2, 1.0, 1.0, out=grp.db)
+            elif db2 is not grp.db:
+                grp.db.copy_(db2)
+            acc_b = True
     try:
         per = 2 if K.fewch_handles(grp.g) else K.WGRAD_MAX_SEGS
         for i in range(0, len(segs), per):
             chunk = segs[i:i + per]
-            if i == 0:
-                K.conv_wgrad_multi(chunk, grp.g, grp.dw, grp.db if any(sg[3] for sg in chunk) else None)
-                if grp.db is not None and not any(sg[3] for sg in chunk):
-                    grp.db.zero_()
-            else:                                               # more uses than one launch takes: accumulate
-                dw2 = torch.empty_like(grp.dw)
-                db2 = torch.empty_like(grp.db) if (grp.db is not None and any(sg[3] for sg in chunk)) else None
-                K.conv_wgrad_multi(chunk, grp.g, dw2, db2)
-                K.axpby(grp.dw, dw2, 1.0, 1.0, out=grp.dw)
-                if db2 is not None:
-                    K.axpby(grp.db, db2, 1.0, 1.0, out=grp.db)
+            cb = any(sg[3] for sg in chunk)
+            direct = not acc_w and not (cb and acc_b)
+            dw2 = grp.dw if direct else torch.empty_like(grp.dw)
+            db2 = (grp.db if direct else torch.empty_like(grp.db)) if cb else None
+            K.conv_wgrad_multi(chunk, grp.g, dw2, db2)
+            put(dw2, db2)
     except NotImplementedError:                                 # shape outside the pipelined kernel: one call per use
-        first = True
         for x, gy, relu_x, with_bias in segs:
             r = K.conv_wgrad(x, gy, grp.g, with_bias=with_bias, relu_x=relu_x)
             gw, gb = r if with_bias else (r, None)
-            (grp.dw.copy_(gw) if first else K.axpby(grp.dw, gw, 1.0, 1.0, out=grp.dw))
-            if gb is not None:
-                grp.db.copy_(gb)
-            first = False
+            put(gw, gb)
+    if grp.db is not None and not acc_b and not grp.pre:
+        grp.db.zero_()
 
 
 def _like_first(t, ref):
@@ -181,20 +203,23 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     key = (w.data_ptr(), gk)
     grp = _DEFER['groups'].get(key)
-    if x.is_cuda and K.wgrad_prefers_x3(g, x.shape[0]):
-        # a large layer: the split-mode kernel is the faster fp32 path (kernels.X3_HYBRID) - launched now, its result joins the
-        # filter's queue as a finished addend (the filter keeps ONE result buffer, filled once at the flush)
-        r = K.conv_wgrad(x, gy, g, with_bias=with_bias, relu_x=relu_x)
-        now = r if with_bias else (r, None)
+    if K.wgrad_prefers_x3(g, x.shape[0], x.device):
+        # a large layer: the split-mode kernel is the faster fp32 path (kernels.X3_HYBRID) - launched now.  The filter keeps ONE result
+        # buffer: the first such use writes straight into it (bias gradient fused into the same launch), the queued segments of the
+        # filter are accumulated onto it by the flush; further uses of this kind are added at the flush.
         gw = gb = None
         if grp is None:
-            grp = _WgradGroup()
-            grp.g, grp.segs, grp.db, grp.pre = g, [], None, []
-            grp.dw = gw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+            grp = _new_group(g, x.device)
+            gw = grp.dw
             _DEFER['groups'][key] = grp
         if with_bias and grp.db is None:
             grp.db = gb = torch.empty(g.K, dtype=torch.float32, device=x.device)
-        grp.pre.append(now)
+        if not grp.inplace and not grp.pre:
+            K.conv_wgrad(x, gy, g, with_bias=with_bias, relu_x=relu_x, out=(grp.dw, grp.db if with_bias else None))
+            grp.inplace, grp.inplace_b = True, bool(with_bias)
+        else:
+            r = K.conv_wgrad(x, gy, g, with_bias=with_bias, relu_x=relu_x)
+            grp.pre.append(r if with_bias else (r, None))
         return gw, gb
     if grp is not None and grp.segs:
         # A later use whose operands have another memory layout is repacked into the first use's layout.  It must NOT open a
@@ -203,9 +228,8 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
         x, gy = _like_first(x, grp.segs[0][0]), _like_first(gy, grp.segs[0][1])
     gw = gb = None
     if grp is None:
-        grp = _WgradGroup()
-        grp.g, grp.segs, grp.db, grp.pre = g, [], None, []
-        grp.dw = gw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+        grp = _new_group(g, x.device)
+        gw = grp.dw
         _DEFER['groups'][key] = grp
     if with_bias and grp.db is None:
         grp.db = gb = torch.empty(g.K, dtype=torch.float32, device=x.device)

@@ -80,10 +80,10 @@ def _conv_mode(d, op, plain):
     return None
 
 
-def wgrad_prefers_x3(g, N):
+def wgrad_prefers_x3(g, N, device=None):
     """True when the fp32 mode routes this weight gradient to the split mode (then it is launched at once, not queued for the fp32
     family's grouped launch).  Needs dense channels-last operands, which the callers of the large layers provide."""
-    if MMA_DTYPE is not None or not X3_HYBRID or g.x_up or fewch_handles(g):
+    if MMA_DTYPE is not None or not X3_HYBRID or g.x_up or fewch_handles(g) or (device is not None and torch.device(device).type != 'cuda'):
         return False
     d = g.desc(N, (g.C * g.H * g.W, 1, g.W * g.C, g.C), (g.K * g.P * g.Q, 1, g.Q * g.K, g.K))
     return bool(lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 2))
@@ -463,14 +463,19 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
     return dx if drop is None else dropout_rng(dx, *drop)
 
 
-def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
-    """dw[R,S,C,K] = sum over pixels of x (gathered) * gy; with_bias also returns db[K] = sum of gy."""
+def conv_wgrad(x, gy, g, with_bias=False, relu_x=False, out=None):
+    """dw[R,S,C,K] = sum over pixels of x (gathered) * gy; with_bias also returns db[K] = sum of gy.
+    out = (dw, db or None): result buffers to write into (default: fresh tensors)."""
     _need_dev(x, gy)
     N = x.shape[0]
     assert tuple(x.shape) == _x_phys_shape(g, N)
     assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
-    dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
-    db = torch.empty(g.K, dtype=torch.float32, device=x.device) if with_bias else None
+    if out is not None:
+        dw, db = out
+        assert tuple(dw.shape) == (g.R, g.S, g.C, g.K) and dw.is_contiguous() and (db is not None) == bool(with_bias)
+    else:
+        dw = torch.empty((g.R, g.S, g.C, g.K), dtype=torch.float32, device=x.device)
+        db = torch.empty(g.K, dtype=torch.float32, device=x.device) if with_bias else None
     if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous():
         gy = to_channels_last(gy)
     d = g.desc(N, x.stride(), gy.stride())
@@ -481,9 +486,13 @@ def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
         if mode is not None:
             ws = workspace(lib.ctgan_conv2d16_wgrad_workspace_bytes(ctypes.byref(d16), _MMA_CODE[mode]), x.device)
             code = _MMA_CODE[mode]
-            _timed(g, N, lambda: check(lib.ctgan_conv2d16_wgrad(ctypes.byref(d16), code, _ptr(x), _ptr(gy16), _ptr(dw), _ptr(ws), ws.numel(), 2 if relu_x else 0, _stream()), 'conv2d16_wgrad'))
+            fused_b = with_bias and g.K % 4 == 0         # bias gradient inside the same launch (no separate column-sum pass)
+            _timed(g, N, lambda: check(lib.ctgan_conv2d16_wgrad_bias(ctypes.byref(d16), code, _ptr(x), _ptr(gy16), _ptr(dw), _ptr(db) if fused_b else None,
+                                                                     _ptr(ws), ws.numel(), 2 if relu_x else 0, _stream()), 'conv2d16_wgrad'))
             if with_bias:
-                return dw, colsum_channels(gy16)
+                if not fused_b:
+                    db.copy_(colsum_channels(gy16))
+                return dw, db
             return dw
     nb = lib.ctgan_conv2d_workspace_bytes(ctypes.byref(d), 2)
     ws = workspace(nb, x.device)
@@ -533,7 +542,9 @@ def conv_wgrad_group(groups):
     assert 1 <= n <= WGRAD_GROUP_LIMIT
     arr = (WgradGroup * n)()
     dev = groups[0][0][0][0].device
-    for i, (segs, g, dw, db) in enumerate(groups):
+    for i, grp in enumerate(groups):
+        segs, g, dw, db = grp[:4]
+        add_dw, add_db = (grp[4], grp[5]) if len(grp) > 4 else (None, None)     # finished addends (may be dw / db themselves)
         assert 1 <= len(segs) <= WGRAD_MAX_SEGS
         x0, gy0 = segs[0][0], segs[0][1]
         for x, gy, _, _ in segs:
@@ -552,6 +563,9 @@ def conv_wgrad_group(groups):
             G.dys[k] = sg[1].data_ptr()
         G.dw = dw.data_ptr()
         G.db = db.data_ptr() if db is not None else None
+        assert add_dw is None or (add_dw.shape == dw.shape and add_dw.is_contiguous())
+        G.add_dw = add_dw.data_ptr() if add_dw is not None else None
+        G.add_db = add_db.data_ptr() if (add_db is not None and db is not None) else None
     nb = lib.ctgan_conv2d_wgrad_group_workspace_bytes(arr, n)
     if nb == 0:
         raise NotImplementedError('conv2d_wgrad_group: unsupported group')

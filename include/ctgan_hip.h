@@ -128,6 +128,10 @@ typedef struct ctgan_wgrad_group {
     const float* dys[CTGAN_WGRAD_MAX_SEGS];
     float* dw;
     float* db;                       /* NULL unless a segment carries CTGAN_WGRAD_SEG_BIAS */
+    /* optional finished addends (grouped launch only): dw = (sum over segments) + add_dw, db likewise - the weight gradient another
+       launch already produced for the same filter.  May alias dw / db (in-place accumulation).  add_db is ignored when db is NULL. */
+    const float* add_dw;
+    const float* add_db;
 } ctgan_wgrad_group;
 size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n);
 int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes,
@@ -232,6 +236,10 @@ int ctgan_conv2d16_dgrad_ex(const ctgan_conv_desc* d, int mma, const float* dy, 
 size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d, int mma);
 int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, void* ws,
                          size_t ws_bytes, int flags, ctgan_stream_t stream);
+/* ... with the bias gradient db[K] = sum over pixels of dy fused into the same launch (the workgroups of the first tile row sum the dy
+ * tiles they stage; fixed-order reduction): replaces the separate ctgan_colsum pass.  db NULL = ctgan_conv2d16_wgrad.              */
+int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, float* db, void* ws,
+                              size_t ws_bytes, int flags, ctgan_stream_t stream);
 /* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K);
  * db[k] = sum_{n,p,q} dy[n,k,p,q] when db != NULL (tf.nn.bias_add gradient, fused when possible) */
 int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,

@@ -112,11 +112,28 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
 
 
 @_export
-def conv_wgrad(x, gy, g, with_bias=False, relu_x=False):
+def conv_wgrad(x, gy, g, with_bias=False, relu_x=False, out=None):
     if relu_x:
         x = torch.relu(x)
     gw = _conv_wgrad(x, gy, g)
-    return (gw, gy.sum(dim=(0, 2, 3))) if with_bias else gw
+    gb = gy.sum(dim=(0, 2, 3)) if with_bias else None
+    if out is not None:
+        out[0].copy_(gw)
+        if with_bias:
+            out[1].copy_(gb)
+        gw, gb = out[0], out[1]
+    return (gw, gb) if with_bias else gw
+
+
+# tests: pixel count from which a weight gradient is "taken at once by the split-mode kernel" (functional._wgrad's in-place path);
+# None = never, like a CPU tensor in the product
+PREFERS_X3_MIN_PIXELS = None
+
+
+@_export
+def wgrad_prefers_x3(g, N, device=None):
+    from ctgan_amd import kernels as _K
+    return PREFERS_X3_MIN_PIXELS is not None and N * g.P * g.Q >= PREFERS_X3_MIN_PIXELS and not _K.fewch_handles(g) and not g.x_up
 
 
 @_export
@@ -136,8 +153,16 @@ def conv_wgrad_multi(segs, g, dw, db=None):
 
 @_export
 def conv_wgrad_group(groups):
-    for segs, g, dw, db in groups:
+    for grp in groups:
+        segs, g, dw, db = grp[:4]
+        add_dw, add_db = (grp[4], grp[5]) if len(grp) > 4 else (None, None)
+        a = add_dw.clone() if add_dw is not None else None          # (the addends may alias dw / db)
+        b = add_db.clone() if (add_db is not None and db is not None) else None
         conv_wgrad_multi(segs, g, dw, db)
+        if a is not None:
+            dw.add_(a)
+        if b is not None:
+            db.add_(b)
 
 
 def _conv_wgrad(x, gy, g):

@@ -119,7 +119,7 @@ def test_conv16_fwd_dgrad_wgrad(K, case, dt):
 X3_CASES = CASES + [
     (24, 32, 32, 32, 128, 3, 1),      # 32-wide images: tile = 4 rows, 6 x 34 patch
     (96, 32, 16, 16, 128, 3, 1),      # 16-wide images: tile = 8 rows (half an image), 10 x 18 patch
-    (96, 32, 16, 16, 128, 5, 1),      # 5x5 taps: 12 x 20 patch = 88 KB with the filter stage - slice kernel
+    (96, 32, 16, 16, 128, 5, 1),      # 5x5 taps: too large a patch beside an LDS filter stage - the fragment-streaming halo kernel on 64-pixel tiles
     (384, 32, 8, 8, 128, 3, 1),       # 8x8 images: tile = two whole images, each with its own 10 x 10 halo block
     (96, 64, 32, 32, 128, 4, 2),      # stride 2 (the folded ConvMeanPool filter): single-stage 128x128 slice kernel; data gradient in 4 phases
     # launches whose 128-pixel tiles cannot fill the chip: the 64- and 32-pixel tiles of the fragment-streaming halo kernel
@@ -175,7 +175,7 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
     assert kern1['fwd'].startswith('igemm') or kern1['fwd'].startswith('fewch'), kern1
     assert kern3['fwd'].startswith('conv16x3') and kern3['dgrad'].startswith('conv16x3'), kern3
     if case in X3_CASES[len(CASES):]:
-        want_kernel = 'conv16x3h' if (st == 1 and k == 3) else 'conv16x3<128x128'      # (5x5: the patch does not fit two workgroups per CU)
+        want_kernel = 'conv16x3h' if st == 1 else 'conv16x3<128x128'
         if case in X3_SMALL_TILE:
             want_kernel = 'conv16x3hf<' + X3_SMALL_TILE[case]
         assert kern3['fwd'].startswith(want_kernel) and (C % 128 != 0 or kern3['dgrad'].startswith(want_kernel)), kern3
@@ -189,7 +189,7 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
         assert m3 <= max(3.0 * m1, 1e-6), (what, m3, m1)
 
 
-@pytest.mark.parametrize('case', [(24, 32, 32, 32, 128, 3, 1), (96, 64, 16, 16, 256, 3, 1), (384, 32, 8, 8, 128, 3, 1)],
+@pytest.mark.parametrize('case', [(24, 128, 32, 32, 128, 3, 1), (96, 128, 16, 16, 256, 3, 1), (384, 128, 8, 8, 128, 3, 1)],
                          ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d' % c)
 def test_f32x3_halo_kernel_with_filter_fragments_from_l2_equals_the_lds_staged_one_bitwise(K, case):
     """conv16x3hf (filter fragments streamed from L2 in MFMA-fragment order, waves split over kout) performs the same MFMAs in the same
@@ -267,6 +267,24 @@ def test_f32x3_halo_kernel_applies_the_epilogue_dropout_of_the_fp32_family(K, ra
     assert torch.equal(got == 0, want == 0) or ((got == 0) != (want == 0)).float().mean().item() < 1e-5
     assert relerr(got, want) < 2e-6
     assert 0.2 < (want == 0).float().mean().item() < 0.9
+
+
+def test_f32x3_wgrad_with_the_fused_bias_gradient(K):
+    """ctgan_conv2d16_wgrad_bias: db = column sums of dy from the same launch (workgroups of the first tile row), equal to the separate
+    column-sum pass to fp32 summation error, for one split and many, and dw unchanged by it (bit-identical to the launch without db)."""
+    for N, C, H, Ko, k, st in [(8, 128, 16, 128, 3, 1), (128, 128, 32, 128, 4, 2), (2, 128, 8, 256, 3, 1)]:
+        g = torch.Generator().manual_seed(N)
+        geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+        x, gy = cl(torch.randn(N, C, H, H, generator=g)), cl(torch.randn(N, Ko, geom.P, geom.Q, generator=g))
+        with K.mma_dtype('f32x3'):
+            dw0 = K.conv_wgrad(x, gy, geom, relu_x=True)
+            assert K.last_kernel().startswith(('wgrad16x3', 'reduce16')), K.last_kernel()
+            dw1, db1 = K.conv_wgrad(x, gy, geom, with_bias=True, relu_x=True)
+            out = (torch.full_like(dw0, 7.0), torch.full((Ko,), 7.0, device='cuda'))
+            dw2, db2 = K.conv_wgrad(x, gy, geom, with_bias=True, relu_x=True, out=out)
+        assert torch.equal(dw0, dw1) and torch.equal(dw1, dw2) and torch.equal(db1, db2) and dw2 is out[0]
+        ref = gy.double().sum(dim=(0, 2, 3))
+        assert relerr(db1, ref) < 2e-6, (N, relerr(db1, ref))
 
 
 def test_conv16_wgrad_runs_on_the_16bit_kernel_and_is_deterministic(K):

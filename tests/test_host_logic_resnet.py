@@ -249,6 +249,54 @@ def test_deferred_multi_segment_wgrads_equal_immediate_wgrads(cpu_kernels):
         R.configure()
 
 
+@pytest.mark.parametrize('min_px', [1, 2048, 5000])
+def test_split_mode_wgrads_written_in_place_equal_immediate_wgrads(cpu_kernels, monkeypatch, min_px):
+    """functional._wgrad with uses the split-mode kernel takes at request time (kernels.wgrad_prefers_x3): the FIRST such use of a
+    filter writes straight into the filter's result buffers (bias gradient included), the queued fp32 segments are accumulated onto
+    it inside the grouped reduction (ctgan_wgrad_group.add_dw / add_db aliasing dw / db), further uses are added at the flush.  For
+    every routing threshold - everything in place (1 pixel), main pass in place + GP segment queued (2048), nothing (5000) - the
+    parameter gradients of a full critic step must equal the immediate path's."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    B, dim = 4, 32
+    lib.set_seed(7)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    try:
+        R.build_params('cpu')
+        tr = R.Trainer(seed=1)
+        g = torch.Generator().manual_seed(100)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        rnd = osteps.make_rnd_resnet_d(B, dim, g, dtype=torch.float32)
+        res, seen = {}, {}
+        for mode in (False, True):
+            F.DEFER_WGRADS = mode
+            monkeypatch.setattr(cpu_kernels, 'PREFERS_X3_MIN_PIXELS', min_px if mode else None)
+            tr.rng.begin_step()
+            out = tr.d_losses(real, labels, rnd)
+            with F.deferred_wgrads():
+                grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+                if mode:
+                    grps = list(F._DEFER['groups'].values())
+                    seen = {'inplace': sum(gr.inplace for gr in grps), 'with_segs': sum(bool(gr.segs) and gr.inplace for gr in grps),
+                            'extra': sum(len(gr.pre) for gr in grps), 'bias_inplace': sum(gr.inplace_b for gr in grps)}
+            res[mode] = [None if x is None else x.clone() for x in grads]
+        if min_px == 1:
+            assert seen['inplace'] >= 8 and seen['extra'] >= 8 and seen['bias_inplace'] >= 6, seen      # both uses taken at once
+        elif min_px == 2048:
+            assert seen['with_segs'] >= 2, seen          # main pass in place, GP segment queued behind it
+        else:
+            assert seen['inplace'] == 0, seen
+        for (n, _), a, b in zip(tr.d_named, res[False], res[True]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                _cmp(b, a, 1e-5, 'in-place split-mode wgrad ' + n, atol=1e-7)
+    finally:
+        F.DEFER_WGRADS = True
+        R.configure()
+
+
 def test_fused_critic_heads_equal_separate_heads(small):
     """Host wiring of HEAD_FUSION (CriticTailHeadsFn, GpHeadGradFn, ConvFn 'mask_done') against the op-by-op head, on the
     CPU stand-ins and identical random streams."""
