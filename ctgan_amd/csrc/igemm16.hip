@@ -177,9 +177,9 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* _
 #pragma unroll
         for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane + pp.off[ph])[i] = o[q];
         if constexpr (planes<MMA>() == 3) {
-            if (pp.frag) {                                   // (the reduction channel is k, the output channel n = c; a phase's FRAG block starts at 3x its plane offset)
+            if (pp.frag) {                                   // (stride 1: one phase; the reduction channel is k, the output channel n = c)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(wp + 3 * plane + 3 * pp.off[ph])[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
+                for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(wp + 3 * plane)[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
             }
         }
     }
@@ -231,7 +231,7 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
             if constexpr (planes<MMA>() == 3) {
                 if (pp.frag) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane + 3 * pp.off[ph])[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
+                    for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane)[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
                 }
             }
         }
@@ -790,33 +790,23 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
 // TN = 32-pixel sub-tiles per workgroup tile (4: 128 pixels; 2 / 1: the 64- / 32-pixel tiles of launches whose 128-pixel tiles
 // could not fill the chip - the 16x16 / 8x8 layers at 64-192 rows; the filter stream per workgroup is the same, so they trade L2
 // bytes per MFMA for workgroups).
-struct PatchGeom4 { PatchGeom g[4]; };      // one per output-parity phase of a stride-2 data gradient (g[0]: single-phase launches)
-
 template <bool RELU_IN, int TN>
-__global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const PatchGeom4 pgs) {
+__global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const PatchGeom pg) {
     constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, MAXIT = 8, BMP = TN * 32;
     constexpr int LDS_K = BK + 8;
     constexpr int LDE = 32 + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int PPLANE = pg.NPX * LDS_K;
     unsigned short* const Xs = smem;                      // patch: 3 planes x NPX pixel rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the filter stream's offset lives in SGPRs (no waterfall loop around its loads)
+    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
     const int tiles_n = p.Ng / 128;
     int bid = blockIdx.x;
     const int nb = gridDim.x;
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // neighbouring pixel tiles (shared halo rows) on one XCD
-    int tile_m = bid / tiles_n;
-    const int tile_n = bid - tile_m * tiles_n;
-    // stride-2 data gradient: the output-parity phase rides the M-tile index; a phase is a stride-1 correlation of dy with its own taps,
-    // pads, packed filter block and (strided) output positions
-    int pa = 0, pb = 0, ph = 0;
-    if (p.nph > 1) { ph = tile_m / p.ph_tiles_m; tile_m -= ph * p.ph_tiles_m; pa = ph >> 1; pb = ph & 1; }
-    const PatchGeom pg = pgs.g[ph];
-    const int PPLANE = pg.NPX * LDS_K;
-    const int R = p.ph_T[pa], S = p.ph_U[pb], RS = R * S;
-    const int pad_t = p.ph_pad_t[pa], pad_l = p.ph_pad_l[pb];
-    const long long d_off = pa * p.ph_d_h + pb * p.ph_d_w;
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * BMP, n0 = tile_n * 128;
     const int nch = p.C / BK;
     const int PQ = p.P * p.Q;
@@ -826,7 +816,7 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
     const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
     // ---- filter fragment stream of this wave: output channels n0 + 32*wave .. +31; 6 KB per (chunk, tap) step, steps contiguous
     const unsigned a_voff = (unsigned)lane * 16u;
-    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(6 * p.ph_w_off[ph] + (long long)((n0 >> 5) + wave) * nch * RS * 6144));
+    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((long long)((n0 >> 5) + wave) * nch * RS * 6144));
     u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
     auto loadA = [&](auto setc) __attribute__((always_inline)) {
         constexpr int SET = decltype(setc)::value;
@@ -847,7 +837,7 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
         if (it < pg.n_it && px < pg.NPX) {
             const int pi = px / pg.PIMG, pr = px - pi * pg.PIMG;
             const int prow = pr / pg.PW, pcol = pr - prow * pg.PW;
-            const int ih = row0 + prow - pad_t, iw = pcol - pad_l;
+            const int ih = row0 + prow - p.ph_pad_t[0], iw = pcol - p.ph_pad_l[0];
             if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
                 p_voff[it] = (unsigned)(((long long)(img + pi) * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + (item & 7) * 4) * 4);
         }
@@ -955,7 +945,7 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
             const int m = m0 + jh * 32 + row, col = n0 + wave * 32 + c4 * 4;
             float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
             const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
-            const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+            const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
             if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
             if (p.mask) {
                 const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
@@ -1301,10 +1291,9 @@ bool mma_ok(int mma) { return mma == CTGAN_MMA_BF16 || mma == CTGAN_MMA_F16 || m
 // shape only (never of N, H, W: the image is cached per filter and operator): stride 1, several taps, 32-channel chunks on the
 // reduction side, 128-channel tiles on the output side - the shapes conv16x3hf_kernel takes.
 bool frag_image_shape(const ctgan_conv_desc* d, int op) {
+    if (d->stride != 1 || d->R * d->S < 2) return false;
     const int nout = op == CTGAN_CONV_FWD ? d->K : d->C, cred = op == CTGAN_CONV_FWD ? d->C : d->K;
-    if (nout % 128 || cred % 32) return false;
-    if (d->stride == 2) return op == CTGAN_CONV_DGRAD && d->R >= 3 && d->S >= 3;      // four output-parity phases, each with its own block
-    return d->stride == 1 && d->R * d->S >= 2 && (op == CTGAN_CONV_FWD || op == CTGAN_CONV_DGRAD);
+    return (op == CTGAN_CONV_FWD || op == CTGAN_CONV_DGRAD) && nout % 128 == 0 && cred % 32 == 0;
 }
 int mma_planes(int mma) { return mma == CTGAN_MMA_F32X3 ? 3 : 1; }
 int dbg16() { static const int v = [] { const char* e = getenv("CTGAN_DBG16"); return e ? atoi(e) : 0; }(); return v; }
@@ -1397,12 +1386,12 @@ size_t conv16x3h_lds(const PatchGeom& g) {
     const size_t stages = (size_t)3 * (128 + g.NPX) * 40 * 2, epi = (size_t)4 * 32 * 68 * 4;
     return stages > epi ? stages : epi;
 }
-bool conv16x3h_ok_ph(const P16& p, int ph, PatchGeom* out, int bmp) {
-    if (p.stride != 1 || p.Ng % 128 || p.C % 32 || p.Q <= 0 || p.M % bmp) return false;
+bool conv16x3h_ok(const P16& p, PatchGeom* out, int bmp = 128) {
+    if (p.nph != 1 || p.stride != 1 || p.Ng % 128 || p.C % 32 || p.Q <= 0 || p.M % bmp) return false;
     const int PQ = p.P * p.Q;
     if (!(PQ % bmp == 0 && bmp % p.Q == 0) && !(PQ < bmp && bmp % PQ == 0)) return false;      // whole rows of one image, or whole images
-    const int R = p.ph_T[ph >> 1], S = p.ph_U[ph & 1];
-    if (R * S < (p.nph > 1 ? 1 : 2)) return false;
+    const int R = p.ph_T[0], S = p.ph_U[0];
+    if (R * S < 2) return false;
     PatchGeom g;
     g.IMGS = PQ < bmp ? bmp / PQ : 1;
     g.TR = PQ < bmp ? p.P : bmp / p.Q;
@@ -1412,27 +1401,16 @@ bool conv16x3h_ok_ph(const P16& p, int ph, PatchGeom* out, int bmp) {
     if (out) *out = g;
     return true;
 }
-// single-phase launches (both halo kernels)
-bool conv16x3h_ok(const P16& p, PatchGeom* out, int bmp = 128) { return p.nph == 1 && conv16x3h_ok_ph(p, 0, out, bmp); }
-// every phase of the launch (the fragment-streaming kernel also takes the four phases of a stride-2 data gradient)
-bool conv16x3hf_ok(const P16& p, PatchGeom4* out, int bmp) {
-    if (p.nph != 1 && p.nph != 4) return false;
-    PatchGeom4 g4{};
-    for (int ph = 0; ph < p.nph; ++ph)
-        if (!conv16x3h_ok_ph(p, ph, &g4.g[ph], bmp)) return false;
-    if (out) *out = g4;
-    return true;
-}
 // Pixels per workgroup tile of the fragment-streaming halo kernel for this launch: the largest of 128 / 64 / 32 whose tiles fill the
 // chip (>= 192 workgroups; the smallest that qualifies otherwise).  0: no tile shape qualifies.
 int conv16x3hf_tile(const P16& p) {
     static const int force = [] { const char* e = getenv("CTGAN_X3_HF_TILE"); return e ? atoi(e) : 0; }();
-    if (force && conv16x3hf_ok(p, nullptr, force)) return force;
+    if (force && conv16x3h_ok(p, nullptr, force)) return force;
     int last = 0;
     for (int bmp = 128; bmp >= 32; bmp >>= 1) {
-        if (!conv16x3hf_ok(p, nullptr, bmp)) continue;
+        if (!conv16x3h_ok(p, nullptr, bmp)) continue;
         last = bmp;
-        if ((long long)p.nph * (p.M / bmp) * (p.Ng / 128) >= 192) return bmp;
+        if ((long long)(p.M / bmp) * (p.Ng / 128) >= 192) return bmp;
     }
     return last;
 }
@@ -1446,7 +1424,7 @@ int conv16x3hf_tile(const P16& p) {
 bool conv16x3hf_wins(const P16& p) {
     const int bmp = conv16x3hf_tile(p);
     if (!bmp) return false;
-    const long long tiles = (long long)p.nph * (p.M / bmp) * (p.Ng / 128);
+    const long long tiles = (long long)(p.M / bmp) * (p.Ng / 128);
     const int PQ = p.P * p.Q;
     static const int small8 = [] { const char* e = getenv("CTGAN_X3_HF_8X8"); return e ? atoi(e) : 0; }();      // experiment: also the 8x8 layers
     if (bmp == 128) return tiles >= 192 && PQ >= 128;
@@ -1463,10 +1441,8 @@ int halo_version() {
 bool conv16x3hf_usable(const P16& p) { return halo_version() != 1 && p.Wf != nullptr && conv16x3hf_tile(p) > 0; }
 
 template <bool RELU_IN, int TN>
-int launch_conv16x3hf_t(const P16& p, const PatchGeom4& pg, hipStream_t st) {
-    int npx = 0;
-    for (int ph = 0; ph < p.nph; ++ph) if (pg.g[ph].NPX > npx) npx = pg.g[ph].NPX;
-    const size_t epi = (size_t)4 * 32 * 36 * 4, stage = (size_t)3 * npx * 40 * 2;
+int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
+    const size_t epi = (size_t)4 * 32 * 36 * 4, stage = (size_t)3 * pg.NPX * 40 * 2;
     const size_t lds = stage > epi ? stage : epi;
     static size_t have = 0;
     if (have < lds) {
@@ -1478,7 +1454,7 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom4& pg, hipStream_t st) {
     q.ph_tiles_m = p.M / (TN * 32);
     q.dbg = dbg16();
     q.ksplit = 1; q.slab = nullptr;
-    hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN>), dim3((unsigned)(p.nph * q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
+    hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
     ctgan_set_last_kernel(TN == 4 ? "conv16x3hf<128x128,k32>" : (TN == 2 ? "conv16x3hf<64x128,k32>" : "conv16x3hf<32x128,k32>"));
     ctgan_set_last_symbol("conv16x3hf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
     return ctgan_check_launch("conv16x3hf");
@@ -1489,8 +1465,8 @@ int launch_conv16x3h(const P16& p, hipStream_t st) {
     const bool prefer_v1 = !g_halo_version_override && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
     if (conv16x3hf_usable(p) && !prefer_v1) {
         const int bmp = conv16x3hf_tile(p);
-        PatchGeom4 pg;
-        conv16x3hf_ok(p, &pg, bmp);
+        PatchGeom pg;
+        conv16x3h_ok(p, &pg, bmp);
         if (bmp == 128) return p.relu_in ? launch_conv16x3hf_t<true, 4>(p, pg, st) : launch_conv16x3hf_t<false, 4>(p, pg, st);
         if (bmp == 64) return p.relu_in ? launch_conv16x3hf_t<true, 2>(p, pg, st) : launch_conv16x3hf_t<false, 2>(p, pg, st);
         return p.relu_in ? launch_conv16x3hf_t<true, 1>(p, pg, st) : launch_conv16x3hf_t<false, 1>(p, pg, st);
