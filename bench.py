@@ -58,6 +58,9 @@ def main():
                     'multi-rank code path be exercised on a single-GPU box (all ranks share cuda:0)')
     ap.add_argument('--launcher', default='auto', choices=['auto', 'always', 'never'],
                     help='auto: start the N rank processes here when --gpus N > 1 and WORLD_SIZE is unset; always: also for N = 1')
+    ap.add_argument('--ar-in-graph', action='store_true',
+                    help='N > 1: capture the gradient all-reduces (RCCL) and Adam inside the step graphs - one graph per iteration as at N = 1 '
+                         '(engine.AR_IN_GRAPH; default: eager all-reduce on a side stream between per-step graphs)')
     ap.add_argument('--spawn-check', action='store_true',
                     help='ranks only join the process group, all-reduce their rank numbers and report (no GPU work): the launcher test')
     args = ap.parse_args()
@@ -65,6 +68,8 @@ def main():
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.spawn_check:
         return spawn_check(args)
+    if args.ar_in_graph:
+        os.environ['CTGAN_AR_IN_GRAPH'] = '1'          # read when ctgan_amd.engine is imported (below)
 
     import numpy as np
     import torch
@@ -145,7 +150,12 @@ def main():
     # N > 1: what the six gradient all-reduces of an iteration cost on the critical path = the same loop with the collective
     # switched off on every rank (the replicas drift apart from here on: nothing below compares them)
     collective = None
-    if world > 1:
+    if world > 1 and eng.ar_in_graph:
+        collective = {'all_reduces_per_step': R.cfg.N_CRITIC + 1, 'in_graph': True,
+                      'bucket_bytes': {'critic': 4 * trainer.d_opt.theta.numel(), 'generator': 4 * trainer.g_opt.theta.numel()},
+                      'note': 'the all-reduces are nodes of the iteration graph (serial in stream order: fully exposed, but no graph boundaries '
+                              'or eager launches between the steps)'}
+    elif world > 1:
         saved_ar, trainer.allreduce = trainer.allreduce, None
         try:
             k2 = max(5, min(20, args.steps))
@@ -354,6 +364,8 @@ def run_unconditional(args):
     K.set_mma_dtype(dtype)
     side = torch.cuda.Stream() if world > 1 else None
     tr = DCGANTrainer(M, seed=2024, rank=rank, world_size=world, allreduce=ddp.FlatAllReduce(side_stream=side))
+    if dtype == 'f16':
+        tr.loss_scale = 1024.0              # power-of-two loss scale of the fp16 mode (dcgan_step.DCGANTrainer.loss_scale)
     ddp.broadcast_params([tr.d_opt.theta, tr.g_opt.theta])
     nrng = np.random.default_rng(1234 + rank)
     batches = [torch.from_numpy(nrng.integers(0, 256, (B, M.cfg.OUTPUT_DIM), dtype=np.int32)).to(dev) for _ in range(8)]
@@ -432,7 +444,7 @@ def run_unconditional(args):
             'dtype': dtype or 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'name': args.config, 'global_batch': B * world, 'images_per_step': n_crit * B * world,
                        'parallelism': 'dp%d' % world, 'hipgraph': bool(eng.graphed), 'last_d_terms': last, 'loss_sane': sane,
-                       'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1]},
+                       'loss_scale': tr.loss_scale, 'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1]},
             'roofline': roofline, 'cpu_baseline': None, 'build': build_provenance()}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

@@ -44,6 +44,19 @@ class DCGANTrainer:
         self.iteration = 0
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
+        # Power-of-two loss scale for the fp16 matrix-core mode (kernels.set_mma_dtype('f16')): the backward passes are linear in the
+        # seed, so the cost gradient is seeded with S instead of 1 - every first-order gradient TENSOR the fp16 kernels round is S
+        # times larger, away from fp16's subnormals (per-pixel gradients shrink with 1 / (B H W)) - and Adam divides it out again
+        # (grad_scale); exact in fp32 (a power of two), a no-op for S = 1.
+        self.loss_scale = float(getattr(module, 'LOSS_SCALE', 1.0))
+        self._seed = None
+
+    def cost_seed(self):
+        """grad_outputs of the final backward: a cached 0-dim tensor holding the loss scale (no fill kernel per step)."""
+        if self._seed is None or float(self._seed_val) != self.loss_scale:
+            self._seed = torch.full((), self.loss_scale, dtype=torch.float32, device=self.dev)
+            self._seed_val = self.loss_scale
+        return self._seed
 
     def d_losses(self, real_in, rnd=None):
         m, cfg = self.mod, self.mod.cfg
@@ -93,24 +106,29 @@ class DCGANTrainer:
             self.allreduce(flat)
             if hasattr(self.allreduce, 'wait'):
                 self.allreduce.wait()
-        opt.step(grad_scale=1.0 / self.world)
+        opt.step(grad_scale=1.0 / (self.world * self.loss_scale))
+
+    def _unscaled(self, grads):
+        if self.loss_scale == 1.0:
+            return grads
+        return [None if g is None else g / self.loss_scale for g in grads]
 
     def d_step(self, real_in, rnd=None):
         self.rng.begin_step()
         out = self.d_losses(real_in, rnd)
-        grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
+        grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.d_opt, grads)
         self.rng.end_step()
-        out['grads'] = dict(zip([n for n, _ in self.d_named], grads))
+        out['grads'] = dict(zip([n for n, _ in self.d_named], self._unscaled(grads)))
         return out
 
     def g_step(self, rnd=None):
         self.rng.begin_step()
         out = self.g_losses(rnd)
-        grads = torch.autograd.grad(out['cost'], self.g_params, allow_unused=True)
+        grads = torch.autograd.grad(out['cost'], self.g_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.g_opt, grads)
         self.rng.end_step()
-        out['grads'] = dict(zip([n for n, _ in self.g_named], grads))
+        out['grads'] = dict(zip([n for n, _ in self.g_named], self._unscaled(grads)))
         return out
 
     def train_iteration(self, iteration, next_batch):

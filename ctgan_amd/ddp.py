@@ -44,10 +44,17 @@ class FlatAllReduce:
     next step's input staging (engine.GraphedTrainer) - overlaps the collective.  Without a side stream (gloo / CPU tests)
     the call is synchronous and `wait()` is a no-op."""
 
-    def __init__(self, group=None, side_stream=None):
+    def __init__(self, group=None, side_stream=None, always=False):
         self.group = group
         self.side = side_stream
+        self.always = always          # tests: issue the collective for a 1-rank group too (exercises the RCCL enqueue / capture path)
         self._pending = None
+
+    def inline(self, flat):
+        """The collective on the CALLER's current stream, synchronously in stream order - the form that can be captured into a
+        hipGraph (engine.GraphedTrainer with CTGAN_AR_IN_GRAPH=1)."""
+        if dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def __call__(self, flat):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:

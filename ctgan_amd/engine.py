@@ -16,10 +16,15 @@ from . import tflib as lib
 import os as _os
 # A/B switch: the whole iteration (G step + fake batches + N_CRITIC critic steps) as ONE hipGraph when world == 1
 ITERATION_GRAPH = _os.environ.get('CTGAN_ITERATION_GRAPH', '1') != '0'
+# world > 1: capture the gradient all-reduce (RCCL supports stream capture) and the Adam step INSIDE the step graphs, so that the
+# multi-GPU loop is the same one-graph-per-iteration replay as the single-GPU loop (no graph boundaries, no eager launches between
+# the steps).  Off by default: the eager side-stream all-reduce (ddp.FlatAllReduce) is the path the CPU (gloo) tests cover; this one
+# is covered on one GPU by a 1-rank RCCL group (tests/test_gpu_graph_loop.py) and awaits a multi-GPU box.
+AR_IN_GRAPH = _os.environ.get('CTGAN_AR_IN_GRAPH', '0') != '0'
 
 
 class GraphedTrainer:
-    def __init__(self, trainer, use_graphs=True, warmup=2):
+    def __init__(self, trainer, use_graphs=True, warmup=2, ar_in_graph=None):
         self.t = trainer
         B = R.cfg.BATCH_SIZE
         dev = trainer.dev
@@ -34,7 +39,9 @@ class GraphedTrainer:
         self.it_graph = None          # ONE graph for a whole iteration (G step + fake batches + N_CRITIC critic steps), world == 1
         self.it_out = None
         self.real_all = torch.zeros(R.cfg.N_CRITIC, B, R.cfg.OUTPUT_DIM, dtype=torch.int32, device=dev) if self.batch_fakes else None
-        self.adam_in_graph = trainer.world == 1
+        self.ar_in_graph = bool(use_graphs and trainer.allreduce is not None and (trainer.world > 1 or getattr(trainer.allreduce, 'always', False))
+                                and (AR_IN_GRAPH if ar_in_graph is None else ar_in_graph))
+        self.adam_in_graph = trainer.world == 1 or self.ar_in_graph
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
         self.graph_error = None
@@ -69,10 +76,16 @@ class GraphedTrainer:
         with F.deferred_wgrads():
             grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
         t.d_opt.gather_grads(grads)
+        self._reduce_in_graph(t.d_opt)
         if self.adam_in_graph:
-            t.d_opt.step(1.0)
+            t.d_opt.step(1.0 / t.world)
         t.rng.end_step()
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
+
+    def _reduce_in_graph(self, opt):
+        """The flat gradient bucket summed over the ranks ON the capturing stream: the collective becomes a node of the step graph."""
+        if self.ar_in_graph:
+            self.t.allreduce.inline(opt.grad)
 
     def _it_body(self):
         """A whole iteration of the loop body (TF/CT_gan_cifar_resnet.py:393-404) with it > 0: generator step, the fake batches
@@ -96,8 +109,9 @@ class GraphedTrainer:
         with F.deferred_wgrads():
             grads = torch.autograd.grad(out['cost'], t.g_params, allow_unused=True)
         t.g_opt.gather_grads(grads)
+        self._reduce_in_graph(t.g_opt)
         if self.adam_in_graph:
-            t.g_opt.step(1.0)
+            t.g_opt.step(1.0 / t.world)
         t.rng.end_step()
         return {'cost': out['cost'].detach()}
 
@@ -294,10 +308,10 @@ class GraphedDCGANTrainer:
         else:
             out = t.g_losses()
             params, opt = t.g_params, t.g_opt
-        grads = torch.autograd.grad(out['cost'], params, allow_unused=True)
+        grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         opt.gather_grads(grads)
         if self.adam_in_graph:
-            opt.step(1.0)
+            opt.step(1.0 / t.loss_scale)
         t.rng.end_step()
         return {k: out[k].detach() for k in ('cost', 'wgan_only', 'ct', 'gp') if out.get(k) is not None}
 
@@ -375,7 +389,7 @@ class GraphedDCGANTrainer:
             t.allreduce(opt.grad)
             if hasattr(t.allreduce, 'wait'):
                 t.allreduce.wait()
-        opt.step(1.0 / t.world)
+        opt.step(1.0 / (t.world * t.loss_scale))
 
     def train_iteration(self, iteration, next_batch):
         """[G step if it > 0] + CRITIC_ITERS x (batch, D step)  (TF/CT_gan_cifar.py:190-204)."""

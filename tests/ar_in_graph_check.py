@@ -1,0 +1,57 @@
+"""Helper of tests/test_gpu_graph_loop.py::test_all_reduce_captured_in_the_step_graphs (run as a subprocess: it owns a process group).
+A 1-rank RCCL group on one GPU: the same training loop (whole-iteration hipGraph replay) with the gradient all-reduce + Adam captured
+inside the graphs (engine.AR_IN_GRAPH) and without any collective must produce bit-identical weights - the sum over one rank is the
+identity, 1/world = 1 - which exercises RCCL enqueue under stream capture and graph replay on this stack.  Prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def run(in_graph, dim, B, iters):
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    from ctgan_amd import ddp
+    from ctgan_amd.engine import GraphedTrainer
+    lib.delete_all_params(); lib.set_device(None); lib.set_seed(0)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    R.build_params()
+    ar = ddp.FlatAllReduce(always=True) if in_graph else None
+    tr = R.Trainer(seed=2024, allreduce=ar)
+    eng = GraphedTrainer(tr, use_graphs=True, ar_in_graph=in_graph)
+    assert eng.graphed and eng.it_graph is not None, eng.graph_error
+    assert eng.ar_in_graph == bool(in_graph)
+    nrng = np.random.default_rng(1)
+    batches = [(torch.from_numpy(nrng.integers(0, 256, (B, 3072), dtype=np.int32)).cuda(),
+                torch.from_numpy(nrng.integers(0, 10, (B,), dtype=np.int32)).cuda()) for _ in range(8)]
+    k = [0]
+
+    def nb():
+        k[0] = (k[0] + 1) % len(batches)
+        return batches[k[0]]
+    out = None
+    for it in range(1, 1 + iters):
+        out = eng.train_iteration(it, nb)
+    torch.cuda.synchronize()
+    res = (tr.d_opt.theta.clone(), tr.g_opt.theta.clone(), float(out['cost'].item()))
+    lib.delete_all_params(); R.configure()
+    return res
+
+
+if __name__ == '__main__':
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    dim, B, iters = (int(v) for v in sys.argv[1:4])
+    a = run(False, dim, B, iters)
+    b = run(True, dim, B, iters)
+    print(json.dumps({'d_equal': bool(torch.equal(a[0], b[0])), 'g_equal': bool(torch.equal(a[1], b[1])), 'cost_plain': a[2], 'cost_in_graph': b[2],
+                      'backend': dist.get_backend(), 'd_moved': float((a[0] - torch.zeros_like(a[0])).abs().max().item())}))
+    dist.destroy_process_group()

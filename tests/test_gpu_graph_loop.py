@@ -297,3 +297,21 @@ def test_whole_iteration_graph_equals_eager_loop(dim, B, iters):
             assert math.isfinite(a[k]) and abs(a[k]) < 1e3
             assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(b[k])), 'iteration %d %s: graph %r eager %r' % (n, k, a[k], b[k])
     assert torch.equal(g[1], e[1]) and torch.equal(g[2], e[2])
+
+
+def test_all_reduce_captured_in_the_step_graphs():
+    """CTGAN_AR_IN_GRAPH (engine.GraphedTrainer(ar_in_graph=True)): the gradient all-reduce and the Adam step captured INSIDE the step /
+    iteration graphs, so that the multi-GPU loop is the single-GPU one-graph-per-iteration replay.  On one GPU: a 1-rank RCCL group
+    (tests/ar_in_graph_check.py in a subprocess) - the loop with the captured collective must end with bit-identical weights to the
+    loop without any collective, and a finite cost."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(here, 'ar_in_graph_check.py'), '32', '8', '4'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert rec['backend'] == 'nccl' and rec['d_equal'] and rec['g_equal'], rec
+    assert math.isfinite(rec['cost_in_graph']) and rec['cost_plain'] == rec['cost_in_graph'], rec

@@ -83,3 +83,34 @@ def test_dcgan_steps_match_oracle(cpu_kernels, which):
             _cmp(out['grads'][n], gref[n], 2e-3, which + ' ggrad ' + n, atol=2e-6)
     finally:
         M.configure()
+
+
+def test_loss_scale_is_divided_out_exactly(cpu_kernels):
+    """DCGANTrainer.loss_scale (the fp16 mode's power-of-two loss scale): seeds the final backward with S and hands Adam 1/S - in fp32
+    a power of two changes no bit: reported gradients, updated weights and Adam slots equal the unscaled step's."""
+    import ctgan_amd.gan_mnist as M
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    from oracle import steps as osteps
+    res = {}
+    for S in (1.0, 1024.0):
+        lib.delete_all_params(); lib.set_device('cpu'); lib.set_seed(3)
+        M.configure(BATCH_SIZE=4, DIM=8)
+        try:
+            with torch.no_grad():
+                M.Discriminator(M.Generator(2, noise=torch.zeros(2, 128)), u=[torch.ones(2, *s) for s in M.feat_shapes()])
+            tr = DCGANTrainer(M, seed=1)
+            tr.loss_scale = S
+            g = torch.Generator().manual_seed(5)
+            real = torch.rand(4, M.cfg.OUTPUT_DIM, generator=g)
+            rnd = osteps.make_rnd_dcgan_d(4, M.feat_shapes(), g, dtype=torch.float32)
+            out = tr.d_step(real, rnd)
+            rg = osteps.make_rnd_dcgan_g(4, M.feat_shapes(), g, dtype=torch.float32)
+            og = tr.g_step(rg)
+            res[S] = ([v.clone() for v in out['grads'].values() if v is not None], tr.d_opt.theta.clone(), tr.d_opt.m.clone(), tr.d_opt.v.clone(),
+                      tr.g_opt.theta.clone(), og['cost'].item())
+        finally:
+            M.configure()
+    a, b = res[1.0], res[1024.0]
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and a[5] == b[5]

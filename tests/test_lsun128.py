@@ -189,3 +189,61 @@ def test_lsun128_full_width_16bit_losses(dt):
     finally:
         K.set_mma_dtype(None)
         M.configure(); lib.delete_all_params()
+
+
+@pytest.mark.gpu
+def test_lsun128_full_width_f16_batch16_with_loss_scale_vs_oracle():
+    """BASELINE.json configs[4] ("fp16 MFMA conv") at the reference widths and B = 16 (the B = 64 check was a tool, the
+    test ran at B = 4): one critic step with the convs on the fp16 matrix cores and the power-of-two loss scale of that mode
+    (DCGANTrainer.loss_scale = 1024, divided out by Adam) against the fp64 oracle on the same draws.  Stated bounds: loss terms 1e-2
+    of max(1, |term|); every parameter gradient within 6 % relative L2 and cosine >= 0.997 of the oracle's (fp16 operand rounding,
+    2^-11 per operand, through ~20 layers with Layernorm; measured at B = 4: worst 4.0 % / 0.9992)."""
+    import ctgan_amd.gan_lsun128 as M
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    lib.delete_all_params(); lib.set_device(None)
+    B = 16
+    M.configure(BATCH_SIZE=B)
+    try:
+        lib.set_seed(9)
+        M.build_params('cuda')
+        ocfg = onets.Lsun128Cfg()
+        reg = _oracle_from_product(lib)
+        g = torch.Generator().manual_seed(3)
+        h = B // 2
+        G = lambda r, n, zz: torch.cat([onets.lsun128_generator(r, ocfg, h, zz[:h]), onets.lsun128_generator(r, ocfg, h, zz[h:])])   # noqa: E731
+        D = lambda r, xx, uu: onets.lsun128_discriminator(r, ocfg, xx, 0.8, 0.5, 0.5, uu)                                         # noqa: E731
+        tr = DCGANTrainer(M, seed=1)
+        tr.loss_scale = 1024.0
+        real_in = torch.randint(0, 256, (B, M.cfg.OUTPUT_DIM), generator=g, dtype=torch.int32)
+        rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
+        ref = osteps.dcgan_d_losses(reg, G, D, 2 * ((real_in.double() / 255.) - .5), rnd)
+        gref = osteps.grads_of(ref['cost'], reg, 'Discriminator')
+        theta0 = tr.d_opt.theta.clone()
+        with K.mma_dtype('f16'):
+            out = tr.d_step(real_in.cuda(), {k: _to(v, 'cuda') for k, v in rnd.items()})
+        for k in ('cost', 'wgan_only', 'ct', 'gp'):
+            a, b = out[k].item(), ref[k].item() * (M.cfg.LAMBDA if k == 'gp' else 1.0)
+            assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), (k, a, b)
+        worst = (0.0, 1.0, None)
+        for n, gr in gref.items():
+            if gr.abs().max() < 1e-12:
+                continue
+            a = out['grads'][n].detach().cpu().double().reshape(-1); b = gr.detach().double().reshape(-1)
+            e = ((a - b).norm() / b.norm()).item()
+            c = torch.nn.functional.cosine_similarity(a.view(1, -1), b.view(1, -1)).item()
+            if e > worst[0]:
+                worst = (e, c, n)
+            assert e <= 0.06 and c >= 0.997, (n, e, c)
+        # the scale is divided out before the update: the first Adam step moves every weight by at most lr (sign-like step), never 1024 lr
+        step = (tr.d_opt.theta - theta0).abs().max().item()
+        assert 0 < step <= 1.01 * M.lr(0), (step, M.lr(0))
+        import json
+        import os
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/lsun16_f16_B16.json', 'w') as f:
+            json.dump({'B': B, 'loss_scale': tr.loss_scale, 'worst_param': worst[2], 'worst_rel_l2': worst[0], 'its_cosine': worst[1],
+                       'losses': {k: out[k].item() for k in ('cost', 'wgan_only', 'ct', 'gp')}}, f, indent=1)
+    finally:
+        lib.delete_all_params(); M.configure()

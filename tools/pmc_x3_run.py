@@ -41,8 +41,9 @@ def case(op, N, C, H, Ko, R, st, relu=False):
                  'flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg}
 
 
-case('fwd', 192, 128, 32, 128, 3, 1, relu=False)      # conv16x3h_kernel<false>
-case('fwd', 192, 128, 16, 128, 3, 1, relu=True)       # conv16x3h_kernel<true>  (the critic's relu-on-load convs)
+case('fwd', 192, 128, 32, 128, 3, 1, relu=False)      # conv16x3hf_kernel<false, 4> (CTGAN_X3_HALO_V=1: conv16x3h_kernel<false>)
+case('fwd', 192, 128, 16, 128, 3, 1, relu=True)       # conv16x3hf_kernel<true, 4>  (the critic's relu-on-load convs)
+case('fwd', 384, 128, 8, 128, 3, 1, relu=True)        # conv16x3h_kernel<true>: whole 8x8 images per tile (the shared tail forward)
 case('fwd', 128, 128, 32, 128, 4, 2, relu=False)      # conv16_kernel<3, 2, 2, 32, false, false>: folded ConvMeanPool, slice kernel
 case('wgrad', 128, 128, 32, 128, 4, 2, relu=True)     # wgrad16_kernel<3, 2, 2, true, false>
 case('wgrad', 128, 128, 16, 128, 3, 1, relu=False)    # wgrad16_kernel<3, 2, 2, false, false>
