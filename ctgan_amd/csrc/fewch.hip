@@ -697,10 +697,8 @@ static bool m2f_ring_ok(const M2FParams& p, int R, int S) {
 
 template <int JS>
 static int launch_m2f_ring(M2FParams p, hipStream_t st) {
-    static const int force_band = [] { const char* e = getenv("CTGAN_M2F_BAND"); return e ? atoi(e) : 0; }();
-    { const char* e = getenv("CTGAN_M2F_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = 0;
     p.band = p.P >= 8 ? 8 : p.P;                                      // strip rows per workgroup
-    if (force_band > 0 && force_band <= p.P) p.band = force_band;
     const int strips = (p.P + p.band - 1) / p.band;
     const size_t smem = (size_t)RING_SLOTS * (p.W + 2) * 128 * 4 + (size_t)p.band * JS * p.W * 4 + (size_t)9 * JS * 128 * 4;
     int rc = set_smem(&m2f_ring_kernel<JS>, smem);
@@ -875,7 +873,7 @@ int ctgan_fewch_wgrad2(const ctgan_conv_desc* d0, const float* x, const float* d
     if (use_mfma && p.CM == 128 && (p.MW & 1) == 0 && smem_m <= 150 * 1024) {
         bool done = true;
         // two workgroups per CU: the loop is a latency-bound stream (one float4 per lane per two pixels), registers are few
-        static const int cap = [] { const char* e = getenv("CTGAN_FW_BLOCKS"); return e ? atoi(e) : 512; }();
+        const int cap = 512;
         int blocks_m = p.total < cap ? p.total : cap;
         if ((size_t)blocks_m * p.n_out * sizeof(float) > ws_bytes) blocks_m = blocks;
         const dim3 grid(blocks_m);

@@ -1427,8 +1427,6 @@ WPlan wgrad_plan(int C, int Mtot, int Ng, int Kg) {
         else if (Ng > 32) w.tile = Mtot > 32 ? W64x64 : W32x128;
         else w.tile = Mtot > 32 ? W128x32 : W32x128;
     }
-    static const int force_tile = [] { const char* e = getenv("CTGAN_WGRAD_TILE"); return e ? atoi(e) : -1; }();
-    if (force_tile >= 0 && C % 128 == 0 && Ng > 64) w.tile = (WTile)force_tile;     // tuning sweeps only
     static const int dims[5][2] = {{128, 128}, {64, 128}, {32, 128}, {64, 64}, {128, 32}};
     w.bm = dims[w.tile][0]; w.bn = dims[w.tile][1];
     w.tiles = ((Mtot + w.bm - 1) / w.bm) * ((Ng + w.bn - 1) / w.bn);
@@ -1559,13 +1557,12 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
     // one or two output tiles (few-channel / skinny weight gradients): a streaming reduction over the pixel axis,
     // bound by load latency.  Measured (tools/skinny_w.py): ~384 pixels per workgroup, at most one workgroup per CU;
     // more splits only add slab traffic and pipeline fill/drain.
-    static const int force_k = [] { const char* e = getenv("CTGAN_WGRAD_K"); return e ? atoi(e) : 0; }();
-    if (tiles <= 2 && !force_k) {
+    if (tiles <= 2) {
         best = Kg / 384;
         if (best > 256 / tiles) best = 256 / tiles;
         if (best > max_splits) best = max_splits;
     } else {
-        for (int k = (force_k ? force_k : 2); k <= 4; ++k) {
+        for (int k = 2; k <= 4; ++k) {
             int s = (256 * k) / tiles;
             if (s < 1) s = 1;
             if (s > max_splits) s = max_splits;
@@ -1574,8 +1571,6 @@ void ctgan_wgrad_split(int tiles, int Kg, int* splits, int* chunk) {
         }
     }
     if (best < 1) best = 1;
-    static const int force_s = [] { const char* e = getenv("CTGAN_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();
-    if (force_s > 0) best = force_s < max_splits ? force_s : max_splits;      // tuning sweeps only
     int ch = (Kg + best - 1) / best;
     ch = ((ch + BK - 1) / BK) * BK;
     *splits = (Kg + ch - 1) / ch;
@@ -1976,10 +1971,9 @@ void coarsen_plan(MultiPlan& m, WgradParams& p, int div) {
         m.splits += m.seg_splits[i];
     }
 }
-int group_div() {
-    static const int v = [] { const char* e = getenv("CTGAN_WGRAD_GROUP_PCT"); return e ? atoi(e) : 100; }();     // chunk scale, percent
-    return v < 10 ? 10 : v;
-}
+// (coarser or finer split-K chunks inside a grouped launch were measured - 2x coarser -1.5 %, 2x finer -1.2 % - and the stand-alone plan
+// kept: group_div() == 100)
+int group_div() { return 100; }
 }
 extern "C" size_t ctgan_conv2d_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n) {
     if (!groups || n < 1) return 0;

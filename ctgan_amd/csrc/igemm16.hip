@@ -1426,10 +1426,8 @@ bool conv16x3hf_wins(const P16& p) {
     if (!bmp) return false;
     const long long tiles = (long long)(p.M / bmp) * (p.Ng / 128);
     const int PQ = p.P * p.Q;
-    static const int small8 = [] { const char* e = getenv("CTGAN_X3_HF_8X8"); return e ? atoi(e) : 0; }();      // experiment: also the 8x8 layers
     if (bmp == 128) return tiles >= 192 && PQ >= 128;
-    if (bmp == 64) return tiles >= 192 && (PQ >= 256 || small8);
-    return small8 && tiles >= 96;
+    return bmp == 64 && tiles >= 192 && PQ >= 256;
 }
 // CTGAN_X3_HALO_V=1: the filter through an LDS stage (conv16x3h_kernel, 128-pixel tiles only); default 2: filter fragments streamed
 // from L2 (conv16x3hf_kernel, 128- / 64- / 32-pixel tiles)
@@ -1531,19 +1529,8 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
     } else
     if (p.C % 64 == 0) {
         if (small) return launch_conv16<MMA, 1, 1, 64>(p, st, p.ksplit > 1 ? "conv16<64x64,k64,ksplit>" : "conv16<64x64,k64>");
-        // EXPERIMENT, off by default (CTGAN_CONV16_WIDE=1): 2x4 accumulators per wave (128 kout x 256 pixels per workgroup, one wave
-        // per SIMD, 0.75 fragment reads per MFMA).  Measured SLOWER than the 2x2 tile at two waves per SIMD (373-458 vs 500-610
-        // TFLOP/s): with one wave per SIMD the staging instructions must be woven between the MFMAs, and although the slice is one
-        // basic block with scheduling groups, the LDS stores of the next slice may not be hoisted above the fragment reads of the
-        // current one (may-alias: both index the same dynamic LDS array) - they stay serial.  Needs restrict-qualified stage
-        // pointers (or hand-placed asm) before it pays.
-        static const int wide = [] { const char* e = getenv("CTGAN_CONV16_WIDE"); return e ? atoi(e) : 0; }();
-        if (wide == 1 && (long long)p.nph * ((p.M + 255) / 256) * (p.Ng / 128) >= 224)
-            return launch_conv16<MMA, 2, 4, 64>(p, st, "conv16<128x256,k64>");
-        // 4x2 accumulators per wave: 256 kout x 128 pixels per workgroup - 15 operand bytes per kFLOP instead of 23 (the fp32 pixel
-        // operand is the expensive one, so the tile grows along kout)
-        if (wide == 2 && p.Ng % 256 == 0 && (long long)p.nph * ((p.M + 127) / 128) * (p.Ng / 256) >= 224)
-            return launch_conv16<MMA, 4, 2, 64>(p, st, "conv16<256x128,k64>");
+        // (wider forward tiles - 128 kout x 256 pixels, 256 kout x 128 pixels, one wave per SIMD - measured slower / neutral against this
+        // tile at two waves per SIMD and removed: DESIGN 4.3)
         return launch_conv16<MMA, 2, 2, 64>(p, st, "conv16<128x128,k64>");
     }
     if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16<64x64,k32,ksplit>" : "conv16<64x64,k32>");
@@ -1946,8 +1933,10 @@ int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x,
     }
     p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)(y_extent * 4);
     hipStream_t st = (hipStream_t)stream;
-    int rc;
+    int rc = 0;
     const bool bf = mma == CTGAN_MMA_BF16;
+    if (flags & CTGAN_WGRAD16_REDUCE_ONLY) { /* the slabs are already in ws (bench.py times the two launches apart) */ }
+    else
     if (mma == CTGAN_MMA_F32X3) rc = launch_wgrad16<CTGAN_MMA_F32X3, 2, 2>(p, w.splits, st, "wgrad16x3<128x128>");
     else if (w.bmc == 256 && w.bnk == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 4>(p, w.splits, st, "wgrad16<256x256>") : launch_wgrad16<CTGAN_MMA_F16, 4, 4>(p, w.splits, st, "wgrad16<256x256>");
     else if (w.bmc == 256) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 4, 2>(p, w.splits, st, "wgrad16<256x128>") : launch_wgrad16<CTGAN_MMA_F16, 4, 2>(p, w.splits, st, "wgrad16<256x128>");
@@ -1956,7 +1945,7 @@ int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x,
     else if (w.bnk == 128) rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 2>(p, w.splits, st, "wgrad16<64x128>") : launch_wgrad16<CTGAN_MMA_F16, 1, 2>(p, w.splits, st, "wgrad16<64x128>");
     else rc = bf ? launch_wgrad16<CTGAN_MMA_BF16, 1, 1>(p, w.splits, st, "wgrad16<64x64>") : launch_wgrad16<CTGAN_MMA_F16, 1, 1>(p, w.splits, st, "wgrad16<64x64>");
     if (rc) return rc;
-    if (slabs) {
+    if (slabs && !(flags & CTGAN_WGRAD16_GEMM_ONLY)) {
         const long long n_main = (long long)p.Mtot * p.Ng, n = n_main + (db ? p.Ng : 0);
         hipLaunchKernelGGL(reduce16_kernel, dim3(ctgan_blocks(n / 4, 256, 1 << 20)), dim3(256), 0, st, (const float*)ws, dw, db ? db : dw, n, n_main, w.splits);
         return ctgan_check_launch("reduce16");

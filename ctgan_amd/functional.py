@@ -23,19 +23,6 @@ _WEIGHT_GRADS = True
 # stores), False = stand-alone mask kernel on the data gradient.  A/B switch CTGAN_MASK_EPI.
 import os as _os
 MASK_IN_DGRAD_EPILOGUE = _os.environ.get('CTGAN_MASK_EPI', '1') != '0'
-# Launch the weight gradient of a conv on a side stream, concurrently with its data gradient (the two are
-# independent): the prologue / epilogue of one kernel overlaps the MFMA stretch of the other.  A/B switch.
-WGRAD_SIDE_STREAM = _os.environ.get('CTGAN_WGRAD_STREAM', '0') != '0'
-WGRAD_SIDE_MAX_ROWS = int(_os.environ.get('CTGAN_WGRAD_STREAM_ROWS', '0'))     # 0 = any size; else only convs with N*P*Q <= this
-_side = {}
-
-
-def _side_stream(dev):
-    st = _side.get(dev)
-    if st is None:
-        st = _side[dev] = torch.cuda.Stream(device=dev)
-    return st
-
 
 @contextlib.contextmanager
 def weight_grads(enabled):
@@ -341,20 +328,9 @@ class ConvFn(Function):
         mask = x.detach() if ctx.relu_in else None      # ReLU backward rides the dgrad epilogue (a constant: no graph edge)
         need_w = ctx.needs_input_grad[1] and ctx.want_w
         need_b = ctx.has_b and ctx.needs_input_grad[2] and ctx.want_w
-        # first-order backward only (under create_graph the wgrad must stay an autograd node)
-        fork = (WGRAD_SIDE_STREAM and need_w and gy.is_cuda and ctx.needs_input_grad[0] and not torch.is_grad_enabled()
-                and (WGRAD_SIDE_MAX_ROWS == 0 or ctx.N * g.P * g.Q <= WGRAD_SIDE_MAX_ROWS))
-        ctx_join = None
-        if fork:
-            side = _side_stream(gy.device)
-            side.wait_stream(torch.cuda.current_stream())      # gy is ready; the dgrad below is NOT waited for
-            with torch.cuda.stream(side):
-                if need_b:
-                    gw, gb = K.conv_wgrad(x, gy, g, with_bias=True, relu_x=ctx.relu_in)
-                else:
-                    gw = K.conv_wgrad(x, gy, g, relu_x=ctx.relu_in)
-            ctx_join = side
-        elif need_w and not torch.is_grad_enabled():
+        # (the weight gradient on a side stream next to the data gradient was measured: -7 %, cross-stream joins cost more than the idle
+        # they fill - removed)
+        if need_w and not torch.is_grad_enabled():
             gw, gb = _wgrad(x, gy, w, g, ctx.relu_in, need_b)          # first-order pass: may be queued (deferred_wgrads)
         elif need_w and need_b:
             gw, gb = ConvWgradBiasFn.apply(x, gy, g, ctx.relu_in)       # bias gradient rides the wgrad kernel
@@ -387,11 +363,6 @@ class ConvFn(Function):
             gx = g_fork
         if ctx.has_resid and ctx.needs_input_grad[3]:
             gr = gr_alias if gr_alias is not None else (Pool2Fn.apply(gy, 1.0) if ctx.resid_up else gy)
-        if fork:
-            torch.cuda.current_stream().wait_stream(ctx_join)
-            for t in (gw, gb):
-                if t is not None:
-                    t.record_stream(torch.cuda.current_stream())
         return gx, gw, gb, gr, None, None, None, None, None
 
 

@@ -288,17 +288,6 @@ def _cat_rows(a, b):
     return torch.cat([a, b], dim=0)
 
 
-class _nullctx:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *a):
-        return False
-
-
-# A/B switch: gradient-penalty branch on a side stream (parallel hipGraph branch).  Measured neutral (-1 %):
-# every kernel of the step already spans all CUs, so overlap only adds contention.  Default off.
-GP_SIDE_STREAM = _os.environ.get('CTGAN_GP_STREAM', '0') != '0'
 # A/B switch: the tail's dropouts (and the final ReLU) inside the neighbouring conv kernels (see DiscriminatorTail)
 DROP_FUSION = _os.environ.get('CTGAN_DROP_FUSION', '1') != '0'
 # A/B switch: the generator's upsampled 1x1 shortcut is read at low resolution by the epilogue of the block's last conv
@@ -406,13 +395,6 @@ class Trainer:
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
 
-    def _gp_stream(self):
-        if not (GP_SIDE_STREAM and self.dev.type == 'cuda'):
-            return None
-        if getattr(self, '_gp_side', None) is None:
-            self._gp_side = torch.cuda.Stream(device=self.dev)
-        return self._gp_side
-
     # ------------------------------------------------------------------ losses
     def d_losses(self, real_int, labels, rnd=None, fake=None):
         """Critic loss graph :194-305.  `rnd` (parity mode) injects every random draw; see
@@ -439,25 +421,18 @@ class Trainer:
                 interp = K.interpolate(real, fake, alpha)
                 rf = _cat_rows(real, fake)
 
-        # gradient penalty :277-286, issued FIRST and on a side stream: it is independent of the two dropout
-        # passes until the losses are summed, so the GPU overlaps its small launches (n=64 rows) with the main
-        # branch (hipGraph capture turns the two streams into parallel graph branches).  The critic is piecewise
-        # linear (no normalisation in D), so the penalty reaches the weights only through the backward ops:
-        # skip the forward's own wgrads.
+        # gradient penalty :277-286, issued FIRST.  The critic is piecewise linear (no normalisation in D), so the penalty reaches the
+        # weights only through the backward ops: skip the forward's own wgrads.  (The branch on a side stream - parallel hipGraph
+        # branches - was measured: -1 %, every kernel of the step already spans all CUs; removed.)
         interp.requires_grad_(True)
-        side = self._gp_stream()
-        if side is not None:
-            F.prepare_dgrad_filters(self.d_params)
-            side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side) if side is not None else _nullctx():
-            fuse_heads = _heads_fusable(rnd, rng)
-            use_ac = cfg.CONDITIONAL and cfg.ACGAN
-            tail = None
-            if TAIL_SHARE and tape is not None and fuse_heads:
-                tail = shared_tail_forward(tape[-1], B, rng, with_clean=use_ac)
-            gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None,
-                                                        tail_tape=(tail[0],) + tail[3]['gp'] if tail is not None else None,
-                                                        specs=tail[1] if tail is not None else None)
+        fuse_heads = _heads_fusable(rnd, rng)
+        use_ac = cfg.CONDITIONAL and cfg.ACGAN
+        tail = None
+        if TAIL_SHARE and tape is not None and fuse_heads:
+            tail = shared_tail_forward(tape[-1], B, rng, with_clean=use_ac)
+        gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None,
+                                                    tail_tape=(tail[0],) + tail[3]['gp'] if tail is not None else None,
+                                                    specs=tail[1] if tail is not None else None)
 
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
         if tape is not None:
@@ -483,13 +458,13 @@ class Trainer:
             cost, wgan, ct, acgan, disc_wgan, d_all = F.critic_tail_heads(
                 y, P('Discriminator.Output.W'), P('Discriminator.Output.b'),
                 P('Discriminator.ACGANOutput.W') if use_ac else None, P('Discriminator.ACGANOutput.b') if use_ac else None,
-                labels, B, cfg.LAMBDA_2, cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, gp if side is None else None)
+                labels, B, cfg.LAMBDA_2, cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, gp)
         else:
             tail_in = _cat_rows(h, h[:B])
             d_all, f_all, a_all = DiscriminatorTail(tail_in, 0.8, 0.5, 0.5, u=u, rng=rng)
             # every loss head of the two dropout passes in one kernel (fwd) / one kernel (bwd): wgan :244, CT :288-291, ACGAN :246-248
             cost, wgan, ct, acgan, disc_wgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2,
-                                                              cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp if side is None else None)
+                                                              cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp)
         if use_ac:
             with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
                 if tail is not None:       # rows of the shared tail forward (ReLU already applied, no dropout in this range)
@@ -510,15 +485,6 @@ class Trainer:
             out['acc_real'], out['acc_fake'] = acc[0], acc[1]
         else:
             acgan = None
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            for t in (gp, slopes, grads):
-                t.record_stream(torch.cuda.current_stream())
-
-        if side is not None:                     # GP branch on a side stream: joined above, added here
-            cost = cost + gp
-            with torch.no_grad():
-                disc_wgan = disc_wgan + gp
         out.update(cost=cost, wgan=disc_wgan, acgan=acgan, wgan_only=wgan, ct=ct, gp=gp, slopes=slopes, fake=fake,
                    real=real, d_real=d_all[:B], d_fake=d_all[B:2 * B], gp_grads=grads)
         return out

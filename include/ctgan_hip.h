@@ -240,6 +240,9 @@ int ctgan_conv2d16_wgrad(const ctgan_conv_desc* d, int mma, const float* x, cons
  * tiles they stage; fixed-order reduction): replaces the separate ctgan_colsum pass.  db NULL = ctgan_conv2d16_wgrad.              */
 int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x, const float* dy, float* dw, float* db, void* ws,
                               size_t ws_bytes, int flags, ctgan_stream_t stream);
+/* flags of ctgan_conv2d16_wgrad(_bias) besides CTGAN_IN_RELU: launch only the split-K GEMM (slabs stay in ws) / only the reduction of
+   slabs a GEMM-only call left there - bench.py times the two kernels apart, as rocprofv3 lists them                               */
+enum { CTGAN_WGRAD16_GEMM_ONLY = 0x100, CTGAN_WGRAD16_REDUCE_ONLY = 0x200 };
 /* dw[r,s,c,k] = sum_{n,p,q} x[..] * dy[n,k,p,q]   (HWIO, contiguous; deterministic split-K);
  * db[k] = sum_{n,p,q} dy[n,k,p,q] when db != NULL (tf.nn.bias_add gradient, fused when possible) */
 int ctgan_conv2d_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
