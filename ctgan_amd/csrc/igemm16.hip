@@ -1405,33 +1405,39 @@ bool conv16x3h_ok(const P16& p, PatchGeom* out, int bmp = 128) {
     if (out) *out = g;
     return true;
 }
-// Pixels per workgroup tile of the fragment-streaming halo kernel for this launch: the largest of 128 / 64 / 32 whose tiles fill the
-// chip (>= 192 workgroups; the smallest that qualifies otherwise).  0: no tile shape qualifies.
+// Pixels per workgroup tile of the fragment-streaming halo kernel for this launch.  Preference order by image size, from the tile sweep
+// (profiles/r03_hf_tile_sweep_*.txt; TFLOP/s forward at 128 / 64 / 32 pixels): 32x32 images 196-221 / 173-195 / 155-184; 16x16 images
+// 177 / 186-188 / 169-175 (64 rows: 95 / 144 / 150); 8x8 images 50-76 / 83-117 / 108-127 - the first that qualifies with >= 192 tiles,
+// else the first that qualifies.  0: no tile shape qualifies.
 int conv16x3hf_tile(const P16& p) {
     static const int force = [] { const char* e = getenv("CTGAN_X3_HF_TILE"); return e ? atoi(e) : 0; }();
     if (force && conv16x3h_ok(p, nullptr, force)) return force;
-    int last = 0;
-    for (int bmp = 128; bmp >= 32; bmp >>= 1) {
+    static const int pref_big[3] = {128, 64, 32}, pref_16[3] = {64, 128, 32}, pref_8[3] = {32, 64, 128};
+    const int PQ = p.P * p.Q;
+    const int* pref = PQ >= 1024 ? pref_big : (PQ >= 256 ? pref_16 : pref_8);
+    int first = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int bmp = pref[k];
         if (!conv16x3h_ok(p, nullptr, bmp)) continue;
-        last = bmp;
+        if (!first) first = bmp;
         if ((long long)(p.M / bmp) * (p.Ng / 128) >= 192) return bmp;
     }
-    return last;
+    return first;
 }
-// Which launches the hybrid (fp32-mode) routing hands to the fragment-streaming kernel, from tools/conv16_bench.py on the headline's
-// layers (profiles/r03_conv_bench_*.txt; TFLOP/s fp32 family / LDS-staged halo or slice kernel / this kernel):
-//   128-pixel tiles, >= 192 of them, images of >= 128 pixels: 112-129 / 171-217 / 174-224       -> this kernel
-//   128-pixel tiles over whole 8x8 images (384 rows):         104 / 144 / 132                   -> the LDS-staged halo kernel
-//   64-pixel tiles on 16x16 images (64 rows):                 103 / 130 / 137                   -> this kernel
-//   64- / 32-pixel tiles on 8x8 images (64-192 rows):         69-94 / 47-105 / 50-105           -> stay on the fp32 family (its fused
-//                                                                                                  epilogues and K-split tiles win or tie)
+// how the 8x8 layers run in the hybrid (fp32-mode) routing: 1 = 64-pixel x 64-kout tiles (conv16x3hf_sq64, default), 2 = 32-pixel x 128-kout
+// tiles, 0 = only the 384-row launches on the LDS-staged halo kernel (round 2)
+int x3_8x8_mode() { static const int v = [] { const char* e = getenv("CTGAN_X3_8X8"); return e ? atoi(e) : 1; }(); return v; }
+// Which launches the hybrid routing hands to the fragment-streaming kernel (tools/conv16_bench.py on the headline's layers,
+// profiles/r03_conv_bench_*.txt, profiles/r03_hf_tile_sweep_*.txt; fp32 family for comparison: 112-129 on 32x32 / 16x16 images at 128-320 rows,
+// 103 at (64, 16x16), 69 / 89 / 94 / 104 at 8x8 images of 64 / 128 / 192 / 384 rows): every launch whose preferred tile yields >= 192 workgroups on
+// images of >= 256 pixels; 8x8 images per x3_8x8_mode() from 128 rows up (64 rows: 53 against the fp32 family's 69 - stays there).
 bool conv16x3hf_wins(const P16& p) {
     const int bmp = conv16x3hf_tile(p);
     if (!bmp) return false;
     const long long tiles = (long long)(p.M / bmp) * (p.Ng / 128);
     const int PQ = p.P * p.Q;
-    if (bmp == 128) return tiles >= 192 && PQ >= 128;
-    return bmp == 64 && tiles >= 192 && PQ >= 256;
+    if (PQ >= 256) return tiles >= 192;
+    return PQ == 64 && x3_8x8_mode() == 2 && bmp == 32 && tiles >= 256;
 }
 // CTGAN_X3_HALO_V=1: the filter through an LDS stage (conv16x3h_kernel, 128-pixel tiles only); default 2: filter fragments streamed
 // from L2 (conv16x3hf_kernel, 128- / 64- / 32-pixel tiles)
@@ -1466,9 +1472,8 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
 }
 // 8x8 images: 64-pixel x 64-kout tiles (one image, half a 128-channel layer) when they fill the chip - see the kernel's KW parameter
 bool conv16x3hf_sq64(const P16& p) {
-    static const bool off = [] { const char* e = getenv("CTGAN_X3_HF_SQ64"); return e && atoi(e) == 0; }();
-    return !off && halo_version() != 1 && p.Wf != nullptr && p.P * p.Q == 64 && p.Ng % 64 == 0 && conv16x3h_ok(p, nullptr, 64) &&
-           (long long)(p.M / 64) * (p.Ng / 64) >= 256;
+    return x3_8x8_mode() == 1 && halo_version() != 1 && p.Wf != nullptr && p.P * p.Q == 64 && p.Ng % 64 == 0 && conv16x3h_ok(p, nullptr, 64) &&
+           (long long)(p.M / 64) * (p.Ng / 64) >= 384;      // from 192 rows up (128 rows: 84-101 against the fp32 family's 89)
 }
 
 int launch_conv16x3h(const P16& p, hipStream_t st) {
@@ -1478,7 +1483,7 @@ int launch_conv16x3h(const P16& p, hipStream_t st) {
         return p.relu_in ? launch_conv16x3hf_t<true, 1, 2>(p, pg, st) : launch_conv16x3hf_t<false, 1, 2>(p, pg, st);
     }
     // whole small images per 128-pixel tile (8x8): the LDS-staged kernel is the faster one when it applies
-    const bool prefer_v1 = !g_halo_version_override && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
+    const bool prefer_v1 = !g_halo_version_override && x3_8x8_mode() == 0 && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
     if (conv16x3hf_usable(p) && !prefer_v1) {
         const int bmp = conv16x3hf_tile(p);
         PatchGeom pg;

@@ -195,7 +195,7 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
 def test_f32x3_halo_kernel_with_filter_fragments_from_l2_equals_the_lds_staged_one_bitwise(K, case):
     """conv16x3hf (filter fragments streamed from L2 in MFMA-fragment order, waves split over kout) performs the same MFMAs in the same
     order per accumulator element as conv16x3h (filter staged through LDS): forward with every epilogue and the data gradient must be
-    BIT-identical on 128-pixel tiles - any error in the fragment-order packed image or the wave -> channel map shows as a mismatch."""
+    BIT-identical (whatever the tile height: the order per accumulator element does not depend on it) - any error in the fragment-order packed image or the wave -> channel map shows as a mismatch."""
     N, C, H, W, Ko, k, st = case
     g = torch.Generator().manual_seed(5)
     geom = K.ConvGeom(C, H, W, Ko, k, k, st, False)
@@ -217,7 +217,7 @@ def test_f32x3_halo_kernel_with_filter_fragments_from_l2_equals_the_lds_staged_o
     a1, c1, d1, n1, nd1 = run(1)
     a2, c2, d2, n2, nd2 = run(2)
     assert n1.startswith('conv16x3h<128x128') and nd1.startswith('conv16x3h<128x128'), (n1, nd1)
-    assert n2.startswith('conv16x3hf<128x128') and nd2.startswith('conv16x3hf<128x128'), (n2, nd2)
+    assert n2.startswith('conv16x3hf<') and nd2.startswith('conv16x3hf<'), (n2, nd2)       # (its preferred tile height for the image size)
     assert torch.equal(a1, a2) and torch.equal(c1, c2) and torch.equal(d1, d2)
 
 
