@@ -790,12 +790,9 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
 // TN = 32-pixel sub-tiles per workgroup tile (4: 128 pixels; 2 / 1: the 64- / 32-pixel tiles of launches whose 128-pixel tiles
 // could not fill the chip - the 16x16 / 8x8 layers at 64-192 rows; the filter stream per workgroup is the same, so they trade L2
 // bytes per MFMA for workgroups).
-// KW = waves along kout (4: a 128-kout tile, every wave covers all of the tile's pixels; 2: a 64-kout x 64-pixel tile for the 8x8 layers -
-// waves 2 (kout) x 2 (pixel halves), 768 workgroups of 24 KB LDS and 159 registers for the 384-row shared forward: three per CU, all
-// co-resident, three waves per SIMD to hide each other's fragment latency - where 128-pixel tiles leave 64 CUs without work).
-template <bool RELU_IN, int TN, int KW = 4>
+template <bool RELU_IN, int TN>
 __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const PatchGeom pg) {
-    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, MAXIT = 8, PWV = 4 / KW, BMP = PWV * TN * 32, KOUT = KW * 32;
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, MAXIT = 8, BMP = TN * 32;
     constexpr int LDS_K = BK + 8;
     constexpr int LDE = 32 + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -805,13 +802,12 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the filter stream's offset lives in SGPRs (no waterfall loop around its loads)
     const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
-    const int tiles_n = p.Ng / KOUT;
+    const int tiles_n = p.Ng / 128;
     int bid = blockIdx.x;
     const int nb = gridDim.x;
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // neighbouring pixel tiles (shared halo rows) on one XCD
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BMP, n0 = tile_n * KOUT;
-    const int wk = wave % KW, wp = wave / KW;              // this wave's 32-kout block / pixel block of the tile (wave-uniform)
+    const int m0 = tile_m * BMP, n0 = tile_n * 128;
     const int nch = p.C / BK;
     const int PQ = p.P * p.Q;
     const int img = m0 / PQ, row0 = (m0 - img * PQ) / p.Q;
@@ -820,7 +816,7 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
     const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
     // ---- filter fragment stream of this wave: output channels n0 + 32*wave .. +31; 6 KB per (chunk, tap) step, steps contiguous
     const unsigned a_voff = (unsigned)lane * 16u;
-    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((long long)((n0 >> 5) + wk) * nch * RS * 6144));
+    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((long long)((n0 >> 5) + wave) * nch * RS * 6144));
     u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
     auto loadA = [&](auto setc) __attribute__((always_inline)) {
         constexpr int SET = decltype(setc)::value;
@@ -880,7 +876,7 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
     int pix[TN];                                           // patch index (tap (0,0)) of this lane's pixel in fragment j: tile pixel 32*j + l31
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int tp = (wp * TN + j) * 32 + l31, per = pg.TR * p.Q, ti = tp / per, tr = tp - ti * per;
+        const int tp = j * 32 + l31, per = pg.TR * p.Q, ti = tp / per, tr = tp - ti * per;
         pix[j] = (ti * pg.PIMG + (tr / p.Q) * pg.PW + (tr % p.Q)) * LDS_K + h * 8;
     }
     constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
@@ -946,7 +942,7 @@ __global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const Patc
 #pragma unroll
         for (int it = 0; it < 32 / ROWS_PER; ++it) {
             const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
-            const int m = m0 + (wp * TN + jh) * 32 + row, col = n0 + wk * 32 + c4 * 4;
+            const int m = m0 + jh * 32 + row, col = n0 + wave * 32 + c4 * 4;
             float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
             const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
             const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
@@ -1424,8 +1420,10 @@ int conv16x3hf_tile(const P16& p) {
     }
     return first;
 }
-// how the 8x8 layers run in the hybrid (fp32-mode) routing: 1 = 64-pixel x 64-kout tiles (conv16x3hf_sq64, default), 2 = 32-pixel x 128-kout
-// tiles, 0 = only the 384-row launches on the LDS-staged halo kernel (round 2)
+// the 8x8 layers in the hybrid (fp32-mode) routing: 1 (default) = 32-pixel x 128-kout tiles of the fragment-streaming kernel from 192 rows up
+// (768 workgroups of 15 KB LDS and 159 registers for the 384-row shared forward: three per CU, all co-resident, three waves per SIMD -
+// where 128-pixel tiles gave 192 workgroups for 256 CUs); 0 = round 2: only the 384-row launches, on the LDS-staged halo kernel.
+// Measured on one box: 15.69 vs 16.08 ms per iteration (64-pixel x 64-kout tiles with waves 2 x 2: the same 15.69 - dropped).
 int x3_8x8_mode() { static const int v = [] { const char* e = getenv("CTGAN_X3_8X8"); return e ? atoi(e) : 1; }(); return v; }
 // Which launches the hybrid routing hands to the fragment-streaming kernel (tools/conv16_bench.py on the headline's layers,
 // profiles/r03_conv_bench_*.txt, profiles/r03_hf_tile_sweep_*.txt; fp32 family for comparison: 112-129 on 32x32 / 16x16 images at 128-320 rows,
@@ -1437,7 +1435,7 @@ bool conv16x3hf_wins(const P16& p) {
     const long long tiles = (long long)(p.M / bmp) * (p.Ng / 128);
     const int PQ = p.P * p.Q;
     if (PQ >= 256) return tiles >= 192;
-    return PQ == 64 && x3_8x8_mode() == 2 && bmp == 32 && tiles >= 256;
+    return PQ == 64 && x3_8x8_mode() == 1 && bmp == 32 && tiles >= 384;
 }
 // CTGAN_X3_HALO_V=1: the filter through an LDS stage (conv16x3h_kernel, 128-pixel tiles only); default 2: filter fragments streamed
 // from L2 (conv16x3hf_kernel, 128- / 64- / 32-pixel tiles)
@@ -1448,40 +1446,27 @@ int halo_version() {
 }
 bool conv16x3hf_usable(const P16& p) { return halo_version() != 1 && p.Wf != nullptr && conv16x3hf_tile(p) > 0; }
 
-template <bool RELU_IN, int TN, int KW = 4>
+template <bool RELU_IN, int TN>
 int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
-    constexpr int BMP = (4 / KW) * TN * 32, KOUT = KW * 32;
     const size_t epi = (size_t)4 * 32 * 36 * 4, stage = (size_t)3 * pg.NPX * 40 * 2;
     const size_t lds = stage > epi ? stage : epi;
     static size_t have = 0;
     if (have < lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv16x3hf_kernel<RELU_IN, TN, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv16x3hf_kernel<RELU_IN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3hf: cannot reserve %zu B of LDS", lds);
         have = lds;
     }
     P16 q = p;
-    q.ph_tiles_m = p.M / BMP;
+    q.ph_tiles_m = p.M / (TN * 32);
     q.dbg = dbg16();
     q.ksplit = 1; q.slab = nullptr;
-    hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN, KW>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / KOUT))), dim3(256), lds, st, q, pg);
-    char name[48];
-    snprintf(name, sizeof name, "conv16x3hf<%dx%d,k32>", BMP, KOUT);
-    ctgan_set_last_kernel(name);
-    ctgan_set_last_symbol("conv16x3hf_kernel<%s, %d, %d>", RELU_IN ? "true" : "false", TN, KW);
+    hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
+    ctgan_set_last_kernel(TN == 4 ? "conv16x3hf<128x128,k32>" : (TN == 2 ? "conv16x3hf<64x128,k32>" : "conv16x3hf<32x128,k32>"));
+    ctgan_set_last_symbol("conv16x3hf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
     return ctgan_check_launch("conv16x3hf");
-}
-// 8x8 images: 64-pixel x 64-kout tiles (one image, half a 128-channel layer) when they fill the chip - see the kernel's KW parameter
-bool conv16x3hf_sq64(const P16& p) {
-    return x3_8x8_mode() == 1 && halo_version() != 1 && p.Wf != nullptr && p.P * p.Q == 64 && p.Ng % 64 == 0 && conv16x3h_ok(p, nullptr, 64) &&
-           (long long)(p.M / 64) * (p.Ng / 64) >= 384;      // from 192 rows up (128 rows: 84-101 against the fp32 family's 89)
 }
 
 int launch_conv16x3h(const P16& p, hipStream_t st) {
-    if (!g_halo_version_override && conv16x3hf_sq64(p)) {
-        PatchGeom pg;
-        conv16x3h_ok(p, &pg, 64);
-        return p.relu_in ? launch_conv16x3hf_t<true, 1, 2>(p, pg, st) : launch_conv16x3hf_t<false, 1, 2>(p, pg, st);
-    }
     // whole small images per 128-pixel tile (8x8): the LDS-staged kernel is the faster one when it applies
     const bool prefer_v1 = !g_halo_version_override && x3_8x8_mode() == 0 && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
     if (conv16x3hf_usable(p) && !prefer_v1) {
@@ -1513,7 +1498,7 @@ int launch_conv16x3h(const P16& p, hipStream_t st) {
     return ctgan_check_launch("conv16x3h<128x128,k32>");
 }
 // can launch_conv16x3h take this launch (either kernel)?
-bool halo_takes(const P16& p) { return conv16x3hf_usable(p) || conv16x3h_ok(p, nullptr) || conv16x3hf_sq64(p); }
+bool halo_takes(const P16& p) { return conv16x3hf_usable(p) || conv16x3h_ok(p, nullptr); }
 
 template <int MMA>
 int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st);
@@ -1543,7 +1528,6 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
         // split mode: stride-1 whole-row tiles go to the halo-patch kernel; everything else to the slice kernels with three planes per
         // operand in LDS - 32-deep slices, the 128x128 tile with ONE 60 KB stage (two workgroups per CU)
         static const int halo = [] { const char* e = getenv("CTGAN_X3_HALO"); return e ? atoi(e) : 1; }();      // 2: also for launches of few tiles (tests)
-        if (halo && conv16x3hf_sq64(p)) return launch_conv16x3h(p, st);
         if (halo && halo_takes(p)) {
             const int bmp = conv16x3hf_usable(p) ? conv16x3hf_tile(p) : 128;
             if (!small || halo == 2 || (bmp < 128 && (long long)(p.M / bmp) * (p.Ng / 128) >= 96)) return launch_conv16x3h(p, st);
@@ -1689,7 +1673,7 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
         // the fragment-streaming halo kernel has 64- and 32-pixel tiles: the 16x16 / 8x8 layers at 64-192 rows qualify too
         P16 q = p;
         q.Wf = reinterpret_cast<const unsigned short*>(d);      // (any non-null value: only the shape matters here)
-        if (conv16x3hf_wins(q) || conv16x3hf_sq64(q)) return 1;
+        if (conv16x3hf_wins(q)) return 1;
     }
     if (!conv16x3h_ok(p, nullptr)) return 0;
     return (long long)(p.M / 128) * (p.Ng / 128) >= 192 ? 1 : 0;

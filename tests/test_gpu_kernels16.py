@@ -126,11 +126,11 @@ X3_CASES = CASES + [
     (64, 32, 16, 16, 128, 3, 1),      # 16-wide, 64-pixel tiles = 4 rows (256 tiles)
     (12, 64, 32, 32, 128, 3, 1),      # 32-wide, 64-pixel tiles = 2 rows (192 tiles)
     (48, 32, 8, 8, 128, 3, 1),        # 8x8 images, 32-pixel tiles = half an image (96 tiles)
-    (160, 32, 8, 8, 256, 3, 1),       # 8x8 images, 64-pixel tiles = one image; two kout tiles (320 tiles)
-    (192, 128, 8, 8, 128, 3, 1),      # 8x8 images, 64-pixel x 64-kout tiles (waves 2 x 2), forward and data gradient (384 workgroups)
+    (160, 32, 8, 8, 256, 3, 1),       # 8x8 images, 32-pixel tiles = half an image; two kout tiles (640 tiles)
+    (192, 128, 8, 8, 128, 3, 1),      # 8x8 images, 32-pixel tiles, forward and data gradient (384 workgroups)
 ]
 X3_SMALL_TILE = {(64, 32, 16, 16, 128, 3, 1): '64x128', (12, 64, 32, 32, 128, 3, 1): '64x128', (48, 32, 8, 8, 128, 3, 1): '32x128',
-                 (160, 32, 8, 8, 256, 3, 1): '64x64', (192, 128, 8, 8, 128, 3, 1): '64x64', (384, 32, 8, 8, 128, 3, 1): '64x64'}
+                 (160, 32, 8, 8, 256, 3, 1): '32x128', (192, 128, 8, 8, 128, 3, 1): '32x128', (384, 32, 8, 8, 128, 3, 1): '32x128'}
 
 
 @pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d' % c)
