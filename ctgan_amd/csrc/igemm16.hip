@@ -280,7 +280,7 @@ template <int MMA, int TM, int TN> constexpr bool conv16_one_wave() { return TM 
 // not weave the staging between the MFMAs), 120-143 for 4 producer + 4 consumer waves per workgroup and 128-150 for the same as a
 // persistent kernel: VALU and LDS stores issued beside a saturated MFMA stream on the same SIMD are not free
 // (tools/mfma_loop_probe.hip: 100 VALU + 18 stores per 48 MFMAs cost 35 % of the matrix rate), whichever wave issues them.
-template <int MMA, int TM, int TN> constexpr bool conv16_single_stage() { return planes<MMA>() == 3 && TM * TN >= 4; }
+template <int MMA, int TM, int TN> constexpr bool conv16_single_stage() { return planes<MMA>() == 3 && TM * TN >= 2; }      // (2 x 1: the 128-kout x 64-pixel tile, 46 KB: three per CU)
 // pixel sub-tiles per epilogue pass (the wide tiles take several passes: <= 70 KB of staging; the single-stage tile: 35 KB)
 template <int MMA, int TM, int TN> constexpr int conv16_je() { return TM >= 4 ? 1 : (TN > 2 ? 2 : (conv16_single_stage<MMA, TM, TN>() ? 1 : TN)); }
 
@@ -791,8 +791,9 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
 // could not fill the chip - the 16x16 / 8x8 layers at 64-192 rows; the filter stream per workgroup is the same, so they trade L2
 // bytes per MFMA for workgroups).
 template <bool RELU_IN, int TN>
-__global__ __launch_bounds__(256) void conv16x3hf_kernel(const P16 p, const PatchGeom pg) {
-    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, MAXIT = 8, BMP = TN * 32;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3 : 2))) void conv16x3hf_kernel(const P16 p, const PatchGeom pg) {
+    // (MAXIT = float4 patch items per thread the registers hold: conv16x3hf_maxit on the host side)
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, MAXIT = TN == 4 ? 8 : (TN == 2 ? 6 : 4), BMP = TN * 32;
     constexpr int LDS_K = BK + 8;
     constexpr int LDE = 32 + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -1397,7 +1398,7 @@ bool conv16x3h_ok(const P16& p, PatchGeom* out, int bmp = 128) {
     g.TR = PQ < bmp ? p.P : bmp / p.Q;
     g.PW = p.Q + S - 1; g.PIMG = (g.TR + R - 1) * g.PW; g.NPX = g.IMGS * g.PIMG;
     g.n_it = (g.NPX * 8 + 255) / 256;
-    if (g.n_it > 8 || conv16x3h_lds(g) > 80 * 1024) return false;      // two workgroups per CU
+    if (g.n_it > (bmp == 128 ? 8 : (bmp == 64 ? 6 : 4)) || conv16x3h_lds(g) > 80 * 1024) return false;      // the kernels' patch registers (MAXIT); two workgroups per CU
     if (out) *out = g;
     return true;
 }
@@ -1533,6 +1534,14 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
             if (!small || halo == 2 || (bmp < 128 && (long long)(p.M / bmp) * (p.Ng / 128) >= 96)) return launch_conv16x3h(p, st);
         }
         if (small) return launch_conv16<MMA, 1, 1, 32>(p, st, p.ksplit > 1 ? "conv16x3<64x64,k32,ksplit>" : "conv16x3<64x64,k32>");
+        {
+            // launches whose 128x128 tiles leave workgroup slots empty (< 512: the stride-2 layers at 128-192 rows have 256-384) run on
+            // 128-kout x 64-pixel tiles, 46 KB of LDS and 112 registers: three workgroups per CU.  Measured (one box): (192, 32x32, 4x4 s2)
+            // forward 144 -> 152, (192, 16x16) data gradient 125 -> 135 TFLOP/s, iteration 16.13 -> 16.02 ms.  CTGAN_X3_SLICE64=0: off, 2: always.
+            static const int s64 = [] { const char* e = getenv("CTGAN_X3_SLICE64"); return e ? atoi(e) : 1; }();
+            const long long t128 = (long long)p.nph * ((p.M + 127) / 128) * (p.Ng / 128);
+            if (s64 && p.Ng % 128 == 0 && (s64 == 2 || t128 < 512)) return launch_conv16<MMA, 2, 1, 32>(p, st, "conv16x3<128x64,k32>");
+        }
         return launch_conv16<MMA, 2, 2, 32>(p, st, "conv16x3<128x128,k32>");
     } else
     if (p.C % 64 == 0) {

@@ -289,7 +289,6 @@ def _cat_rows(a, b):
     return torch.cat([a, b], dim=0)
 
 
-GP_SIDE_STREAM = _os.environ.get('CTGAN_GP_STREAM', '0') != '0'
 # A/B switch: the tail's dropouts (and the final ReLU) inside the neighbouring conv kernels (see DiscriminatorTail)
 DROP_FUSION = _os.environ.get('CTGAN_DROP_FUSION', '1') != '0'
 # A/B switch: the generator's upsampled 1x1 shortcut is read at low resolution by the epilogue of the block's last conv
@@ -397,14 +396,6 @@ class Trainer:
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
 
-    def _gp_stream(self):
-        """EXPERIMENT (CTGAN_GP_STREAM=1): the gradient-penalty branch of the shared-forward step on a side stream."""
-        if not (GP_SIDE_STREAM and self.dev.type == 'cuda'):
-            return None
-        if getattr(self, '_gp_side', None) is None:
-            self._gp_side = torch.cuda.Stream(device=self.dev)
-        return self._gp_side
-
     # ------------------------------------------------------------------ losses
     def d_losses(self, real_int, labels, rnd=None, fake=None):
         """Critic loss graph :194-305.  `rnd` (parity mode) injects every random draw; see
@@ -433,28 +424,18 @@ class Trainer:
 
         # gradient penalty :277-286, issued FIRST.  The critic is piecewise linear (no normalisation in D), so the penalty reaches the
         # weights only through the backward ops: skip the forward's own wgrads.  (The branch on a side stream - parallel hipGraph
-        # branches - was measured: -1 %, every kernel of the step already spans all CUs; removed.)
+        # branches, so that the penalty's 64-row double backward overlaps the main pass's backward - was measured twice: -1 % in round 1,
+        # -2.5 % in round 3 (16.47 vs 16.06 ms on one box): removed.)
         interp.requires_grad_(True)
         fuse_heads = _heads_fusable(rnd, rng)
         use_ac = cfg.CONDITIONAL and cfg.ACGAN
         tail = None
         if TAIL_SHARE and tape is not None and fuse_heads:
             tail = shared_tail_forward(tape[-1], B, rng, with_clean=use_ac)
-        side = self._gp_stream() if tail is not None else None
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())      # the shared forward launches (and the filter rebuild) are enqueued
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None,
+        gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None,
                                                         tail_tape=(tail[0],) + tail[3]['gp'] if tail is not None else None,
                                                         specs=tail[1] if tail is not None else None)
 
-        if side is not None:
-            # the penalty's first-order pass (64-row launches) ran on the side stream while the main stream goes on below; the heads
-            # kernel adds gp, so join here.  What the fork buys is the BACKWARD: autograd runs a node on the stream of its forward, so
-            # the penalty's double backward (64-row launches that fill a quarter of the chip) overlaps the main pass's backward.
-            torch.cuda.current_stream().wait_stream(side)
-            for t in (gp, slopes, grads):
-                t.record_stream(torch.cuda.current_stream())
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
         if tape is not None:
             with F.tape_replay(tape, 0, 2 * B):

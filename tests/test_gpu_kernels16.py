@@ -176,7 +176,7 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
     assert kern1['fwd'].startswith('igemm') or kern1['fwd'].startswith('fewch'), kern1
     assert kern3['fwd'].startswith('conv16x3') and kern3['dgrad'].startswith('conv16x3'), kern3
     if case in X3_CASES[len(CASES):]:
-        want_kernel = 'conv16x3h' if st == 1 else 'conv16x3<128x128'
+        want_kernel = 'conv16x3h' if st == 1 else 'conv16x3<128x'       # (stride 2: the slice kernel, 128 kout x 128 or 64 pixels)
         if case in X3_SMALL_TILE:
             want_kernel = 'conv16x3hf<' + X3_SMALL_TILE[case]
         assert kern3['fwd'].startswith(want_kernel) and (C % 128 != 0 or kern3['dgrad'].startswith(want_kernel)), kern3
