@@ -23,6 +23,15 @@ ITERATION_GRAPH = _os.environ.get('CTGAN_ITERATION_GRAPH', '1') != '0'
 AR_IN_GRAPH = _os.environ.get('CTGAN_AR_IN_GRAPH', '0') != '0'
 
 
+def _capture_kw():
+    """Keyword arguments of torch.cuda.graph for this process.  With a process group alive, the c10d RCCL watchdog thread polls its work
+    events (hipEventQuery) at any time - under the default GLOBAL capture error mode a poll that lands inside a capture aborts the
+    process ("operation not permitted when stream is capturing": seen once in four runs of the 1-rank test).  THREAD_LOCAL mode restricts
+    the capture's legality checks to the capturing thread, which is what the PyTorch notes prescribe for graphs next to NCCL."""
+    import torch.distributed as dist
+    return {'capture_error_mode': 'thread_local'} if (dist.is_available() and dist.is_initialized()) else {}
+
+
 class GraphedTrainer:
     def __init__(self, trainer, use_graphs=True, warmup=2, ar_in_graph=None):
         self.t = trainer
@@ -147,14 +156,14 @@ class GraphedTrainer:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self.d_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.d_graph):
+            with torch.cuda.graph(self.d_graph, **_capture_kw()):
                 self.d_out = self._d_body()
             self.g_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_graph):
+            with torch.cuda.graph(self.g_graph, **_capture_kw()):
                 self.g_out = self._g_body()
             if self.batch_fakes:
                 self.f_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.f_graph):
+                with torch.cuda.graph(self.f_graph, **_capture_kw()):
                     self.fake_all = self._f_body()
                 if self.adam_in_graph and ITERATION_GRAPH:
                     # Seven graph launches per iteration leave ~150 us of idle GPU at each boundary (profiles/
@@ -162,7 +171,7 @@ class GraphedTrainer:
                     # Optional: if only this capture fails (a fourth private pool), the three per-step graphs stay in use.
                     try:
                         self.it_graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(self.it_graph):
+                        with torch.cuda.graph(self.it_graph, **_capture_kw()):
                             self.it_out = self._it_body()
                     except Exception as e:
                         self.it_graph = self.it_out = None
@@ -335,10 +344,10 @@ class GraphedDCGANTrainer:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self.d_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.d_graph):
+            with torch.cuda.graph(self.d_graph, **_capture_kw()):
                 self.d_out = self._body('d')
             self.g_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_graph):
+            with torch.cuda.graph(self.g_graph, **_capture_kw()):
                 self.g_out = self._body('g')
         finally:
             torch.cuda.synchronize()
