@@ -11,6 +11,7 @@ averaging is the faithful generalisation; generator BatchNorm statistics stay pe
 reference's per-tower statistics (no SyncBN).
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -31,7 +32,21 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local)
         elif torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # RCCL (and gloo) print banner lines to the process's C-level stdout when the first communicator is created ("Librccl path : ...",
+        # "[Gloo] Rank 0 is connected ..."); the rank-0 stdout of bench.py is a one-JSON-line contract, so file descriptor 1 points at
+        # stderr while the group and its first collective are set up.
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            t = torch.zeros(1, device=torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t)
+            if t.is_cuda:
+                torch.cuda.synchronize()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     return rank, world, local
 
 

@@ -12,11 +12,13 @@ import sys
 
 d = sys.argv[1]
 info = json.load(open(os.path.join(d, 'info.json')))
+if os.path.exists(os.path.join(d, 'info_group.json')):
+    info.update(json.load(open(os.path.join(d, 'info_group.json'))))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, 'counters_*.csv')):
     for r in csv.DictReader(open(f)):
         k = r.get('Kernel_Name', '')
-        m = re.search(r'((conv16x3hf|conv16x3h|conv16|wgrad16)_kernel<[^>]*>)', k)
+        m = re.search(r'((conv16x3hf|conv16x3h|conv16|wgrad16|igemm_wgrad_pipe_group)_kernel<[^>]*>)', k)
         if m:
             agg[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {'_how': 'tools/pmc_x3.sh on one MI355X: separate rocprofv3 --kernel-trace --pmc passes per counter group; means over the launches '
@@ -43,8 +45,10 @@ for sym, rec in info.items():
     if busy:
         busy = 1024.0 * busy / 32.0
         o['shader_cycles_per_launch'] = round(busy / 1024.0)
-        n_mfma = rec['flops_per_launch'] * 6 / 32768.0            # six bf16 32x32x16 MFMAs (32,768 FLOP, 32 cycles each) per fp32 product
-        o['mfma_busy_check'] = '%.4g MFMAs x 32 cycles = %.4g vs SQ_VALU_MFMA_BUSY_CYCLES %.4g' % (n_mfma, n_mfma * 32, mf or 0)
+        # split mode: six bf16 32x32x16 MFMAs (32,768 FLOP, 32 cycles each) per fp32 product; fp32 family: v_mfma_f32_32x32x2 (4,096 FLOP, 64 cycles)
+        mflop, mcyc = rec.get('mfma_flop'), rec.get('mfma_cycles', 32)
+        n_mfma = rec['flops_per_launch'] / mflop if mflop else rec['flops_per_launch'] * 6 / 32768.0
+        o['mfma_busy_check'] = '%.4g MFMAs x %d cycles = %.4g vs SQ_VALU_MFMA_BUSY_CYCLES %.4g' % (n_mfma, mcyc, n_mfma * mcyc, mf or 0)
     for key, num, den in (('mfma_busy_frac', mf, busy), ('valu_active_frac', mean('SQ_ACTIVE_INST_VALU'), wave),
                           ('lds_wait_frac', mean('SQ_WAIT_INST_LDS'), wave), ('wave_parked_frac', mean('SQ_WAIT_ANY'), wave),
                           ('issue_stall_frac', mean('SQ_WAIT_INST_ANY'), wave), ('inst_active_frac', mean('SQ_ACTIVE_INST_ANY'), wave)):

@@ -36,15 +36,17 @@ def case(op, N, C, H, Ko, R, st, relu=False):
         sym = 'wgrad16_kernel<3, 2, 2, %s, false>' % ('true' if relu else 'false')
         alg = xb + yb + 4 * R * R * C * Ko
     else:
-        alg = xb + yb + 6 * R * R * C * Ko             # three bf16 planes of the packed filter
+        alg = xb + yb + 6 * R * R * C * Ko             # (dy or x) + (dx or y) + three bf16 planes of the packed filter
     info[sym] = {'geometry': '%s (N,C,H,W,K,R,stride) = (%d,%d,%d,%d,%d,%d,%d)%s' % (op, N, C, H, H, Ko, R, st, ', relu on load' if relu else ''),
                  'flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg}
 
 
 case('fwd', 192, 128, 32, 128, 3, 1, relu=False)      # conv16x3hf_kernel<false, 4> (CTGAN_X3_HALO_V=1: conv16x3h_kernel<false>)
-case('fwd', 192, 128, 16, 128, 3, 1, relu=True)       # conv16x3hf_kernel<true, 4>  (the critic's relu-on-load convs)
-case('fwd', 384, 128, 8, 128, 3, 1, relu=True)        # conv16x3h_kernel<true>: whole 8x8 images per tile (the shared tail forward)
-case('fwd', 128, 128, 32, 128, 4, 2, relu=False)      # conv16_kernel<3, 2, 2, 32, false, false>: folded ConvMeanPool, slice kernel
+case('fwd', 192, 128, 16, 128, 3, 1, relu=True)       # conv16x3hf_kernel<true, 2>: 16x16 images on 64-pixel tiles (the critic's relu-on-load convs)
+case('fwd', 384, 128, 8, 128, 3, 1, relu=True)        # conv16x3hf_kernel<true, 1>: the 384-row shared tail forward on 32-pixel tiles
+case('dgrad', 192, 128, 8, 128, 3, 1)                 # conv16x3hf_kernel<false, 1>: the main pass's 8x8 data gradients
+case('dgrad', 128, 128, 32, 128, 4, 2)                # conv16_kernel<3, 2, 2, 32, false, false>: four-phase data gradient of the folded ConvMeanPool, 1024 tiles
+case('fwd', 192, 128, 32, 128, 4, 2, relu=True)       # conv16_kernel<3, 2, 1, 32, true, false>: its forward at 192 rows on 128-kout x 64-pixel tiles
 case('wgrad', 128, 128, 32, 128, 4, 2, relu=True)     # wgrad16_kernel<3, 2, 2, true, false>
 case('wgrad', 128, 128, 16, 128, 3, 1, relu=False)    # wgrad16_kernel<3, 2, 2, false, false>
 print(json.dumps(info))
