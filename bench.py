@@ -283,20 +283,35 @@ def launch_ranks(args, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained by a thread (a full pipe would block it); the launcher polls ALL ranks: the first rank that dies with a
+    # non-zero status ends the run - the others would otherwise sit in a collective until the RCCL timeout
+    import threading
+    import time as _time
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     status = 0
     try:
-        out, _ = procs[0].communicate()
-        for line in out.decode().splitlines():       # stdout carries the record only; library chatter (gloo prints to stdout) -> stderr
-            print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
-        sys.stdout.flush()
-        for pr in procs:
-            rc = pr.wait()
-            if rc and not status:
-                status = rc
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                status = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            _time.sleep(0.05)
     finally:
-        for pr in procs:                 # a rank that died leaves the others in a collective: end exactly the processes started here
+        for pr in procs:                 # end exactly the processes started here (never by pattern)
             if pr.poll() is None:
                 pr.kill()
+        for pr in procs:
+            pr.wait()
+        reader.join(timeout=5)
+    for line in b''.join(c for c in chunks if c).decode(errors='replace').splitlines():
+        # stdout carries the record only; library chatter (gloo / RCCL print banners to stdout) -> stderr
+        print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
+    sys.stdout.flush()
     return status
 
 
@@ -313,6 +328,8 @@ def spawn_check(args):
     import torch.distributed as dist
 
     from ctgan_amd import ddp
+    if os.environ.get('CTGAN_TEST_DIE_RANK') == os.environ.get('RANK'):       # launcher test: this rank dies before the rendezvous
+        sys.exit(7)
     rank, world, local = ddp.init_from_env(backend=args.backend or 'gloo')
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))

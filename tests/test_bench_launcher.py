@@ -50,3 +50,13 @@ def test_a_failing_rank_fails_the_launcher():
     # rank processes that cannot rendezvous with the requested backend must surface as a non-zero exit, not as a hang or a 0
     r = _run('--gpus', '2', '--backend', 'no_such_backend', '--spawn-check')
     assert r.returncode != 0
+
+
+def test_one_dying_rank_ends_the_run_instead_of_hanging_the_others():
+    """Rank 1 exits with status 7 before joining the group: rank 0 would wait in the rendezvous; the launcher must end it and return 7
+    within seconds (CTGAN_TEST_DIE_RANK is read by bench.py's rank side in --spawn-check mode only)."""
+    import time
+    t0 = time.time()
+    r = _run('--gpus', '2', '--backend', 'gloo', '--spawn-check', env={'CTGAN_TEST_DIE_RANK': '1'})
+    assert r.returncode == 7, (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 60
