@@ -24,6 +24,39 @@ __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g,
 __global__ void adam_advance_kernel(float* state, float b1, float b2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] *= b1; state[2] *= b2; }
 }
+// End of a step inside the update launch itself: the workgroup that finishes LAST (a device counter, reset for the next
+// launch) multiplies the beta powers and bumps the Philox step counter - what adam_advance_kernel and rng_advance_kernel do as
+// two dependent one-thread launches (~5 us each on the critical path of a captured step).  Every workgroup has read `state`
+// before it signals (the barrier orders its threads' reads before thread 0's fence + atomic), so the writes race with nothing.
+struct StepEnd { unsigned* done; uint64_t* ctr; uint64_t by; };
+__device__ __forceinline__ void step_end(float* state, float b1, float b2, const StepEnd& e) {
+    if (!e.done) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned total = gridDim.x * gridDim.y;
+        if (atomicAdd(e.done, 1u) == total - 1) {
+            state[1] *= b1; state[2] *= b2;
+            if (e.ctr) e.ctr[0] += e.by;
+            *e.done = 0u;
+        }
+    }
+}
+__global__ void adam_end_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long long n, float* state, float b1, float b2, float eps, float gscale,
+                                const StepEnd e) {
+    const float lr = state[0], b1p = state[1], b2p = state[2];
+    const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        th[i] = th[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+    step_end(state, b1, b2, e);
+}
 
 // Gather separately allocated gradient tensors into the flat bucket in ONE launch.  The pointer table travels
 // by value in the kernel arguments (no device table, no host->device copy => hipGraph-capture safe: the
@@ -45,6 +78,53 @@ __global__ void pack_kernel(const PackTable t, float* __restrict__ flat) {
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         flat[off + i] = src ? src[i] : 0.f;
+}
+
+// pack_kernel + adam_kernel + the step end in one launch (single-rank steps: nothing happens between the gather and the update).
+// The flat bucket is still written - it is the gradient the caller reports and the tests read.  Same per-element arithmetic as
+// adam_kernel on the packed bucket (bit-identical results).
+__global__ void adam_packed_kernel(const PackTable t, float* __restrict__ flat, float* __restrict__ th, float* __restrict__ m,
+                                   float* __restrict__ v, float* state, float b1, float b2, float eps, float gscale, const StepEnd e) {
+    const float lr = state[0], b1p = state[1], b2p = state[2];
+    const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+    const float* src = t.src[blockIdx.y];
+    const long long off = t.dst_off[blockIdx.y], n = t.n[blockIdx.y];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    if (((n | off) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {        // (the flat buffers are 16-B aligned: checked by the host)
+        const long long n4 = n >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        float4* f4 = reinterpret_cast<float4*>(flat + off);
+        float4* th4 = reinterpret_cast<float4*>(th + off);
+        float4* m4 = reinterpret_cast<float4*>(m + off);
+        float4* v4 = reinterpret_cast<float4*>(v + off);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float4 gr = src ? src4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            f4[i] = gr;
+            float4 mm = m4[i], vv = v4[i], tt = th4[i];
+            const float gv[4] = {gr.x, gr.y, gr.z, gr.w};
+            float* mp = &mm.x; float* vp = &vv.x; float* tp = &tt.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gi = gv[k] * gscale;
+                const float mi = b1 * mp[k] + (1.f - b1) * gi;
+                const float vi = b2 * vp[k] + (1.f - b2) * gi * gi;
+                mp[k] = mi; vp[k] = vi;
+                tp[k] = tp[k] - lr_t * mi / (sqrtf(vi) + eps);
+            }
+            m4[i] = mm; v4[i] = vv; th4[i] = tt;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const float gr = src ? src[i] : 0.f;
+            flat[off + i] = gr;
+            const float gi = gr * gscale;
+            const float mi = b1 * m[off + i] + (1.f - b1) * gi;
+            const float vi = b2 * v[off + i] + (1.f - b2) * gi * gi;
+            m[off + i] = mi; v[off + i] = vi;
+            th[off + i] = th[off + i] - lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+    step_end(state, b1, b2, e);
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11); constants of the Random123 reference
@@ -249,6 +329,35 @@ int ctgan_pack(const float* const* srcs, const int64_t* dst_offs, const int64_t*
         if (rc) return rc;
     }
     return CTGAN_OK;
+}
+int ctgan_adam_step_end(float* theta, const float* g, float* m, float* v, int64_t n, float* state, float beta1, float beta2,
+                        float eps, float grad_scale, uint32_t* done, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t s) {
+    if (!theta || !g || !m || !v || !state || !done || n <= 0) return ctgan_fail(CTGAN_E_BADARG, "adam_step_end: bad argument");
+    StepEnd e{done, rng_ctr, rng_by};
+    hipLaunchKernelGGL(adam_end_kernel, dim3(ctgan_blocks(n, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), theta, g, m,
+                       v, (long long)n, state, beta1, beta2, eps, grad_scale, e);
+    return ctgan_check_launch("adam_step_end");
+}
+int ctgan_adam_step_packed(const float* const* srcs, const int64_t* dst_offs, const int64_t* counts, int32_t n_tensors, float* flat,
+                           float* theta, float* m, float* v, float* state, float beta1, float beta2, float eps, float grad_scale,
+                           uint32_t* done, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t s) {
+    if (!srcs || !dst_offs || !counts || !flat || !theta || !m || !v || !state || !done || n_tensors <= 0)
+        return ctgan_fail(CTGAN_E_BADARG, "adam_step_packed: bad argument");
+    if (n_tensors > PACK_MAX) return ctgan_fail(CTGAN_E_UNSUPPORTED, "adam_step_packed: more than %d tensors", PACK_MAX);
+    if ((reinterpret_cast<uintptr_t>(flat) | reinterpret_cast<uintptr_t>(theta) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15)
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "adam_step_packed: flat buffers must be 16-byte aligned");
+    PackTable t;
+    long long mx = 1;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (counts[i] < 0 || dst_offs[i] < 0) return ctgan_fail(CTGAN_E_BADARG, "adam_step_packed: negative extent");
+        t.src[i] = srcs[i]; t.dst_off[i] = dst_offs[i]; t.n[i] = counts[i];
+        if (t.n[i] > mx) mx = t.n[i];
+    }
+    StepEnd e{done, rng_ctr, rng_by};
+    hipLaunchKernelGGL(adam_packed_kernel, dim3(ctgan_blocks(mx, 1024, 512), n_tensors), dim3(256), 0, static_cast<hipStream_t>(s), t,
+                       flat, theta, m, v, state, beta1, beta2, eps, grad_scale, e);
+    return ctgan_check_launch("adam_step_packed");
 }
 int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t s) {
     if (!state) return ctgan_fail(CTGAN_E_BADARG, "adam_advance: null");

@@ -101,12 +101,15 @@ class DCGANTrainer:
 
     def _apply(self, opt, grads):
         opt.set_lr(self.mod.lr(self.iteration) if hasattr(self.mod, 'lr') else self.mod.cfg.LR)
+        scale = 1.0 / (self.world * self.loss_scale)
+        if self.allreduce is None or self.world <= 1:
+            opt.update(grads, scale, rng=self.rng)          # bucket + Adam + end of the step (beta powers, Philox counter): one launch
+            return
         flat = opt.gather_grads(grads)
-        if self.allreduce is not None and self.world > 1:
-            self.allreduce(flat)
-            if hasattr(self.allreduce, 'wait'):
-                self.allreduce.wait()
-        opt.step(grad_scale=1.0 / (self.world * self.loss_scale))
+        self.allreduce(flat)
+        if hasattr(self.allreduce, 'wait'):
+            self.allreduce.wait()
+        opt.step(grad_scale=scale, rng=self.rng)
 
     def _unscaled(self, grads):
         if self.loss_scale == 1.0:
@@ -118,7 +121,6 @@ class DCGANTrainer:
         out = self.d_losses(real_in, rnd)
         grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.d_opt, grads)
-        self.rng.end_step()
         out['grads'] = dict(zip([n for n, _ in self.d_named], self._unscaled(grads)))
         return out
 
@@ -127,7 +129,6 @@ class DCGANTrainer:
         out = self.g_losses(rnd)
         grads = torch.autograd.grad(out['cost'], self.g_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.g_opt, grads)
-        self.rng.end_step()
         out['grads'] = dict(zip([n for n, _ in self.g_named], self._unscaled(grads)))
         return out
 

@@ -83,13 +83,24 @@ class GraphedTrainer:
         t.rng.begin_step()
         out = t.d_losses(real, labels, fake=fake)
         with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], t.d_params, allow_unused=True)
-        t.d_opt.gather_grads(grads)
-        self._reduce_in_graph(t.d_opt)
-        if self.adam_in_graph:
-            t.d_opt.step(1.0 / t.world)
-        t.rng.end_step()
+            grads = torch.autograd.grad(out['cost'], t.d_params, grad_outputs=t.cost_seed(out['cost']), allow_unused=True)
+        self._finish(t.d_opt, grads)
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
+
+    def _finish(self, opt, grads):
+        """End of a captured step body.  Adam inside the graph: bucket + update + step end in one launch (single rank), or bucket,
+        in-graph all-reduce, update + step end.  Adam outside (side-stream all-reduce): the graph ends at the packed bucket and at
+        the Philox counter's own advance - Trainer.reduce_and_update must not advance it again, hence rng=None there."""
+        t = self.t
+        if self.adam_in_graph and not self.ar_in_graph:
+            opt.update(grads, 1.0 / t.world, rng=t.rng)
+            return
+        opt.gather_grads(grads)
+        self._reduce_in_graph(opt)
+        if self.adam_in_graph:
+            opt.step(1.0 / t.world, rng=t.rng)
+        else:
+            t.rng.end_step()
 
     def _reduce_in_graph(self, opt):
         """The flat gradient bucket summed over the ranks ON the capturing stream: the collective becomes a node of the step graph."""
@@ -116,12 +127,8 @@ class GraphedTrainer:
         t.rng.begin_step()
         out = t.g_losses()
         with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], t.g_params, allow_unused=True)
-        t.g_opt.gather_grads(grads)
-        self._reduce_in_graph(t.g_opt)
-        if self.adam_in_graph:
-            t.g_opt.step(1.0 / t.world)
-        t.rng.end_step()
+            grads = torch.autograd.grad(out['cost'], t.g_params, grad_outputs=t.cost_seed(out['cost']), allow_unused=True)
+        self._finish(t.g_opt, grads)
         return {'cost': out['cost'].detach()}
 
     def _capture(self, warmup):
@@ -208,7 +215,7 @@ class GraphedTrainer:
         t.d_opt.set_lr(t.lr(iteration))
         self.d_graph.replay()
         if not self.adam_in_graph:
-            t.reduce_and_update(t.d_opt, t.d_opt.grad, between)
+            t.reduce_and_update(t.d_opt, t.d_opt.grad, between, end_rng=False)
         else:
             t.d_opt.t += 1
             self._weights_moved('Discriminator')
@@ -223,7 +230,7 @@ class GraphedTrainer:
         t.g_opt.set_lr(t.lr(iteration))
         self.g_graph.replay()
         if not self.adam_in_graph:
-            t.reduce_and_update(t.g_opt, t.g_opt.grad, between)
+            t.reduce_and_update(t.g_opt, t.g_opt.grad, between, end_rng=False)
         else:
             t.g_opt.t += 1
             self._weights_moved('Generator')
@@ -318,10 +325,11 @@ class GraphedDCGANTrainer:
             out = t.g_losses()
             params, opt = t.g_params, t.g_opt
         grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
-        opt.gather_grads(grads)
         if self.adam_in_graph:
-            opt.step(1.0 / t.loss_scale)
-        t.rng.end_step()
+            opt.update(grads, 1.0 / t.loss_scale, rng=t.rng)
+        else:
+            opt.gather_grads(grads)
+            t.rng.end_step()
         return {k: out[k].detach() for k in ('cost', 'wgan_only', 'ct', 'gp') if out.get(k) is not None}
 
     def _capture(self, warmup):

@@ -1338,6 +1338,7 @@ class GradPenaltyFn(Function):
         ctx.lam = lam
         ctx.save_for_backward(g, slopes)
         ctx.mark_non_differentiable(slopes)
+        ctx.set_materialize_grads(False)          # no zero-filled gradient for the (unused) slopes output: one fill launch per step less
         return gp, slopes
 
     @staticmethod
@@ -1486,6 +1487,7 @@ class GenTailHeadsFn(Function):
         else:
             ctx.save_for_backward(y, w_out)
         ctx.mark_non_differentiable(d)
+        ctx.set_materialize_grads(False)          # (no zero-filled gradient for the unused d output)
         return out.reshape(()), d
 
     @staticmethod

@@ -395,6 +395,13 @@ class Trainer:
         self.g_opt = FlatAdam(self.g_named, 0.0, 0.9)
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
+        self._one = None
+
+    def cost_seed(self, cost):
+        """grad_outputs of a step's backward: a cached tensor of ones (autograd otherwise launches a fill kernel per step)."""
+        if self._one is None or self._one.device != cost.device:
+            self._one = torch.ones((), dtype=torch.float32, device=cost.device)
+        return self._one.reshape(cost.shape)
 
     # ------------------------------------------------------------------ losses
     def d_losses(self, real_int, labels, rnd=None, fake=None):
@@ -546,9 +553,8 @@ class Trainer:
         self.rng.begin_step()
         out = self.d_losses(real_int, labels, rnd, fake=fake)
         with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], self.d_params, allow_unused=True)
+            grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed(out['cost']), allow_unused=True)
         self._apply(self.d_opt, grads, iteration, set_lr)
-        self.rng.end_step()
         out['grads'] = dict(zip([n for n, _ in self.d_named], grads))
         return out
 
@@ -558,22 +564,26 @@ class Trainer:
         self.rng.begin_step()
         out = self.g_losses(rnd)
         with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], self.g_params, allow_unused=True)
+            grads = torch.autograd.grad(out['cost'], self.g_params, grad_outputs=self.cost_seed(out['cost']), allow_unused=True)
         self._apply(self.g_opt, grads, iteration, set_lr)
-        self.rng.end_step()
         out['grads'] = dict(zip([n for n, _ in self.g_named], grads))
         return out
 
     def _apply(self, opt, grads, iteration, set_lr):
         if set_lr:
             opt.set_lr(self.lr(iteration))
+        if self.allreduce is None or self.world <= 1:
+            # single rank: gradient bucket, Adam and the end of the step (beta powers, Philox step counter) in ONE launch
+            opt.update(grads, 1.0 / self.world, rng=self.rng)
+            return
         flat = opt.gather_grads(grads)
         self.reduce_and_update(opt, flat)
 
-    def reduce_and_update(self, opt, flat, between=None):
+    def reduce_and_update(self, opt, flat, between=None, end_rng=True):
         """All-reduce the flat gradient bucket (asynchronous on the side stream, ddp.FlatAllReduce), run `between()` - work
         that does not depend on the update, e.g. staging the next step's inputs - while it is in flight, then Adam with
-        the 1/world average folded in."""
+        the 1/world average folded in.  The update launch also ends the step (FlatAdam.step(rng=...)) unless the caller's captured
+        graph already advanced the Philox counter (end_rng=False)."""
         ar = self.allreduce if (self.allreduce is not None and self.world > 1) else None
         if ar is not None:
             ar(flat)
@@ -581,7 +591,7 @@ class Trainer:
             between()
         if ar is not None and hasattr(ar, 'wait'):
             ar.wait()
-        opt.step(grad_scale=1.0 / self.world)
+        opt.step(grad_scale=1.0 / self.world, rng=self.rng if end_rng else None)
 
     def train_iteration(self, iteration, next_batch):
         """One pass of the loop body :393-404: [G step if it>0] then N_CRITIC x (batch, D step)."""

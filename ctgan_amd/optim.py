@@ -36,6 +36,7 @@ class FlatAdam:
                 off += n
         # {lr, beta1^t, beta2^t, unused}; TF initialises the power accumulators to beta (t = 1)
         self.state = torch.tensor([0.0, self.beta1, self.beta2, 0.0], dtype=torch.float32, device=dev)
+        self.done = torch.zeros(1, dtype=torch.int32, device=dev)      # workgroups-finished counter of the fused step end
         self._lr_last = None      # value currently in state[0] if written by set_lr (None = unknown)
         self.t = 0
         self._keepalive = []
@@ -68,12 +69,25 @@ class FlatAdam:
         self._keepalive = srcs          # sources stay allocated until the next gather
         return self.grad
 
-    def step(self, grad_scale=1.0):
-        """theta <- Adam(theta, grad); advances the beta-power accumulators."""
-        K.adam_step(self.theta, self.grad, self.m, self.v, self.state, self.beta1, self.beta2, self.eps, grad_scale)
-        K.adam_advance(self.state, self.beta1, self.beta2)
+    def step(self, grad_scale=1.0, rng=None):
+        """theta <- Adam(theta, grad); advances the beta-power accumulators and, with `rng`, that stream's step counter
+        (DeviceRNG.end_step) - all in the update launch."""
+        K.adam_step_end(self.theta, self.grad, self.m, self.v, self.state, self.done, self.beta1, self.beta2, self.eps, grad_scale,
+                        rng.ctr if rng is not None else None, 1)
         self.t += 1
         lib.bump_epoch(self.group)    # this network's weights changed: its derived-filter caches are stale
+
+    def update(self, grads, grad_scale=1.0, rng=None):
+        """gather_grads + step in ONE launch: the single-rank form of a step (no collective between gather and update)."""
+        if self.grad.device.type != 'cuda' or len(grads) > K.ADAM_PACKED_MAX:
+            self.gather_grads(grads)
+            return self.step(grad_scale, rng)
+        srcs = [g.contiguous() if g is not None else None for g in grads]
+        K.adam_step_packed(srcs, self.offsets, self.sizes, self.grad, self.theta, self.m, self.v, self.state, self.done, self.beta1,
+                           self.beta2, self.eps, grad_scale, rng.ctr if rng is not None else None, 1)
+        self._keepalive = srcs
+        self.t += 1
+        lib.bump_epoch(self.group)
 
     def load_named_slots(self, m_by_name, v_by_name, t):
         """Overwrite the Adam slots from per-parameter tensors (teacher-forced parity tests, resume)."""

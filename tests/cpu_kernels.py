@@ -696,6 +696,14 @@ def adam_advance(state, beta1, beta2):
     state[2] *= beta2
 
 
+@_export
+def adam_step_end(theta, g, m, v, state, done, beta1, beta2, eps=1e-8, grad_scale=1.0, rng_ctr=None, rng_by=1):
+    adam_step(theta, g, m, v, state, beta1, beta2, eps, grad_scale)
+    adam_advance(state, beta1, beta2)
+    if rng_ctr is not None:
+        rng_ctr += rng_by
+
+
 def _step_of(ctr):
     return int(ctr.reshape(-1)[0]) if torch.is_tensor(ctr) else int(ctr or 0)
 
