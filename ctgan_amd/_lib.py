@@ -59,7 +59,7 @@ class EpilogueExt(ctypes.Structure):
     """struct ctgan_epilogue_ext (include/ctgan_hip.h)."""
     _fields_ = [('drop_keep', ctypes.c_float), ('drop_seed', ctypes.c_uint64), ('drop_stream_id', ctypes.c_uint64),
                 ('drop_ctr', ctypes.c_void_p), ('n_ranges', c_int32), ('range_end', c_int32 * 3), ('range_keep', ctypes.c_float * 3),
-                ('range_stream_id', ctypes.c_uint64 * 3)]
+                ('range_stream_id', ctypes.c_uint64 * 3), ('out_mask', ctypes.c_void_p)]
 
 
 I64x4 = c_int64 * 4
@@ -168,6 +168,7 @@ SIGNATURES = {
                                        c_float, c_float, _p, _p, c_uint64, _p]),
     'ctgan_pack': (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), c_int32, _p, _p]),
     'ctgan_dropout_rng': (c_int, [_p, _p, c_int64, c_float, c_uint64, c_uint64, _p, _p]),
+    'ctgan_dropout_rng_mask': (c_int, [_p, _p, _p, _p, c_int64, c_float, c_uint64, c_uint64, _p, _p]),
     'ctgan_rng_uniform': (c_int, [_p, c_int64, c_uint64, c_uint64, _p, c_float, c_float, _p]),
     'ctgan_rng_normal': (c_int, [_p, c_int64, c_uint64, c_uint64, _p, _p]),
     'ctgan_rng_labels': (c_int, [_p, c_int64, c_int32, c_uint64, c_uint64, _p, _p]),

@@ -36,8 +36,8 @@ void ctgan_set_last_symbol(const char* fmt, ...);
 // fewch.hip: direct kernels for convs with <= 4 channels on one side.  fwd / dgrad / wgrad return 1 when they
 // handled the call, 0 when the caller should fall through to the GEMM kernels, < 0 on error.
 bool ctgan_fewch_handles(const ctgan_conv_desc* d);
-int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid, float* y,
-                    int relu, int relu_in, hipStream_t st);
+int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* mask, const float* resid,
+                    float* y, int relu, int relu_in, hipStream_t st);
 int ctgan_fewch_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, hipStream_t st);
 size_t ctgan_fewch_wgrad_workspace(const ctgan_conv_desc* d);
 int ctgan_fewch_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,

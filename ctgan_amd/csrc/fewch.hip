@@ -60,6 +60,7 @@ struct F2MParams {
     float* y; long long ys_n, ys_p, ys_q; int P, Q, KM;               // many-channel output, unit channel stride
     const float* w; long long w_off, ws_r, ws_s, ws_c, ws_k;           // w(r,s,c,k) = w[w_off + r*ws_r + s*ws_s + c*ws_c + k*ws_k]
     const float* bias; const float* resid;
+    const float* mask;                                                 // result kept where mask > 0 (strides of y; before resid)
     int N, stride, pad_t, pad_l, relu, relu_in, band;                  // band = output rows per workgroup
 };
 
@@ -112,6 +113,10 @@ __global__ __launch_bounds__(NT) void f2m_kernel(const F2MParams p) {
             }
         const long long off = n * p.ys_n + (long long)(p0 + pr) * p.ys_p + (long long)qc * p.ys_q + kq * 4;
         float4 o = to_f4(acc);
+        if (p.mask) {
+            const float4 mv = *reinterpret_cast<const float4*>(p.mask + off);
+            o.x = mv.x > 0.f ? o.x : 0.f; o.y = mv.y > 0.f ? o.y : 0.f; o.z = mv.z > 0.f ? o.z : 0.f; o.w = mv.w > 0.f ? o.w : 0.f;
+        }
         if (p.resid) {
             const float4 rv = *reinterpret_cast<const float4*>(p.resid + off);
             o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
@@ -730,23 +735,23 @@ static int launch_m2f(const M2FParams& p, int R, int S, int JS, hipStream_t st) 
 }
 
 // forward: returns 1 when handled, 0 when the caller should use the GEMM kernels, < 0 on error
-int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid, float* y,
-                    int relu, int relu_in, hipStream_t st) {
+int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* mask, const float* resid,
+                    float* y, int relu, int relu_in, hipStream_t st) {
     if (!ctgan_fewch_handles(d)) return 0;
     if (d->C <= 4) {
-        if (d->ys[1] != 1 || (d->ys[0] | d->ys[2] | d->ys[3]) % 4 || !al16(y) || !al16(resid) || !al16(bias)) return 0;
+        if (d->ys[1] != 1 || (d->ys[0] | d->ys[2] | d->ys[3]) % 4 || !al16(y) || !al16(resid) || !al16(bias) || !al16(mask)) return 0;
         F2MParams p;
         p.x = x; p.xs_n = d->xs[0]; p.xs_c = d->xs[1]; p.xs_h = d->xs[2]; p.xs_w = d->xs[3]; p.H = d->H; p.W = d->W;
         p.y = y; p.ys_n = d->ys[0]; p.ys_p = d->ys[2]; p.ys_q = d->ys[3]; p.P = d->P; p.Q = d->Q; p.KM = d->K;
         p.w = w; p.w_off = 0; p.ws_r = (long long)d->S * d->C * d->K; p.ws_s = (long long)d->C * d->K; p.ws_c = d->K; p.ws_k = 1;
-        p.bias = bias; p.resid = resid;
+        p.bias = bias; p.resid = resid; p.mask = mask;
         p.N = d->N; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.relu = relu; p.relu_in = relu_in;
         p.band = pick_band(d->N, d->P, 4);
         ctgan_set_last_kernel("fewch_f2m");
         const int rc = launch_f2m(p, d->R, d->S, d->C, st);
         return rc ? rc : 1;
     }
-    if (resid || relu) return 0;
+    if (resid || relu || mask) return 0;
     if (d->xs[1] != 1 || (d->xs[0] | d->xs[2] | d->xs[3]) % 4 || !al16(x)) return 0;
     M2FParams p; p.dbg = 0;
     p.x = x; p.xs_n = d->xs[0]; p.xs_h = d->xs[2]; p.xs_w = d->xs[3]; p.H = d->H; p.W = d->W; p.CM = d->C;
@@ -789,7 +794,7 @@ int ctgan_fewch_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w,
     p.x = dy; p.xs_n = d->ys[0]; p.xs_c = d->ys[1]; p.xs_h = d->ys[2]; p.xs_w = d->ys[3]; p.H = d->P; p.W = d->Q;
     p.y = dx; p.ys_n = d->xs[0]; p.ys_p = d->xs[2]; p.ys_q = d->xs[3]; p.P = d->H; p.Q = d->W; p.KM = d->C;
     p.w = w; p.w_off = rot_off; p.ws_r = -tapR; p.ws_s = -tapS; p.ws_c = 1; p.ws_k = d->K;
-    p.bias = bias; p.resid = nullptr;
+    p.bias = bias; p.resid = nullptr; p.mask = nullptr;
     p.N = d->N; p.stride = 1; p.pad_t = d->R - 1 - d->pad_t; p.pad_l = d->S - 1 - d->pad_l; p.relu = 0; p.relu_in = 0;
     p.band = pick_band(d->N, p.P, 4);
     ctgan_set_last_kernel("fewch_f2m(dgrad)");

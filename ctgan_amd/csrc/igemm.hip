@@ -1647,12 +1647,13 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
     const bool want_drop = ext_wants_drop(ext);
     if (rc) return rc;
     if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
-    if (ctgan_is_small_linear(d) && !resid && !(flags & CTGAN_IN_RELU) && !g_force_generic && !want_drop) {
+    const float* out_mask = ext ? ext->out_mask : nullptr;
+    if (ctgan_is_small_linear(d) && !resid && !out_mask && !(flags & CTGAN_IN_RELU) && !g_force_generic && !want_drop) {
         ctgan_set_last_kernel("linear_small_fwd");
         return ctgan_small_linear_fwd(d, x, w, bias, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));
     }
     if (!g_force_generic && !want_drop && !(flags & CTGAN_RESID_UP)) {
-        rc = ctgan_fewch_fwd(d, x, w, bias, resid, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, (flags & CTGAN_IN_RELU) ? 1 : 0,
+        rc = ctgan_fewch_fwd(d, x, w, bias, out_mask, resid, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, (flags & CTGAN_IN_RELU) ? 1 : 0,
                              static_cast<hipStream_t>(stream));
         if (rc) return rc < 0 ? rc : CTGAN_OK;
     }
@@ -1664,7 +1665,7 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
     p.ds_n = d->ys[0]; p.ds_k = d->ys[1]; p.ds_p = d->ys[2]; p.ds_q = d->ys[3];
     p.relu = (flags & CTGAN_EPI_RELU) ? 1 : 0;
     p.relu_in = (flags & CTGAN_IN_RELU) ? 1 : 0;
-    p.mask = nullptr;
+    p.mask = out_mask;
     p.phases = 1;
     p.resid_up = (resid && (flags & CTGAN_RESID_UP)) ? 1 : 0;
     if (p.resid_up && ((d->P | d->Q) & 1)) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: CTGAN_RESID_UP needs even P, Q");

@@ -1803,7 +1803,7 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
     if (x_extent * 4 >= (1LL << 32) || w_plane * mma_planes(mma) >= (1LL << 32))
         return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: operand exceeds the 4 GiB buffer range");
     P16 p{};
-    p.X = x; p.Wp = (const unsigned short*)wp; p.bias = bias; p.resid = resid; p.mask = nullptr; p.D = y;
+    p.X = x; p.Wp = (const unsigned short*)wp; p.bias = bias; p.resid = resid; p.mask = ext ? ext->out_mask : nullptr; p.D = y;
     p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.C = d->C; p.stride = d->stride;
     p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
     p.M = d->N * d->P * d->Q; p.Ng = d->K;

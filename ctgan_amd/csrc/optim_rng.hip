@@ -169,6 +169,40 @@ __global__ void dropout_rng_kernel(const float* __restrict__ x, float* __restric
         }
     }
 }
+// dropout_rng_kernel followed by the ReLU mask of lrelu_bwd (alpha 0) in one pass: y = dropout(x) (optional), ym = y where ref > 0
+// else 0.  The double backward of a data gradient whose result is masked, added to and dropped needs both (functional.ConvDgradFn).
+__global__ void dropout_rng_mask_kernel(const float* __restrict__ x, const float* __restrict__ ref, float* __restrict__ y,
+                                        float* __restrict__ ym, long long n, float keep, float inv, uint64_t seed, uint32_t sid,
+                                        const uint64_t* __restrict__ ctr) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long nblk = (n + 3) >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ym) |
+                       reinterpret_cast<uintptr_t>(ref)) & 15) == 0;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        uint32_t c[4];
+        draw4(seed, sid, step, (uint32_t)b, c);
+        const long long i = b * 4;
+        if (vec && i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            const float4 r = *reinterpret_cast<const float4*>(ref + i);
+            float4 o;
+            o.x = v.x * inv * floorf(keep + u01(c[0])); o.y = v.y * inv * floorf(keep + u01(c[1]));
+            o.z = v.z * inv * floorf(keep + u01(c[2])); o.w = v.w * inv * floorf(keep + u01(c[3]));
+            if (y) *reinterpret_cast<float4*>(y + i) = o;
+            o.x = r.x > 0.f ? o.x : 0.f; o.y = r.y > 0.f ? o.y : 0.f; o.z = r.z > 0.f ? o.z : 0.f; o.w = r.w > 0.f ? o.w : 0.f;
+            *reinterpret_cast<float4*>(ym + i) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) {
+                    const float o = x[i + k] * inv * floorf(keep + u01(c[k]));
+                    if (y) y[i + k] = o;
+                    ym[i + k] = ref[i + k] > 0.f ? o : 0.f;
+                }
+        }
+    }
+}
 __global__ void rng_normal_kernel(float* __restrict__ out, long long n, uint64_t seed, uint32_t sid,
                                   const uint64_t* __restrict__ ctr) {
     const uint64_t step = ctr ? ctr[0] : 0;
@@ -381,6 +415,15 @@ int ctgan_dropout_rng(const float* x, float* y, int64_t n, float keep, uint64_t 
     hipLaunchKernelGGL(dropout_rng_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, y,
                        (long long)n, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr);
     return ctgan_check_launch("dropout_rng");
+}
+int ctgan_dropout_rng_mask(const float* x, const float* ref, float* y, float* y_masked, int64_t n, float keep, uint64_t seed,
+                           uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t s) {
+    if (!x || !ref || !y_masked || n < 0 || n >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "dropout_rng_mask: bad argument");
+    if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "dropout_rng_mask: keep=%g not in (0,1]", keep);
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(dropout_rng_mask_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, ref,
+                       y, y_masked, (long long)n, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr);
+    return ctgan_check_launch("dropout_rng_mask");
 }
 int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t s) {
     if (!out || n < 0 || n >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "rng_normal: bad argument");

@@ -9,6 +9,7 @@ static buffers.  With world_size > 1 the all-reduce and the Adam kernels stay ou
 import torch
 
 from . import functional as F
+from . import kernels as K
 from . import gan_cifar_resnet as R
 from . import tflib as lib
 
@@ -41,13 +42,17 @@ class GraphedTrainer:
         self.labels = torch.zeros(B, dtype=torch.int32, device=dev)
         # fake batches come from one batched generator forward per iteration (Trainer.generate_fakes)
         self.batch_fakes = R.BATCH_FAKES
-        self.labels_all = torch.zeros(B * R.cfg.N_CRITIC, dtype=torch.int32, device=dev)
+        # static inputs of a whole iteration: the N_CRITIC real batches and their labels in ONE allocation, so that an iteration's
+        # inputs are staged by one launch (K.pack with a pointer table) instead of 2 x N_CRITIC copies
+        n_real = R.cfg.N_CRITIC * B * R.cfg.OUTPUT_DIM if self.batch_fakes else 0
+        self._stage = torch.zeros(n_real + B * R.cfg.N_CRITIC, dtype=torch.int32, device=dev)
+        self.labels_all = self._stage[n_real:]
         self.fake = torch.zeros(B, R.cfg.OUTPUT_DIM, dtype=torch.float32, device=dev) if self.batch_fakes else None
         self.f_graph = None
         self.fake_all = None
         self.it_graph = None          # ONE graph for a whole iteration (G step + fake batches + N_CRITIC critic steps), world == 1
         self.it_out = None
-        self.real_all = torch.zeros(R.cfg.N_CRITIC, B, R.cfg.OUTPUT_DIM, dtype=torch.int32, device=dev) if self.batch_fakes else None
+        self.real_all = self._stage[:n_real].view(R.cfg.N_CRITIC, B, R.cfg.OUTPUT_DIM) if self.batch_fakes else None
         self.ar_in_graph = bool(use_graphs and trainer.allreduce is not None and (trainer.world > 1 or getattr(trainer.allreduce, 'always', False))
                                 and (AR_IN_GRAPH if ar_in_graph is None else ar_in_graph))
         self.adam_in_graph = trainer.world == 1 or self.ar_in_graph
@@ -204,6 +209,23 @@ class GraphedTrainer:
                 fake = self.t.generate_fakes(self.labels)[0]
             self.fake.copy_(fake, non_blocking=True)
 
+    def _stage_iteration(self, batches):
+        """The iteration's N_CRITIC (data, labels) batches -> the static input buffers, in one launch when they are device-resident
+        dense int32 tensors (4-byte elements move as bit patterns through the gradient-bucket gather kernel)."""
+        B, n_out = R.cfg.BATCH_SIZE, R.cfg.OUTPUT_DIM
+        srcs = [d for d, _ in batches] + [lab for _, lab in batches]
+        ok = all(x.is_cuda and x.device == self._stage.device and x.dtype == torch.int32 and x.is_contiguous() for x in srcs)
+        ok = ok and all(d.numel() == B * n_out for d, _ in batches) and all(lab.numel() == B for _, lab in batches)
+        if not ok or len(batches) != R.cfg.N_CRITIC:
+            for i, (data, lab) in enumerate(batches):
+                self.labels_all[i * B:(i + 1) * B].copy_(lab, non_blocking=True)
+                self.real_all[i].copy_(data, non_blocking=True)
+            return
+        n = len(batches)
+        offs = [i * B * n_out for i in range(n)] + [n * B * n_out + i * B for i in range(n)]
+        counts = [B * n_out] * n + [B] * n
+        K.pack([x.view(torch.float32) for x in srcs], offs, counts, self._stage.view(torch.float32))
+
     def d_step(self, real_int, labels, iteration=0, fake=None, staged=False, between=None):
         """One critic update.  world > 1: the graph ends at the packed gradient; the all-reduce runs on the side stream
         while `between()` (the NEXT step's input staging) is enqueued, then Adam (Trainer.reduce_and_update)."""
@@ -266,11 +288,8 @@ class GraphedTrainer:
                 self.labels_all[i * B:(i + 1) * B].copy_(lab, non_blocking=True)
         if self.it_graph is not None and iteration > 0:
             t = self.t
-            stage_labels()
-            for i, (data, _) in enumerate(batches):
-                self.real_all[i].copy_(data, non_blocking=True)
-            t.g_opt.set_lr(t.lr(iteration))
-            t.d_opt.set_lr(t.lr(iteration))
+            self._stage_iteration(batches)
+            t.set_lr(t.lr(iteration))
             self.it_graph.replay()
             t.g_opt.t += 1
             t.d_opt.t += len(batches)

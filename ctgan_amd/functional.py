@@ -23,6 +23,24 @@ _WEIGHT_GRADS = True
 # stores), False = stand-alone mask kernel on the data gradient.  A/B switch CTGAN_MASK_EPI.
 import os as _os
 MASK_IN_DGRAD_EPILOGUE = _os.environ.get('CTGAN_MASK_EPI', '1') != '0'
+# Double backward of the gradient penalty: a data gradient g_a = mask(a) * conv^T(g_y) multiplies whatever arrives for g_a by mask(a)
+# again.  When g_a's consumer is itself a data-gradient node (the block's first conv), the conv that node launches in the double
+# backward takes mask(a) in its epilogue and the separate mask pass (one launch per block per step) disappears.  Experiment switch.
+PREMASK_FUSION = _os.environ.get('CTGAN_PREMASK', '1') != '0'
+
+
+class _PreMask:
+    """Link between the node that produced a masked data gradient (`dx`, kept alive here so that its address cannot be reused while
+    the entry exists) and the node that consumes it.  `fused` = the conv result of the double backward that already carries the mask
+    (kept alive until the producer has looked at it: an accumulated gradient is a different tensor at a different address)."""
+    __slots__ = ('dx', 'mask', 'fused')
+
+
+_PREMASK = {}          # data_ptr of a masked data gradient -> _PreMask; emptied at the start and at the end of every step
+
+
+def clear_premasks():
+    _PREMASK.clear()
 
 @contextlib.contextmanager
 def weight_grads(enabled):
@@ -76,6 +94,7 @@ def deferred_wgrads():
     finally:
         groups, post = _DEFER['groups'], _DEFER['post']
         _DEFER.update(on=False, groups=None, post=None)
+        _PREMASK.clear()
         _flush_groups(list(groups.values()))
         folds = [e[1:] for e in post if isinstance(e, tuple) and e[0] == 'fold']
         if folds:
@@ -285,6 +304,7 @@ class ConvFn(Function):
         ctx.out_drop_bwd_fused = bool(epi.get('out_drop_bwd_fused'))
         ctx.mask_done = bool(epi.get('mask_done'))      # the consumer returns the gradient w.r.t. the conv result itself
         ctx.resid_up = bool(epi.get('resid_up')) and resid is not None      # resid is the low-resolution shortcut
+        ctx.out_mask = epi.get('out_mask')         # constant tensor: y kept where out_mask > 0 (no resid / relu / dropout with it)
         ctx.g = g
         ctx.N = x.shape[0]
         ctx.x_strides = x.stride()
@@ -295,8 +315,11 @@ class ConvFn(Function):
         ctx.fork = bool(fork)
         if fork:
             ctx.set_materialize_grads(False)       # an unused shortcut branch must not cost a zero-filled add
-        y = _taped(lambda: K.conv_fwd(x, w, b, g, resid=resid, relu=ctx.out_relu, out_strides=out_strides, relu_in=relu_in,
-                                      drop=ctx.out_drop, resid_up=ctx.resid_up))
+        if ctx.out_mask is not None:
+            y = K.conv_fwd(x, w, b, g, out_strides=out_strides, relu_in=relu_in, mask=ctx.out_mask)
+        else:
+            y = _taped(lambda: K.conv_fwd(x, w, b, g, resid=resid, relu=ctx.out_relu, out_strides=out_strides, relu_in=relu_in,
+                                          drop=ctx.out_drop, resid_up=ctx.resid_up))
         if ctx.out_relu:
             ctx.save_for_backward(x, w, y)         # y > 0  <=>  pre-activation > 0 and the element survived the dropout
         else:
@@ -316,6 +339,8 @@ class ConvFn(Function):
         g = ctx.g
         if gy is None:                                   # fork only: y itself was not used
             return g_fork, None, None, None, None, None, None, None, None
+        if ctx.out_mask is not None:
+            gy = _relu_mask(gy, ctx.out_mask, 0.0)
         # gradient w.r.t. the conv result z, given the gradient w.r.t. y = dropout(relu(z))
         if ctx.mask_done:
             pass
@@ -388,24 +413,53 @@ class ConvDgradFn(Function):
             ctx.save_for_backward(gy, w, mask)
         else:
             ctx.save_for_backward(gy, w)
+        ctx.pre = ctx.own = None
+        if PREMASK_FUSION and not fork:                 # is gy a masked data gradient whose only processing there is the mask?
+            tok = _PREMASK.get(gy.data_ptr())
+            if tok is not None and tok.dx.shape == gy.shape and tok.dx.stride() == gy.stride():
+                ctx.pre = tok
         dx = K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid, drop=drop)
+        if PREMASK_FUSION and mask is not None and resid is None and drop is None and b is None:
+            tok = _PreMask()
+            tok.dx, tok.mask, tok.fused = dx, mask, None
+            _PREMASK[dx.data_ptr()] = ctx.own = tok
         return (dx, gy.view_as(gy)) if fork else dx
 
     @staticmethod
     def backward(ctx, ggx, gg_fork=None):
         if ggx is None:                                 # fork only: dx itself was not used
             return gg_fork, None, None, None, None, None, None, None, None, None
-        if ctx.drop is not None:                        # the dropout mask is a constant of the second pass
-            ggx = DropoutRngFn.apply(ggx, ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], _cl_strides(ggx.shape))
-        g_res = ggx if (ctx.has_resid and ctx.needs_input_grad[7]) else None    # added after the mask
-        if ctx.has_mask:
+        need_res = ctx.has_resid and ctx.needs_input_grad[7]
+        masked = False
+        if (isinstance(ctx.drop, tuple) and ctx.has_mask and PREMASK_FUSION and not torch.is_grad_enabled()
+                and tuple(ggx.stride()) == tuple(_cl_strides(ggx.shape)) and ctx.saved_tensors[2].stride() == ggx.stride()):
+            # dropout and ReLU mask (both constants of the second pass) in one launch; the dropped-only tensor is the residual's gradient
+            g_res, ggx = K.dropout_rng_mask(ggx, ctx.saved_tensors[2], ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], want_dropped=need_res)
+            masked = True
+        else:
+            if ctx.drop is not None:                    # the dropout mask is a constant of the second pass
+                ggx = DropoutRngFn.apply(ggx, ctx.drop[0], ctx.drop[1], ctx.drop[2], ctx.drop[3], _cl_strides(ggx.shape))
+            g_res = ggx if need_res else None           # added after the mask
+        if masked:
             gy, w, mask = ctx.saved_tensors
-            ggx = _relu_mask(ggx, mask, 0.0)      # the mask is a constant of the second pass
+        elif ctx.has_mask:
+            gy, w, mask = ctx.saved_tensors
+            fused = None
+            if ctx.own is not None:
+                fused, ctx.own.fused = ctx.own.fused, None
+            if not (fused is not None and fused.data_ptr() == ggx.data_ptr() and fused.shape == ggx.shape
+                    and fused.stride() == ggx.stride()):
+                ggx = _relu_mask(ggx, mask, 0.0)      # the mask is a constant of the second pass
+            # (else: ggx IS the result of the consumer's conv, whose epilogue applied this node's mask)
         else:
             gy, w = ctx.saved_tensors
         g = ctx.g
         g_gy = g_w = g_b = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.pre is not None and gg_fork is None:
+            # gy = mask(a) * (...) was produced by a data-gradient node that masks what arrives for it: apply that mask here
+            g_gy = ConvFn.apply(ggx, w, None, None, g, None, False, False, {'out_mask': ctx.pre.mask})
+            ctx.pre.fused = g_gy
+        elif ctx.needs_input_grad[0]:
             g_gy = ConvFn.apply(ggx, w, None, gg_fork, g, None, False)        # + the fork branch's gradient, in the epilogue
         elif gg_fork is not None:
             g_gy = gg_fork
@@ -494,6 +548,7 @@ def prepare_filters():
     """Rebuild every known derived filter for the current weight version now, on the current stream, in one launch (the
     data-gradient layouts of spread filters are computed from the parameter, not from the spread buffer)."""
     from . import tflib as lib
+    _PREMASK.clear()
     todo = [e for e in _FCACHE.values() if e.epoch != lib.epoch(e.group)]
     if todo:
         K.filter_batch([e.job() for e in todo])

@@ -391,8 +391,9 @@ class Trainer:
         self.rng = DeviceRNG(seed, rank, self.dev)
         self.d_named = lib.named_params_with_name('Discriminator.', trainable_only=True)
         self.g_named = lib.named_params_with_name('Generator', trainable_only=True)
-        self.d_opt = FlatAdam(self.d_named, 0.0, 0.9)
-        self.g_opt = FlatAdam(self.g_named, 0.0, 0.9)
+        self._opt_state = torch.zeros(8, dtype=torch.float32, device=self.dev)      # both optimizers' {lr, b1^t, b2^t, -}: set_lr()
+        self.d_opt = FlatAdam(self.d_named, 0.0, 0.9, state=self._opt_state[0:4])
+        self.g_opt = FlatAdam(self.g_named, 0.0, 0.9, state=self._opt_state[4:8])
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
         self._one = None
@@ -531,6 +532,14 @@ class Trainer:
     def lr(self, iteration):
         decay = max(0., 1. - float(iteration) / cfg.ITERS) if cfg.DECAY else 1.
         return cfg.LR * decay
+
+    def set_lr(self, lr):
+        """The (common, :333-338) learning rate of both optimizers in ONE fill of their shared state allocation."""
+        lr = float(lr)
+        if self.d_opt._lr_last == lr and self.g_opt._lr_last == lr:
+            return
+        self._opt_state[0::4].fill_(lr)
+        self.d_opt._lr_last = self.g_opt._lr_last = lr
 
     def generate_fakes(self, labels_all):
         """The fake batches of the next len(labels_all)/B critic steps in ONE generator forward.  The generator does

@@ -303,12 +303,18 @@ def _x_phys_shape(g, N):
     return (N, g.C, g.H // 2, g.W // 2) if g.x_up else (N, g.C, g.H, g.W)
 
 
-def _ext(drop):
+def _ext(drop, out_mask=None):
     """drop = (keep, seed, stream_id, ctr) -> ctgan_epilogue_ext*, or None.  Ranged form (forward launches shared by several
-    passes): {'ranges': [(end_sample, spec or None), ...]} - consecutive sample ranges with their own dropout."""
-    if drop is None:
+    passes): {'ranges': [(end_sample, spec or None), ...]} - consecutive sample ranges with their own dropout.
+    out_mask (forward convs): tensor with the result's strides, the result is kept where it is > 0."""
+    if drop is None and out_mask is None:
         return None
     from ._lib import EpilogueExt
+    if drop is None:
+        e = EpilogueExt(0.0, 0, 0, None)               # keep outside (0,1): no dropout
+        e.out_mask = out_mask.data_ptr()
+        return ctypes.byref(e)
+    assert out_mask is None
     if isinstance(drop, dict):
         rs = drop['ranges']
         assert 1 <= len(rs) <= 3
@@ -336,10 +342,14 @@ def _dropout_ranges(y, drop):
     return y
 
 
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False):
-    """y = conv(x,w) [+bias] [+resid] [relu] [dropout]; relu_in: conv(relu(x)).  x logical [N,C,H(/2),W(/2)], w HWIO.
-    drop = (keep, seed, stream_id, ctr): tf.nn.dropout of the result inside the epilogue (== dropout_rng(y, ...))."""
-    _need_dev(x, w, bias, resid)
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False, mask=None):
+    """y = conv(x,w) [+bias] [kept where mask > 0] [+resid] [relu] [dropout]; relu_in: conv(relu(x)).  x logical [N,C,H(/2),W(/2)],
+    w HWIO.  drop = (keep, seed, stream_id, ctr): tf.nn.dropout of the result inside the epilogue (== dropout_rng(y, ...)).
+    mask (same shape and strides as the result; only without resid / relu / drop): == lrelu_bwd(conv(x,w)+bias, mask, 0)."""
+    _need_dev(x, w, bias, resid, mask)
+    if mask is not None:
+        assert resid is None and not relu and drop is None
+        return _conv_fwd_masked(x, w, bias, g, out_strides, relu_in, mask)
     N = x.shape[0]
     assert tuple(x.shape) == _x_phys_shape(g, N), (tuple(x.shape), _x_phys_shape(g, N))
     assert tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
@@ -392,6 +402,35 @@ def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=Fa
     if drop is None:
         return y
     return _dropout_ranges(y, drop) if isinstance(drop, dict) else dropout_rng(y, *drop)
+
+
+def _conv_fwd_masked(x, w, bias, g, out_strides, relu_in, mask):
+    """conv_fwd with the out_mask epilogue (ctgan_epilogue_ext.out_mask) on whichever kernel family serves the launch."""
+    N = x.shape[0]
+    assert tuple(x.shape) == _x_phys_shape(g, N) and tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
+    if out_strides is None:
+        y = empty_cl(N, g.K, g.P, g.Q, x.device)
+    else:
+        y = torch.empty_strided((N, g.K, g.P, g.Q), out_strides, dtype=torch.float32, device=x.device)
+    if tuple(mask.shape) != tuple(y.shape) or mask.stride() != y.stride():
+        return lrelu_bwd(conv_fwd(x, w, bias, g, out_strides=out_strides, relu_in=relu_in), mask, 0.0)
+    d = g.desc(N, x.stride(), y.stride())
+    fl = 2 if relu_in else 0
+    mode = _conv_mode(d, 0, not fewch_handles(g))
+    _x3_log(g, N, d, 0, drop=False, resid_up=False, x_up=bool(g.x_up))
+    try:
+        if mode is not None:
+            wp = _packed16(w, d, 0, g, mode)
+            nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), 0)
+            ws = workspace(nb, x.device) if nb else None
+            _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd_ex(ctypes.byref(d), _MMA_CODE[mode], _ptr(x), _ptr(wp), _ptr(bias), None, _ptr(y), fl,
+                                                                 _ext(None, mask), _ptr(ws), nb, _stream()), 'conv2d16_fwd_ex'))
+        else:
+            _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), None, _ptr(y), fl, _ext(None, mask),
+                                                               _stream()), 'conv2d_fwd'))
+        return y
+    except NotImplementedError:
+        return lrelu_bwd(conv_fwd(x, w, bias, g, out_strides=out_strides, relu_in=relu_in), mask, 0.0)
 
 
 def repack_filter(w, g):
@@ -697,6 +736,18 @@ def dropout_rng(x, keep, seed, stream_id, ctr):
     y = _ew_out(x)
     check(lib.ctgan_dropout_rng(_ptr(x), _ptr(y), x.numel(), keep, seed, stream_id, _ptr(ctr), _stream()), 'dropout_rng')
     return y
+
+
+def dropout_rng_mask(x, ref, keep, seed, stream_id, ctr, want_dropped=True):
+    """-> (dropout_rng(x, ...) or None, lrelu_bwd(dropout_rng(x, ...), ref, 0)) in one launch; ref in x's physical layout."""
+    _need_dev(x, ref)
+    assert ctr.is_cuda and ctr.dtype == torch.int64
+    assert tuple(ref.shape) == tuple(x.shape) and ref.stride() == x.stride()
+    y = _ew_out(x) if want_dropped else None
+    ym = _ew_out(x)
+    check(lib.ctgan_dropout_rng_mask(_ptr(x), _ptr(ref), _ptr(y), _ptr(ym), x.numel(), keep, seed, stream_id, _ptr(ctr), _stream()),
+          'dropout_rng_mask')
+    return y, ym
 
 
 def tanh_fwd(x):

@@ -11,8 +11,9 @@ from . import tflib as lib
 
 
 class FlatAdam:
-    def __init__(self, named_params, beta1, beta2, eps=1e-8):
-        """named_params: [(name, Parameter)] - the trainable variable list, in registry order."""
+    def __init__(self, named_params, beta1, beta2, eps=1e-8, state=None):
+        """named_params: [(name, Parameter)] - the trainable variable list, in registry order.  state: optional float[4] device
+        slice to keep {lr, beta1^t, beta2^t, -} in (two optimizers sharing one allocation take a common learning rate in one fill)."""
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         if not self.params:
@@ -35,7 +36,13 @@ class FlatAdam:
                 p.data = self.theta[off:off + n].view(p.shape)
                 off += n
         # {lr, beta1^t, beta2^t, unused}; TF initialises the power accumulators to beta (t = 1)
-        self.state = torch.tensor([0.0, self.beta1, self.beta2, 0.0], dtype=torch.float32, device=dev)
+        init = torch.tensor([0.0, self.beta1, self.beta2, 0.0], dtype=torch.float32, device=dev)
+        if state is None:
+            self.state = init
+        else:
+            assert state.shape == (4,) and state.dtype == torch.float32 and state.device.type == dev.type and state.is_contiguous()
+            self.state = state
+            self.state.copy_(init)
         self.done = torch.zeros(1, dtype=torch.int32, device=dev)      # workgroups-finished counter of the fused step end
         self._lr_last = None      # value currently in state[0] if written by set_lr (None = unknown)
         self.t = 0

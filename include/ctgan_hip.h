@@ -94,6 +94,10 @@ typedef struct ctgan_epilogue_ext {
     int32_t range_end[CTGAN_DROP_RANGES];
     float range_keep[CTGAN_DROP_RANGES];
     uint64_t range_stream_id[CTGAN_DROP_RANGES];
+    /* forward only (ctgan_conv2d_fwd_ex, ctgan_conv2d16_fwd_ex): the result is kept only where out_mask > 0 (strides of y; after the
+     * bias, before resid - the order of the dgrad epilogue's mask).  Used by the double backward of the gradient penalty, where the
+     * conv that follows multiplies its input with a constant ReLU mask (TF/CT_gan_cifar_resnet.py:284-286 through :109-141).  NULL = none. */
+    const float* out_mask;
 } ctgan_epilogue_ext;
 int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                         float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream);
@@ -495,6 +499,10 @@ int ctgan_pack(const float* const* srcs, const int64_t* dst_offs, const int64_t*
  * same call on the gradient with the same (seed, stream_id, ctr) - no mask tensor is stored.              */
 int ctgan_dropout_rng(const float* x, float* y, int64_t n, float keep, uint64_t seed, uint64_t stream_id,
                       const uint64_t* ctr, ctgan_stream_t stream);
+/* ctgan_dropout_rng followed by ctgan_lrelu_bwd(., ref, alpha = 0) in one pass: y (NULL = not wanted) = dropout(x),
+ * y_masked = y where ref > 0, else 0.  x, ref, y, y_masked share one physical layout.                        */
+int ctgan_dropout_rng_mask(const float* x, const float* ref, float* y, float* y_masked, int64_t n, float keep, uint64_t seed,
+                           uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t stream);
 int ctgan_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
                       float lo, float hi, ctgan_stream_t stream);
 int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,

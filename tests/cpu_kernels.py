@@ -46,7 +46,11 @@ def _xin(x, g):
 
 
 @_export
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False):
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False, mask=None):
+    if mask is not None:
+        assert resid is None and not relu and drop is None
+        y = conv_fwd(x, w, bias, g, None, False, out_strides, relu_in)
+        return y * (mask > 0).to(y.dtype)
     if resid is not None and resid_up:
         resid = upsample2(resid, 1.0)
     if isinstance(drop, dict):
@@ -238,6 +242,12 @@ def dropout_rng(x, keep, seed, stream_id, ctr):
     u = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype)
     rng_uniform(u, seed, stream_id, ctr)
     return dropout(x, u, keep)
+
+
+@_export
+def dropout_rng_mask(x, ref, keep, seed, stream_id, ctr, want_dropped=True):
+    y = dropout_rng(x, keep, seed, stream_id, ctr)
+    return (y if want_dropped else None), lrelu_bwd(y, ref, 0.0)
 
 
 @_export

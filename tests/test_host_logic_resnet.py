@@ -454,3 +454,62 @@ def test_default_fused_step_matches_oracle_on_identical_philox_streams(cpu_kerne
             _cmp(out['grads'][n], ref['grads'][n], 2e-3, 'ggrad ' + n, atol=1e-6)
     finally:
         R.configure()
+
+
+def test_gp_double_backward_mask_rides_the_consumers_conv_epilogue(cpu_kernels, monkeypatch):
+    """functional.PREMASK_FUSION: in the double backward of the gradient penalty, the ReLU mask a block's second data-gradient node
+    applies to what arrives for it is taken by the conv epilogue of the node that produces it (conv_fwd(mask=...)) - one mask pass per
+    residual block less; a node that drops and masks does both in one launch (dropout_rng_mask) - and the parameter gradients of the
+    critic step do not change."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    B, dim = 4, 32
+    lib.set_seed(9)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    try:
+        R.build_params('cpu')
+        tr = R.Trainer(seed=3)
+        g = torch.Generator().manual_seed(5)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        calls = {'mask_pass': 0, 'masked_conv': 0, 'drop_mask': 0}
+        real_bwd, real_fwd, real_dm = K.lrelu_bwd, K.conv_fwd, K.dropout_rng_mask
+
+        def count_dm(*a, **k):
+            calls['drop_mask'] += 1
+            return real_dm(*a, **k)
+
+        def count_bwd(*a, **k):
+            calls['mask_pass'] += 1
+            return real_bwd(*a, **k)
+
+        def count_fwd(*a, **k):
+            if k.get('mask') is not None:
+                calls['masked_conv'] += 1
+            return real_fwd(*a, **k)
+        monkeypatch.setattr(K, 'lrelu_bwd', count_bwd)
+        monkeypatch.setattr(K, 'conv_fwd', count_fwd)
+        monkeypatch.setattr(K, 'dropout_rng_mask', count_dm)
+        res, seen = {}, {}
+        for mode in (False, True):
+            monkeypatch.setattr(F, 'PREMASK_FUSION', mode)
+            calls.update(mask_pass=0, masked_conv=0, drop_mask=0)
+            F.prepare_filters()
+            tr.rng.begin_step()
+            out = tr.d_losses(real, labels)
+            with F.deferred_wgrads():
+                grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+            res[mode], seen[mode] = [None if x is None else x.clone() for x in grads], dict(calls)
+            assert not F._PREMASK                       # emptied at the end of the step
+        assert seen[False]['masked_conv'] == 0
+        assert seen[True]['masked_conv'] == 4, seen     # one per residual block of the critic
+        assert seen[True]['drop_mask'] == 2 and seen[False]['drop_mask'] == 0, seen     # blocks 3 and 4: dropout + mask in one launch
+        assert seen[True]['mask_pass'] == seen[False]['mask_pass'] - 6, seen
+        for (n, _), a, b in zip(tr.d_named, res[False], res[True]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                assert torch.equal(a, b), n
+    finally:
+        R.configure()
