@@ -241,6 +241,56 @@ def test_f32x3_halo_kernel_adds_the_upsampled_residual(K):
     assert relerr(got, want) < 2e-6
 
 
+# (N, C, H, K, k, stride): the forward convs of the gradient penalty's double backward (CIFAR ResNet critic, B = 64) + small shapes
+MASK_CASES = [
+    (64, 3, 32, 128, 3, 1),           # few -> many (fewch f2m)
+    (64, 128, 32, 128, 3, 1),         # 32x32: halo-patch split-mode kernel
+    (64, 128, 8, 128, 3, 1),          # 8x8: fp32 MFMA family (hybrid routing) / halo-patch small tiles
+    (64, 128, 32, 128, 4, 2),         # stride 2 (slice kernel)
+    (3, 32, 8, 32, 3, 1),             # partial tiles
+    (2, 8, 5, 12, 3, 1),              # generic fp32 kernel (odd extents)
+]
+
+
+@pytest.mark.parametrize('mode', [None, 'f32x3', 'bf16'])
+@pytest.mark.parametrize('case', MASK_CASES, ids=lambda c: 'N%d_C%d_H%d_K%d_k%d_s%d' % c)
+def test_forward_conv_with_the_out_mask_epilogue_equals_conv_then_relu_mask_bitwise(K, case, mode):
+    """ctgan_epilogue_ext.out_mask on every kernel family a forward conv can land on: the result kept where mask > 0 must be
+    BIT-identical to the unmasked launch followed by ctgan_lrelu_bwd(., mask, 0) - same kernel, same arithmetic, one pass less."""
+    N, C, H, Ko, k, st = case
+    geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+    g = torch.Generator().manual_seed(21)
+    x = cl(torch.randn(N, C, H, H, generator=g)) if C > 4 else torch.randn(N, C, H, H, generator=g).cuda()
+    w, b = (torch.randn(k, k, C, Ko, generator=g) / 9).cuda(), torch.randn(Ko, generator=g).cuda()
+    m = cl(torch.randn(N, Ko, geom.P, geom.Q, generator=g))
+    ctx = K.mma_dtype(mode) if mode is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        plain = K.conv_fwd(x, w, b, geom, relu_in=C > 4)
+        name = K.last_kernel()
+        got = K.conv_fwd(x, w, b, geom, relu_in=C > 4, mask=m)
+        assert K.last_kernel() == name, (K.last_kernel(), name)       # the mask does not change the routing
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    want = K.lrelu_bwd(plain, m, 0.0)
+    assert torch.equal(got, want), name
+    assert 0.3 < (got == 0).float().mean().item() < 0.7
+
+
+def test_dropout_rng_mask_equals_dropout_then_relu_mask_bitwise(K):
+    g = torch.Generator().manual_seed(5)
+    ctr = torch.tensor([9], dtype=torch.int64, device='cuda')
+    for shape in [(64, 128, 8, 8), (3, 5, 7, 3)]:
+        x, ref = cl(torch.randn(*shape, generator=g)), cl(torch.randn(*shape, generator=g))
+        y0 = K.dropout_rng(x, 0.5, 77, 3, ctr)
+        y, ym = K.dropout_rng_mask(x, ref, 0.5, 77, 3, ctr)
+        assert torch.equal(y, y0) and torch.equal(ym, K.lrelu_bwd(y0, ref, 0.0))
+        none, ym2 = K.dropout_rng_mask(x, ref, 0.5, 77, 3, ctr, want_dropped=False)
+        assert none is None and torch.equal(ym2, ym)
+
+
 @pytest.mark.parametrize('ranged', [False, True])
 def test_f32x3_halo_kernel_applies_the_epilogue_dropout_of_the_fp32_family(K, ranged):
     """tf.nn.dropout of the conv result inside the epilogue (one spec, or sample ranges with their own keep / stream as the shared
