@@ -7,19 +7,24 @@ using namespace ctgan_philox;
 
 // tf.train.AdamOptimizer:  lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m=b1 m+(1-b1) g; v=b2 v+(1-b2) g^2;
 // theta -= lr_t*m/(sqrt(v)+eps)    (eps outside the bias correction, unlike torch.optim.Adam)
+// one element of the update; contraction off, so that every kernel that inlines it (plain, step-end, packed; scalar or 4-wide)
+// rounds identically - the fused forms are tested bit-for-bit against the separate launches
+__device__ __forceinline__ void adam_elem(float& th, float& m, float& v, float graw, float gscale, float b1, float b2, float eps, float lr_t) {
+#pragma clang fp contract(off)
+    const float gi = graw * gscale;
+    const float mi = b1 * m + (1.f - b1) * gi;
+    const float vi = b2 * v + (1.f - b2) * gi * gi;
+    m = mi; v = vi;
+    th = th - lr_t * mi / (sqrtf(vi) + eps);
+}
 __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, const float* __restrict__ state, float b1, float b2,
                             float eps, float gscale) {
     const float lr = state[0], b1p = state[1], b2p = state[2];
     const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        th[i] = th[i] - lr_t * mi / (sqrtf(vi) + eps);
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        adam_elem(th[i], m[i], v[i], g[i], gscale, b1, b2, eps, lr_t);
 }
 __global__ void adam_advance_kernel(float* state, float b1, float b2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] *= b1; state[2] *= b2; }
@@ -48,13 +53,8 @@ __global__ void adam_end_kernel(float* __restrict__ th, const float* __restrict_
     const float lr = state[0], b1p = state[1], b2p = state[2];
     const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        th[i] = th[i] - lr_t * mi / (sqrtf(vi) + eps);
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        adam_elem(th[i], m[i], v[i], g[i], gscale, b1, b2, eps, lr_t);
     step_end(state, b1, b2, e);
 }
 
@@ -104,24 +104,14 @@ __global__ void adam_packed_kernel(const PackTable t, float* __restrict__ flat, 
             const float gv[4] = {gr.x, gr.y, gr.z, gr.w};
             float* mp = &mm.x; float* vp = &vv.x; float* tp = &tt.x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gi = gv[k] * gscale;
-                const float mi = b1 * mp[k] + (1.f - b1) * gi;
-                const float vi = b2 * vp[k] + (1.f - b2) * gi * gi;
-                mp[k] = mi; vp[k] = vi;
-                tp[k] = tp[k] - lr_t * mi / (sqrtf(vi) + eps);
-            }
+            for (int k = 0; k < 4; ++k) adam_elem(tp[k], mp[k], vp[k], gv[k], gscale, b1, b2, eps, lr_t);
             m4[i] = mm; v4[i] = vv; th4[i] = tt;
         }
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             const float gr = src ? src[i] : 0.f;
             flat[off + i] = gr;
-            const float gi = gr * gscale;
-            const float mi = b1 * m[off + i] + (1.f - b1) * gi;
-            const float vi = b2 * v[off + i] + (1.f - b2) * gi * gi;
-            m[off + i] = mi; v[off + i] = vi;
-            th[off + i] = th[off + i] - lr_t * mi / (sqrtf(vi) + eps);
+            adam_elem(th[off + i], m[off + i], v[off + i], gr, gscale, b1, b2, eps, lr_t);
         }
     }
     step_end(state, b1, b2, e);
