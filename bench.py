@@ -621,7 +621,8 @@ def measure_gp_unit(trainer, batch, torch):
                 by_pipe[pipe_of(p[0])] = by_pipe.get(pipe_of(p[0]), 0.0) + p[1] / 1e9
         finally:
             K.PROFILE = None
-        from ctgan_amd.engine import _capture_kw
+        from ctgan_amd.engine import _capture_kw, quiesce_collectives
+        quiesce_collectives()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, **_capture_kw()):
             unit()

@@ -33,6 +33,19 @@ def _capture_kw():
     return {'capture_error_mode': 'thread_local'} if (dist.is_available() and dist.is_initialized()) else {}
 
 
+def quiesce_collectives():
+    """Call before a capture when a process group is alive.  Collectives enqueued eagerly (warm-up passes, communicator start-up) leave
+    work items on the c10d watchdog's list; it retires them by polling their events every ~100 ms, and a poll that lands inside a
+    capture raised a HIP error in the watchdog thread on this stack even under THREAD_LOCAL mode (2 of 3 runs once the warm-up got
+    shorter).  After a device synchronize every item is complete: one poll period later the list is empty and nothing is polled
+    while capturing (collectives enqueued under capture are never put on that list)."""
+    import time
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
+        torch.cuda.synchronize()
+        time.sleep(0.35)
+
+
 class GraphedTrainer:
     def __init__(self, trainer, use_graphs=True, warmup=2, ar_in_graph=None):
         self.t = trainer
@@ -167,6 +180,7 @@ class GraphedTrainer:
                     self._g_body()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
+            quiesce_collectives()
             self.d_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.d_graph, **_capture_kw()):
                 self.d_out = self._d_body()
@@ -370,6 +384,7 @@ class GraphedDCGANTrainer:
                     self._body('g')
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
+            quiesce_collectives()
             self.d_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.d_graph, **_capture_kw()):
                 self.d_out = self._body('d')

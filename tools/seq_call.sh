@@ -9,6 +9,6 @@ rocprofv3 --kernel-trace --stats -d $o/raw -o trace -- python3 $GRAFT_REPO_ROOT/
 cd $GRAFT_REPO_ROOT
 db=$(find $o/raw -name '*.db' | head -1)
 python tools/prof_gaps.py $db 8 90 > $o/steady_state.txt 2>/dev/null
-for b in 0 1 2 5 6; do python tools/prof_seq.py $db adam_kernel 1 $b > $o/seq_back$b.txt 2>&1; done
+for b in 0 1 2 5 6; do python tools/prof_seq.py $db adam_packed_kernel 1 $b > $o/seq_back$b.txt 2>&1; done
 rm -rf $o/raw
 head -4 $o/steady_state.txt
