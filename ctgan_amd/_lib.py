@@ -154,6 +154,8 @@ SIGNATURES = {
     'ctgan_tail_heads_fwd': (c_int, [_p, c_int32, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int32, _p, _p, _p, _p]),
     'ctgan_tail_critic_heads_fwd': (c_int, [_p, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int32, _p, _p, c_float, c_float, c_float,
                                             _p, _p, _p, _p, _p, _p, _p, _p]),
+    'ctgan_tail_critic_heads_fwd2': (c_int, [_p, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int32, _p, _p, _p, c_float, _p, c_int32, _p, _p, _p,
+                                             c_float, c_float, c_float, _p, _p, _p, _p, _p, _p, _p, _p]),
     'ctgan_tail_heads_bwd': (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float,
                                      _p, _p, _p, _p, _p, _p, _p, _p]),
     'ctgan_gen_heads_fwd': (c_int, [_p, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int32, _p, c_float, _p, _p, _p, _p, _p, _p]),

@@ -319,13 +319,21 @@ __global__ __launch_bounds__(256) void tail_heads_rows_kernel(const float* __res
                                                               const float* __restrict__ w_ac, const float* __restrict__ b_ac, int ncls,
                                                               float* __restrict__ f, float* __restrict__ d, float* __restrict__ a,
                                                               int pair_B, const int32_t* __restrict__ labels, float l2,
-                                                              float* __restrict__ ct_i, float* __restrict__ probs, float* __restrict__ ce_i) {
+                                                              float* __restrict__ ct_i, float* __restrict__ probs, float* __restrict__ ce_i,
+                                                              const float* __restrict__ y2, int n_main, int relu2,
+                                                              float* __restrict__ f2, float* __restrict__ a2) {
     __shared__ __attribute__((aligned(16))) float part[1024];
     __shared__ float fs0[1024], fs1[1024];
     __shared__ float dsh[2];
     __shared__ float sh[4];
     const int r = blockIdx.x;
     const long long row_elems = (long long)hw * nf;
+    if (y2 && r >= n_main) {        // rows of a second tensor that only feed the class head (the clean pass of the accuracies, :249-266)
+        const int q = r - n_main;
+        head_row(y2 + q * row_elems, hw, nf, relu2, nullptr, nullptr, w_ac, b_ac, ncls, part, fs0, f2 + (long long)q * nf, nullptr,
+                 a2 + (long long)q * ncls, dsh);
+        return;
+    }
     head_row(y + r * row_elems, hw, nf, relu, w_out, b_out, w_ac, b_ac, ncls, part, fs0, f + (long long)r * nf, d ? d + r : nullptr,
              a ? a + (long long)r * ncls : nullptr, dsh);
     if (pair_B == 0 || r >= pair_B) return;
@@ -351,10 +359,34 @@ __global__ __launch_bounds__(256) void tail_heads_rows_kernel(const float* __res
     }
 }
 // the batch means over those per-sample terms: out[5] as ctgan_critic_heads_fwd
+// slopes != NULL: the gradient penalty's batch mean is taken here (gp_mean_kernel's arithmetic) and WRITTEN to gp[0] before it is used;
+// a_clean != NULL: the accuracies of the clean pass (accuracy2_kernel's arithmetic) are written to acc[2].
 __global__ __launch_bounds__(256) void critic_heads_final_kernel(const float* __restrict__ d, const float* __restrict__ ct_i,
-                                                                 const float* __restrict__ ce_i, const float* __restrict__ gp, int B,
-                                                                 float M, float scale, float* __restrict__ out) {
+                                                                 const float* __restrict__ ce_i, float* gp, int B,
+                                                                 float M, float scale, float* __restrict__ out,
+                                                                 const float* __restrict__ slopes, float gp_lambda,
+                                                                 const float* __restrict__ a_clean, const int32_t* __restrict__ labels,
+                                                                 int ncls, float* __restrict__ acc) {
     __shared__ float sh[4];
+    if (slopes) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < B; i += 256) { const float t = slopes[i] - 1.f; s += t * t; }
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) gp[0] = gp_lambda * s / (float)B;
+        __syncthreads();
+    }
+    if (a_clean) {
+        float cr = 0.f, cf = 0.f;
+        for (int i = threadIdx.x; i < 2 * B; i += 256) {
+            const float* z = a_clean + (long long)i * ncls;
+            float mx = z[0]; int am = 0;
+            for (int k = 1; k < ncls; ++k) if (z[k] > mx) { mx = z[k]; am = k; }
+            const float hit = (am == labels[i < B ? i : i - B]) ? 1.f : 0.f;
+            if (i < B) cr += hit; else cf += hit;
+        }
+        cr = block_sum(cr, sh); cf = block_sum(cf, sh);
+        if (threadIdx.x == 0) { acc[0] = cr / (float)B; acc[1] = cf / (float)B; }
+    }
     float sr = 0.f, sf = 0.f, sc = 0.f, sl = 0.f;
     for (int i = threadIdx.x; i < B; i += 256) {
         sr += d[i]; sf += d[B + i];
@@ -581,11 +613,11 @@ __global__ __launch_bounds__(256) void gp_head_wgrad_stage2_kernel(const float* 
 extern "C" {
 
 int ctgan_gp_fwd(const float* g, int32_t b, int32_t d, float lambda, float* slopes, float* gp, ctgan_stream_t s) {
-    if (!g || !slopes || !gp || b <= 0 || d <= 0) return ctgan_fail(CTGAN_E_BADARG, "gp_fwd: bad argument");
+    if (!g || !slopes || b <= 0 || d <= 0) return ctgan_fail(CTGAN_E_BADARG, "gp_fwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(s);
     hipLaunchKernelGGL(gp_slopes_kernel, dim3(b), dim3(256), 0, st, g, d, slopes);
     int rc = ctgan_check_launch("gp_slopes");
-    if (rc) return rc;
+    if (rc || !gp) return rc;                        // gp == NULL: the mean is taken by ctgan_tail_critic_heads_fwd2 (from slopes)
     hipLaunchKernelGGL(gp_mean_kernel, dim3(1), dim3(256), 0, st, slopes, b, lambda, gp);
     return ctgan_check_launch("gp_mean");
 }
@@ -660,23 +692,36 @@ int ctgan_tail_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, int3
         (reinterpret_cast<uintptr_t>(y) & 15))
         return ctgan_fail(CTGAN_E_BADARG, "tail_heads_fwd: bad argument");
     hipLaunchKernelGGL(tail_heads_rows_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(s), y, hw, nf, relu, w_out, b_out, w_ac,
-                       b_ac, ncls, f, d, a, 0, (const int32_t*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       b_ac, ncls, f, d, a, 0, (const int32_t*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (const float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr);
     return ctgan_check_launch("tail_heads_rows");
 }
 int ctgan_tail_critic_heads_fwd(const float* y, int32_t B, int32_t hw, int32_t nf, const float* w_out, const float* b_out,
                                 const float* w_ac, const float* b_ac, int32_t ncls, const int32_t* labels, const float* gp,
                                 float lambda2, float M, float acgan_scale, float* f, float* d, float* a, float* ct_i, float* probs,
                                 float* ce_i, float* out, ctgan_stream_t s) {
+    return ctgan_tail_critic_heads_fwd2(y, B, hw, nf, w_out, b_out, w_ac, b_ac, ncls, labels, const_cast<float*>(gp), nullptr, 0.f, nullptr, 0,
+                                        nullptr, nullptr, nullptr, lambda2, M, acgan_scale, f, d, a, ct_i, probs, ce_i, out, s);
+}
+int ctgan_tail_critic_heads_fwd2(const float* y, int32_t B, int32_t hw, int32_t nf, const float* w_out, const float* b_out,
+                                 const float* w_ac, const float* b_ac, int32_t ncls, const int32_t* labels, float* gp,
+                                 const float* slopes, float gp_lambda, const float* y_clean, int32_t clean_relu, float* f_clean,
+                                 float* a_clean, float* acc, float lambda2, float M, float acgan_scale, float* f, float* d, float* a,
+                                 float* ct_i, float* probs, float* ce_i, float* out, ctgan_stream_t s) {
     if (!y || !f || !d || !w_out || !ct_i || !out || B <= 0 || hw <= 0 || nf <= 0 || (nf & 3) || nf > 1024 ||
         (w_ac && (!a || !labels || !probs || !ce_i || ncls <= 0)) || (reinterpret_cast<uintptr_t>(y) & 15))
         return ctgan_fail(CTGAN_E_BADARG, "tail_critic_heads_fwd: bad argument");
+    if (slopes && !gp) return ctgan_fail(CTGAN_E_BADARG, "tail_critic_heads_fwd2: slopes without a gp slot");
+    if (y_clean && (!w_ac || !f_clean || !a_clean || !acc || !labels || (reinterpret_cast<uintptr_t>(y_clean) & 15)))
+        return ctgan_fail(CTGAN_E_BADARG, "tail_critic_heads_fwd2: clean rows need the class head, f_clean, a_clean, acc, labels");
     hipStream_t st = static_cast<hipStream_t>(s);
-    hipLaunchKernelGGL(tail_heads_rows_kernel, dim3(2 * B), dim3(256), 0, st, y, hw, nf, 0, w_out, b_out, w_ac, b_ac, ncls, f, d,
-                       w_ac ? a : (float*)nullptr, B, labels, lambda2, ct_i, probs, ce_i);
+    const int n_clean = y_clean ? 2 * B : 0;
+    hipLaunchKernelGGL(tail_heads_rows_kernel, dim3(2 * B + n_clean), dim3(256), 0, st, y, hw, nf, 0, w_out, b_out, w_ac, b_ac, ncls, f, d,
+                       w_ac ? a : (float*)nullptr, B, labels, lambda2, ct_i, probs, ce_i, y_clean, 2 * B, clean_relu, f_clean, a_clean);
     int rc = ctgan_check_launch("tail_heads_rows");
     if (rc) return rc;
     hipLaunchKernelGGL(critic_heads_final_kernel, dim3(1), dim3(256), 0, st, d, ct_i, w_ac ? ce_i : (const float*)nullptr, gp, B, M,
-                       acgan_scale, out);
+                       acgan_scale, out, slopes, gp_lambda, y_clean ? a_clean : (const float*)nullptr, labels, ncls, acc);
     return ctgan_check_launch("critic_heads_final");
 }
 int ctgan_tail_heads_bwd(const float* y, const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
@@ -702,7 +747,8 @@ int ctgan_gen_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, const
         return ctgan_fail(CTGAN_E_BADARG, "gen_heads_fwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(s);
     hipLaunchKernelGGL(tail_heads_rows_kernel, dim3(n), dim3(256), 0, st, y, hw, nf, 0, w_out, b_out, w_ac, b_ac, ncls, f, d,
-                       w_ac ? a : (float*)nullptr, 0, (const int32_t*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+                       w_ac ? a : (float*)nullptr, 0, (const int32_t*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (const float*)nullptr, 0, 0, (float*)nullptr, (float*)nullptr);
     int rc = ctgan_check_launch("tail_heads_rows");
     if (rc) return rc;
     hipLaunchKernelGGL(gen_heads_loss_kernel, dim3(1), dim3(256), 0, st, d, w_ac ? a : (const float*)nullptr, labels, n, ncls, ac_scale, probs, out);

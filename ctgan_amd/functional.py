@@ -1388,8 +1388,9 @@ class GradPenaltyFn(Function):
     """lambda * mean((||g_b|| - 1)^2)"""
 
     @staticmethod
-    def forward(ctx, g, lam):
-        gp, slopes = K.gp_fwd(g, lam)
+    def forward(ctx, g, lam, defer_mean=False):
+        # defer_mean: gp is a slot that critic_tail_heads(slopes=...) fills (the batch mean rides that function's last kernel)
+        gp, slopes = K.gp_fwd(g, lam, defer_mean)
         ctx.lam = lam
         ctx.save_for_backward(g, slopes)
         ctx.mark_non_differentiable(slopes)
@@ -1399,7 +1400,7 @@ class GradPenaltyFn(Function):
     @staticmethod
     def backward(ctx, gout, _):
         g, slopes = ctx.saved_tensors
-        return K.gp_bwd(g, slopes, gout, ctx.lam), None
+        return K.gp_bwd(g, slopes, gout, ctx.lam), None, None
 
 
 class ConsistencyFn(Function):
@@ -1487,9 +1488,13 @@ class CriticTailHeadsFn(Function):
     w.r.t. the conv result (mask and 1/keep applied here).  First-order only."""
 
     @staticmethod
-    def forward(ctx, y, w_out, b_out, w_ac, b_ac, labels, B, lam2, M, scale, mask_scale, gp=None):
-        out, f, d, a, ct_i, probs = K.tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp.reshape(1) if gp is not None else None,
-                                                            lam2, M, scale)
+    def forward(ctx, y, w_out, b_out, w_ac, b_ac, labels, B, lam2, M, scale, mask_scale, gp=None, slopes=None, gp_lambda=0.0, y_clean=None,
+                clean_relu=False):
+        # slopes: gp is the unwritten slot of gradient_penalty(defer_mean=True), filled here; y_clean: rows of the dropout-free pass,
+        # their accuracies come back as the last output (both ride the two launches of the heads)
+        out, f, d, a, ct_i, probs, acc = K.tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp.reshape(1) if gp is not None else None,
+                                                                 lam2, M, scale, slopes=slopes, gp_lambda=gp_lambda, y_clean=y_clean,
+                                                                 clean_relu=clean_relu)
         ctx.has_gp = gp is not None
         ctx.cfg = (B, lam2, M, scale, mask_scale)
         ctx.labels = labels
@@ -1499,12 +1504,14 @@ class CriticTailHeadsFn(Function):
             ctx.save_for_backward(y, w_out, w_ac, d, f, ct_i, probs)
         else:
             ctx.save_for_backward(y, w_out, d, f, ct_i)
-        ctx.mark_non_differentiable(out[4], d)
-        return out[0], out[1], out[2], out[3], out[4], d
+        if acc is None:
+            acc = out.new_zeros(0)
+        ctx.mark_non_differentiable(out[4], d, acc)
+        return out[0], out[1], out[2], out[3], out[4], d, acc
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g0, g1, g2, g3, _g4=None, _gd=None):
+    def backward(ctx, g0, g1, g2, g3, _g4=None, _gd=None, _gacc=None):
         B, lam2, M, scale, mask_scale = ctx.cfg
         if ctx.has_a:
             y, w_out, w_ac, d, f, ct_i, probs = ctx.saved_tensors
@@ -1517,13 +1524,14 @@ class CriticTailHeadsFn(Function):
             gout = torch.cat([z(g0), z(g1), z(g2), z(g3)])
         gy, gw_out, gb_out, gw_ac, gb_ac = K.tail_heads_bwd(y, d, f, probs, ctx.labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac)
         return (gy, gw_out, gb_out, gw_ac, gb_ac, None, None, None, None, None, None,
-                (g0.reshape(()) if (ctx.has_gp and g0 is not None) else None))
+                (g0.reshape(()) if (ctx.has_gp and g0 is not None) else None), None, None, None, None)
 
 
-def critic_tail_heads(y, w_out, b_out, w_ac, b_ac, labels, B, lam2=2.0, M=0.0, acgan_scale=1.0, mask_scale=1.0, gp=None):
-    """-> (cost, wgan, ct, acgan, wgan + ct + gp, d [3B]); see CriticTailHeadsFn."""
+def critic_tail_heads(y, w_out, b_out, w_ac, b_ac, labels, B, lam2=2.0, M=0.0, acgan_scale=1.0, mask_scale=1.0, gp=None, slopes=None,
+                      gp_lambda=0.0, y_clean=None, clean_relu=False):
+    """-> (cost, wgan, ct, acgan, wgan + ct + gp, d [3B], acc [2] (empty without y_clean)); see CriticTailHeadsFn."""
     return CriticTailHeadsFn.apply(y, w_out, b_out, w_ac, b_ac, labels, int(B), float(lam2), float(M), float(acgan_scale),
-                                   float(mask_scale), gp)
+                                   float(mask_scale), gp, slopes, float(gp_lambda), y_clean, bool(clean_relu))
 
 
 class GenTailHeadsFn(Function):
@@ -1594,8 +1602,9 @@ def critic_heads(d_all, f_all, a_all, labels, B, lam2=2.0, M=0.0, acgan_scale=1.
     return CriticHeadsFn.apply(d_all, f_all, a_all, labels, int(B), float(lam2), float(M), float(acgan_scale), gp)
 
 
-def gradient_penalty(g, lam):
-    return GradPenaltyFn.apply(g, float(lam))
+def gradient_penalty(g, lam, defer_mean=False):
+    """-> (gp, slopes).  defer_mean: gp holds no value until critic_tail_heads(..., gp, slopes=slopes, gp_lambda=lam) has run."""
+    return GradPenaltyFn.apply(g, float(lam), bool(defer_mean))
 
 
 def consistency_term(d, d_, f, f_, lam2=2.0, M=0.0):

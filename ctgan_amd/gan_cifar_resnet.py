@@ -306,6 +306,8 @@ TRUNK_SHARE = _os.environ.get('CTGAN_TRUNK_SHARE', '1') != '0'
 # A/B switch: blocks 3-4 of every pass of a critic step (dropout passes, clean pass, GP pass) in one set of forward launches
 # with per-row-range dropout (shared_tail_forward); needs TRUNK_SHARE
 TAIL_SHARE = _os.environ.get('CTGAN_TAIL_SHARE', '1') != '0'
+# the penalty's batch mean and the clean pass's class head + accuracies inside the two launches of the fused loss heads (experiment switch)
+HEADS_FOLD = _os.environ.get('CTGAN_HEADS_FOLD', '1') != '0'
 # A/B switch: dequantisation, interpolation and the [real ; fake] concat of a critic step in one launch
 PREP_FUSION = _os.environ.get('CTGAN_PREP_FUSION', '1') != '0'
 
@@ -351,9 +353,10 @@ def shared_tail_forward(h_all, B, rng, with_clean):
     return tape, gp_specs, main_specs, {'main': (0, n_main), 'clean': (n_main, r_gp), 'gp': (r_gp, r_gp + B)}
 
 
-def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None, tail_tape=None, specs=None):
+def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None, tail_tape=None, specs=None, defer_mean=False):
     """GP = lambda * mean((||dD(x_hat)/dx_hat||_2 - 1)^2) with its own dropout masks (:277-286): critic forward on x_hat,
-    data gradient back to x_hat under create_graph.  -> (gp, slopes, dD/dx_hat).  interp must require grad."""
+    data gradient back to x_hat under create_graph.  -> (gp, slopes, dD/dx_hat).  interp must require grad.
+    defer_mean: gp is returned as a slot that the caller's F.critic_tail_heads(..., gp, slopes=slopes, gp_lambda=...) fills."""
     fuse_heads = _heads_fusable(rnd, rng)
     with F.weight_grads(not _critic_piecewise_linear()):
         if fuse_heads:
@@ -377,7 +380,7 @@ def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None, tail
     else:
         ones = torch.ones_like(d_gp)
         (grads,) = torch.autograd.grad(d_gp, interp, grad_outputs=ones, create_graph=True)
-    gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA)
+    gp, slopes = F.gradient_penalty(grads, cfg.GP_LAMBDA, defer_mean=defer_mean)
     return gp, slopes, grads
 
 
@@ -442,7 +445,7 @@ class Trainer:
             tail = shared_tail_forward(tape[-1], B, rng, with_clean=use_ac)
         gp, slopes, grads = gradient_penalty_branch(interp, labels, rng, rnd, trunk_tape=(tape, 2 * B, 3 * B) if tape is not None else None,
                                                         tail_tape=(tail[0],) + tail[3]['gp'] if tail is not None else None,
-                                                        specs=tail[1] if tail is not None else None)
+                                                        specs=tail[1] if tail is not None else None, defer_mean=fuse_heads and HEADS_FOLD)
 
         # dropout passes 1 and 2 share the trunk; pass 2 is needed on the real half only
         if tape is not None:
@@ -456,6 +459,7 @@ class Trainer:
             u = None
         out = {}
         use_ac = cfg.CONDITIONAL and cfg.ACGAN
+        y_clean = None
         if fuse_heads:
             # mean + both Linear heads + every loss head: two launches forward, one backward (gradient w.r.t. the last conv's
             # result and the head weights)
@@ -465,17 +469,26 @@ class Trainer:
             else:
                 y = DiscriminatorTailBody(h, 0.8, 0.5, 0.5, rng=rng, mask_done=True, cat_extra=B)
             P = lib.param
-            cost, wgan, ct, acgan, disc_wgan, d_all = F.critic_tail_heads(
+            # the penalty's batch mean (slopes -> gp) and, with the shared tail, the clean pass's class head + accuracies (:249-266)
+            # ride the two launches of the heads
+            y_clean = None
+            if HEADS_FOLD and use_ac and tail is not None:
+                c0, c1 = tail[3]['clean']
+                y_clean = tail[0][-1][c0:c1].detach()
+            cost, wgan, ct, acgan, disc_wgan, d_all, acc = F.critic_tail_heads(
                 y, P('Discriminator.Output.W'), P('Discriminator.Output.b'),
                 P('Discriminator.ACGANOutput.W') if use_ac else None, P('Discriminator.ACGANOutput.b') if use_ac else None,
-                labels, B, cfg.LAMBDA_2, cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, gp)
+                labels, B, cfg.LAMBDA_2, cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, gp,
+                slopes if HEADS_FOLD else None, cfg.GP_LAMBDA, y_clean, False)
         else:
             tail_in = _cat_rows(h, h[:B])
             d_all, f_all, a_all = DiscriminatorTail(tail_in, 0.8, 0.5, 0.5, u=u, rng=rng)
             # every loss head of the two dropout passes in one kernel (fwd) / one kernel (bwd): wgan :244, CT :288-291, ACGAN :246-248
             cost, wgan, ct, acgan, disc_wgan = F.critic_heads(d_all, f_all, a_all if use_ac else None, labels, B, cfg.LAMBDA_2,
                                                               cfg.Factor_M, cfg.ACGAN_SCALE if use_ac else 0.0, gp)
-        if use_ac:
+        if use_ac and fuse_heads and y_clean is not None:
+            out['acc_real'], out['acc_fake'] = acc[0], acc[1]
+        elif use_ac:
             with torch.no_grad():                                            # clean pass: accuracies only :228,249-266
                 if tail is not None:       # rows of the shared tail forward (ReLU already applied, no dropout in this range)
                     c0, c1 = tail[3]['clean']

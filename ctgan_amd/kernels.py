@@ -1113,13 +1113,15 @@ def bn_bwd(gy, x4, mean, rstd, scale, offset, labels, groups, relu):
 
 
 # ------------------------------------------------------------------------------- loss heads
-def gp_fwd(g, lam):
+def gp_fwd(g, lam, defer_mean=False):
+    """-> (gp, slopes).  defer_mean: only the slopes are computed here; gp is an UNWRITTEN slot that tail_critic_heads_fwd(slopes=...,
+    gp=...) fills with lam * mean((slopes - 1)^2) in its one-workgroup kernel before using it (one launch per critic step less)."""
     _need_dev(g)
     g = g.contiguous()
     B, D = g.shape
     slopes = torch.empty(B, dtype=torch.float32, device=g.device)
     gp = torch.empty((), dtype=torch.float32, device=g.device)
-    check(lib.ctgan_gp_fwd(_ptr(g), B, D, lam, _ptr(slopes), _ptr(gp), _stream()), 'gp_fwd')
+    check(lib.ctgan_gp_fwd(_ptr(g), B, D, lam, _ptr(slopes), None if defer_mean else _ptr(gp), _stream()), 'gp_fwd')
     return gp, slopes
 
 
@@ -1287,13 +1289,38 @@ def tail_heads_fwd(y, w_out, b_out, w_ac, b_ac, relu=False):
     return f, d, a
 
 
-def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, scale):
+def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, scale, slopes=None, gp_lambda=0.0, y_clean=None,
+                          clean_relu=False):
     """tail_heads_fwd over the 3B rows of a critic step + critic_heads_fwd, two launches.
-    -> (out[5], f [3B,nf], d [3B], a [3B,ncls] or None, ct_i [B], probs [B,ncls] or None)."""
-    _need_dev(y, w_out, b_out, w_ac, b_ac, labels, gp)
+    -> (out[5], f [3B,nf], d [3B], a [3B,ncls] or None, ct_i [B], probs [B,ncls] or None, acc [2] or None).
+    slopes (with gp = the slot of gp_fwd(defer_mean=True)): gp is computed from the slopes and written in place first.
+    y_clean [2B,nf,H,W] (dense channels-last): its class-head logits and the two accuracies ride the same two launches."""
+    _need_dev(y, w_out, b_out, w_ac, b_ac, labels, gp, slopes, y_clean)
     n, hw, nf = _cl_rows(y)
     assert n == 3 * B and w_out.is_contiguous() and w_out.numel() == nf
     dev = y.device
+    if slopes is not None or y_clean is not None:
+        assert slopes is None or (gp is not None and slopes.is_contiguous() and slopes.numel() == B)
+        ncls = w_ac.shape[1] if w_ac is not None else 0
+        f_c = a_c = acc = None
+        if y_clean is not None:
+            n2, hw2, nf2 = _cl_rows(y_clean)
+            assert (n2, hw2, nf2) == (2 * B, hw, nf) and w_ac is not None
+            f_c = torch.empty(n2, nf, dtype=torch.float32, device=dev)
+            a_c = torch.empty(n2, ncls, dtype=torch.float32, device=dev)
+            acc = torch.empty(2, dtype=torch.float32, device=dev)
+        f = torch.empty(n, nf, dtype=torch.float32, device=dev)
+        d = torch.empty(n, dtype=torch.float32, device=dev)
+        a = torch.empty(n, ncls, dtype=torch.float32, device=dev) if w_ac is not None else None
+        probs = torch.empty(B, ncls, dtype=torch.float32, device=dev) if w_ac is not None else None
+        ce_i = torch.empty(B, dtype=torch.float32, device=dev) if w_ac is not None else None
+        ct_i = torch.empty(B, dtype=torch.float32, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        check(lib.ctgan_tail_critic_heads_fwd2(_ptr(y), B, hw, nf, _ptr(w_out), _ptr(b_out), _ptr(w_ac), _ptr(b_ac), ncls, _ptr(labels), _ptr(gp),
+                                               _ptr(slopes), gp_lambda, _ptr(y_clean), 1 if clean_relu else 0, _ptr(f_c), _ptr(a_c), _ptr(acc),
+                                               lam2, M, scale, _ptr(f), _ptr(d), _ptr(a), _ptr(ct_i), _ptr(probs), _ptr(ce_i), _ptr(out),
+                                               _stream()), 'tail_critic_heads_fwd2')
+        return out, f, d, a, ct_i, probs, acc
     f = torch.empty(n, nf, dtype=torch.float32, device=dev)
     d = torch.empty(n, dtype=torch.float32, device=dev)
     ncls = w_ac.shape[1] if w_ac is not None else 0
@@ -1305,7 +1332,7 @@ def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, s
     check(lib.ctgan_tail_critic_heads_fwd(_ptr(y), B, hw, nf, _ptr(w_out), _ptr(b_out), _ptr(w_ac), _ptr(b_ac), ncls, _ptr(labels), _ptr(gp),
                                           lam2, M, scale, _ptr(f), _ptr(d), _ptr(a), _ptr(ct_i), _ptr(probs), _ptr(ce_i), _ptr(out),
                                           _stream()), 'tail_critic_heads_fwd')
-    return out, f, d, a, ct_i, probs
+    return out, f, d, a, ct_i, probs, None
 
 
 def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac):

@@ -389,7 +389,7 @@ int ctgan_bn_bwd(const float* gy, const float* x, const float* mean, const float
 size_t ctgan_bn_workspace_bytes(int32_t n, int32_t hw, int32_t c, int32_t groups, int32_t n_labels);
 
 /* ---- fused loss heads (K16-K20) ------------------------------------------------------------- */
-/* slopes[b] = ||g[b,:]||_2 ; gp = lambda*mean((slopes-1)^2)   (TF/CT_gan_cifar_resnet.py:285-286) */
+/* slopes[b] = ||g[b,:]||_2 ; gp = lambda*mean((slopes-1)^2)   (TF/CT_gan_cifar_resnet.py:285-286); gp == NULL: slopes only */
 int ctgan_gp_fwd(const float* g, int32_t b, int32_t d, float lambda, float* slopes, float* gp,
                  ctgan_stream_t stream);
 /* gg[b,:] = gout * lambda*2*(s-1)/(s*B) * g[b,:]                                               */
@@ -444,6 +444,17 @@ int ctgan_tail_critic_heads_fwd(const float* y, int32_t B, int32_t hw, int32_t n
                                 const float* w_ac, const float* b_ac, int32_t ncls, const int32_t* labels,
                                 const float* gp, float lambda2, float M, float acgan_scale, float* f, float* d, float* a,
                                 float* ct_i, float* probs, float* ce_i, float* out, ctgan_stream_t stream);
+/* ... with two more reductions folded into the same two launches:
+ *   slopes != NULL (gp then non-NULL): the gradient penalty's batch mean gp[0] = gp_lambda * mean((slopes - 1)^2) (:286) is taken by the
+ *     one-workgroup kernel and written to gp[0] before it enters out[] (pair with ctgan_gp_fwd(.., gp = NULL));
+ *   y_clean != NULL ([2B][hw][nf], real rows then fake rows, the dropout-free pass :228): a_clean [2B,ncls] = class head of its rows
+ *     (relu'd first when clean_relu; f_clean [2B,nf] scratch) by extra workgroups of the rows launch, and the accuracies acc[2]
+ *     (:249-266, as ctgan_accuracy2) by the one-workgroup kernel.                                                              */
+int ctgan_tail_critic_heads_fwd2(const float* y, int32_t B, int32_t hw, int32_t nf, const float* w_out, const float* b_out,
+                                 const float* w_ac, const float* b_ac, int32_t ncls, const int32_t* labels, float* gp,
+                                 const float* slopes, float gp_lambda, const float* y_clean, int32_t clean_relu, float* f_clean,
+                                 float* a_clean, float* acc, float lambda2, float M, float acgan_scale, float* f, float* d, float* a,
+                                 float* ct_i, float* probs, float* ce_i, float* out, ctgan_stream_t stream);
 int ctgan_tail_heads_bwd(const float* y, const float* d, const float* f, const float* probs, const int32_t* labels,
                          const float* ct_i, const float* gout, int32_t n_gout, int32_t B, int32_t hw, int32_t nf,
                          int32_t ncls, float lambda2, float M, float acgan_scale, float mask_scale, const float* w_out,

@@ -524,8 +524,10 @@ def bn_bwd(gy, x4, mean, rstd, scale, offset, labels, groups, relu):
 
 
 @_export
-def gp_fwd(g, lam):
+def gp_fwd(g, lam, defer_mean=False):
     slopes = torch.sqrt((g * g).sum(dim=1))
+    if defer_mean:
+        return torch.full((), float('nan'), dtype=g.dtype), slopes          # unwritten slot: filled by tail_critic_heads_fwd
     return lam * ((slopes - 1) ** 2).mean(), slopes
 
 
@@ -608,10 +610,17 @@ def tail_heads_fwd(y, w_out, b_out, w_ac, b_ac, relu=False):
 
 
 @_export
-def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, scale):
+def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, scale, slopes=None, gp_lambda=0.0, y_clean=None,
+                          clean_relu=False):
     f, d, a = tail_heads_fwd(y, w_out, b_out, w_ac, b_ac)
+    if slopes is not None:
+        gp.copy_((gp_lambda * ((slopes - 1) ** 2).mean()).reshape(gp.shape))
+    acc = None
+    if y_clean is not None:
+        _, _, a_c = tail_heads_fwd(y_clean, None, None, w_ac, b_ac, relu=clean_relu)
+        acc = accuracy2(a_c, labels, B)
     out, ct_i, probs = critic_heads_fwd(d, f, a, labels, B, lam2, M, scale, gp)
-    return out, f, d, a, ct_i, probs
+    return out, f, d, a, ct_i, probs, acc
 
 
 @_export

@@ -842,6 +842,32 @@ def test_fused_critic_tail_heads(K, B, nf, H, with_a):
     assert relerr(gw, gw_ref) < 1e-5
 
 
+@pytest.mark.parametrize('B,nf,H', [(64, 128, 8), (5, 32, 4)])
+def test_penalty_mean_and_clean_accuracies_folded_into_the_heads_launches(K, B, nf, H):
+    """ctgan_tail_critic_heads_fwd2: gp from the slopes (written into the slot gp_fwd(defer_mean=True) left) and the clean pass's class
+    head + accuracies inside the two launches of the fused heads - bit-identical to gp_fwd + tail_critic_heads_fwd + tail_heads_fwd +
+    accuracy2 as separate launches."""
+    g = torch.Generator().manual_seed(B + nf)
+    ncls = 10
+    y = cl(torch.relu(torch.randn(3 * B, nf, H, H, generator=g)))
+    yc = cl(torch.relu(torch.randn(2 * B, nf, H, H, generator=g)))
+    w_out, b_out = dev(torch.randn(nf, 1, generator=g) * 0.1), dev(torch.randn(1, generator=g))
+    w_ac, b_ac = dev(torch.randn(nf, ncls, generator=g) * 0.1), dev(torch.randn(ncls, generator=g))
+    lab = dev(torch.randint(0, ncls, (B,), generator=g, dtype=torch.int32))
+    grads = dev(torch.randn(B, 3072, generator=g) * 0.02)
+    gp0, sl0 = K.gp_fwd(grads, 10.0)
+    ref = K.tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, lab, gp0.reshape(1), 2.0, 0.0, 1.0)
+    _, _, a_c = K.tail_heads_fwd(yc, None, None, w_ac, b_ac, relu=False)
+    acc0 = K.accuracy2(a_c.contiguous(), lab, B)
+    gp1, sl1 = K.gp_fwd(grads, 10.0, defer_mean=True)
+    got = K.tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, lab, gp1.reshape(1), 2.0, 0.0, 1.0, slopes=sl1, gp_lambda=10.0,
+                                  y_clean=yc, clean_relu=False)
+    assert torch.equal(sl0, sl1) and torch.equal(gp0, gp1) and float(gp0) > 0
+    for a, b in zip(ref[:6], got[:6]):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    assert torch.equal(got[6], acc0) and 0.0 <= float(acc0[0]) <= 1.0
+
+
 @pytest.mark.parametrize('C,H,Ko,k,st,Ns', [(128, 8, 128, 3, 1, (12, 4)), (128, 16, 128, 4, 2, (8, 4, 2)), (64, 8, 96, 1, 1, (5,)),
                                             (128, 32, 128, 3, 1, (64, 16))])
 def test_multi_segment_wgrad(K, C, H, Ko, k, st, Ns):

@@ -513,3 +513,40 @@ def test_gp_double_backward_mask_rides_the_consumers_conv_epilogue(cpu_kernels, 
                 assert torch.equal(a, b), n
     finally:
         R.configure()
+
+
+def test_penalty_mean_and_clean_pass_accuracies_folded_into_the_heads_launches(cpu_kernels, monkeypatch):
+    """gan_cifar_resnet.HEADS_FOLD: gradient_penalty(defer_mean=True) leaves gp as a slot that critic_tail_heads fills from the slopes,
+    and the clean pass's class head + accuracies are computed by the same call (y_clean) - cost, wgan / ct / gp terms, accuracies and every
+    parameter gradient must equal the unfolded path's."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    B, dim = 4, 32
+    lib.set_seed(11)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    try:
+        R.build_params('cpu')
+        tr = R.Trainer(seed=4)
+        g = torch.Generator().manual_seed(6)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        res = {}
+        for mode in (False, True):
+            monkeypatch.setattr(R, 'HEADS_FOLD', mode)
+            F.prepare_filters()
+            tr.rng.begin_step()
+            out = tr.d_losses(real, labels)
+            with F.deferred_wgrads():
+                grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+            res[mode] = ({k: out[k].detach().clone() for k in ('cost', 'wgan', 'ct', 'gp', 'acgan', 'acc_real', 'acc_fake')},
+                         [None if x is None else x.clone() for x in grads])
+        for k, v in res[False][0].items():
+            assert torch.isfinite(v).all() and torch.allclose(res[True][0][k], v, rtol=1e-6, atol=1e-7), k
+        assert float(res[True][0]['gp']) > 0
+        for (n, _), a, b in zip(tr.d_named, res[False][1], res[True][1]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                _cmp(b, a, 1e-6, 'folded heads ' + n, atol=1e-8)
+    finally:
+        R.configure()

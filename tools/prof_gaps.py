@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Steady-state analysis of a rocprofv3 kernel trace (rocpd SQLite) of `bench.py --no-roofline --no-cpu-baseline`:
-the window of the last `iters` training iterations (delimited by adam_kernel launches: 6 per iteration),
+the window of the last `iters` training iterations (delimited by the Adam update launches: 6 per iteration),
 its busy time, idle gaps, and the per-kernel table inside that window.
 usage: python tools/prof_gaps.py results.db [iters=8] [top=40]"""
 import sqlite3
@@ -15,7 +15,7 @@ def main(path, iters=8, top=40):
     namecol = 'display_name' if 'display_name' in sym_cols else 'kernel_name'
     rows = cur.execute("select s.%s, d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
                        "on d.kernel_id = s.id order by d.start" % namecol).fetchall()
-    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    adam = [i for i, r in enumerate(rows) if any(k in r[0] for k in ('adam_kernel', 'adam_packed_kernel', 'adam_end_kernel'))]
     need = 6 * iters
     if len(adam) < need + 1:
         print('not enough adam launches', len(adam)); return
