@@ -165,9 +165,9 @@ SIGNATURES = {
     'ctgan_accuracy2': (c_int, [_p, _p, c_int32, c_int32, _p, _p]),
     'ctgan_adam_step': (c_int, [_p, _p, _p, _p, c_int64, _p, c_float, c_float, c_float, c_float, _p]),
     'ctgan_adam_advance': (c_int, [_p, c_float, c_float, _p]),
-    'ctgan_adam_step_end': (c_int, [_p, _p, _p, _p, c_int64, _p, c_float, c_float, c_float, c_float, _p, _p, c_uint64, _p]),
+    'ctgan_step_advance': (c_int, [_p, c_float, c_float, _p, c_uint64, _p]),
     'ctgan_adam_step_packed': (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), c_int32, _p, _p, _p, _p, _p, c_float, c_float,
-                                       c_float, c_float, _p, _p, c_uint64, _p]),
+                                       c_float, c_float, _p]),
     'ctgan_pack': (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), c_int32, _p, _p]),
     'ctgan_dropout_rng': (c_int, [_p, _p, c_int64, c_float, c_uint64, c_uint64, _p, _p]),
     'ctgan_dropout_rng_mask': (c_int, [_p, _p, _p, _p, c_int64, c_float, c_uint64, c_uint64, _p, _p]),

@@ -29,33 +29,15 @@ __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g,
 __global__ void adam_advance_kernel(float* state, float b1, float b2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] *= b1; state[2] *= b2; }
 }
-// End of a step inside the update launch itself: the workgroup that finishes LAST (a device counter, reset for the next
-// launch) multiplies the beta powers and bumps the Philox step counter - what adam_advance_kernel and rng_advance_kernel do as
-// two dependent one-thread launches (~5 us each on the critical path of a captured step).  Every workgroup has read `state`
-// before it signals (the barrier orders its threads' reads before thread 0's fence + atomic), so the writes race with nothing.
-struct StepEnd { unsigned* done; uint64_t* ctr; uint64_t by; };
-__device__ __forceinline__ void step_end(float* state, float b1, float b2, const StepEnd& e) {
-    if (!e.done) return;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned total = gridDim.x * gridDim.y;
-        if (atomicAdd(e.done, 1u) == total - 1) {
-            state[1] *= b1; state[2] *= b2;
-            if (e.ctr) e.ctr[0] += e.by;
-            *e.done = 0u;
-        }
+// End of a step: the beta powers of one optimizer and the Philox step counter advance in ONE one-thread launch (they used to be two
+// dependent launches, ~5 us each on the critical path of a captured step).  Doing it inside the update kernel itself - the workgroup
+// that finishes last, found with a device-scope fence + atomic per workgroup - was measured: 142 us for the 3456-workgroup update
+// (the XCDs' L2s are not coherent: every release fence writes back), against 6.6 us without; removed.
+__global__ void step_advance_kernel(float* state, float b1, float b2, uint64_t* ctr, uint64_t by) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        state[1] *= b1; state[2] *= b2;
+        if (ctr) ctr[0] += by;
     }
-}
-__global__ void adam_end_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
-                                float* __restrict__ v, long long n, float* state, float b1, float b2, float eps, float gscale,
-                                const StepEnd e) {
-    const float lr = state[0], b1p = state[1], b2p = state[2];
-    const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        adam_elem(th[i], m[i], v[i], g[i], gscale, b1, b2, eps, lr_t);
-    step_end(state, b1, b2, e);
 }
 
 // Gather separately allocated gradient tensors into the flat bucket in ONE launch.  The pointer table travels
@@ -80,11 +62,11 @@ __global__ void pack_kernel(const PackTable t, float* __restrict__ flat) {
         flat[off + i] = src ? src[i] : 0.f;
 }
 
-// pack_kernel + adam_kernel + the step end in one launch (single-rank steps: nothing happens between the gather and the update).
+// pack_kernel + adam_kernel in one launch (single-rank steps: nothing happens between the gather and the update).
 // The flat bucket is still written - it is the gradient the caller reports and the tests read.  Same per-element arithmetic as
 // adam_kernel on the packed bucket (bit-identical results).
 __global__ void adam_packed_kernel(const PackTable t, float* __restrict__ flat, float* __restrict__ th, float* __restrict__ m,
-                                   float* __restrict__ v, float* state, float b1, float b2, float eps, float gscale, const StepEnd e) {
+                                   float* __restrict__ v, const float* __restrict__ state, float b1, float b2, float eps, float gscale) {
     const float lr = state[0], b1p = state[1], b2p = state[2];
     const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     const float* src = t.src[blockIdx.y];
@@ -114,7 +96,6 @@ __global__ void adam_packed_kernel(const PackTable t, float* __restrict__ flat, 
             adam_elem(th[off + i], m[off + i], v[off + i], gr, gscale, b1, b2, eps, lr_t);
         }
     }
-    step_end(state, b1, b2, e);
 }
 
 // ---- Philox4x32-10 (Salmon et al., SC'11); constants of the Random123 reference
@@ -354,18 +335,15 @@ int ctgan_pack(const float* const* srcs, const int64_t* dst_offs, const int64_t*
     }
     return CTGAN_OK;
 }
-int ctgan_adam_step_end(float* theta, const float* g, float* m, float* v, int64_t n, float* state, float beta1, float beta2,
-                        float eps, float grad_scale, uint32_t* done, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t s) {
-    if (!theta || !g || !m || !v || !state || !done || n <= 0) return ctgan_fail(CTGAN_E_BADARG, "adam_step_end: bad argument");
-    StepEnd e{done, rng_ctr, rng_by};
-    hipLaunchKernelGGL(adam_end_kernel, dim3(ctgan_blocks(n, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), theta, g, m,
-                       v, (long long)n, state, beta1, beta2, eps, grad_scale, e);
-    return ctgan_check_launch("adam_step_end");
+int ctgan_step_advance(float* state, float beta1, float beta2, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t s) {
+    if (!state) return ctgan_fail(CTGAN_E_BADARG, "step_advance: null");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(s), state, beta1, beta2, rng_ctr, rng_by);
+    return ctgan_check_launch("step_advance");
 }
 int ctgan_adam_step_packed(const float* const* srcs, const int64_t* dst_offs, const int64_t* counts, int32_t n_tensors, float* flat,
-                           float* theta, float* m, float* v, float* state, float beta1, float beta2, float eps, float grad_scale,
-                           uint32_t* done, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t s) {
-    if (!srcs || !dst_offs || !counts || !flat || !theta || !m || !v || !state || !done || n_tensors <= 0)
+                           float* theta, float* m, float* v, const float* state, float beta1, float beta2, float eps, float grad_scale,
+                           ctgan_stream_t s) {
+    if (!srcs || !dst_offs || !counts || !flat || !theta || !m || !v || !state || n_tensors <= 0)
         return ctgan_fail(CTGAN_E_BADARG, "adam_step_packed: bad argument");
     if (n_tensors > PACK_MAX) return ctgan_fail(CTGAN_E_UNSUPPORTED, "adam_step_packed: more than %d tensors", PACK_MAX);
     if ((reinterpret_cast<uintptr_t>(flat) | reinterpret_cast<uintptr_t>(theta) | reinterpret_cast<uintptr_t>(m) |
@@ -378,9 +356,8 @@ int ctgan_adam_step_packed(const float* const* srcs, const int64_t* dst_offs, co
         t.src[i] = srcs[i]; t.dst_off[i] = dst_offs[i]; t.n[i] = counts[i];
         if (t.n[i] > mx) mx = t.n[i];
     }
-    StepEnd e{done, rng_ctr, rng_by};
     hipLaunchKernelGGL(adam_packed_kernel, dim3(ctgan_blocks(mx, 1024, 512), n_tensors), dim3(256), 0, static_cast<hipStream_t>(s), t,
-                       flat, theta, m, v, state, beta1, beta2, eps, grad_scale, e);
+                       flat, theta, m, v, state, beta1, beta2, eps, grad_scale);
     return ctgan_check_launch("adam_step_packed");
 }
 int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t s) {

@@ -103,7 +103,7 @@ class DCGANTrainer:
         opt.set_lr(self.mod.lr(self.iteration) if hasattr(self.mod, 'lr') else self.mod.cfg.LR)
         scale = 1.0 / (self.world * self.loss_scale)
         if self.allreduce is None or self.world <= 1:
-            opt.update(grads, scale, rng=self.rng)          # bucket + Adam + end of the step (beta powers, Philox counter): one launch
+            opt.update(grads, scale, rng=self.rng)          # bucket + Adam: one launch; end of the step (beta powers, Philox counter): one launch
             return
         flat = opt.gather_grads(grads)
         self.allreduce(flat)

@@ -106,7 +106,7 @@ class GraphedTrainer:
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
 
     def _finish(self, opt, grads):
-        """End of a captured step body.  Adam inside the graph: bucket + update + step end in one launch (single rank), or bucket,
+        """End of a captured step body.  Adam inside the graph: bucket + update in one launch and the step end in another (single rank), or bucket,
         in-graph all-reduce, update + step end.  Adam outside (side-stream all-reduce): the graph ends at the packed bucket and at
         the Philox counter's own advance - Trainer.reduce_and_update must not advance it again, hence rng=None there."""
         t = self.t

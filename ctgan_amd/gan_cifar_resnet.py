@@ -595,7 +595,7 @@ class Trainer:
         if set_lr:
             opt.set_lr(self.lr(iteration))
         if self.allreduce is None or self.world <= 1:
-            # single rank: gradient bucket, Adam and the end of the step (beta powers, Philox step counter) in ONE launch
+            # single rank: gradient bucket + Adam in one launch, the end of the step (beta powers, Philox step counter) in another
             opt.update(grads, 1.0 / self.world, rng=self.rng)
             return
         flat = opt.gather_grads(grads)

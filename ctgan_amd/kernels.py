@@ -1204,32 +1204,28 @@ def adam_step(theta, g, m, v, state, beta1, beta2, eps=1e-8, grad_scale=1.0):
                               grad_scale, _stream()), 'adam_step')
 
 
-def adam_step_end(theta, g, m, v, state, done, beta1, beta2, eps=1e-8, grad_scale=1.0, rng_ctr=None, rng_by=1):
-    """adam_step + adam_advance (+ rng_advance(rng_ctr, rng_by)) in one launch; `done` = device int32[1] counter, zero between launches."""
-    _need_dev(theta, g, m, v, state, done)
-    for t in (theta, g, m, v):
-        assert t.is_contiguous() and t.numel() == theta.numel()
-    assert done.dtype == torch.int32 and (rng_ctr is None or (rng_ctr.is_cuda and rng_ctr.dtype == torch.int64))
-    check(lib.ctgan_adam_step_end(_ptr(theta), _ptr(g), _ptr(m), _ptr(v), theta.numel(), _ptr(state), beta1, beta2, eps, grad_scale,
-                                  _ptr(done), _ptr(rng_ctr), rng_by, _stream()), 'adam_step_end')
+def step_advance(state, beta1, beta2, rng_ctr=None, rng_by=1):
+    """adam_advance(state) and rng_advance(rng_ctr, rng_by) in one launch - the end of a step."""
+    _need_dev(state)
+    assert rng_ctr is None or (rng_ctr.is_cuda and rng_ctr.dtype == torch.int64)
+    check(lib.ctgan_step_advance(_ptr(state), beta1, beta2, _ptr(rng_ctr), rng_by, _stream()), 'step_advance')
 
 
 ADAM_PACKED_MAX = 64
 
 
-def adam_step_packed(srcs, dst_offs, counts, flat, theta, m, v, state, done, beta1, beta2, eps=1e-8, grad_scale=1.0, rng_ctr=None,
-                     rng_by=1):
-    """pack(srcs -> flat) + adam_step_end in one launch (len(srcs) <= ADAM_PACKED_MAX)."""
-    _need_dev(flat, theta, m, v, state, done, *[t for t in srcs if t is not None])
+def adam_step_packed(srcs, dst_offs, counts, flat, theta, m, v, state, beta1, beta2, eps=1e-8, grad_scale=1.0):
+    """pack(srcs -> flat) + adam_step in one launch (len(srcs) <= ADAM_PACKED_MAX)."""
+    _need_dev(flat, theta, m, v, state, *[t for t in srcs if t is not None])
     n = len(srcs)
-    assert n <= ADAM_PACKED_MAX and done.dtype == torch.int32 and (rng_ctr is None or (rng_ctr.is_cuda and rng_ctr.dtype == torch.int64))
+    assert n <= ADAM_PACKED_MAX
     for t, c in zip(srcs, counts):
         assert t is None or (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == c)
     P = (ctypes.c_void_p * n)(*[t.data_ptr() if t is not None else None for t in srcs])
     O = (ctypes.c_int64 * n)(*dst_offs)
     C = (ctypes.c_int64 * n)(*counts)
     check(lib.ctgan_adam_step_packed(P, O, C, n, _ptr(flat), _ptr(theta), _ptr(m), _ptr(v), _ptr(state), beta1, beta2, eps, grad_scale,
-                                     _ptr(done), _ptr(rng_ctr), rng_by, _stream()), 'adam_step_packed')
+                                     _stream()), 'adam_step_packed')
 
 
 def pack(srcs, dst_offs, counts, flat):

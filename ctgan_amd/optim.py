@@ -43,7 +43,6 @@ class FlatAdam:
             assert state.shape == (4,) and state.dtype == torch.float32 and state.device.type == dev.type and state.is_contiguous()
             self.state = state
             self.state.copy_(init)
-        self.done = torch.zeros(1, dtype=torch.int32, device=dev)      # workgroups-finished counter of the fused step end
         self._lr_last = None      # value currently in state[0] if written by set_lr (None = unknown)
         self.t = 0
         self._keepalive = []
@@ -77,24 +76,27 @@ class FlatAdam:
         return self.grad
 
     def step(self, grad_scale=1.0, rng=None):
-        """theta <- Adam(theta, grad); advances the beta-power accumulators and, with `rng`, that stream's step counter
-        (DeviceRNG.end_step) - all in the update launch."""
-        K.adam_step_end(self.theta, self.grad, self.m, self.v, self.state, self.done, self.beta1, self.beta2, self.eps, grad_scale,
-                        rng.ctr if rng is not None else None, 1)
+        """theta <- Adam(theta, grad); then ONE launch advances the beta-power accumulators and, with `rng`, that stream's step
+        counter (DeviceRNG.end_step)."""
+        K.adam_step(self.theta, self.grad, self.m, self.v, self.state, self.beta1, self.beta2, self.eps, grad_scale)
+        self._end(rng)
+
+    def _end(self, rng):
+        K.step_advance(self.state, self.beta1, self.beta2, rng.ctr if rng is not None else None, 1)
         self.t += 1
         lib.bump_epoch(self.group)    # this network's weights changed: its derived-filter caches are stale
 
     def update(self, grads, grad_scale=1.0, rng=None):
-        """gather_grads + step in ONE launch: the single-rank form of a step (no collective between gather and update)."""
+        """gather_grads + step with the bucket and the update in ONE launch: the single-rank form of a step (no collective between
+        gather and update)."""
         if self.grad.device.type != 'cuda' or len(grads) > K.ADAM_PACKED_MAX:
             self.gather_grads(grads)
             return self.step(grad_scale, rng)
         srcs = [g.contiguous() if g is not None else None for g in grads]
-        K.adam_step_packed(srcs, self.offsets, self.sizes, self.grad, self.theta, self.m, self.v, self.state, self.done, self.beta1,
-                           self.beta2, self.eps, grad_scale, rng.ctr if rng is not None else None, 1)
+        K.adam_step_packed(srcs, self.offsets, self.sizes, self.grad, self.theta, self.m, self.v, self.state, self.beta1, self.beta2,
+                           self.eps, grad_scale)
         self._keepalive = srcs
-        self.t += 1
-        lib.bump_epoch(self.group)
+        self._end(rng)
 
     def load_named_slots(self, m_by_name, v_by_name, t):
         """Overwrite the Adam slots from per-parameter tensors (teacher-forced parity tests, resume)."""

@@ -485,16 +485,14 @@ int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32
 int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, const float* state,
                     float beta1, float beta2, float eps, float grad_scale, ctgan_stream_t stream);
 int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t stream);
-/* ctgan_adam_step + the end of the step in the same launch: the workgroup that finishes last (device counter `done`, zero before
- * the first call; the kernel resets it) does ctgan_adam_advance and, with rng_ctr != NULL, ctgan_rng_advance(rng_ctr, rng_by).    */
-int ctgan_adam_step_end(float* theta, const float* g, float* m, float* v, int64_t n, float* state, float beta1, float beta2,
-                        float eps, float grad_scale, uint32_t* done, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t stream);
-/* ctgan_pack + ctgan_adam_step_end in one launch (n_tensors <= 64, 16-byte aligned flat buffers; CTGAN_E_UNSUPPORTED otherwise):
+/* End of a step in one launch: ctgan_adam_advance(state) and, with rng_ctr != NULL, ctgan_rng_advance(rng_ctr, rng_by).            */
+int ctgan_step_advance(float* state, float beta1, float beta2, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t stream);
+/* ctgan_pack + ctgan_adam_step in one launch (n_tensors <= 64, 16-byte aligned flat buffers; CTGAN_E_UNSUPPORTED otherwise):
  * compute_gradients' bucket and apply_gradients (TF/CT_gan_cifar_resnet.py:335-338) of a single-rank step.  flat receives the
  * packed gradients as ctgan_pack writes them; theta/m/v are updated with bit-identical arithmetic to the two-launch form.        */
 int ctgan_adam_step_packed(const float* const* srcs, const int64_t* dst_offs, const int64_t* counts, int32_t n_tensors, float* flat,
-                           float* theta, float* m, float* v, float* state, float beta1, float beta2, float eps, float grad_scale,
-                           uint32_t* done, uint64_t* rng_ctr, uint64_t rng_by, ctgan_stream_t stream);
+                           float* theta, float* m, float* v, const float* state, float beta1, float beta2, float eps, float grad_scale,
+                           ctgan_stream_t stream);
 /* flat[dst_offs[i] : dst_offs[i] + counts[i]] = srcs[i][0:counts[i]] (srcs[i] == NULL: zeros), i < n_tensors, in one
  * launch per 64 tensors.  The three arrays are HOST arrays (the pointers are device pointers); they are passed to
  * the kernel by value, so the call is hipGraph-capture safe.  This is the gradient bucket of compute_gradients

@@ -716,8 +716,7 @@ def adam_advance(state, beta1, beta2):
 
 
 @_export
-def adam_step_end(theta, g, m, v, state, done, beta1, beta2, eps=1e-8, grad_scale=1.0, rng_ctr=None, rng_by=1):
-    adam_step(theta, g, m, v, state, beta1, beta2, eps, grad_scale)
+def step_advance(state, beta1, beta2, rng_ctr=None, rng_by=1):
     adam_advance(state, beta1, beta2)
     if rng_ctr is not None:
         rng_ctr += rng_by

@@ -539,9 +539,9 @@ def test_tf_adam_kernel(K):
     assert abs(state[1].item() - 0.5 ** 4) < 1e-7
 
 
-def test_fused_step_end_is_bit_identical_to_the_separate_launches(K):
-    """adam_step_packed (bucket + Adam + beta powers + Philox counter in one launch) and adam_step_end against
-    pack + adam_step + adam_advance + rng_advance, bit for bit, over several steps; the workgroup counter is back at 0."""
+def test_packed_update_and_step_advance_are_bit_identical_to_the_separate_launches(K):
+    """adam_step_packed (gradient bucket + Adam in one launch) + step_advance (beta powers + Philox counter in one launch) against
+    pack + adam_step + adam_advance + rng_advance, bit for bit, over several steps (a None gradient, unaligned sizes)."""
     sizes = [128 * 128 * 9, 37, 128, 3 * 3 * 3 * 128, 1, 4096]
     offs = [sum(sizes[:i]) for i in range(len(sizes))]
     n = sum(sizes)
@@ -551,9 +551,7 @@ def test_fused_step_end_is_bit_identical_to_the_separate_launches(K):
         th = torch.randn(n, generator=g)
         return [dev(th), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'),
                 dev(torch.tensor([2e-4, 0.5, 0.9, 0.0])), torch.zeros(1, dtype=torch.int64, device='cuda')]
-    A, B, C = fresh(), fresh(), fresh()                      # [theta, m, v, flat, state, ctr]
-    doneB = torch.zeros(1, dtype=torch.int32, device='cuda')
-    doneC = torch.zeros(1, dtype=torch.int32, device='cuda')
+    A, B = fresh(), fresh()                                  # [theta, m, v, flat, state, ctr]
     gen = torch.Generator().manual_seed(11)
     for t in range(1, 5):
         srcs = [dev(torch.randn(k, generator=gen)) if (i != 2 or t % 2) else None for i, k in enumerate(sizes)]
@@ -561,13 +559,11 @@ def test_fused_step_end_is_bit_identical_to_the_separate_launches(K):
         K.adam_step(A[0], A[3], A[1], A[2], A[4], 0.5, 0.9, 1e-8, 0.5)
         K.adam_advance(A[4], 0.5, 0.9)
         K.rng_advance(A[5], 1)
-        K.adam_step_packed(srcs, offs, sizes, B[3], B[0], B[1], B[2], B[4], doneB, 0.5, 0.9, 1e-8, 0.5, B[5], 1)
-        K.pack(srcs, offs, sizes, C[3])
-        K.adam_step_end(C[0], C[3], C[1], C[2], C[4], doneC, 0.5, 0.9, 1e-8, 0.5, C[5], 1)
-        for X in (B, C):
-            for a, x in zip(A, X):
-                assert torch.equal(a, x)
-        assert int(doneB) == 0 and int(doneC) == 0 and int(B[5]) == t
+        K.adam_step_packed(srcs, offs, sizes, B[3], B[0], B[1], B[2], B[4], 0.5, 0.9, 1e-8, 0.5)
+        K.step_advance(B[4], 0.5, 0.9, B[5], 1)
+        for a, x in zip(A, B):
+            assert torch.equal(a, x)
+        assert int(B[5]) == t
 
 
 def _philox_np(seed, sid, step, nblk):
