@@ -992,8 +992,9 @@ template <int MMA, int TM, int TN> constexpr bool wgrad16_one_wave() { return TM
 // one LDS stage, two workgroups per CU: the 128x128 tile of the split mode (see conv16_single_stage)
 template <int MMA, int TM, int TN> constexpr bool wgrad16_single_stage() { return planes<MMA>() == 3 && TM * TN == 4; }
 
-template <int MMA, int TM, int TN, bool RELU_X, bool SPLIT = wgrad16_one_wave<MMA, TM, TN>()>
-__global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
+// RMODE: relu on the x operand - 0 never, 1 always, 2 per problem (p.relu_x; the grouped launch)
+template <int MMA, int TM, int TN, int RMODE, bool SPLIT = wgrad16_one_wave<MMA, TM, TN>()>
+__device__ __forceinline__ void wgrad16_body(const W16& p, const int bx, const int by) {
     // block tile: (2*TM*32) channels of ONE tap  x  (2*TN*32) kout, K slices of 64 pixels (32 in the split mode: three planes per operand)
     constexpr int NP = planes<MMA>();
     constexpr int NT = 256, BKP = NP == 3 ? 32 : 64;
@@ -1018,7 +1019,6 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.Ng + BNK - 1) / BNK;
-    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     const int tile_m = bx / tiles_n, tile_n = bx - tile_m * tiles_n;
     const int cblocks = p.C / BMC;                       // M tiles per tap
     const int tap = tile_m / cblocks, c0 = (tile_m - tap * cblocks) * BMC;
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         for (int b = 0; b < X_PER; ++b) {
             const int pg = tid % XPG + XPG * (b % (PGS / XPG)), cg = tid / XPG + (NT / XPG) * (b / (PGS / XPG));
             float4 (&v)[4] = rxv[SET][b];
-            if (RELU_X) {
+            if (RMODE == 1 || (RMODE == 2 && p.relu_x)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e].x = fmaxf(v[e].x, 0.f); v[e].y = fmaxf(v[e].y, 0.f); v[e].z = fmaxf(v[e].z, 0.f); v[e].w = fmaxf(v[e].w, 0.f); }
             }
@@ -1122,7 +1122,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
         for (int b = 0; b < Y_PER; ++b) {
             const int pg = tid % YPG + YPG * (b % (PGS / YPG)), cg = tid / YPG + (NT / YPG) * (b / (PGS / YPG));
             const float4 (&v)[4] = ryv[SET][b];
-            if (bias_wg) {           // workgroup-uniform: the bias gradient rides the staging of dy (rows past the chunk were loaded as zeros)
+            if (bias_wg && p.with_bias == 1) {      // workgroup-uniform: the bias gradient rides the staging of dy (rows past the chunk were loaded as zeros); with_bias == 2: the row stays zero
                 bsum[b].x += (v[0].x + v[1].x) + (v[2].x + v[3].x); bsum[b].y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
                 bsum[b].z += (v[0].z + v[1].z) + (v[2].z + v[3].z); bsum[b].w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
             }
@@ -1263,6 +1263,66 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
                 out[((long long)tap * p.C + c) * p.Ng + col] = acc[i][j][e];
             }
         }
+}
+
+template <int MMA, int TM, int TN, bool RELU_X>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const W16 p) {
+    wgrad16_body<MMA, TM, TN, RELU_X ? 1 : 0>(p, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Several weight-gradient problems (different filters, or several (x, dy) uses of one filter) in ONE launch: the small launches of a
+// step - 8x8 layers, the 64-row gradient-penalty segments - each fill a fraction of the chip and pay a launch of their own; together
+// they fill it.  Workgroups [first[j], first[j+1]) belong to problem j, tile-major inside a split (the splits of one tile are far apart).
+constexpr int W16_GROUP_MAX = 20;
+struct W16Group { int n; int first[W16_GROUP_MAX + 1]; int tiles[W16_GROUP_MAX]; W16 j[W16_GROUP_MAX]; };
+template <int MMA, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad16_group_kernel(const W16Group g) {
+    int job = 0;
+    while (job + 1 < g.n && (int)blockIdx.x >= g.first[job + 1]) ++job;
+    job = __builtin_amdgcn_readfirstlane(job);
+    const int local = (int)blockIdx.x - g.first[job];
+    const int tiles = g.tiles[job];
+    const int by = local / tiles;
+    wgrad16_body<MMA, TM, TN, 2>(g.j[job], local - by * tiles, by);
+}
+
+// the reductions of all problems of a grouped launch in one launch: job = blockIdx.y; out = sum of the slabs [+ add] (fixed order)
+constexpr int R16_BATCH = 16;
+struct R16Job { const float* part; float* out; float* out2; const float* add; const float* add2; long long n, n_main; int splits, pad; };
+struct R16Jobs { int n; int pad; R16Job j[R16_BATCH]; };
+__global__ void reduce16_batch_kernel(const R16Jobs jobs) {
+    const R16Job& jb = jobs.j[blockIdx.y];
+    const long long n = jb.n, n_main = jb.n_main;
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float* part = jb.part;
+    const int splits = jb.splits;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)(k + 0) * n + i);
+        const float4 v1 = *reinterpret_cast<const float4*>(part + (long long)(k + 1) * n + i);
+        const float4 v2 = *reinterpret_cast<const float4*>(part + (long long)(k + 2) * n + i);
+        const float4 v3 = *reinterpret_cast<const float4*>(part + (long long)(k + 3) * n + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; k < splits; ++k) {
+        const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float4 r;
+    r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
+    r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
+    if (i < n_main) {
+        if (jb.add) { const float4 v = *reinterpret_cast<const float4*>(jb.add + i); r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        *reinterpret_cast<float4*>(jb.out + i) = r;
+    } else {
+        if (jb.add2) { const float4 v = *reinterpret_cast<const float4*>(jb.add2 + (i - n_main)); r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        *reinterpret_cast<float4*>(jb.out2 + (i - n_main)) = r;
+    }
 }
 
 // elements [0, n_main) go to `out`, the trailing n - n_main (the bias row of the slabs) to `out2`; n, n_main multiples of 4
@@ -1975,6 +2035,152 @@ int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x,
         return ctgan_check_launch("reduce16");
     }
     return 0;
+}
+
+}  // extern "C"
+
+// ---- grouped split-mode weight gradients -----------------------------------------------------------------------------------------
+namespace {
+struct G16Seg { W16 p; int tiles, splits; };
+struct G16Plan { int nseg_total; int chunk; long long blocks; size_t ws_bytes; };
+bool group16_member_ok(const ctgan_wgrad_group& G) {
+    const ctgan_conv_desc* d = &G.d;
+    if (G.nseg < 1 || G.nseg > CTGAN_WGRAD_MAX_SEGS || !shape_ok_wgrad_x3(d) || d->x_up || d->xs[1] != 1) return false;
+    if (d->ys[1] != 1 || d->ys[3] != d->K || d->ys[2] != (int64_t)d->Q * d->K || d->ys[0] != (int64_t)d->P * d->Q * d->K) return false;   // dense channels-last dy
+    if (G.db && (d->K % 4 || (reinterpret_cast<uintptr_t>(G.db) & 15))) return false;
+    for (int k = 0; k < G.nseg; ++k) {
+        if (G.Ns[k] < 1) return false;
+        const long long x_extent = (long long)(G.Ns[k] - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
+        if (x_extent * 4 >= (1LL << 32) || (long long)G.Ns[k] * d->P * d->Q * d->K * 4 >= (1LL << 32)) return false;
+    }
+    return true;
+}
+// One chunk (pixels per split, multiple of 64) for every problem of the call: workgroups of equal length.  Estimated time of the launch
+// for a candidate = rounds of 512 resident workgroups (two per CU) x (chunk pixels at ~70 ns each + a fixed prologue / 64 KB slab
+// store); the smallest estimate wins, longer chunks (fewer slabs to write and reduce) among near-equals.
+G16Plan group16_plan(const ctgan_wgrad_group* groups, int n) {
+    G16Plan best{0, 0, 0, 0};
+    double best_t = 1e30;
+    int max_kg = 0, nseg = 0;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < groups[i].nseg; ++k) { const int kg = groups[i].Ns[k] * groups[i].d.P * groups[i].d.Q; if (kg > max_kg) max_kg = kg; ++nseg; }
+    static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_GROUP_CHUNK"); return e ? atoi(e) : 0; }();
+    for (int chunk = 256; chunk <= 8192; chunk += 64) {
+        if (forced && chunk != forced) continue;
+        long long blocks = 0; size_t ws = 0;
+        for (int i = 0; i < n; ++i) {
+            const ctgan_conv_desc& d = groups[i].d;
+            const long long tiles = (long long)d.R * d.S * (d.C / 128) * (d.K / 128);
+            long long splits = 0;
+            for (int k = 0; k < groups[i].nseg; ++k) splits += ((long long)groups[i].Ns[k] * d.P * d.Q + chunk - 1) / chunk;
+            blocks += tiles * splits;
+            ws += ((size_t)splits * ((size_t)d.R * d.S * d.C + (groups[i].db ? 1 : 0)) * d.K * sizeof(float) + 255) & ~(size_t)255;
+        }
+        const long long rounds = (blocks + 511) / 512;
+        const double t = (double)rounds * (chunk * 0.07 + 5.0) + (double)blocks * 0.02;
+        if (t < best_t * 0.985) { best_t = t; best = G16Plan{nseg, chunk, blocks, ws}; }
+        if (chunk >= max_kg && !forced) break;
+    }
+    return best;
+}
+}  // namespace
+
+extern "C" {
+
+size_t ctgan_conv2d16_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n) {
+    if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT) return 0;
+    for (int i = 0; i < n; ++i) if (!group16_member_ok(groups[i])) return 0;
+    return group16_plan(groups, n).ws_bytes;
+}
+
+int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, int phases, ctgan_stream_t stream) {
+    if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (!groups[i].dw) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: null dw");
+        for (int k = 0; k < groups[i].nseg && k < CTGAN_WGRAD_MAX_SEGS; ++k)
+            if (!groups[i].xs[k] || !groups[i].dys[k]) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: null operand");
+        if (!group16_member_ok(groups[i])) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad_group: problem %d outside the split-mode 128x128 tile", i);
+    }
+    const G16Plan plan = group16_plan(groups, n);
+    if (!ws || plan.ws_bytes > ws_bytes) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: workspace %zu B < %zu B", ws_bytes, plan.ws_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    static thread_local G16Seg segs[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
+    static thread_local R16Job red[CTGAN_WGRAD_GROUP_LIMIT];
+    int ns = 0;
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const ctgan_wgrad_group& G = groups[i];
+        const ctgan_conv_desc* d = &G.d;
+        const int rows = d->R * d->S * d->C + (G.db ? 1 : 0);
+        float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + off);
+        int splits_total = 0;
+        for (int k = 0; k < G.nseg; ++k) {
+            W16 p{};
+            p.X = G.xs[k]; p.DY = G.dys[k];
+            p.OUT = slab + (size_t)splits_total * rows * d->K;
+            p.with_bias = G.db ? ((G.seg_flags[k] & CTGAN_WGRAD_SEG_BIAS) ? 1 : 2) : 0;
+            p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.C = d->C; p.R = d->R; p.S = d->S; p.stride = d->stride;
+            p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+            p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
+            p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = G.Ns[k] * d->P * d->Q;
+            p.chunk = plan.chunk; p.relu_x = (G.seg_flags[k] & CTGAN_IN_RELU) ? 1 : 0; p.dbg = 0;
+            p.pq_shift = __builtin_ctz(d->P * d->Q); p.q_shift = __builtin_ctz(d->Q);
+            const long long x_extent = (long long)(G.Ns[k] - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
+            p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)((long long)p.Kg * d->K * 4);
+            G16Seg& sg = segs[ns++];
+            sg.p = p; sg.tiles = d->R * d->S * (d->C / 128) * (d->K / 128); sg.splits = (p.Kg + plan.chunk - 1) / plan.chunk;
+            splits_total += sg.splits;
+        }
+        const long long n_main = (long long)d->R * d->S * d->C * d->K;
+        red[i].part = slab; red[i].out = G.dw; red[i].out2 = G.db ? G.db : G.dw;
+        red[i].add = G.add_dw; red[i].add2 = G.db ? G.add_db : nullptr;
+        red[i].n = n_main + (G.db ? d->K : 0); red[i].n_main = n_main; red[i].splits = splits_total; red[i].pad = 0;
+        off += ((size_t)splits_total * rows * d->K * sizeof(float) + 255) & ~(size_t)255;
+    }
+    if (phases & CTGAN_WGRAD_GROUP_GEMM) {
+        constexpr size_t lds = (size_t)3 * (128 + 128) * (32 + 8) * 2;       // one stage, three planes (wgrad16_single_stage)
+        auto kern = wgrad16_group_kernel<CTGAN_MMA_F32X3, 2, 2>;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16_group: cannot reserve %zu B of LDS", lds);
+            attr = true;
+        }
+        // longest problems first (their last, short split aside every workgroup runs one chunk; order by pixels keeps the tails together)
+        int order[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
+        for (int a = 0; a < ns; ++a) order[a] = a;
+        for (int a = 1; a < ns; ++a)
+            for (int b = a; b > 0 && segs[order[b]].p.Kg > segs[order[b - 1]].p.Kg; --b) { const int x = order[b]; order[b] = order[b - 1]; order[b - 1] = x; }
+        for (int base = 0; base < ns; base += W16_GROUP_MAX) {
+            W16Group g;
+            g.n = (ns - base) < W16_GROUP_MAX ? (ns - base) : W16_GROUP_MAX;
+            int b0 = 0;
+            for (int k = 0; k < W16_GROUP_MAX; ++k) {
+                const G16Seg& sg = segs[order[base + (k < g.n ? k : 0)]];
+                g.first[k] = b0; g.tiles[k] = sg.tiles; g.j[k] = sg.p;
+                if (k < g.n) b0 += sg.tiles * sg.splits;
+            }
+            g.first[W16_GROUP_MAX] = b0;
+            hipLaunchKernelGGL(kern, dim3((unsigned)b0), dim3(256), lds, st, g);
+            int rc = ctgan_check_launch("wgrad16_group");
+            if (rc) return rc;
+        }
+        ctgan_set_last_kernel("wgrad16x3_group<128x128>");
+        ctgan_set_last_symbol("wgrad16_group_kernel<3, 2, 2>");
+    }
+    for (int base = 0; base < n && (phases & CTGAN_WGRAD_GROUP_REDUCE); base += R16_BATCH) {
+        R16Jobs jobs;
+        jobs.n = (n - base) < R16_BATCH ? (n - base) : R16_BATCH; jobs.pad = 0;
+        long long max_n = 0;
+        for (int k = 0; k < R16_BATCH; ++k) {
+            jobs.j[k] = red[base + (k < jobs.n ? k : 0)];
+            if (k < jobs.n && jobs.j[k].n > max_n) max_n = jobs.j[k].n;
+        }
+        hipLaunchKernelGGL(reduce16_batch_kernel, dim3((unsigned)((max_n / 4 + 255) / 256), jobs.n), dim3(256), 0, st, jobs);
+        int rc = ctgan_check_launch("reduce16_batch");
+        if (rc) return rc;
+    }
+    return CTGAN_OK;
 }
 
 }  // extern "C"

@@ -80,11 +80,18 @@ def _conv_mode(d, op, plain):
     return None
 
 
+# Hybrid fp32 mode: the queued weight gradients of a step ride ONE grouped split-mode launch (ctgan_conv2d16_wgrad_group) where they
+# qualify, instead of the fp32 family's grouped launch.  2: also the large ones that would be launched at once (wgrad_prefers_x3).
+X3_WGRAD_GROUP = int(os.environ.get('CTGAN_X3_WGRAD_GROUP', '1'))
+
+
 def wgrad_prefers_x3(g, N, device=None):
     """True when the fp32 mode routes this weight gradient to the split mode (then it is launched at once, not queued for the fp32
     family's grouped launch).  Needs dense channels-last operands, which the callers of the large layers provide."""
     if MMA_DTYPE is not None or not X3_HYBRID or g.x_up or fewch_handles(g) or (device is not None and torch.device(device).type != 'cuda'):
         return False
+    if X3_WGRAD_GROUP >= 2:
+        return False              # everything is queued: the grouped split-mode launch takes the large problems as well
     d = g.desc(N, (g.C * g.H * g.W, 1, g.W * g.C, g.C), (g.K * g.P * g.Q, 1, g.Q * g.K, g.K))
     return bool(lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 2))
 
@@ -613,10 +620,40 @@ def conv_wgrad_group(groups):
         assert add_dw is None or (add_dw.shape == dw.shape and add_dw.is_contiguous())
         G.add_dw = add_dw.data_ptr() if add_dw is not None else None
         G.add_db = add_db.data_ptr() if (add_db is not None and db is not None) else None
+    # hybrid fp32 mode / split mode: the members the 128x128 split-mode tile takes ride ONE grouped split-mode launch
+    x3 = []
+    if X3_WGRAD_GROUP and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID)):
+        x3 = [i for i in range(n) if lib.ctgan_conv2d16_wgrad_group_workspace_bytes(ctypes.byref(arr[i]), 1) > 0]
+    if x3:
+        arr3 = (WgradGroup * len(x3))()
+        for k, i in enumerate(x3):
+            arr3[k] = arr[i]
+        nb3 = lib.ctgan_conv2d16_wgrad_group_workspace_bytes(arr3, len(x3))
+        ws3 = workspace(nb3, dev)
+        if PROFILE is None:
+            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), _ptr(ws3), ws3.numel(), 3, _stream()), 'conv2d16_wgrad_group')
+        else:
+            st = torch.cuda.current_stream()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(PROFILE_REPS):
+                check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), _ptr(ws3), ws3.numel(), 1, _stream()), 'conv2d16_wgrad_group')
+            e1.record(st)
+            flops = sum(_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in x3)
+            PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, ('group', len(x3)), last_symbol()))
+            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), _ptr(ws3), ws3.numel(), 2, _stream()), 'conv2d16_wgrad_group')
+        rest = [i for i in range(n) if i not in set(x3)]
+        if not rest:
+            return
+        arr_r = (WgradGroup * len(rest))()
+        for k, i in enumerate(rest):
+            arr_r[k] = arr[i]
+        groups = [groups[i] for i in rest]
+        arr, n = arr_r, len(rest)
     nb = lib.ctgan_conv2d_wgrad_group_workspace_bytes(arr, n)
     if nb == 0:
         raise NotImplementedError('conv2d_wgrad_group: unsupported group')
-    ws = workspace(nb, dev)
+    ws = workspace(nb, dev)            # (stream order: the split-mode launch above has read its slabs before these are written)
     if PROFILE is None:
         check(lib.ctgan_conv2d_wgrad_group(arr, n, _ptr(ws), ws.numel(), _stream()), 'conv2d_wgrad_group')
         return
