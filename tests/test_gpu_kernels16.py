@@ -338,6 +338,46 @@ def test_f32x3_wgrad_with_the_fused_bias_gradient(K):
         assert relerr(db1, ref) < 2e-6, (N, relerr(db1, ref))
 
 
+def test_grouped_split_mode_wgrad_equals_the_fp32_family(K):
+    """ctgan_conv2d16_wgrad_group (hybrid fp32 mode): the queued weight gradients that fit the 128x128 split-mode tile - several filters,
+    geometries, 1-3 segments each with their own relu / bias flags, a finished addend - from ONE grouped launch + one batched reduction
+    agree with the fp32 MFMA family to fp32 rounding; a member outside the tile (C = 64) stays on the fp32 family's grouped launch in the
+    same call; the result is deterministic."""
+    g = torch.Generator().manual_seed(78)
+    cases = [(128, 8, 128, 3, 1, (64, 64, 32)), (128, 8, 128, 3, 1, (96,)), (128, 16, 128, 4, 2, (48, 16)), (128, 16, 128, 3, 1, (64, 8)),
+             (128, 32, 128, 4, 2, (32, 8)), (64, 8, 96, 1, 1, (5,)), (128, 8, 128, 1, 1, (192, 64)), (256, 8, 128, 3, 1, (7, 3)),
+             (128, 4, 256, 3, 1, (16,)), (128, 8, 128, 3, 1, (33,))]
+    groups, refs = [], []
+    for ci, (C, H, Ko, k, st, Ns) in enumerate(cases):
+        geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+        segs = []
+        for i, n in enumerate(Ns):
+            x = cl(torch.randn(n, C, H, H, generator=g)); gy = cl(torch.randn(n, Ko, geom.P, geom.Q, generator=g))
+            segs.append((x, gy, (i + ci) % 2 == 0, i != 1 and ci % 3 != 2))
+        has_b = any(sg[3] for sg in segs)
+        dw = torch.empty(k, k, C, Ko, device='cuda'); db = torch.empty(Ko, device='cuda') if has_b else None
+        dw_r = torch.empty_like(dw); db_r = torch.empty_like(db) if has_b else None
+        K.conv_wgrad_multi(segs, geom, dw_r, db_r)
+        add = (torch.randn(k, k, C, Ko, generator=g).cuda(), torch.randn(Ko, generator=g).cuda() if has_b else None) if ci % 4 == 1 else (None, None)
+        if add[0] is not None:
+            dw_r = dw_r + add[0]
+            db_r = db_r + add[1] if has_b else None
+        groups.append((segs, geom, dw, db, add[0], add[1])); refs.append((dw_r, db_r))
+    assert K.X3_WGRAD_GROUP and K.X3_HYBRID
+    K.conv_wgrad_group(groups)
+    first = [(dw.clone(), None if db is None else db.clone()) for _, _, dw, db, _, _ in groups]
+    for (segs, geom, dw, db, _, _), (dw_r, db_r) in zip(groups, refs):
+        assert relerr(dw, dw_r) < 3e-6, (geom.C, geom.H, geom.R, relerr(dw, dw_r))
+        if db is not None:
+            assert relerr(db, db_r) < 3e-6
+    K.conv_wgrad_group(groups)
+    for (segs, geom, dw, db, _, _), (dw0, db0) in zip(groups, first):
+        assert torch.equal(dw, dw0) and (db is None or torch.equal(db, db0))
+    with K.mma_dtype('f32x3'):
+        K.conv_wgrad_group(groups[:5])
+        assert 'wgrad16x3_group' in K.last_kernel(), K.last_kernel()
+
+
 def test_conv16_wgrad_runs_on_the_16bit_kernel_and_is_deterministic(K):
     N, C, H, Ko = 16, 128, 16, 256
     geom = K.ConvGeom(C, H, H, Ko, 5, 5, 2, False)
