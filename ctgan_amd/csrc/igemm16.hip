@@ -2123,12 +2123,16 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void*
             p.pad_t = d->pad_t; p.pad_l = d->pad_l;
             p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
             p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = G.Ns[k] * d->P * d->Q;
-            p.chunk = plan.chunk; p.relu_x = (G.seg_flags[k] & CTGAN_IN_RELU) ? 1 : 0; p.dbg = 0;
+            p.relu_x = (G.seg_flags[k] & CTGAN_IN_RELU) ? 1 : 0; p.dbg = 0;
+            {   // the planned number of splits, of EQUAL length within the problem (the planner's chunk is the upper bound)
+                const int sp = (p.Kg + plan.chunk - 1) / plan.chunk;
+                p.chunk = (((p.Kg + sp - 1) / sp) + 63) / 64 * 64;
+            }
             p.pq_shift = __builtin_ctz(d->P * d->Q); p.q_shift = __builtin_ctz(d->Q);
             const long long x_extent = (long long)(G.Ns[k] - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
             p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)((long long)p.Kg * d->K * 4);
             G16Seg& sg = segs[ns++];
-            sg.p = p; sg.tiles = d->R * d->S * (d->C / 128) * (d->K / 128); sg.splits = (p.Kg + plan.chunk - 1) / plan.chunk;
+            sg.p = p; sg.tiles = d->R * d->S * (d->C / 128) * (d->K / 128); sg.splits = (p.Kg + p.chunk - 1) / p.chunk;
             splits_total += sg.splits;
         }
         const long long n_main = (long long)d->R * d->S * d->C * d->K;
@@ -2146,11 +2150,11 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void*
                 return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16_group: cannot reserve %zu B of LDS", lds);
             attr = true;
         }
-        // longest problems first (their last, short split aside every workgroup runs one chunk; order by pixels keeps the tails together)
+        // longest workgroups first
         int order[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
         for (int a = 0; a < ns; ++a) order[a] = a;
         for (int a = 1; a < ns; ++a)
-            for (int b = a; b > 0 && segs[order[b]].p.Kg > segs[order[b - 1]].p.Kg; --b) { const int x = order[b]; order[b] = order[b - 1]; order[b - 1] = x; }
+            for (int b = a; b > 0 && segs[order[b]].p.chunk > segs[order[b - 1]].p.chunk; --b) { const int x = order[b]; order[b] = order[b - 1]; order[b - 1] = x; }
         for (int base = 0; base < ns; base += W16_GROUP_MAX) {
             W16Group g;
             g.n = (ns - base) < W16_GROUP_MAX ? (ns - base) : W16_GROUP_MAX;

@@ -421,7 +421,9 @@ class ConvDgradFn(Function):
         dx = K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid, drop=drop)
         if PREMASK_FUSION and mask is not None and resid is None and drop is None and b is None:
             tok = _PreMask()
-            tok.dx, tok.mask, tok.fused = dx, mask, None
+            # (a DETACHED alias: dx itself gets this node as grad_fn -> ctx -> token -> dx would be a reference cycle that keeps the whole
+            # first-backward graph alive until the cycle collector runs - inside a stream capture that crashed capture_end)
+            tok.dx, tok.mask, tok.fused = dx.detach(), mask, None
             _PREMASK[dx.data_ptr()] = ctx.own = tok
         return (dx, gy.view_as(gy)) if fork else dx
 
@@ -458,7 +460,7 @@ class ConvDgradFn(Function):
         if ctx.needs_input_grad[0] and ctx.pre is not None and gg_fork is None:
             # gy = mask(a) * (...) was produced by a data-gradient node that masks what arrives for it: apply that mask here
             g_gy = ConvFn.apply(ggx, w, None, None, g, None, False, False, {'out_mask': ctx.pre.mask})
-            ctx.pre.fused = g_gy
+            ctx.pre.fused = g_gy.detach()
         elif ctx.needs_input_grad[0]:
             g_gy = ConvFn.apply(ggx, w, None, gg_fork, g, None, False)        # + the fork branch's gradient, in the epilogue
         elif gg_fork is not None:

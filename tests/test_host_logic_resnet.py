@@ -550,3 +550,44 @@ def test_penalty_mean_and_clean_pass_accuracies_folded_into_the_heads_launches(c
                 _cmp(b, a, 1e-6, 'folded heads ' + n, atol=1e-8)
     finally:
         R.configure()
+
+
+def test_premask_links_do_not_keep_the_backward_graph_alive(cpu_kernels, monkeypatch):
+    """The producer/consumer links of functional.PREMASK_FUSION must die with the step by reference counting alone: a link that held the
+    data gradient ITSELF (whose grad_fn owns the link) was a reference cycle, freed only by the cycle collector - at an arbitrary later
+    point, once inside hipStreamEndCapture (segfault of `bench.py --gp-unit-only`)."""
+    import gc
+    import weakref
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    B, dim = 4, 32
+    lib.set_seed(13)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    made = []
+
+    class Tracked(F._PreMask):
+        def __init__(self):
+            made.append(weakref.ref(self))
+    monkeypatch.setattr(F, '_PreMask', Tracked)
+    try:
+        R.build_params('cpu')
+        tr = R.Trainer(seed=5)
+        g = torch.Generator().manual_seed(7)
+        real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+        labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+        gc.collect()
+        gc.disable()
+        try:
+            F.prepare_filters()
+            tr.rng.begin_step()
+            out = tr.d_losses(real, labels)
+            with F.deferred_wgrads():
+                grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+            assert len(made) >= 4
+            del out, grads
+            assert all(r() is None for r in made), 'a premask link survived the step without the cycle collector'
+        finally:
+            gc.enable()
+    finally:
+        R.configure()
