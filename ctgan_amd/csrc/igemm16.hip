@@ -1489,14 +1489,15 @@ int x3_8x8_mode() { static const int v = [] { const char* e = getenv("CTGAN_X3_8
 // Which launches the hybrid routing hands to the fragment-streaming kernel (tools/conv16_bench.py on the headline's layers,
 // profiles/r03_conv_bench_*.txt, profiles/r03_hf_tile_sweep_*.txt; fp32 family for comparison: 112-129 on 32x32 / 16x16 images at 128-320 rows,
 // 103 at (64, 16x16), 69 / 89 / 94 / 104 at 8x8 images of 64 / 128 / 192 / 384 rows): every launch whose preferred tile yields >= 192 workgroups on
-// images of >= 256 pixels; 8x8 images per x3_8x8_mode() from 128 rows up (64 rows: 53 against the fp32 family's 69 - stays there).
+// images of >= 256 pixels; 8x8 images per x3_8x8_mode() from 128 rows up (>= 256 tiles of 32 pixels; 64 rows: 53 against the fp32 family's 69 - stays there).
 bool conv16x3hf_wins(const P16& p) {
     const int bmp = conv16x3hf_tile(p);
     if (!bmp) return false;
     const long long tiles = (long long)(p.M / bmp) * (p.Ng / 128);
     const int PQ = p.P * p.Q;
     if (PQ >= 256) return tiles >= 192;
-    return PQ == 64 && x3_8x8_mode() == 1 && bmp == 32 && tiles >= 384;
+    static const int min_tiles = [] { const char* e = getenv("CTGAN_X3_8X8_MIN_TILES"); return e ? atoi(e) : 256; }();     // 256 = from 128 rows: 15.50 vs 15.65 ms per iteration on one box (384: round-3 mid-state; 128 = 64 rows: 15.79)
+    return PQ == 64 && x3_8x8_mode() == 1 && bmp == 32 && tiles >= min_tiles;
 }
 // CTGAN_X3_HALO_V=1: the filter through an LDS stage (conv16x3h_kernel, 128-pixel tiles only); default 2: filter fragments streamed
 // from L2 (conv16x3hf_kernel, 128- / 64- / 32-pixel tiles)
