@@ -1277,6 +1277,9 @@ constexpr int W16_GROUP_MAX = 20;
 struct W16Group { int n; int first[W16_GROUP_MAX + 1]; int tiles[W16_GROUP_MAX]; W16 j[W16_GROUP_MAX]; };
 template <int MMA, int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad16_group_kernel(const W16Group g) {
+    // (An XCD-aware order - the tap tiles of one split on one XCD's L2, logical index = the XCD's contiguous range - was measured: 14.246
+    // vs 14.253 ms per iteration, no effect, although the launch misses L2 on 70 % of its requests (profiles/r03_pmc_traffic_x3.json):
+    // the misses are served by the memory-side cache at a rate the kernel does not wait for.  Not kept.)
     int job = 0;
     while (job + 1 < g.n && (int)blockIdx.x >= g.first[job + 1]) ++job;
     job = __builtin_amdgcn_readfirstlane(job);
@@ -1644,7 +1647,7 @@ int launch_wgrad16(const W16& p, int splits, hipStream_t st, const char* name) {
     const int tiles_m = p.R * p.S * (p.C / BMC), tiles_n = (p.Ng + BNK - 1) / BNK;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * tiles_n), (unsigned)splits), dim3(256), lds, st, p);
     ctgan_set_last_kernel(name);
-    ctgan_set_last_symbol("wgrad16_kernel<%d, %d, %d, %s, %s>", MMA, TM, TN, p.relu_x ? "true" : "false", wgrad16_one_wave<MMA, TM, TN>() ? "true" : "false");
+    ctgan_set_last_symbol("wgrad16_kernel<%d, %d, %d, %s>", MMA, TM, TN, p.relu_x ? "true" : "false");
     return ctgan_check_launch(name);
 }
 

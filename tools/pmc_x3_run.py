@@ -33,7 +33,7 @@ def case(op, N, C, H, Ko, R, st, relu=False):
     xb, yb = 4 * N * C * H * H, 4 * N * Ko * g.P * g.Q
     if op == 'wgrad':
         # (the last launch of a weight gradient is its split-K reduction: name the GEMM kernel explicitly)
-        sym = 'wgrad16_kernel<3, 2, 2, %s, false>' % ('true' if relu else 'false')
+        sym = 'wgrad16_kernel<3, 2, 2, %s>' % ('true' if relu else 'false')
         alg = xb + yb + 4 * R * R * C * Ko
     else:
         alg = xb + yb + 6 * R * R * C * Ko             # (dy or x) + (dx or y) + three bf16 planes of the packed filter
@@ -47,6 +47,6 @@ case('fwd', 384, 128, 8, 128, 3, 1, relu=True)        # conv16x3hf_kernel<true, 
 case('dgrad', 192, 128, 8, 128, 3, 1)                 # conv16x3hf_kernel<false, 1>: the main pass's 8x8 data gradients
 case('dgrad', 128, 128, 32, 128, 4, 2)                # conv16_kernel<3, 2, 2, 32, false, false>: four-phase data gradient of the folded ConvMeanPool, 1024 tiles
 case('fwd', 192, 128, 32, 128, 4, 2, relu=True)       # conv16_kernel<3, 2, 1, 32, true, false>: its forward at 192 rows on 128-kout x 64-pixel tiles
-case('wgrad', 128, 128, 32, 128, 4, 2, relu=True)     # wgrad16_kernel<3, 2, 2, true, false>
-case('wgrad', 128, 128, 16, 128, 3, 1, relu=False)    # wgrad16_kernel<3, 2, 2, false, false>
+case('wgrad', 128, 128, 32, 128, 4, 2, relu=True)     # wgrad16_kernel<3, 2, 2, true>
+case('wgrad', 128, 128, 16, 128, 3, 1, relu=False)    # wgrad16_kernel<3, 2, 2, false>
 print(json.dumps(info))
