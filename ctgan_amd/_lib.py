@@ -81,8 +81,8 @@ SIGNATURES = {
     'ctgan_conv2d_wgrad_group_workspace_bytes': (c_size_t, [POINTER(WgradGroup), c_int32]),
     'ctgan_conv2d_wgrad_group': (c_int, [POINTER(WgradGroup), c_int32, _p, c_size_t, _p]),
     'ctgan_conv2d_wgrad_group_ex': (c_int, [POINTER(WgradGroup), c_int32, _p, c_size_t, c_int, _p]),
-    'ctgan_conv2d16_wgrad_group_workspace_bytes': (c_size_t, [POINTER(WgradGroup), c_int32]),
-    'ctgan_conv2d16_wgrad_group': (c_int, [POINTER(WgradGroup), c_int32, _p, c_size_t, c_int, _p]),
+    'ctgan_conv2d16_wgrad_group_workspace_bytes': (c_size_t, [POINTER(WgradGroup), c_int32, c_int]),
+    'ctgan_conv2d16_wgrad_group': (c_int, [POINTER(WgradGroup), c_int32, c_int, _p, c_size_t, c_int, _p]),
     'ctgan_conv2d_wgrad_group_tile': (c_int, [POINTER(WgradGroup)]),
     'ctgan_conv2d_workspace_bytes': (c_size_t, [_D, c_int]),
     'ctgan_conv2d_fwd': (c_int, [_D, _p, _p, _p, _p, _p, c_int, _p]),

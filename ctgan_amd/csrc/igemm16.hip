@@ -2047,9 +2047,10 @@ int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x,
 namespace {
 struct G16Seg { W16 p; int tiles, splits; };
 struct G16Plan { int nseg_total; int chunk; long long blocks; size_t ws_bytes; };
-bool group16_member_ok(const ctgan_wgrad_group& G) {
+bool group16_member_ok(const ctgan_wgrad_group& G, int mma) {
     const ctgan_conv_desc* d = &G.d;
-    if (G.nseg < 1 || G.nseg > CTGAN_WGRAD_MAX_SEGS || !shape_ok_wgrad_x3(d) || d->x_up || d->xs[1] != 1) return false;
+    if (G.nseg < 1 || G.nseg > CTGAN_WGRAD_MAX_SEGS || d->x_up || d->xs[1] != 1) return false;
+    if (mma == CTGAN_MMA_F32X3 ? !shape_ok_wgrad_x3(d) : (d->C % 128 != 0 || d->K % 128 != 0 || d->Q % 4 != 0)) return false;
     if (d->ys[1] != 1 || d->ys[3] != d->K || d->ys[2] != (int64_t)d->Q * d->K || d->ys[0] != (int64_t)d->P * d->Q * d->K) return false;   // dense channels-last dy
     if (G.db && (d->K % 4 || (reinterpret_cast<uintptr_t>(G.db) & 15))) return false;
     for (int k = 0; k < G.nseg; ++k) {
@@ -2062,7 +2063,8 @@ bool group16_member_ok(const ctgan_wgrad_group& G) {
 // One chunk (pixels per split, multiple of 64) for every problem of the call: workgroups of equal length.  Estimated time of the launch
 // for a candidate = rounds of 512 resident workgroups (two per CU) x (chunk pixels at ~70 ns each + a fixed prologue / 64 KB slab
 // store); the smallest estimate wins, longer chunks (fewer slabs to write and reduce) among near-equals.
-G16Plan group16_plan(const ctgan_wgrad_group* groups, int n) {
+G16Plan group16_plan(const ctgan_wgrad_group* groups, int n, int mma) {
+    const double px_us = mma == CTGAN_MMA_F32X3 ? 0.07 : 0.02;        // one MFMA per product instead of six, 64-pixel slices
     G16Plan best{0, 0, 0, 0};
     double best_t = 1e30;
     int max_kg = 0, nseg = 0;
@@ -2081,7 +2083,7 @@ G16Plan group16_plan(const ctgan_wgrad_group* groups, int n) {
             ws += ((size_t)splits * ((size_t)d.R * d.S * d.C + (groups[i].db ? 1 : 0)) * d.K * sizeof(float) + 255) & ~(size_t)255;
         }
         const long long rounds = (blocks + 511) / 512;
-        const double t = (double)rounds * (chunk * 0.07 + 5.0) + (double)blocks * 0.02;
+        const double t = (double)rounds * (chunk * px_us + 5.0) + (double)blocks * 0.02;
         if (t < best_t * 0.985) { best_t = t; best = G16Plan{nseg, chunk, blocks, ws}; }
         if (chunk >= max_kg && !forced) break;
     }
@@ -2089,23 +2091,40 @@ G16Plan group16_plan(const ctgan_wgrad_group* groups, int n) {
 }
 }  // namespace
 
-extern "C" {
-
-size_t ctgan_conv2d16_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n) {
-    if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT) return 0;
-    for (int i = 0; i < n; ++i) if (!group16_member_ok(groups[i])) return 0;
-    return group16_plan(groups, n).ws_bytes;
+template <int MMA>
+static int launch_wgrad16_group(const W16Group& g, int blocks, hipStream_t st) {
+    constexpr int bkp = planes<MMA>() == 3 ? 32 : 64;
+    constexpr size_t lds = (size_t)(wgrad16_single_stage<MMA, 2, 2>() ? 1 : 2) * planes<MMA>() * (128 + 128) * (bkp + 8) * 2;
+    auto kern = wgrad16_group_kernel<MMA, 2, 2>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16_group: cannot reserve %zu B of LDS", lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, g);
+    ctgan_set_last_kernel(MMA == CTGAN_MMA_F32X3 ? "wgrad16x3_group<128x128>" : "wgrad16_group<128x128>");
+    ctgan_set_last_symbol("wgrad16_group_kernel<%d, 2, 2>", MMA);
+    return ctgan_check_launch("wgrad16_group");
 }
 
-int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, int phases, ctgan_stream_t stream) {
-    if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: bad argument");
+extern "C" {
+
+size_t ctgan_conv2d16_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n, int mma) {
+    if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT || !mma_ok(mma)) return 0;
+    for (int i = 0; i < n; ++i) if (!group16_member_ok(groups[i], mma)) return 0;
+    return group16_plan(groups, n, mma).ws_bytes;
+}
+
+int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int mma, void* ws, size_t ws_bytes, int phases, ctgan_stream_t stream) {
+    if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: bad argument");
     for (int i = 0; i < n; ++i) {
         if (!groups[i].dw) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: null dw");
         for (int k = 0; k < groups[i].nseg && k < CTGAN_WGRAD_MAX_SEGS; ++k)
             if (!groups[i].xs[k] || !groups[i].dys[k]) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: null operand");
-        if (!group16_member_ok(groups[i])) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad_group: problem %d outside the split-mode 128x128 tile", i);
+        if (!group16_member_ok(groups[i], mma)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad_group: problem %d outside the grouped 128x128 tile", i);
     }
-    const G16Plan plan = group16_plan(groups, n);
+    const G16Plan plan = group16_plan(groups, n, mma);
     if (!ws || plan.ws_bytes > ws_bytes) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: workspace %zu B < %zu B", ws_bytes, plan.ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     static thread_local G16Seg segs[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
@@ -2132,7 +2151,11 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void*
                 const int sp = (p.Kg + plan.chunk - 1) / plan.chunk;
                 p.chunk = (((p.Kg + sp - 1) / sp) + 63) / 64 * 64;
             }
-            p.pq_shift = __builtin_ctz(d->P * d->Q); p.q_shift = __builtin_ctz(d->Q);
+            {
+                const int pq = d->P * d->Q;
+                const bool pow2 = !(pq & (pq - 1)) && !(d->Q & (d->Q - 1));
+                p.pq_shift = pow2 ? __builtin_ctz(pq) : -1; p.q_shift = pow2 ? __builtin_ctz(d->Q) : -1;
+            }
             const long long x_extent = (long long)(G.Ns[k] - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
             p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)((long long)p.Kg * d->K * 4);
             G16Seg& sg = segs[ns++];
@@ -2146,14 +2169,6 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void*
         off += ((size_t)splits_total * rows * d->K * sizeof(float) + 255) & ~(size_t)255;
     }
     if (phases & CTGAN_WGRAD_GROUP_GEMM) {
-        constexpr size_t lds = (size_t)3 * (128 + 128) * (32 + 8) * 2;       // one stage, three planes (wgrad16_single_stage)
-        auto kern = wgrad16_group_kernel<CTGAN_MMA_F32X3, 2, 2>;
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16_group: cannot reserve %zu B of LDS", lds);
-            attr = true;
-        }
         // longest workgroups first
         int order[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
         for (int a = 0; a < ns; ++a) order[a] = a;
@@ -2169,12 +2184,10 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void*
                 if (k < g.n) b0 += sg.tiles * sg.splits;
             }
             g.first[W16_GROUP_MAX] = b0;
-            hipLaunchKernelGGL(kern, dim3((unsigned)b0), dim3(256), lds, st, g);
-            int rc = ctgan_check_launch("wgrad16_group");
+            const int rc = mma == CTGAN_MMA_F32X3 ? launch_wgrad16_group<CTGAN_MMA_F32X3>(g, b0, st)
+                         : (mma == CTGAN_MMA_BF16 ? launch_wgrad16_group<CTGAN_MMA_BF16>(g, b0, st) : launch_wgrad16_group<CTGAN_MMA_F16>(g, b0, st));
             if (rc) return rc;
         }
-        ctgan_set_last_kernel("wgrad16x3_group<128x128>");
-        ctgan_set_last_symbol("wgrad16_group_kernel<3, 2, 2>");
     }
     for (int base = 0; base < n && (phases & CTGAN_WGRAD_GROUP_REDUCE); base += R16_BATCH) {
         R16Jobs jobs;

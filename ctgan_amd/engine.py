@@ -357,7 +357,8 @@ class GraphedDCGANTrainer:
         else:
             out = t.g_losses()
             params, opt = t.g_params, t.g_opt
-        grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        with F.deferred_wgrads():
+            grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         if self.adam_in_graph:
             opt.update(grads, 1.0 / t.loss_scale, rng=t.rng)
         else:

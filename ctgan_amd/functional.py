@@ -198,14 +198,16 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _SPREAD_BUFS     # same identity in every pass of the step
     fewch = K.fewch_handles(g)                    # few-channel convs: the direct kernel sums two uses in one launch
     defer = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
-             and K.MMA_DTYPE is None        # the multi-segment / grouped launches exist in the fp32 family only
+             # fp32 mode: the fp32 family's / the split mode's grouped launches; mixed-precision modes: the small problems the grouped
+             # 16-bit launch takes (kernels.grouped16_takes), everything else at once on its own tile
+             and (K.MMA_DTYPE is None or (x.is_cuda and K.grouped16_takes(g, x.shape[0])))
              and ((g.C % 32 == 0 and g.K % 4 == 0) or (fewch and FEWCH_DEFER)) and not (g.R == 1 and g.H == 1 and g.W == 1))
     if not defer:
         if with_bias:
             return K.conv_wgrad(x, gy, g, with_bias=True, relu_x=relu_x)
         return K.conv_wgrad(x, gy, g, relu_x=relu_x), None
-    if with_bias and not gy.permute(0, 2, 3, 1).is_contiguous() and not fewch:
-        gy = K.to_channels_last(gy)
+    if (with_bias or K.MMA_DTYPE is not None) and not gy.permute(0, 2, 3, 1).is_contiguous() and not fewch:
+        gy = K.to_channels_last(gy)          # (the grouped 16-bit launch reads dy dense channels-last)
     gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     key = (w.data_ptr(), gk)
     grp = _DEFER['groups'].get(key)

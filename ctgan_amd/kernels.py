@@ -86,6 +86,23 @@ def _conv_mode(d, op, plain):
 X3_WGRAD_GROUP = int(os.environ.get('CTGAN_X3_WGRAD_GROUP', '2'))
 
 
+def grouped16_mode():
+    """The 16-bit family mode whose grouped weight-gradient launch (ctgan_conv2d16_wgrad_group) takes the queued weight gradients of a
+    step: 'f32x3' in the hybrid fp32 mode and in the split mode, the mixed-precision mode itself under set_mma_dtype('bf16' / 'f16')."""
+    if not X3_WGRAD_GROUP:
+        return None
+    if MMA_DTYPE is not None:
+        return MMA_DTYPE
+    return 'f32x3' if X3_HYBRID else None
+
+
+def grouped16_takes(g, rows):
+    """Mixed-precision modes: is this weight gradient (geometry g over `rows` samples) queued for the grouped 16-bit launch?  The SMALL
+    problems only (<= 16 K pixels, <= 512 channels): large ones run faster on the wide tiles of their own launch."""
+    return (X3_WGRAD_GROUP and MMA_DTYPE in ('bf16', 'f16') and g.C % 128 == 0 and g.K % 128 == 0 and g.C <= 512 and g.K <= 512
+            and g.Q % 4 == 0 and not g.x_up and not fewch_handles(g) and rows * g.P * g.Q <= 16384)
+
+
 def wgrad_prefers_x3(g, N, device=None):
     """True when the fp32 mode routes this weight gradient to the split mode (then it is launched at once, not queued for the fp32
     family's grouped launch).  Needs dense channels-last operands, which the callers of the large layers provide."""
@@ -623,26 +640,28 @@ def conv_wgrad_group(groups):
         G.add_db = add_db.data_ptr() if (add_db is not None and db is not None) else None
     # hybrid fp32 mode / split mode: the members the 128x128 split-mode tile takes ride ONE grouped split-mode launch
     x3 = []
-    if X3_WGRAD_GROUP and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID)):
-        x3 = [i for i in range(n) if lib.ctgan_conv2d16_wgrad_group_workspace_bytes(ctypes.byref(arr[i]), 1) > 0]
+    gmode = grouped16_mode()
+    if gmode is not None:
+        code = _MMA_CODE[gmode]
+        x3 = [i for i in range(n) if lib.ctgan_conv2d16_wgrad_group_workspace_bytes(ctypes.byref(arr[i]), 1, code) > 0]
     if x3:
         arr3 = (WgradGroup * len(x3))()
         for k, i in enumerate(x3):
             arr3[k] = arr[i]
-        nb3 = lib.ctgan_conv2d16_wgrad_group_workspace_bytes(arr3, len(x3))
+        nb3 = lib.ctgan_conv2d16_wgrad_group_workspace_bytes(arr3, len(x3), code)
         ws3 = workspace(nb3, dev)
         if PROFILE is None:
-            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), _ptr(ws3), ws3.numel(), 3, _stream()), 'conv2d16_wgrad_group')
+            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 3, _stream()), 'conv2d16_wgrad_group')
         else:
             st = torch.cuda.current_stream()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(st)
             for _ in range(PROFILE_REPS):
-                check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), _ptr(ws3), ws3.numel(), 1, _stream()), 'conv2d16_wgrad_group')
+                check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1, _stream()), 'conv2d16_wgrad_group')
             e1.record(st)
             flops = sum(_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in x3)
             PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, ('group', len(x3)), last_symbol()))
-            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), _ptr(ws3), ws3.numel(), 2, _stream()), 'conv2d16_wgrad_group')
+            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 2, _stream()), 'conv2d16_wgrad_group')
         rest = [i for i in range(n) if i not in set(x3)]
         if not rest:
             return

@@ -145,13 +145,14 @@ int ctgan_conv2d_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* w
 enum { CTGAN_WGRAD_GROUP_GEMM = 1, CTGAN_WGRAD_GROUP_REDUCE = 2,
        /* optional: restrict the GEMM phase to the launch of one tile configuration (bit CTGAN_WGRAD_GROUP_TILE0 << t, t = 0..3) */
        CTGAN_WGRAD_GROUP_TILE0 = 16, CTGAN_WGRAD_GROUP_TILE_MASK = 16 | 32 | 64 | 128 };
-/* The same grouped call on the split mode (CTGAN_MMA_F32X3: fp32 accuracy on the bf16 matrix cores at 6/16 of the fp32 MFMA's cost):
+/* The same grouped call on the 16-bit family - mma = CTGAN_MMA_F32X3 (fp32 accuracy on the bf16 matrix cores at 6/16 of the fp32 MFMA's
+   cost: the hybrid fp32 mode's weight gradients) or CTGAN_MMA_BF16 / CTGAN_MMA_F16 (the small weight gradients of the mixed-precision configs):
    every segment of every group is one problem of ONE launch of 128x128-tile workgroups with a common pixels-per-split, then one batched
-   reduction (add_dw / add_db as above).  Members: C and K multiples of 128, power-of-two pixel grid, unit channel stride of x, dense
+   reduction (add_dw / add_db as above).  Members: C and K multiples of 128, power-of-two pixel grid (split mode; Q % 4 == 0 otherwise), unit channel stride of x, dense
    channels-last dy, no x_up; workspace_bytes returns 0 and the call CTGAN_E_UNSUPPORTED (nothing launched) if a member does not
    qualify - the caller then uses ctgan_conv2d_wgrad_group for it.  phases as CTGAN_WGRAD_GROUP_GEMM | CTGAN_WGRAD_GROUP_REDUCE.   */
-size_t ctgan_conv2d16_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n);
-int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, void* ws, size_t ws_bytes, int phases,
+size_t ctgan_conv2d16_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n, int mma);
+int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int mma, void* ws, size_t ws_bytes, int phases,
                                ctgan_stream_t stream);
 /* the launch (0..3) of a grouped call that problem g rides in; -1 if it does not qualify */
 int ctgan_conv2d_wgrad_group_tile(const ctgan_wgrad_group* g);

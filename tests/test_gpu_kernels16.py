@@ -378,6 +378,33 @@ def test_grouped_split_mode_wgrad_equals_the_fp32_family(K):
         assert 'wgrad16x3_group' in K.last_kernel(), K.last_kernel()
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+def test_grouped_16bit_wgrad_equals_separate_16bit_launches(K, dt):
+    """Mixed-precision modes: the small weight gradients of a step (kernels.grouped16_takes) ride ctgan_conv2d16_wgrad_group with
+    mma = bf16 / f16 - same operand rounding, fp32 accumulation, another summation order than the stand-alone launches: equal to
+    fp32 summation error."""
+    g = torch.Generator().manual_seed(91)
+    cases = [(128, 16, 256, 5, 2, (16,)), (256, 8, 512, 5, 2, (16, 16)), (128, 8, 128, 3, 1, (64, 32)), (256, 4, 256, 3, 1, (64,))]
+    with K.mma_dtype(dt):
+        groups, refs = [], []
+        for ci, (C, H, Ko, k, st, Ns) in enumerate(cases):
+            geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+            assert all(K.grouped16_takes(geom, n) for n in Ns)
+            segs, dw_r, db_r = [], 0, 0
+            for i, n in enumerate(Ns):
+                x = cl(torch.randn(n, C, H, H, generator=g)); gy = cl(torch.randn(n, Ko, geom.P, geom.Q, generator=g))
+                segs.append((x, gy, i % 2 == 0, True))
+                w_, b_ = K.conv_wgrad(x, gy, geom, with_bias=True, relu_x=i % 2 == 0)
+                assert K.last_kernel().startswith('wgrad16'), K.last_kernel()
+                dw_r, db_r = dw_r + w_, db_r + b_
+            dw = torch.empty(k, k, C, Ko, device='cuda'); db = torch.empty(Ko, device='cuda')
+            groups.append((segs, geom, dw, db)); refs.append((dw_r, db_r))
+        K.conv_wgrad_group(groups)
+        assert K.last_kernel() == 'wgrad16_group<128x128>', K.last_kernel()
+    for (segs, geom, dw, db), (dw_r, db_r) in zip(groups, refs):
+        assert relerr(dw, dw_r) < 2e-5 and relerr(db, db_r) < 2e-5, (geom.C, geom.H, relerr(dw, dw_r))
+
+
 def test_conv16_wgrad_runs_on_the_16bit_kernel_and_is_deterministic(K):
     N, C, H, Ko = 16, 128, 16, 256
     geom = K.ConvGeom(C, H, H, Ko, 5, 5, 2, False)
