@@ -119,8 +119,7 @@ class DCGANTrainer:
     def d_step(self, real_in, rnd=None):
         self.rng.begin_step()
         out = self.d_losses(real_in, rnd)
-        with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.d_opt, grads)
         out['grads'] = dict(zip([n for n, _ in self.d_named], self._unscaled(grads)))
         return out
@@ -128,8 +127,7 @@ class DCGANTrainer:
     def g_step(self, rnd=None):
         self.rng.begin_step()
         out = self.g_losses(rnd)
-        with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], self.g_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        grads = torch.autograd.grad(out['cost'], self.g_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.g_opt, grads)
         out['grads'] = dict(zip([n for n, _ in self.g_named], self._unscaled(grads)))
         return out
