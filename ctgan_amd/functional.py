@@ -27,6 +27,11 @@ MASK_IN_DGRAD_EPILOGUE = _os.environ.get('CTGAN_MASK_EPI', '1') != '0'
 # again.  When g_a's consumer is itself a data-gradient node (the block's first conv), the conv that node launches in the double
 # backward takes mask(a) in its epilogue and the separate mask pass (one launch per block per step) disappears.  Experiment switch.
 PREMASK_FUSION = _os.environ.get('CTGAN_PREMASK', '1') != '0'
+# Mixed-precision modes: queue the small weight gradients for the grouped 16-bit launch (kernels.grouped16_takes).  Off: a filter whose
+# uses fall on both sides of the size rule would get one queued and one immediate result (two gradient tensors for one parameter, summed
+# by autograd before the flush has written the queued one) - safe only for steps where every use of a filter has the same row count,
+# and the steps that would profit (DCGAN family) do not queue at all for now.
+DEFER_16BIT = _os.environ.get('CTGAN_DEFER_16BIT', '0') == '1'
 
 
 class _PreMask:
@@ -200,7 +205,7 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     defer = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
              # fp32 mode: the fp32 family's / the split mode's grouped launches; mixed-precision modes: the small problems the grouped
              # 16-bit launch takes (kernels.grouped16_takes), everything else at once on its own tile
-             and (K.MMA_DTYPE is None or (x.is_cuda and K.grouped16_takes(g, x.shape[0])))
+             and (K.MMA_DTYPE is None or (DEFER_16BIT and x.is_cuda and K.grouped16_takes(g, x.shape[0])))
              and ((g.C % 32 == 0 and g.K % 4 == 0) or (fewch and FEWCH_DEFER)) and not (g.R == 1 and g.H == 1 and g.W == 1))
     if not defer:
         if with_bias:
