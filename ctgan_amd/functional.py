@@ -44,9 +44,6 @@ class _PreMask:
 _PREMASK = {}          # data_ptr of a masked data gradient -> _PreMask; emptied at the start and at the end of every step
 
 
-def clear_premasks():
-    _PREMASK.clear()
-
 @contextlib.contextmanager
 def weight_grads(enabled):
     """Forward passes inside this context record (enabled) or skip (not enabled) parameter grads."""

@@ -591,3 +591,25 @@ def test_premask_links_do_not_keep_the_backward_graph_alive(cpu_kernels, monkeyp
             gc.enable()
     finally:
         R.configure()
+
+
+def test_both_optimizers_share_one_state_allocation_and_one_learning_rate_fill(small):
+    """Trainer.set_lr: one fill writes the learning rate of the critic's and the generator's Adam state (slices of one allocation);
+    their beta powers stay independent; a repeated value is not written again."""
+    R, lib = small
+    tr = R.Trainer(seed=1)
+    assert tr.d_opt.state.data_ptr() == tr._opt_state.data_ptr() and tr.g_opt.state.data_ptr() == tr._opt_state[4:].data_ptr()
+    tr.set_lr(3e-4)
+    assert float(tr.d_opt.state[0]) == pytest.approx(3e-4) and float(tr.g_opt.state[0]) == pytest.approx(3e-4)
+    assert float(tr.d_opt.state[1]) == 0.0 and float(tr.d_opt.state[2]) == pytest.approx(0.9)       # beta1 = 0, beta2 = 0.9 at t = 1
+    tr._opt_state[0::4].fill_(7.0)
+    tr.set_lr(3e-4)                                       # same value as the last call: skipped
+    assert float(tr.d_opt.state[0]) == 7.0
+    tr.set_lr(2e-4)
+    assert float(tr.g_opt.state[0]) == pytest.approx(2e-4)
+    tr.d_opt.grad.zero_()
+    tr.d_opt.step(rng=tr.rng)                             # the critic's step advances ITS powers and the Philox counter only
+    assert float(tr.d_opt.state[2]) == pytest.approx(0.81) and float(tr.g_opt.state[2]) == pytest.approx(0.9) and int(tr.rng.ctr) == 1
+    sd = tr.d_opt.state_dict()
+    tr.d_opt.load_state_dict(sd)
+    assert float(tr.g_opt.state[0]) == pytest.approx(2e-4)
