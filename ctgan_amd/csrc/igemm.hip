@@ -1842,7 +1842,9 @@ MultiPlan multi_plan(const ctgan_conv_desc* d, int nseg, const int32_t* Ns) {
             m.seg_splits[i] = (int)((k + m.w.chunk - 1) / m.w.chunk);
             m.splits += m.seg_splits[i];
         }
-        if (m.splits <= target || nseg == 1) break;
+        // (every segment needs at least one split: with a planned count below the number of segments - three small segments, one planned
+        // split - `splits <= target` can never hold; this loop then never ended: the 128x128 ResNet's 8x8 shortcut at B = 4, round 3)
+        if (m.splits <= target || m.splits <= nseg || nseg == 1) break;
         m.w.chunk += BK;
     }
     return m;

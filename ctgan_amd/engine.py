@@ -358,7 +358,8 @@ class GraphedDCGANTrainer:
             out = t.g_losses()
             params, opt = t.g_params, t.g_opt
         # (weight gradients launched at once: queuing them for the grouped launches - F.deferred_wgrads(), as the ResNet step does - bought
-        # config[1] 3.2 % but made the 128x128 ResNet's GPU tests an order of magnitude slower; not diagnosed within round 3's GPU budget)
+        # config[1] 3.2 % but hung the 128x128 ResNet's GPU tests in the fp32 family's multi-segment planner; that loop is fixed
+        # (csrc/igemm.hip multi_plan), re-enabling was not re-measured within round 3's GPU budget: DESIGN 6.1)
         grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         if self.adam_in_graph:
             opt.update(grads, 1.0 / t.loss_scale, rng=t.rng)

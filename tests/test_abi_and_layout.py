@@ -1,5 +1,6 @@
 """The C-ABI library loads and exports every symbol include/ctgan_hip.h declares (no compute calls,
 no GPU needed); the product never imports the oracle; the ctypes table matches the header."""
+import pytest
 import ctypes
 import os
 import re
@@ -96,3 +97,27 @@ def test_shared_library_was_built_from_the_sources_in_this_tree():
         pytest.skip('library not built through __graft_entry__.build()')
     stamp = json.load(open(stamp_path))
     assert stamp['sources_sha256'] == ge.source_digest(), 'libctgan_hip.so is older than the kernel sources: run python __graft_entry__.py'
+
+
+@pytest.mark.timeout(60)
+def test_multi_segment_weight_gradient_planner_terminates_for_small_segments():
+    """Host-side planners only (no launch, no GPU): the split-K plan of a filter used by several SMALL segments - more segments than
+    planned splits - must come back.  ctgan_conv2d_wgrad_group_workspace_bytes looped forever on the 128x128 ResNet's 8x8 1x1 shortcut
+    at B = 4 (three segments of 8 / 4 / 4 samples, one planned split): every segment needs a split of its own."""
+    import ctgan_amd.kernels as K
+    from ctgan_amd._lib import WgradGroup, lib
+    for C, H, Ko, k, st, Ns in [(64, 8, 128, 1, 1, (8, 4, 4)), (64, 8, 128, 1, 1, (1, 1, 1)), (128, 4, 128, 3, 1, (2, 2, 2)),
+                                (128, 8, 128, 3, 1, (192, 64)), (32, 2, 64, 3, 1, (1, 1))]:
+        g = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+        arr = (WgradGroup * 2)()
+        for G in arr:
+            G.d = g.desc(Ns[0], (C * H * H, 1, H * C, C), (Ko * g.P * g.Q, 1, g.Q * Ko, Ko))
+            G.nseg = len(Ns)
+            for i, n in enumerate(Ns):
+                G.Ns[i] = n
+        one = lib.ctgan_conv2d_wgrad_group_workspace_bytes(arr, 1)
+        two = lib.ctgan_conv2d_wgrad_group_workspace_bytes(arr, 2)
+        slab = 4 * (k * k * C + 1) * Ko
+        assert one >= len(Ns) * slab and one % 256 == 0 and two == 2 * one, (C, H, Ns, one, two)
+        ns = (ctypes.c_int32 * len(Ns))(*Ns)
+        assert lib.ctgan_conv2d_wgrad_multi_workspace_bytes(ctypes.byref(arr[0].d), len(Ns), ns) >= len(Ns) * slab
