@@ -114,3 +114,53 @@ def test_loss_scale_is_divided_out_exactly(cpu_kernels):
     a, b = res[1.0], res[1024.0]
     assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and a[5] == b[5]
+
+
+@pytest.mark.parametrize('net', ['cifar', 'lsun128'])
+def test_queued_weight_gradients_equal_immediate_ones_in_the_dcgan_family_steps(cpu_kernels, net):
+    """The DCGAN-family steps do not queue their weight gradients yet; when they do (`with F.deferred_wgrads():` around the
+    backward, as the ResNet step), every parameter gradient of a critic step and of a generator step must equal the immediate path's -
+    several uses per filter (dropout passes, GP double backward through Layernorm for the 128x128 ResNet), few-channel layers, spread
+    filters."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    if net == 'cifar':
+        import ctgan_amd.gan_cifar as M
+        M.configure(DIM=32, BATCH_SIZE=4)
+    else:
+        import ctgan_amd.gan_lsun128 as M
+        M.configure(BATCH_SIZE=2, DIM_G_64=4, DIM_G_32=8, DIM_G_16=8, DIM_G_8=16, DIM_G_4=16, DIM_D_64=8, DIM_D_32=8, DIM_D_16=16, DIM_D_8=16)
+    try:
+        B = M.cfg.BATCH_SIZE
+        lib.set_seed(21)
+        if hasattr(M, 'build_params'):
+            M.build_params('cpu')
+        else:                                   # the DCGAN scripts create their parameters lazily: one forward of each net
+            with torch.no_grad():
+                x0 = M.Generator(2, noise=torch.zeros(2, 128))
+                M.Discriminator(x0, u=[torch.full((2,) + s, 0.9) for s in M.feat_shapes()])
+        tr = DCGANTrainer(M, seed=2)
+        g = torch.Generator().manual_seed(8)
+        real = torch.randint(0, 256, (B, M.cfg.OUTPUT_DIM), generator=g, dtype=torch.int32)
+        res = {}
+        for queued in (False, True):
+            outs = []
+            for which in ('d', 'g'):
+                tr.rng.begin_step()
+                out = tr.d_losses(real, None) if which == 'd' else tr.g_losses(None)
+                params = tr.d_params if which == 'd' else tr.g_params
+                if queued:
+                    with F.deferred_wgrads():
+                        grads = torch.autograd.grad(out['cost'], params, allow_unused=True)
+                else:
+                    grads = torch.autograd.grad(out['cost'], params, allow_unused=True)
+                outs.append([None if x is None else x.clone() for x in grads])
+            res[queued] = outs
+        for a_list, b_list, named in zip(res[False], res[True], (tr.d_named, tr.g_named)):
+            for (n, _), a, b in zip(named, a_list, b_list):
+                assert (a is None) == (b is None), n
+                if a is not None:
+                    _cmp(b, a, 2e-5, 'queued wgrad ' + n, atol=1e-7)
+    finally:
+        M.configure()
