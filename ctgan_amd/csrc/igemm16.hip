@@ -28,73 +28,11 @@
 #include "common.h"
 #include "philox.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#include "mma16.h"
+#include "wgrad16c.h"
 
 namespace {
 
-template <int MMA> struct Cvt;
-template <> struct Cvt<CTGAN_MMA_BF16> {
-    static __device__ __forceinline__ unsigned pk(float a, float b) {
-        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
-        v2 v; v.x = (__bf16)a; v.y = (__bf16)b;
-        return __builtin_bit_cast(unsigned, v);
-    }
-    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-    }
-};
-// fp32 values as three bf16 terms (x = h + m + l, each the nearest-even bf16 of what the previous ones left: 24 significand bits):
-// the product x*w = hh + hm + mh + mm + hl + lh (+ terms below 2^-24 relative that are dropped) - six bf16 MFMAs that accumulate in
-// fp32 reproduce an fp32 multiply-accumulate to fp32 rounding accuracy at 6/16 of the fp32 MFMA's cycle cost.
-template <> struct Cvt<CTGAN_MMA_F32X3> : Cvt<CTGAN_MMA_BF16> {};
-template <> struct Cvt<CTGAN_MMA_F16> {
-    static __device__ __forceinline__ unsigned pk(float a, float b) {
-        typedef _Float16 v2 __attribute__((ext_vector_type(2)));
-        v2 v; v.x = (_Float16)a; v.y = (_Float16)b;
-        return __builtin_bit_cast(unsigned, v);
-    }
-    static __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-    }
-};
-
-template <int MMA> constexpr int planes() { return MMA == CTGAN_MMA_F32X3 ? 3 : 1; }
-// the 16-bit pieces of the pair (a, b), packed (a low, b high): one rounded piece, or the three terms of the split
-template <int MMA>
-__device__ __forceinline__ void split_pk(float a, float b, unsigned (&o)[planes<MMA>()]) {
-    if constexpr (planes<MMA>() == 1) {
-        o[0] = Cvt<MMA>::pk(a, b);
-    } else {
-        // remainder of an element = x - piece: v_dot2c_f32_bf16 with the packed constants (-1, 0) / (0, -1) subtracts the low / high
-        // piece of the pair in ONE instruction (no unpacking); the difference is exactly representable, so the result is exact
-        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-        // (the constants are made opaque: folded into the instruction, (-1, 0) becomes the inline operand "-1.0", which the hardware
-        // does not read as that bf16 pair - tools/dot2_check.hip)
-        unsigned klo = 0x0000BF80u, khi = 0xBF800000u;
-        asm("" : "+s"(klo));
-        asm("" : "+s"(khi));
-        const bf2 lo = __builtin_bit_cast(bf2, klo), hi = __builtin_bit_cast(bf2, khi);
-#ifdef CTGAN_SPLIT_SUB
-        const unsigned h0 = Cvt<MMA>::pk(a, b);
-        const float ra0 = a - __builtin_bit_cast(float, h0 << 16), rb0 = b - __builtin_bit_cast(float, h0 & 0xFFFF0000u);
-        const unsigned m0 = Cvt<MMA>::pk(ra0, rb0);
-        const float sa0 = ra0 - __builtin_bit_cast(float, m0 << 16), sb0 = rb0 - __builtin_bit_cast(float, m0 & 0xFFFF0000u);
-        o[0] = h0; o[1] = m0; o[2] = Cvt<MMA>::pk(sa0, sb0);
-        return;
-#endif
-        const unsigned h = Cvt<MMA>::pk(a, b);
-        const float ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, h), lo, a, false);
-        const float rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, h), hi, b, false);
-        const unsigned m = Cvt<MMA>::pk(ra, rb);
-        const float sa = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, m), lo, ra, false);
-        const float sb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, m), hi, rb, false);
-        o[0] = h; o[1] = m; o[2] = Cvt<MMA>::pk(sa, sb);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- filter packing
 // (the three planes of the split mode follow each other, `plane` 16-bit elements apart)
@@ -1708,6 +1646,8 @@ static bool extents_ok(const ctgan_conv_desc* d, int op, int mma) {
 extern "C" {
 
 void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = version; }
+static thread_local int g_last_group_kinds = 0;
+int ctgan_debug_last_wgrad_group_kinds(void) { return g_last_group_kinds; }
 
 int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     if (!d || !mma_ok(mma)) return 0;
@@ -2046,7 +1986,6 @@ int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x,
 // ---- grouped split-mode weight gradients -----------------------------------------------------------------------------------------
 namespace {
 struct G16Seg { W16 p; int tiles, splits; };
-struct G16Plan { int nseg_total; int chunk; long long blocks; size_t ws_bytes; };
 bool group16_member_ok(const ctgan_wgrad_group& G, int mma) {
     const ctgan_conv_desc* d = &G.d;
     if (G.nseg < 1 || G.nseg > CTGAN_WGRAD_MAX_SEGS || d->x_up || d->xs[1] != 1) return false;
@@ -2060,34 +1999,75 @@ bool group16_member_ok(const ctgan_wgrad_group& G, int mma) {
     }
     return true;
 }
-// One chunk (pixels per split, multiple of 64) for every problem of the call: workgroups of equal length.  Estimated time of the launch
-// for a candidate = rounds of 512 resident workgroups (two per CU) x (chunk pixels at ~70 ns each + a fixed prologue / 64 KB slab
-// store); the smallest estimate wins, longer chunks (fewer slabs to write and reduce) among near-equals.
-G16Plan group16_plan(const ctgan_wgrad_group* groups, int n, int mma) {
+// The plan of a grouped call: pixels per split of every (problem, segment) and the slab workspace.  Problems the filter-column kernel
+// takes (wgrad16c.hip: split mode, 8- / 16- / 32-pixel rows, stride 1 or 2) are planned by ctgan_wgrad16c_plan; the others ride the
+// slice kernel's grouped launch with ONE chunk (pixels per split, multiple of 64) for all of them: workgroups of equal length, estimated
+// time = rounds of 512 resident workgroups (two per CU) x (chunk pixels at ~70 ns each + a fixed prologue / 64 KB slab store); the
+// smallest estimate wins, longer chunks (fewer slabs to write and reduce) among near-equals.  A function of the geometries and row counts
+// only, so the workspace query and the launch agree.
+struct G16Plan {
+    size_t ws_bytes;
+    bool col[CTGAN_WGRAD_GROUP_LIMIT];                                   // problem i rides the column kernel
+    int chunk[CTGAN_WGRAD_GROUP_LIMIT][CTGAN_WGRAD_MAX_SEGS];
+};
+void group16_plan(const ctgan_wgrad_group* groups, int n, int mma, G16Plan* plan) {
     const double px_us = mma == CTGAN_MMA_F32X3 ? 0.07 : 0.02;        // one MFMA per product instead of six, 64-pixel slices
-    G16Plan best{0, 0, 0, 0};
+    // column-kernel problems
+    ctgan_wc_problem wc[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
+    int wc_chunk[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
+    int nwc = 0;
+    for (int i = 0; i < n; ++i) {
+        plan->col[i] = ctgan_wgrad16c_takes(&groups[i].d, mma);
+        if (!plan->col[i]) continue;
+        for (int k = 0; k < groups[i].nseg; ++k) { ctgan_wc_problem& w = wc[nwc++]; w = ctgan_wc_problem{}; w.d = &groups[i].d; w.N = groups[i].Ns[k]; }
+    }
+    if (nwc) ctgan_wgrad16c_plan(wc, nwc, wc_chunk);
+    // slice-kernel problems
+    int best_chunk = 0;
     double best_t = 1e30;
-    int max_kg = 0, nseg = 0;
-    for (int i = 0; i < n; ++i)
-        for (int k = 0; k < groups[i].nseg; ++k) { const int kg = groups[i].Ns[k] * groups[i].d.P * groups[i].d.Q; if (kg > max_kg) max_kg = kg; ++nseg; }
+    int max_kg = 0, nrest = 0;
+    for (int i = 0; i < n; ++i) {
+        if (plan->col[i]) continue;
+        ++nrest;
+        for (int k = 0; k < groups[i].nseg; ++k) { const int kg = groups[i].Ns[k] * groups[i].d.P * groups[i].d.Q; if (kg > max_kg) max_kg = kg; }
+    }
     static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_GROUP_CHUNK"); return e ? atoi(e) : 0; }();
-    for (int chunk = 256; chunk <= 8192; chunk += 64) {
+    for (int chunk = 256; nrest && chunk <= 8192; chunk += 64) {
         if (forced && chunk != forced) continue;
-        long long blocks = 0; size_t ws = 0;
+        long long blocks = 0;
         for (int i = 0; i < n; ++i) {
+            if (plan->col[i]) continue;
             const ctgan_conv_desc& d = groups[i].d;
             const long long tiles = (long long)d.R * d.S * (d.C / 128) * (d.K / 128);
             long long splits = 0;
             for (int k = 0; k < groups[i].nseg; ++k) splits += ((long long)groups[i].Ns[k] * d.P * d.Q + chunk - 1) / chunk;
             blocks += tiles * splits;
-            ws += ((size_t)splits * ((size_t)d.R * d.S * d.C + (groups[i].db ? 1 : 0)) * d.K * sizeof(float) + 255) & ~(size_t)255;
         }
         const long long rounds = (blocks + 511) / 512;
         const double t = (double)rounds * (chunk * px_us + 5.0) + (double)blocks * 0.02;
-        if (t < best_t * 0.985) { best_t = t; best = G16Plan{nseg, chunk, blocks, ws}; }
+        if (t < best_t * 0.985) { best_t = t; best_chunk = chunk; }
         if (chunk >= max_kg && !forced) break;
     }
-    return best;
+    if (nrest && !best_chunk) best_chunk = forced ? forced : 256;
+    size_t ws = 0;
+    int w = 0;
+    for (int i = 0; i < n; ++i) {
+        const ctgan_conv_desc& d = groups[i].d;
+        size_t splits = 0;
+        for (int k = 0; k < groups[i].nseg; ++k) {
+            const int Kg = groups[i].Ns[k] * d.P * d.Q;
+            int ch;
+            if (plan->col[i]) ch = wc_chunk[w++];
+            else {      // the planned number of splits, of EQUAL length within the problem (the planner's chunk is the upper bound)
+                const int sp = (Kg + best_chunk - 1) / best_chunk;
+                ch = (((Kg + sp - 1) / sp) + 63) / 64 * 64;
+            }
+            plan->chunk[i][k] = ch;
+            splits += (size_t)((Kg + ch - 1) / ch);
+        }
+        ws += (splits * ((size_t)d.R * d.S * d.C + (groups[i].db ? 1 : 0)) * d.K * sizeof(float) + 255) & ~(size_t)255;
+    }
+    plan->ws_bytes = ws;
 }
 }  // namespace
 
@@ -2113,7 +2093,9 @@ extern "C" {
 size_t ctgan_conv2d16_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n, int mma) {
     if (!groups || n < 1 || n > CTGAN_WGRAD_GROUP_LIMIT || !mma_ok(mma)) return 0;
     for (int i = 0; i < n; ++i) if (!group16_member_ok(groups[i], mma)) return 0;
-    return group16_plan(groups, n, mma).ws_bytes;
+    static thread_local G16Plan plan;
+    group16_plan(groups, n, mma, &plan);
+    return plan.ws_bytes;
 }
 
 int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int mma, void* ws, size_t ws_bytes, int phases, ctgan_stream_t stream) {
@@ -2124,12 +2106,14 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int m
             if (!groups[i].xs[k] || !groups[i].dys[k]) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: null operand");
         if (!group16_member_ok(groups[i], mma)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad_group: problem %d outside the grouped 128x128 tile", i);
     }
-    const G16Plan plan = group16_plan(groups, n, mma);
+    static thread_local G16Plan plan;
+    group16_plan(groups, n, mma, &plan);
     if (!ws || plan.ws_bytes > ws_bytes) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad_group: workspace %zu B < %zu B", ws_bytes, plan.ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     static thread_local G16Seg segs[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
+    static thread_local ctgan_wc_problem wcs[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
     static thread_local R16Job red[CTGAN_WGRAD_GROUP_LIMIT];
-    int ns = 0;
+    int ns = 0, nwc = 0;
     size_t off = 0;
     for (int i = 0; i < n; ++i) {
         const ctgan_wgrad_group& G = groups[i];
@@ -2138,19 +2122,27 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int m
         float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + off);
         int splits_total = 0;
         for (int k = 0; k < G.nseg; ++k) {
+            const int Kg = G.Ns[k] * d->P * d->Q;
+            const int chunk = plan.chunk[i][k];
+            const int with_bias = G.db ? ((G.seg_flags[k] & CTGAN_WGRAD_SEG_BIAS) ? 1 : 2) : 0;
+            const int relu_x = (G.seg_flags[k] & CTGAN_IN_RELU) ? 1 : 0;
+            float* out = slab + (size_t)splits_total * rows * d->K;
+            if (plan.col[i]) {
+                ctgan_wc_problem& w = wcs[nwc++];
+                w.d = d; w.x = G.xs[k]; w.dy = G.dys[k]; w.out = out; w.N = G.Ns[k]; w.relu_x = relu_x; w.with_bias = with_bias; w.chunk = chunk;
+                splits_total += (Kg + chunk - 1) / chunk;
+                continue;
+            }
             W16 p{};
             p.X = G.xs[k]; p.DY = G.dys[k];
-            p.OUT = slab + (size_t)splits_total * rows * d->K;
-            p.with_bias = G.db ? ((G.seg_flags[k] & CTGAN_WGRAD_SEG_BIAS) ? 1 : 2) : 0;
+            p.OUT = out;
+            p.with_bias = with_bias;
             p.H = d->H; p.W = d->W; p.P = d->P; p.Q = d->Q; p.C = d->C; p.R = d->R; p.S = d->S; p.stride = d->stride;
             p.pad_t = d->pad_t; p.pad_l = d->pad_l;
             p.s_n = d->xs[0]; p.s_h = d->xs[2]; p.s_w = d->xs[3];
-            p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = G.Ns[k] * d->P * d->Q;
-            p.relu_x = (G.seg_flags[k] & CTGAN_IN_RELU) ? 1 : 0; p.dbg = 0;
-            {   // the planned number of splits, of EQUAL length within the problem (the planner's chunk is the upper bound)
-                const int sp = (p.Kg + plan.chunk - 1) / plan.chunk;
-                p.chunk = (((p.Kg + sp - 1) / sp) + 63) / 64 * 64;
-            }
+            p.Mtot = d->R * d->S * d->C; p.Ng = d->K; p.Kg = Kg;
+            p.relu_x = relu_x; p.dbg = 0;
+            p.chunk = chunk;
             {
                 const int pq = d->P * d->Q;
                 const bool pow2 = !(pq & (pq - 1)) && !(d->Q & (d->Q - 1));
@@ -2168,7 +2160,12 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int m
         red[i].n = n_main + (G.db ? d->K : 0); red[i].n_main = n_main; red[i].splits = splits_total; red[i].pad = 0;
         off += ((size_t)splits_total * rows * d->K * sizeof(float) + 255) & ~(size_t)255;
     }
-    if (phases & CTGAN_WGRAD_GROUP_GEMM) {
+    g_last_group_kinds = (nwc ? 1 : 0) | (ns ? 2 : 0);
+    if ((phases & CTGAN_WGRAD_GROUP_GEMM) && nwc) {
+        const int rc = ctgan_wgrad16c_launch(wcs, nwc, mma, st);
+        if (rc) return rc;
+    }
+    if ((phases & CTGAN_WGRAD_GROUP_GEMM) && ns) {
         // longest workgroups first
         int order[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
         for (int a = 0; a < ns; ++a) order[a] = a;

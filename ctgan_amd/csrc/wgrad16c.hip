@@ -1,0 +1,430 @@
+// wgrad16c.hip - the "filter column" weight-gradient kernel of the 16-bit matrix-core family (round 4).
+//
+//   dW[r][s][c][k] = sum over pixels (n,p,q) of  X(n, p*st - pad_t + r, q*st - pad_l + s, c) * dY(n,p,q,k)
+//                    (the gradient TF builds for tf.nn.conv2d, TF/tflib/ops/conv2d.py:106-112, under compute_gradients,
+//                     TF/CT_gan_cifar_resnet.py:335-336)
+//
+// The slice kernel (igemm16.hip: wgrad16_body) gives every tap its own 128x128 tile: each of the R*S tap tiles of a filter re-reads and
+// re-splits the same dy slice and a shifted copy of the same x slice (4.8x the algorithmic traffic, 112 split VALU + 24 LDS stores per
+// 48 MFMAs per wave: matrix pipes busy 0.45 - profiles/r03_pmc_traffic_x3.json).  Here ONE staged dy slice and ONE x stream feed all the
+// taps of a filter COLUMN (fixed s, r = 0..R-1):
+//   * the K axis (pixels) is walked in slices of 32 pixels; x lives in an LDS RING of four slices (128 pixels per channel row, pixel
+//     contiguous, three bf16 planes of the fp32 split), staged one slice ahead of dy.  x is staged with the column's horizontal shift
+//     applied (and its zero padding), once per slice: 32 new pixels per slice whatever the number of taps.
+//   * tap r reads its "A" fragments from the ring at a ROW offset: pixel t + (r - pad_t)*Q.  Q is a multiple of 8, so the shifted
+//     fragment is again a 16-byte aligned unit of 8 consecutive pixels - a horizontal shift would not be, which is why the column, not
+//     the filter row, is the unit of reuse.  Rows outside the image (the SAME padding rows) are read from a zero row of LDS instead:
+//     one v_cndmask on the fragment address, no exec masking, no branch.
+//   * a stride-2 filter is the sum of four stride-1 filters on the (row parity, column parity) decimations of x (polyphase): ih = 2p - pad_t + r
+//     = 2(p + dr) + rho.  Decimation is a stride change of the gather, so the same kernel takes the folded ConvMeanPool / UpsampleConv
+//     filters (4x4, stride 2: eight columns of two taps each) - 48 % of the critic step's weight-gradient FLOPs.
+//   * workgroup = 8 waves (4 channel blocks x 2 kout blocks), one per CU: wave = 32 channels x 64 kout x NTAP taps (2 accumulators per
+//     tap); waves 0-3 stage x, waves 4-7 stage dy (one 4-pixel x 4-channel block per thread per slice, transposed by register naming as
+//     in wgrad16_body); ONE barrier per slice.  Per wave and slice with three taps: 72 MFMAs against 56 split VALU + 12 LDS stores.
+// Split over the pixel axis into fp32 slabs, fixed-order reduction (reduce16_batch_kernel): deterministic.  Same slab layout as the slice
+// kernel, so both kinds of problem share the reduction launch of a grouped call.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "common.h"
+#include "mma16.h"
+#include "wgrad16c.h"
+
+namespace {
+
+constexpr int XPL = 272;                 // bytes per (channel row, plane): 128 ring pixels (16 units of 16 B) + 16 B so that the row stride
+constexpr int XROW = 3 * XPL;            // ... of 816 B = 204 dwords = 12 (mod 64) spreads 16 rows over all 64 banks (ds_read_b128 groups)
+constexpr int XZERO = 128 * XROW;        // a row of zeros: the fragment address of a tap whose image row is padding
+constexpr int XBYTES = 129 * XROW;
+constexpr int YROW = 3 * 64 + 16;        // dy: [kout row][plane][32 pixels]; 208 B = 52 dwords = 4 * 13: conflict-free the same way
+constexpr int YSTAGE = 128 * YROW;
+constexpr int LDS_TOTAL = XBYTES + 2 * YSTAGE;      // 158,512 B: one workgroup per CU
+
+struct WCol { int xoff; unsigned pk; };  // pk = (dr0 + 8) | (dc + 8) << 4 | ntap << 8 | tap0 << 12 | tap1 << 18 | tap2 << 24   (tap = r*S + s < 64)
+struct W16C {
+    const float* X; const float* DY;
+    float* OUT;                          // [splits][Mtot (+1)][Ng] fp32 slabs
+    int P, Q, C, Ng, Kg, chunk;          // dy grid, channels, kout, pixels N*P*Q, pixels per split (multiple of 64)
+    int s_n, s_h, s_w;                   // element strides of the DECIMATED x view (stride * the tensor's), channel stride 1
+    int Mtot, relu_x, with_bias;
+    unsigned x_bytes, dy_bytes;
+    int pq_shift, q_shift;
+    int ncols, tiles;                    // columns; workgroups per split = ncols * (C/128) * (Ng/128)
+    WCol col[CTGAN_WC_MAXCOL];
+};
+constexpr int WC_GROUP_MAX = 16;
+struct W16CGroup { int n; int first[WC_GROUP_MAX + 1]; W16C j[WC_GROUP_MAX]; };
+static_assert(sizeof(W16CGroup) <= 4000, "kernel arguments");
+
+template <int MMA, int NTAP>
+__device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, const int cb, const int tn, const int by, unsigned char* smem) {
+    constexpr int NP = planes<MMA>();
+    static_assert(NP == 3, "the column kernel is built for the split mode");
+    unsigned char* const xs = smem;
+    unsigned char* const ys = smem + XBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool is_x = tid < 256;                           // waves 0-3 stage x, waves 4-7 stage dy
+    const int stg = tid & 255, pg = stg & 7, cg = stg >> 3; // staging block: 4 pixels (group pg of the slice) x 4 channels (group cg)
+    const int dr0 = (int)(col.pk & 15u) - 8, dc = (int)((col.pk >> 4) & 15u) - 8;
+    const int c0 = cb * 128, n0 = tn * 128;
+    const int k_begin = by * p.chunk;
+    const int k_end = min(k_begin + p.chunk, p.Kg);
+    const int t0 = k_begin >> 5, t1 = (k_end + 31) >> 5;
+    const int PQ = p.P * p.Q;
+    const int qu = p.Q >> 3;                               // ring units (8 pixels) per image row
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.dy_bytes, 0x00020000);
+    const unsigned wstep = (unsigned)p.s_w * 4u, ystep = (unsigned)p.Ng * 4u;
+
+    // x block of slice sl: pixels 32 sl + 4 pg .. +3 of the decimated view, shifted by the column's dc (zeros where the shifted column
+    // leaves the image: the SAME padding columns); pixels before 0 / past Kg read as zeros
+    auto load_x = [&](int sl, float4 (&rv)[4]) {
+        const int px = sl * 32 + pg * 4;
+        const bool inr = (px >= 0) & (px < p.Kg);
+        const int pc = inr ? px : 0;
+        const int n = pc >> p.pq_shift, rem = pc & (PQ - 1), pp = rem >> p.q_shift, qq = rem & (p.Q - 1);
+        const unsigned base = (unsigned)(col.xoff + n * p.s_n + pp * p.s_h + c0 + cg * 4) * 4u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qe = qq + e + dc;
+            const bool ok = inr & ((unsigned)qe < (unsigned)p.Q);
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? base + (unsigned)qe * wstep : 0xFFFFFFFFu, 0, 0);
+            rv[e] = __builtin_bit_cast(float4, v);
+        }
+    };
+    auto load_y = [&](int sl, float4 (&rv)[4]) {
+        const int px = sl * 32 + pg * 4;
+        const unsigned ybase = ((unsigned)px * (unsigned)p.Ng + (unsigned)(n0 + cg * 4)) * 4u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = px + e < k_end;               // the pixels of the next split are not this workgroup's
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? ybase + e * ystep : 0xFFFFFFFFu, 0, 0);
+            rv[e] = __builtin_bit_cast(float4, v);
+        }
+    };
+    // transpose by register naming: channel j of pixels 0..3 -> two packed dwords per plane (8-byte LDS stores, conflict-free)
+    auto put = [&](unsigned char* dst, int plane, float a0, float a1, float a2, float a3) {
+        unsigned o0[NP], o1[NP];
+        split_pk<MMA>(a0, a1, o0);
+        split_pk<MMA>(a2, a3, o1);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { const u32x2 o = {o0[q], o1[q]}; *reinterpret_cast<u32x2*>(dst + q * plane) = o; }
+    };
+    auto store_x = [&](float4 (&v)[4], int slot) {
+        if (p.relu_x) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e].x = fmaxf(v[e].x, 0.f); v[e].y = fmaxf(v[e].y, 0.f); v[e].z = fmaxf(v[e].z, 0.f); v[e].w = fmaxf(v[e].w, 0.f); }
+        }
+        unsigned char* dst = xs + (cg * 4) * XROW + slot * 64 + pg * 8;
+        put(dst, XPL, v[0].x, v[1].x, v[2].x, v[3].x);
+        put(dst + XROW, XPL, v[0].y, v[1].y, v[2].y, v[3].y);
+        put(dst + 2 * XROW, XPL, v[0].z, v[1].z, v[2].z, v[3].z);
+        put(dst + 3 * XROW, XPL, v[0].w, v[1].w, v[2].w, v[3].w);
+    };
+    const bool bias_wg = p.with_bias && cb == 0 && (col.pk >> 31);      // the first column's workgroups sum the dy tiles they stage
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto store_y = [&](const float4 (&v)[4], int stage) {
+        if (bias_wg && p.with_bias == 1) {                 // (with_bias == 2: a segment that does not contribute - its slab row stays zero)
+            bsum.x += (v[0].x + v[1].x) + (v[2].x + v[3].x); bsum.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+            bsum.z += (v[0].z + v[1].z) + (v[2].z + v[3].z); bsum.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+        }
+        unsigned char* dst = ys + stage * YSTAGE + (cg * 4) * YROW + pg * 8;
+        put(dst, 64, v[0].x, v[1].x, v[2].x, v[3].x);
+        put(dst + YROW, 64, v[0].y, v[1].y, v[2].y, v[3].y);
+        put(dst + 2 * YROW, 64, v[0].z, v[1].z, v[2].z, v[3].z);
+        put(dst + 3 * YROW, 64, v[0].w, v[1].w, v[2].w, v[3].w);
+    };
+
+    f32x16 acc[NTAP][2];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
+
+    const unsigned xrow_lane = (unsigned)(wm * 32 + l31) * XROW;
+    const unsigned yrow_lane = (unsigned)(wn * 64 + l31) * YROW + (unsigned)h * 16u;
+    auto mma_slice = [&](int sl) {
+        const unsigned char* yst = ys + (sl & 1) * YSTAGE + yrow_lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fb[NP][2], fa[NP][NTAP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[q][j] = *reinterpret_cast<const u32x4*>(yst + j * 32 * YROW + q * 64 + ks * 32);
+            // the lane half's 8 pixels lie in image row prow (a k step of 16 pixels spans two rows of an 8-wide image)
+            const int prow = ((sl * 32 + ks * 16 + h * 8) >> p.q_shift) & (p.P - 1);
+            const int ubase = sl * 4 + ks * 2;
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int dr = dr0 + t;
+                const bool valid = (unsigned)(prow + dr) < (unsigned)p.P;
+                const unsigned unit = (unsigned)(ubase + dr * qu + h) & 15u;
+                const unsigned a = valid ? xrow_lane + unit * 16u : (unsigned)XZERO;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) fa[q][t] = *reinterpret_cast<const u32x4*>(xs + a + q * XPL);
+            }
+            constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // small products first (as conv16_kernel)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[t][j] = Cvt<MMA>::mma(fa[QA[c]][t], fb[QB[c]][j], acc[t][j]);
+        }
+    };
+
+    // prologue: the zero row; x slices t0-1, t0, t0+1 and dy slice t0 staged, the next slice of each in registers
+    if (tid < XROW / 4) reinterpret_cast<unsigned*>(xs + XZERO)[tid] = 0u;
+    float4 rv[4];
+    if (is_x) {
+        float4 r3[3][4];
+        load_x(t0 - 1, r3[0]); load_x(t0, r3[1]); load_x(t0 + 1, r3[2]);
+        if (t0 + 1 < t1) load_x(t0 + 2, rv);
+        store_x(r3[0], (t0 - 1) & 3); store_x(r3[1], t0 & 3); store_x(r3[2], (t0 + 1) & 3);
+    } else {
+        float4 r1[4];
+        load_y(t0, r1);
+        if (t0 + 1 < t1) load_y(t0 + 1, rv);
+        store_y(r1, t0 & 1);
+    }
+    __syncthreads();
+    for (int sl = t0; sl < t1; ++sl) {
+        // slice sl is multiplied while x slice sl+2 / dy slice sl+1 go from registers to LDS and the loads of the slices after them are issued
+        if (sl + 1 < t1) {
+            if (is_x) store_x(rv, (sl + 2) & 3); else store_y(rv, (sl + 1) & 1);
+        }
+        if (sl + 2 < t1) {
+            if (is_x) load_x(sl + 3, rv); else load_y(sl + 2, rv);
+        }
+        mma_slice(sl);
+        __syncthreads();
+    }
+
+    // acc[t][j][4g + e] = dW(tap_t, channel c0 + wm*32 + 8g + 4h + e, kout n0 + wn*64 + j*32 + l31): 32 lanes = 128-byte rows
+    float* out = p.OUT + (long long)by * (p.Mtot + (p.with_bias ? 1 : 0)) * p.Ng;
+    if (bias_wg) {
+        // column sums of this split's dy tile: a dy-staging thread holds 4 kout of its pixel group; fold the 8 pixel groups through LDS in a fixed order
+        float* red = reinterpret_cast<float*>(ys);
+        if (!is_x) *reinterpret_cast<float4*>(&red[pg * 128 + cg * 4]) = bsum;
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < 8; ++g2) t += red[g2 * 128 + tid];
+            out[(long long)p.Mtot * p.Ng + n0 + tid] = t;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int tap = (int)((col.pk >> (12 + 6 * t)) & 63u);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kcol = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = c0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[((long long)tap * p.C + c) * p.Ng + kcol] = acc[t][j][e];
+            }
+        }
+    }
+}
+
+// Workgroups [first[j], first[j+1]) belong to problem j: split-major, then (column, channel block, kout block).
+template <int MMA>
+__global__ __launch_bounds__(512) void wgrad16c_group_kernel(const W16CGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int job = 0;
+    while (job + 1 < g.n && (int)blockIdx.x >= g.first[job + 1]) ++job;
+    job = __builtin_amdgcn_readfirstlane(job);
+    const W16C& p = g.j[job];
+    const int local = (int)blockIdx.x - g.first[job];
+    const int by = local / p.tiles, tile = local - by * p.tiles;
+    const int tiles_n = p.Ng >> 7, cblocks = p.C >> 7;
+    const int tn = tile % tiles_n, t2 = tile / tiles_n, cb = t2 % cblocks, ci = t2 / cblocks;
+    WCol col = p.col[ci];
+    if (ci == 0) col.pk |= 0x80000000u;                    // (bit 31: the column that owns the bias row)
+    const int ntap = (int)((col.pk >> 8) & 15u);
+    if (ntap == 3) wgrad16c_body<MMA, 3>(p, col, cb, tn, by, smem);
+    else if (ntap == 2) wgrad16c_body<MMA, 2>(p, col, cb, tn, by, smem);
+    else wgrad16c_body<MMA, 1>(p, col, cb, tn, by, smem);
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+int posmod(int a, int b) { const int m = a % b; return m < 0 ? m + b : m; }
+
+struct ColGeom { int ncols; WCol col[CTGAN_WC_MAXCOL]; int ntap[CTGAN_WC_MAXCOL]; };
+
+// The columns of a filter: (row class rho, s) -> the taps r with (r - pad_t) mod stride == rho, in runs of at most three consecutive
+// row offsets dr = (r - pad_t - rho) / stride.  false: outside the kernel (see ctgan_wgrad16c_takes).
+bool col_geom(const ctgan_conv_desc* d, ColGeom* out) {
+    const int st = d->stride;
+    ColGeom g{};
+    for (int rho = 0; rho < st; ++rho) {
+        int rs[16], nr = 0;
+        for (int r = 0; r < d->R; ++r) if (posmod(r - d->pad_t, st) == rho) { if (nr == 16) return false; rs[nr++] = r; }
+        if (!nr) continue;
+        for (int s = 0; s < d->S; ++s) {
+            const int sigma = posmod(s - d->pad_l, st), dc = floordiv(s - d->pad_l - sigma, st);
+            if (dc < -8 || dc > 7) return false;
+            for (int b = 0; b < nr; b += 3) {
+                const int nt = std::min(3, nr - b);
+                if (g.ncols == CTGAN_WC_MAXCOL) return false;
+                const int dr0 = floordiv(rs[b] - d->pad_t - rho, st);
+                if (dr0 < -8 || dr0 + nt - 1 > 7) return false;
+                // the ring holds one slice (32 pixels) behind and one ahead of the slice being multiplied
+                if (std::max(-dr0, 0) * d->Q > 32 || std::max(dr0 + nt - 1, 0) * d->Q > 32) return false;
+                WCol& c = g.col[g.ncols];
+                c.xoff = (int)(rho * d->xs[2] + sigma * d->xs[3]);
+                c.pk = (unsigned)(dr0 + 8) | ((unsigned)(dc + 8) << 4) | ((unsigned)nt << 8);
+                for (int t = 0; t < nt; ++t) {
+                    const int tap = rs[b + t] * d->S + s;
+                    if (tap >= 64) return false;
+                    c.pk |= (unsigned)tap << (12 + 6 * t);
+                }
+                g.ntap[g.ncols++] = nt;
+            }
+        }
+    }
+    if (!g.ncols) return false;
+    if (out) *out = g;
+    return true;
+}
+
+// estimated microseconds of one workgroup: slices x (staging + taps x MFMAs of a slice) + prologue / slab store
+double wg_cost(int ntap, int chunk) { return (double)(chunk / 32) * (0.35 + 1.05 * ntap) + 4.0; }
+
+}  // namespace
+
+// Geometry the column kernel takes (mma = CTGAN_MMA_F32X3 for now): channel and kout counts multiples of 128, dense channels-last dy
+// (checked by the caller), power-of-two dy grid with rows of 8 / 16 / 32 pixels and at least 64 pixels per image, SAME geometry with
+// H = stride * P and W = stride * Q, stride 1 or 2, every tap within one slice of its pixel (|dr| * Q <= 32).
+bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma) {
+    static const int off = [] { const char* e = getenv("CTGAN_WGRAD16_COL"); return e && atoi(e) == 0; }();
+    if (off || mma != CTGAN_MMA_F32X3) return false;
+    if (d->x_up || d->C % 128 || d->K % 128 || d->xs[1] != 1) return false;
+    if (d->Q != 8 && d->Q != 16 && d->Q != 32) return false;
+    const int pq = d->P * d->Q;
+    if ((pq & (pq - 1)) || pq < 64) return false;
+    if (d->stride != 1 && d->stride != 2) return false;
+    if (d->H != d->stride * d->P || d->W != d->stride * d->Q) return false;
+    if (d->xs[0] >= (1LL << 30) || d->xs[2] >= (1LL << 28) || d->xs[3] >= (1LL << 28)) return false;
+    return col_geom(d, nullptr);
+}
+
+int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d) {
+    ColGeom g;
+    if (!col_geom(d, &g)) return 0;
+    return g.ncols * (d->C / 128) * (d->K / 128);
+}
+
+// Pixels per split for every problem of a grouped call.  Workgroups differ in cost (one to three taps per column), so the plan gives a
+// problem of cheaper columns proportionally longer chunks, and picks the scale whose simulated schedule on 256 CUs (one workgroup per CU,
+// longest first) plus the slab traffic it causes is shortest.  Deterministic: a function of the geometries and row counts only.
+void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks) {
+    static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_COL_CHUNK"); return e ? atoi(e) : 0; }();
+    static const int cand[] = {256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 2048, 3072, 4096, 8192};
+    std::vector<ColGeom> geoms(n);
+    for (int i = 0; i < n; ++i) col_geom(probs[i].d, &geoms[i]);
+    double best_t = 1e30;
+    std::vector<int> cur(n);
+    std::vector<std::pair<double, int>> wgs;       // (cost, count)
+    for (int base : cand) {
+        if (forced && base != forced) continue;
+        wgs.clear();
+        double slab_bytes = 0.;
+        for (int i = 0; i < n; ++i) {
+            const ctgan_conv_desc* d = probs[i].d;
+            const int Kg = probs[i].N * d->P * d->Q;
+            int mt = 1;
+            for (int c = 0; c < geoms[i].ncols; ++c) mt = std::max(mt, geoms[i].ntap[c]);
+            // equal workgroup cost across problems: a problem whose columns carry fewer taps gets longer chunks
+            int ch = (int)((double)base * (0.35 + 1.05 * 3) / (0.35 + 1.05 * mt));
+            ch = std::max(128, (ch + 63) / 64 * 64);
+            const int sp = (Kg + ch - 1) / ch;
+            ch = (((Kg + sp - 1) / sp) + 63) / 64 * 64;
+            cur[i] = ch;
+            const int splits = (Kg + ch - 1) / ch;
+            const int per = (d->C / 128) * (d->K / 128);
+            for (int c = 0; c < geoms[i].ncols; ++c) wgs.emplace_back(wg_cost(geoms[i].ntap[c], ch), splits * per);
+            slab_bytes += (double)splits * ((double)d->R * d->S * d->C + 1) * d->K * 4.;
+        }
+        std::sort(wgs.begin(), wgs.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+        std::priority_queue<double, std::vector<double>, std::greater<double>> cus;
+        for (int k = 0; k < 256; ++k) cus.push(0.);
+        double makespan = 0.;
+        for (const auto& w : wgs)
+            for (int k = 0; k < w.second; ++k) {
+                const double t = cus.top() + w.first;
+                cus.pop(); cus.push(t);
+                if (t > makespan) makespan = t;
+            }
+        const double t = makespan + slab_bytes * 2. / 3.0e6;      // slabs written, then read by the reduction: ~3 TB/s each way
+        if (t < best_t * 0.99) { best_t = t; for (int i = 0; i < n; ++i) chunks[i] = cur[i]; }
+        static const bool log = getenv("CTGAN_WGRAD16_COL_LOG") != nullptr;
+        if (log) fprintf(stderr, "wgrad16c plan: base %d -> makespan %.1f us + slabs %.1f MB = %.1f us%s\n", base, makespan, slab_bytes / 1e6, t, t == best_t ? " *" : "");
+    }
+}
+
+int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStream_t st) {
+    if (mma != CTGAN_MMA_F32X3) return ctgan_fail(CTGAN_E_UNSUPPORTED, "wgrad16c: split mode only");
+    auto kern = wgrad16c_group_kernel<CTGAN_MMA_F32X3>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16c: cannot reserve %d B of LDS", LDS_TOTAL);
+        attr = true;
+    }
+    // most expensive workgroups first
+    std::vector<int> order(n);
+    std::vector<double> cost(n);
+    std::vector<ColGeom> geoms(n);
+    for (int i = 0; i < n; ++i) {
+        order[i] = i;
+        if (!col_geom(probs[i].d, &geoms[i])) return ctgan_fail(CTGAN_E_UNSUPPORTED, "wgrad16c: problem %d outside the column kernel", i);
+        int mt = 1;
+        for (int c = 0; c < geoms[i].ncols; ++c) mt = std::max(mt, geoms[i].ntap[c]);
+        cost[i] = wg_cost(mt, probs[i].chunk);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    for (int base = 0; base < n; base += WC_GROUP_MAX) {
+        W16CGroup g;
+        g.n = std::min(n - base, WC_GROUP_MAX);
+        int b0 = 0;
+        for (int k = 0; k < WC_GROUP_MAX; ++k) {
+            const int i = order[base + (k < g.n ? k : 0)];
+            const ctgan_wc_problem& pr = probs[i];
+            const ctgan_conv_desc* d = pr.d;
+            W16C& p = g.j[k];
+            p = W16C{};
+            p.X = pr.x; p.DY = pr.dy; p.OUT = pr.out;
+            p.P = d->P; p.Q = d->Q; p.C = d->C; p.Ng = d->K; p.Kg = pr.N * d->P * d->Q; p.chunk = pr.chunk;
+            p.s_n = (int)d->xs[0]; p.s_h = (int)(d->xs[2] * d->stride); p.s_w = (int)(d->xs[3] * d->stride);
+            p.Mtot = d->R * d->S * d->C; p.relu_x = pr.relu_x; p.with_bias = pr.with_bias;
+            const long long x_extent = (long long)(pr.N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
+            p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)((long long)p.Kg * d->K * 4);
+            p.pq_shift = __builtin_ctz(d->P * d->Q); p.q_shift = __builtin_ctz(d->Q);
+            p.ncols = geoms[i].ncols; p.tiles = p.ncols * (d->C / 128) * (d->K / 128);
+            for (int c = 0; c < p.ncols; ++c) p.col[c] = geoms[i].col[c];
+            g.first[k] = b0;
+            if (k < g.n) b0 += p.tiles * ((p.Kg + p.chunk - 1) / p.chunk);
+        }
+        g.first[WC_GROUP_MAX] = b0;
+        hipLaunchKernelGGL(kern, dim3((unsigned)b0), dim3(512), LDS_TOTAL, st, g);
+        ctgan_set_last_kernel("wgrad16x3_group<col>");
+        ctgan_set_last_symbol("wgrad16c_group_kernel<%d>", CTGAN_MMA_F32X3);
+        const int rc = ctgan_check_launch("wgrad16c_group");
+        if (rc) return rc;
+    }
+    return CTGAN_OK;
+}

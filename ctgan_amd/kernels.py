@@ -739,6 +739,11 @@ def debug_x3_halo_version(v):
     lib.ctgan_debug_x3_halo_version(int(v))
 
 
+def debug_last_wgrad_group_kinds():
+    """Tests only: bit 0 = the last grouped 16-bit weight-gradient call launched the filter-column kernel, bit 1 = the slice kernel."""
+    return int(lib.ctgan_debug_last_wgrad_group_kinds())
+
+
 def colsum_channels(gy):
     """sum over (n,h,w) of a channels-last [N,K,P,Q] tensor -> [K] (bias gradient)."""
     _need_dev(gy)

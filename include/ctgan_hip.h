@@ -73,6 +73,9 @@ void ctgan_debug_force_generic(int on);
 /* tests only: which halo-patch kernel of the split mode takes the launches that qualify - 1: filter through an LDS stage
    (conv16x3h_kernel), 2: filter fragments streamed from L2 (conv16x3hf_kernel), 0: back to the default (env CTGAN_X3_HALO_V, else 2) */
 void ctgan_debug_x3_halo_version(int version);
+/* tests only: which weight-gradient kernels the last ctgan_conv2d16_wgrad_group call on this thread launched - bit 0: the filter-column
+   kernel (wgrad16c_group_kernel), bit 1: the slice kernel (wgrad16_group_kernel)                                                     */
+int ctgan_debug_last_wgrad_group_kinds(void);
 
 /* Optional epilogue extension of ctgan_conv2d_fwd / ctgan_conv2d_dgrad: tf.nn.dropout (:173-177) applied to the
  * RESULT inside the kernel, y *= floor(keep + u)/keep, where u is what ctgan_rng_uniform(.., seed, stream_id, ctr)
