@@ -2017,7 +2017,9 @@ void group16_plan(const ctgan_wgrad_group* groups, int n, int mma, G16Plan* plan
     int wc_chunk[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
     int nwc = 0;
     for (int i = 0; i < n; ++i) {
-        plan->col[i] = ctgan_wgrad16c_takes(&groups[i].d, mma);
+        int max_rows = 1;
+        for (int k = 0; k < groups[i].nseg; ++k) if (groups[i].Ns[k] > max_rows) max_rows = groups[i].Ns[k];
+        plan->col[i] = ctgan_wgrad16c_takes(&groups[i].d, mma, max_rows);
         if (!plan->col[i]) continue;
         for (int k = 0; k < groups[i].nseg; ++k) { ctgan_wc_problem& w = wc[nwc++]; w = ctgan_wc_problem{}; w.d = &groups[i].d; w.N = groups[i].Ns[k]; }
     }

@@ -16,7 +16,7 @@ struct ctgan_wc_problem {
     int chunk;
 };
 
-bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma);
+bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma, int max_rows);
 int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d);                                   // workgroups per split
 void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks);          // pixels per split of every problem (multiples of 64)
 int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStream_t st);

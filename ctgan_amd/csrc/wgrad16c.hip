@@ -28,12 +28,19 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <queue>
 #include <vector>
 
 #include "common.h"
 #include "mma16.h"
 #include "wgrad16c.h"
+
+// WC_DBG: compile-time perf-diagnosis bits for A/B builds (tools/build_variant.sh; results are then WRONG by design, never set in the product):
+// 2 = no split arithmetic (three roundings, no remainders), 4 = no MFMAs, 8 = no staging stores, 16 = remainders by unpack + v_sub instead of v_dot2c
+#ifndef WC_DBG
+#define WC_DBG 0
+#endif
 
 namespace {
 
@@ -55,13 +62,14 @@ struct W16C {
     unsigned x_bytes, dy_bytes;
     int pq_shift, q_shift;
     int ncols, tiles;                    // columns; workgroups per split = ncols * (C/128) * (Ng/128)
+    int flags;                           // bit 0: the dy-staging waves multiply first, then stage (each SIMD hosts one wave of either kind)
     WCol col[CTGAN_WC_MAXCOL];
 };
 constexpr int WC_GROUP_MAX = 16;
 struct W16CGroup { int n; int first[WC_GROUP_MAX + 1]; W16C j[WC_GROUP_MAX]; };
 static_assert(sizeof(W16CGroup) <= 4000, "kernel arguments");
 
-template <int MMA, int NTAP>
+template <int MMA, int NTAP, bool Q8>
 __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, const int cb, const int tn, const int by, unsigned char* smem) {
     constexpr int NP = planes<MMA>();
     static_assert(NP == 3, "the column kernel is built for the split mode");
@@ -69,7 +77,9 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     unsigned char* const ys = smem + XBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const bool is_x = tid < 256;                           // waves 0-3 stage x, waves 4-7 stage dy
+    // waves 0-3 stage x, waves 4-7 stage dy.  (Wave-uniform BY CONSTRUCTION for the compiler - readfirstlane - so that the two roles are
+    // scalar branches / scalar selects of the buffer descriptor, not exec masks and v_readfirstlane waterfall loops around the loads.)
+    const bool is_x = __builtin_amdgcn_readfirstlane(wave) < 4;
     const int stg = tid & 255, pg = stg & 7, cg = stg >> 3; // staging block: 4 pixels (group pg of the slice) x 4 channels (group cg)
     const int dr0 = (int)(col.pk & 15u) - 8, dc = (int)((col.pk >> 4) & 15u) - 8;
     const int c0 = cb * 128, n0 = tn * 128;
@@ -80,53 +90,93 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     const int qu = p.Q >> 3;                               // ring units (8 pixels) per image row
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, (unsigned)k_end * (unsigned)p.Ng * 4u, 0x00020000);
     const unsigned wstep = (unsigned)p.s_w * 4u, ystep = (unsigned)p.Ng * 4u;
 
     // x block of slice sl: pixels 32 sl + 4 pg .. +3 of the decimated view, shifted by the column's dc (zeros where the shifted column
-    // leaves the image: the SAME padding columns); pixels before 0 / past Kg read as zeros
-    auto load_x = [&](int sl, float4 (&rv)[4]) {
-        const int px = sl * 32 + pg * 4;
-        const bool inr = (px >= 0) & (px < p.Kg);
-        const int pc = inr ? px : 0;
-        const int n = pc >> p.pq_shift, rem = pc & (PQ - 1), pp = rem >> p.q_shift, qq = rem & (p.Q - 1);
-        const unsigned base = (unsigned)(col.xoff + n * p.s_n + pp * p.s_h + c0 + cg * 4) * 4u;
+    // leaves the image: the SAME padding columns).  x is dense per image (s_n = P * s_h, checked by the host), so the byte offset of a
+    // pixel is linear in its global row index: a thread's four offsets are loop invariants plus one scalar per slice.  Pixels past Kg lie
+    // past the tensor (hardware range check: zeros); an invalid column gets an offset past every tensor (x_bytes < 2 GiB).
+    unsigned xoff_e[4], yoff_e[4];
+    {
+        const int px = pg * 4, pp = px >> p.q_shift, qq = px & (p.Q - 1);       // (32 % Q == 0: the slice adds whole rows)
+        const unsigned base = (unsigned)(col.xoff + pp * p.s_h + c0 + cg * 4) * 4u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int qe = qq + e + dc;
-            const bool ok = inr & ((unsigned)qe < (unsigned)p.Q);
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? base + (unsigned)qe * wstep : 0xFFFFFFFFu, 0, 0);
-            rv[e] = __builtin_bit_cast(float4, v);
+            xoff_e[e] = (unsigned)qe < (unsigned)p.Q ? base + (unsigned)qe * wstep : 0x80000000u;
+            yoff_e[e] = ((unsigned)(px + e) * (unsigned)p.Ng + (unsigned)(n0 + cg * 4)) * 4u;
         }
+    }
+    const unsigned x_slice = (unsigned)(32 >> p.q_shift) * (unsigned)p.s_h * 4u, y_slice = 32u * ystep;
+    auto load_x = [&](int sl, float4 (&rv)[4]) {
+        const unsigned so = (unsigned)sl * x_slice;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff_e[e] + so, 0, 0));
     };
-    auto load_y = [&](int sl, float4 (&rv)[4]) {
-        const int px = sl * 32 + pg * 4;
-        const unsigned ybase = ((unsigned)px * (unsigned)p.Ng + (unsigned)(n0 + cg * 4)) * 4u;
+    auto load_y = [&](int sl, float4 (&rv)[4]) {         // (the descriptor ends at this split's last pixel: the next split's read as zeros)
+        const unsigned so = (unsigned)sl * y_slice;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yoff_e[e] + so, 0, 0));
+    };
+    // A staging block = 4 consecutive pixels x 4 channels.  Transposed by register naming: channel j of pixels (0,1) and (2,3) -> two
+    // packed dwords per plane (8-byte LDS stores, conflict-free).  The eight pairs go through the three split levels TOGETHER (level by
+    // level, not pair by pair): eight independent chains, so no instruction waits for the one before it (v_dot2c -> v_cvt_pk needs two
+    // idle slots when they are adjacent).
+    auto put_block = [&](unsigned char* dst, int rowstride, int plane, const float4 (&v)[4]) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        unsigned klo = 0x0000BF80u, khi = 0xBF800000u;        // bf16 pairs (-1, 0) / (0, -1), kept opaque (see split_pk)
+        asm("" : "+s"(klo));
+        asm("" : "+s"(khi));
+        const bf2 lo = __builtin_bit_cast(bf2, klo), hi = __builtin_bit_cast(bf2, khi);
+        float a[8], b[8];
+        a[0] = v[0].x; b[0] = v[1].x; a[1] = v[2].x; b[1] = v[3].x;
+        a[2] = v[0].y; b[2] = v[1].y; a[3] = v[2].y; b[3] = v[3].y;
+        a[4] = v[0].z; b[4] = v[1].z; a[5] = v[2].z; b[5] = v[3].z;
+        a[6] = v[0].w; b[6] = v[1].w; a[7] = v[2].w; b[7] = v[3].w;
+        unsigned pl[NP][8];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pl[q][k] = Cvt<MMA>::pk(a[k], b[k]);
+            if (q + 1 < NP && !(WC_DBG & 2)) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {       // remainder = value - piece, exact (one v_dot2c per value)
+                    if (WC_DBG & 16) {
+                        a[k] -= __builtin_bit_cast(float, pl[q][k] << 16);
+                        b[k] -= __builtin_bit_cast(float, pl[q][k] & 0xFFFF0000u);
+                    } else {
+                        a[k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pl[q][k]), lo, a[k], false);
+                        b[k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, pl[q][k]), hi, b[k], false);
+                    }
+                }
+            }
+        }
+        if (WC_DBG & 8) {      // (keep the values alive without storing them)
+            unsigned x = 0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x ^= pl[q][k];
+            if (x == 0x12345678u) *reinterpret_cast<unsigned*>(dst) = x;
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { const u32x2 o = {pl[q][2 * j], pl[q][2 * j + 1]}; *reinterpret_cast<u32x2*>(dst + j * rowstride + q * plane) = o; }
+    };
+    const int relu_lim = p.relu_x ? 0 : (int)0x80000000;
+    auto store_x = [&](float4 (&v)[4], int slot) {
+        // relu on load, branch-free: as signed integers every negative float (and -0) is below 0, every positive one unchanged by
+        // max(., 0); a problem without relu takes max(., INT_MIN)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool ok = px + e < k_end;               // the pixels of the next split are not this workgroup's
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, ok ? ybase + e * ystep : 0xFFFFFFFFu, 0, 0);
-            rv[e] = __builtin_bit_cast(float4, v);
-        }
-    };
-    // transpose by register naming: channel j of pixels 0..3 -> two packed dwords per plane (8-byte LDS stores, conflict-free)
-    auto put = [&](unsigned char* dst, int plane, float a0, float a1, float a2, float a3) {
-        unsigned o0[NP], o1[NP];
-        split_pk<MMA>(a0, a1, o0);
-        split_pk<MMA>(a2, a3, o1);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { const u32x2 o = {o0[q], o1[q]}; *reinterpret_cast<u32x2*>(dst + q * plane) = o; }
-    };
-    auto store_x = [&](float4 (&v)[4], int slot) {
-        if (p.relu_x) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e].x = fmaxf(v[e].x, 0.f); v[e].y = fmaxf(v[e].y, 0.f); v[e].z = fmaxf(v[e].z, 0.f); v[e].w = fmaxf(v[e].w, 0.f); }
+            v[e].x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].x), relu_lim)); v[e].y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].y), relu_lim));
+            v[e].z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].z), relu_lim)); v[e].w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].w), relu_lim));
         }
         unsigned char* dst = xs + (cg * 4) * XROW + slot * 64 + pg * 8;
-        put(dst, XPL, v[0].x, v[1].x, v[2].x, v[3].x);
-        put(dst + XROW, XPL, v[0].y, v[1].y, v[2].y, v[3].y);
-        put(dst + 2 * XROW, XPL, v[0].z, v[1].z, v[2].z, v[3].z);
-        put(dst + 3 * XROW, XPL, v[0].w, v[1].w, v[2].w, v[3].w);
+        put_block(dst, XROW, XPL, v);
     };
     const bool bias_wg = p.with_bias && cb == 0 && (col.pk >> 31);      // the first column's workgroups sum the dy tiles they stage
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -136,10 +186,7 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
             bsum.z += (v[0].z + v[1].z) + (v[2].z + v[3].z); bsum.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
         }
         unsigned char* dst = ys + stage * YSTAGE + (cg * 4) * YROW + pg * 8;
-        put(dst, 64, v[0].x, v[1].x, v[2].x, v[3].x);
-        put(dst + YROW, 64, v[0].y, v[1].y, v[2].y, v[3].y);
-        put(dst + 2 * YROW, 64, v[0].z, v[1].z, v[2].z, v[3].z);
-        put(dst + 3 * YROW, 64, v[0].w, v[1].w, v[2].w, v[3].w);
+        put_block(dst, YROW, 64, v);
     };
 
     f32x16 acc[NTAP][2];
@@ -152,35 +199,68 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
 
     const unsigned xrow_lane = (unsigned)(wm * 32 + l31) * XROW;
     const unsigned yrow_lane = (unsigned)(wn * 64 + l31) * YROW + (unsigned)h * 16u;
-    auto mma_slice = [&](int sl) {
+    // Fragment reads are software-pipelined at tap granularity: the 12 MFMAs of (k step, tap) run while the fragments of the next
+    // (k step, tap) are in flight (left to itself the compiler reads a fragment right before the MFMA that needs it: a dozen exposed LDS
+    // round trips per slice, waves parked 27 % of their time).  The first fragments of a slice are requested before the slice's
+    // staging work, right behind the barrier.
+    auto load_b = [&](int sl, int ks, u32x4 (&fb)[NP][2]) {
         const unsigned char* yst = ys + (sl & 1) * YSTAGE + yrow_lane;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 fb[NP][2], fa[NP][NTAP];
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int q = 0; q < NP; ++q)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[q][j] = *reinterpret_cast<const u32x4*>(yst + j * 32 * YROW + q * 64 + ks * 32);
-            // the lane half's 8 pixels lie in image row prow (a k step of 16 pixels spans two rows of an 8-wide image)
-            const int prow = ((sl * 32 + ks * 16 + h * 8) >> p.q_shift) & (p.P - 1);
-            const int ubase = sl * 4 + ks * 2;
-#pragma unroll
-            for (int t = 0; t < NTAP; ++t) {
-                const int dr = dr0 + t;
-                const bool valid = (unsigned)(prow + dr) < (unsigned)p.P;
-                const unsigned unit = (unsigned)(ubase + dr * qu + h) & 15u;
-                const unsigned a = valid ? xrow_lane + unit * 16u : (unsigned)XZERO;
-#pragma unroll
-                for (int q = 0; q < NP; ++q) fa[q][t] = *reinterpret_cast<const u32x4*>(xs + a + q * XPL);
-            }
-            constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // small products first (as conv16_kernel)
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-#pragma unroll
-                for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[t][j] = Cvt<MMA>::mma(fa[QA[c]][t], fb[QB[c]][j], acc[t][j]);
+            for (int j = 0; j < 2; ++j) fb[q][j] = *reinterpret_cast<const u32x4*>(yst + j * 32 * YROW + q * 64 + ks * 32);
+    };
+    const unsigned xrow_lane_h = xrow_lane + (unsigned)h * 16u;
+    auto load_a = [&](int sl, int ks, int t, u32x4 (&fa)[NP]) {
+        const int dr = dr0 + t;
+        unsigned a;
+        if constexpr (Q8) {
+            // a k step of 16 pixels spans two rows of an 8-wide image: the lane half's 8 pixels lie in image row prow
+            const int prow = ((sl * 32 + ks * 16 + h * 8) >> 3) & (p.P - 1);
+            const bool valid = (unsigned)(prow + dr) < (unsigned)p.P;
+            const unsigned unit = (unsigned)(sl * 4 + ks * 2 + dr + h) & 15u;
+            a = valid ? xrow_lane + unit * 16u : (unsigned)XZERO;
+        } else {
+            // rows of 16 / 32 pixels: the k step lies in ONE image row - validity and ring unit are wave-uniform (scalar ALU), the unit is
+            // even, so the lane half adds its 16 bytes without wrapping
+            const int prow = ((sl * 32 + ks * 16) >> p.q_shift) & (p.P - 1);
+            const bool valid = (unsigned)(prow + dr) < (unsigned)p.P;
+            const unsigned uoff = ((unsigned)(sl * 4 + ks * 2 + dr * qu) & 15u) * 16u;
+            a = (valid ? xrow_lane_h : (unsigned)XZERO) + (valid ? uoff : 0u);
         }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) fa[q] = *reinterpret_cast<const u32x4*>(xs + a + q * XPL);
+    };
+    auto mma_tap = [&](const u32x4 (&fa)[NP], const u32x4 (&fb)[NP][2], auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // small products first (as conv16_kernel)
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (WC_DBG & 4) { acc[t][j][c] += __builtin_bit_cast(float, fa[QA[c]][0] ^ fb[QB[c]][j][1]); continue; }
+                acc[t][j] = Cvt<MMA>::mma(fa[QA[c]], fb[QB[c]][j], acc[t][j]);
+            }
+    };
+    u32x4 fbr[2][NP][2], far[2][NP];
+    auto mma_head = [&](int sl) { load_b(sl, 0, fbr[0]); load_a(sl, 0, 0, far[0]); };
+    auto mma_steps = [&](int sl) {
+        // step i = ks * NTAP + t uses far[i & 1], fbr[ks]; the next step's fragments are requested first
+        auto step = [&](auto i_c) {
+            constexpr int i = decltype(i_c)::value, ks = i / NTAP, t = i % NTAP;
+            if constexpr (i + 1 < 2 * NTAP) {
+                constexpr int ks1 = (i + 1) / NTAP, t1 = (i + 1) % NTAP;
+                if constexpr (t1 == 0) load_b(sl, ks1, fbr[ks1]);
+                load_a(sl, ks1, t1, far[(i + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(far[i & 1], fbr[ks], std::integral_constant<int, t>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        if constexpr (NTAP >= 2) { step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{}); }
+        if constexpr (NTAP >= 3) { step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); }
     };
 
     // prologue: the zero row; x slices t0-1, t0, t0+1 and dy slice t0 staged, the next slice of each in registers
@@ -188,26 +268,58 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     float4 rv[4];
     if (is_x) {
         float4 r3[3][4];
-        load_x(t0 - 1, r3[0]); load_x(t0, r3[1]); load_x(t0 + 1, r3[2]);
-        if (t0 + 1 < t1) load_x(t0 + 2, rv);
+        if (t0 > 0) load_x(t0 - 1, r3[0]);
+        else {      // before the first pixel: rows no tap reads as valid
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r3[0][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        load_x(t0, r3[1]); load_x(t0 + 1, r3[2]);
+        load_x(t0 + 2, rv);
         store_x(r3[0], (t0 - 1) & 3); store_x(r3[1], t0 & 3); store_x(r3[2], (t0 + 1) & 3);
     } else {
         float4 r1[4];
         load_y(t0, r1);
-        if (t0 + 1 < t1) load_y(t0 + 1, rv);
+        load_y(t0 + 1, rv);
         store_y(r1, t0 & 1);
     }
     __syncthreads();
-    for (int sl = t0; sl < t1; ++sl) {
-        // slice sl is multiplied while x slice sl+2 / dy slice sl+1 go from registers to LDS and the loads of the slices after them are issued
-        if (sl + 1 < t1) {
-            if (is_x) store_x(rv, (sl + 2) & 3); else store_y(rv, (sl + 1) & 1);
+    // Slice sl is multiplied while x slice sl+2 / dy slice sl+1 go from registers to LDS and the loads of the slices after them are issued.
+    // Staging and multiplying touch disjoint LDS regions within an iteration, so their order inside a wave is free: waves w and w+4 share a
+    // SIMD (a workgroup's waves go to the SIMDs round-robin), and with flag bit 0 the x-staging waves stage first while the dy-staging
+    // waves multiply first.
+    // (Stores and loads run unconditionally, also in the last two iterations: what they stage is never multiplied - x of the next split,
+    // dy past the descriptor's end = zeros - and a conditional load would keep the staging registers live across the iteration, which
+    // costs a register copy per value in front of the in-place split.)
+    if (p.flags & 1) {
+        if (is_x) {
+            for (int sl = t0; sl < t1; ++sl) {
+                mma_head(sl);
+                __builtin_amdgcn_sched_barrier(0);
+                store_x(rv, (sl + 2) & 3);
+                load_x(sl + 3, rv);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_steps(sl);
+                __syncthreads();
+            }
+        } else {
+            for (int sl = t0; sl < t1; ++sl) {
+                mma_head(sl);
+                mma_steps(sl);
+                store_y(rv, (sl + 1) & 1);
+                load_y(sl + 2, rv);
+                __syncthreads();
+            }
         }
-        if (sl + 2 < t1) {
-            if (is_x) load_x(sl + 3, rv); else load_y(sl + 2, rv);
+    } else {
+        for (int sl = t0; sl < t1; ++sl) {
+            mma_head(sl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (is_x) { store_x(rv, (sl + 2) & 3); load_x(sl + 3, rv); }
+            else { store_y(rv, (sl + 1) & 1); load_y(sl + 2, rv); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_steps(sl);
+            __syncthreads();
         }
-        mma_slice(sl);
-        __syncthreads();
     }
 
     // acc[t][j][4g + e] = dW(tap_t, channel c0 + wm*32 + 8g + 4h + e, kout n0 + wn*64 + j*32 + l31): 32 lanes = 128-byte rows
@@ -254,9 +366,15 @@ __global__ __launch_bounds__(512) void wgrad16c_group_kernel(const W16CGroup g) 
     WCol col = p.col[ci];
     if (ci == 0) col.pk |= 0x80000000u;                    // (bit 31: the column that owns the bias row)
     const int ntap = (int)((col.pk >> 8) & 15u);
-    if (ntap == 3) wgrad16c_body<MMA, 3>(p, col, cb, tn, by, smem);
-    else if (ntap == 2) wgrad16c_body<MMA, 2>(p, col, cb, tn, by, smem);
-    else wgrad16c_body<MMA, 1>(p, col, cb, tn, by, smem);
+    if (p.Q == 8) {
+        if (ntap == 3) wgrad16c_body<MMA, 3, true>(p, col, cb, tn, by, smem);
+        else if (ntap == 2) wgrad16c_body<MMA, 2, true>(p, col, cb, tn, by, smem);
+        else wgrad16c_body<MMA, 1, true>(p, col, cb, tn, by, smem);
+    } else {
+        if (ntap == 3) wgrad16c_body<MMA, 3, false>(p, col, cb, tn, by, smem);
+        else if (ntap == 2) wgrad16c_body<MMA, 2, false>(p, col, cb, tn, by, smem);
+        else wgrad16c_body<MMA, 1, false>(p, col, cb, tn, by, smem);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -308,8 +426,9 @@ double wg_cost(int ntap, int chunk) { return (double)(chunk / 32) * (0.35 + 1.05
 
 // Geometry the column kernel takes (mma = CTGAN_MMA_F32X3 for now): channel and kout counts multiples of 128, dense channels-last dy
 // (checked by the caller), power-of-two dy grid with rows of 8 / 16 / 32 pixels and at least 64 pixels per image, SAME geometry with
-// H = stride * P and W = stride * Q, stride 1 or 2, every tap within one slice of its pixel (|dr| * Q <= 32).
-bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma) {
+// H = stride * P and W = stride * Q, stride 1 or 2, every tap within one slice of its pixel (|dr| * Q <= 32), x dense per image and, over
+// `max_rows` samples, below 2 GiB.
+bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma, int max_rows) {
     static const int off = [] { const char* e = getenv("CTGAN_WGRAD16_COL"); return e && atoi(e) == 0; }();
     if (off || mma != CTGAN_MMA_F32X3) return false;
     if (d->x_up || d->C % 128 || d->K % 128 || d->xs[1] != 1) return false;
@@ -318,7 +437,10 @@ bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma) {
     if ((pq & (pq - 1)) || pq < 64) return false;
     if (d->stride != 1 && d->stride != 2) return false;
     if (d->H != d->stride * d->P || d->W != d->stride * d->Q) return false;
-    if (d->xs[0] >= (1LL << 30) || d->xs[2] >= (1LL << 28) || d->xs[3] >= (1LL << 28)) return false;
+    if (d->xs[0] != (int64_t)d->H * d->xs[2]) return false;           // images dense in memory: a pixel's offset is linear in its global row index
+    if (d->xs[0] >= (1LL << 28) || d->xs[2] >= (1LL << 26) || d->xs[3] >= (1LL << 26)) return false;
+    // byte offsets: an invalid column is addressed at 2 GiB + its offset, which must lie past the tensor and below 4 GiB
+    if (((long long)max_rows * d->xs[0] + d->C) * 4 >= (1LL << 31) || (long long)max_rows * d->P * d->Q * d->K * 4 >= (1LL << 32)) return false;
     return col_geom(d, nullptr);
 }
 
@@ -385,6 +507,7 @@ int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStre
             return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16c: cannot reserve %d B of LDS", LDS_TOTAL);
         attr = true;
     }
+    static const int pp_flag = [] { const char* e = getenv("CTGAN_WGRAD16_COL_PP"); return e ? atoi(e) : 0; }();
     // most expensive workgroups first
     std::vector<int> order(n);
     std::vector<double> cost(n);
@@ -415,6 +538,7 @@ int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStre
             p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)((long long)p.Kg * d->K * 4);
             p.pq_shift = __builtin_ctz(d->P * d->Q); p.q_shift = __builtin_ctz(d->Q);
             p.ncols = geoms[i].ncols; p.tiles = p.ncols * (d->C / 128) * (d->K / 128);
+            p.flags = pp_flag;
             for (int c = 0; c < p.ncols; ++c) p.col[c] = geoms[i].col[c];
             g.first[k] = b0;
             if (k < g.n) b0 += p.tiles * ((p.Kg + p.chunk - 1) / p.chunk);

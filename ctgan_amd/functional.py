@@ -120,14 +120,20 @@ def _flush_groups(grps):
         for g in simple:                                   # a queued bias buffer nothing contributes to
             if g.db is not None and not _seg_bias(g) and not g.inplace_b:
                 g.db.zero_()
+        done = []
         try:
             for i in range(0, len(simple), K.WGRAD_GROUP_LIMIT):
+                part = simple[i:i + K.WGRAD_GROUP_LIMIT]
                 K.conv_wgrad_group([(g.segs, g.g, g.dw, g.db if _seg_bias(g) else None,
                                      g.dw if g.inplace else None, g.db if (g.inplace_b and _seg_bias(g)) else None)
-                                    for g in simple[i:i + K.WGRAD_GROUP_LIMIT]])
-            grps = [g for g in grps if g not in simple]
+                                    for g in part])
+                done.extend(part)
         except NotImplementedError:
-            pass                                           # nothing was launched: fall back below
+            # K.conv_wgrad_group validates every member before its first launch: the call that raised launched nothing.  Calls that
+            # completed (earlier parts of a queue longer than WGRAD_GROUP_LIMIT) stay done - re-running them would add an in-place
+            # addend twice.
+            pass
+        grps = [g for g in grps if not any(g is d for d in done)]
     for grp in grps:
         _flush_group(grp)
     for grp in _all:

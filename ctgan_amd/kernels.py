@@ -638,17 +638,29 @@ def conv_wgrad_group(groups):
         assert add_dw is None or (add_dw.shape == dw.shape and add_dw.is_contiguous())
         G.add_dw = add_dw.data_ptr() if add_dw is not None else None
         G.add_db = add_db.data_ptr() if (add_db is not None and db is not None) else None
-    # hybrid fp32 mode / split mode: the members the 128x128 split-mode tile takes ride ONE grouped split-mode launch
+    # hybrid fp32 mode / split mode: the members the split-mode kernels take ride ONE grouped split-mode call (filter-column kernel +
+    # slice kernel, csrc/wgrad16c.hip / igemm16.hip).  All-or-nothing: every member is validated - the split-mode subset AND the fp32
+    # family's remainder - before the first launch, so that a NotImplementedError always means "nothing was launched" (ADVICE r3).
     x3 = []
     gmode = grouped16_mode()
     if gmode is not None:
         code = _MMA_CODE[gmode]
         x3 = [i for i in range(n) if lib.ctgan_conv2d16_wgrad_group_workspace_bytes(ctypes.byref(arr[i]), 1, code) > 0]
+    rest = [i for i in range(n) if i not in set(x3)]
+    arr_r = None
+    if x3 and rest:
+        arr_r = (WgradGroup * len(rest))()
+        for k, i in enumerate(rest):
+            arr_r[k] = arr[i]
+        if lib.ctgan_conv2d_wgrad_group_workspace_bytes(arr_r, len(rest)) == 0:
+            raise NotImplementedError('conv2d_wgrad_group: unsupported group')
     if x3:
         arr3 = (WgradGroup * len(x3))()
         for k, i in enumerate(x3):
             arr3[k] = arr[i]
         nb3 = lib.ctgan_conv2d16_wgrad_group_workspace_bytes(arr3, len(x3), code)
+        if nb3 == 0:
+            raise NotImplementedError('conv2d16_wgrad_group: unsupported group')
         ws3 = workspace(nb3, dev)
         if PROFILE is None:
             check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 3, _stream()), 'conv2d16_wgrad_group')
@@ -662,12 +674,8 @@ def conv_wgrad_group(groups):
             flops = sum(_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in x3)
             PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, ('group', len(x3)), last_symbol()))
             check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 2, _stream()), 'conv2d16_wgrad_group')
-        rest = [i for i in range(n) if i not in set(x3)]
         if not rest:
             return
-        arr_r = (WgradGroup * len(rest))()
-        for k, i in enumerate(rest):
-            arr_r[k] = arr[i]
         groups = [groups[i] for i in rest]
         arr, n = arr_r, len(rest)
     nb = lib.ctgan_conv2d_wgrad_group_workspace_bytes(arr, n)
