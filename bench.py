@@ -78,7 +78,7 @@ def main():
     from ctgan_amd import ddp
     if args.config != 'resnet':
         return run_unconditional(args)
-    rank, world, local = ddp.init_from_env(backend=args.backend)
+    rank, world, local = init_ranks(args.backend)
     if local >= torch.cuda.device_count():
         if world > 1 and dist.get_backend() != 'gloo':
             raise SystemExit('rank %d: LOCAL_RANK %d but only %d device(s) visible - two RCCL ranks cannot share a GPU '
@@ -146,6 +146,17 @@ def main():
     # Loss guard: a WGAN-GP critic on bounded inputs cannot leave this band in a few hundred Adam steps of <= 3*lr each.
     # Round 1 timed a loop whose cost had run to -6e18 (graph outputs aliased in a shared pool) and nothing looked.
     sane = all(v == v and abs(v) < 1e4 for v in last.values())
+
+    # N > 1: the replicas must have stayed bit-identical through the timed loop (same initial weights, averaged gradients, the same Adam):
+    # every rank's parameter checksums (bit patterns of the fp64 sums of both networks' flat buffers), gathered and compared
+    replicas_identical = None
+    if world > 1:
+        cs = torch.stack([trainer.d_opt.theta.double().sum(), trainer.g_opt.theta.double().sum(),
+                          trainer.d_opt.theta.double().abs().sum(), trainer.g_opt.theta.double().abs().sum()]).view(torch.int64)
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        replicas_identical = all(torch.equal(allcs[0], c) for c in allcs[1:])
+        sane = sane and replicas_identical
 
     # N > 1: what the six gradient all-reduces of an iteration cost on the critical path = the same loop with the collective
     # switched off on every rank (the replicas drift apart from here on: nothing below compares them)
@@ -232,7 +243,8 @@ def main():
                                    'N_CRITIC=5 + 1 G step (128 samples) per step', 'global_batch': B * world,
                        'images_per_step': R.cfg.N_CRITIC * B * world, 'parallelism': 'dp%d' % world,
                        'hipgraph': bool(eng.graphed), 'last_d_cost': last_cost, 'last_d_terms': last, 'loss_sane': sane,
-                       'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1], 'collective': collective,
+                       'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1], 'replicas_identical': replicas_identical,
+                       'collective': collective,
                        'arithmetic': ('fp32 throughout; the large stride-1 conv layers (roofline.by_kernel: conv16x3h) compute the fp32 products as '
                                       'three-bf16-term splits on the bf16 matrix cores (six MFMAs per product, fp32 accumulate; error vs fp64 '
                                       'no larger than the fp32 MFMA family\'s, tests/test_gpu_kernels16.py, DESIGN 4.6), every other layer on '
@@ -249,7 +261,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if not sane:
-        print('bench: critic loss terms out of band %r - the timed loop is not computing the reference step' % (last,), file=sys.stderr)
+        print('bench: critic loss terms out of band %r (replicas identical: %r) - the timed loop is not computing the reference step' % (last, replicas_identical), file=sys.stderr)
         sys.exit(3)
 
 
@@ -272,47 +284,81 @@ def launch_ranks(args, argv):
             print('bench: --gpus %d but %d device(s) visible - two RCCL ranks cannot share a GPU (use --backend gloo to exercise the '
                   'multi-rank code path on one device)' % (n, ndev), file=sys.stderr)
             return 2
-    sock = socket.socket()
-    sock.bind(('127.0.0.1', 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    child_argv = [a for a in argv]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    # rank 0's stdout is drained by a thread (a full pipe would block it); the launcher polls ALL ranks: the first rank that dies with a
-    # non-zero status ends the run - the others would otherwise sit in a collective until the RCCL timeout
+    # A rendezvous that fails (the port picked by bind-close-reuse can be taken in between) makes the ranks exit with RENDEZVOUS_EXIT:
+    # the launch is repeated on another port.  SIGTERM / SIGINT to the launcher (a driver timeout) end the ranks too: without that they
+    # would sit in a collective, holding the GPUs, until the RCCL timeout.
+    import signal
     import threading
     import time as _time
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    status = 0
+
+    def _term(signum, frame):
+        raise SystemExit(128 + signum)
+    old_handlers = {sg: signal.signal(sg, _term) for sg in (signal.SIGTERM, signal.SIGINT)}
+    status, chunks = 0, []
     try:
-        while True:
-            codes = [pr.poll() for pr in procs]
-            bad = [c for c in codes if c not in (None, 0)]
-            if bad:
-                status = bad[0]
+        for attempt in range(3):
+            sock = socket.socket()
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+            sock.close()
+            procs, chunks = [], []
+            try:
+                for r in range(n):
+                    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+                    # rank 0's stdout carries the record; the other ranks' stdout (library banners, diagnostics) goes to the launcher's stderr
+                    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                                  stdout=subprocess.PIPE if r == 0 else sys.stderr))
+                # rank 0's stdout is drained by a thread (a full pipe would block it); the launcher polls ALL ranks: the first rank that
+                # dies with a non-zero status ends the run - the others would otherwise sit in a collective until the RCCL timeout
+                reader = threading.Thread(target=lambda c=chunks, pr=procs[0]: c.append(pr.stdout.read()), daemon=True)
+                reader.start()
+                status = 0
+                while True:
+                    codes = [pr.poll() for pr in procs]
+                    bad = [c for c in codes if c not in (None, 0)]
+                    if bad:
+                        status = bad[0]
+                        break
+                    if all(c == 0 for c in codes):
+                        break
+                    _time.sleep(0.05)
+            finally:
+                for pr in procs:                 # end exactly the processes started here (never by pattern)
+                    if pr.poll() is None:
+                        pr.kill()
+                for pr in procs:
+                    pr.wait()
+                if procs:
+                    reader.join(timeout=5)
+            if status != RENDEZVOUS_EXIT:
                 break
-            if all(c == 0 for c in codes):
-                break
-            _time.sleep(0.05)
+            print('bench: rendezvous on port %d failed, retrying on another port' % port, file=sys.stderr)
     finally:
-        for pr in procs:                 # end exactly the processes started here (never by pattern)
-            if pr.poll() is None:
-                pr.kill()
-        for pr in procs:
-            pr.wait()
-        reader.join(timeout=5)
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     for line in b''.join(c for c in chunks if c).decode(errors='replace').splitlines():
         # stdout carries the record only; library chatter (gloo / RCCL print banners to stdout) -> stderr
         print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
     sys.stdout.flush()
     return status
+
+
+RENDEZVOUS_EXIT = 75      # exit status of a rank whose torch.distributed rendezvous failed (launch_ranks retries on another port)
+
+
+def init_ranks(backend):
+    """ddp.init_from_env, with a failed rendezvous turned into RENDEZVOUS_EXIT for the launcher."""
+    from ctgan_amd import ddp
+    try:
+        return ddp.init_from_env(backend=backend)
+    except Exception as e:      # noqa: BLE001  (DistNetworkError / RuntimeError, by torch version)
+        import torch.distributed as dist
+        net = isinstance(e, getattr(dist, 'DistNetworkError', ())) or 'address already in use' in str(e).lower() or 'EADDRINUSE' in str(e)
+        if net and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            print('bench: rank %s: rendezvous failed: %r' % (os.environ.get('RANK'), e), file=sys.stderr)
+            sys.exit(RENDEZVOUS_EXIT)
+        raise
 
 
 def dist_info(world):
@@ -330,7 +376,11 @@ def spawn_check(args):
     from ctgan_amd import ddp
     if os.environ.get('CTGAN_TEST_DIE_RANK') == os.environ.get('RANK'):       # launcher test: this rank dies before the rendezvous
         sys.exit(7)
-    rank, world, local = ddp.init_from_env(backend=args.backend or 'gloo')
+    if os.environ.get('CTGAN_TEST_HANG_RANK') == os.environ.get('RANK'):      # launcher test: this rank never joins (a stuck collective)
+        import time
+        open(os.environ['CTGAN_TEST_PID_FILE'] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))
+        time.sleep(600)
+    rank, world, local = init_ranks(args.backend or 'gloo')
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     t = torch.tensor([float(rank + 1)])
@@ -360,7 +410,7 @@ def run_unconditional(args):
     from ctgan_amd.dcgan_step import DCGANTrainer
     from ctgan_amd.engine import GraphedDCGANTrainer
     modname, dtype, workload = ALT_CONFIGS[args.config]
-    rank, world, local = ddp.init_from_env(backend=args.backend)
+    rank, world, local = init_ranks(args.backend)
     if local >= torch.cuda.device_count():
         if world > 1 and dist.get_backend() != 'gloo':
             raise SystemExit('two RCCL ranks cannot share a GPU')

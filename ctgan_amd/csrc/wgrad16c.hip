@@ -29,7 +29,6 @@
 
 #include <algorithm>
 #include <type_traits>
-#include <queue>
 #include <vector>
 
 #include "common.h"
@@ -37,7 +36,8 @@
 #include "wgrad16c.h"
 
 // WC_DBG: compile-time perf-diagnosis bits for A/B builds (tools/build_variant.sh; results are then WRONG by design, never set in the product):
-// 2 = no split arithmetic (three roundings, no remainders), 4 = no MFMAs, 8 = no staging stores, 16 = remainders by unpack + v_sub instead of v_dot2c
+// 2 = no split arithmetic (three roundings, no remainders), 4 = no MFMAs, 8 = no staging stores, 16 = remainders by unpack + v_sub instead of v_dot2c,
+// 32 = no fragment reads from LDS, 64 = no barriers, 128 = no global loads in the loop
 #ifndef WC_DBG
 #define WC_DBG 0
 #endif
@@ -62,7 +62,8 @@ struct W16C {
     unsigned x_bytes, dy_bytes;
     int pq_shift, q_shift;
     int ncols, tiles;                    // columns; workgroups per split = ncols * (C/128) * (Ng/128)
-    int flags;                           // bit 0: the dy-staging waves multiply first, then stage (each SIMD hosts one wave of either kind)
+    int flags;                           // bit 1: split-major block order (A/B switch CTGAN_WGRAD16_COL_ORDER=1)
+    int splits;
     WCol col[CTGAN_WC_MAXCOL];
 };
 constexpr int WC_GROUP_MAX = 16;
@@ -86,7 +87,6 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     const int k_begin = by * p.chunk;
     const int k_end = min(k_begin + p.chunk, p.Kg);
     const int t0 = k_begin >> 5, t1 = (k_end + 31) >> 5;
-    const int PQ = p.P * p.Q;
     const int qu = p.Q >> 3;                               // ring units (8 pixels) per image row
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
@@ -112,12 +112,18 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     auto load_x = [&](int sl, float4 (&rv)[4]) {
         const unsigned so = (unsigned)sl * x_slice;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff_e[e] + so, 0, 0));
+        for (int e = 0; e < 4; ++e) {
+            if ((WC_DBG & 128) && sl > t0 + 2) { rv[e].x += 1.f; continue; }
+            rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff_e[e] + so, 0, 0));
+        }
     };
     auto load_y = [&](int sl, float4 (&rv)[4]) {         // (the descriptor ends at this split's last pixel: the next split's read as zeros)
         const unsigned so = (unsigned)sl * y_slice;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yoff_e[e] + so, 0, 0));
+        for (int e = 0; e < 4; ++e) {
+            if ((WC_DBG & 128) && sl > t0 + 2) { rv[e].x += 1.f; continue; }
+            rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yoff_e[e] + so, 0, 0));
+        }
     };
     // A staging block = 4 consecutive pixels x 4 channels.  Transposed by register naming: channel j of pixels (0,1) and (2,3) -> two
     // packed dwords per plane (8-byte LDS stores, conflict-free).  The eight pairs go through the three split levels TOGETHER (level by
@@ -208,7 +214,10 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[q][j] = *reinterpret_cast<const u32x4*>(yst + j * 32 * YROW + q * 64 + ks * 32);
+            for (int j = 0; j < 2; ++j) {
+                if (WC_DBG & 32) { fb[q][j] = u32x4{(unsigned)sl, (unsigned)ks, (unsigned)q, (unsigned)j}; continue; }
+                fb[q][j] = *reinterpret_cast<const u32x4*>(yst + j * 32 * YROW + q * 64 + ks * 32);
+            }
     };
     const unsigned xrow_lane_h = xrow_lane + (unsigned)h * 16u;
     auto load_a = [&](int sl, int ks, int t, u32x4 (&fa)[NP]) {
@@ -229,7 +238,10 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
             a = (valid ? xrow_lane_h : (unsigned)XZERO) + (valid ? uoff : 0u);
         }
 #pragma unroll
-        for (int q = 0; q < NP; ++q) fa[q] = *reinterpret_cast<const u32x4*>(xs + a + q * XPL);
+        for (int q = 0; q < NP; ++q) {
+            if (WC_DBG & 32) { fa[q] = u32x4{a, (unsigned)q, 1u, 2u}; continue; }
+            fa[q] = *reinterpret_cast<const u32x4*>(xs + a + q * XPL);
+        }
     };
     auto mma_tap = [&](const u32x4 (&fa)[NP], const u32x4 (&fb)[NP][2], auto t_c) {
         constexpr int t = decltype(t_c)::value;
@@ -284,42 +296,19 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     }
     __syncthreads();
     // Slice sl is multiplied while x slice sl+2 / dy slice sl+1 go from registers to LDS and the loads of the slices after them are issued.
-    // Staging and multiplying touch disjoint LDS regions within an iteration, so their order inside a wave is free: waves w and w+4 share a
-    // SIMD (a workgroup's waves go to the SIMDs round-robin), and with flag bit 0 the x-staging waves stage first while the dy-staging
-    // waves multiply first.
     // (Stores and loads run unconditionally, also in the last two iterations: what they stage is never multiplied - x of the next split,
     // dy past the descriptor's end = zeros - and a conditional load would keep the staging registers live across the iteration, which
-    // costs a register copy per value in front of the in-place split.)
-    if (p.flags & 1) {
-        if (is_x) {
-            for (int sl = t0; sl < t1; ++sl) {
-                mma_head(sl);
-                __builtin_amdgcn_sched_barrier(0);
-                store_x(rv, (sl + 2) & 3);
-                load_x(sl + 3, rv);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_steps(sl);
-                __syncthreads();
-            }
-        } else {
-            for (int sl = t0; sl < t1; ++sl) {
-                mma_head(sl);
-                mma_steps(sl);
-                store_y(rv, (sl + 1) & 1);
-                load_y(sl + 2, rv);
-                __syncthreads();
-            }
-        }
-    } else {
-        for (int sl = t0; sl < t1; ++sl) {
-            mma_head(sl);
-            __builtin_amdgcn_sched_barrier(0);
-            if (is_x) { store_x(rv, (sl + 2) & 3); load_x(sl + 3, rv); }
-            else { store_y(rv, (sl + 1) & 1); load_y(sl + 2, rv); }
-            __builtin_amdgcn_sched_barrier(0);
-            mma_steps(sl);
-            __syncthreads();
-        }
+    // costs a register copy per value in front of the in-place split.  Measured and dropped: the dy-staging waves multiplying first and
+    // staging afterwards, so that each SIMD's two waves are in opposite phases - 351 vs 361 us on the critic step's table, 416 vs 403 on
+    // the generator step's: neutral.)
+    for (int sl = t0; sl < t1; ++sl) {
+        mma_head(sl);
+        __builtin_amdgcn_sched_barrier(0);
+        if (is_x) { store_x(rv, (sl + 2) & 3); load_x(sl + 3, rv); }
+        else { store_y(rv, (sl + 1) & 1); load_y(sl + 2, rv); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_steps(sl);
+        if (!(WC_DBG & 64)) __syncthreads();
     }
 
     // acc[t][j][4g + e] = dW(tap_t, channel c0 + wm*32 + 8g + 4h + e, kout n0 + wn*64 + j*32 + l31): 32 lanes = 128-byte rows
@@ -360,7 +349,18 @@ __global__ __launch_bounds__(512) void wgrad16c_group_kernel(const W16CGroup g) 
     job = __builtin_amdgcn_readfirstlane(job);
     const W16C& p = g.j[job];
     const int local = (int)blockIdx.x - g.first[job];
-    const int by = local / p.tiles, tile = local - by * p.tiles;
+    // Block order inside a problem.  The columns of a filter read the SAME dy chunk and (shifted) the same x chunk: launched as
+    // (split, column) they land on different XCDs at different times and every column fetches its operands from memory again (L2 hit rate
+    // 0.05, 2.5x the algorithmic bytes, and the launch takes 190 us with its MFMAs switched off: the fabric, not the matrix pipe, sets its
+    // pace).  Workgroup b runs on XCD b % 8, so the blocks of eight consecutive splits are interleaved: all column / channel / kout tiles of
+    // one split are 8 block indices apart - same XCD, dispatched back to back, sharing one L2.
+    int by, tile;
+    if (p.flags & 2) { by = local / p.tiles; tile = local - by * p.tiles; }
+    else {
+        const int per_group = 8 * p.tiles, q = local / per_group, r = local - q * per_group;
+        const int m = min(8, p.splits - 8 * q);
+        tile = r / m; by = 8 * q + (r - tile * m);
+    }
     const int tiles_n = p.Ng >> 7, cblocks = p.C >> 7;
     const int tn = tile % tiles_n, t2 = tile / tiles_n, cb = t2 % cblocks, ci = t2 / cblocks;
     WCol col = p.col[ci];
@@ -450,51 +450,57 @@ int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d) {
     return g.ncols * (d->C / 128) * (d->K / 128);
 }
 
-// Pixels per split for every problem of a grouped call.  Workgroups differ in cost (one to three taps per column), so the plan gives a
-// problem of cheaper columns proportionally longer chunks, and picks the scale whose simulated schedule on 256 CUs (one workgroup per CU,
-// longest first) plus the slab traffic it causes is shortest.  Deterministic: a function of the geometries and row counts only.
+// Pixels per split for every problem of a grouped call.  One workgroup per CU is resident, workgroups differ in cost (one to three taps per
+// column, problems of different length), and a launch is one to three rounds long: the plan is chosen by a target workgroup time T - every
+// problem gets the longest chunk (multiple of 64 pixels, splits of equal length) whose workgroups stay within T - over a grid of T, by the
+// simulated schedule on 256 CUs (most expensive first, as the launch orders them) plus the slab traffic the plan causes.  Deterministic: a
+// function of the geometries and row counts only (the workspace query and the launch must agree).
 void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks) {
     static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_COL_CHUNK"); return e ? atoi(e) : 0; }();
-    static const int cand[] = {256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 2048, 3072, 4096, 8192};
+    static const bool log = getenv("CTGAN_WGRAD16_COL_LOG") != nullptr;
     std::vector<ColGeom> geoms(n);
-    for (int i = 0; i < n; ++i) col_geom(probs[i].d, &geoms[i]);
+    std::vector<int> mt(n, 1), kg(n);
+    for (int i = 0; i < n; ++i) {
+        col_geom(probs[i].d, &geoms[i]);
+        for (int c = 0; c < geoms[i].ncols; ++c) mt[i] = std::max(mt[i], geoms[i].ntap[c]);
+        kg[i] = probs[i].N * probs[i].d->P * probs[i].d->Q;
+    }
     double best_t = 1e30;
     std::vector<int> cur(n);
     std::vector<std::pair<double, int>> wgs;       // (cost, count)
-    for (int base : cand) {
-        if (forced && base != forced) continue;
+    std::vector<double> cus(256);
+    for (double T = 40.; T < 2000.; T *= 1.04) {
         wgs.clear();
         double slab_bytes = 0.;
         for (int i = 0; i < n; ++i) {
             const ctgan_conv_desc* d = probs[i].d;
-            const int Kg = probs[i].N * d->P * d->Q;
-            int mt = 1;
-            for (int c = 0; c < geoms[i].ncols; ++c) mt = std::max(mt, geoms[i].ntap[c]);
-            // equal workgroup cost across problems: a problem whose columns carry fewer taps gets longer chunks
-            int ch = (int)((double)base * (0.35 + 1.05 * 3) / (0.35 + 1.05 * mt));
-            ch = std::max(128, (ch + 63) / 64 * 64);
-            const int sp = (Kg + ch - 1) / ch;
-            ch = (((Kg + sp - 1) / sp) + 63) / 64 * 64;
+            int ch = forced ? forced : (int)((T - 4.0) / (0.35 + 1.05 * mt[i])) * 32;
+            ch = std::max(128, ch / 64 * 64);
+            const int sp = (kg[i] + ch - 1) / ch;
+            ch = (((kg[i] + sp - 1) / sp) + 63) / 64 * 64;
             cur[i] = ch;
-            const int splits = (Kg + ch - 1) / ch;
+            const int splits = (kg[i] + ch - 1) / ch;
             const int per = (d->C / 128) * (d->K / 128);
             for (int c = 0; c < geoms[i].ncols; ++c) wgs.emplace_back(wg_cost(geoms[i].ntap[c], ch), splits * per);
             slab_bytes += (double)splits * ((double)d->R * d->S * d->C + 1) * d->K * 4.;
         }
         std::sort(wgs.begin(), wgs.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
-        std::priority_queue<double, std::vector<double>, std::greater<double>> cus;
-        for (int k = 0; k < 256; ++k) cus.push(0.);
+        // list scheduling on 256 CUs: a min-heap of finish times
+        std::fill(cus.begin(), cus.end(), 0.);
+        std::make_heap(cus.begin(), cus.end(), std::greater<double>());
         double makespan = 0.;
         for (const auto& w : wgs)
             for (int k = 0; k < w.second; ++k) {
-                const double t = cus.top() + w.first;
-                cus.pop(); cus.push(t);
+                std::pop_heap(cus.begin(), cus.end(), std::greater<double>());
+                const double t = cus.back() + w.first;
+                cus.back() = t;
+                std::push_heap(cus.begin(), cus.end(), std::greater<double>());
                 if (t > makespan) makespan = t;
             }
         const double t = makespan + slab_bytes * 2. / 3.0e6;      // slabs written, then read by the reduction: ~3 TB/s each way
-        if (t < best_t * 0.99) { best_t = t; for (int i = 0; i < n; ++i) chunks[i] = cur[i]; }
-        static const bool log = getenv("CTGAN_WGRAD16_COL_LOG") != nullptr;
-        if (log) fprintf(stderr, "wgrad16c plan: base %d -> makespan %.1f us + slabs %.1f MB = %.1f us%s\n", base, makespan, slab_bytes / 1e6, t, t == best_t ? " *" : "");
+        if (t < best_t * 0.995) { best_t = t; for (int i = 0; i < n; ++i) chunks[i] = cur[i]; }
+        if (log) fprintf(stderr, "wgrad16c plan: T %.0f us -> makespan %.1f us + slabs %.1f MB = %.1f us%s\n", T, makespan, slab_bytes / 1e6, t, t == best_t ? " *" : "");
+        if (forced) break;
     }
 }
 
@@ -507,7 +513,7 @@ int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStre
             return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16c: cannot reserve %d B of LDS", LDS_TOTAL);
         attr = true;
     }
-    static const int pp_flag = [] { const char* e = getenv("CTGAN_WGRAD16_COL_PP"); return e ? atoi(e) : 0; }();
+    static const int order_flag = [] { const char* e = getenv("CTGAN_WGRAD16_COL_ORDER"); return (e && atoi(e) == 1) ? 2 : 0; }();
     // most expensive workgroups first
     std::vector<int> order(n);
     std::vector<double> cost(n);
@@ -538,10 +544,11 @@ int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStre
             p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)((long long)p.Kg * d->K * 4);
             p.pq_shift = __builtin_ctz(d->P * d->Q); p.q_shift = __builtin_ctz(d->Q);
             p.ncols = geoms[i].ncols; p.tiles = p.ncols * (d->C / 128) * (d->K / 128);
-            p.flags = pp_flag;
+            p.flags = order_flag;
+            p.splits = (p.Kg + p.chunk - 1) / p.chunk;
             for (int c = 0; c < p.ncols; ++c) p.col[c] = geoms[i].col[c];
             g.first[k] = b0;
-            if (k < g.n) b0 += p.tiles * ((p.Kg + p.chunk - 1) / p.chunk);
+            if (k < g.n) b0 += p.tiles * p.splits;
         }
         g.first[WC_GROUP_MAX] = b0;
         hipLaunchKernelGGL(kern, dim3((unsigned)b0), dim3(512), LDS_TOTAL, st, g);

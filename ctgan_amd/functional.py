@@ -35,13 +35,12 @@ DEFER_16BIT = _os.environ.get('CTGAN_DEFER_16BIT', '0') == '1'
 
 
 class _PreMask:
-    """Link between the node that produced a masked data gradient (`dx`, kept alive here so that its address cannot be reused while
-    the entry exists) and the node that consumes it.  `fused` = the conv result of the double backward that already carries the mask
-    (kept alive until the producer has looked at it: an accumulated gradient is a different tensor at a different address)."""
-    __slots__ = ('dx', 'mask', 'fused')
-
-
-_PREMASK = {}          # data_ptr of a masked data gradient -> _PreMask; emptied at the start and at the end of every step
+    """Link between the node that produced a masked data gradient and the node that consumes it.  The token travels ON the tensor
+    (attribute `_ctgan_premask` of the producer's result; `_ctgan_fused_for` of the consumer's) - not in a table keyed by device address:
+    a tensor that passed through anything else (a view, an accumulation by the autograd engine) is another Python object without the
+    attribute and simply does not fuse, whatever the allocator did with the addresses in between.  `fused_done` = the consumer's conv
+    already applied this node's mask to what it hands back."""
+    __slots__ = ('mask', 'fused_done')
 
 
 @contextlib.contextmanager
@@ -96,7 +95,6 @@ def deferred_wgrads():
     finally:
         groups, post = _DEFER['groups'], _DEFER['post']
         _DEFER.update(on=False, groups=None, post=None)
-        _PREMASK.clear()
         _flush_groups(list(groups.values()))
         folds = [e[1:] for e in post if isinstance(e, tuple) and e[0] == 'fold']
         if folds:
@@ -425,16 +423,12 @@ class ConvDgradFn(Function):
             ctx.save_for_backward(gy, w)
         ctx.pre = ctx.own = None
         if PREMASK_FUSION and not fork:                 # is gy a masked data gradient whose only processing there is the mask?
-            tok = _PREMASK.get(gy.data_ptr())
-            if tok is not None and tok.dx.shape == gy.shape and tok.dx.stride() == gy.stride():
-                ctx.pre = tok
+            ctx.pre = getattr(gy, '_ctgan_premask', None)
         dx = K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid, drop=drop)
         if PREMASK_FUSION and mask is not None and resid is None and drop is None and b is None:
             tok = _PreMask()
-            # (a DETACHED alias: dx itself gets this node as grad_fn -> ctx -> token -> dx would be a reference cycle that keeps the whole
-            # first-backward graph alive until the cycle collector runs - inside a stream capture that crashed capture_end)
-            tok.dx, tok.mask, tok.fused = dx.detach(), mask, None
-            _PREMASK[dx.data_ptr()] = ctx.own = tok
+            tok.mask, tok.fused_done = mask, False      # (the token does not reference dx: no cycle dx -> grad_fn -> ctx -> token -> dx)
+            dx._ctgan_premask = ctx.own = tok
         return (dx, gy.view_as(gy)) if fork else dx
 
     @staticmethod
@@ -456,11 +450,10 @@ class ConvDgradFn(Function):
             gy, w, mask = ctx.saved_tensors
         elif ctx.has_mask:
             gy, w, mask = ctx.saved_tensors
-            fused = None
+            fused = ctx.own is not None and getattr(ggx, '_ctgan_fused_for', None) is ctx.own and ctx.own.fused_done
             if ctx.own is not None:
-                fused, ctx.own.fused = ctx.own.fused, None
-            if not (fused is not None and fused.data_ptr() == ggx.data_ptr() and fused.shape == ggx.shape
-                    and fused.stride() == ggx.stride()):
+                ctx.own.fused_done = False
+            if not fused:
                 ggx = _relu_mask(ggx, mask, 0.0)      # the mask is a constant of the second pass
             # (else: ggx IS the result of the consumer's conv, whose epilogue applied this node's mask)
         else:
@@ -470,7 +463,8 @@ class ConvDgradFn(Function):
         if ctx.needs_input_grad[0] and ctx.pre is not None and gg_fork is None:
             # gy = mask(a) * (...) was produced by a data-gradient node that masks what arrives for it: apply that mask here
             g_gy = ConvFn.apply(ggx, w, None, None, g, None, False, False, {'out_mask': ctx.pre.mask})
-            ctx.pre.fused = g_gy.detach()
+            g_gy._ctgan_fused_for = ctx.pre
+            ctx.pre.fused_done = True
         elif ctx.needs_input_grad[0]:
             g_gy = ConvFn.apply(ggx, w, None, gg_fork, g, None, False)        # + the fork branch's gradient, in the epilogue
         elif gg_fork is not None:
@@ -560,7 +554,6 @@ def prepare_filters():
     """Rebuild every known derived filter for the current weight version now, on the current stream, in one launch (the
     data-gradient layouts of spread filters are computed from the parameter, not from the spread buffer)."""
     from . import tflib as lib
-    _PREMASK.clear()
     todo = [e for e in _FCACHE.values() if e.epoch != lib.epoch(e.group)]
     if todo:
         K.filter_batch([e.job() for e in todo])

@@ -60,3 +60,42 @@ def test_one_dying_rank_ends_the_run_instead_of_hanging_the_others():
     r = _run('--gpus', '2', '--backend', 'gloo', '--spawn-check', env={'CTGAN_TEST_DIE_RANK': '1'})
     assert r.returncode == 7, (r.returncode, r.stderr[-500:])
     assert time.time() - t0 < 60
+
+
+def test_sigterm_to_the_launcher_ends_its_ranks(tmp_path):
+    """A driver timeout sends SIGTERM to the launcher: the ranks it started - here rank 1 hangs before the rendezvous and rank 0 waits for
+    it - must be gone when the launcher exits (they would otherwise hold the GPUs until the RCCL timeout)."""
+    import signal
+    import time
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    pidfile = str(tmp_path / 'rank_pid')
+    e.update(CTGAN_TEST_HANG_RANK='1', CTGAN_TEST_PID_FILE=pidfile)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--spawn-check'], env=e,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        t0 = time.time()
+        while not os.path.exists(pidfile + '.1') and time.time() - t0 < 120:
+            time.sleep(0.2)
+        assert os.path.exists(pidfile + '.1'), 'the hanging rank never started'
+        time.sleep(0.5)
+        rank_pid = int(open(pidfile + '.1').read())
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=30)
+        assert p.returncode == 128 + signal.SIGTERM, p.returncode
+        time.sleep(0.5)
+        alive = True
+        try:
+            os.kill(rank_pid, 0)
+        except ProcessLookupError:
+            alive = False
+        if alive:       # a zombie of another parent would still answer kill(0): check its state
+            try:
+                state = open('/proc/%d/stat' % rank_pid).read().split()[2]
+                alive = state != 'Z'
+            except FileNotFoundError:
+                alive = False
+        assert not alive, 'rank process %d survived the launcher' % rank_pid
+    finally:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
