@@ -58,9 +58,14 @@ def main():
                     'multi-rank code path be exercised on a single-GPU box (all ranks share cuda:0)')
     ap.add_argument('--launcher', default='auto', choices=['auto', 'always', 'never'],
                     help='auto: start the N rank processes here when --gpus N > 1 and WORLD_SIZE is unset; always: also for N = 1')
+    ap.add_argument('--no-ar-in-graph', action='store_true', help='N > 1: the eager side-stream all-reduce + Adam outside the step graphs (the default for gloo)')
     ap.add_argument('--ar-in-graph', action='store_true',
                     help='N > 1: capture the gradient all-reduces (RCCL) and Adam inside the step graphs - one graph per iteration as at N = 1 '
                          '(engine.AR_IN_GRAPH; default: eager all-reduce on a side stream between per-step graphs)')
+    ap.add_argument('--feed', default='both', choices=['device', 'both'],
+                    help='device: the timed loop cycles 16 device-resident batches (the headline `value`); both: also re-time the loop with the\n'
+                         'real input path - tflib.cifar10.EpochFeed over synthetic uint8 images -> pinned host buffers -> H2D on a copy stream ->\n'
+                         'staging kernel (the span TF/CT_gan_cifar_resnet.py:394-412 times includes the feed) - reported as config.host_feed')
     ap.add_argument('--spawn-check', action='store_true',
                     help='ranks only join the process group, all-reduce their rank numbers and report (no GPU work): the launcher test')
     args = ap.parse_args()
@@ -69,7 +74,9 @@ def main():
     if args.spawn_check:
         return spawn_check(args)
     if args.ar_in_graph:
-        os.environ['CTGAN_AR_IN_GRAPH'] = '1'          # read when ctgan_amd.engine is imported (below)
+        os.environ['CTGAN_AR_IN_GRAPH'] = '1'
+    if args.no_ar_in_graph:
+        os.environ['CTGAN_AR_IN_GRAPH'] = '0'          # read when ctgan_amd.engine is imported (below)
 
     import numpy as np
     import torch
@@ -117,8 +124,19 @@ def main():
         print(json.dumps(measure_gp_unit(trainer, batches[0], torch)))
         return
     eng = GraphedTrainer(trainer, use_graphs=not args.no_graph)
+    if world > 1 and eng.ar_in_graph is not None:
+        # every rank must run the same path: if any rank could not capture the in-graph collective, all fall back to the side-stream one
+        bad = torch.tensor([1.0 if (eng.ar_in_graph and (eng.graph_error or eng.it_graph is None)) else 0.0], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() > 0 and eng.ar_in_graph:
+            if rank == 0:
+                print('bench: in-graph all-reduce not captured on every rank (%s / %s): falling back to the side-stream collective'
+                      % (eng.graph_error, eng.it_graph_error), file=sys.stderr)
+            eng = GraphedTrainer(trainer, use_graphs=not args.no_graph, ar_in_graph=False)
     if eng.graph_error and rank == 0:
         print('hipGraph capture failed, running eager: ' + eng.graph_error, file=sys.stderr)
+    elif eng.it_graph_error and rank == 0:
+        print('whole-iteration graph not captured (per-step graphs in use): ' + eng.it_graph_error, file=sys.stderr)
 
     it = 1
     for _ in range(args.warmup):
@@ -188,6 +206,34 @@ def main():
                       'exposed_ms_per_step': round(ms_per_step - ms_local, 3),
                       'overlap': 'side stream; the next critic step\'s input staging is enqueued while the bucket is in flight (DESIGN 5)'}
 
+    # The same loop fed the way the reference's loop is (TF/CT_gan_cifar_resnet.py:394-412 times the feed too; TF/tflib/cifar10.py:40-63 is
+    # the contract): uint8 epochs shuffled on the host, pinned prefetch two batches deep, H2D on a copy stream, the iteration's staging
+    # kernel.  Device-resident batches stay the headline (`value`); this is the PCIe-inclusive rate beside it.
+    host_feed = None
+    if args.feed == 'both':
+        from ctgan_amd.tflib import cifar10
+        frng = np.random.default_rng(99 + rank)
+        n_img = 10000
+        feed_src = cifar10.EpochFeed(frng.integers(0, 256, (n_img, 3072), dtype=np.uint8), frng.integers(0, 10, (n_img,), dtype=np.uint8).astype(np.int32), B)
+        feed = cifar10.prefetch_to_device(cifar10.inf_train_gen(feed_src), dev)
+        nxt = lambda: next(feed)      # noqa: E731
+        k3 = max(5, min(args.steps, 50))
+        for _ in range(3):
+            eng.train_iteration(it, nxt); it += 1
+        ddp.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k3):
+            eng.train_iteration(it, nxt); it += 1
+        torch.cuda.synchronize(); ddp.barrier()
+        dth = time.perf_counter() - t1
+        if world > 1:
+            th = torch.tensor([dth], dtype=torch.float64, device=dev)
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+            dth = th.item()
+        host_feed = {'value': round(R.cfg.N_CRITIC * B * world * k3 / dth, 2), 'ms_per_step': round(1e3 * dth / k3, 3), 'steps': k3,
+                     'h2d_bytes_per_step': R.cfg.N_CRITIC * (B * 3072 * 4 + B * 4),
+                     'path': 'tflib.cifar10.EpochFeed (synthetic uint8, %d images) -> int32 pinned host -> H2D copy stream, 2 deep -> staging kernel' % n_img}
+
     roofline = None
     if not args.no_roofline and rank == 0:
         roofline = measure_roofline(trainer, next_batch, K, torch, ms_per_step)
@@ -244,7 +290,7 @@ def main():
                        'images_per_step': R.cfg.N_CRITIC * B * world, 'parallelism': 'dp%d' % world,
                        'hipgraph': bool(eng.graphed), 'last_d_cost': last_cost, 'last_d_terms': last, 'loss_sane': sane,
                        'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1], 'replicas_identical': replicas_identical,
-                       'collective': collective,
+                       'host_feed': host_feed, 'collective': collective,
                        'arithmetic': ('fp32 throughout; the large stride-1 conv layers (roofline.by_kernel: conv16x3h) compute the fp32 products as '
                                       'three-bf16-term splits on the bf16 matrix cores (six MFMAs per product, fp32 accumulate; error vs fp64 '
                                       'no larger than the fp32 MFMA family\'s, tests/test_gpu_kernels16.py, DESIGN 4.6), every other layer on '

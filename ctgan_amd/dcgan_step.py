@@ -119,7 +119,8 @@ class DCGANTrainer:
     def d_step(self, real_in, rnd=None):
         self.rng.begin_step()
         out = self.d_losses(real_in, rnd)
-        grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        with F.deferred_wgrads():       # the queued weight gradients of the step: one grouped launch (functional._flush_groups)
+            grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.d_opt, grads)
         out['grads'] = dict(zip([n for n, _ in self.d_named], self._unscaled(grads)))
         return out
@@ -127,7 +128,8 @@ class DCGANTrainer:
     def g_step(self, rnd=None):
         self.rng.begin_step()
         out = self.g_losses(rnd)
-        grads = torch.autograd.grad(out['cost'], self.g_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        with F.deferred_wgrads():
+            grads = torch.autograd.grad(out['cost'], self.g_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.g_opt, grads)
         out['grads'] = dict(zip([n for n, _ in self.g_named], self._unscaled(grads)))
         return out

@@ -19,9 +19,20 @@ import os as _os
 ITERATION_GRAPH = _os.environ.get('CTGAN_ITERATION_GRAPH', '1') != '0'
 # world > 1: capture the gradient all-reduce (RCCL supports stream capture) and the Adam step INSIDE the step graphs, so that the
 # multi-GPU loop is the same one-graph-per-iteration replay as the single-GPU loop (no graph boundaries, no eager launches between
-# the steps).  Off by default: the eager side-stream all-reduce (ddp.FlatAllReduce) is the path the CPU (gloo) tests cover; this one
-# is covered on one GPU by a 1-rank RCCL group (tests/test_gpu_graph_loop.py) and awaits a multi-GPU box.
-AR_IN_GRAPH = _os.environ.get('CTGAN_AR_IN_GRAPH', '0') != '0'
+# the steps).  Default (round 4) when the process group's backend is RCCL ('nccl'); the eager side-stream all-reduce
+# (ddp.FlatAllReduce) stays the path for gloo (its CUDA collectives stage through the host: not capturable) and is what the CPU tests
+# cover.  CTGAN_AR_IN_GRAPH=0 / 1 forces either.  Covered on one GPU by a 1-rank RCCL group incl. grad_scale = 1 / world != 1
+# (tests/test_gpu_graph_loop.py); bench.py falls back to the side-stream path on every rank if any rank's capture fails.
+_AR_ENV = _os.environ.get('CTGAN_AR_IN_GRAPH')
+AR_IN_GRAPH = None if _AR_ENV is None else (_AR_ENV != '0')
+
+
+def ar_in_graph_default():
+    """In-graph collectives by default exactly when they are RCCL collectives."""
+    if AR_IN_GRAPH is not None:
+        return AR_IN_GRAPH
+    import torch.distributed as dist
+    return bool(dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl')
 
 
 def _capture_kw():
@@ -67,11 +78,12 @@ class GraphedTrainer:
         self.it_out = None
         self.real_all = self._stage[:n_real].view(R.cfg.N_CRITIC, B, R.cfg.OUTPUT_DIM) if self.batch_fakes else None
         self.ar_in_graph = bool(use_graphs and trainer.allreduce is not None and (trainer.world > 1 or getattr(trainer.allreduce, 'always', False))
-                                and (AR_IN_GRAPH if ar_in_graph is None else ar_in_graph))
+                                and (ar_in_graph_default() if ar_in_graph is None else ar_in_graph))
         self.adam_in_graph = trainer.world == 1 or self.ar_in_graph
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
         self.graph_error = None
+        self.it_graph_error = None    # only the whole-iteration graph failed to capture: the per-step graphs are in use (still `graphed`)
         if use_graphs:
             try:
                 self._capture(warmup)
@@ -201,7 +213,11 @@ class GraphedTrainer:
                             self.it_out = self._it_body()
                     except Exception as e:
                         self.it_graph = self.it_out = None
-                        self.graph_error = 'iteration graph not captured (per-step graphs in use): %s: %s' % (type(e).__name__, e)
+                        self.it_graph_error = '%s: %s' % (type(e).__name__, e)
+                        torch.cuda.synchronize()
+                        # an exception inside an active capture can leave the stream / pools in a bad state: prove the per-step graphs
+                        # still replay (weights do not move: the learning rate is 0 here) before relying on them
+                        self.d_graph.replay(); self.g_graph.replay(); self.f_graph.replay()
                         torch.cuda.synchronize()
         finally:
             torch.cuda.synchronize()
@@ -357,10 +373,8 @@ class GraphedDCGANTrainer:
         else:
             out = t.g_losses()
             params, opt = t.g_params, t.g_opt
-        # (weight gradients launched at once: queuing them for the grouped launches - F.deferred_wgrads(), as the ResNet step does - bought
-        # config[1] 3.2 % but hung the 128x128 ResNet's GPU tests in the fp32 family's multi-segment planner; that loop is fixed
-        # (csrc/igemm.hip multi_plan), re-enabling was not re-measured within round 3's GPU budget: DESIGN 6.1)
-        grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        with F.deferred_wgrads():       # the step's queued weight gradients in one grouped launch, as the ResNet step
+            grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         if self.adam_in_graph:
             opt.update(grads, 1.0 / t.loss_scale, rng=t.rng)
         else:

@@ -27,11 +27,11 @@ MASK_IN_DGRAD_EPILOGUE = _os.environ.get('CTGAN_MASK_EPI', '1') != '0'
 # again.  When g_a's consumer is itself a data-gradient node (the block's first conv), the conv that node launches in the double
 # backward takes mask(a) in its epilogue and the separate mask pass (one launch per block per step) disappears.  Experiment switch.
 PREMASK_FUSION = _os.environ.get('CTGAN_PREMASK', '1') != '0'
-# Mixed-precision modes: queue the small weight gradients for the grouped 16-bit launch (kernels.grouped16_takes).  Off: a filter whose
-# uses fall on both sides of the size rule would get one queued and one immediate result (two gradient tensors for one parameter, summed
-# by autograd before the flush has written the queued one) - safe only for steps where every use of a filter has the same row count,
-# and the steps that would profit (DCGAN family) do not queue at all for now.
-DEFER_16BIT = _os.environ.get('CTGAN_DEFER_16BIT', '0') == '1'
+# Mixed-precision modes: queue the small weight gradients for the grouped 16-bit launch (kernels.grouped16_takes).  The size rule is
+# applied PER FILTER, by its first use of the step: a filter must not get one queued and one immediate result - two gradient tensors for
+# one parameter, which autograd sums the moment the second arrives, before the flush has written the queued one (_wgrad keeps the
+# first use's choice for every later use).  CTGAN_DEFER_16BIT=0: every weight gradient of those modes at once, as in round 3.
+DEFER_16BIT = _os.environ.get('CTGAN_DEFER_16BIT', '1') == '1'
 
 
 class _PreMask:
@@ -61,7 +61,7 @@ def weight_grads(enabled):
 # returns the (still empty) result buffer, later requests of the same filter return None, and on exit every filter
 # gets ONE multi-segment launch (K.conv_wgrad_multi) that sums its uses - the dropout passes and the gradient-penalty
 # double backward - instead of one wgrad + reduction per use and an autograd `add` per extra use.
-_DEFER = {'on': False, 'groups': None, 'post': None}
+_DEFER = {'on': False, 'groups': None, 'post': None, 'imm': None}      # imm: filters whose first use of the step was launched at once
 DEFER_WGRADS = _os.environ.get('CTGAN_DEFER_WGRADS', '1') != '0'
 # A/B switch: the few-channel weight gradients (first critic conv / shortcut) are queued too: both uses of a filter in one launch
 FEWCH_DEFER = _os.environ.get('CTGAN_FEWCH_DEFER', '1') != '0'
@@ -89,12 +89,12 @@ def deferred_wgrads():
     if not DEFER_WGRADS or _DEFER['on']:
         yield
         return
-    _DEFER.update(on=True, groups={}, post=[])
+    _DEFER.update(on=True, groups={}, post=[], imm=set())
     try:
         yield
     finally:
         groups, post = _DEFER['groups'], _DEFER['post']
-        _DEFER.update(on=False, groups=None, post=None)
+        _DEFER.update(on=False, groups=None, post=None, imm=None)
         _flush_groups(list(groups.values()))
         folds = [e[1:] for e in post if isinstance(e, tuple) and e[0] == 'fold']
         if folds:
@@ -203,19 +203,28 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     Returns (gw, gb); either may be None when another request of the same filter already owns the result."""
     stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _SPREAD_BUFS     # same identity in every pass of the step
     fewch = K.fewch_handles(g)                    # few-channel convs: the direct kernel sums two uses in one launch
-    defer = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
-             # fp32 mode: the fp32 family's / the split mode's grouped launches; mixed-precision modes: the small problems the grouped
-             # 16-bit launch takes (kernels.grouped16_takes), everything else at once on its own tile
-             and (K.MMA_DTYPE is None or (DEFER_16BIT and x.is_cuda and K.grouped16_takes(g, x.shape[0])))
-             and ((g.C % 32 == 0 and g.K % 4 == 0) or (fewch and FEWCH_DEFER)) and not (g.R == 1 and g.H == 1 and g.W == 1))
+    gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
+    key = (w.data_ptr(), gk)       # (w: a registry parameter or a cached derived filter - persistent tensors, their addresses are stable)
+    can = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
+           and ((g.C % 32 == 0 and g.K % 4 == 0) or (fewch and FEWCH_DEFER)) and not (g.R == 1 and g.H == 1 and g.W == 1))
+    if can and K.MMA_DTYPE is not None:
+        # mixed-precision modes: the small problems the grouped 16-bit launch takes (kernels.grouped16_takes), everything else at once on
+        # its own tile - decided by the filter's FIRST use of the step and kept for its later uses
+        if key in _DEFER['groups']:
+            can = x.is_cuda and K.grouped16_member(g)
+        elif key in _DEFER['imm']:
+            can = False
+        else:
+            can = DEFER_16BIT and x.is_cuda and K.grouped16_takes(g, x.shape[0])
+            if not can:
+                _DEFER['imm'].add(key)
+    defer = can
     if not defer:
         if with_bias:
             return K.conv_wgrad(x, gy, g, with_bias=True, relu_x=relu_x)
         return K.conv_wgrad(x, gy, g, relu_x=relu_x), None
     if (with_bias or K.MMA_DTYPE is not None) and not gy.permute(0, 2, 3, 1).is_contiguous() and not fewch:
         gy = K.to_channels_last(gy)          # (the grouped 16-bit launch reads dy dense channels-last)
-    gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
-    key = (w.data_ptr(), gk)
     grp = _DEFER['groups'].get(key)
     if K.wgrad_prefers_x3(g, x.shape[0], x.device):
         # a large layer: the split-mode kernel is the faster fp32 path (kernels.X3_HYBRID) - launched now.  The filter keeps ONE result

@@ -103,6 +103,12 @@ def grouped16_takes(g, rows):
             and g.Q % 4 == 0 and not g.x_up and not fewch_handles(g) and rows * g.P * g.Q <= 16384)
 
 
+def grouped16_member(g):
+    """Can the grouped 16-bit launch take this geometry at all (whatever its size)?  The capability behind grouped16_takes' size rule."""
+    return (X3_WGRAD_GROUP and MMA_DTYPE in ('bf16', 'f16') and g.C % 128 == 0 and g.K % 128 == 0 and g.Q % 4 == 0 and not g.x_up
+            and not fewch_handles(g))
+
+
 def wgrad_prefers_x3(g, N, device=None):
     """True when the fp32 mode routes this weight gradient to the split mode (then it is launched at once, not queued for the fp32
     family's grouped launch).  Needs dense channels-last operands, which the callers of the large layers provide."""

@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 
-def run(in_graph, dim, B, iters):
+def run(in_graph, dim, B, iters, world=1):
     import ctgan_amd.gan_cifar_resnet as R
     import ctgan_amd.tflib as lib
     from ctgan_amd import ddp
@@ -22,9 +22,11 @@ def run(in_graph, dim, B, iters):
     R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
     R.build_params()
     ar = ddp.FlatAllReduce(always=True) if in_graph else None
-    tr = R.Trainer(seed=2024, allreduce=ar)
+    # world = 2 on a 1-rank group: the sum over one rank is the identity, so the only effect is Adam's grad_scale = 1 / world = 0.5 -
+    # the in-graph path (gather, all-reduce, step(1/world)) against the path without a collective at the same scale
+    tr = R.Trainer(seed=2024, world_size=world, allreduce=ar)
     eng = GraphedTrainer(tr, use_graphs=True, ar_in_graph=in_graph)
-    assert eng.graphed and eng.it_graph is not None, eng.graph_error
+    assert eng.graphed and (eng.it_graph is not None or (world > 1 and not in_graph)), eng.graph_error
     assert eng.ar_in_graph == bool(in_graph)
     nrng = np.random.default_rng(1)
     batches = [(torch.from_numpy(nrng.integers(0, 256, (B, 3072), dtype=np.int32)).cuda(),
@@ -52,6 +54,10 @@ if __name__ == '__main__':
     dim, B, iters = (int(v) for v in sys.argv[1:4])
     a = run(False, dim, B, iters)
     b = run(True, dim, B, iters)
-    print(json.dumps({'d_equal': bool(torch.equal(a[0], b[0])), 'g_equal': bool(torch.equal(a[1], b[1])), 'cost_plain': a[2], 'cost_in_graph': b[2],
+    a2 = run(False, dim, B, iters, world=2)
+    b2 = run(True, dim, B, iters, world=2)
+    print(json.dumps({'scaled_d_equal': bool(torch.equal(a2[0], b2[0])), 'scaled_g_equal': bool(torch.equal(a2[1], b2[1])),
+                      'scaled_differs_from_unscaled': bool(not torch.equal(a[0], a2[0])),
+                      'd_equal': bool(torch.equal(a[0], b[0])), 'g_equal': bool(torch.equal(a[1], b[1])), 'cost_plain': a[2], 'cost_in_graph': b[2],
                       'backend': dist.get_backend(), 'd_moved': float((a[0] - torch.zeros_like(a[0])).abs().max().item())}))
     dist.destroy_process_group()

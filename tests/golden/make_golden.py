@@ -170,6 +170,10 @@ if __name__ == '__main__':
         loop_trace_fixture()
     if 'loop32' in which:       # the oracle's own fp32 twin on the same streams: how far ANY fp32 evaluation drifts from the fp64 trace
         loop_trace_fixture(fname='resnet_loop_trace_f32twin.npz', dtype=torch.float32)
+    if 'loopfull' in which:     # the loop at FULL width (DIM 128, B 64), 2 iterations: what tests/test_gpu_graph_loop.py replays on the device
+        torch.set_num_threads(8)
+        loop_trace_fixture(dim=128, B=64, iters=2, fname='resnet_loop_128_64.npz')
+        loop_trace_fixture(dim=128, B=64, iters=2, fname='resnet_loop_128_64_f32twin.npz', dtype=torch.float32)
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_gpus_8_gloo_on_one_device():
     e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--steps', '2', '--warmup', '1',
-                        '--no-roofline', '--no-cpu-baseline'], env=e, capture_output=True, text=True, timeout=580)
+                        '--no-roofline', '--no-cpu-baseline', '--feed', 'device'], env=e, capture_output=True, text=True, timeout=580)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
