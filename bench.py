@@ -215,7 +215,7 @@ def main():
         frng = np.random.default_rng(99 + rank)
         n_img = 10000
         feed_src = cifar10.EpochFeed(frng.integers(0, 256, (n_img, 3072), dtype=np.uint8), frng.integers(0, 10, (n_img,), dtype=np.uint8).astype(np.int32), B)
-        feed = cifar10.prefetch_to_device(cifar10.inf_train_gen(feed_src), dev)
+        feed = cifar10.prefetch_to_device(cifar10.inf_train_gen(feed_src), dev, depth=2 * R.cfg.N_CRITIC)
         nxt = lambda: next(feed)      # noqa: E731
         k3 = max(5, min(args.steps, 50))
         for _ in range(3):
@@ -232,7 +232,7 @@ def main():
             dth = th.item()
         host_feed = {'value': round(R.cfg.N_CRITIC * B * world * k3 / dth, 2), 'ms_per_step': round(1e3 * dth / k3, 3), 'steps': k3,
                      'h2d_bytes_per_step': R.cfg.N_CRITIC * (B * 3072 * 4 + B * 4),
-                     'path': 'tflib.cifar10.EpochFeed (synthetic uint8, %d images) -> int32 pinned host -> H2D copy stream, 2 deep -> staging kernel' % n_img}
+                     'path': 'tflib.cifar10.EpochFeed (synthetic uint8, %d images) -> int32 pinned ring -> H2D copy stream, two iterations deep -> staging kernel' % n_img}
 
     roofline = None
     if not args.no_roofline and rank == 0:

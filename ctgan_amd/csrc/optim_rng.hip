@@ -140,6 +140,33 @@ __global__ void dropout_rng_kernel(const float* __restrict__ x, float* __restric
         }
     }
 }
+// LeakyReLU and dropout in ONE pass (the DCGAN critics' `dropout(LeakyReLU(conv))`, TF/CT_gan_cifar.py:84-98): y = x * slope(ref) / keep *
+// floor(keep + u), slope(r) = r > 0 ? 1 : alpha.  Forward: ref = x (y = dropout(lrelu(x))).  Backward and double backward: x = the arriving
+// gradient, ref = the forward RESULT - where the mask kept the value its sign is the pre-activation's, where it dropped it the product is 0.
+__global__ void lrelu_dropout_rng_kernel(const float* __restrict__ x, const float* __restrict__ ref, float* __restrict__ y, long long n,
+                                         float alpha, float keep, float inv, uint64_t seed, uint32_t sid, const uint64_t* __restrict__ ctr) {
+    const uint64_t step = ctr ? ctr[0] : 0;
+    const long long nblk = (n + 3) >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ref)) & 15) == 0;
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
+        uint32_t c[4];
+        draw4(seed, sid, step, (uint32_t)b, c);
+        const long long i = b * 4;
+        if (vec && i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            const float4 r = *reinterpret_cast<const float4*>(ref + i);
+            float4 o;
+            o.x = v.x * (r.x > 0.f ? 1.f : alpha) * inv * floorf(keep + u01(c[0])); o.y = v.y * (r.y > 0.f ? 1.f : alpha) * inv * floorf(keep + u01(c[1]));
+            o.z = v.z * (r.z > 0.f ? 1.f : alpha) * inv * floorf(keep + u01(c[2])); o.w = v.w * (r.w > 0.f ? 1.f : alpha) * inv * floorf(keep + u01(c[3]));
+            *reinterpret_cast<float4*>(y + i) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) y[i + k] = x[i + k] * (ref[i + k] > 0.f ? 1.f : alpha) * inv * floorf(keep + u01(c[k]));
+        }
+    }
+}
 // dropout_rng_kernel followed by the ReLU mask of lrelu_bwd (alpha 0) in one pass: y = dropout(x) (optional), ym = y where ref > 0
 // else 0.  The double backward of a data gradient whose result is masked, added to and dropped needs both (functional.ConvDgradFn).
 __global__ void dropout_rng_mask_kernel(const float* __restrict__ x, const float* __restrict__ ref, float* __restrict__ y,
@@ -382,6 +409,15 @@ int ctgan_dropout_rng(const float* x, float* y, int64_t n, float keep, uint64_t 
     hipLaunchKernelGGL(dropout_rng_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, y,
                        (long long)n, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr);
     return ctgan_check_launch("dropout_rng");
+}
+int ctgan_lrelu_dropout_rng(const float* x, const float* ref, float* y, int64_t n, float alpha, float keep, uint64_t seed, uint64_t stream_id,
+                            const uint64_t* ctr, ctgan_stream_t s) {
+    if (!x || !ref || !y || n < 0 || n >= (1LL << 34)) return ctgan_fail(CTGAN_E_BADARG, "lrelu_dropout_rng: bad argument");
+    if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "lrelu_dropout_rng: keep=%g not in (0,1]", keep);
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(lrelu_dropout_rng_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, ref, y,
+                       (long long)n, alpha, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr);
+    return ctgan_check_launch("lrelu_dropout_rng");
 }
 int ctgan_dropout_rng_mask(const float* x, const float* ref, float* y, float* y_masked, int64_t n, float keep, uint64_t seed,
                            uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t s) {

@@ -926,6 +926,53 @@ class DropoutRngFn(Function):
         return DropoutRngFn.apply(gy, keep, seed, sid, ctr, strides), None, None, None, None, None, None
 
 
+# A/B switch: LeakyReLU + dropout of the DCGAN critics as one launch (forward / backward / double backward each)
+LRELU_DROP_FUSION = _os.environ.get('CTGAN_LRELU_DROP', '1') != '0'
+
+
+class LReluDropFn(Function):
+    """dropout(LeakyReLU(x)) - the activation pair after every conv of the DCGAN critics (TF/CT_gan_cifar.py:84-98) - in one launch, mask from
+    the Philox stream; the backward (a diagonal scaling by slope * mask / keep, hence its own adjoint: the double backward is the same op)
+    in one launch as well, with the forward RESULT as the sign reference."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, keep, seed, sid, ctr):
+        if not K.is_dense(x):
+            x = x.contiguous()
+        y = K.lrelu_dropout_rng(x, x, alpha, keep, seed, sid, ctr)
+        ctx.cfg = (alpha, keep, seed, sid, ctr)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return (LReluDropBwdFn.apply(gy, y.detach(), *ctx.cfg),) + (None,) * 5
+
+
+class LReluDropBwdFn(Function):
+    @staticmethod
+    def forward(ctx, gy, ref, alpha, keep, seed, sid, ctr):
+        if tuple(gy.stride()) != tuple(ref.stride()):      # the draws are indexed by physical offset: same layout as the forward
+            gy = K.copy4d(gy, torch.empty_strided(gy.shape, ref.stride(), dtype=gy.dtype, device=gy.device)) if gy.dim() == 4 else gy.contiguous()
+        ctx.cfg = (alpha, keep, seed, sid, ctr)
+        ctx.save_for_backward(ref)
+        return K.lrelu_dropout_rng(gy, ref, alpha, keep, seed, sid, ctr)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        (ref,) = ctx.saved_tensors
+        return (LReluDropBwdFn.apply(ggx, ref, *ctx.cfg),) + (None,) * 6
+
+
+def lrelu_dropout(x, alpha, keep_prob, rng):
+    """dropout(leaky_relu(x, alpha), keep_prob) with the mask drawn from `rng`'s next dropout stream: one launch each way."""
+    if keep_prob == 1.0:
+        return leaky_relu(x, alpha)
+    spec = drop_spec(rng, keep_prob)
+    return LReluDropFn.apply(x, alpha, spec[0], spec[1], spec[2], spec[3])
+
+
 class RowsCatDropFn(Function):
     """dropout([x ; x[:n_extra]]) in one launch; the dropout's backward is applied by the consumer (conv dgrad epilogue,
     `bwd_fused`), so the backward here is the concat's adjoint alone - one launch instead of slice + zero-fill + add."""

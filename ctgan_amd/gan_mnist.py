@@ -71,15 +71,21 @@ def Discriminator(inputs, u=None, rng=None):
     """:89-108 - returns (D [n], D_ [n, 4*4*4*DIM])."""
     D = cfg.DIM
 
-    def drop(x, i):
-        return F.dropout(x, 0.5, u[i]) if u is not None else F.dropout(x, 0.5, rng=rng)
+    def act(x, i):
+        """dropout(LeakyReLU(x)), keep 0.5: one launch each way when the mask comes from the Philox stream (F.lrelu_dropout); the two ops
+        apart in parity mode (injected uniforms `u`)."""
+        if u is not None:
+            return F.dropout(LeakyReLU(x), 0.5, u[i])
+        if F.LRELU_DROP_FUSION:
+            return F.lrelu_dropout(x, 0.2, 0.5, rng)
+        return F.dropout(LeakyReLU(x), 0.5, rng=rng)
     output = inputs.reshape(-1, 1, 28, 28)
     output = _conv2d.Conv2D('Discriminator.1', 1, D, 5, output, stride=2)
-    output = drop(LeakyReLU(output), 0)
+    output = act(output, 0)
     output = _conv2d.Conv2D('Discriminator.2', D, 2 * D, 5, output, stride=2)
-    output = drop(LeakyReLU(output), 1)
+    output = act(output, 1)
     output = _conv2d.Conv2D('Discriminator.3', 2 * D, 4 * D, 5, output, stride=2)
-    output = drop(LeakyReLU(output), 2)
+    output = act(output, 2)
     output2 = F.to_nchw(output).reshape(-1, 4 * 4 * 4 * D)
     output = _linear.Linear('Discriminator.Output', 4 * 4 * 4 * D, 1, output2)
     return output.reshape(-1), output2

@@ -673,12 +673,13 @@ def conv_wgrad_group(groups):
         else:
             st = torch.cuda.current_stream()
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            # ONE launch per bracket: this launch is hundreds of microseconds long (the ~10 us of event overhead is 3 %), and repeated back
+            # to back it runs 15 % slower than in the step - the sustained MFMA stream pulls the clock down (410 vs 333 us, round 4)
             e0.record(st)
-            for _ in range(PROFILE_REPS):
-                check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1, _stream()), 'conv2d16_wgrad_group')
+            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1, _stream()), 'conv2d16_wgrad_group')
             e1.record(st)
             flops = sum(_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in x3)
-            PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, ('group', len(x3)), last_symbol()))
+            PROFILE.append((last_kernel(), flops, e0, e1, 1, ('group', len(x3)), last_symbol()))
             check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 2, _stream()), 'conv2d16_wgrad_group')
         if not rest:
             return
@@ -811,6 +812,18 @@ def dropout_rng(x, keep, seed, stream_id, ctr):
     assert ctr.is_cuda and ctr.dtype == torch.int64
     y = _ew_out(x)
     check(lib.ctgan_dropout_rng(_ptr(x), _ptr(y), x.numel(), keep, seed, stream_id, _ptr(ctr), _stream()), 'dropout_rng')
+    return y
+
+
+def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr):
+    """x * (ref > 0 ? 1 : alpha) / keep * floor(keep + u) in one launch: dropout(LeakyReLU(x)) for ref = x; the backward of that pair for
+    x = the gradient, ref = the forward result.  ref in x's physical layout; draws as dropout_rng."""
+    _need_dev(x, ref)
+    assert ctr.is_cuda and ctr.dtype == torch.int64
+    assert tuple(ref.shape) == tuple(x.shape) and ref.stride() == x.stride()
+    y = _ew_out(x)
+    check(lib.ctgan_lrelu_dropout_rng(_ptr(x), _ptr(ref), _ptr(y), x.numel(), alpha, keep, seed, stream_id, _ptr(ctr), _stream()),
+          'lrelu_dropout_rng')
     return y
 
 

@@ -68,26 +68,46 @@ def inf_train_gen(train_gen):
 
 def prefetch_to_device(gen, device, depth=2):
     """(images uint8, labels) iterator -> (int32 [B,3072], int32 [B]) device tensors (the placeholder dtypes of
-    TF/CT_gan_cifar_resnet.py:191-192), `depth` batches in flight."""
+    TF/CT_gan_cifar_resnet.py:191-192), `depth` batches in flight.  The uint8 -> int32 widening is written straight into a ring of
+    pinned host buffers (allocated once per batch shape), the H2D copies run on a copy stream; a consumer that takes several batches
+    per step (the N_CRITIC critic batches of an iteration) should ask for a depth of two steps' worth."""
     import torch
     on_gpu = torch.device(device).type == 'cuda'
     stream = torch.cuda.Stream(device=device) if on_gpu else None
     inflight = collections.deque()
+    ring, slot, slot_done = {}, [0], {}
+
+    def pinned(shape, k):
+        """Slot `slot` of the ring of pinned int32 buffers for operand k of this shape (depth + 2 slots: a slot is rewritten only after
+        its copy has been waited for by the consumer's stream and `depth` newer ones were issued)."""
+        key = (k, tuple(shape))
+        if key not in ring:
+            ring[key] = [torch.empty(tuple(shape), dtype=torch.int32).pin_memory() for _ in range(depth + 2)]
+        return ring[key][slot[0] % (depth + 2)]
 
     def stage():
         item = next(gen, None)
         if item is None:
             return
-        host = [torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)) for a in item]
         if not on_gpu:
+            host = [torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)) for a in item]
             inflight.append((host[0].to(device), host[1].to(device), None, None))
             return
-        host = [h.pin_memory() for h in host]
+        prev = slot_done.get(slot[0] % (depth + 2))
+        if prev is not None:
+            prev.synchronize()        # the copy that last read this slot's pinned buffers has run (long ago, normally)
+        host = []
+        for k, a in enumerate(item):
+            h = pinned(np.shape(a), k)
+            np.copyto(h.numpy(), a, casting='unsafe')        # uint8 / int -> int32, no intermediate array
+            host.append(h)
+        slot[0] += 1
         with torch.cuda.stream(stream):
             dev = [h.to(device, non_blocking=True) for h in host]
             done = torch.cuda.Event()
             done.record(stream)
-        inflight.append((dev[0], dev[1], done, host))           # `host` stays alive until the copy has been consumed
+        slot_done[(slot[0] - 1) % (depth + 2)] = done
+        inflight.append((dev[0], dev[1], done, host))
 
     for _ in range(depth):
         stage()

@@ -524,6 +524,11 @@ int ctgan_dropout_rng(const float* x, float* y, int64_t n, float keep, uint64_t 
  * y_masked = y where ref > 0, else 0.  x, ref, y, y_masked share one physical layout.                        */
 int ctgan_dropout_rng_mask(const float* x, const float* ref, float* y, float* y_masked, int64_t n, float keep, uint64_t seed,
                            uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t stream);
+/* LeakyReLU + dropout in one pass (TF/CT_gan_cifar.py:84-98, TF/CT_gan_mnist.py:92-100: `dropout(LeakyReLU(conv))`): y = x * (ref > 0 ? 1 :
+ * alpha) / keep * floor(keep + u_i), draws as ctgan_dropout_rng.  Forward: ref = x.  Backward (and its backward): x = the arriving gradient,
+ * ref = the forward result (kept values carry the pre-activation's sign, dropped ones are multiplied by 0).  One physical layout.     */
+int ctgan_lrelu_dropout_rng(const float* x, const float* ref, float* y, int64_t n, float alpha, float keep, uint64_t seed,
+                            uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t stream);
 int ctgan_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
                       float lo, float hi, ctgan_stream_t stream);
 int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,

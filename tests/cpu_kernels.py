@@ -245,6 +245,11 @@ def dropout_rng(x, keep, seed, stream_id, ctr):
 
 
 @_export
+def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr):
+    return dropout_rng(lrelu_bwd(x, ref, alpha), keep, seed, stream_id, ctr)
+
+
+@_export
 def dropout_rng_mask(x, ref, keep, seed, stream_id, ctr, want_dropped=True):
     y = dropout_rng(x, keep, seed, stream_id, ctr)
     return (y if want_dropped else None), lrelu_bwd(y, ref, 0.0)

@@ -159,3 +159,23 @@ def test_graphed_unconditional_trainer_equals_eager(which, dtype):
     finally:
         K.set_mma_dtype(None)
         M.configure(); lib.delete_all_params()
+
+
+def test_fused_lrelu_dropout_kernel_equals_the_separate_launches_bitwise():
+    """ctgan_lrelu_dropout_rng: dropout(LeakyReLU(x)) of the DCGAN critics (TF/CT_gan_cifar.py:84-98) in one launch - the same products in
+    the same order as ctgan_lrelu_fwd followed by ctgan_dropout_rng on the same Philox stream; its backward form (gradient in, forward
+    result as sign reference) equals dropout_rng followed by lrelu_bwd."""
+    import ctgan_amd.kernels as K
+    g = torch.Generator().manual_seed(6)
+    ctr = torch.tensor([9], dtype=torch.int64, device='cuda')
+    for shape in [(64, 128, 16, 16), (3, 7, 5, 5), (50, 64, 14, 14)]:
+        x = torch.randn(shape, generator=g).cuda()
+        gy = torch.randn(shape, generator=g).cuda()
+        y = K.lrelu_dropout_rng(x, x, 0.2, 0.5, 77, 3, ctr)
+        want = K.dropout_rng(K.lrelu_fwd(x, 0.2), 0.5, 77, 3, ctr)
+        assert torch.equal(y, want)
+        gx = K.lrelu_dropout_rng(gy, y, 0.2, 0.5, 77, 3, ctr)
+        want_g = K.lrelu_bwd(K.dropout_rng(gy, 0.5, 77, 3, ctr), K.lrelu_fwd(x, 0.2), 0.2)
+        # (kept positions: identical factors; the two orders of the same two multiplications may differ in the last bit)
+        assert torch.allclose(gx, want_g, rtol=2e-7, atol=0) and torch.equal(gx == 0, want_g == 0)
+        assert 0.4 < (y == 0).float().mean().item() < 0.6

@@ -164,3 +164,27 @@ def test_queued_weight_gradients_equal_immediate_ones_in_the_dcgan_family_steps(
                     _cmp(b, a, 2e-5, 'queued wgrad ' + n, atol=1e-7)
     finally:
         M.configure()
+
+
+def test_fused_lrelu_dropout_equals_the_two_ops_through_the_double_backward(cpu_kernels):
+    """F.lrelu_dropout (one launch each way) against dropout(leaky_relu(x)) on the same Philox stream: value, gradient, and the gradient
+    of a function of that gradient (the gradient penalty differentiates the critic twice; the pair is piecewise linear, so the second
+    derivative w.r.t. x is zero and the double backward reaches only the seed)."""
+    import ctgan_amd.functional as F
+    from ctgan_amd.rng import DeviceRNG
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(4, 8, 6, 6, generator=g)
+    res = []
+    for fused in (True, False):
+        rng = DeviceRNG(seed=11, device='cpu')
+        rng.begin_step()
+        x = x0.clone().requires_grad_(True)
+        w = torch.randn(x0.shape, generator=torch.Generator().manual_seed(3)).requires_grad_(True)
+        y = F.lrelu_dropout(x * w, 0.2, 0.5, rng) if fused else F.dropout(F.leaky_relu(x * w, 0.2), 0.5, rng=rng)
+        (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+        pen = (gx ** 2).sum()                       # a function of the first gradient, differentiated w.r.t. w
+        (gw,) = torch.autograd.grad(pen, w)
+        res.append((y.detach(), gx.detach(), gw))
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert 0.3 < (res[0][0] == 0).float().mean().item() < 0.7          # about half the values dropped
