@@ -26,6 +26,10 @@ import os as _os
 TRUNK_SHARE = _os.environ.get('CTGAN_UNCOND_TRUNK_SHARE', '1') != '0'
 
 
+# The fake batches of an iteration's critic steps from one generator forward (A/B switch; the ResNet trainer's BATCH_FAKES)
+BATCH_FAKES = _os.environ.get('CTGAN_DCGAN_BATCH_FAKES', '1') != '0'
+
+
 class DCGANTrainer:
     def __init__(self, module, seed=2024, rank=0, world_size=1, allreduce=None):
         """`module` = ctgan_amd.gan_cifar or ctgan_amd.gan_mnist (provides cfg, Generator, Discriminator,
@@ -58,11 +62,12 @@ class DCGANTrainer:
             self._seed_val = self.loss_scale
         return self._seed
 
-    def d_losses(self, real_in, rnd=None):
+    def d_losses(self, real_in, rnd=None, fake=None):
         m, cfg = self.mod, self.mod.cfg
         B = cfg.BATCH_SIZE
         with torch.no_grad():
-            fake = self._gen(B, rnd['z'] if rnd is not None else None)
+            if fake is None:        # `fake`: a batch drawn earlier from the same generator weights (generate_fakes)
+                fake = self._gen(B, rnd['z'] if rnd is not None else None)
             real = m.real_prep(real_in)
             alpha = rnd['alpha'] if rnd is not None else self.rng.uniform(B, 1)
             interp = K.interpolate(real, fake, alpha)
@@ -87,10 +92,22 @@ class DCGANTrainer:
         cost, wgan, ct, _, _ = F.critic_heads(d, f, None, None, B, cfg.LAMBDA_2, cfg.Factor_M, 0.0, gp)
         return {'cost': cost, 'wgan_only': wgan, 'ct': ct, 'gp': gp, 'fake': fake, 'slopes': slopes, 'gp_grads': grads}
 
-    def _gen(self, n, z):
-        if self.towers > 1:
-            return self.mod.Generator(n, noise=z, rng=self.rng, groups=self.towers)
+    def _gen(self, n, z, groups=1):
+        g = self.towers * groups
+        if g > 1:
+            return self.mod.Generator(n, noise=z, rng=self.rng, groups=g)
         return self.mod.Generator(n, noise=z, rng=self.rng)
+
+    def generate_fakes(self, n_steps):
+        """The fake batches of the next `n_steps` critic steps in ONE generator forward: the generator does not change between the critic
+        updates of an iteration (TF/CT_gan_cifar.py:190-204), each step's batch keeps its own BatchNorm statistic group(s).  A step of its
+        own in the Philox numbering (as gan_cifar_resnet.Trainer.generate_fakes)."""
+        B = self.mod.cfg.BATCH_SIZE
+        self.rng.begin_step()
+        with torch.no_grad():
+            fake = self._gen(n_steps * B, None, groups=n_steps)
+        self.rng.end_step()
+        return fake.reshape(n_steps, B, -1)
 
     def g_losses(self, rnd=None):
         m, B = self.mod, self.mod.cfg.BATCH_SIZE
@@ -116,9 +133,9 @@ class DCGANTrainer:
             return grads
         return [None if g is None else g / self.loss_scale for g in grads]
 
-    def d_step(self, real_in, rnd=None):
+    def d_step(self, real_in, rnd=None, fake=None):
         self.rng.begin_step()
-        out = self.d_losses(real_in, rnd)
+        out = self.d_losses(real_in, rnd, fake=fake)
         with F.deferred_wgrads():       # the queued weight gradients of the step: one grouped launch (functional._flush_groups)
             grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         self._apply(self.d_opt, grads)
@@ -139,6 +156,8 @@ class DCGANTrainer:
         if iteration > 0:
             self.g_step()
         out = None
-        for _ in range(self.mod.cfg.CRITIC_ITERS):
-            out = self.d_step(next_batch())
+        n = self.mod.cfg.CRITIC_ITERS
+        fakes = self.generate_fakes(n) if BATCH_FAKES else None
+        for i in range(n):
+            out = self.d_step(next_batch(), fake=None if fakes is None else fakes[i])
         return out

@@ -348,8 +348,15 @@ class GraphedDCGANTrainer:
     live in device memory, capture leaves no trace in them, Adam inside the graph when world == 1."""
 
     def __init__(self, trainer, real_shape, real_dtype, use_graphs=True, warmup=2):
+        from . import dcgan_step
         self.t = trainer
         self.real = torch.zeros(real_shape, dtype=real_dtype, device=trainer.dev)
+        # the fake batches of an iteration's critic steps come from ONE generator forward (a third graph, replayed once per iteration):
+        # the critic graph then neither runs the generator nor rebuilds its derived / packed filters five times per iteration
+        self.batch_fakes = dcgan_step.BATCH_FAKES
+        self.fake = torch.zeros(real_shape[0], trainer.mod.cfg.OUTPUT_DIM, dtype=torch.float32, device=trainer.dev) if self.batch_fakes else None
+        self.f_graph = None
+        self.fake_all = None
         self.adam_in_graph = trainer.world == 1
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
@@ -359,16 +366,24 @@ class GraphedDCGANTrainer:
                 self._capture(warmup)
             except Exception as e:
                 self.graph_error = '%s: %s' % (type(e).__name__, e)
-                self.d_graph = self.g_graph = None
+                self.d_graph = self.g_graph = self.f_graph = None
+                self.fake_all = None
                 torch.cuda.synchronize()
+
+    def _f_body(self):
+        lib.bump_epoch('Generator')       # runs after the generator update of the iteration
+        F.prepare_filters()
+        return self.t.generate_fakes(self.t.mod.cfg.CRITIC_ITERS)
 
     def _body(self, which):
         t = self.t
-        lib.bump_epoch()                 # weights changed since the last replay: derived / packed filters are rebuilt in-graph
+        # weights changed since the last replay: derived / packed filters are rebuilt in-graph - the critic's only in the critic graph
+        # when its fake batch is an input (the generator's are rebuilt by the fake-batch graph)
+        lib.bump_epoch('Discriminator' if (which == 'd' and self.batch_fakes) else None)
         F.prepare_filters()
         t.rng.begin_step()
         if which == 'd':
-            out = t.d_losses(self.real)
+            out = t.d_losses(self.real, fake=self.fake)
             params, opt = t.d_params, t.d_opt
         else:
             out = t.g_losses()
@@ -397,6 +412,8 @@ class GraphedDCGANTrainer:
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(warmup):
+                    if self.batch_fakes:
+                        self._f_body()
                     self._body('d')
                     self._body('g')
             torch.cuda.current_stream().wait_stream(s)
@@ -408,6 +425,10 @@ class GraphedDCGANTrainer:
             self.g_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_graph, **_capture_kw()):
                 self.g_out = self._body('g')
+            if self.batch_fakes:
+                self.f_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.f_graph, **_capture_kw()):
+                    self.fake_all = self._f_body()
         finally:
             torch.cuda.synchronize()
             for b, sn in zip(bufs, snap):
@@ -424,11 +445,15 @@ class GraphedDCGANTrainer:
         m = self.t.mod
         return m.lr(self.t.iteration) if hasattr(m, 'lr') else m.cfg.LR
 
-    def d_step(self, real_in):
+    def d_step(self, real_in, fake=None):
         t = self.t
         if not self.graphed:
-            return t.d_step(real_in)
+            return t.d_step(real_in, fake=fake)
         self.real.copy_(real_in, non_blocking=True)
+        if self.batch_fakes:
+            if fake is None:            # a stand-alone critic step: draw its fake batch now
+                fake = t.generate_fakes(1)[0]
+            self.fake.copy_(fake, non_blocking=True)
         t.d_opt.set_lr(self._lr())
         self.d_graph.replay()
         if self.adam_in_graph:
@@ -465,6 +490,14 @@ class GraphedDCGANTrainer:
         if iteration > 0:
             self.g_step()
         out = None
-        for _ in range(self.t.mod.cfg.CRITIC_ITERS):
-            out = self.d_step(next_batch())
+        n = self.t.mod.cfg.CRITIC_ITERS
+        fakes = None
+        if self.batch_fakes:
+            if self.graphed:
+                self.f_graph.replay()
+                fakes = self.fake_all
+            else:
+                fakes = self.t.generate_fakes(n)
+        for i in range(n):
+            out = self.d_step(next_batch(), fake=None if fakes is None else fakes[i])
         return out

@@ -51,18 +51,18 @@ def feat_shapes():
     return [(D, 16, 16), (2 * D, 8, 8), (4 * D, 4, 4)]
 
 
-def Generator(n_samples, noise=None, rng=None):
-    """:58-79"""
+def Generator(n_samples, noise=None, rng=None, groups=1):
+    """:58-79.  `groups` > 1 (build-only): that many generator calls in one batch, each with its own BatchNorm statistics."""
     D = cfg.DIM
     if noise is None:
         noise = rng.normal(n_samples, 128)
     output = _linear.Linear('Generator.Input', 128, 4 * 4 * 4 * D, noise)
-    output = _bn.Batchnorm('Generator.BN1', [0], output, relu=True)
+    output = _bn.Batchnorm('Generator.BN1', [0], output, relu=True, groups=groups)
     output = F.to_channels_last(output.reshape(-1, 4 * D, 4, 4))
     output = _deconv2d.Deconv2D('Generator.2', 4 * D, 2 * D, 5, output)
-    output = _bn.Batchnorm('Generator.BN2', [0, 2, 3], output, relu=True)
+    output = _bn.Batchnorm('Generator.BN2', [0, 2, 3], output, relu=True, groups=groups)
     output = _deconv2d.Deconv2D('Generator.3', 2 * D, D, 5, output)
-    output = _bn.Batchnorm('Generator.BN3', [0, 2, 3], output, relu=True)
+    output = _bn.Batchnorm('Generator.BN3', [0, 2, 3], output, relu=True, groups=groups)
     output = _deconv2d.Deconv2D('Generator.5', D, 3, 5, output)
     output = F.tanh(F.to_nchw(output))
     return output.reshape(-1, cfg.OUTPUT_DIM)

@@ -49,8 +49,8 @@ def feat_shapes():
     return [(D, 14, 14), (2 * D, 7, 7), (4 * D, 4, 4)]
 
 
-def Generator(n_samples, noise=None, rng=None):
-    """:62-87"""
+def Generator(n_samples, noise=None, rng=None, groups=1):
+    """:62-87  (`groups`: accepted for the batched fake draws of dcgan_step - this generator has no batch statistics.)"""
     D = cfg.DIM
     if noise is None:
         noise = rng.normal(n_samples, 128)
