@@ -12,6 +12,10 @@ using namespace ctgan_philox;
 __device__ __forceinline__ void adam_elem(float& th, float& m, float& v, float graw, float gscale, float b1, float b2, float eps, float lr_t) {
 #pragma clang fp contract(off)
     const float gi = graw * gscale;
+    // A gradient element that is not finite (an overflow of the fp16 matrix-core mode under its fixed loss scale; a degenerate input)
+    // leaves ITS weight and slots untouched: one inf would otherwise sit in m and v for good and turn theta into NaN - also at a learning
+    // rate of 0, as in the warm-up passes of a graph capture (0 * inf).  Finite gradients take the unchanged path.
+    if (!(fabsf(gi) <= 3.0e38f)) return;
     const float mi = b1 * m + (1.f - b1) * gi;
     const float vi = b2 * v + (1.f - b2) * gi * gi;
     m = mi; v = vi;

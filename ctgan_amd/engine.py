@@ -413,7 +413,7 @@ class GraphedDCGANTrainer:
             with torch.cuda.stream(s):
                 for _ in range(warmup):
                     if self.batch_fakes:
-                        self._f_body()
+                        self.fake.copy_(self._f_body()[0])      # (a real fake batch, not the zeros the static buffer starts with)
                     self._body('d')
                     self._body('g')
             torch.cuda.current_stream().wait_stream(s)

@@ -493,7 +493,9 @@ int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32
 /* ---- optimizer (K21): tf.train.AdamOptimizer on a flat buffer
  *      (TF/CT_gan_cifar_resnet.py:333-338).  `state` = device float[4]: {lr, beta1^t, beta2^t, _};
  *      the kernel reads lr and the running beta powers from it (graph-replay safe) and
- *      ctgan_adam_advance multiplies the powers after all buckets of a step are applied. ------ */
+ *      ctgan_adam_advance multiplies the powers after all buckets of a step are applied.  An element whose scaled gradient is not
+ *      finite (NaN / inf: an overflow of the fp16 matrix-core mode, a degenerate input) keeps its weight and slots unchanged - one
+ *      inf would otherwise poison m, v and theta for good, also at lr = 0 (build-only safeguard; TF would propagate it). ------ */
 int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, const float* state,
                     float beta1, float beta2, float eps, float grad_scale, ctgan_stream_t stream);
 int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t stream);

@@ -962,3 +962,27 @@ def test_conv_epilogue_reads_low_resolution_residual(K, N, H):
     assert 'igemm_fwd_pipe' in K.last_kernel()
     y_ref = K.conv_fwd(x, w, b, geom, resid=K.upsample2(r, 1.0), relu_in=True)
     assert torch.equal(y, y_ref)
+
+
+def test_adam_leaves_elements_with_a_non_finite_gradient_untouched():
+    """ctgan_adam_step / ctgan_adam_step_packed: an inf or NaN gradient element (fp16-mode overflow, degenerate warm-up input) must not
+    reach theta, m or v - not even at lr = 0, where 0 * inf = NaN; finite elements take the unchanged path (bit-identical)."""
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.optim import FlatAdam
+    lib.delete_all_params(); lib.set_device(None)
+    try:
+        p = lib.param('T.w', np.linspace(-1, 1, 64, dtype='float32'))
+        ref = lib.param('U.w', np.linspace(-1, 1, 64, dtype='float32'))
+        opt, opt_ref = FlatAdam([('T.w', p)], 0.5, 0.9), FlatAdam([('U.w', ref)], 0.5, 0.9)
+        g = torch.linspace(1, 2, 64, device='cuda')
+        bad = g.clone(); bad[3] = float('inf'); bad[10] = float('nan'); bad[40] = -float('inf')
+        for lr in (0.0, 1e-3):
+            opt.set_lr(lr); opt_ref.set_lr(lr)
+            opt.update([bad], 1.0); opt_ref.update([g], 1.0)
+        torch.cuda.synchronize()
+        ok = torch.ones(64, dtype=torch.bool, device='cuda'); ok[[3, 10, 40]] = False
+        assert torch.isfinite(opt.theta).all() and torch.isfinite(opt.m).all() and torch.isfinite(opt.v).all()
+        assert torch.equal(opt.theta[ok], opt_ref.theta[ok]) and torch.equal(opt.m[ok], opt_ref.m[ok])
+        assert torch.equal(opt.theta[~ok].cpu(), torch.linspace(-1, 1, 64)[~ok.cpu()]) and (opt.m[~ok] == 0).all() and (opt.v[~ok] == 0).all()
+    finally:
+        lib.delete_all_params()
