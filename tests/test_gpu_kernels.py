@@ -983,6 +983,7 @@ def test_adam_leaves_elements_with_a_non_finite_gradient_untouched():
         ok = torch.ones(64, dtype=torch.bool, device='cuda'); ok[[3, 10, 40]] = False
         assert torch.isfinite(opt.theta).all() and torch.isfinite(opt.m).all() and torch.isfinite(opt.v).all()
         assert torch.equal(opt.theta[ok], opt_ref.theta[ok]) and torch.equal(opt.m[ok], opt_ref.m[ok])
-        assert torch.equal(opt.theta[~ok].cpu(), torch.linspace(-1, 1, 64)[~ok.cpu()]) and (opt.m[~ok] == 0).all() and (opt.v[~ok] == 0).all()
+        init = torch.from_numpy(np.linspace(-1, 1, 64, dtype='float32'))
+        assert torch.equal(opt.theta[~ok].cpu(), init[~ok.cpu()]) and (opt.m[~ok] == 0).all() and (opt.v[~ok] == 0).all()
     finally:
         lib.delete_all_params()
