@@ -357,6 +357,14 @@ class GraphedDCGANTrainer:
         self.fake = torch.zeros(real_shape[0], trainer.mod.cfg.OUTPUT_DIM, dtype=torch.float32, device=trainer.dev) if self.batch_fakes else None
         self.f_graph = None
         self.fake_all = None
+        # ONE graph for a whole iteration (generator step, the fake batches, CRITIC_ITERS critic steps on rows of a static batch buffer),
+        # as GraphedTrainer's: seven graph launches and their input copies per iteration leave ~20 idle gaps of 8-20 us (rocprofv3,
+        # config[1]: 4 % of the iteration)
+        self.it_graph = None
+        self.it_out = None
+        self.it_graph_error = None
+        n_it = trainer.mod.cfg.CRITIC_ITERS
+        self.real_all = torch.zeros((n_it,) + tuple(real_shape), dtype=real_dtype, device=trainer.dev) if self.batch_fakes else None
         self.adam_in_graph = trainer.world == 1
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
@@ -366,16 +374,21 @@ class GraphedDCGANTrainer:
                 self._capture(warmup)
             except Exception as e:
                 self.graph_error = '%s: %s' % (type(e).__name__, e)
-                self.d_graph = self.g_graph = self.f_graph = None
-                self.fake_all = None
+                self.d_graph = self.g_graph = self.f_graph = self.it_graph = None
+                self.fake_all = self.it_out = None
                 torch.cuda.synchronize()
+
+    def _it_body(self):
+        g_out = self._body('g')
+        fakes = self._f_body()
+        return {'g': g_out, 'd': [self._body('d', self.real_all[i], fakes[i]) for i in range(self.t.mod.cfg.CRITIC_ITERS)]}
 
     def _f_body(self):
         lib.bump_epoch('Generator')       # runs after the generator update of the iteration
         F.prepare_filters()
         return self.t.generate_fakes(self.t.mod.cfg.CRITIC_ITERS)
 
-    def _body(self, which):
+    def _body(self, which, real=None, fake=None):
         t = self.t
         # weights changed since the last replay: derived / packed filters are rebuilt in-graph - the critic's only in the critic graph
         # when its fake batch is an input (the generator's are rebuilt by the fake-batch graph)
@@ -383,7 +396,7 @@ class GraphedDCGANTrainer:
         F.prepare_filters()
         t.rng.begin_step()
         if which == 'd':
-            out = t.d_losses(self.real, fake=self.fake)
+            out = t.d_losses(self.real if real is None else real, fake=self.fake if fake is None else fake)
             params, opt = t.d_params, t.d_opt
         else:
             out = t.g_losses()
@@ -429,6 +442,17 @@ class GraphedDCGANTrainer:
                 self.f_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.f_graph, **_capture_kw()):
                     self.fake_all = self._f_body()
+                if self.adam_in_graph and ITERATION_GRAPH:
+                    try:
+                        self.it_graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.it_graph, **_capture_kw()):
+                            self.it_out = self._it_body()
+                    except Exception as e:      # only this capture failed: the per-step graphs stay in use
+                        self.it_graph = self.it_out = None
+                        self.it_graph_error = '%s: %s' % (type(e).__name__, e)
+                        torch.cuda.synchronize()
+                        self.d_graph.replay(); self.g_graph.replay(); self.f_graph.replay()      # (still replayable; lr is 0 here)
+                        torch.cuda.synchronize()
         finally:
             torch.cuda.synchronize()
             for b, sn in zip(bufs, snap):
@@ -487,10 +511,22 @@ class GraphedDCGANTrainer:
     def train_iteration(self, iteration, next_batch):
         """[G step if it > 0] + CRITIC_ITERS x (batch, D step)  (TF/CT_gan_cifar.py:190-204)."""
         self.t.iteration = iteration
+        n = self.t.mod.cfg.CRITIC_ITERS
+        if self.it_graph is not None and iteration > 0:
+            t = self.t
+            for i in range(n):
+                self.real_all[i].copy_(next_batch(), non_blocking=True)
+            lr = self._lr()
+            t.d_opt.set_lr(lr); t.g_opt.set_lr(lr)
+            self.it_graph.replay()
+            t.g_opt.t += 1
+            t.d_opt.t += n
+            lib.bump_epoch()
+            self.g_out = self.it_out['g']
+            return self.it_out['d'][-1]
         if iteration > 0:
             self.g_step()
         out = None
-        n = self.t.mod.cfg.CRITIC_ITERS
         fakes = None
         if self.batch_fakes:
             if self.graphed:
