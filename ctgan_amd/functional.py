@@ -201,7 +201,7 @@ def _like_first(t, ref):
 def _wgrad(x, gy, w, g, relu_x, with_bias):
     """Weight (and bias) gradient of one use of filter `w`: launched now, or queued (see deferred_wgrads).
     Returns (gw, gb); either may be None when another request of the same filter already owns the result."""
-    stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _SPREAD_BUFS     # same identity in every pass of the step
+    stable = isinstance(w, torch.nn.Parameter) or w.data_ptr() in _SPREAD_BUFS or w.data_ptr() in _QUEUEABLE_GEMM     # same identity in every pass of the step
     fewch = K.fewch_handles(g)                    # few-channel convs: the direct kernel sums two uses in one launch
     gk = (g.C, g.H, g.W, g.K, g.R, g.S, g.stride)
     key = (w.data_ptr(), gk)       # (w: a registry parameter or a cached derived filter - persistent tensors, their addresses are stable)
@@ -685,6 +685,82 @@ class Col2imFn(Function):
         return Im2colFn.apply(gx, ctx.g, ctx.cpad), None, None, None
 
 
+# The GEMM filters of the few-channel routes - the first critic conv of the DCGAN scripts as im2col + 1x1 conv (TF/CT_gan_cifar.py:84), the
+# image-producing Deconv2D as 1x1 conv + col2im (:76) - are reshapes of a registry parameter, zero-padded to a multiple of 32 rows /
+# columns.  Built per CALL (reshape, cat with a fresh zero block, contiguous) they cost three launches per use plus a 16-bit pack per use
+# (a temporary is not cacheable): 40-50 launches per iteration of config[1].  Kept in a buffer per (parameter, layout) instead, refreshed by
+# one copy when the parameter's network was updated; the buffer's address is stable, so its packed image is cached per weight version and
+# its weight gradients can be queued per filter.
+_GEMM_FILTERS = {}        # (param data_ptr, kind, pad) -> [buffer, epoch, group, param]
+_QUEUEABLE_GEMM = set()   # addresses of the 'cols' buffers: their weight gradient maps back to the parameter's by a VIEW, so it may be queued
+
+
+def _clear_gemm_filters():
+    K._STABLE_PTRS.difference_update(e[0].data_ptr() for e in _GEMM_FILTERS.values())
+    for e in _GEMM_FILTERS.values():
+        K._STABLE_GROUP.pop(e[0].data_ptr(), None)
+    _QUEUEABLE_GEMM.clear()
+    _GEMM_FILTERS.clear()
+
+
+class GemmFilterFn(Function):
+    """kind 'cols': w [R,S,C,K] -> [R*S*C padded to `pad`, K] (rows of zeros appended); kind 'taps': w [R,S,Co,Ci] -> [Ci, R*S*Co padded to
+    `pad`] (the transposed-conv filter as Ci -> (tap, channel) columns).  Linear; the adjoint slices / transposes the gradient back."""
+
+    @staticmethod
+    def forward(ctx, w, kind, pad):
+        from . import tflib as lib
+        ctx.kind, ctx.shape = kind, tuple(w.shape)
+        # the weight gradient of this buffer is queued per filter (deferred_wgrads): the first use returns the result buffer - a VIEW of
+        # it goes on to the parameter, filled when the queue is flushed - and later uses return None, which must stay None (a materialised
+        # zero would be added to the still empty buffer at once)
+        ctx.set_materialize_grads(False)
+        rows = w.shape[0] * w.shape[1] * w.shape[2]
+        key = (w.data_ptr(), kind, pad)
+        e = _GEMM_FILTERS.get(key)
+        if e is None:
+            if not _GEMM_FILTERS:
+                lib.on_delete_all_params(_clear_gemm_filters)
+            shape = (pad, w.shape[3]) if kind == 'cols' else (w.shape[3], pad)
+            e = [torch.zeros(shape, dtype=torch.float32, device=w.device), None, lib.group_of(w), w]
+            _GEMM_FILTERS[key] = e
+            K._STABLE_PTRS.add(e[0].data_ptr())
+            K._STABLE_GROUP[e[0].data_ptr()] = e[2]
+            if kind == 'cols':
+                _QUEUEABLE_GEMM.add(e[0].data_ptr())
+        ver = lib.epoch(e[2])
+        if e[1] != ver:
+            src = w.detach().reshape(rows, w.shape[3])
+            if kind == 'cols':
+                e[0][:rows].copy_(src)
+            else:
+                e[0][:, :rows].copy_(src.t())
+            e[1] = ver
+        return e[0].view(e[0].shape)          # a fresh tensor object per call (autograd attaches this node to it), same storage
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        R, S, C, Kk = ctx.shape
+        rows = R * S * C
+        if ctx.kind == 'cols':
+            return g.reshape(-1, Kk)[:rows].reshape(ctx.shape), None, None
+        return g.reshape(Kk, -1)[:, :rows].t().reshape(ctx.shape), None, None
+
+
+def _gemm_filter(w, kind, pad):
+    """The padded GEMM filter of a few-channel route: cached for registry parameters, built per call for anything else."""
+    rows = w.shape[0] * w.shape[1] * w.shape[2]
+    if isinstance(w, torch.nn.Parameter):
+        return GemmFilterFn.apply(w, kind, pad)
+    w2 = w.reshape(rows, w.shape[3])
+    if kind == 'cols':
+        return torch.cat([w2, w2.new_zeros(pad - rows, w.shape[3])], 0) if pad > rows else w2
+    w2 = w2.t()
+    return (torch.cat([w2, w2.new_zeros(w.shape[3], pad - rows)], 1) if pad > rows else w2).contiguous()
+
+
 def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_in=False, pool=False, fork=False, epi=None):
     """TF-SAME conv on a logical NCHW tensor (any strides) with HWIO filter `w`.
     relu_in=True computes conv(relu(x)) without materialising relu(x); pool=True returns
@@ -719,9 +795,7 @@ def conv2d(x, w, b=None, stride=1, resid=None, x_up=False, out_nchw=False, relu_
         g = ConvGeom(C, H, W, Kout, R, S, stride, False)
         cpad = -(-(R * S * C) // 32) * 32
         cols = Im2colFn.apply(x, g, cpad)
-        w2 = w.reshape(R * S * C, Kout)
-        if cpad > R * S * C:
-            w2 = torch.cat([w2, w2.new_zeros(cpad - R * S * C, Kout)], 0)
+        w2 = _gemm_filter(w, 'cols', cpad)
         if relu_in:
             x = relu(x)
             cols = Im2colFn.apply(x, g, cpad)
@@ -754,10 +828,8 @@ def conv2d_transpose(x, w_hwoi, b=None, stride=2):
         # adjoint of im2col (col2im) sums the overlapping taps: no wasted MACs, no dilation zeros.
         rsc = R * S * Cout
         cpad = -(-rsc // 32) * 32
-        w2 = w_hwoi.reshape(rsc, Cin).t()
-        if cpad > rsc:
-            w2 = torch.cat([w2, w2.new_zeros(Cin, cpad - rsc)], 1)
-        cols = conv2d(x, w2.contiguous().view(1, 1, Cin, cpad))
+        w2 = _gemm_filter(w_hwoi, 'taps', cpad)
+        cols = conv2d(x, w2.view(1, 1, Cin, cpad))
         y = Col2imFn.apply(cols, g, N, None)
         if b is not None:
             y = ChannelAffineFn.apply(y, torch.ones_like(b), b)

@@ -249,12 +249,12 @@ def test_deferred_multi_segment_wgrads_equal_immediate_wgrads(cpu_kernels):
         R.configure()
 
 
-@pytest.mark.parametrize('min_px', [1, 2048, 5000])
+@pytest.mark.parametrize('min_px', [1, 2048, 20000])
 def test_split_mode_wgrads_written_in_place_equal_immediate_wgrads(cpu_kernels, monkeypatch, min_px):
     """functional._wgrad with uses the split-mode kernel takes at request time (kernels.wgrad_prefers_x3): the FIRST such use of a
     filter writes straight into the filter's result buffers (bias gradient included), the queued fp32 segments are accumulated onto
     it inside the grouped reduction (ctgan_wgrad_group.add_dw / add_db aliasing dw / db), further uses are added at the flush.  For
-    every routing threshold - everything in place (1 pixel), main pass in place + GP segment queued (2048), nothing (5000) - the
+    every routing threshold - everything in place (1 pixel), main pass in place + GP segment queued (2048), nothing (20000: more pixels than any use has) - the
     parameter gradients of a full critic step must equal the immediate path's."""
     import ctgan_amd.functional as F
     import ctgan_amd.gan_cifar_resnet as R
