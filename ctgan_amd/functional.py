@@ -567,6 +567,8 @@ def prepare_filters():
     if todo:
         K.filter_batch([e.job() for e in todo])
         _mark_built(todo)
+    for key, e in _GEMM_FILTERS.items():      # before the packs: a packed image is built from the buffer's CURRENT contents
+        _refresh_gemm_filter(key, e)
     if (todo or K._pack16) and (K.MMA_DTYPE is not None or K.X3_HYBRID):       # no 16-bit / split-mode launch can be routed otherwise
         K.prepare_packs()                 # the 16-bit / split-mode images of the parameters and of the filters just rebuilt: one launch
 
@@ -703,6 +705,21 @@ def _clear_gemm_filters():
     _GEMM_FILTERS.clear()
 
 
+def _refresh_gemm_filter(key, e):
+    from . import tflib as lib
+    ver = lib.epoch(e[2])
+    if e[1] == ver:
+        return
+    w, kind = e[3], key[1]
+    rows = w.shape[0] * w.shape[1] * w.shape[2]
+    src = w.detach().reshape(rows, w.shape[3])
+    if kind == 'cols':
+        e[0][:rows].copy_(src)
+    else:
+        e[0][:, :rows].copy_(src.t())
+    e[1] = ver
+
+
 class GemmFilterFn(Function):
     """kind 'cols': w [R,S,C,K] -> [R*S*C padded to `pad`, K] (rows of zeros appended); kind 'taps': w [R,S,Co,Ci] -> [Ci, R*S*Co padded to
     `pad`] (the transposed-conv filter as Ci -> (tap, channel) columns).  Linear; the adjoint slices / transposes the gradient back."""
@@ -728,14 +745,7 @@ class GemmFilterFn(Function):
             K._STABLE_GROUP[e[0].data_ptr()] = e[2]
             if kind == 'cols':
                 _QUEUEABLE_GEMM.add(e[0].data_ptr())
-        ver = lib.epoch(e[2])
-        if e[1] != ver:
-            src = w.detach().reshape(rows, w.shape[3])
-            if kind == 'cols':
-                e[0][:rows].copy_(src)
-            else:
-                e[0][:, :rows].copy_(src.t())
-            e[1] = ver
+        _refresh_gemm_filter(key, e)
         return e[0].view(e[0].shape)          # a fresh tensor object per call (autograd attaches this node to it), same storage
 
     @staticmethod
