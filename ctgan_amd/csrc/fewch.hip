@@ -670,8 +670,7 @@ int pick_band(int N, int rows, int unit) {         // rows per workgroup: >= ~51
 
 // ---- host entry points (called from igemm.hip's C-ABI functions) -------------------------------------------
 bool ctgan_fewch_handles(const ctgan_conv_desc* d) {
-    static const bool off = [] { const char* e = getenv("CTGAN_FEWCH"); return e && atoi(e) == 0; }();
-    if (off || d->x_up) return false;
+    if (d->x_up) return false;
     if (d->C <= 4 && tap_case(d->R, d->S, d->C) && many_ok(d->K)) return true;                       // few -> many
     if (d->K <= 4 && d->stride == 1 && tap_case(d->R, d->S, d->K) && many_ok(d->C)) return true;     // many -> few
     return false;
@@ -695,8 +694,7 @@ static int launch_f2m(const F2MParams& p, int R, int S, int CS, hipStream_t st) 
 }
 
 static bool m2f_ring_ok(const M2FParams& p, int R, int S) {
-    static const bool off = [] { const char* e = getenv("CTGAN_M2F_RING"); return e && atoi(e) == 0; }();
-    return !off && R == 3 && S == 3 && p.CM == 128 && p.pad_t == 1 && p.pad_l == 1 && (p.W == 32 || p.W == 16) && p.P == p.H && p.Q == p.W &&
+    return R == 3 && S == 3 && p.CM == 128 && p.pad_t == 1 && p.pad_l == 1 && (p.W == 32 || p.W == 16) && p.P == p.H && p.Q == p.W &&
            (p.xs_w % 4 == 0) && (p.xs_h % 4 == 0) && (p.xs_n % 4 == 0);
 }
 
@@ -872,7 +870,7 @@ int ctgan_fewch_wgrad2(const ctgan_conv_desc* d0, const float* x, const float* d
     if (smem > 150 * 1024) return 0;
     int rc = 0;
     const dim3 grid(blocks), blk(NT);
-    static const int use_mfma = [] { const char* e = getenv("CTGAN_FW_MFMA"); return e ? atoi(e) : 1; }();
+    const int use_mfma = 1;
     const size_t red_mfma = (size_t)(3 * 64 * 64 + 3 * 64) * sizeof(float);
     const size_t smem_m = tile_b > red_mfma ? tile_b : red_mfma;
     if (use_mfma && p.CM == 128 && (p.MW & 1) == 0 && smem_m <= 150 * 1024) {

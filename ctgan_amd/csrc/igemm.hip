@@ -791,8 +791,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void igemm_wgrad_kernel(con
     const int nk = (k_end - k_begin + BK - 1) / BK;
     const int PQ = g.P * g.Q;
 
-    const bool pow2 = ((PQ & (PQ - 1)) | (g.Q & (g.Q - 1))) == 0;      // the per-pixel table is filled by one wave: keep it short
-    const int pq_sh = __builtin_ctz(PQ), q_sh = __builtin_ctz(g.Q);
     auto fill_ptab = [&](int kt) {
         if (tid < BK) {
             const int buf = kt & 1, px = k_begin + kt * BK + tid;
@@ -1221,8 +1219,7 @@ __global__ void repack_dgrad_phase_filter_kernel(const float* __restrict__ w, fl
 
 // shape-only rule shared by the repack, the workspace query and the launcher
 inline bool dgrad_phase_mode(const ctgan_conv_desc* d) {
-    static const bool off = [] { const char* e = getenv("CTGAN_DGRAD_PHASES"); return e && atoi(e) == 0; }();
-    return !off && d->stride == 2 && !(d->H & 1) && !(d->W & 1) && (d->C % 4 == 0) && (d->K % 32 == 0) &&
+    return d->stride == 2 && !(d->H & 1) && !(d->W & 1) && (d->C % 4 == 0) && (d->K % 32 == 0) &&
            d->P * 2 == d->H && d->Q * 2 == d->W;
 }
 inline size_t dgrad_filter_elems(const ctgan_conv_desc* d) {
@@ -1292,9 +1289,8 @@ int launch_fwd_pipe(const FwdParams& p, hipStream_t st) {
 int dispatch_fwd_pipe(const FwdParams& p, hipStream_t st) {
     // Work per launch in units of 32x32 output tiles; 1024 SIMDs want >= 1024 waves of work.
     const long long M = p.M;
-    static const int force = [] { const char* e = getenv("CTGAN_FWD_CFG"); return e ? atoi(e) : 0; }();
-    int cfg = force;
-    if (!cfg) {
+    int cfg = 0;
+    {
         // measured on MI355X (tools/cfg_sweep.py, 128->128 3x3): the best tile shrinks with the number of
         // output rows so that >= ~1024 waves exist; the register ring depth RD bought nothing (kept at 1)
         const long long rows = M * (p.phases > 1 ? p.phases : 1) * ((p.Ng + 127) / 128);
@@ -1337,7 +1333,7 @@ int run_fwd(const FwdParams& p0, hipStream_t st) {
     FwdParams p = p0;
     const Geom& g = p.g;
     p.d_lin = (p.phases <= 1) && (p.ds_p == (long long)g.Q * p.ds_q) && (p.ds_n == (long long)g.P * g.Q * p.ds_q);
-    { const char* e = getenv("CTGAN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = 0;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     p.d_vec = !(p.dbg & 32) && p.ds_k == 1 && (p.Ng % 4 == 0) && (p.ds_n % 4 == 0) && (p.ds_p % 4 == 0) && (p.ds_q % 4 == 0) &&
               (p.phases <= 1 || ((p.ph_d_h % 4 == 0) && (p.ph_d_w % 4 == 0))) && al16(p.D) && al16(p.mask) && al16(p.resid) &&

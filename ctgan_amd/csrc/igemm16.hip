@@ -1345,8 +1345,7 @@ __global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const P16 p
 // K split of a forward / data-gradient launch whose pixel x kout tiles cannot fill the chip (8x8 / 4x4 layers at batch 64:
 // 1024 pixels x 512 kout = 128 tiles of 64x64 for K = 6400).  Returns the split count for `blocks` tiles and `nk` slices.
 int conv16_ksplit(long long blocks, int nk) {
-    static const int off = [] { const char* e = getenv("CTGAN_CONV16_KSPLIT"); return e && atoi(e) == 0; }();
-    if (off || blocks >= 256 || nk < 32) return 1;
+    if (blocks >= 256 || nk < 32) return 1;
     int s = (int)(512 / blocks);
     if (s > 8) s = 8;
     while (s > 1 && nk / s < 12) --s;
@@ -1408,8 +1407,6 @@ bool conv16x3h_ok(const P16& p, PatchGeom* out, int bmp = 128) {
 // 177 / 186-188 / 169-175 (64 rows: 95 / 144 / 150); 8x8 images 50-76 / 83-117 / 108-127 - the first that qualifies with >= 192 tiles,
 // else the first that qualifies.  0: no tile shape qualifies.
 int conv16x3hf_tile(const P16& p) {
-    static const int force = [] { const char* e = getenv("CTGAN_X3_HF_TILE"); return e ? atoi(e) : 0; }();
-    if (force && conv16x3h_ok(p, nullptr, force)) return force;
     static const int pref_big[3] = {128, 64, 32}, pref_16[3] = {64, 128, 32}, pref_8[3] = {32, 64, 128};
     const int PQ = p.P * p.Q;
     const int* pref = PQ >= 1024 ? pref_big : (PQ >= 256 ? pref_16 : pref_8);
@@ -1426,7 +1423,7 @@ int conv16x3hf_tile(const P16& p) {
 // (768 workgroups of 15 KB LDS and 159 registers for the 384-row shared forward: three per CU, all co-resident, three waves per SIMD -
 // where 128-pixel tiles gave 192 workgroups for 256 CUs); 0 = round 2: only the 384-row launches, on the LDS-staged halo kernel.
 // Measured on one box: 15.69 vs 16.08 ms per iteration (64-pixel x 64-kout tiles with waves 2 x 2: the same 15.69 - dropped).
-int x3_8x8_mode() { static const int v = [] { const char* e = getenv("CTGAN_X3_8X8"); return e ? atoi(e) : 1; }(); return v; }
+int x3_8x8_mode() { return 1; }
 // Which launches the hybrid routing hands to the fragment-streaming kernel (tools/conv16_bench.py on the headline's layers,
 // profiles/r03_conv_bench_*.txt, profiles/r03_hf_tile_sweep_*.txt; fp32 family for comparison: 112-129 on 32x32 / 16x16 images at 128-320 rows,
 // 103 at (64, 16x16), 69 / 89 / 94 / 104 at 8x8 images of 64 / 128 / 192 / 384 rows): every launch whose preferred tile yields >= 192 workgroups on
@@ -1437,15 +1434,14 @@ bool conv16x3hf_wins(const P16& p) {
     const long long tiles = (long long)(p.M / bmp) * (p.Ng / 128);
     const int PQ = p.P * p.Q;
     if (PQ >= 256) return tiles >= 192;
-    static const int min_tiles = [] { const char* e = getenv("CTGAN_X3_8X8_MIN_TILES"); return e ? atoi(e) : 256; }();     // 256 = from 128 rows: 15.50 vs 15.65 ms per iteration on one box (384: round-3 mid-state; 128 = 64 rows: 15.79)
+    const int min_tiles = 256;     // 256 = from 128 rows: 15.50 vs 15.65 ms per iteration on one box (384: round-3 mid-state; 128 = 64 rows: 15.79)
     return PQ == 64 && x3_8x8_mode() == 1 && bmp == 32 && tiles >= min_tiles;
 }
 // CTGAN_X3_HALO_V=1: the filter through an LDS stage (conv16x3h_kernel, 128-pixel tiles only); default 2: filter fragments streamed
 // from L2 (conv16x3hf_kernel, 128- / 64- / 32-pixel tiles)
 int g_halo_version_override = 0;      // tests: ctgan_debug_x3_halo_version
 int halo_version() {
-    static const int v = [] { const char* e = getenv("CTGAN_X3_HALO_V"); return e ? atoi(e) : 2; }();
-    return g_halo_version_override ? g_halo_version_override : v;
+    return g_halo_version_override ? g_halo_version_override : 2;
 }
 bool conv16x3hf_usable(const P16& p) { return halo_version() != 1 && p.Wf != nullptr && conv16x3hf_tile(p) > 0; }
 
@@ -1530,8 +1526,8 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
     if constexpr (planes<MMA>() == 3) {
         // split mode: stride-1 whole-row tiles go to the halo-patch kernel; everything else to the slice kernels with three planes per
         // operand in LDS - 32-deep slices, the 128x128 tile with ONE 60 KB stage (two workgroups per CU)
-        static const int halo = [] { const char* e = getenv("CTGAN_X3_HALO"); return e ? atoi(e) : 1; }();      // 2: also for launches of few tiles (tests)
-        if (halo && halo_takes(p)) {
+        const int halo = 1;
+        if (halo_takes(p)) {
             const int bmp = conv16x3hf_usable(p) ? conv16x3hf_tile(p) : 128;
             if (!small || halo == 2 || (bmp < 128 && (long long)(p.M / bmp) * (p.Ng / 128) >= 96)) return launch_conv16x3h(p, st);
         }
@@ -1540,7 +1536,7 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
             // launches whose 128x128 tiles leave workgroup slots empty (< 512: the stride-2 layers at 128-192 rows have 256-384) run on
             // 128-kout x 64-pixel tiles, 46 KB of LDS and 112 registers: three workgroups per CU.  Measured (one box): (192, 32x32, 4x4 s2)
             // forward 144 -> 152, (192, 16x16) data gradient 125 -> 135 TFLOP/s, iteration 16.13 -> 16.02 ms.  CTGAN_X3_SLICE64=0: off, 2: always.
-            static const int s64 = [] { const char* e = getenv("CTGAN_X3_SLICE64"); return e ? atoi(e) : 1; }();
+            const int s64 = 1;
             const long long t128 = (long long)p.nph * ((p.M + 127) / 128) * (p.Ng / 128);
             if (s64 && p.Ng % 128 == 0 && (s64 == 2 || t128 < 512)) return launch_conv16<MMA, 2, 1, 32>(p, st, "conv16x3<128x64,k32>");
         }
@@ -1553,7 +1549,7 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
         {
             // launches whose 128x128 tiles leave workgroup slots empty (< 512) on 128-kout x 64-pixel tiles: config[1] 7.90 -> 7.82 ms per
             // iteration, config[4] unchanged (170.9 vs 170.4-171.1).  CTGAN_CONV16_TILE64=0: off.
-            static const int t64 = [] { const char* e = getenv("CTGAN_CONV16_TILE64"); return e ? atoi(e) : 1; }();
+            const int t64 = 1;
             const long long t128 = (long long)p.nph * ((p.M + 127) / 128) * (p.Ng / 128);
             if (t64 && p.Ng % 128 == 0 && t128 < 512) return launch_conv16<MMA, 2, 1, 64>(p, st, "conv16<128x64,k64>");
         }
@@ -1598,7 +1594,7 @@ WPlan16 wgrad16_plan(const ctgan_conv_desc* d, int mma) {
     WPlan16 w;
     w.bmc = d->C % 128 == 0 ? 128 : 64;
     w.bnk = d->K % 128 == 0 ? 128 : 64;
-    static const int wide_env = [] { const char* e = getenv("CTGAN_WGRAD16_WIDE"); return e ? atoi(e) : 2; }();
+    const int wide_env = 2;
     const int wide = mma == CTGAN_MMA_F32X3 ? 0 : wide_env;
     const int pq = d->P * d->Q;
     // 4x2 accumulators per wave (256 x 128): 0.75 operand bytes per MFMA of the 128x128 tile
@@ -1658,10 +1654,7 @@ int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     return (shape_ok_wgrad(d) && (mma != CTGAN_MMA_F32X3 || shape_ok_wgrad_x3(d))) ? 1 : 0;
 }
 
-static long long x3_wgrad_min_pixels() {      // CTGAN_X3_WGRAD_MIN: experiment switch for the routing threshold of weight gradients
-    static const long long v = [] { const char* e = getenv("CTGAN_X3_WGRAD_MIN"); return e ? atoll(e) : 32768LL; }();
-    return v;
-}
+static long long x3_wgrad_min_pixels() { return 32768LL; }      // routing threshold of weight gradients launched at request time
 
 int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
     // 1 for the launches on which CTGAN_MMA_F32X3 is measured faster than the fp32 MFMA family (tools/conv16_bench.py): stride-1 layers
@@ -2033,7 +2026,7 @@ void group16_plan(const ctgan_wgrad_group* groups, int n, int mma, G16Plan* plan
         ++nrest;
         for (int k = 0; k < groups[i].nseg; ++k) { const int kg = groups[i].Ns[k] * groups[i].d.P * groups[i].d.Q; if (kg > max_kg) max_kg = kg; }
     }
-    static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_GROUP_CHUNK"); return e ? atoi(e) : 0; }();
+    const int forced = 0;
     for (int chunk = 256; nrest && chunk <= 8192; chunk += 64) {
         if (forced && chunk != forced) continue;
         long long blocks = 0;

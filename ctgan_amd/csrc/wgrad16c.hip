@@ -456,8 +456,7 @@ int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d) {
 // simulated schedule on 256 CUs (most expensive first, as the launch orders them) plus the slab traffic the plan causes.  Deterministic: a
 // function of the geometries and row counts only (the workspace query and the launch must agree).
 void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks) {
-    static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_COL_CHUNK"); return e ? atoi(e) : 0; }();
-    static const bool log = getenv("CTGAN_WGRAD16_COL_LOG") != nullptr;
+    static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_COL_CHUNK"); return e ? atoi(e) : 0; }();      // (tools/wgrad_group_bench.py: chunk sweep)
     std::vector<ColGeom> geoms(n);
     std::vector<int> mt(n, 1), kg(n);
     for (int i = 0; i < n; ++i) {
@@ -499,7 +498,6 @@ void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks) {
             }
         const double t = makespan + slab_bytes * 2. / 3.0e6;      // slabs written, then read by the reduction: ~3 TB/s each way
         if (t < best_t * 0.995) { best_t = t; for (int i = 0; i < n; ++i) chunks[i] = cur[i]; }
-        if (log) fprintf(stderr, "wgrad16c plan: T %.0f us -> makespan %.1f us + slabs %.1f MB = %.1f us%s\n", T, makespan, slab_bytes / 1e6, t, t == best_t ? " *" : "");
         if (forced) break;
     }
 }

@@ -41,7 +41,7 @@ def case(op, N, C, H, Ko, R, st, relu=False):
                  'flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg}
 
 
-case('fwd', 192, 128, 32, 128, 3, 1, relu=False)      # conv16x3hf_kernel<false, 4> (CTGAN_X3_HALO_V=1: conv16x3h_kernel<false>)
+case('fwd', 192, 128, 32, 128, 3, 1, relu=False)      # conv16x3hf_kernel<false, 4>
 case('fwd', 192, 128, 16, 128, 3, 1, relu=True)       # conv16x3hf_kernel<true, 2>: 16x16 images on 64-pixel tiles (the critic's relu-on-load convs)
 case('fwd', 384, 128, 8, 128, 3, 1, relu=True)        # conv16x3hf_kernel<true, 1>: the 384-row shared tail forward on 32-pixel tiles
 case('dgrad', 192, 128, 8, 128, 3, 1)                 # conv16x3hf_kernel<false, 1>: the main pass's 8x8 data gradients
