@@ -1912,9 +1912,23 @@ int ctgan_conv2d16_dgrad_ex(const ctgan_conv_desc* d, int mma, const float* dy, 
     return run_conv16(mma, p, st);
 }
 
+// A single weight gradient on the filter-column kernel (wgrad16c.hip) where it takes the geometry: its pixels per split, 0 otherwise.
+static int wgrad16_col_chunk(const ctgan_conv_desc* d, int mma) {
+    if (!ctgan_wgrad16c_takes(d, mma, d->N)) return 0;
+    ctgan_wc_problem w{};
+    w.d = d; w.N = d->N;
+    int chunk = 0;
+    ctgan_wgrad16c_plan(&w, 1, mma, &chunk);
+    return chunk;
+}
+
 size_t ctgan_conv2d16_wgrad_workspace_bytes(const ctgan_conv_desc* d, int mma) {
     // (sized for the bias row as well: with db the partial sums always go through the slabs, also when the plan has one split)
     if (!d || !ctgan_conv2d16_supported(d, CTGAN_CONV_WGRAD, mma)) return 0;
+    if (const int chunk = wgrad16_col_chunk(d, mma)) {
+        const int Kg = d->N * d->P * d->Q;
+        return (size_t)((Kg + chunk - 1) / chunk) * ((size_t)d->R * d->S * d->C + 1) * d->K * sizeof(float);
+    }
     const WPlan16 w = wgrad16_plan(d, mma);
     return (size_t)w.splits * ((size_t)d->R * d->S * d->C + 1) * d->K * sizeof(float);
 }
@@ -1934,6 +1948,26 @@ int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x,
     const long long y_extent = (long long)d->N * d->P * d->Q * d->K;
     if (x_extent * 4 >= (1LL << 32) || y_extent * 4 >= (1LL << 32))
         return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_wgrad: operand exceeds the 4 GiB buffer range");
+    hipStream_t st = (hipStream_t)stream;
+    if (const int chunk = wgrad16_col_chunk(d, mma)) {
+        // the filter-column kernel: always through slabs ([splits][R*S*C (+1)][K]) and the fixed-order reduction
+        const int Kg = d->N * d->P * d->Q, splits = (Kg + chunk - 1) / chunk;
+        const size_t rows = (size_t)d->R * d->S * d->C + (db ? 1 : 0);
+        const size_t need = (size_t)splits * rows * d->K * sizeof(float);
+        if (need > ws_bytes || !ws) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_wgrad: workspace %zu B < %zu B", ws_bytes, need);
+        if (!(flags & CTGAN_WGRAD16_REDUCE_ONLY)) {
+            ctgan_wc_problem w{};
+            w.d = d; w.x = x; w.dy = dy; w.out = (float*)ws; w.N = d->N; w.relu_x = (flags & CTGAN_IN_RELU) ? 1 : 0; w.with_bias = db ? 1 : 0; w.chunk = chunk;
+            const int rc = ctgan_wgrad16c_launch(&w, 1, mma, st);
+            if (rc) return rc;
+        }
+        if (!(flags & CTGAN_WGRAD16_GEMM_ONLY)) {
+            const long long n_main = (long long)d->R * d->S * d->C * d->K, n = n_main + (db ? d->K : 0);
+            hipLaunchKernelGGL(reduce16_kernel, dim3(ctgan_blocks(n / 4, 256, 1 << 20)), dim3(256), 0, st, (const float*)ws, dw, db ? db : dw, n, n_main, splits);
+            return ctgan_check_launch("reduce16");
+        }
+        return 0;
+    }
     const WPlan16 w = wgrad16_plan(d, mma);
     const bool slabs = w.splits > 1 || db;
     const size_t need = slabs ? (size_t)w.splits * ((size_t)d->R * d->S * d->C + (db ? 1 : 0)) * d->K * sizeof(float) : 0;
@@ -1953,7 +1987,6 @@ int ctgan_conv2d16_wgrad_bias(const ctgan_conv_desc* d, int mma, const float* x,
         p.q_shift = pow2 ? __builtin_ctz(d->Q) : -1;
     }
     p.x_bytes = (unsigned)(x_extent * 4); p.dy_bytes = (unsigned)(y_extent * 4);
-    hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     const bool bf = mma == CTGAN_MMA_BF16;
     if (flags & CTGAN_WGRAD16_REDUCE_ONLY) { /* the slabs are already in ws (bench.py times the two launches apart) */ }
@@ -2016,7 +2049,7 @@ void group16_plan(const ctgan_wgrad_group* groups, int n, int mma, G16Plan* plan
         if (!plan->col[i]) continue;
         for (int k = 0; k < groups[i].nseg; ++k) { ctgan_wc_problem& w = wc[nwc++]; w = ctgan_wc_problem{}; w.d = &groups[i].d; w.N = groups[i].Ns[k]; }
     }
-    if (nwc) ctgan_wgrad16c_plan(wc, nwc, wc_chunk);
+    if (nwc) ctgan_wgrad16c_plan(wc, nwc, mma, wc_chunk);
     // slice-kernel problems
     int best_chunk = 0;
     double best_t = 1e30;

@@ -17,6 +17,6 @@ struct ctgan_wc_problem {
 };
 
 bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma, int max_rows);
-int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d);                                   // workgroups per split
-void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks);          // pixels per split of every problem (multiples of 64)
+int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d, int mma);                          // workgroups per split
+void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int mma, int* chunks); // pixels per split of every problem (multiples of 64)
 int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStream_t st);

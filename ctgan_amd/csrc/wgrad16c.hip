@@ -44,13 +44,22 @@
 
 namespace {
 
-constexpr int XPL = 272;                 // bytes per (channel row, plane): 128 ring pixels (16 units of 16 B) + 16 B so that the row stride
-constexpr int XROW = 3 * XPL;            // ... of 816 B = 204 dwords = 12 (mod 64) spreads 16 rows over all 64 banks (ds_read_b128 groups)
-constexpr int XZERO = 128 * XROW;        // a row of zeros: the fragment address of a tap whose image row is padding
-constexpr int XBYTES = 129 * XROW;
-constexpr int YROW = 3 * 64 + 16;        // dy: [kout row][plane][32 pixels]; 208 B = 52 dwords = 4 * 13: conflict-free the same way
-constexpr int YSTAGE = 128 * YROW;
-constexpr int LDS_TOTAL = XBYTES + 2 * YSTAGE;      // 158,512 B: one workgroup per CU
+// LDS layout per arithmetic mode.  Split mode (three bf16 planes per operand): slices of 32 pixels; bf16 / fp16 (one plane): slices of 64.
+template <int MMA> struct WC {
+    static constexpr int NP = planes<MMA>();
+    static constexpr int BKP = NP == 3 ? 32 : 64;        // pixels per K slice
+    static constexpr int KS = BKP / 16;                  // MFMA k steps per slice
+    static constexpr int XB = BKP / 32;                  // staging blocks (4 pixels x 4 channels) per thread and slice
+    static constexpr int UNITS = 4 * BKP / 8;            // the x ring: four slices, in units of 8 pixels (16 B per plane)
+    static constexpr int XPL = 4 * BKP * 2 + 16;         // bytes per (channel row, plane): the ring + 16 B, so that the row stride - 816 B =
+    static constexpr int XROW = NP * XPL;                // 204 dwords = 12 (mod 64), or 528 B = 132 = 4 (mod 64) - spreads 16 rows over all banks
+    static constexpr int XZERO = 128 * XROW;             // a row of zeros: the fragment address of a tap whose image row is padding
+    static constexpr int XBYTES = 129 * XROW;
+    static constexpr int YPL = BKP * 2;                  // dy: [kout row][plane][slice pixels]
+    static constexpr int YROW = NP * YPL + 16;           // 208 B = 52 dwords = 4 * 13 / 144 B = 36 = 4 * 9: conflict-free the same way
+    static constexpr int YSTAGE = 128 * YROW;
+    static constexpr int LDS_TOTAL = XBYTES + 2 * YSTAGE;      // 158,512 B (split mode) / 104,976 B: one workgroup per CU
+};
 
 struct WCol { int xoff; unsigned pk; };  // pk = (dr0 + 8) | (dc + 8) << 4 | ntap << 8 | tap0 << 12 | tap1 << 18 | tap2 << 24   (tap = r*S + s < 64)
 struct W16C {
@@ -72,8 +81,9 @@ static_assert(sizeof(W16CGroup) <= 4000, "kernel arguments");
 
 template <int MMA, int NTAP, bool Q8>
 __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, const int cb, const int tn, const int by, unsigned char* smem) {
-    constexpr int NP = planes<MMA>();
-    static_assert(NP == 3, "the column kernel is built for the split mode");
+    using T = WC<MMA>;
+    constexpr int NP = T::NP, BKP = T::BKP, KS = T::KS, XB = T::XB, UMASK = T::UNITS - 1, XPL = T::XPL, XROW = T::XROW, XZERO = T::XZERO,
+                  XBYTES = T::XBYTES, YPL = T::YPL, YROW = T::YROW, YSTAGE = T::YSTAGE;
     unsigned char* const xs = smem;
     unsigned char* const ys = smem + XBYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
@@ -86,7 +96,7 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     const int c0 = cb * 128, n0 = tn * 128;
     const int k_begin = by * p.chunk;
     const int k_end = min(k_begin + p.chunk, p.Kg);
-    const int t0 = k_begin >> 5, t1 = (k_end + 31) >> 5;
+    const int t0 = k_begin / BKP, t1 = (k_end + BKP - 1) / BKP;
     const int qu = p.Q >> 3;                               // ring units (8 pixels) per image row
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
@@ -97,33 +107,38 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     // leaves the image: the SAME padding columns).  x is dense per image (s_n = P * s_h, checked by the host), so the byte offset of a
     // pixel is linear in its global row index: a thread's four offsets are loop invariants plus one scalar per slice.  Pixels past Kg lie
     // past the tensor (hardware range check: zeros); an invalid column gets an offset past every tensor (x_bytes < 2 GiB).
-    unsigned xoff_e[4], yoff_e[4];
-    {
-        const int px = pg * 4, pp = px >> p.q_shift, qq = px & (p.Q - 1);       // (32 % Q == 0: the slice adds whole rows)
+    unsigned xoff_e[XB][4], yoff_e[XB][4];
+#pragma unroll
+    for (int b = 0; b < XB; ++b) {
+        const int px = (pg + 8 * b) * 4, pp = px >> p.q_shift, qq = px & (p.Q - 1);       // (BKP % Q == 0: the slice adds whole rows)
         const unsigned base = (unsigned)(col.xoff + pp * p.s_h + c0 + cg * 4) * 4u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int qe = qq + e + dc;
-            xoff_e[e] = (unsigned)qe < (unsigned)p.Q ? base + (unsigned)qe * wstep : 0x80000000u;
-            yoff_e[e] = ((unsigned)(px + e) * (unsigned)p.Ng + (unsigned)(n0 + cg * 4)) * 4u;
+            xoff_e[b][e] = (unsigned)qe < (unsigned)p.Q ? base + (unsigned)qe * wstep : 0x80000000u;
+            yoff_e[b][e] = ((unsigned)(px + e) * (unsigned)p.Ng + (unsigned)(n0 + cg * 4)) * 4u;
         }
     }
-    const unsigned x_slice = (unsigned)(32 >> p.q_shift) * (unsigned)p.s_h * 4u, y_slice = 32u * ystep;
-    auto load_x = [&](int sl, float4 (&rv)[4]) {
+    const unsigned x_slice = (unsigned)(BKP >> p.q_shift) * (unsigned)p.s_h * 4u, y_slice = (unsigned)BKP * ystep;
+    auto load_x = [&](int sl, float4 (&rv)[XB][4]) {
         const unsigned so = (unsigned)sl * x_slice;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if ((WC_DBG & 128) && sl > t0 + 2) { rv[e].x += 1.f; continue; }
-            rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff_e[e] + so, 0, 0));
-        }
+        for (int b = 0; b < XB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if ((WC_DBG & 128) && sl > t0 + 2) { rv[b][e].x += 1.f; continue; }
+                rv[b][e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff_e[b][e] + so, 0, 0));
+            }
     };
-    auto load_y = [&](int sl, float4 (&rv)[4]) {         // (the descriptor ends at this split's last pixel: the next split's read as zeros)
+    auto load_y = [&](int sl, float4 (&rv)[XB][4]) {     // (the descriptor ends at this split's last pixel: the next split's read as zeros)
         const unsigned so = (unsigned)sl * y_slice;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if ((WC_DBG & 128) && sl > t0 + 2) { rv[e].x += 1.f; continue; }
-            rv[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yoff_e[e] + so, 0, 0));
-        }
+        for (int b = 0; b < XB; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if ((WC_DBG & 128) && sl > t0 + 2) { rv[b][e].x += 1.f; continue; }
+                rv[b][e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, yoff_e[b][e] + so, 0, 0));
+            }
     };
     // A staging block = 4 consecutive pixels x 4 channels.  Transposed by register naming: channel j of pixels (0,1) and (2,3) -> two
     // packed dwords per plane (8-byte LDS stores, conflict-free).  The eight pairs go through the three split levels TOGETHER (level by
@@ -145,7 +160,7 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
         for (int q = 0; q < NP; ++q) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) pl[q][k] = Cvt<MMA>::pk(a[k], b[k]);
-            if (q + 1 < NP && !(WC_DBG & 2)) {
+            if (q + 1 < NP && !(WC_DBG & 2)) {      // (one-plane modes: the rounded piece is all there is)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {       // remainder = value - piece, exact (one v_dot2c per value)
                     if (WC_DBG & 16) {
@@ -173,26 +188,34 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
             for (int q = 0; q < NP; ++q) { const u32x2 o = {pl[q][2 * j], pl[q][2 * j + 1]}; *reinterpret_cast<u32x2*>(dst + j * rowstride + q * plane) = o; }
     };
     const int relu_lim = p.relu_x ? 0 : (int)0x80000000;
-    auto store_x = [&](float4 (&v)[4], int slot) {
+    auto store_x = [&](float4 (&vv)[XB][4], int slot) {
         // relu on load, branch-free: as signed integers every negative float (and -0) is below 0, every positive one unchanged by
         // max(., 0); a problem without relu takes max(., INT_MIN)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e].x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].x), relu_lim)); v[e].y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].y), relu_lim));
-            v[e].z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].z), relu_lim)); v[e].w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].w), relu_lim));
+        for (int b = 0; b < XB; ++b) {
+            float4 (&v)[4] = vv[b];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e].x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].x), relu_lim)); v[e].y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].y), relu_lim));
+                v[e].z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].z), relu_lim)); v[e].w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v[e].w), relu_lim));
+            }
+            unsigned char* dst = xs + (cg * 4) * XROW + slot * (BKP * 2) + (pg + 8 * b) * 8;
+            put_block(dst, XROW, XPL, v);
         }
-        unsigned char* dst = xs + (cg * 4) * XROW + slot * 64 + pg * 8;
-        put_block(dst, XROW, XPL, v);
     };
     const bool bias_wg = p.with_bias && cb == 0 && (col.pk >> 31);      // the first column's workgroups sum the dy tiles they stage
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto store_y = [&](const float4 (&v)[4], int stage) {
-        if (bias_wg && p.with_bias == 1) {                 // (with_bias == 2: a segment that does not contribute - its slab row stays zero)
-            bsum.x += (v[0].x + v[1].x) + (v[2].x + v[3].x); bsum.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
-            bsum.z += (v[0].z + v[1].z) + (v[2].z + v[3].z); bsum.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+    auto store_y = [&](const float4 (&vv)[XB][4], int stage) {
+#pragma unroll
+        for (int b = 0; b < XB; ++b) {
+            const float4 (&v)[4] = vv[b];
+            if (bias_wg && p.with_bias == 1) {             // (with_bias == 2: a segment that does not contribute - its slab row stays zero)
+                bsum.x += (v[0].x + v[1].x) + (v[2].x + v[3].x); bsum.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+                bsum.z += (v[0].z + v[1].z) + (v[2].z + v[3].z); bsum.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+            }
+            unsigned char* dst = ys + stage * YSTAGE + (cg * 4) * YROW + (pg + 8 * b) * 8;
+            put_block(dst, YROW, YPL, v);
         }
-        unsigned char* dst = ys + stage * YSTAGE + (cg * 4) * YROW + pg * 8;
-        put_block(dst, YROW, 64, v);
     };
 
     f32x16 acc[NTAP][2];
@@ -216,7 +239,7 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (WC_DBG & 32) { fb[q][j] = u32x4{(unsigned)sl, (unsigned)ks, (unsigned)q, (unsigned)j}; continue; }
-                fb[q][j] = *reinterpret_cast<const u32x4*>(yst + j * 32 * YROW + q * 64 + ks * 32);
+                fb[q][j] = *reinterpret_cast<const u32x4*>(yst + j * 32 * YROW + q * YPL + ks * 32);
             }
     };
     const unsigned xrow_lane_h = xrow_lane + (unsigned)h * 16u;
@@ -225,16 +248,16 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
         unsigned a;
         if constexpr (Q8) {
             // a k step of 16 pixels spans two rows of an 8-wide image: the lane half's 8 pixels lie in image row prow
-            const int prow = ((sl * 32 + ks * 16 + h * 8) >> 3) & (p.P - 1);
+            const int prow = ((sl * BKP + ks * 16 + h * 8) >> 3) & (p.P - 1);
             const bool valid = (unsigned)(prow + dr) < (unsigned)p.P;
-            const unsigned unit = (unsigned)(sl * 4 + ks * 2 + dr + h) & 15u;
+            const unsigned unit = (unsigned)(sl * (BKP / 8) + ks * 2 + dr + h) & (unsigned)UMASK;
             a = valid ? xrow_lane + unit * 16u : (unsigned)XZERO;
         } else {
             // rows of 16 / 32 pixels: the k step lies in ONE image row - validity and ring unit are wave-uniform (scalar ALU), the unit is
             // even, so the lane half adds its 16 bytes without wrapping
-            const int prow = ((sl * 32 + ks * 16) >> p.q_shift) & (p.P - 1);
+            const int prow = ((sl * BKP + ks * 16) >> p.q_shift) & (p.P - 1);
             const bool valid = (unsigned)(prow + dr) < (unsigned)p.P;
-            const unsigned uoff = ((unsigned)(sl * 4 + ks * 2 + dr * qu) & 15u) * 16u;
+            const unsigned uoff = ((unsigned)(sl * (BKP / 8) + ks * 2 + dr * qu) & (unsigned)UMASK) * 16u;
             a = (valid ? xrow_lane_h : (unsigned)XZERO) + (valid ? uoff : 0u);
         }
 #pragma unroll
@@ -245,51 +268,59 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
     };
     auto mma_tap = [&](const u32x4 (&fa)[NP], const u32x4 (&fb)[NP][2], auto t_c) {
         constexpr int t = decltype(t_c)::value;
-        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // small products first (as conv16_kernel)
+        if constexpr (NP == 1) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
+            for (int j = 0; j < 2; ++j) acc[t][j] = Cvt<MMA>::mma(fa[0], fb[0][j], acc[t][j]);
+        } else {
+            constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};      // small products first (as conv16_kernel)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (WC_DBG & 4) { acc[t][j][c] += __builtin_bit_cast(float, fa[QA[c]][0] ^ fb[QB[c]][j][1]); continue; }
-                acc[t][j] = Cvt<MMA>::mma(fa[QA[c]], fb[QB[c]][j], acc[t][j]);
-            }
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (WC_DBG & 4) { acc[t][j][c] += __builtin_bit_cast(float, fa[QA[c]][0] ^ fb[QB[c]][j][1]); continue; }
+                    acc[t][j] = Cvt<MMA>::mma(fa[QA[c]], fb[QB[c]][j], acc[t][j]);
+                }
+        }
     };
     u32x4 fbr[2][NP][2], far[2][NP];
     auto mma_head = [&](int sl) { load_b(sl, 0, fbr[0]); load_a(sl, 0, 0, far[0]); };
     auto mma_steps = [&](int sl) {
-        // step i = ks * NTAP + t uses far[i & 1], fbr[ks]; the next step's fragments are requested first
+        // step i = ks * NTAP + t uses far[i & 1], fbr[ks & 1]; the next step's fragments are requested first
         auto step = [&](auto i_c) {
             constexpr int i = decltype(i_c)::value, ks = i / NTAP, t = i % NTAP;
-            if constexpr (i + 1 < 2 * NTAP) {
+            if constexpr (i + 1 < KS * NTAP) {
                 constexpr int ks1 = (i + 1) / NTAP, t1 = (i + 1) % NTAP;
-                if constexpr (t1 == 0) load_b(sl, ks1, fbr[ks1]);
+                if constexpr (t1 == 0) load_b(sl, ks1, fbr[ks1 & 1]);
                 load_a(sl, ks1, t1, far[(i + 1) & 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma_tap(far[i & 1], fbr[ks], std::integral_constant<int, t>{});
+            mma_tap(far[i & 1], fbr[ks & 1], std::integral_constant<int, t>{});
             __builtin_amdgcn_sched_barrier(0);
         };
-        step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
-        if constexpr (NTAP >= 2) { step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{}); }
-        if constexpr (NTAP >= 3) { step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); }
+        auto run = [&](auto self, auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr (i < KS * NTAP) { step(i_c); self(self, std::integral_constant<int, i + 1>{}); }
+        };
+        run(run, std::integral_constant<int, 0>{});
     };
 
     // prologue: the zero row; x slices t0-1, t0, t0+1 and dy slice t0 staged, the next slice of each in registers
     if (tid < XROW / 4) reinterpret_cast<unsigned*>(xs + XZERO)[tid] = 0u;
-    float4 rv[4];
+    float4 rv[XB][4];
     if (is_x) {
-        float4 r3[3][4];
+        float4 r3[3][XB][4];
         if (t0 > 0) load_x(t0 - 1, r3[0]);
         else {      // before the first pixel: rows no tap reads as valid
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r3[0][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b = 0; b < XB; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r3[0][b][e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         load_x(t0, r3[1]); load_x(t0 + 1, r3[2]);
         load_x(t0 + 2, rv);
         store_x(r3[0], (t0 - 1) & 3); store_x(r3[1], t0 & 3); store_x(r3[2], (t0 + 1) & 3);
     } else {
-        float4 r1[4];
+        float4 r1[XB][4];
         load_y(t0, r1);
         load_y(t0 + 1, rv);
         store_y(r1, t0 & 1);
@@ -342,7 +373,7 @@ __device__ __forceinline__ void wgrad16c_body(const W16C& p, const WCol col, con
 
 // Workgroups [first[j], first[j+1]) belong to problem j: split-major, then (column, channel block, kout block).
 template <int MMA>
-__global__ __launch_bounds__(512) void wgrad16c_group_kernel(const W16CGroup g) {
+__global__ __launch_bounds__(512) void wgrad16c_group_kernel(const W16CGroup g) {      // dynamic LDS: WC<MMA>::LDS_TOTAL
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int job = 0;
     while (job + 1 < g.n && (int)blockIdx.x >= g.first[job + 1]) ++job;
@@ -385,7 +416,7 @@ struct ColGeom { int ncols; WCol col[CTGAN_WC_MAXCOL]; int ntap[CTGAN_WC_MAXCOL]
 
 // The columns of a filter: (row class rho, s) -> the taps r with (r - pad_t) mod stride == rho, in runs of at most three consecutive
 // row offsets dr = (r - pad_t - rho) / stride.  false: outside the kernel (see ctgan_wgrad16c_takes).
-bool col_geom(const ctgan_conv_desc* d, ColGeom* out) {
+bool col_geom(const ctgan_conv_desc* d, ColGeom* out, int bkp) {
     const int st = d->stride;
     ColGeom g{};
     for (int rho = 0; rho < st; ++rho) {
@@ -400,8 +431,8 @@ bool col_geom(const ctgan_conv_desc* d, ColGeom* out) {
                 if (g.ncols == CTGAN_WC_MAXCOL) return false;
                 const int dr0 = floordiv(rs[b] - d->pad_t - rho, st);
                 if (dr0 < -8 || dr0 + nt - 1 > 7) return false;
-                // the ring holds one slice (32 pixels) behind and one ahead of the slice being multiplied
-                if (std::max(-dr0, 0) * d->Q > 32 || std::max(dr0 + nt - 1, 0) * d->Q > 32) return false;
+                // the ring holds one slice (32 / 64 pixels) behind and one ahead of the slice being multiplied
+                if (std::max(-dr0, 0) * d->Q > bkp || std::max(dr0 + nt - 1, 0) * d->Q > bkp) return false;
                 WCol& c = g.col[g.ncols];
                 c.xoff = (int)(rho * d->xs[2] + sigma * d->xs[3]);
                 c.pk = (unsigned)(dr0 + 8) | ((unsigned)(dc + 8) << 4) | ((unsigned)nt << 8);
@@ -419,8 +450,12 @@ bool col_geom(const ctgan_conv_desc* d, ColGeom* out) {
     return true;
 }
 
-// estimated microseconds of one workgroup: slices x (staging + taps x MFMAs of a slice) + prologue / slab store
-double wg_cost(int ntap, int chunk) { return (double)(chunk / 32) * (0.35 + 1.05 * ntap) + 4.0; }
+int slice_px(int mma) { return mma == CTGAN_MMA_F32X3 ? 32 : 64; }
+// estimated microseconds of a slice - staging + taps x its MFMAs: 72 x 2 waves x 32 cycles per tap and SIMD in the split mode, a sixth of
+// that in the one-plane modes, where the staging (64 pixels) is the larger part
+double slice_us(int mma, int ntap) { return mma == CTGAN_MMA_F32X3 ? 0.35 + 1.05 * ntap : 0.75 + 0.40 * ntap; }
+// ... of one workgroup: its slices + prologue / slab store
+double wg_cost(int mma, int ntap, int chunk) { return (double)(chunk / slice_px(mma)) * slice_us(mma, ntap) + 4.0; }
 
 }  // namespace
 
@@ -430,9 +465,9 @@ double wg_cost(int ntap, int chunk) { return (double)(chunk / 32) * (0.35 + 1.05
 // `max_rows` samples, below 2 GiB.
 bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma, int max_rows) {
     static const int off = [] { const char* e = getenv("CTGAN_WGRAD16_COL"); return e && atoi(e) == 0; }();
-    if (off || mma != CTGAN_MMA_F32X3) return false;
+    if (off || (mma != CTGAN_MMA_F32X3 && mma != CTGAN_MMA_BF16 && mma != CTGAN_MMA_F16)) return false;
     if (d->x_up || d->C % 128 || d->K % 128 || d->xs[1] != 1) return false;
-    if (d->Q != 8 && d->Q != 16 && d->Q != 32) return false;
+    if (d->Q != 8 && d->Q != 16 && d->Q != 32 && !(d->Q == 64 && slice_px(mma) == 64)) return false;
     const int pq = d->P * d->Q;
     if ((pq & (pq - 1)) || pq < 64) return false;
     if (d->stride != 1 && d->stride != 2) return false;
@@ -441,12 +476,12 @@ bool ctgan_wgrad16c_takes(const ctgan_conv_desc* d, int mma, int max_rows) {
     if (d->xs[0] >= (1LL << 28) || d->xs[2] >= (1LL << 26) || d->xs[3] >= (1LL << 26)) return false;
     // byte offsets: an invalid column is addressed at 2 GiB + its offset, which must lie past the tensor and below 4 GiB
     if (((long long)max_rows * d->xs[0] + d->C) * 4 >= (1LL << 31) || (long long)max_rows * d->P * d->Q * d->K * 4 >= (1LL << 32)) return false;
-    return col_geom(d, nullptr);
+    return col_geom(d, nullptr, slice_px(mma));
 }
 
-int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d) {
+int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d, int mma) {
     ColGeom g;
-    if (!col_geom(d, &g)) return 0;
+    if (!col_geom(d, &g, slice_px(mma))) return 0;
     return g.ncols * (d->C / 128) * (d->K / 128);
 }
 
@@ -455,12 +490,12 @@ int ctgan_wgrad16c_tiles(const ctgan_conv_desc* d) {
 // problem gets the longest chunk (multiple of 64 pixels, splits of equal length) whose workgroups stay within T - over a grid of T, by the
 // simulated schedule on 256 CUs (most expensive first, as the launch orders them) plus the slab traffic the plan causes.  Deterministic: a
 // function of the geometries and row counts only (the workspace query and the launch must agree).
-void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks) {
+void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int mma, int* chunks) {
     static const int forced = [] { const char* e = getenv("CTGAN_WGRAD16_COL_CHUNK"); return e ? atoi(e) : 0; }();      // (tools/wgrad_group_bench.py: chunk sweep)
     std::vector<ColGeom> geoms(n);
     std::vector<int> mt(n, 1), kg(n);
     for (int i = 0; i < n; ++i) {
-        col_geom(probs[i].d, &geoms[i]);
+        col_geom(probs[i].d, &geoms[i], slice_px(mma));
         for (int c = 0; c < geoms[i].ncols; ++c) mt[i] = std::max(mt[i], geoms[i].ntap[c]);
         kg[i] = probs[i].N * probs[i].d->P * probs[i].d->Q;
     }
@@ -473,14 +508,14 @@ void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks) {
         double slab_bytes = 0.;
         for (int i = 0; i < n; ++i) {
             const ctgan_conv_desc* d = probs[i].d;
-            int ch = forced ? forced : (int)((T - 4.0) / (0.35 + 1.05 * mt[i])) * 32;
+            int ch = forced ? forced : (int)((T - 4.0) / slice_us(mma, mt[i])) * slice_px(mma);
             ch = std::max(128, ch / 64 * 64);
             const int sp = (kg[i] + ch - 1) / ch;
             ch = (((kg[i] + sp - 1) / sp) + 63) / 64 * 64;
             cur[i] = ch;
             const int splits = (kg[i] + ch - 1) / ch;
             const int per = (d->C / 128) * (d->K / 128);
-            for (int c = 0; c < geoms[i].ncols; ++c) wgs.emplace_back(wg_cost(geoms[i].ntap[c], ch), splits * per);
+            for (int c = 0; c < geoms[i].ncols; ++c) wgs.emplace_back(wg_cost(mma, geoms[i].ntap[c], ch), splits * per);
             slab_bytes += (double)splits * ((double)d->R * d->S * d->C + 1) * d->K * 4.;
         }
         std::sort(wgs.begin(), wgs.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
@@ -502,15 +537,24 @@ void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int* chunks) {
     }
 }
 
-int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStream_t st) {
-    if (mma != CTGAN_MMA_F32X3) return ctgan_fail(CTGAN_E_UNSUPPORTED, "wgrad16c: split mode only");
-    auto kern = wgrad16c_group_kernel<CTGAN_MMA_F32X3>;
+template <int MMA>
+static int launch_wc(const W16CGroup& g, int blocks, hipStream_t st) {
+    auto kern = wgrad16c_group_kernel<MMA>;
+    constexpr int lds = WC<MMA>::LDS_TOTAL;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
-            return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16c: cannot reserve %d B of LDS", LDS_TOTAL);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "wgrad16c: cannot reserve %d B of LDS", lds);
         attr = true;
     }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, g);
+    ctgan_set_last_kernel(MMA == CTGAN_MMA_F32X3 ? "wgrad16x3_group<col>" : "wgrad16_group<col>");
+    ctgan_set_last_symbol("wgrad16c_group_kernel<%d>", MMA);
+    return ctgan_check_launch("wgrad16c_group");
+}
+
+int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStream_t st) {
+    if (mma != CTGAN_MMA_F32X3 && mma != CTGAN_MMA_BF16 && mma != CTGAN_MMA_F16) return ctgan_fail(CTGAN_E_UNSUPPORTED, "wgrad16c: unknown mode");
     static const int order_flag = [] { const char* e = getenv("CTGAN_WGRAD16_COL_ORDER"); return (e && atoi(e) == 1) ? 2 : 0; }();
     // most expensive workgroups first
     std::vector<int> order(n);
@@ -518,10 +562,10 @@ int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStre
     std::vector<ColGeom> geoms(n);
     for (int i = 0; i < n; ++i) {
         order[i] = i;
-        if (!col_geom(probs[i].d, &geoms[i])) return ctgan_fail(CTGAN_E_UNSUPPORTED, "wgrad16c: problem %d outside the column kernel", i);
+        if (!col_geom(probs[i].d, &geoms[i], slice_px(mma))) return ctgan_fail(CTGAN_E_UNSUPPORTED, "wgrad16c: problem %d outside the column kernel", i);
         int mt = 1;
         for (int c = 0; c < geoms[i].ncols; ++c) mt = std::max(mt, geoms[i].ntap[c]);
-        cost[i] = wg_cost(mt, probs[i].chunk);
+        cost[i] = wg_cost(mma, mt, probs[i].chunk);
     }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
     for (int base = 0; base < n; base += WC_GROUP_MAX) {
@@ -549,10 +593,8 @@ int ctgan_wgrad16c_launch(const ctgan_wc_problem* probs, int n, int mma, hipStre
             if (k < g.n) b0 += p.tiles * p.splits;
         }
         g.first[WC_GROUP_MAX] = b0;
-        hipLaunchKernelGGL(kern, dim3((unsigned)b0), dim3(512), LDS_TOTAL, st, g);
-        ctgan_set_last_kernel("wgrad16x3_group<col>");
-        ctgan_set_last_symbol("wgrad16c_group_kernel<%d>", CTGAN_MMA_F32X3);
-        const int rc = ctgan_check_launch("wgrad16c_group");
+        const int rc = mma == CTGAN_MMA_F32X3 ? launch_wc<CTGAN_MMA_F32X3>(g, b0, st)
+                     : (mma == CTGAN_MMA_BF16 ? launch_wc<CTGAN_MMA_BF16>(g, b0, st) : launch_wc<CTGAN_MMA_F16>(g, b0, st));
         if (rc) return rc;
     }
     return CTGAN_OK;

@@ -142,3 +142,34 @@ def test_addend_and_zero_bias_row(K):
     dw_r, db_r = oracle_wgrad(segs, geom)
     assert relerr(dw, dw_r + add_w.cpu().double()) <= 5e-6
     assert relerr(db, db_r + add_b.cpu().double()) <= 5e-6
+
+
+def _q16(t, dt):
+    return t.to(torch.bfloat16 if dt == 'bf16' else torch.float16).float()
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', [
+    # (N, C, H, K, k, stride): 64-pixel rows (one-plane modes only: 64-pixel slices), the DCGAN 5x5 stride-2 layers (polyphase columns of
+    # three and two taps), config[4]'s 3x3 stride-2 down convs (pad 0 / 1) and its 1024-channel 8x8 layers
+    (6, 128, 64, 128, 3, 1), (16, 128, 16, 256, 5, 2), (8, 256, 8, 512, 5, 2), (5, 128, 32, 256, 3, 2), (3, 1024, 8, 1024, 3, 1),
+    (7, 128, 32, 128, 4, 2),
+])
+def test_column_kernel_in_the_16bit_modes_is_exact_on_representable_operands(K, dt, case):
+    """bf16 / fp16 modes (BASELINE configs[1] / [4]): one rounded plane per operand, 64-pixel slices.  With operands that are representable in
+    the 16-bit format every product is exact in fp32, so the kernel must agree with the fp64 oracle to fp32 summation error - any
+    indexing / ring / polyphase / transposition mistake shows at full size.  Through the single-problem entry (ctgan_conv2d16_wgrad_bias),
+    which routes to the filter-column kernel."""
+    N, C, H, Ko, k, st = case
+    gen = torch.Generator().manual_seed(N * 7 + H)
+    geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+    x = cl(_q16(torch.randn(N, C, H, H, generator=gen), dt))
+    gy = cl(_q16(torch.randn(N, Ko, geom.P, geom.Q, generator=gen), dt))
+    with K.mma_dtype(dt):
+        dw, db = K.conv_wgrad(x, gy, geom, with_bias=True, relu_x=True)
+        assert K.last_kernel() == 'wgrad16_group<col>', K.last_kernel()
+        dw2 = K.conv_wgrad(x, gy, geom, relu_x=True)
+    dw_r, db_r = oracle_wgrad([(x, gy, True, True)], geom)
+    assert relerr(dw, dw_r) <= 2e-5, (case, dt, relerr(dw, dw_r))
+    assert relerr(db, db_r) <= 2e-5
+    assert torch.equal(dw, dw2)                       # the bias row changes nothing else; deterministic
