@@ -164,7 +164,7 @@ def test_lsun128_full_width_16bit_losses(dt):
                 K.PROFILE = None
         # the step really ran on the 16-bit matrix cores: forward / data-gradient AND weight-gradient kernels of that family, and they
         # are the majority of its conv launches (the 3-channel layers and the heads stay fp32)
-        n16 = sum(n.startswith('conv16<') for n in ran), sum(n.startswith('wgrad16<') for n in ran)
+        n16 = sum(n.startswith('conv16<') for n in ran), sum(n.startswith(('wgrad16<', 'wgrad16_group<')) for n in ran)
         assert n16[0] >= 20 and n16[1] >= 10 and sum(n16) > len(ran) // 2, (n16, len(ran), sorted(set(ran)))
         tol = 1e-2 if dt == 'f16' else 4e-2
         for k in ('cost', 'wgan_only', 'ct', 'gp'):
