@@ -97,10 +97,16 @@ def grouped16_mode():
 
 
 def grouped16_takes(g, rows):
-    """Mixed-precision modes: is this weight gradient (geometry g over `rows` samples) queued for the grouped 16-bit launch?  The SMALL
-    problems only (<= 16 K pixels, <= 512 channels): large ones run faster on the wide tiles of their own launch."""
-    return (X3_WGRAD_GROUP and MMA_DTYPE in ('bf16', 'f16') and g.C % 128 == 0 and g.K % 128 == 0 and g.C <= 512 and g.K <= 512
-            and g.Q % 4 == 0 and not g.x_up and not fewch_handles(g) and rows * g.P * g.Q <= 16384)
+    """Mixed-precision modes: is this weight gradient (geometry g over `rows` samples) queued for the grouped 16-bit launch?  Every
+    problem the filter-column kernel takes (csrc/wgrad16c.hip: 128-multiples of channels, rows of 8-64 pixels, stride 1 / 2) - one grouped
+    launch per step balances them over the CUs - and otherwise the SMALL problems only (<= 16 K pixels, <= 512 channels): large ones
+    outside the column kernel run faster on the wide tiles of their own launch."""
+    if not (X3_WGRAD_GROUP and MMA_DTYPE in ('bf16', 'f16') and g.C % 128 == 0 and g.K % 128 == 0 and g.Q % 4 == 0 and not g.x_up
+            and not fewch_handles(g)):
+        return False
+    if g.Q in (8, 16, 32, 64) and g.stride in (1, 2) and g.H == g.stride * g.P and g.W == g.stride * g.Q and g.P * g.Q >= 64 and not (g.P * g.Q & (g.P * g.Q - 1)):
+        return True
+    return g.C <= 512 and g.K <= 512 and rows * g.P * g.Q <= 16384
 
 
 def grouped16_member(g):
