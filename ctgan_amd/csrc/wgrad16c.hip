@@ -451,11 +451,17 @@ bool col_geom(const ctgan_conv_desc* d, ColGeom* out, int bkp) {
 }
 
 int slice_px(int mma) { return mma == CTGAN_MMA_F32X3 ? 32 : 64; }
-// estimated microseconds of a slice - staging + taps x its MFMAs: 72 x 2 waves x 32 cycles per tap and SIMD in the split mode, a sixth of
-// that in the one-plane modes, where the staging (64 pixels) is the larger part
-double slice_us(int mma, int ntap) { return mma == CTGAN_MMA_F32X3 ? 0.35 + 1.05 * ntap : 0.75 + 0.40 * ntap; }
-// ... of one workgroup: its slices + prologue / slab store
-double wg_cost(int mma, int ntap, int chunk) { return (double)(chunk / slice_px(mma)) * slice_us(mma, ntap) + 4.0; }
+// Microseconds of a slice and of a workgroup's fixed part (prologue, slab store), measured with one round of 256 equal workgroups per tap
+// count (tools/wgrad_col_calib.py, profiles/r04_wgrad_col_calib.txt).  Split mode: MFMA-bound, 32-pixel slices (the two-tap columns are
+// the stride-2 ones: their gather touches twice the cache lines).  One-plane modes: 64 KB of operands per 64-pixel slice and CU at
+// ~25 GB/s per CU - the fabric, not the matrix pipe - whatever the number of taps.
+double slice_us(int mma, int ntap) {
+    static const double x3[3] = {2.06, 3.46, 3.98}, h16[3] = {3.19, 2.60, 2.65};
+    return (mma == CTGAN_MMA_F32X3 ? x3 : h16)[ntap < 1 ? 0 : (ntap > 3 ? 2 : ntap - 1)];
+}
+double fixed_us(int mma) { return mma == CTGAN_MMA_F32X3 ? 6.0 : 10.0; }
+// ... of one workgroup
+double wg_cost(int mma, int ntap, int chunk) { return (double)(chunk / slice_px(mma)) * slice_us(mma, ntap) + fixed_us(mma); }
 
 }  // namespace
 
@@ -508,7 +514,7 @@ void ctgan_wgrad16c_plan(const ctgan_wc_problem* probs, int n, int mma, int* chu
         double slab_bytes = 0.;
         for (int i = 0; i < n; ++i) {
             const ctgan_conv_desc* d = probs[i].d;
-            int ch = forced ? forced : (int)((T - 4.0) / slice_us(mma, mt[i])) * slice_px(mma);
+            int ch = forced ? forced : (int)((T - fixed_us(mma)) / slice_us(mma, mt[i])) * slice_px(mma);
             ch = std::max(128, ch / 64 * 64);
             const int sp = (kg[i] + ch - 1) / ch;
             ch = (((kg[i] + sp - 1) / sp) + 63) / 64 * 64;
