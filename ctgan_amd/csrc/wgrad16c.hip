@@ -451,15 +451,18 @@ bool col_geom(const ctgan_conv_desc* d, ColGeom* out, int bkp) {
 }
 
 int slice_px(int mma) { return mma == CTGAN_MMA_F32X3 ? 32 : 64; }
-// Microseconds of a slice and of a workgroup's fixed part (prologue, slab store), measured with one round of 256 equal workgroups per tap
-// count (tools/wgrad_col_calib.py, profiles/r04_wgrad_col_calib.txt).  Split mode: MFMA-bound, 32-pixel slices (the two-tap columns are
-// the stride-2 ones: their gather touches twice the cache lines).  One-plane modes: 64 KB of operands per 64-pixel slice and CU at
-// ~25 GB/s per CU - the fabric, not the matrix pipe - whatever the number of taps.
+// Microseconds of a slice and of a workgroup's fixed part (prologue, slab store).  Split mode: MFMA-bound, 0.35 + 1.05 per tap and 32-pixel
+// slice.  (One round of 256 EQUAL workgroups measures more - 2.06 / 3.46 / 3.98 us for 1 / 2 / 3 taps, tools/wgrad_col_calib.py,
+// profiles/r04_wgrad_col_calib.txt: a launch of identical MFMA-dense workgroups pulls the clock down - but the plan those costs select
+// for the critic step's mixed table, two rounds at 80 MB of slabs, measured 487-531 us against 351 for this model's one-round plan.)
+// One-plane modes: 64 KB of operands per 64-pixel slice and CU at ~25 GB/s per CU - the fabric, not the matrix pipe - whatever the number
+// of taps: 3.19 / 2.60 / 2.65 us measured the same way.
 double slice_us(int mma, int ntap) {
-    static const double x3[3] = {2.06, 3.46, 3.98}, h16[3] = {3.19, 2.60, 2.65};
-    return (mma == CTGAN_MMA_F32X3 ? x3 : h16)[ntap < 1 ? 0 : (ntap > 3 ? 2 : ntap - 1)];
+    static const double h16[3] = {3.19, 2.60, 2.65};
+    if (mma == CTGAN_MMA_F32X3) return 0.35 + 1.05 * ntap;
+    return h16[ntap < 1 ? 0 : (ntap > 3 ? 2 : ntap - 1)];
 }
-double fixed_us(int mma) { return mma == CTGAN_MMA_F32X3 ? 6.0 : 10.0; }
+double fixed_us(int mma) { return mma == CTGAN_MMA_F32X3 ? 4.0 : 10.0; }
 // ... of one workgroup
 double wg_cost(int mma, int ntap, int chunk) { return (double)(chunk / slice_px(mma)) * slice_us(mma, ntap) + fixed_us(mma); }
 
