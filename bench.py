@@ -583,12 +583,13 @@ def load_pmc_traffic():
     """profiles/r03_pmc_traffic_x3.json (tools/pmc_x3.sh: separate rocprofv3 --pmc passes, gfx950 corrections of the guide) + the
     round-1 files of the fp32 tiles, keyed by device symbol."""
     out = {}
-    try:
-        for sym, rec in json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic_x3.json'))).items():
-            if isinstance(rec, dict) and 'hbm_bytes_per_launch' in rec:
-                out[sym] = dict(rec, file='profiles/r03_pmc_traffic_x3.json')
-    except Exception:
-        pass
+    for fn in ('r03_pmc_traffic_x3.json', 'r04_pmc_wgrad_col.json'):      # (round 4: the filter-column weight-gradient kernel, tools/pmc_wgrad_col.sh)
+        try:
+            for sym, rec in json.load(open(os.path.join(ROOT, 'profiles', fn))).items():
+                if isinstance(rec, dict) and 'hbm_bytes_per_launch' in rec and 'flops_per_launch' in rec:
+                    out[sym] = dict(rec, file='profiles/' + fn)
+        except Exception:
+            pass
     for fn, sym in (('r01_pmc_traffic_64x128.json', 'igemm_fwd_pipe_kernel<1, 4, 1, 2, 1, 1, false, 1>'),
                     ('r01_pmc_traffic.json', 'igemm_fwd_pipe_kernel<2, 2, 1, 2, 2, 1, false, 1>')):
         try:
@@ -676,7 +677,7 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
                           'frac': round(v[1] / v[2] / 1e12 / PIPE_PEAK[pipe_of(sorted(v[3])[0])], 4), 'pipe': pipe_of(sorted(v[3])[0]),
                           'variant': sorted(v[3]), 'traffic': traffic_of(k, v[1] / v[0])}
                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
-        'note': 'by_kernel keys are device symbols: look them up in profiles/r03_kernel_stats_resnet_*.txt / r03_steady_state_resnet_*.txt '
+        'note': 'by_kernel keys are device symbols: look them up in profiles/r04_kernel_stats_resnet_*.txt / r04_steady_state_resnet_*.txt '
                 '(tools/roofline_crosscheck.py prints both side by side)',
     }
 

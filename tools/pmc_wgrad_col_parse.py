@@ -11,6 +11,11 @@ import re
 import sys
 
 d, tag = sys.argv[1], sys.argv[2]
+# the critic step's job table (tools/wgrad_group_bench.py D_STEP): algorithmic work and bytes of ONE grouped launch
+D_STEP = [(128, 8, 128, 3, 1, (192, 64))] * 4 + [(128, 16, 128, 2, 2, (128, 64)), (128, 16, 128, 4, 2, (128, 64)), (128, 16, 128, 3, 1, (128, 64)),
+                                                 (128, 32, 128, 4, 2, (128, 64))]
+FLOPS = sum(2.0 * sum(Ns) * (H // st) ** 2 * k * k * C * Ko for C, H, Ko, k, st, Ns in D_STEP)
+ALG_BYTES = sum(4.0 * (sum(Ns) * (H * H * C + (H // st) ** 2 * Ko) + k * k * C * Ko) for C, H, Ko, k, st, Ns in D_STEP)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(d, tag + '_*.csv')):
@@ -29,12 +34,17 @@ out = {}
 for sym, c in agg.items():
     mean = lambda n: (sum(c[n][1:]) / len(c[n][1:])) if len(c.get(n, [])) > 1 else (c[n][0] if c.get(n) else None)
     o = {'launches_seen': max(len(v) for v in c.values())}
+    if 'wgrad16' in sym:
+        o.update(flops_per_launch=FLOPS, algorithmic_bytes_per_launch=ALG_BYTES,
+                 geometry='critic-step job table: 8 filters x 2 uses, 67.65 GFLOP (tools/wgrad_group_bench.py d)')
     if dur.get(sym):
         v = dur[sym][1:] or dur[sym]
         o['us_under_pmc'] = round(sum(v) / len(v), 1)
     fs, ws = mean('FETCH_SIZE'), mean('WRITE_SIZE')
     if fs is not None and ws is not None:
         o.update(fetch_size_kb=fs, write_size_kb=ws, hbm_bytes_per_launch=2 * fs * 1024 + ws * 1024)
+        if 'algorithmic_bytes_per_launch' in o:
+            o['traffic_over_algorithmic'] = round(o['hbm_bytes_per_launch'] / o['algorithmic_bytes_per_launch'], 2)
     hit, miss = mean('TCC_HIT_sum'), mean('TCC_MISS_sum')
     if hit is not None and miss is not None and hit + miss > 0:
         o['l2_hit_rate'] = round(hit / (hit + miss), 4)
