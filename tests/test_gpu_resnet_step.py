@@ -85,7 +85,7 @@ def _teacher_force(lib, reg, opt, oopt):
     opt.load_named_slots(oopt.m, oopt.v, oopt.t)
 
 
-@pytest.mark.parametrize('dim,B,steps,streams', [(16, 8, 3, False), (128, 64, 1, False),
+@pytest.mark.parametrize('dim,B,steps,streams', [(16, 8, 3, False), pytest.param(128, 64, 1, False, marks=pytest.mark.slow),
                                                  (16, 8, 3, True), (32, 8, 2, True), (128, 64, 2, True)])
 def test_d_and_g_step_parity_teacher_forced(setup, dim, B, steps, streams):
     """streams=False: every random tensor is injected into both sides (`rnd=`), which switches the product to its op-by-op
