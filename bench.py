@@ -293,7 +293,7 @@ def main():
                        'host_feed': host_feed, 'collective': collective,
                        'arithmetic': ('fp32 throughout; the large stride-1 conv layers (roofline.by_kernel: conv16x3h) compute the fp32 products as '
                                       'three-bf16-term splits on the bf16 matrix cores (six MFMAs per product, fp32 accumulate; error vs fp64 '
-                                      'no larger than the fp32 MFMA family\'s, tests/test_gpu_kernels16.py, DESIGN 4.6), every other layer on '
+                                      'no larger than the fp32 MFMA family\'s, tests/test_gpu_kernels16.py, DESIGN 4.3), every other layer on '
                                       'v_mfma_f32_32x32x2_f32' if (K.X3_HYBRID and K.MMA_DTYPE is None) else 'fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout'),
                        'fp32_mfma_only': fp32_only},
             'ms_per_step_p50': round(p50, 3),

@@ -1545,7 +1545,7 @@ int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st) {
     if (p.C % 64 == 0) {
         if (small) return launch_conv16<MMA, 1, 1, 64>(p, st, p.ksplit > 1 ? "conv16<64x64,k64,ksplit>" : "conv16<64x64,k64>");
         // (wider forward tiles - 128 kout x 256 pixels, 256 kout x 128 pixels, one wave per SIMD - measured slower / neutral against this
-        // tile at two waves per SIMD and removed: DESIGN 4.3)
+        // tile at two waves per SIMD and removed: DESIGN_HISTORY 4.3)
         {
             // launches whose 128x128 tiles leave workgroup slots empty (< 512) on 128-kout x 64-pixel tiles: config[1] 7.90 -> 7.82 ms per
             // iteration, config[4] unchanged (170.9 vs 170.4-171.1).  CTGAN_CONV16_TILE64=0: off.

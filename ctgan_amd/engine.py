@@ -401,7 +401,7 @@ class GraphedDCGANTrainer:
         else:
             out = t.g_losses()
             params, opt = t.g_params, t.g_opt
-        with F.deferred_wgrads():       # the step's queued weight gradients in one grouped launch, as the ResNet step (DESIGN 6.1)
+        with F.deferred_wgrads():       # the step's queued weight gradients in one grouped launch, as the ResNet step (DESIGN 4.7)
             grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         if self.adam_in_graph:
             opt.update(grads, 1.0 / t.loss_scale, rng=t.rng)

@@ -100,7 +100,7 @@ def grouped16_takes(g, rows):
     """Mixed-precision modes: is this weight gradient (geometry g over `rows` samples) queued for the grouped 16-bit launch?  Every
     problem the filter-column kernel takes (csrc/wgrad16c.hip: 128-multiples of channels, rows of 8-64 pixels, stride 1 / 2) - one grouped
     launch per step balances them over the CUs - and otherwise the SMALL problems only (<= 16 K pixels, <= 512 channels): large ones
-    outside the column kernel run faster on the wide tiles of their own launch (DESIGN 4.3)."""
+    outside the column kernel run faster on the wide tiles of their own launch (DESIGN 4.4)."""
     if not (X3_WGRAD_GROUP and MMA_DTYPE in ('bf16', 'f16') and g.C % 128 == 0 and g.K % 128 == 0 and g.Q % 4 == 0 and not g.x_up
             and not fewch_handles(g)):
         return False

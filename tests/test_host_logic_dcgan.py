@@ -118,8 +118,8 @@ def test_loss_scale_is_divided_out_exactly(cpu_kernels):
 
 @pytest.mark.parametrize('net', ['cifar', 'lsun128'])
 def test_queued_weight_gradients_equal_immediate_ones_in_the_dcgan_family_steps(cpu_kernels, net):
-    """The DCGAN-family steps do not queue their weight gradients yet; when they do (`with F.deferred_wgrads():` around the
-    backward, as the ResNet step), every parameter gradient of a critic step and of a generator step must equal the immediate path's -
+    """The DCGAN-family steps queue their weight gradients (`with F.deferred_wgrads():` around the backward, as the ResNet step; DESIGN
+    4.7): every parameter gradient of a critic step and of a generator step must equal the immediate path's -
     several uses per filter (dropout passes, GP double backward through Layernorm for the 128x128 ResNet), few-channel layers, spread
     filters."""
     import ctgan_amd.functional as F
