@@ -76,6 +76,7 @@ SIGNATURES = {
     'ctgan_debug_force_generic': (None, [c_int]),
     'ctgan_debug_x3_halo_version': (None, [c_int]),
     'ctgan_debug_last_wgrad_group_kinds': (c_int, []),
+    'ctgan_debug_last_wgrad_group_col_mask': (ctypes.c_uint, []),
     'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     'ctgan_conv2d_wgrad_multi': (c_int, [POINTER(ConvDesc), c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), _p, _p, _p,
                                          c_size_t, _p]),

@@ -1643,7 +1643,9 @@ extern "C" {
 
 void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = version; }
 static thread_local int g_last_group_kinds = 0;
+static thread_local unsigned g_last_group_col_mask = 0;
 int ctgan_debug_last_wgrad_group_kinds(void) { return g_last_group_kinds; }
+unsigned ctgan_debug_last_wgrad_group_col_mask(void) { return g_last_group_col_mask; }
 
 int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     if (!d || !mma_ok(mma)) return 0;
@@ -2189,11 +2191,15 @@ int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int m
         off += ((size_t)splits_total * rows * d->K * sizeof(float) + 255) & ~(size_t)255;
     }
     g_last_group_kinds = (nwc ? 1 : 0) | (ns ? 2 : 0);
-    if ((phases & CTGAN_WGRAD_GROUP_GEMM) && nwc) {
+    g_last_group_col_mask = 0;
+    for (int i = 0; i < n; ++i) if (plan.col[i]) g_last_group_col_mask |= 1u << i;
+    // (CTGAN_WGRAD_GROUP_TILE0 << 0 / << 1: only the filter-column / only the slice kernel's launch - bench.py times them apart)
+    const int only = phases & CTGAN_WGRAD_GROUP_TILE_MASK;
+    if ((phases & CTGAN_WGRAD_GROUP_GEMM) && nwc && (!only || (only & CTGAN_WGRAD_GROUP_TILE0))) {
         const int rc = ctgan_wgrad16c_launch(wcs, nwc, mma, st);
         if (rc) return rc;
     }
-    if ((phases & CTGAN_WGRAD_GROUP_GEMM) && ns) {
+    if ((phases & CTGAN_WGRAD_GROUP_GEMM) && ns && (!only || (only & (CTGAN_WGRAD_GROUP_TILE0 << 1)))) {
         // longest workgroups first
         int order[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];
         for (int a = 0; a < ns; ++a) order[a] = a;

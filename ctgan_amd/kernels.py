@@ -681,11 +681,17 @@ def conv_wgrad_group(groups):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             # ONE launch per bracket: this launch is hundreds of microseconds long (the ~10 us of event overhead is 3 %), and repeated back
             # to back it runs 15 % slower than in the step - the sustained MFMA stream pulls the clock down (410 vs 333 us, round 4)
-            e0.record(st)
-            check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1, _stream()), 'conv2d16_wgrad_group')
-            e1.record(st)
-            flops = sum(_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in x3)
-            PROFILE.append((last_kernel(), flops, e0, e1, 1, ('group', len(x3)), last_symbol()))
+            # (the two kernels of a mixed call - filter-column and slice - in brackets of their own, each under its own device symbol)
+            fl = [_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in x3]
+            for which in (0, 1):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1 | (16 << which), _stream()), 'conv2d16_wgrad_group')
+                e1.record(st)
+                mask = int(lib.ctgan_debug_last_wgrad_group_col_mask())
+                flops = sum(f for k, f in enumerate(fl) if bool((mask >> k) & 1) == (which == 0))
+                if flops:
+                    PROFILE.append((last_kernel(), flops, e0, e1, 1, ('group', len(x3)), last_symbol()))
             check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 2, _stream()), 'conv2d16_wgrad_group')
         if not rest:
             return

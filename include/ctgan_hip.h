@@ -76,6 +76,8 @@ void ctgan_debug_x3_halo_version(int version);
 /* tests only: which weight-gradient kernels the last ctgan_conv2d16_wgrad_group call on this thread launched - bit 0: the filter-column
    kernel (wgrad16c_group_kernel), bit 1: the slice kernel (wgrad16_group_kernel)                                                     */
 int ctgan_debug_last_wgrad_group_kinds(void);
+/* ... and which members (bit i = groups[i]) rode the filter-column kernel                                                             */
+unsigned ctgan_debug_last_wgrad_group_col_mask(void);
 
 /* Optional epilogue extension of ctgan_conv2d_fwd / ctgan_conv2d_dgrad: tf.nn.dropout (:173-177) applied to the
  * RESULT inside the kernel, y *= floor(keep + u)/keep, where u is what ctgan_rng_uniform(.., seed, stream_id, ctr)
@@ -153,7 +155,8 @@ enum { CTGAN_WGRAD_GROUP_GEMM = 1, CTGAN_WGRAD_GROUP_REDUCE = 2,
    every segment of every group is one problem of ONE launch of 128x128-tile workgroups with a common pixels-per-split, then one batched
    reduction (add_dw / add_db as above).  Members: C and K multiples of 128, power-of-two pixel grid (split mode; Q % 4 == 0 otherwise), unit channel stride of x, dense
    channels-last dy, no x_up; workspace_bytes returns 0 and the call CTGAN_E_UNSUPPORTED (nothing launched) if a member does not
-   qualify - the caller then uses ctgan_conv2d_wgrad_group for it.  phases as CTGAN_WGRAD_GROUP_GEMM | CTGAN_WGRAD_GROUP_REDUCE.   */
+   qualify - the caller then uses ctgan_conv2d_wgrad_group for it.  phases as CTGAN_WGRAD_GROUP_GEMM | CTGAN_WGRAD_GROUP_REDUCE; with
+   CTGAN_WGRAD_GROUP_TILE0 << 0 / << 1 the GEMM phase launches only the filter-column / only the slice kernel.                  */
 size_t ctgan_conv2d16_wgrad_group_workspace_bytes(const ctgan_wgrad_group* groups, int32_t n, int mma);
 int ctgan_conv2d16_wgrad_group(const ctgan_wgrad_group* groups, int32_t n, int mma, void* ws, size_t ws_bytes, int phases,
                                ctgan_stream_t stream);
