@@ -75,6 +75,7 @@ SIGNATURES = {
     'ctgan_last_symbol': (c_char_p, []),
     'ctgan_debug_force_generic': (None, [c_int]),
     'ctgan_debug_x3_halo_version': (None, [c_int]),
+    'ctgan_debug_x3_s2halo': (None, [c_int]),
     'ctgan_debug_last_wgrad_group_kinds': (c_int, []),
     'ctgan_debug_last_wgrad_group_col_mask': (ctypes.c_uint, []),
     'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),

@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "philox.h"
@@ -115,9 +116,9 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* _
 #pragma unroll
         for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane + pp.off[ph])[i] = o[q];
         if constexpr (planes<MMA>() == 3) {
-            if (pp.frag) {                                   // (stride 1: one phase; the reduction channel is k, the output channel n = c)
+            if (pp.frag) {                                   // (the reduction channel is k, the output channel n = c; stride 2: step = 4 * phase + tap)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(wp + 3 * plane)[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
+                for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(wp + 3 * plane)[frag_u32_index(n, ph * T * U + tu, k, pp.nph * T * U, pp.K >> 5, q)] = o[q];
             }
         }
     }
@@ -169,7 +170,7 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
             if constexpr (planes<MMA>() == 3) {
                 if (pp.frag) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane)[frag_u32_index(n, tu, k, T * U, pp.K >> 5, q)] = o[q];
+                    for (int q = 0; q < 3; ++q) reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane)[frag_u32_index(n, ph * T * U + tu, k, pp.nph * T * U, pp.K >> 5, q)] = o[q];
                 }
             }
         }
@@ -1292,10 +1293,14 @@ bool mma_ok(int mma) { return mma == CTGAN_MMA_BF16 || mma == CTGAN_MMA_F16 || m
 // Does the split-mode packed image of (d, op) carry the FRAG copy (frag_u32_index) behind its planes?  A function of the filter's
 // shape only (never of N, H, W: the image is cached per filter and operator): stride 1, several taps, 32-channel chunks on the
 // reduction side, 128-channel tiles on the output side - the shapes conv16x3hf_kernel takes.
+// ... and the data gradient of the folded ConvMeanPool / UpsampleConv filters (4x4, stride 2, pad 1) for the stride-2 halo kernel
+// (conv16s2.h): its image in (phase, tap) step order.
+bool s2_halo_shape(const ctgan_conv_desc* d) { return d->stride == 2 && d->R == 4 && d->S == 4 && d->pad_t == 1 && d->pad_l == 1 && !d->x_up; }
 bool frag_image_shape(const ctgan_conv_desc* d, int op) {
-    if (d->stride != 1 || d->R * d->S < 2) return false;
     const int nout = op == CTGAN_CONV_FWD ? d->K : d->C, cred = op == CTGAN_CONV_FWD ? d->C : d->K;
-    return (op == CTGAN_CONV_FWD || op == CTGAN_CONV_DGRAD) && nout % 128 == 0 && cred % 32 == 0;
+    if (!(op == CTGAN_CONV_FWD || op == CTGAN_CONV_DGRAD) || nout % 128 != 0 || cred % 32 != 0) return false;
+    if (d->stride == 1) return d->R * d->S >= 2;
+    return op == CTGAN_CONV_DGRAD && s2_halo_shape(d);
 }
 int mma_planes(int mma) { return mma == CTGAN_MMA_F32X3 ? 3 : 1; }
 int dbg16() { static const int v = [] { const char* e = getenv("CTGAN_DBG16"); return e ? atoi(e) : 0; }(); return v; }
@@ -1499,6 +1504,10 @@ int launch_conv16x3h(const P16& p, hipStream_t st) {
 // can launch_conv16x3h take this launch (either kernel)?
 bool halo_takes(const P16& p) { return conv16x3hf_usable(p) || conv16x3h_ok(p, nullptr); }
 
+#include "conv16s2.h"
+int g_s2halo = 1;                     // tests / A-B: ctgan_debug_x3_s2halo(0) puts the stride-2 data gradients back on the slice kernel
+int x3_s2halo() { return g_s2halo; }
+
 template <int MMA>
 int dispatch_conv16_tiles(const P16& p, bool small, hipStream_t st);
 
@@ -1507,6 +1516,9 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
     // small pixel grids (8x8 / 4x4 layers at batch 64): 64x64 tiles expose 4x the workgroups
     const long long big_tiles = (long long)p.nph * ((p.M + 127) / 128) * ((p.Ng + 127) / 128);
     const bool small = big_tiles < 192 || p.Ng % 128 != 0;
+    if constexpr (planes<MMA>() == 3) {
+        if (p.nph == 4 && x3_s2halo() && conv16x3p_tile(p) && big_tiles >= 96) return launch_conv16x3p(p, st);
+    }
     P16 q = p;
     q.ksplit = 1;
     if (small && p.slab) {
@@ -1642,6 +1654,7 @@ static bool extents_ok(const ctgan_conv_desc* d, int op, int mma) {
 extern "C" {
 
 void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = version; }
+void ctgan_debug_x3_s2halo(int on) { g_s2halo = on ? 1 : 0; }
 static thread_local int g_last_group_kinds = 0;
 static thread_local unsigned g_last_group_col_mask = 0;
 int ctgan_debug_last_wgrad_group_kinds(void) { return g_last_group_kinds; }
@@ -1677,7 +1690,18 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
         const long long M = op == CTGAN_CONV_FWD ? (long long)d->N * d->P * d->Q : (long long)d->N * (d->H / 2) * (d->W / 2);
         const int Ng = op == CTGAN_CONV_FWD ? d->K : d->C, Cg = op == CTGAN_CONV_FWD ? d->C : d->K;
         const int nph = op == CTGAN_CONV_FWD ? 1 : 4;
-        return (Ng % 128 == 0 && Cg % 32 == 0 && nph * ((M + 127) / 128) * (Ng / 128) >= 192) ? 1 : 0;
+        if (Ng % 128 != 0 || Cg % 32 != 0) return 0;
+        const long long t128 = nph * ((M + 127) / 128) * (Ng / 128);
+        if (s2_halo_shape(d) && x3_s2halo()) {
+            // the stride-2 halo kernel (conv16s2.h; tools/conv16_bench.py f32x3 s2 against f32): the four-phase data gradient on 8- / 16-wide
+            // dy grids (155-196 against 88-117 TFLOP/s from 128 rows up)
+            // (from 192 tiles of 128x128, as the slice kernel before it: 96 measured 13.61 against 13.58 ms per iteration)
+            const int pq = (d->H / 2) * (d->W / 2), q = d->W / 2;
+            if (op == CTGAN_CONV_DGRAD && pq % 32 == 0 && (q == 8 || q == 16) && t128 >= 192) return 1;
+        }
+        // the slice kernel: forward 130-146 against 101-125 TFLOP/s from 128 tiles of 128x128, four-phase data gradient from 192
+        // (forward from 128 tiles: the 64-row launches of the penalty's double backward - 13.60 against 13.67 ms per iteration with 192)
+        return t128 >= (op == CTGAN_CONV_FWD ? 128 : 192) ? 1 : 0;
     }
     P16 p{};
     p.nph = 1; p.stride = d->stride;

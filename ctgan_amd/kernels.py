@@ -766,6 +766,15 @@ def debug_x3_halo_version(v):
     lib.ctgan_debug_x3_halo_version(int(v))
 
 
+def debug_x3_s2halo(on):
+    """Tests / A-B: False = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel."""
+    lib.ctgan_debug_x3_s2halo(1 if on else 0)
+
+
+if os.environ.get('CTGAN_X3_S2HALO') == '0':      # (bench A/B; the routing query ctgan_conv2d16_x3_prefers follows the switch)
+    debug_x3_s2halo(False)
+
+
 def debug_last_wgrad_group_kinds():
     """Tests only: bit 0 = the last grouped 16-bit weight-gradient call launched the filter-column kernel, bit 1 = the slice kernel."""
     return int(lib.ctgan_debug_last_wgrad_group_kinds())

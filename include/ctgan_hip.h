@@ -73,6 +73,8 @@ void ctgan_debug_force_generic(int on);
 /* tests only: which halo-patch kernel of the split mode takes the launches that qualify - 1: filter through an LDS stage
    (conv16x3h_kernel), 2: filter fragments streamed from L2 (conv16x3hf_kernel), 0: back to the default (env CTGAN_X3_HALO_V, else 2) */
 void ctgan_debug_x3_halo_version(int version);
+/* tests / A-B: 0 = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel (conv16x3p_kernel) */
+void ctgan_debug_x3_s2halo(int on);
 /* tests only: which weight-gradient kernels the last ctgan_conv2d16_wgrad_group call on this thread launched - bit 0: the filter-column
    kernel (wgrad16c_group_kernel), bit 1: the slice kernel (wgrad16_group_kernel)                                                     */
 int ctgan_debug_last_wgrad_group_kinds(void);

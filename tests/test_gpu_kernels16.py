@@ -128,7 +128,13 @@ X3_CASES = CASES + [
     (48, 32, 8, 8, 128, 3, 1),        # 8x8 images, 32-pixel tiles = half an image (96 tiles)
     (160, 32, 8, 8, 256, 3, 1),       # 8x8 images, 32-pixel tiles = half an image; two kout tiles (640 tiles)
     (192, 128, 8, 8, 128, 3, 1),      # 8x8 images, 32-pixel tiles, forward and data gradient (384 workgroups)
+    # the folded ConvMeanPool / UpsampleConv filters on the stride-2 halo kernels (csrc/conv16s2.h): data gradient = four phases from one dy patch
+    (128, 128, 32, 32, 128, 4, 2),    # dy 16x16: 64-position tiles (4 rows + halo), 512 workgroups of eight waves
+    (128, 128, 16, 16, 128, 4, 2),    # dy 8x8: 32-position tiles (half an image)
+    (40, 256, 32, 32, 128, 4, 2),     # two channel tiles on the output side of the data gradient, 4 chunks on its reduction side
 ]
+X3_S2_DGRAD = {(128, 128, 32, 32, 128, 4, 2): 'conv16x3p<4x64x128', (128, 128, 16, 16, 128, 4, 2): 'conv16x3p<4x32x128', (40, 256, 32, 32, 128, 4, 2): 'conv16x3p<4x64x128'}
+X3_S2_FWD = {(40, 256, 32, 32, 128, 4, 2): 'conv16x3<', (128, 128, 16, 16, 128, 4, 2): 'conv16x3<'}      # (the forward stays on the slice kernels; 80 tiles: the 64x64 one)
 X3_SMALL_TILE = {(64, 32, 16, 16, 128, 3, 1): '64x128', (12, 64, 32, 32, 128, 3, 1): '64x128', (48, 32, 8, 8, 128, 3, 1): '32x128',
                  (160, 32, 8, 8, 256, 3, 1): '32x128', (192, 128, 8, 8, 128, 3, 1): '32x128', (384, 32, 8, 8, 128, 3, 1): '32x128'}
 
@@ -179,7 +185,7 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
         want_kernel = 'conv16x3h' if st == 1 else 'conv16x3<128x'       # (stride 2: the slice kernel, 128 kout x 128 or 64 pixels)
         if case in X3_SMALL_TILE:
             want_kernel = 'conv16x3hf<' + X3_SMALL_TILE[case]
-        assert kern3['fwd'].startswith(want_kernel) and (C % 128 != 0 or kern3['dgrad'].startswith(want_kernel)), kern3
+        assert kern3['fwd'].startswith(X3_S2_FWD.get(case, want_kernel)) and (C % 128 != 0 or kern3['dgrad'].startswith(X3_S2_DGRAD.get(case, want_kernel))), kern3
     pq = geom.P * geom.Q
     if C % 128 == 0 and Ko % 128 == 0 and geom.Q % 4 == 0 and not (pq & (pq - 1)) and not (geom.Q & (geom.Q - 1)):
         assert kern3['wgrad'].startswith('wgrad16x3') or kern3['wgrad'].startswith('reduce16'), kern3
@@ -188,6 +194,38 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
         assert e3 <= max(2.0 * e1, 3e-7), (what, e3, e1)
         m3, m1 = relerr(got3[what], want[what]), relerr(got1[what], want[what])
         assert m3 <= max(3.0 * m1, 1e-6), (what, m3, m1)
+
+
+@pytest.mark.parametrize('case', [(128, 128, 32, 32, 128), (192, 128, 16, 16, 256), (40, 256, 32, 32, 64), (48, 128, 16, 16, 128)],
+                         ids=lambda c: 'N%d_C%d_H%dx%d_K%d' % c)
+def test_f32x3_stride2_halo_data_gradient_equals_the_slice_kernel(K, case):
+    """conv16x3p_kernel (csrc/conv16s2.h): the four output-parity phases of the folded 4x4 / stride-2 data gradient from ONE staged dy
+    patch.  Same products as the slice kernel in another fp32 summation order: the two must agree to 2e-6 of the largest element, with
+    and without the bias / mask / residual epilogue, and the plain result must match the fp64 oracle's data gradient."""
+    N, C, H, W, Ko = case
+    g = torch.Generator().manual_seed(sum(case))
+    geom = K.ConvGeom(C, H, W, Ko, 4, 4, 2, False)
+    w = (torch.randn(4, 4, C, Ko, generator=g) / np.sqrt(16 * Ko)).cuda()
+    gy = cl(torch.randn(N, Ko, geom.P, geom.Q, generator=g))
+    bc = torch.randn(C, generator=g).cuda(); m = cl(torch.randn(N, C, H, W, generator=g)); rr = cl(torch.randn(N, C, H, W, generator=g))
+
+    def run():
+        a = K.conv_dgrad(gy, w, geom, N); ka = K.last_kernel()
+        b = K.conv_dgrad(gy, w, geom, N, bias=bc, mask=m, resid=rr)
+        return a, b, ka
+    with K.mma_dtype('f32x3'):
+        a1, b1, k1 = run()
+        K.debug_x3_s2halo(False)
+        try:
+            a0, b0, k0 = run()
+        finally:
+            K.debug_x3_s2halo(True)
+    assert k1.startswith('conv16x3p<') and k0.startswith('conv16x3<'), (k1, k0)
+    for x1, x0 in ((a1, a0), (b1, b0)):
+        assert float((x1 - x0).abs().max()) <= 2e-6 * float(x0.abs().max())
+    xr = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    gx, = torch.autograd.grad(tf_ops.conv2d_same(xr, w.cpu().double(), 2), [xr], gy.cpu().double())
+    assert relerr(a1, gx) <= 3e-6
 
 
 @pytest.mark.parametrize('case', [(24, 128, 32, 32, 128, 3, 1), (96, 128, 16, 16, 256, 3, 1), (384, 128, 8, 8, 128, 3, 1)],

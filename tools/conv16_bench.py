@@ -14,14 +14,20 @@ SHAPES = [(192, 1024, 8, 8, 1024, 3, 1), (192, 128, 64, 64, 128, 3, 1), (192, 25
 RESNET = [(192, 128, 32, 32, 128, 3, 1), (192, 128, 32, 32, 128, 4, 2), (192, 128, 16, 16, 128, 3, 1), (192, 128, 16, 16, 128, 4, 2),
           (192, 128, 8, 8, 128, 3, 1), (64, 128, 32, 32, 128, 3, 1), (64, 128, 16, 16, 128, 3, 1), (64, 128, 8, 8, 128, 3, 1),
           (384, 128, 8, 8, 128, 3, 1), (128, 128, 8, 8, 128, 3, 1), (128, 128, 16, 16, 128, 3, 1), (320, 128, 32, 32, 128, 3, 1)]
+# the stride-2 layers of the headline (folded ConvMeanPool / UpsampleConv, 4x4 stride 2) at the row counts of the step
+S2 = [(192, 128, 32, 32, 128, 4, 2), (128, 128, 32, 32, 128, 4, 2), (64, 128, 32, 32, 128, 4, 2), (320, 128, 32, 32, 128, 4, 2),
+      (192, 128, 16, 16, 128, 4, 2), (128, 128, 16, 16, 128, 4, 2), (64, 128, 16, 16, 128, 4, 2), (320, 128, 16, 16, 128, 4, 2),
+      (128, 128, 8, 8, 128, 4, 2), (320, 128, 8, 8, 128, 4, 2)]
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f16'
 if len(sys.argv) > 2 and sys.argv[2] == 'resnet':
     SHAPES = RESNET
+if len(sys.argv) > 2 and sys.argv[2] == 's2':
+    SHAPES = S2
 if dt == 'f32':
     dt = None
 
 
-def timed(fn, reps=20):
+def timed(fn, reps=50):
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
