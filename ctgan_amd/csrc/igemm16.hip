@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include <utility>
 
@@ -1700,8 +1701,9 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
             if (op == CTGAN_CONV_DGRAD && pq % 32 == 0 && (q == 8 || q == 16) && t128 >= 192) return 1;
         }
         // the slice kernel: forward 130-146 against 101-125 TFLOP/s from 128 tiles of 128x128, four-phase data gradient from 192
-        // (forward from 128 tiles: the 64-row launches of the penalty's double backward - 13.60 against 13.67 ms per iteration with 192)
-        return t128 >= (op == CTGAN_CONV_FWD ? 128 : 192) ? 1 : 0;
+        // (forward from 96 tiles: the 64-row launches of the penalty's double backward on 32x32 inputs - 13.60 against 13.67 ms per iteration
+        // with 192 - and the 192-row trunk forward on 16x16 inputs, 113 against 96-102 TFLOP/s)
+        return t128 >= (op == CTGAN_CONV_FWD ? 96 : 192) ? 1 : 0;
     }
     P16 p{};
     p.nph = 1; p.stride = d->stride;
@@ -2062,7 +2064,34 @@ struct G16Plan {
     bool col[CTGAN_WGRAD_GROUP_LIMIT];                                   // problem i rides the column kernel
     int chunk[CTGAN_WGRAD_GROUP_LIMIT][CTGAN_WGRAD_MAX_SEGS];
 };
+void group16_plan_compute(const ctgan_wgrad_group* groups, int n, int mma, G16Plan* plan);
+// The plan of a job table is a pure function of its geometry, and a training loop presents the same two or three tables for ever: the last
+// eight plans are kept per thread (the column kernel's planner simulates a list schedule over a grid of target times - 0.4 ms of host
+// time per call, which an eager (un-graphed) step would pay at every flush).
 void group16_plan(const ctgan_wgrad_group* groups, int n, int mma, G16Plan* plan) {
+    constexpr int PER = 16 + CTGAN_WGRAD_MAX_SEGS, SLOTS = 8;
+    struct Entry { int len; int key[2 + CTGAN_WGRAD_GROUP_LIMIT * PER]; G16Plan plan; };
+    static thread_local Entry cache[SLOTS];
+    static thread_local int used = 0, next = 0;
+    static thread_local int key[2 + CTGAN_WGRAD_GROUP_LIMIT * PER];
+    int len = 0;
+    key[len++] = n; key[len++] = mma;
+    for (int i = 0; i < n; ++i) {
+        const ctgan_conv_desc& d = groups[i].d;
+        const long long hi = (d.xs[0] | d.xs[1] | d.xs[2] | d.xs[3]) >> 31;      // (strides beyond 2^31 elements are outside every kernel here)
+        const int f[16] = {d.C, d.H, d.W, d.K, d.R * 64 + d.S, d.P, d.Q, d.stride * 4 + (d.x_up ? 2 : 0) + (groups[i].db ? 1 : 0), d.pad_t, d.pad_l,
+                           groups[i].nseg, (int)(hi != 0), (int)d.xs[0], (int)d.xs[1], (int)d.xs[2], (int)d.xs[3]};
+        for (int k = 0; k < 16; ++k) key[len++] = f[k];
+        for (int k = 0; k < CTGAN_WGRAD_MAX_SEGS; ++k) key[len++] = k < groups[i].nseg ? groups[i].Ns[k] : 0;
+    }
+    for (int s = 0; s < used; ++s)
+        if (cache[s].len == len && memcmp(cache[s].key, key, (size_t)len * sizeof(int)) == 0) { *plan = cache[s].plan; return; }
+    group16_plan_compute(groups, n, mma, plan);
+    Entry& e = cache[next];
+    e.len = len; memcpy(e.key, key, (size_t)len * sizeof(int)); e.plan = *plan;
+    next = (next + 1) % SLOTS; if (used < SLOTS) ++used;
+}
+void group16_plan_compute(const ctgan_wgrad_group* groups, int n, int mma, G16Plan* plan) {
     const double px_us = mma == CTGAN_MMA_F32X3 ? 0.07 : 0.02;        // one MFMA per product instead of six, 64-pixel slices
     // column-kernel problems
     ctgan_wc_problem wc[CTGAN_WGRAD_GROUP_LIMIT * CTGAN_WGRAD_MAX_SEGS];

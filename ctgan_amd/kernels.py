@@ -678,13 +678,15 @@ def conv_wgrad_group(groups):
             check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 3, _stream()), 'conv2d16_wgrad_group')
         else:
             st = torch.cuda.current_stream()
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             # ONE launch per bracket: this launch is hundreds of microseconds long (the ~10 us of event overhead is 3 %), and repeated back
             # to back it runs 15 % slower than in the step - the sustained MFMA stream pulls the clock down (410 vs 333 us, round 4)
             # (the two kernels of a mixed call - filter-column and slice - in brackets of their own, each under its own device symbol)
             fl = [_conv_flops(groups[i][1], sum(sg[0].shape[0] for sg in groups[i][0])) for i in x3]
             for which in (0, 1):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                # (a spin of ~0.1 ms in front of the bracket: the host has recorded e0 and submitted the launch before the device gets there -
+                # on an idle queue the bracket would include the host's submission time)
+                torch.cuda._sleep(200000)
                 e0.record(st)
                 check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1 | (16 << which), _stream()), 'conv2d16_wgrad_group')
                 e1.record(st)
