@@ -196,7 +196,7 @@ def _packed16(w, d, op, g, mode):
     return ent[0]
 
 
-PACK_BATCH_MAX_ELEMS = 1 << 20      # 16-bit elements per image (all planes)
+PACK_BATCH_MAX_ELEMS = 1 << 21      # 16-bit elements per image (all planes; the folded 4x4x128x128 filters with their fragment image: 1.57 M)
 
 
 def prepare_packs():
