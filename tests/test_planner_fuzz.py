@@ -2,8 +2,8 @@
 job tables - 1-3 segments per filter, tiny and huge row counts, odd image sizes, channel counts on and off the tile grid - each call
 under a hard timeout in a child process.  A planner that spins (round 3: `multi_plan` in csrc/igemm.hip never returned for more segments
 than planned splits) shows up here as a timeout instead of a hung GPU suite.  Also checks the invariants callers rely on: the grouped
-query is deterministic, monotone in what it covers (slabs for every split fit), and agrees between a group of one and the same problem
-inside a larger group's total."""
+query is deterministic (also through the per-thread memo of the last eight tables), monotone in what it covers (slabs for every split
+fit), and agrees between a group of one and the same problem inside a larger group's total."""
 import ctypes
 import multiprocessing as mp
 import random
@@ -35,6 +35,7 @@ def _worker(seed, n_iter, q):
     from ctgan_amd._lib import WgradGroup, lib
     rng = random.Random(seed)
     done = 0
+    seen = []
     try:
         for it in range(n_iter):
             ng = rng.randint(1, 12)
@@ -86,6 +87,11 @@ def _worker(seed, n_iter, q):
                     d = arr[i].d
                     need += arr[i].nseg * 4 * (d.R * d.S * d.C + (1 if arr[i].db else 0)) * d.K
                 assert tot >= need, (tot, need)
+                # plans are memoised per thread (eight tables): an earlier table asked again, between other tables, must get its own answer
+                seen.append((sub, len(members), mma, tot))
+                for sub0, n0, mma0, tot0 in rng.sample(seen, min(2, len(seen))):
+                    assert lib.ctgan_conv2d16_wgrad_group_workspace_bytes(sub0, n0, mma0) == tot0, 'stale or colliding memoised plan'
+                del seen[:-24]
             done += 1
         q.put(('ok', seed, done, None))
     except Exception as e:      # noqa: BLE001
