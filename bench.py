@@ -623,10 +623,15 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
     finally:
         trainer.world = saved_world
     agg = {}
+    wide = {}          # few-channel kernels (csrc/fewch.hip) stream the wide tensor once: they are rated against HBM, not against a matrix pipe
     for name, flops, e0, e1, reps, _shape, sym in prof:
         a = agg.setdefault(sym, [0, 0.0, 0.0, set()])
         a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
         a[3].add(name.replace(',ph4', '').split(',split')[0].rstrip('>') + ('>' if '<' in name else ''))
+        if name.startswith('fewch') and len(_shape) == 8:
+            n_, c_, h_, w_, k_, _r, st_, _up = _shape
+            px = (h_ // st_) * (w_ // st_) if k_ > c_ else h_ * w_          # pixels of the wide side (output grid when it is the output)
+            wide[sym] = wide.get(sym, 0.0) + 4.0 * n_ * px * max(c_, k_)
     if not agg:
         return None
     total_t = sum(a[2] for a in agg.values())
@@ -675,7 +680,11 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
                              'note': 'mixed pipes: see by_pipe for the roofline fractions'},
         'by_kernel': {k: {'launches': v[0], 'avg_launch_us': round(v[2] / v[0] * 1e6, 2), 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3),
                           'frac': round(v[1] / v[2] / 1e12 / PIPE_PEAK[pipe_of(sorted(v[3])[0])], 4), 'pipe': pipe_of(sorted(v[3])[0]),
-                          'variant': sorted(v[3]), 'traffic': traffic_of(k, v[1] / v[0])}
+                          'variant': sorted(v[3]), 'traffic': traffic_of(k, v[1] / v[0]),
+                          **({'hbm': {'wide_tensor_bytes_per_launch': round(wide[k] / v[0]), 'achieved_GBps': round(wide[k] / v[2] / 1e9, 1),
+                                      'peak_GBps': 8000.0, 'frac': round(wide[k] / v[2] / 8e12, 4),
+                                      'note': 'HBM-bound kernel: bytes of the wide (128-channel) tensor / time; the MFMA fraction above does not bound it'}}
+                             if k in wide else {})}
                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
         'note': 'by_kernel keys are device symbols: look them up in profiles/r04_kernel_stats_resnet_*.txt / r04_steady_state_resnet_*.txt '
                 '(tools/roofline_crosscheck.py prints both side by side)',
