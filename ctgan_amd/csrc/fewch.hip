@@ -700,7 +700,10 @@ static bool m2f_ring_ok(const M2FParams& p, int R, int S) {
 
 template <int JS>
 static int launch_m2f_ring(M2FParams p, hipStream_t st) {
-    p.dbg = 0;
+#ifndef M2F_DBG
+#define M2F_DBG 0      // diagnosis builds (tools/build_variant.sh): 1 = no row loads, 2 = no arithmetic (results are then wrong by design)
+#endif
+    p.dbg = M2F_DBG;
     p.band = p.P >= 8 ? 8 : p.P;                                      // strip rows per workgroup
     const int strips = (p.P + p.band - 1) / p.band;
     const size_t smem = (size_t)RING_SLOTS * (p.W + 2) * 128 * 4 + (size_t)p.band * JS * p.W * 4 + (size_t)9 * JS * 128 * 4;
