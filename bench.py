@@ -583,7 +583,7 @@ def load_pmc_traffic():
     """profiles/r03_pmc_traffic_x3.json (tools/pmc_x3.sh: separate rocprofv3 --pmc passes, gfx950 corrections of the guide) + the
     round-1 files of the fp32 tiles, keyed by device symbol."""
     out = {}
-    for fn in ('r03_pmc_traffic_x3.json', 'r04_pmc_wgrad_col.json'):      # (round 4: the filter-column weight-gradient kernel, tools/pmc_wgrad_col.sh)
+    for fn in ('r03_pmc_traffic_x3.json', 'r04_pmc_traffic_x3.json', 'r04_pmc_wgrad_col.json'):      # (later files override earlier ones per symbol; the last: tools/pmc_wgrad_col.sh)
         try:
             for sym, rec in json.load(open(os.path.join(ROOT, 'profiles', fn))).items():
                 if isinstance(rec, dict) and 'hbm_bytes_per_launch' in rec and 'flops_per_launch' in rec:

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TN == 1 ? 4
     const unsigned a_voff = (unsigned)lane * 16u;
     // this wave's filter stream: steps 8 * pa .. 8 * pa + 7 of every chunk of its 32-channel block (16 steps of 6 KB per chunk)
     unsigned a_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(((long long)((n0 >> 5) + kb) * nch * 16 + 8 * pa) * 6144));
-    u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
+    constexpr int DIST = TN == 2 ? 2 : 1, NSET = 2 * DIST;      // filter fragments DIST steps ahead (the 32-position tile runs four waves per SIMD on 128 registers: one)
+    u32x4 fa[NSET][2][NP];                                // [register set][k step][plane]
     auto loadA = [&](auto setc, unsigned soff) __attribute__((always_inline)) {
         constexpr int SET = decltype(setc)::value;
 #pragma unroll
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TN == 1 ? 4
 
     load_patch(0);
     loadA(set0{}, a_base);
+    if constexpr (DIST == 2) loadA(std::integral_constant<int, 1>{}, a_base + 6144u);
     for (int c = 0; c < nch; ++c) {
         store_patch();
         if (c + 1 < nch) load_patch(c + 1);                // in flight during this chunk's steps
@@ -132,9 +134,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TN == 1 ? 4
         // step S = 4 * b + 2 * t + u of phase (a, b): dy (i - pad_t[a] + t, j - pad_l[b] + u), pad_t = pad_l = {1, 0} (phase_geom of
         // R = S = 4, pad 1) = patch (i - row0 + a + t, j + b + u)
         s2_static_for<8>([&](auto sc) __attribute__((always_inline)) {
-            constexpr int S = decltype(sc)::value, B = S >> 2, T = (S >> 1) & 1, U = S & 1, CUR = S & 1;
-            if (S < 7) loadA(std::integral_constant<int, CUR ^ 1>{}, a_base + (unsigned)((S + 1) * 6144));
-            else if (more) loadA(std::integral_constant<int, CUR ^ 1>{}, a_base + 16u * 6144u);
+            constexpr int S = decltype(sc)::value, B = S >> 2, T = (S >> 1) & 1, U = S & 1, CUR = S % NSET, NXT = (S + DIST) % NSET;
+            // (one step ahead left the waves parked 49 % of the time - PMC, profiles/r04_pmc_traffic_x3.json: a step is 24 MFMAs = 0.4 us,
+            // less than an L2 round trip under load)
+            if (S + DIST < 8) loadA(std::integral_constant<int, NXT>{}, a_base + (unsigned)((S + DIST) * 6144));
+            else if (more) loadA(std::integral_constant<int, NXT>{}, a_base + (unsigned)((16 + S + DIST - 8) * 6144));
             const int tap_off = (T * pg.PW + (B + U)) * LDS_K;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""gpurun_out/pmc_x3/counters_*.csv + info.json -> the JSON bench.py reads (profiles/r03_pmc_traffic_x3.json), keyed by device symbol.
+"""gpurun_out/pmc_x3/counters_*.csv + info.json -> the JSON bench.py reads (profiles/r04_pmc_traffic_x3.json; round 3: r03_...), keyed by device symbol.
 HBM bytes per launch = 2 x FETCH_SIZE (the guide's gfx950 correction: rocprofv3 tallies 128-B requests of wide coalesced reads at
 64 B) + WRITE_SIZE, both reported in KB by rocprofv3; SQ counters are summed over all shader engines."""
 import collections
@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, 'counters_*.csv')):
     for r in csv.DictReader(open(f)):
         k = r.get('Kernel_Name', '')
-        m = re.search(r'((conv16x3hf|conv16x3h|conv16|wgrad16_group|wgrad16|igemm_wgrad_pipe_group)_kernel<[^>]*>)', k)
+        m = re.search(r'((conv16x3hf|conv16x3h|conv16x3p|conv16|wgrad16_group|wgrad16|igemm_wgrad_pipe_group)_kernel<[^>]*>)', k)
         if m:
             agg[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {'_how': 'tools/pmc_x3.sh on one MI355X: separate rocprofv3 --kernel-trace --pmc passes per counter group; means over the launches '

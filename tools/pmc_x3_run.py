@@ -45,8 +45,8 @@ case('fwd', 192, 128, 32, 128, 3, 1, relu=False)      # conv16x3hf_kernel<false,
 case('fwd', 192, 128, 16, 128, 3, 1, relu=True)       # conv16x3hf_kernel<true, 2>: 16x16 images on 64-pixel tiles (the critic's relu-on-load convs)
 case('fwd', 384, 128, 8, 128, 3, 1, relu=True)        # conv16x3hf_kernel<true, 1>: the 384-row shared tail forward on 32-pixel tiles
 case('dgrad', 192, 128, 8, 128, 3, 1)                 # conv16x3hf_kernel<false, 1>: the main pass's 8x8 data gradients
-case('dgrad', 128, 128, 32, 128, 4, 2)                # conv16_kernel<3, 2, 2, 32, false, false>: four-phase data gradient of the folded ConvMeanPool, 1024 tiles
+case('dgrad', 128, 128, 32, 128, 4, 2)                # conv16x3p_kernel<2> (round 4): four-phase data gradient of the folded ConvMeanPool, 512 workgroups of eight waves
+case('dgrad', 128, 128, 16, 128, 4, 2)                # conv16x3p_kernel<1>: the same on an 8x8 dy grid, 32-position tiles
 case('fwd', 192, 128, 32, 128, 4, 2, relu=True)       # conv16_kernel<3, 2, 1, 32, true, false>: its forward at 192 rows on 128-kout x 64-pixel tiles
-case('wgrad', 128, 128, 32, 128, 4, 2, relu=True)     # wgrad16_kernel<3, 2, 2, true>
-case('wgrad', 128, 128, 16, 128, 3, 1, relu=False)    # wgrad16_kernel<3, 2, 2, false>
+# (weight gradients: tools/pmc_wgrad_col.sh on the step's grouped job table)
 print(json.dumps(info))
