@@ -247,3 +247,51 @@ def test_lsun128_full_width_f16_batch16_with_loss_scale_vs_oracle():
                        'losses': {k: out[k].item() for k in ('cost', 'wgan_only', 'ct', 'gp')}}, f, indent=1)
     finally:
         lib.delete_all_params(); M.configure()
+
+
+@pytest.mark.gpu
+def test_lsun128_full_width_f16_batch64_size_independent_properties():
+    """BASELINE.json configs[4] at its FULL size (reference widths, B = 64), where the fp64 oracle does not finish in seconds: the
+    properties of the path that do not depend on the size, through the fp16 kernels.
+    (i) Batch-split invariance: the samples of a critic batch are independent (Layernorm is per sample), and no kernel's summation
+        order depends on the batch size - the critic on 64 generated images equals the critic on its two halves, bit for bit.
+    (ii) Adjointness and linearity of the largest layers (3x3 on 64x64x128 and 8x8x1024, the 3x3 stride-2 'down' conv 128 -> 256): with
+        operands that are exactly representable in fp16 the kernels' products are exact, so <conv(x), y> and <x, conv^T(y)> agree to
+        fp32 summation error, and the data gradient is linear in dy to the same error."""
+    import ctgan_amd.gan_lsun128 as M
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    lib.delete_all_params(); lib.set_device(None)
+    B = 64
+    M.configure(BATCH_SIZE=B)
+    try:
+        lib.set_seed(5)
+        M.build_params('cuda')
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad(), K.mma_dtype('f16'):
+            x = M.Generator(B, noise=torch.randn(B, 128, generator=g).cuda())
+            u = [torch.rand(B, *s, generator=g).cuda() for s in M.feat_shapes()]
+            d, f = M.Discriminator(x, 0.8, 0.5, 0.5, u=u)
+            parts = [M.Discriminator(x[i:i + 32], 0.8, 0.5, 0.5, u=[t[i:i + 32] for t in u]) for i in (0, 32)]
+            assert torch.isfinite(d).all() and torch.isfinite(f).all()
+            assert torch.equal(d, torch.cat([p[0] for p in parts])) and torch.equal(f, torch.cat([p[1] for p in parts]))
+
+            def q(t):       # values with 8 significant bits: exact in fp16, and so are their pairwise products in fp32
+                return (t * 16).round().clamp(-120, 120) / 64
+            for (C, H, Ko, k, st) in [(128, 64, 128, 3, 1), (1024, 8, 1024, 3, 1), (128, 64, 256, 3, 2)]:
+                geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+                xx = K.empty_cl(B, C, H, H, 'cuda').copy_(q(torch.randn(B, C, H, H, generator=g)).cuda())
+                w = q(torch.randn(k, k, C, Ko, generator=g)).cuda()
+                gy1 = K.empty_cl(B, Ko, geom.P, geom.Q, 'cuda').copy_(q(torch.randn(B, Ko, geom.P, geom.Q, generator=g)).cuda())
+                gy2 = K.empty_cl(B, Ko, geom.P, geom.Q, 'cuda').copy_(q(torch.randn(B, Ko, geom.P, geom.Q, generator=g)).cuda())
+                y = K.conv_fwd(xx, w, None, geom)
+                assert K.last_kernel().startswith('conv16<'), K.last_kernel()
+                gx1 = K.conv_dgrad(gy1, w, geom, B)
+                lhs, rhs = (y.double() * gy1.double()).sum().item(), (xx.double() * gx1.double()).sum().item()
+                scale = (y.double().abs() * gy1.double().abs()).sum().item()
+                assert abs(lhs - rhs) <= 2e-6 * scale, ((C, H, Ko, k, st), lhs, rhs, scale)
+                gx2 = K.conv_dgrad(gy2, w, geom, B)
+                gxs = K.conv_dgrad(gy1 + gy2, w, geom, B)       # (sums of two 8-bit values: still exact in fp16)
+                assert float((gxs - (gx1 + gx2)).abs().max()) <= 2e-6 * float(gxs.abs().max())
+    finally:
+        lib.delete_all_params(); M.configure()
