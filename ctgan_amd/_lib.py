@@ -184,6 +184,8 @@ SIGNATURES = {
     'ctgan_critic_prep': (c_int, [_p, _p, c_int32, c_int32, c_uint64, c_uint64, c_uint64, _p, c_float, c_float, c_float, _p, _p, _p]),
     'ctgan_rows_cat_dropout': (c_int, [_p, c_int64, c_int64, c_int64, c_float, c_uint64, c_uint64, _p, _p, _p]),
     'ctgan_rows_cat_bwd': (c_int, [_p, c_int64, c_int64, c_int64, _p, _p]),
+    'ctgan_rows_cat_bwd2': (c_int, [_p, c_int64, c_int64, c_int64, c_int64, _p, _p]),
+    'ctgan_gp_bwd_mean': (c_int, [_p, _p, _p, c_int32, c_int32, c_float, _p, _p, _p, _p]),
     'ctgan_rows_gather_dropout': (c_int, [_p, POINTER(RowSegment), c_int32, c_int64, c_uint64, _p, _p, _p]),
 }
 

@@ -1722,8 +1722,17 @@ int ctgan_conv2d_dgrad_ex(const ctgan_conv_desc* d, const float* dy, const float
     p.relu = 0;
     p.phases = 1;
     p.resid_up = 0;
-    if (ext && ext->n_ranges > 0) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: dropout row ranges are a forward-only option");
-    set_drop(p, ext);
+    // Row ranges (round 5: the merged backward of a critic step carries the main rows and the gradient-penalty rows in ONE data gradient,
+    // each range with the mask of its own forward dropout): stride-1 form on a dense channels-last dx, boundaries on 128-pixel tiles.
+    if (ext && ext->n_ranges > 0) {
+        if (ext->n_ranges > CTGAN_DROP_RANGES || d->stride != 1 || d->xs[1] != 1 || d->xs[3] != d->C || d->xs[2] != (long long)d->W * d->C ||
+            d->xs[0] != (long long)d->H * d->W * d->C)
+            return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: dropout row ranges need stride 1, a dense channels-last dx and <= %d ranges", CTGAN_DROP_RANGES);
+        for (int i = 0; i + 1 < ext->n_ranges; ++i)
+            if (((long long)ext->range_end[i] * d->H * d->W) % 128)
+                return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: dropout row ranges must start at multiples of 128 pixels");
+    }
+    set_drop(p, ext, d->H * d->W, (long long)d->H * d->W * d->C);
     const size_t need = dgrad_filter_elems(d) * sizeof(float);
     const bool pre = (flags & CTGAN_DGRAD_W_REPACKED) != 0;
     const bool repack = !pre && ws && ws_bytes >= need && (d->C % 4 == 0) && (d->K % 32 == 0);

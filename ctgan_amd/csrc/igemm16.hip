@@ -1924,17 +1924,36 @@ int ctgan_conv2d16_dgrad_ex(const ctgan_conv_desc* d, int mma, const float* dy, 
     }
     p.M = d->N * p.P * p.Q;
     hipStream_t st = (hipStream_t)stream;
-    if (ext && ext->n_ranges > 0) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad_ex: sample ranges are a forward-only epilogue");
-    if (ext && ext->drop_keep > 0.f && ext->drop_keep < 1.f) {
+    const bool ranged = ext && ext->n_ranges > 0;
+    bool range_drop = false;
+    if (ranged)
+        for (int i = 0; i < ext->n_ranges && i < CTGAN_DROP_RANGES; ++i) range_drop = range_drop || (ext->range_keep[i] > 0.f && ext->range_keep[i] < 1.f);
+    if (range_drop || (ext && !ranged && ext->drop_keep > 0.f && ext->drop_keep < 1.f)) {
         // the data gradient multiplied by a dropout mask (the mask of the dropout whose result the forward conv consumed), as
         // ctgan_conv2d_dgrad_ex: only the halo-patch kernels have the dropout epilogue, on a dense channels-last dx
         const bool dense = d->xs[1] == 1 && d->xs[3] == d->C && d->xs[2] == (int64_t)d->W * d->C && d->xs[0] == (int64_t)d->H * d->W * d->C;
         if (mma != CTGAN_MMA_F32X3 || g.nph != 1 || !dense || !halo_takes(p))
             return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad_ex: epilogue dropout outside the halo-patch form");
-        p.drop = 1; p.drop_keep = ext->drop_keep; p.drop_seed = ext->drop_seed; p.drop_sid = (unsigned)ext->drop_stream_id;
+        p.drop = 1; p.drop_keep = ranged ? 1.f : ext->drop_keep; p.drop_seed = ext->drop_seed; p.drop_sid = ranged ? 0u : (unsigned)ext->drop_stream_id;
         p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
         p.drop_nr = 0;
         for (int i = 0; i < CTGAN_DROP_RANGES; ++i) { p.drop_mend[i] = 0x7fffffff; p.drop_rkeep[i] = 1.f; p.drop_rsid[i] = 0; p.drop_roff[i] = 0; }
+        if (ranged) {
+            // sample ranges of dx, each with the mask of its own forward dropout (the merged backward of a critic step, round 5): as in the
+            // forward, boundaries on 128-pixel tiles, Philox indices relative to the range's first element
+            if (ext->n_ranges > CTGAN_DROP_RANGES) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad_ex: more than %d sample ranges", CTGAN_DROP_RANGES);
+            p.drop_nr = ext->n_ranges;
+            long long start = 0;
+            for (int i = 0; i < p.drop_nr; ++i) {
+                if (i + 1 < p.drop_nr && ((long long)ext->range_end[i] * d->H * d->W) % 128)
+                    return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_dgrad_ex: dropout row ranges must start at multiples of 128 pixels");
+                p.drop_mend[i] = (int)((long long)ext->range_end[i] * d->H * d->W);
+                p.drop_rkeep[i] = (ext->range_keep[i] > 0.f && ext->range_keep[i] < 1.f) ? ext->range_keep[i] : 1.f;
+                p.drop_rsid[i] = (unsigned)ext->range_stream_id[i];
+                p.drop_roff[i] = start * (long long)d->H * d->W * d->C;
+                start = ext->range_end[i];
+            }
+        }
         return launch_conv16x3h(p, st);
     }
     return run_conv16(mma, p, st);

@@ -50,6 +50,32 @@ __global__ void gp_bwd_kernel(const float* __restrict__ g, const float* __restri
     }
 }
 
+// gp_bwd_kernel + the penalty's value: block 0 also takes gp = lambda * mean((slopes - 1)^2) (b values) and adds it into out5[0] (cost) and
+// out5[4] (wgan + ct + gp) - the two sums of ctgan_tail_critic_heads_fwd that contain the penalty.  For the hand-scheduled critic step
+// (round 5), whose loss heads run BEFORE the penalty's gradient exists: no extra launch for a number only the log reads.
+__global__ void gp_bwd_mean_kernel(const float* __restrict__ g, const float* __restrict__ slopes, const float* __restrict__ gout,
+                                   int b, int d, float lambda, float* __restrict__ gg, float* __restrict__ gp, float* __restrict__ out5) {
+    const long long total = (long long)b * d;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float go = gout[0];
+    if (blockIdx.x == 0) {
+        __shared__ float sh[4];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < b; i += 256) { const float t = slopes[i] - 1.f; s += t * t; }
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) {
+            const float v = lambda * s / (float)b;
+            if (gp) gp[0] = v;
+            if (out5) { out5[0] += v; out5[4] += v; }
+        }
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const float s = slopes[i / d];
+        const float coef = s > 0.f ? go * lambda * 2.f * (s - 1.f) / (s * (float)b) : 0.f;
+        gg[i] = coef * g[i];
+    }
+}
+
 // CT_i = l2*(d-d_)^2 + 0.1*l2*mean_j (f-f_)^2
 __global__ __launch_bounds__(256) void ct_rows_kernel(const float* __restrict__ d, const float* __restrict__ d_,
                                                       const float* __restrict__ f, const float* __restrict__ f_, int nf,
@@ -627,6 +653,14 @@ int ctgan_gp_bwd(const float* g, const float* slopes, const float* gout, int32_t
     hipLaunchKernelGGL(gp_bwd_kernel, dim3(ctgan_blocks((long long)b * d, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(s), g, slopes, gout, b, d, lambda, gg);
     return ctgan_check_launch("gp_bwd");
+}
+
+int ctgan_gp_bwd_mean(const float* g, const float* slopes, const float* gout, int32_t b, int32_t d, float lambda, float* gg, float* gp,
+                      float* out5, ctgan_stream_t s) {
+    if (!g || !slopes || !gout || !gg || b <= 0 || d <= 0) return ctgan_fail(CTGAN_E_BADARG, "gp_bwd_mean: bad argument");
+    hipLaunchKernelGGL(gp_bwd_mean_kernel, dim3(ctgan_blocks((long long)b * d, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(s), g, slopes, gout, b, d, lambda, gg, gp, out5);
+    return ctgan_check_launch("gp_bwd_mean");
 }
 
 int ctgan_ct_fwd(const float* d, const float* d_, const float* f, const float* f_, int32_t b, int32_t nf, float lambda2,

@@ -9,26 +9,29 @@ using namespace ctgan_philox;
 // theta -= lr_t*m/(sqrt(v)+eps)    (eps outside the bias correction, unlike torch.optim.Adam)
 // one element of the update; contraction off, so that every kernel that inlines it (plain, step-end, packed; scalar or 4-wide)
 // rounds identically - the fused forms are tested bit-for-bit against the separate launches
-__device__ __forceinline__ void adam_elem(float& th, float& m, float& v, float graw, float gscale, float b1, float b2, float eps, float lr_t) {
+__device__ __forceinline__ void adam_elem(float& th, float& m, float& v, float graw, float gscale, float b1, float b2, float eps, float lr_t,
+                                          float* skipped) {
 #pragma clang fp contract(off)
     const float gi = graw * gscale;
     // A gradient element that is not finite (an overflow of the fp16 matrix-core mode under its fixed loss scale; a degenerate input)
     // leaves ITS weight and slots untouched: one inf would otherwise sit in m and v for good and turn theta into NaN - also at a learning
     // rate of 0, as in the warm-up passes of a graph capture (0 * inf).  Finite gradients take the unchanged path.
-    if (!(fabsf(gi) <= 3.0e38f)) return;
+    // The skip is COUNTED (state[3], a float accumulator: exact up to 2^24 elements, only touched on this branch) so that an overflowing
+    // or diverged run does not look healthy: FlatAdam.skipped() / bench.py / the training log read it back.
+    if (!(fabsf(gi) <= 3.0e38f)) { atomicAdd(skipped, 1.0f); return; }
     const float mi = b1 * m + (1.f - b1) * gi;
     const float vi = b2 * v + (1.f - b2) * gi * gi;
     m = mi; v = vi;
     th = th - lr_t * mi / (sqrtf(vi) + eps);
 }
 __global__ void adam_kernel(float* __restrict__ th, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, const float* __restrict__ state, float b1, float b2,
+                            float* __restrict__ v, long long n, float* state, float b1, float b2,
                             float eps, float gscale) {
     const float lr = state[0], b1p = state[1], b2p = state[2];
     const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        adam_elem(th[i], m[i], v[i], g[i], gscale, b1, b2, eps, lr_t);
+        adam_elem(th[i], m[i], v[i], g[i], gscale, b1, b2, eps, lr_t, state + 3);
 }
 __global__ void adam_advance_kernel(float* state, float b1, float b2) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { state[1] *= b1; state[2] *= b2; }
@@ -70,7 +73,7 @@ __global__ void pack_kernel(const PackTable t, float* __restrict__ flat) {
 // The flat bucket is still written - it is the gradient the caller reports and the tests read.  Same per-element arithmetic as
 // adam_kernel on the packed bucket (bit-identical results).
 __global__ void adam_packed_kernel(const PackTable t, float* __restrict__ flat, float* __restrict__ th, float* __restrict__ m,
-                                   float* __restrict__ v, const float* __restrict__ state, float b1, float b2, float eps, float gscale) {
+                                   float* __restrict__ v, float* state, float b1, float b2, float eps, float gscale) {
     const float lr = state[0], b1p = state[1], b2p = state[2];
     const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
     const float* src = t.src[blockIdx.y];
@@ -90,14 +93,14 @@ __global__ void adam_packed_kernel(const PackTable t, float* __restrict__ flat, 
             const float gv[4] = {gr.x, gr.y, gr.z, gr.w};
             float* mp = &mm.x; float* vp = &vv.x; float* tp = &tt.x;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) adam_elem(tp[k], mp[k], vp[k], gv[k], gscale, b1, b2, eps, lr_t);
+            for (int k = 0; k < 4; ++k) adam_elem(tp[k], mp[k], vp[k], gv[k], gscale, b1, b2, eps, lr_t, state + 3);
             m4[i] = mm; v4[i] = vv; th4[i] = tt;
         }
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             const float gr = src ? src[i] : 0.f;
             flat[off + i] = gr;
-            adam_elem(th[off + i], m[off + i], v[off + i], gr, gscale, b1, b2, eps, lr_t);
+            adam_elem(th[off + i], m[off + i], v[off + i], gr, gscale, b1, b2, eps, lr_t, state + 3);
         }
     }
 }
@@ -322,6 +325,23 @@ __global__ void rows_gather_dropout_kernel(const float* __restrict__ src, const 
     *reinterpret_cast<float4*>(dst + q * 4) = v;
 }
 // adjoint of the concat: gsrc[r] = g[r] + (r < n_extra ? g[n_src + r] : 0)
+// the same with n_pass rows behind the concat that pass straight through: g = [a (n_src) ; a' (n_extra) ; c (n_pass)] -> gsrc = [a + a' ; c]
+// (the merged backward of a critic step: rows [real, fake | real' | x_hat] of the tail -> rows [real, fake, x_hat] of the trunk)
+__global__ void rows_cat_bwd2_kernel(const float* __restrict__ g, long long n4_src, long long n4_extra, long long n4_pass, float* __restrict__ gsrc) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n4_src + n4_pass) return;
+    float4 v;
+    if (q < n4_src) {
+        v = *reinterpret_cast<const float4*>(g + q * 4);
+        if (q < n4_extra) {
+            const float4 w = *reinterpret_cast<const float4*>(g + (n4_src + q) * 4);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+    } else {
+        v = *reinterpret_cast<const float4*>(g + (n4_extra + q) * 4);
+    }
+    *reinterpret_cast<float4*>(gsrc + q * 4) = v;
+}
 __global__ void rows_cat_bwd_kernel(const float* __restrict__ g, long long n4_src, long long n4_extra, float* __restrict__ gsrc) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n4_src) return;
@@ -341,7 +361,7 @@ __global__ void rng_advance_kernel(uint64_t* ctr, uint64_t by) {
 
 extern "C" {
 
-int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, const float* state, float beta1,
+int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, float* state, float beta1,
                     float beta2, float eps, float grad_scale, ctgan_stream_t s) {
     if (!theta || !g || !m || !v || !state || n < 0) return ctgan_fail(CTGAN_E_BADARG, "adam_step: bad argument");
     if (n == 0) return CTGAN_OK;
@@ -372,7 +392,7 @@ int ctgan_step_advance(float* state, float beta1, float beta2, uint64_t* rng_ctr
     return ctgan_check_launch("step_advance");
 }
 int ctgan_adam_step_packed(const float* const* srcs, const int64_t* dst_offs, const int64_t* counts, int32_t n_tensors, float* flat,
-                           float* theta, float* m, float* v, const float* state, float beta1, float beta2, float eps, float grad_scale,
+                           float* theta, float* m, float* v, float* state, float beta1, float beta2, float eps, float grad_scale,
                            ctgan_stream_t s) {
     if (!srcs || !dst_offs || !counts || !flat || !theta || !m || !v || !state || n_tensors <= 0)
         return ctgan_fail(CTGAN_E_BADARG, "adam_step_packed: bad argument");
@@ -494,6 +514,15 @@ int ctgan_rows_gather_dropout(const float* src, const ctgan_row_segment* segs, i
     hipLaunchKernelGGL(rows_gather_dropout_kernel, dim3(ctgan_blocks(n4, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(s), src, t, n4,
                        seed, ctr, dst);
     return ctgan_check_launch("rows_gather_dropout");
+}
+int ctgan_rows_cat_bwd2(const float* g, int64_t n_src, int64_t n_extra, int64_t n_pass, int64_t row_elems, float* gsrc, ctgan_stream_t s) {
+    if (!g || !gsrc || n_src <= 0 || n_extra < 0 || n_extra > n_src || n_pass < 0 || row_elems <= 0 || (row_elems & 3) ||
+        ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gsrc)) & 15))
+        return ctgan_fail(CTGAN_E_BADARG, "rows_cat_bwd2: bad argument");
+    const long long n4_src = n_src * row_elems / 4, n4_extra = n_extra * row_elems / 4, n4_pass = n_pass * row_elems / 4;
+    hipLaunchKernelGGL(rows_cat_bwd2_kernel, dim3(ctgan_blocks(n4_src + n4_pass, 256, 1 << 20)), dim3(256), 0, static_cast<hipStream_t>(s), g,
+                       n4_src, n4_extra, n4_pass, gsrc);
+    return ctgan_check_launch("rows_cat_bwd2");
 }
 int ctgan_rows_cat_bwd(const float* g, int64_t n_src, int64_t n_extra, int64_t row_elems, float* gsrc, ctgan_stream_t s) {
     if (!g || !gsrc || n_src <= 0 || n_extra < 0 || n_extra > n_src || row_elems <= 0 || (row_elems & 3) ||

@@ -111,9 +111,7 @@ class GraphedTrainer:
         lib.bump_epoch('Discriminator' if self.batch_fakes else None)
         F.prepare_filters()
         t.rng.begin_step()
-        out = t.d_losses(real, labels, fake=fake)
-        with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], t.d_params, grad_outputs=t.cost_seed(out['cost']), allow_unused=True)
+        out, grads = t.d_grads(real, labels, fake=fake)
         self._finish(t.d_opt, grads)
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
 

@@ -53,13 +53,13 @@ def feat_shapes():
     return [(4 * D, 16, 16), (8 * D, 8, 8), (8 * D, 4, 4)]
 
 
-def Normalize(name, axes, inputs, relu=False):
-    """:87-92"""
+def Normalize(name, axes, inputs, relu=False, groups=1):
+    """:87-92 (+ build-only `groups`: independent BatchNorm statistic groups of a batched generator forward)"""
     if ('Discriminator' in name) and (cfg.MODE == 'wgan-ct'):
         if axes != [0, 2, 3]:
             raise Exception('Layernorm over non-standard axes is unsupported')
         return _ln.Layernorm(name, [1, 2, 3], inputs, relu=relu)      # ReLU fused into the Layernorm kernels
-    return _bn.Batchnorm(name, axes, inputs, fused=True, relu=relu)
+    return _bn.Batchnorm(name, axes, inputs, fused=True, relu=relu, groups=groups)
 
 
 def ConvMeanPool(name, input_dim, output_dim, filter_size, inputs, he_init=True, biases=True, resid=None):
@@ -77,7 +77,7 @@ def UpsampleConv(name, input_dim, output_dim, filter_size, inputs, he_init=True,
     return _conv2d.Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=he_init, biases=biases, x_up=True)
 
 
-def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=None, he_init=True):
+def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=None, he_init=True, groups=1):
     """:127-162 (Conv1 has no bias, :157)"""
     if resample not in (None, 'down', 'up'):
         raise Exception('invalid resample value')
@@ -89,30 +89,31 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
         shortcut = UpsampleConv(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
     else:
         shortcut = _conv2d.Conv2D(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
-    out = Normalize(name + '.BN1', [0, 2, 3], inputs, relu=True)
+    out = Normalize(name + '.BN1', [0, 2, 3], inputs, relu=True, groups=groups)
     if resample == 'up':
         out = UpsampleConv(name + '.Conv1', input_dim, output_dim, filter_size, out, he_init=he_init, biases=False)
-        out = Normalize(name + '.BN2', [0, 2, 3], out, relu=True)
+        out = Normalize(name + '.BN2', [0, 2, 3], out, relu=True, groups=groups)
         return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, he_init=he_init, resid=shortcut)
     out = _conv2d.Conv2D(name + '.Conv1', input_dim, input_dim, filter_size, out, he_init=he_init, biases=False)
-    out = Normalize(name + '.BN2', [0, 2, 3], out, relu=True)
+    out = Normalize(name + '.BN2', [0, 2, 3], out, relu=True, groups=groups)
     if resample == 'down':
         return ConvMeanPool(name + '.Conv2', input_dim, output_dim, filter_size, out, he_init=he_init, resid=shortcut)
     return _conv2d.Conv2D(name + '.Conv2', input_dim, output_dim, filter_size, out, he_init=he_init, resid=shortcut)
 
 
-def Generator(n_samples, noise=None, rng=None):
-    """GoodGenerator :204-221"""
+def Generator(n_samples, noise=None, rng=None, groups=1):
+    """GoodGenerator :204-221.  `groups` > 1 (build-only): that many generator calls in one batch, each with its own BatchNorm
+    statistics (dcgan_step.DCGANTrainer.generate_fakes)."""
     dim = cfg.DIM
     if noise is None:
         noise = rng.normal(n_samples, 128)
     out = _linear.Linear('Generator.Input', 128, 4 * 4 * 8 * dim, noise)
     out = F.to_channels_last(out.reshape(-1, 8 * dim, 4, 4))
-    out = ResidualBlock('Generator.Res1', 8 * dim, 8 * dim, 3, out, resample='up')
-    out = ResidualBlock('Generator.Res2', 8 * dim, 4 * dim, 3, out, resample='up')
-    out = ResidualBlock('Generator.Res3', 4 * dim, 2 * dim, 3, out, resample='up')
-    out = ResidualBlock('Generator.Res4', 2 * dim, 1 * dim, 3, out, resample='up')
-    out = Normalize('Generator.OutputN', [0, 2, 3], out, relu=True)
+    out = ResidualBlock('Generator.Res1', 8 * dim, 8 * dim, 3, out, resample='up', groups=groups)
+    out = ResidualBlock('Generator.Res2', 8 * dim, 4 * dim, 3, out, resample='up', groups=groups)
+    out = ResidualBlock('Generator.Res3', 4 * dim, 2 * dim, 3, out, resample='up', groups=groups)
+    out = ResidualBlock('Generator.Res4', 2 * dim, 1 * dim, 3, out, resample='up', groups=groups)
+    out = Normalize('Generator.OutputN', [0, 2, 3], out, relu=True, groups=groups)
     out = _conv2d.Conv2D('Generator.Output', 1 * dim, 3, 3, out, out_nchw=True)
     out = F.tanh(out)
     return out.reshape(-1, cfg.OUTPUT_DIM)

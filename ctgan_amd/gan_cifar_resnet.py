@@ -323,26 +323,27 @@ def _heads_fusable(rnd, rng):
 
 def shared_tail_forward(h_all, B, rng, with_clean):
     """Blocks 3-4 of the critic for every pass of a critic step in ONE set of forward launches (F.tape_record): rows of the
-    result are [real, fake, real' (dropout passes, specs `main`) | real, fake (clean pass, no dropout) | x_hat (gradient-penalty
-    pass, specs `gp`)], h_all = the shared trunk output [real ; fake ; x_hat].  Each range's dropout masks are those of its own
-    tensor (ctgan_epilogue_ext row ranges), so the passes replay rows of this forward and keep their separate backward graphs.
+    result are [real, fake, real' (dropout passes, specs `main`) | x_hat (gradient-penalty pass, specs `gp`) | real, fake (clean
+    pass, no dropout)], h_all = the shared trunk output [real ; fake ; x_hat].  Each range's dropout masks are those of its own
+    tensor (ctgan_epilogue_ext row ranges), so the passes replay rows of this forward and keep their separate backward graphs -
+    or (critic_schedule.py) share ONE backward over the leading 4B rows: the rows that carry a gradient come first.
     -> (tape, gp_specs, main_specs, ranges = {'main': (r0, r1), 'clean': ..., 'gp': ...})"""
     D = cfg.DIM_D
     kps = (0.8, 0.5, 0.5)
     gp_specs = tuple(F.drop_spec(rng, kp) for kp in kps)            # call-site order of the unshared step: GP pass first
     main_specs = tuple(F.drop_spec(rng, kp) for kp in kps)
     n_main, n_clean = 3 * B, (2 * B if with_clean else 0)
-    r_gp = n_main + n_clean
+    r_gp = n_main
+    r_clean = n_main + B
     segs = [(0, 2 * B, kps[0], main_specs[0][2], 0), (0, B, kps[0], main_specs[0][2], 0)]
-    if with_clean:
-        segs.append((0, 2 * B, 1.0, 0, n_main))
     segs.append((2 * B, B, kps[0], gp_specs[0][2], r_gp))
+    if with_clean:
+        segs.append((0, 2 * B, 1.0, 0, r_clean))
 
     def ranged(i):
-        rs = [(n_main, main_specs[i])]
+        rs = [(n_main, main_specs[i]), (r_gp + B, gp_specs[i])]
         if with_clean:
-            rs.append((r_gp, None))
-        rs.append((r_gp + B, gp_specs[i]))
+            rs.append((r_clean + n_clean, None))
         return {'ranges': rs}
 
     with torch.no_grad(), F.tape_record() as tape:
@@ -350,7 +351,7 @@ def shared_tail_forward(h_all, B, rng, with_clean):
         tape.append(tin)
         out = ResidualBlock('Discriminator.3', D, D, 3, tin, resample=None, out_epi={'out_drop': ranged(1)})
         ResidualBlock('Discriminator.4', D, D, 3, out, resample=None, out_epi={'out_drop': ranged(2), 'out_relu': True})
-    return tape, gp_specs, main_specs, {'main': (0, n_main), 'clean': (n_main, r_gp), 'gp': (r_gp, r_gp + B)}
+    return tape, gp_specs, main_specs, {'main': (0, n_main), 'clean': (r_clean, r_clean + n_clean), 'gp': (r_gp, r_gp + B)}
 
 
 def gradient_penalty_branch(interp, labels, rng, rnd=None, trunk_tape=None, tail_tape=None, specs=None, defer_mean=False):
@@ -512,6 +513,23 @@ class Trainer:
                    real=real, d_real=d_all[:B], d_fake=d_all[B:2 * B], gp_grads=grads)
         return out
 
+    def d_grads(self, real_int, labels, rnd=None, fake=None):
+        """Losses and parameter gradients of one critic step -> (out, grads aligned with self.d_params): compute_gradients(disc_cost) of
+        :335-336.  Default: the hand-scheduled step (critic_schedule.py - one backward chain over the rows of the dropout passes and of the
+        gradient-penalty pass); the autograd path (d_losses + torch.autograd.grad) wherever that schedule does not apply - injected draws
+        (parity mode), a Layernorm critic, widths outside the few-channel kernels, any fusion switch off."""
+        from . import critic_schedule as CS
+        if fake is None and rnd is None:
+            with torch.no_grad():      # (the draw d_losses would make first: same Philox call sites either way)
+                fake = Generator(cfg.BATCH_SIZE, labels, groups=2, rng=self.rng)
+        if CS.usable(_this_module(), rnd, self.rng, real_int, fake):
+            with torch.no_grad(), F.deferred_wgrads():
+                return CS.critic_step(self, _this_module(), real_int, labels, fake)
+        out = self.d_losses(real_int, labels, rnd, fake=fake)
+        with F.deferred_wgrads():
+            grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed(out['cost']), allow_unused=True)
+        return out, grads
+
     def g_losses(self, rnd=None):
         """Generator loss graph :314-330: two towers of GEN_BS_MULTIPLE*B/2 samples."""
         n = cfg.GEN_BS_MULTIPLE * cfg.BATCH_SIZE
@@ -573,9 +591,7 @@ class Trainer:
         """session.run([..., disc_train_op]) :402"""
         F.prepare_filters()
         self.rng.begin_step()
-        out = self.d_losses(real_int, labels, rnd, fake=fake)
-        with F.deferred_wgrads():
-            grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed(out['cost']), allow_unused=True)
+        out, grads = self.d_grads(real_int, labels, rnd, fake=fake)
         self._apply(self.d_opt, grads, iteration, set_lr)
         out['grads'] = dict(zip([n for n, _ in self.d_named], grads))
         return out
@@ -682,3 +698,8 @@ def train(data_dir, n_examples=50000, iters=None, out_dir='.', seed=2024, use_gr
 
 def _critic_piecewise_linear():
     return not cfg.NORMALIZATION_D
+
+
+def _this_module():
+    import sys
+    return sys.modules[__name__]

@@ -506,7 +506,7 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
         resid = match_layout(resid, dx)
     mode = _conv_mode(d, 1, drop is None and not fewch_handles(g))
     _x3_log(g, N, d, 1, drop=drop is not None)
-    if (mode is None and drop is not None and not isinstance(drop, dict) and g.stride == 1 and not fewch_handles(g)
+    if (mode is None and drop is not None and g.stride == 1 and not fewch_handles(g)
             and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID)) and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 1)):
         # the halo-patch kernels carry the fp32 family's epilogue dropout (same Philox draws at the same offsets)
         wp = _packed16(w, d, 1, g, 'f32x3')
@@ -536,7 +536,9 @@ def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, res
         except NotImplementedError:
             pass
     _timed(g, N, lambda: check(lib.ctgan_conv2d_dgrad(ctypes.byref(d), _ptr(gy), _ptr(filt), _ptr(bias), _ptr(mask), _ptr(resid), _ptr(dx), _ptr(ws_p), ws_n, fl, _stream()), 'conv2d_dgrad'))
-    return dx if drop is None else dropout_rng(dx, *drop)
+    if drop is None:
+        return dx
+    return _dropout_ranges(dx, drop) if isinstance(drop, dict) else dropout_rng(dx, *drop)
 
 
 def conv_wgrad(x, gy, g, with_bias=False, relu_x=False, out=None):
@@ -1246,6 +1248,19 @@ def gp_bwd(g, slopes, gout, lam):
     return gg
 
 
+def gp_bwd_mean(g, slopes, gout, lam, out5=None):
+    """gp_bwd + the penalty's value in the same launch: -> (gg, gp); with out5 (the five sums of tail_critic_heads_fwd evaluated WITHOUT
+    the penalty) gp is also added into out5[0] (cost) and out5[4] (wgan + ct + gp)."""
+    _need_dev(g, slopes, gout, out5)
+    g = g.contiguous()
+    B, D = g.shape
+    gg = torch.empty_like(g)
+    gp = torch.empty((), dtype=torch.float32, device=g.device)
+    assert out5 is None or (out5.is_contiguous() and out5.numel() == 5)
+    check(lib.ctgan_gp_bwd_mean(_ptr(g), _ptr(slopes), _ptr(gout.contiguous()), B, D, lam, _ptr(gg), _ptr(gp), _ptr(out5), _stream()), 'gp_bwd_mean')
+    return gg, gp
+
+
 def ct_fwd(d, d_, f, f_, lam2, M):
     _need_dev(d, d_, f, f_)
     d, d_, f, f_ = d.contiguous(), d_.contiguous(), f.contiguous(), f_.contiguous()
@@ -1443,12 +1458,17 @@ def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, s
     return out, f, d, a, ct_i, probs, None
 
 
-def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac):
-    """-> (gy like y: gradient w.r.t. the last block's pre-activation; gw_out, gb_out, gw_ac, gb_ac) - one launch."""
-    _need_dev(y, d, f, probs, labels, ct_i, gout, w_out, w_ac)
+def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac, out=None):
+    """-> (gy like y: gradient w.r.t. the last block's pre-activation; gw_out, gb_out, gw_ac, gb_ac) - one launch.
+    out: buffer for gy (y's shape, dense channels-last - e.g. the leading rows of a larger batch)."""
+    _need_dev(y, d, f, probs, labels, ct_i, gout, w_out, w_ac, out)
     n, hw, nf = _cl_rows(y)
     assert n == 3 * B and gout.is_contiguous() and gout.numel() in (1, 4)
-    gy = empty_cl(n, nf, y.shape[2], y.shape[3], y.device)
+    if out is not None:
+        assert tuple(out.shape) == tuple(y.shape) and _cl_rows(out) == (n, hw, nf)
+        gy = out
+    else:
+        gy = empty_cl(n, nf, y.shape[2], y.shape[3], y.device)
     gw_out = torch.empty_like(w_out); gb_out = torch.empty(1, dtype=torch.float32, device=y.device)
     ncls = w_ac.shape[1] if w_ac is not None else 0
     gw_ac = torch.empty_like(w_ac) if w_ac is not None else None
@@ -1485,12 +1505,16 @@ def gen_heads_bwd(y, probs, labels, gout, ac_scale, mask_scale, w_out, w_ac):
     return gy
 
 
-def gp_head_grad(y, w_out, mask_scale):
-    """gz = (y > 0) * w_out / hw * mask_scale  (dD/dz of D = mean_hw(relu(dropout(z))) . w_out)."""
-    _need_dev(y, w_out)
+def gp_head_grad(y, w_out, mask_scale, out=None):
+    """gz = (y > 0) * w_out / hw * mask_scale  (dD/dz of D = mean_hw(relu(dropout(z))) . w_out); out: buffer for gz (as tail_heads_bwd)."""
+    _need_dev(y, w_out, out)
     n, hw, nf = _cl_rows(y)
     assert w_out.is_contiguous() and w_out.numel() == nf
-    gz = empty_cl(n, nf, y.shape[2], y.shape[3], y.device)
+    if out is not None:
+        assert tuple(out.shape) == tuple(y.shape) and _cl_rows(out) == (n, hw, nf)
+        gz = out
+    else:
+        gz = empty_cl(n, nf, y.shape[2], y.shape[3], y.device)
     check(lib.ctgan_gp_head_grad(_ptr(y), _ptr(w_out), n, hw, nf, mask_scale, _ptr(gz), _stream()), 'gp_head_grad')
     return gz
 
@@ -1592,18 +1616,22 @@ def rows_gather_dropout(src, segs, seed, ctr):
     return out
 
 
-def rows_cat_bwd(g, n_src, n_extra):
-    """adjoint of [x ; x[:n_extra]]: g[:n_src] with g[n_src:] added onto its first n_extra rows."""
+def rows_cat_bwd(g, n_src, n_extra, n_pass=0):
+    """adjoint of [x ; x[:n_extra]]: g[:n_src] with g[n_src:n_src + n_extra] added onto its first n_extra rows; n_pass further rows of g
+    behind the concat pass straight through (result: n_src + n_pass rows)."""
     _need_dev(g)
-    assert is_dense(g) and g.shape[0] == n_src + n_extra
+    assert is_dense(g) and g.shape[0] == n_src + n_extra + n_pass
     row = g.numel() // g.shape[0]
     if g.dim() == 4 and not g.is_contiguous():
         assert g.permute(0, 2, 3, 1).is_contiguous()
-        out = empty_cl(n_src, g.shape[1], g.shape[2], g.shape[3], g.device)
+        out = empty_cl(n_src + n_pass, g.shape[1], g.shape[2], g.shape[3], g.device)
     else:
         assert g.is_contiguous()
-        out = torch.empty((n_src,) + tuple(g.shape[1:]), dtype=torch.float32, device=g.device)
-    check(lib.ctgan_rows_cat_bwd(_ptr(g), n_src, n_extra, row, _ptr(out), _stream()), 'rows_cat_bwd')
+        out = torch.empty((n_src + n_pass,) + tuple(g.shape[1:]), dtype=torch.float32, device=g.device)
+    if n_pass:
+        check(lib.ctgan_rows_cat_bwd2(_ptr(g), n_src, n_extra, n_pass, row, _ptr(out), _stream()), 'rows_cat_bwd2')
+    else:
+        check(lib.ctgan_rows_cat_bwd(_ptr(g), n_src, n_extra, row, _ptr(out), _stream()), 'rows_cat_bwd')
     return out
 
 

@@ -35,7 +35,8 @@ class FlatAdam:
                 self.theta[off:off + n].copy_(p.reshape(-1))
                 p.data = self.theta[off:off + n].view(p.shape)
                 off += n
-        # {lr, beta1^t, beta2^t, unused}; TF initialises the power accumulators to beta (t = 1)
+        # {lr, beta1^t, beta2^t, skipped}; TF initialises the power accumulators to beta (t = 1).  skipped: elements the update
+        # kernels left untouched because their gradient was not finite, accumulated over the run (skipped())
         init = torch.tensor([0.0, self.beta1, self.beta2, 0.0], dtype=torch.float32, device=dev)
         if state is None:
             self.state = init
@@ -57,6 +58,13 @@ class FlatAdam:
             return
         self.state[0:1].fill_(lr)
         self._lr_last = lr
+
+    def skipped(self):
+        """Number of parameter elements the update kernels have left untouched so far because their (scaled) gradient was NaN / inf
+        (csrc/optim_rng.hip adam_elem; the reference's tf.train.AdamOptimizer would propagate the NaN instead).  Non-zero means the
+        run overflowed (fp16 mode under its fixed loss scale) or diverged: the trainers log it, bench.py fails its loss guard on it.
+        Reads device memory: call it outside captured regions, at logging cadence."""
+        return int(self.state[3].item())
 
     def gather_grads(self, grads):
         """Pack per-parameter gradients (None = zero) into the flat bucket with ONE kernel (the pointer table rides

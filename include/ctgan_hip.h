@@ -412,6 +412,12 @@ int ctgan_gp_fwd(const float* g, int32_t b, int32_t d, float lambda, float* slop
 /* gg[b,:] = gout * lambda*2*(s-1)/(s*B) * g[b,:]                                               */
 int ctgan_gp_bwd(const float* g, const float* slopes, const float* gout, int32_t b, int32_t d,
                  float lambda, float* gg, ctgan_stream_t stream);
+/* ctgan_gp_bwd that also takes the penalty's value in the same launch: gp[0] = lambda*mean((slopes-1)^2) (gp may be NULL) and, with
+ * out5 != NULL, out5[0] += gp, out5[4] += gp - the two sums of ctgan_tail_critic_heads_fwd (cost; wgan + ct + gp) that contain the
+ * penalty, for a step whose loss heads ran before dD/dx_hat existed (the hand-scheduled critic step: TF/CT_gan_cifar_resnet.py:284-286,
+ * :295-300 evaluated after the merged backward).                                                                               */
+int ctgan_gp_bwd_mean(const float* g, const float* slopes, const float* gout, int32_t b, int32_t d, float lambda, float* gg, float* gp,
+                      float* out5, ctgan_stream_t stream);
 /* CT_i = l2*(d-d_)^2 + l2*0.1*mean_j (f-f_)^2 ; ct = mean_i max(CT_i - M, 0)   (:288-291)      */
 int ctgan_ct_fwd(const float* d, const float* d_, const float* f, const float* f_, int32_t b,
                  int32_t nf, float lambda2, float M, float* ct_i, float* ct, ctgan_stream_t stream);
@@ -496,12 +502,13 @@ int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32
                     ctgan_stream_t stream);
 
 /* ---- optimizer (K21): tf.train.AdamOptimizer on a flat buffer
- *      (TF/CT_gan_cifar_resnet.py:333-338).  `state` = device float[4]: {lr, beta1^t, beta2^t, _};
+ *      (TF/CT_gan_cifar_resnet.py:333-338).  `state` = device float[4]: {lr, beta1^t, beta2^t, skipped};
  *      the kernel reads lr and the running beta powers from it (graph-replay safe) and
  *      ctgan_adam_advance multiplies the powers after all buckets of a step are applied.  An element whose scaled gradient is not
  *      finite (NaN / inf: an overflow of the fp16 matrix-core mode, a degenerate input) keeps its weight and slots unchanged - one
- *      inf would otherwise poison m, v and theta for good, also at lr = 0 (build-only safeguard; TF would propagate it). ------ */
-int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, const float* state,
+ *      inf would otherwise poison m, v and theta for good, also at lr = 0 (build-only safeguard; TF would propagate it) - and
+ *      state[3] is incremented by one per skipped element (float accumulator, exact to 2^24), so the caller can see it. ------ */
+int ctgan_adam_step(float* theta, const float* g, float* m, float* v, int64_t n, float* state,
                     float beta1, float beta2, float eps, float grad_scale, ctgan_stream_t stream);
 int ctgan_adam_advance(float* state, float beta1, float beta2, ctgan_stream_t stream);
 /* End of a step in one launch: ctgan_adam_advance(state) and, with rng_ctr != NULL, ctgan_rng_advance(rng_ctr, rng_by).            */
@@ -510,7 +517,7 @@ int ctgan_step_advance(float* state, float beta1, float beta2, uint64_t* rng_ctr
  * compute_gradients' bucket and apply_gradients (TF/CT_gan_cifar_resnet.py:335-338) of a single-rank step.  flat receives the
  * packed gradients as ctgan_pack writes them; theta/m/v are updated with bit-identical arithmetic to the two-launch form.        */
 int ctgan_adam_step_packed(const float* const* srcs, const int64_t* dst_offs, const int64_t* counts, int32_t n_tensors, float* flat,
-                           float* theta, float* m, float* v, const float* state, float beta1, float beta2, float eps, float grad_scale,
+                           float* theta, float* m, float* v, float* state, float beta1, float beta2, float eps, float grad_scale,
                            ctgan_stream_t stream);
 /* flat[dst_offs[i] : dst_offs[i] + counts[i]] = srcs[i][0:counts[i]] (srcs[i] == NULL: zeros), i < n_tensors, in one
  * launch per 64 tensors.  The three arrays are HOST arrays (the pointers are device pointers); they are passed to
@@ -557,6 +564,11 @@ int ctgan_critic_prep(const int32_t* x_int, const float* fake, int32_t b, int32_
 int ctgan_rows_cat_dropout(const float* src, int64_t n_src, int64_t n_extra, int64_t row_elems, float keep, uint64_t seed,
                            uint64_t stream_id, const uint64_t* ctr, float* dst, ctgan_stream_t stream);
 int ctgan_rows_cat_bwd(const float* g, int64_t n_src, int64_t n_extra, int64_t row_elems, float* gsrc, ctgan_stream_t stream);
+/* The same with n_pass further rows behind the concat that pass straight through: g = [a (n_src) ; a' (n_extra) ; c (n_pass)] ->
+ * gsrc [n_src + n_pass rows] = [a + a' ; c].  One launch for the step from the critic tail's merged backward (rows real, fake |
+ * real' | x_hat: the two dropout passes of :226-227 and the penalty pass of :283-284) to the trunk's (rows real, fake, x_hat).  */
+int ctgan_rows_cat_bwd2(const float* g, int64_t n_src, int64_t n_extra, int64_t n_pass, int64_t row_elems, float* gsrc,
+                        ctgan_stream_t stream);
 /* General form: dst = concatenation of up to CTGAN_ROW_SEGMENTS row segments of src (segment i = rows [src_row0,
  * src_row0 + rows)), each with its own tf.nn.dropout (keep >= 1: none) whose Philox element index is counted from dst row
  * index_row0 (<= the segment's first dst row): segments that share index_row0 and stream_id reproduce the dropout of their

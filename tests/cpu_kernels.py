@@ -93,6 +93,14 @@ def dgrad_wants_repack(g):
 
 @_export
 def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None, drop=None):
+    if isinstance(drop, dict):             # sample ranges, each with the mask of its own dropout (indices relative to the range)
+        dx = conv_dgrad(gy, w, g, N, out_strides, bias, wt, mask, resid)
+        r0 = 0
+        for end, sp in drop['ranges']:
+            if sp is not None and sp[0] < 1.0:
+                dx[r0:end] = dropout_rng(dx[r0:end], *sp)
+            r0 = end
+        return dx
     if drop is not None:
         return dropout_rng(conv_dgrad(gy, w, g, N, out_strides, bias, wt, mask, resid), *drop)
     if wt is not None:
@@ -537,6 +545,14 @@ def gp_fwd(g, lam, defer_mean=False):
 
 
 @_export
+def gp_bwd_mean(g, slopes, gout, lam, out5=None):
+    gp = (lam * ((slopes - 1) ** 2).mean()).to(g.dtype)
+    if out5 is not None:
+        out5[0] += gp; out5[4] += gp
+    return gp_bwd(g, slopes, gout, lam), gp
+
+
+@_export
 def gp_bwd(g, slopes, gout, lam):
     B = g.shape[0]
     coef = torch.where(slopes > 0, gout * lam * 2 * (slopes - 1) / (slopes * B), torch.zeros_like(slopes))
@@ -629,7 +645,7 @@ def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, s
 
 
 @_export
-def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac):
+def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac, out=None):
     gd, gf, ga = critic_heads_bwd(d, f, probs if w_ac is not None else None, labels, ct_i, gout, B, lam2, M, scale)
     t = gf + gd[:, None] * w_out.reshape(1, -1)
     if w_ac is not None:
@@ -639,6 +655,9 @@ def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_s
     gw_out = (f.t() @ gd).reshape(w_out.shape); gb_out = gd.sum().reshape(1)
     gw_ac = f.t() @ ga if w_ac is not None else None
     gb_ac = ga.sum(dim=0) if w_ac is not None else None
+    if out is not None:
+        out.copy_(gy)
+        return out, gw_out, gb_out, gw_ac, gb_ac
     return gy.contiguous(memory_format=torch.channels_last), gw_out, gb_out, gw_ac, gb_ac
 
 
@@ -666,9 +685,13 @@ def gen_heads_bwd(y, probs, labels, gout, ac_scale, mask_scale, w_out, w_ac):
 
 
 @_export
-def gp_head_grad(y, w_out, mask_scale):
+def gp_head_grad(y, w_out, mask_scale, out=None):
     hw = y.shape[2] * y.shape[3]
-    return ((y > 0).to(y.dtype) * (w_out.reshape(1, -1, 1, 1) / hw * mask_scale)).contiguous(memory_format=torch.channels_last)
+    gz = (y > 0).to(y.dtype) * (w_out.reshape(1, -1, 1, 1) / hw * mask_scale)
+    if out is not None:
+        out.copy_(gz)
+        return out
+    return gz.contiguous(memory_format=torch.channels_last)
 
 
 @_export
@@ -709,6 +732,15 @@ def adam_step(theta, g, m, v, state, beta1, beta2, eps=1e-8, grad_scale=1.0):
     lr, b1p, b2p = state[0].item(), state[1].item(), state[2].item()
     lr_t = lr * (1 - b2p) ** 0.5 / (1 - b1p)
     gi = g * grad_scale
+    ok = torch.isfinite(gi)              # the HIP kernels leave elements with a non-finite gradient untouched and count them in state[3]
+    if not bool(ok.all()):
+        state[3] += float((~ok).sum().item())
+        gi = torch.where(ok, gi, torch.zeros_like(gi))
+        m2 = m * beta1 + gi * (1 - beta1)
+        v2 = v * beta2 + gi * gi * (1 - beta2)
+        th2 = theta - lr_t * m2 / (v2.sqrt() + eps)
+        m.copy_(torch.where(ok, m2, m)); v.copy_(torch.where(ok, v2, v)); theta.copy_(torch.where(ok, th2, theta))
+        return
     m.mul_(beta1).add_(gi, alpha=1 - beta1)
     v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
     theta.sub_(lr_t * m / (v.sqrt() + eps))
@@ -797,9 +829,11 @@ def rows_gather_dropout(src, segs, seed, ctr):
 
 
 @_export
-def rows_cat_bwd(g, n_src, n_extra):
-    out = g[:n_src].clone()
-    out[:n_extra] += g[n_src:]
+def rows_cat_bwd(g, n_src, n_extra, n_pass=0):
+    out = torch.cat([g[:n_src], g[n_src + n_extra:]], 0) if n_pass else g[:n_src].clone()
+    if g.dim() == 4 and n_pass:
+        out = _cl(out)
+    out[:n_extra] += g[n_src:n_src + n_extra]
     return out
 
 

@@ -105,7 +105,7 @@ def test_dcgan_d_and_g_step(which, dim, B):
         M.configure(); lib.delete_all_params()
 
 
-@pytest.mark.parametrize('which,dtype', [('cifar', None), ('cifar', 'bf16'), ('lsun128', 'f16')])
+@pytest.mark.parametrize('which,dtype', [('cifar', None), ('cifar', 'bf16'), ('lsun128', 'f16'), ('64x64', None)])
 def test_graphed_unconditional_trainer_equals_eager(which, dtype):
     """engine.GraphedDCGANTrainer (what `bench.py --config ...` times: hipGraph replay of the shared unconditional CT-WGAN step,
     in-kernel Philox dropout, packed 16-bit filters rebuilt inside the graphs) against the eager DCGANTrainer on the same batches
@@ -118,6 +118,9 @@ def test_graphed_unconditional_trainer_equals_eager(which, dtype):
     if which == 'cifar':
         import ctgan_amd.gan_cifar as M
         cfgkw = dict(DIM=32, BATCH_SIZE=8)
+    elif which == '64x64':          # (the loop of this module raised - its Generator lacked the batched draw's `groups`)
+        import ctgan_amd.gan_64x64 as M
+        cfgkw = dict(BATCH_SIZE=4, DIM=32)
     else:
         import ctgan_amd.gan_lsun128 as M
         cfgkw = dict(BATCH_SIZE=4, DIM_G_64=32, DIM_G_32=32, DIM_G_16=64, DIM_G_8=64, DIM_G_4=64, DIM_D_64=32, DIM_D_32=64, DIM_D_16=64, DIM_D_8=128)

@@ -980,6 +980,11 @@ def test_adam_leaves_elements_with_a_non_finite_gradient_untouched():
             opt.set_lr(lr); opt_ref.set_lr(lr)
             opt.update([bad], 1.0); opt_ref.update([g], 1.0)
         torch.cuda.synchronize()
+        # the skips are counted: 3 elements x 2 packed updates; the two-launch form (gather + step) counts the same way
+        assert opt.skipped() == 6 and opt_ref.skipped() == 0
+        opt.gather_grads([bad]); opt.step(1.0)
+        opt_ref.gather_grads([g]); opt_ref.step(1.0)
+        assert opt.skipped() == 9 and opt_ref.skipped() == 0
         ok = torch.ones(64, dtype=torch.bool, device='cuda'); ok[[3, 10, 40]] = False
         assert torch.isfinite(opt.theta).all() and torch.isfinite(opt.m).all() and torch.isfinite(opt.v).all()
         assert torch.equal(opt.theta[ok], opt_ref.theta[ok]) and torch.equal(opt.m[ok], opt_ref.m[ok])

@@ -382,3 +382,59 @@ def test_layernorm_critic_d_step_on_gpu(setup):
             _cmp_l2(out['grads'][n], ref['grads'][n], 5e-3, 'dgrad ' + n, atol=1e-7)
     finally:
         lib0.delete_all_params(); R0.configure()
+
+
+@pytest.mark.parametrize('dim,B,ac', [(64, 8, True), (128, 64, True), (128, 64, False)])
+def test_hand_scheduled_critic_step_equals_the_autograd_path_on_gpu(setup, dim, B, ac):
+    """critic_schedule.critic_step (one backward chain over the rows of the dropout passes and of the gradient-penalty
+    pass; weight gradients restricted to the dropout-pass rows; the penalty's double backward on the x_hat rows only) against the path it
+    replaces (Trainer.d_losses + two autograd calls), at the benchmarked size: same weights, inputs and Philox streams.  The merged
+    launches run other tile shapes over other row counts than the separate chains (another summation order inside fp32), and ReLU
+    masks are taken from the same forward tensors, so the gradients agree to fp32 rounding - not bit for bit."""
+    import ctgan_amd.functional as F
+    from tests.test_host_logic_resnet import _scheduled_vs_autograd
+    R, lib = setup(dim, B)
+    a, b = _scheduled_vs_autograd(R, lib, F, B, dim, ac, None)
+    for k in ('cost', 'wgan', 'acgan', 'wgan_only', 'ct', 'gp', 'acc_real', 'acc_fake', 'd_real', 'd_fake', 'real'):
+        assert (a[0].get(k) is None) == (b[0].get(k) is None), k
+        if a[0].get(k) is not None:
+            _cmp(b[0][k], a[0][k], 1e-5, 'scheduled.' + k, atol=1e-6)
+    assert _rel_l2(b[0]['slopes'], a[0]['slopes']) < 1e-5 and _rel_l2(b[0]['gp_grads'], a[0]['gp_grads']) < 1e-5
+    assert a[2] == b[2]
+    for n, x, y in zip(a[2], a[1], b[1]):
+        assert (x is None) == (y is None), n
+        if x is not None and x.abs().max() > 0:
+            assert _rel_l2(y, x) < 2e-5, (n, _rel_l2(y, x))
+
+
+@pytest.mark.parametrize('split_mode', [True, False])
+def test_data_gradient_with_per_range_dropout_masks_equals_one_dropout_per_range(split_mode):
+    """ctgan_conv2d16_dgrad_ex / ctgan_conv2d_dgrad_ex with sample ranges (round 5: the merged backward carries the rows of the dropout
+    passes and of the penalty pass in one data gradient, each range with the mask of its own forward dropout): the epilogue form
+    against the plain data gradient followed by ctgan_dropout_rng on each range's own rows - same Philox draws, bit for bit."""
+    import ctgan_amd.kernels as K
+    from ctgan_amd.kernels import ConvGeom
+    old = K.X3_HYBRID
+    K.X3_HYBRID = split_mode
+    try:
+        g = torch.Generator().manual_seed(4)
+        N, C = 256, 128
+        geom = ConvGeom(C, 8, 8, C, 3, 3, 1)
+        cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)       # noqa: E731
+        gy = cl(torch.randn(N, C, 8, 8, generator=g))
+        mask = cl(torch.randn(N, C, 8, 8, generator=g))
+        resid = cl(torch.randn(N, C, 8, 8, generator=g))
+        w = (torch.randn(3, 3, C, C, generator=g) * 0.05).cuda()
+        ctr = torch.full((1,), 3, dtype=torch.int64, device='cuda')
+        drop = {'ranges': [(192, (0.5, 77, 5, ctr)), (256, (0.8, 77, 9, ctr))]}
+        got = K.conv_dgrad(gy, w, geom, N, mask=mask, resid=resid, drop=drop)
+        name = K.last_kernel()
+        assert ('conv16x3' in name) == split_mode, name
+        ref = K.conv_dgrad(gy, w, geom, N, mask=mask, resid=resid)
+        ref = K._dropout_ranges(ref, drop)
+        assert torch.equal(got, ref)
+        # the ranges really differ: range 2 keeps ~80 %, range 1 ~50 %
+        z = (got == 0).float()
+        assert 0.4 < z[:192].mean().item() < 0.6 and 0.1 < z[192:].mean().item() < 0.3
+    finally:
+        K.X3_HYBRID = old

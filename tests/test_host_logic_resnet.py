@@ -612,3 +612,97 @@ def test_both_optimizers_share_one_state_allocation_and_one_learning_rate_fill(s
     sd = tr.d_opt.state_dict()
     tr.d_opt.load_state_dict(sd)
     assert float(tr.g_opt.state[0]) == pytest.approx(2e-4)
+
+
+def _scheduled_vs_autograd(R, lib, F, B, D, ac, dev, seed=1):
+    """One critic step's losses and parameter gradients through critic_schedule.critic_step (merged=True) and through d_losses +
+    autograd (merged=False), from identical weights, inputs and Philox streams."""
+    import ctgan_amd.critic_schedule as CS
+    res = {}
+    for merged in (False, True):
+        lib.delete_all_params(); lib.set_device(dev); lib.set_seed(seed)
+        R.configure(DIM_G=32, DIM_D=D, BATCH_SIZE=B, CONDITIONAL=ac, ACGAN=ac)
+        R.build_params()
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for n, p in lib._params.items():
+                if n.endswith(('.Biases', '.b')):           # zero-initialised in the reference: make them count
+                    p.add_((0.1 * torch.randn(p.shape, generator=g)).to(p.device))
+        tr = R.Trainer(seed=3)
+        real = torch.randint(0, 256, (B, 3072), dtype=torch.int32, generator=g).to(tr.dev)
+        labels = torch.randint(0, 10, (B,), dtype=torch.int32, generator=g).to(tr.dev)
+        old, CS.MERGED_BWD = CS.MERGED_BWD, merged
+        try:
+            F.prepare_filters()
+            fake = tr.generate_fakes(labels)[0]
+            assert CS.usable(R, None, tr.rng, real, fake) == merged
+            tr.rng.begin_step()
+            out, grads = tr.d_grads(real, labels, fake=fake)
+        finally:
+            CS.MERGED_BWD = old
+        res[merged] = (out, grads, [n for n, _ in tr.d_named])
+    return res[False], res[True]
+
+
+@pytest.mark.parametrize('ac', [True, False])
+def test_hand_scheduled_critic_step_equals_the_autograd_path(cpu_kernels, ac):
+    """critic_schedule.critic_step - ONE backward chain over the rows of the two dropout passes and the rows of the gradient-penalty
+    pass, weight gradients from the dropout-pass rows only, the penalty's double backward on the x_hat rows only -
+    against the path it replaces (Trainer.d_losses + two torch.autograd.grad calls): every loss term, the slopes, dD/dx_hat and every
+    parameter gradient, with and without the class head."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    try:
+        a, b = _scheduled_vs_autograd(R, lib, F, 2, 64, ac, 'cpu')
+        for k in ('cost', 'wgan', 'acgan', 'wgan_only', 'ct', 'gp', 'acc_real', 'acc_fake', 'slopes', 'gp_grads', 'd_real', 'd_fake', 'real'):
+            assert (a[0].get(k) is None) == (b[0].get(k) is None), k
+            if a[0].get(k) is not None:
+                _cmp(b[0][k], a[0][k], 2e-6, 'scheduled.' + k, atol=1e-7)
+        assert a[2] == b[2]
+        for n, x, y in zip(a[2], a[1], b[1]):
+            assert (x is None) == (y is None), n
+            if x is not None:
+                assert tuple(x.shape) == tuple(dict(lib.named_params_with_name('Discriminator.', True))[n].shape), n
+                _cmp(y, x, 5e-6, 'scheduled grad ' + n, atol=1e-8)
+    finally:
+        R.configure()
+
+
+def test_hand_scheduled_critic_step_matches_oracle_on_identical_philox_streams(cpu_kernels):
+    """The scheduled step (DIM_D = 64: the width from which the first critic convs run on the direct few-channel kernels, which the
+    schedule requires) through Trainer.d_step against the fp64 oracle of the reference graph AS WRITTEN, fed the same Philox streams."""
+    from oracle import philox
+    import ctgan_amd.critic_schedule as CS
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    B, dim = 2, 64
+    lib.set_seed(5)
+    R.configure(DIM_G=dim, DIM_D=dim, BATCH_SIZE=B)
+    try:
+        R.build_params('cpu')
+        reg = _oracle_from_product(lib)
+        cfg = onets.ResnetCfg(DIM_G=dim, DIM_D=dim)
+        g = torch.Generator().manual_seed(1)
+        tr = R.Trainer(seed=77)
+        optD = osteps.TFAdam(reg, [n for n, _ in reg.trainable_with_name('Discriminator.')], 0.0, 0.9)
+        calls = []
+        orig = CS.critic_step
+        CS.critic_step = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            for it in range(2):
+                real = torch.randint(0, 256, (B, 3072), generator=g, dtype=torch.int32)
+                labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32)
+                out = tr.d_step(real, labels, None, iteration=it)
+                ref = osteps.resnet_d_step(reg, cfg, optD, real, labels, philox.rnd_resnet_d(77, 0, it, B, dim), iteration=it, B=B)
+                for k in ('cost', 'wgan', 'acgan', 'ct', 'gp', 'wgan_only', 'acc_real', 'acc_fake'):
+                    _cmp(out[k], ref[k], 2e-4, 'd_step[%d].%s' % (it, k), atol=1e-6)
+                _cmp(out['gp_grads'], ref['gp_grads'], 5e-4, 'gp grads')
+                assert set(n for n, v in out['grads'].items() if v is not None) == set(ref['grads'])
+                for n in ref['grads']:
+                    _cmp(out['grads'][n], ref['grads'][n], 1e-3, 'dgrad ' + n, atol=1e-6)
+        finally:
+            CS.critic_step = orig
+        assert len(calls) == 2, 'the default critic step did not take the hand-scheduled path'
+    finally:
+        R.configure()
