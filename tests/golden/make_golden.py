@@ -159,6 +159,88 @@ def loop_trace_fixture(dim=32, B=8, iters=1000, seed=2024, init_seed=0, fname='r
                         d=np.array([[r[k] for k in keys] for r in d_recs]), g=np.array(g_recs), stream_pos=np.array(pos))
 
 
+def _sample_index(name, numel, k):
+    """Fixed pseudo-random positions of a parameter's gradient (by name: the GPU test draws the same ones)."""
+    import zlib
+    if numel <= k:
+        return np.arange(numel)
+    return np.sort(np.random.default_rng([7, zlib.crc32(name.encode())]).choice(numel, size=k, replace=False))
+
+
+def dstep_b64_fixture(which, B=64, chunk=8, init_seed=9, data_seed=3, nsample=1024):
+    """One critic step of config[4] (`which` = 'lsun128': LS/wgan_LSUN_Bedrooms128.py:137-296 at the reference widths, critic 47.7 M
+    parameters) or config[1] ('cifar': TF/CT_gan_cifar.py:58-154, DIM 128) at the FULL batch B = 64 in fp64 (the GPU suite
+    compared these configs with the oracle at B <= 16 only).  Seeds, not tensors: initial weights = the registry's per-name init streams
+    (`init_seed`; lib.set_seed draws the same values - checked by weight checksums in the fixture), inputs and every random draw from
+    torch.Generator(data_seed) exactly as tests/test_lsun128.py / test_gpu_dcgan_step.py build them.  Stored: the loss terms, every
+    critic parameter gradient's norm and `nsample` fixed entries of it (all of it for small parameters).
+
+    The fp64 graph of the 128x128 critic at B = 64 (three passes + the penalty's double backward) does not fit this container's
+    memory, and it does not have to: every loss term is a batch MEAN of per-sample terms and the critic couples no samples (Layernorm is
+    per sample; the generator's BatchNorm does, but its forward is evaluated once, for the whole batch, without a graph), so the step is
+    evaluated on `chunk` rows at a time through the SAME oracle function (steps.dcgan_d_losses, with the generator replaced by the
+    rows of the precomputed fake batch) and the chunk results are averaged - an identity in exact arithmetic."""
+    import time
+    g = torch.Generator().manual_seed(data_seed)
+    reg = ops.Registry(dtype=F64, seed=init_seed)
+    if which == 'lsun128':
+        cfg = nets.Lsun128Cfg()
+        h = B // 2       # two generator towers per batch, each with its own BN statistics (gan_lsun128.GEN_TOWERS)
+        Gfull = lambda r, n, zz: torch.cat([nets.lsun128_generator(r, cfg, h, zz[:h]), nets.lsun128_generator(r, cfg, h, zz[h:])])   # noqa: E731
+        D = lambda r, xx, uu: nets.lsun128_discriminator(r, cfg, xx, 0.8, 0.5, 0.5, uu)                                            # noqa: E731
+        out_dim = cfg.OUTPUT_DIM
+        feat = [(cfg.DIM_D_8, 8, 8)] * 3
+        with torch.no_grad():
+            D(reg, Gfull(reg, 4, torch.zeros(4, 128, dtype=F64)), [torch.ones(4, *s, dtype=F64) for s in feat])
+    else:
+        Gfull = lambda r, n, zz: nets.cifar_generator(r, n, zz, DIM=128)        # noqa: E731
+        D = lambda r, xx, uu: nets.cifar_discriminator(r, xx, uu, DIM=128)      # noqa: E731
+        out_dim = 3072
+        feat = [(128, 16, 16), (256, 8, 8), (512, 4, 4)]
+        with torch.no_grad():
+            D(reg, Gfull(reg, 2, torch.zeros(2, 128, dtype=F64)), [torch.full((2,) + s, 0.9, dtype=F64) for s in feat])
+    for n, t in reg.items():                       # fp32-representable weights on both sides
+        with torch.no_grad():
+            t.copy_(t.float().double())
+    real_in = torch.randint(0, 256, (B, out_dim), generator=g, dtype=torch.int32)
+    rnd = steps.make_rnd_dcgan_d(B, feat, g)
+    real = 2 * ((real_in.double() / 255.) - .5)
+    t0 = time.time()
+    with torch.no_grad():
+        fake = Gfull(reg, B, rnd['z'])
+    print('generator forward %.1f s' % (time.time() - t0), flush=True)
+    names = [n for n, _ in reg.trainable_with_name('Discriminator')]
+    acc = {n: torch.zeros_like(reg[n]) for n in names}
+    terms = {k: 0.0 for k in ('cost', 'wgan_only', 'ct', 'gp')}
+    slopes = []
+    nch = B // chunk
+    assert nch * chunk == B
+    for c in range(nch):
+        rows = slice(c * chunk, (c + 1) * chunk)
+        sub = {k: ([t[rows] for t in v] if isinstance(v, list) else v[rows]) for k, v in rnd.items()}
+        o = steps.dcgan_d_losses(reg, lambda r, n, zz: fake[rows], D, real[rows], sub)
+        gr = steps.grads_of(o['cost'], reg, 'Discriminator')
+        for n in names:
+            if n in gr:
+                acc[n] += gr[n].detach() / nch
+        for k in terms:
+            terms[k] += o[k].item() / nch
+        slopes.append(o['slopes'].detach())
+        del o, gr
+        print('chunk %d/%d  %.1f s  cost so far %.6f' % (c + 1, nch, time.time() - t0, terms['cost'] * nch / (c + 1)), flush=True)
+    out = {'cfg': np.array([B, chunk, init_seed, data_seed, nsample]), 'names': np.array(names), 'slopes': npy(torch.cat(slopes)),
+           'fake_abs_sum': np.array(fake.abs().sum().item()),
+           'theta_abs_sum': np.array(sum(reg[n].detach().abs().sum().item() for n in names))}
+    for k, v in terms.items():
+        out['loss.' + k] = np.array(v)
+    for n in names:
+        flat = acc[n].reshape(-1)
+        idx = _sample_index(n, flat.numel(), nsample)
+        out['norm.' + n] = np.array(flat.norm().item())
+        out['vals.' + n] = npy(flat[torch.from_numpy(idx)]).astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, '%s_dstep_%d.npz' % (which, B)), **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     which = sys.argv[1:] or ['ops', 'resnet', 'loop']
@@ -174,6 +256,12 @@ if __name__ == '__main__':
         torch.set_num_threads(8)
         loop_trace_fixture(dim=128, B=64, iters=2, fname='resnet_loop_128_64.npz')
         loop_trace_fixture(dim=128, B=64, iters=2, fname='resnet_loop_128_64_f32twin.npz', dtype=torch.float32)
+    if 'lsun64' in which:       # config[4] at B = 64 (chunked, ~minutes of host time): what tests/test_lsun128.py compares the fp16 step with
+        torch.set_num_threads(6)
+        dstep_b64_fixture('lsun128')
+    if 'cifar64' in which:      # config[1] at B = 64
+        torch.set_num_threads(6)
+        dstep_b64_fixture('cifar')
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -183,3 +183,53 @@ def test_fused_lrelu_dropout_kernel_equals_the_separate_launches_bitwise():
         # (kept positions: identical factors; the two orders of the same two multiplications may differ in the last bit)
         assert torch.allclose(gx, want_g, rtol=2e-7, atol=0) and torch.equal(gx == 0, want_g == 0)
         assert 0.4 < (y == 0).float().mean().item() < 0.6
+
+
+def test_cifar_dcgan_bf16_batch64_d_step_vs_fp64_fixture():
+    """BASELINE.json configs[1] as it is benchmarked - CT_gan_cifar.py nets at DIM 128, B = 64, convs on the bf16 matrix cores (fp32
+    accumulate, fp32 master weights) - one whole critic step against the fp64 oracle, through the committed fixture
+    tests/golden/cifar_dstep_64.npz (seeds, loss terms, gradient norms, 1024 sampled entries per parameter; `make_golden.py cifar64`).
+    bf16 keeps 8 significant bits per operand (2^-9 relative rounding, 8x fp16's): stated bounds = loss terms 2e-2 of max(1, |term|);
+    per parameter the gradient norm within 5 %, relative L2 over the sampled entries <= 10 %, cosine >= 0.994 (measured in round 2 at
+    B = 64 against the fp32 kernels: 4.3-5.8 % / 0.9983, profiles/r02_dcgan16_bf16_errors.json)."""
+    import json
+    import os
+    import numpy as np
+    import ctgan_amd.gan_cifar as M
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    from tests.test_lsun128 import _fixture_grad_errors
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cifar_dstep_64.npz')))
+    B, _chunk, init_seed, data_seed, _ns = [int(v) for v in fx['cfg']]
+    lib.delete_all_params(); lib.set_device(None)
+    M.configure(BATCH_SIZE=B, DIM=128)
+    try:
+        lib.set_seed(init_seed)
+        with torch.no_grad():
+            M.Discriminator(M.Generator(2, noise=torch.zeros(2, 128, device='cuda')), u=[torch.ones(2, *s, device='cuda') for s in M.feat_shapes()])
+        tr = DCGANTrainer(M, seed=1)
+        names = [str(n) for n in fx['names']]
+        assert names == [n for n, _ in tr.d_named]
+        th = sum(p.detach().double().abs().sum().item() for _, p in tr.d_named)
+        assert abs(th - float(fx['theta_abs_sum'])) <= 1e-9 * th, 'the product drew other initial weights than the fixture'
+        g = torch.Generator().manual_seed(data_seed)
+        real_in = torch.randint(0, 256, (B, M.cfg.OUTPUT_DIM), generator=g, dtype=torch.int32)
+        rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
+        res = {}
+        for dt, (tl, tn, te, tc) in ((None, (2e-4, 1e-3, 5e-3, 0.9999)), ('bf16', (2e-2, 0.05, 0.10, 0.994))):
+            with K.mma_dtype(dt):           # (losses + gradients only: the weights stay the fixture's for both modes)
+                tr.rng.begin_step()
+                out = tr.d_losses(real_in.cuda(), {k: _dv(v) for k, v in rnd.items()})
+                grads = torch.autograd.grad(out['cost'], tr.d_params, allow_unused=True)
+            for k in ('cost', 'wgan_only', 'ct', 'gp'):
+                a, b = out[k].item(), float(fx['loss.' + k]) * (M.cfg.LAMBDA if k == 'gp' else 1.0)
+                assert abs(a - b) <= tl * max(1.0, abs(b)), (dt, k, a, b)
+            rows = _fixture_grad_errors(fx, dict(zip(names, grads)), names)
+            res[str(dt)] = {'worst_sample_rel_l2': max(r[2] for r in rows), 'worst_cosine': min(r[3] for r in rows), 'worst_norm_dev': max(r[1] for r in rows)}
+            for n, dn, e, c in rows:
+                assert dn <= tn and e <= te and c >= tc, (dt, n, dn, e, c)
+        os.makedirs('gpurun_out', exist_ok=True)
+        json.dump(res, open('gpurun_out/cifar_dcgan_B64_vs_fixture.json', 'w'), indent=1)
+    finally:
+        M.configure(); lib.delete_all_params()

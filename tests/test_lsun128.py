@@ -295,3 +295,75 @@ def test_lsun128_full_width_f16_batch64_size_independent_properties():
                 assert float((gxs - (gx1 + gx2)).abs().max()) <= 2e-6 * float(gxs.abs().max())
     finally:
         lib.delete_all_params(); M.configure()
+
+
+def _fixture_grad_errors(fx, grads, names):
+    """Per parameter: (|norm ratio - 1|, relative L2 error and cosine over the fixture's sampled entries) of the product's gradient
+    against the fp64 fixture (tests/golden/make_golden.py dstep_b64_fixture)."""
+    import numpy as np
+    from tests.golden.make_golden import _sample_index
+    rows = []
+    for n in names:
+        ref = torch.from_numpy(fx['vals.' + n]).double()
+        if float(fx['norm.' + n]) < 1e-12:
+            continue
+        a = grads[n].detach().cpu().double().reshape(-1)
+        idx = torch.from_numpy(np.asarray(_sample_index(n, a.numel(), int(fx['cfg'][4]))))
+        s = a[idx]
+        rows.append((n, abs(a.norm().item() / float(fx['norm.' + n]) - 1.0), ((s - ref).norm() / ref.norm()).item(),
+                     torch.nn.functional.cosine_similarity(s.view(1, -1), ref.view(1, -1)).item()))
+    return rows
+
+
+@pytest.mark.gpu
+def test_lsun128_full_width_f16_batch64_d_step_vs_fp64_fixture():
+    """BASELINE.json configs[4] at its FULL single-GPU size - reference widths (critic 47.7 M parameters), B = 64, convs on the fp16 matrix
+    cores, loss scale 1024 - one whole critic step (three critic passes, Layernorm backward and bwd2, the penalty's double backward, every
+    weight gradient) against the fp64 oracle (until round 5 the oracle contact of this config was B <= 16).  The oracle's
+    side is a committed fixture (tests/golden/lsun128_dstep_64.npz: seeds, loss terms, per-parameter gradient norms and 1024 sampled
+    entries each; generated in the build container by `python tests/golden/make_golden.py lsun64`) - both sides rebuild weights, inputs
+    and draws from the same seeds.  Bounds = the B = 16 test's: loss terms 1e-2 of max(1, |term|); per parameter the gradient norm within
+    3 %, relative L2 over the sampled entries <= 8 % (the B = 16 bound of 6 % on full tensors + sampling slack), cosine >= 0.995."""
+    import json
+    import os
+    import numpy as np
+    import ctgan_amd.gan_lsun128 as M
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lsun128_dstep_64.npz')))
+    B, _chunk, init_seed, data_seed, _ns = [int(v) for v in fx['cfg']]
+    lib.delete_all_params(); lib.set_device(None)
+    M.configure(BATCH_SIZE=B)
+    try:
+        lib.set_seed(init_seed)
+        M.build_params('cuda')
+        tr = DCGANTrainer(M, seed=1)
+        tr.loss_scale = 1024.0
+        names = [str(n) for n in fx['names']]
+        assert names == [n for n, _ in tr.d_named]
+        th = sum(p.detach().double().abs().sum().item() for _, p in tr.d_named)
+        assert abs(th - float(fx['theta_abs_sum'])) <= 1e-9 * th, 'the product drew other initial weights than the fixture'
+        g = torch.Generator().manual_seed(data_seed)
+        real_in = torch.randint(0, 256, (B, M.cfg.OUTPUT_DIM), generator=g, dtype=torch.int32)
+        assert [tuple(s) for s in M.feat_shapes()] == [(1024, 8, 8)] * 3
+        rnd = osteps.make_rnd_dcgan_d(B, M.feat_shapes(), g)
+        with K.mma_dtype('f16'):
+            out = tr.d_step(real_in.cuda(), {k: _to(v, 'cuda') for k, v in rnd.items()})
+        losses = {}
+        for k in ('cost', 'wgan_only', 'ct', 'gp'):
+            a, b = out[k].item(), float(fx['loss.' + k]) * (M.cfg.LAMBDA if k == 'gp' else 1.0)
+            losses[k] = (a, b)
+            assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), (k, a, b)
+        rows = _fixture_grad_errors(fx, out['grads'], names)
+        worst = max(rows, key=lambda r: r[2])
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/lsun128_f16_B64_vs_fixture.json', 'w') as f:
+            json.dump({'B': B, 'loss_scale': tr.loss_scale, 'losses': losses, 'worst_param': worst[0], 'worst_sample_rel_l2': worst[2],
+                       'its_cosine': worst[3], 'worst_norm_dev': max(r[1] for r in rows), 'adam_skipped': tr.d_opt.skipped(),
+                       'rows': rows}, f, indent=1)
+        for n, dn, e, c in rows:
+            assert dn <= 0.03 and e <= 0.08 and c >= 0.995, (n, dn, e, c)
+        assert tr.d_opt.skipped() == 0          # no gradient element overflowed fp16 under the loss scale
+    finally:
+        lib.delete_all_params(); M.configure()
