@@ -76,6 +76,7 @@ SIGNATURES = {
     'ctgan_debug_force_generic': (None, [c_int]),
     'ctgan_debug_x3_halo_version': (None, [c_int]),
     'ctgan_debug_x3_s2halo': (None, [c_int]),
+    'ctgan_debug_m2f_px': (None, [c_int]),
     'ctgan_debug_last_wgrad_group_kinds': (c_int, []),
     'ctgan_debug_last_wgrad_group_col_mask': (ctypes.c_uint, []),
     'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),

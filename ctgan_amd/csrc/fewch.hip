@@ -329,6 +329,110 @@ __global__ __launch_bounds__(RING_NT) void m2f_ring_kernel(const M2FParams p) {
     }
 }
 
+
+// ---- many -> few, 3x3, 32-pixel rows: one output pixel per lane ("px" variant, round 5) ---------------------------------
+// The lane-group kernels above give a pixel to C/4 lanes and finish every pixel with cross-lane reductions (DPP adds + a bpermute per
+// output channel): a chain of dependent cross-lane operations per pixel at two waves per SIMD - the ring kernel spent 26 of its 48 us
+// (128 rows) in arithmetic that overlapped nothing.  Here a lane OWNS a pixel: 256 threads = an 8 x 32 output tile, the
+// many-channel operand is staged 32 channels at a time into LDS (10 x 34 halo pixels, 36-float pixel pitch: a 16-lane group of a
+// ds_read_b128 touches 16 different 4-bank slots) and every lane walks the 9 taps x 32 channels of the chunk.  The filter is the same
+// for all pixels: its chunk (9 taps x 8 channel quads x JS outputs, one float4 each) sits in LDS too and is read with WAVE-UNIFORM
+// addresses (a broadcast ds_read_b128: one LDS cycle per lane group whatever the lane count) - no filter registers held per lane, no
+// reductions, no per-row barriers (two per chunk), 2 * JS independent accumulator chains.  The next chunk's global loads are issued
+// into registers before the current chunk's arithmetic and parked in LDS after it.
+// (Measured and dropped: the filter as SCALAR operands (s_load_dwordx16 -> v_pk_fma_f32 with SGPR pairs; 4 us per 64 rows of arithmetic) -
+// the tap loop needs 96 SGPRs per step and cannot run ahead, so on the cold scalar cache of a fresh launch each of its 36 steps waited an
+// L2 round trip: 32 us per launch whatever the batch.)
+struct PXParams {
+    const float* x; long long xs_n, xs_h, xs_w; int H, CM;
+    float* y; long long ys_n, ys_c, ys_p, ys_q;
+    const float* w; long long w_off, ws_r, ws_s, ws_c, ws_j;
+    const float* bias;
+    int relu_in, tiles;
+};
+constexpr int PX_TH = 8, PX_W = 32, PX_CC = 32, PX_PS = 36, PX_NT = 256;
+constexpr int PX_PIX = (PX_TH + 2) * (PX_W + 2);            // 340 staged pixels per chunk
+constexpr int PX_F4 = PX_PIX * (PX_CC / 4);                 // 2720 float4 per chunk
+constexpr int PX_PF = (PX_F4 + PX_NT - 1) / PX_NT;          // 11 prefetch registers (float4) per thread
+
+template <int JS>
+__global__ __launch_bounds__(PX_NT) void m2f_px_kernel(const PXParams p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [340 px][36] then the filter chunk [9][8][JS] float4
+    float4* wl = reinterpret_cast<float4*>(tile + PX_PIX * PX_PS);
+    constexpr int WF4 = 9 * (PX_CC / 4) * JS;
+    static_assert(WF4 <= PX_NT, "one filter float4 per thread");
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / p.tiles, tb = blockIdx.x - n * p.tiles;
+    const int p0 = tb * PX_TH;
+    const int row = tid >> 5, col = tid & 31;
+    const float* img = p.x + (long long)n * p.xs_n;
+    float4 pf[PX_PF], wpf = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < PX_PF; ++k) {
+            const int i = tid + k * PX_NT;
+            const int pix = i >> 3, c4 = i & 7;
+            const int tr = pix / (PX_W + 2), tw = pix - tr * (PX_W + 2);
+            const int ih = p0 - 1 + tr, iw = tw - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < PX_F4 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)PX_W)
+                v = *reinterpret_cast<const float4*>(img + (long long)ih * p.xs_h + (long long)iw * p.xs_w + chunk * PX_CC + c4 * 4);
+            pf[k] = v;
+        }
+        if (tid < WF4) {                                               // wl[(t * 8 + c4) * JS + j] = w(t, channels c .. c+3, j)
+            const int j = tid % JS, tc = tid / JS, c4 = tc & 7, t = tc >> 3;
+            const float* q = p.w + p.w_off + (t / 3) * p.ws_r + (t % 3) * p.ws_s + (long long)(chunk * PX_CC + c4 * 4) * p.ws_c + j * p.ws_j;
+            wpf = make_float4(q[0], q[p.ws_c], q[2 * p.ws_c], q[3 * p.ws_c]);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int k = 0; k < PX_PF; ++k) {
+            const int i = tid + k * PX_NT;
+            if (i < PX_F4) {
+                float4 v = pf[k];
+                if (p.relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(&tile[(i >> 3) * PX_PS + (i & 7) * 4]) = v;
+            }
+        }
+        if (tid < WF4) wl[tid] = wpf;
+    };
+    f32x2 acc[JS][2];
+#pragma unroll
+    for (int j = 0; j < JS; ++j) { acc[j][0] = f32x2{0.f, 0.f}; acc[j][1] = f32x2{0.f, 0.f}; }
+    const int nchunk = p.CM / PX_CC;
+    fetch(0);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        __syncthreads();                      // the previous chunk's tile fully consumed
+        stash();
+        __syncthreads();
+        if (chunk + 1 < nchunk) fetch(chunk + 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, s2 = t % 3;
+            const float* xp = &tile[((row + r) * (PX_W + 2) + col + s2) * PX_PS];
+#pragma unroll
+            for (int c4 = 0; c4 < PX_CC / 4; ++c4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xp + c4 * 4);
+#pragma unroll
+                for (int j = 0; j < JS; ++j) {
+                    const float4 wv = wl[(t * (PX_CC / 4) + c4) * JS + j];
+                    acc[j][0] = pkfma(f32x2{xv.x, xv.y}, f32x2{wv.x, wv.y}, acc[j][0]);
+                    acc[j][1] = pkfma(f32x2{xv.z, xv.w}, f32x2{wv.z, wv.w}, acc[j][1]);
+                }
+            }
+        }
+    }
+    if (p0 + row < p.H) {
+        const long long off = (long long)n * p.ys_n + (long long)(p0 + row) * p.ys_p + (long long)col * p.ys_q;
+#pragma unroll
+        for (int j = 0; j < JS; ++j) {
+            const f32x2 a = acc[j][0] + acc[j][1];
+            p.y[off + j * p.ys_c] = (a.x + a.y) + (p.bias ? p.bias[j] : 0.f);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 struct FWParams {
     const float* many; long long ms_n, ms_h, ms_w; int MH, MW, CM;    // wide operand [N, MH, MW, CM], channels-last
@@ -714,7 +818,31 @@ static int launch_m2f_ring(M2FParams p, hipStream_t st) {
     return ctgan_check_launch("fewch_m2f_ring");
 }
 
+static int g_m2f_px = 1;       // tests / A-B: ctgan_debug_m2f_px(0) puts the 3x3 many -> few convs back on the row-ring kernel
+extern "C" void ctgan_debug_m2f_px(int on) { g_m2f_px = on ? 1 : 0; }
+
+static bool m2f_px_ok(const M2FParams& p, int R, int S, int JS) {
+    return g_m2f_px && JS == 3 && R == 3 && S == 3 && p.pad_t == 1 && p.pad_l == 1 && p.W == PX_W && p.P == p.H && p.Q == p.W && p.CM % PX_CC == 0 &&
+           (p.xs_w % 4 == 0) && (p.xs_h % 4 == 0) && (p.xs_n % 4 == 0);
+}
+
+static int launch_m2f_px(const M2FParams& m, hipStream_t st) {
+    PXParams p;
+    p.x = m.x; p.xs_n = m.xs_n; p.xs_h = m.xs_h; p.xs_w = m.xs_w; p.H = m.H; p.CM = m.CM;
+    p.y = m.y; p.ys_n = m.ys_n; p.ys_c = m.ys_c; p.ys_p = m.ys_p; p.ys_q = m.ys_q;
+    p.w = m.w; p.w_off = m.w_off; p.ws_r = m.ws_r; p.ws_s = m.ws_s; p.ws_c = m.ws_c; p.ws_j = m.ws_j;
+    p.bias = m.bias; p.relu_in = m.relu_in;
+    p.tiles = (m.H + PX_TH - 1) / PX_TH;
+    const size_t smem = (size_t)PX_PIX * PX_PS * sizeof(float) + (size_t)9 * (PX_CC / 4) * 3 * sizeof(float4);
+    int rc = set_smem(&m2f_px_kernel<3>, smem);
+    if (rc) return rc;
+    hipLaunchKernelGGL((m2f_px_kernel<3>), dim3(m.N * p.tiles), dim3(PX_NT), smem, st, p);
+    ctgan_set_last_symbol("m2f_px_kernel<3>");
+    return ctgan_check_launch("fewch_m2f_px");
+}
+
 static int launch_m2f(const M2FParams& p, int R, int S, int JS, hipStream_t st) {
+    if (m2f_px_ok(p, R, S, JS)) return launch_m2f_px(p, st);
     if (m2f_ring_ok(p, R, S)) {
         if (JS == 3) return launch_m2f_ring<3>(p, st);
         if (JS == 1) return launch_m2f_ring<1>(p, st);

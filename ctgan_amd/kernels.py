@@ -775,6 +775,13 @@ def debug_x3_s2halo(on):
     lib.ctgan_debug_x3_s2halo(1 if on else 0)
 
 
+def debug_m2f_px(on):
+    """Tests / A-B: False = the 3x3 many -> few convs on the row-ring kernel instead of the one-pixel-per-lane kernel (csrc/fewch.hip)."""
+    lib.ctgan_debug_m2f_px(1 if on else 0)
+
+
+if os.environ.get('CTGAN_M2F_PX') == '0':
+    debug_m2f_px(False)
 if os.environ.get('CTGAN_X3_S2HALO') == '0':      # (bench A/B; the routing query ctgan_conv2d16_x3_prefers follows the switch)
     debug_x3_s2halo(False)
 

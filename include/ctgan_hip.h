@@ -75,6 +75,9 @@ void ctgan_debug_force_generic(int on);
 void ctgan_debug_x3_halo_version(int version);
 /* tests / A-B: 0 = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel (conv16x3p_kernel) */
 void ctgan_debug_x3_s2halo(int on);
+/* Tests / A-B: 0 = the 3x3 many -> few convs (generator output conv, data gradient of the first critic conv) on the row-ring kernel
+ * instead of the one-pixel-per-lane kernel with the filter as scalar operands (csrc/fewch.hip, round 5).                          */
+void ctgan_debug_m2f_px(int on);
 /* tests only: which weight-gradient kernels the last ctgan_conv2d16_wgrad_group call on this thread launched - bit 0: the filter-column
    kernel (wgrad16c_group_kernel), bit 1: the slice kernel (wgrad16_group_kernel)                                                     */
 int ctgan_debug_last_wgrad_group_kinds(void);

@@ -992,3 +992,39 @@ def test_adam_leaves_elements_with_a_non_finite_gradient_untouched():
         assert torch.equal(opt.theta[~ok].cpu(), init[~ok.cpu()]) and (opt.m[~ok] == 0).all() and (opt.v[~ok] == 0).all()
     finally:
         lib.delete_all_params()
+
+
+@pytest.mark.parametrize('N,C,dgrad', [(3, 128, False), (64, 128, True), (5, 64, True), (2, 256, False)])
+def test_many_to_few_one_pixel_per_lane_kernel(K, N, C, dgrad):
+    """m2f_px_kernel (csrc/fewch.hip, round 5): the 3x3 many -> few convs on 32-pixel rows with one output pixel per lane and the filter
+    as scalar operands - the generator's output conv (forward, NCHW result, filter [r,s,many,few]: the few index has unit stride) and the
+    data gradient of the first critic conv (filter [r,s,few,many]: the many index has unit stride) - against the fp64 oracle and
+    against the row-ring kernel it replaces, with bias / relu-on-load where the entry point has them."""
+    g = torch.Generator().manual_seed(N + C)
+    H = 32
+    if dgrad:
+        geom = K.ConvGeom(3, H, H, C, 3, 3, 1, False)
+        w = torch.randn(3, 3, 3, C, generator=g) / np.sqrt(27)
+        gy = torch.randn(N, C, H, H, generator=g)
+        x_ = torch.zeros(N, 3, H, H, dtype=torch.float64, requires_grad=True)
+        (ref,) = torch.autograd.grad(tf_ops.conv2d_same(x_, w.double(), 1), x_, gy.double())
+        run = lambda: K.conv_dgrad(cl(gy), dev(w), geom, N, out_strides=(3 * H * H, H * H, H, 1))      # noqa: E731
+        sym = 'm2f_px_kernel<3>'
+    else:
+        geom = K.ConvGeom(C, H, H, 3, 3, 3, 1, False)
+        w = torch.randn(3, 3, C, 3, generator=g) / np.sqrt(9 * C)
+        b = torch.randn(3, generator=g)
+        x = torch.randn(N, C, H, H, generator=g)
+        ref = tf_ops.bias_add_nchw(tf_ops.conv2d_same(torch.relu(x.double()), w.double(), 1), b.double())
+        run = lambda: K.conv_fwd(cl(x), dev(w), dev(b), geom, out_strides=(3 * H * H, H * H, H, 1), relu_in=True)      # noqa: E731
+        sym = 'm2f_px_kernel<3>'
+    y = run()
+    assert K.last_symbol() == sym, K.last_symbol()
+    assert y.is_contiguous() and relerr(y, ref) < 2e-5
+    K.debug_m2f_px(False)
+    try:
+        y_ring = run()
+        assert 'm2f_px' not in K.last_symbol()
+    finally:
+        K.debug_m2f_px(True)
+    assert relerr(y, y_ring) < 2e-6
