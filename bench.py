@@ -178,35 +178,62 @@ def main():
         replicas_identical = all(torch.equal(allcs[0], c) for c in allcs[1:])
         sane = sane and replicas_identical
 
-    # N > 1: what the six gradient all-reduces of an iteration cost on the critical path = the same loop with the collective
-    # switched off on every rank (the replicas drift apart from here on: nothing below compares them)
+    # N > 1: what the six gradient all-reduces of an iteration cost on the critical path.  Three engines on the same loop: the default (one
+    # bucket per step), the split flush (Trainer.split_flush: blocks 1-2 of the critic's bucket all-reduced under the rest of the backward -
+    # the overlap the north star asks for, behind a switch) and the same launches with the collective replaced by nothing
+    # (the replicas drift apart from there on: nothing below compares them).  exposed = loop time - loop time without the collective.
     collective = None
-    if world > 1 and eng.ar_in_graph:
-        collective = {'all_reduces_per_step': R.cfg.N_CRITIC + 1, 'in_graph': True,
-                      'bucket_bytes': {'critic': 4 * trainer.d_opt.theta.numel(), 'generator': 4 * trainer.g_opt.theta.numel()},
-                      'note': 'the all-reduces are nodes of the iteration graph (serial in stream order: fully exposed, but no graph boundaries '
-                              'or eager launches between the steps)'}
-    elif world > 1:
-        saved_ar, trainer.allreduce = trainer.allreduce, None
-        try:
-            k2 = max(5, min(20, args.steps))
+    if world > 1:
+        def timed_loop(e, k):
+            nonlocal it
             for _ in range(3):
-                eng.train_iteration(it, next_batch); it += 1
+                e.train_iteration(it, next_batch); it += 1
             ddp.barrier(); torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(k2):
-                eng.train_iteration(it, next_batch); it += 1
+            for _ in range(k):
+                e.train_iteration(it, next_batch); it += 1
             torch.cuda.synchronize(); ddp.barrier()
             tl = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
-            ms_local = 1e3 * tl.item() / k2
+            return 1e3 * tl.item() / k
+
+        class _NoComm:          # same call surface as ddp.FlatAllReduce, no communication: the launches of the step without the collective
+            always = True
+            def inline(self, flat): pass
+            def __call__(self, flat): pass
+            def wait(self): pass
+        k2 = max(5, min(20, args.steps))
+        collective = {'all_reduces_per_step': R.cfg.N_CRITIC + 1, 'in_graph': bool(eng.ar_in_graph), 'steps': k2,
+                      'bucket_bytes': {'critic': 4 * trainer.d_opt.theta.numel(), 'generator': 4 * trainer.g_opt.theta.numel()},
+                      'critic_bucket_prefix_bytes_split_flush': 4 * trainer.d_opt.offsets[trainer._n_early] if trainer._n_early < len(trainer.d_opt.offsets) else None}
+        try:
+            trainer.split_flush = True
+            eng_s = GraphedTrainer(trainer, use_graphs=not args.no_graph, ar_in_graph=eng.ar_in_graph)
+            ms_split = timed_loop(eng_s, k2)
+            collective['split_flush'] = {'ms_per_step': round(ms_split, 3), 'graph_error': eng_s.graph_error,
+                                         'what': 'critic steps hand blocks 1-2 of the bucket (a prefix) to their own all-reduce on the side stream as soon '
+                                                 'as the hand-scheduled step has completed them; the rest follows at the end of the step'}
+            del eng_s
+        except Exception as e:          # noqa: BLE001   (report, never fail the record over the comparison)
+            collective['split_flush'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        finally:
+            trainer.split_flush = False
+        saved_ar = trainer.allreduce
+        try:
+            trainer.allreduce = _NoComm()
+            eng_n = GraphedTrainer(trainer, use_graphs=not args.no_graph, ar_in_graph=eng.ar_in_graph)
+            ms_local = timed_loop(eng_n, k2)
+            del eng_n
+            collective['ms_per_step_without_all_reduce'] = round(ms_local, 3)
+            collective['exposed_ms_per_step'] = round(ms_per_step - ms_local, 3)
+            if 'ms_per_step' in collective.get('split_flush', {}):
+                collective['split_flush']['exposed_ms_per_step'] = round(collective['split_flush']['ms_per_step'] - ms_local, 3)
+        except Exception as e:          # noqa: BLE001
+            collective['without_all_reduce_error'] = '%s: %s' % (type(e).__name__, e)
         finally:
             trainer.allreduce = saved_ar
-        collective = {'all_reduces_per_step': R.cfg.N_CRITIC + 1,
-                      'bucket_bytes': {'critic': 4 * trainer.d_opt.theta.numel(), 'generator': 4 * trainer.g_opt.theta.numel()},
-                      'ms_per_step_without_all_reduce': round(ms_local, 3), 'steps': k2,
-                      'exposed_ms_per_step': round(ms_per_step - ms_local, 3),
-                      'overlap': 'side stream; the next critic step\'s input staging is enqueued while the bucket is in flight (DESIGN 5)'}
+        collective['note'] = ('in_graph: the all-reduces are nodes of the iteration graph (RCCL under stream capture); otherwise eager collectives on a '
+                              'side stream between per-step graphs, the next step\'s input staging enqueued while the bucket is in flight (DESIGN 5)')
 
     # The same loop fed the way the reference's loop is (TF/CT_gan_cifar_resnet.py:394-412 times the feed too; TF/tflib/cifar10.py:40-63 is
     # the contract): uint8 epochs shuffled on the host, pinned prefetch two batches deep, H2D on a copy stream, the iteration's staging
@@ -281,6 +308,10 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(lib, torch)
 
+    import ctgan_amd.critic_schedule as CS
+    critic_scheduled = bool(CS.usable(R, None, trainer.rng, batches[0][0], torch.zeros(B, R.cfg.OUTPUT_DIM, device=dev)))
+    # a finite-gradient guard fired during the timed loops = the run overflowed or diverged: not a valid measurement
+    sane = sane and trainer.d_opt.skipped() == 0 and trainer.g_opt.skipped() == 0
     if rank == 0:
         rec = {
             'metric': 'img/s per (n_critic D + 1 G) step, CIFAR-10 ResNet',
@@ -299,6 +330,10 @@ def main():
                                       'v_mfma_f32_32x32x2_f32' if (K.X3_HYBRID and K.MMA_DTYPE is None) else 'fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout'),
                        'fp32_mfma_only': fp32_only},
             'ms_per_step_p50': round(p50, 3),
+            # (also at the top level, so that a parse of the line shows them: the host-fed loop, the all-fp32-MFMA number, Adam's skip count)
+            'host_feed': host_feed, 'fp32_mfma_only': fp32_only,
+            'adam_skipped_elements': {'critic': trainer.d_opt.skipped(), 'generator': trainer.g_opt.skipped()},
+            'critic_step': 'hand-scheduled (critic_schedule.py: one backward chain over dropout-pass rows + penalty rows)' if critic_scheduled else 'autograd',
             'step': step_exec,
             'step_effective_frac': round(ITER_GFLOP * 1e9 / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             'step_effective_frac_note': 'EFFECTIVE rate, not a roofline fraction: FLOPs of the REFERENCE formulation (SURVEY 8(d), 2990.5 GFLOP / iteration) / time / fp32 MFMA peak; the executed count is lower (resampled convs run as stride-2 convs with the spread filter): see step.frac_executed',
@@ -560,7 +595,8 @@ def run_unconditional(args):
             'dtype': dtype or 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'name': args.config, 'global_batch': B * world, 'images_per_step': n_crit * B * world,
                        'parallelism': 'dp%d' % world, 'hipgraph': bool(eng.graphed), 'last_d_terms': last, 'loss_sane': sane,
-                       'loss_scale': tr.loss_scale, 'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1]},
+                       'loss_scale': tr.loss_scale, 'backend': dist_info(world)[0], 'rccl_world': dist_info(world)[1],
+                       'adam_skipped_elements': {'critic': tr.d_opt.skipped(), 'generator': tr.g_opt.skipped()}},
             'roofline': roofline, 'cpu_baseline': None, 'build': build_provenance()}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

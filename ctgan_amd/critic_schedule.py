@@ -60,8 +60,10 @@ class _Grads:
 
     def __init__(self):
         self.by_name = {}
+        self.keys = {}          # conv name -> the queue key of its filter (functional._wgrad)
 
     def wgrad(self, name, x, gy, w, g, relu_x, with_bias, spread=None):
+        self.keys[name] = (w.data_ptr(), (g.C, g.H, g.W, g.K, g.R, g.S, g.stride))
         gw, gb = F._wgrad(x, gy, w, g, relu_x, with_bias)
         if gw is not None:
             if spread is not None:
@@ -80,9 +82,18 @@ class _Grads:
             self.by_name[name + '.Biases'] = gb
 
 
-def critic_step(tr, R, real_int, labels, fake):
+EARLY_CONVS = ('Discriminator.1.Conv1', 'Discriminator.1.Conv2', 'Discriminator.1.Shortcut', 'Discriminator.2.Conv1', 'Discriminator.2.Conv2',
+               'Discriminator.2.Shortcut')
+
+
+def critic_step(tr, R, real_int, labels, fake, early=None):
     """One critic step's losses AND parameter gradients -> (out, grads): `out` as Trainer.d_losses returns it, `grads` aligned with
-    tr.d_params.  Must run inside torch.no_grad() and functional.deferred_wgrads() (the caller flushes the queue by leaving the latter)."""
+    tr.d_params.  Must run inside torch.no_grad() and functional.deferred_wgrads() (the caller flushes the queue by leaving the latter).
+
+    early (batch-sharded steps, SURVEY 5.7 / north star: "all-reduce overlapped with backward"): callable(dict name -> gradient).  The
+    weight gradients of blocks 1-2 - a contiguous prefix of the flat bucket, 45 % of its bytes - are complete as soon as the
+    penalty's double backward has left block 2, while six more launches of blocks 3-4 are still to come: with `early` they are flushed
+    there (functional.flush_partial: a grouped launch of their own) and handed over, so that their all-reduce can run under the rest."""
     cfg = R.cfg
     B, D = cfg.BATCH_SIZE, cfg.DIM_D
     rng = tr.rng
@@ -185,6 +196,9 @@ def critic_step(tr, R, real_int, labels, fake):
     G.wgrad('Discriminator.2.Conv2', u_a2, g_h2[m:], w22, g22, False, False, spread=0.25)
     u_h2 = K.conv_fwd(u_h1, wsc2, None, gsc2, resid=t)                # cotangent of g_h2 = of the penalty rows of g_tin
     G.wgrad('Discriminator.2.Shortcut', u_h1, g_h2[m:], wsc2, gsc2, False, False, spread=0.25)
+    if early is not None and F._DEFER['on']:
+        F.flush_partial([G.keys[c] for c in EARLY_CONVS])
+        early({n: G.by_name[n] for c in EARLY_CONVS for n in (c + '.Filters', c + '.Biases')})
     # block 3: dropout mask, then the ReLU mask (constants of the second pass); the dropped-only tensor goes on through the shortcut
     s1, s2 = gp_specs[0], gp_specs[1]
     r3, u = K.dropout_rng_mask(u_h2, tin[3 * B:T], s1[0], s1[1], s1[2], s1[3], want_dropped=True)

@@ -63,7 +63,7 @@ class FlatAllReduce:
         self.group = group
         self.side = side_stream
         self.always = always          # tests: issue the collective for a 1-rank group too (exercises the RCCL enqueue / capture path)
-        self._pending = None
+        self._pending = []            # completion events of the collectives in flight (a step may hand its bucket over in parts)
 
     def inline(self, flat):
         """The collective on the CALLER's current stream, synchronously in stream order - the form that can be captured into a
@@ -72,12 +72,12 @@ class FlatAllReduce:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def __call__(self, flat):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.always):
             return
         if self.side is None or not flat.is_cuda:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             return
-        assert self._pending is None, 'previous all-reduce was never waited for'
+        assert len(self._pending) < 4, 'earlier all-reduces were never waited for'
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
@@ -85,13 +85,13 @@ class FlatAllReduce:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             done = torch.cuda.Event()
             done.record(self.side)
-        self._pending = done
+        self._pending.append(done)
 
     def wait(self):
-        """Order the caller's current stream behind the outstanding collective (if any)."""
-        if self._pending is not None:
-            torch.cuda.current_stream().wait_event(self._pending)
-            self._pending = None
+        """Order the caller's current stream behind the outstanding collectives (if any)."""
+        for done in self._pending:
+            torch.cuda.current_stream().wait_event(done)
+        self._pending = []
 
 
 def broadcast_params(flat_buffers, src=0, group=None):

@@ -82,6 +82,7 @@ class GraphedTrainer:
         self.adam_in_graph = trainer.world == 1 or self.ar_in_graph
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
+        self.graphed_capture = bool(use_graphs)      # the step bodies run under capture / replay (as opposed to eager launches)
         self.graph_error = None
         self.it_graph_error = None    # only the whole-iteration graph failed to capture: the per-step graphs are in use (still `graphed`)
         if use_graphs:
@@ -111,11 +112,19 @@ class GraphedTrainer:
         lib.bump_epoch('Discriminator' if self.batch_fakes else None)
         F.prepare_filters()
         t.rng.begin_step()
-        out, grads = t.d_grads(real, labels, fake=fake)
-        self._finish(t.d_opt, grads)
+        handed = [0]
+        early = None
+        if t.split_flush and t.world > 1 and t.allreduce is not None and t._n_early and (self.ar_in_graph or not self.graphed_capture):
+            # the bucket's prefix (blocks 1-2) goes to its all-reduce from inside the step: on the side stream - forked into the capture
+            # when the collectives are graph nodes (RCCL) - under the rest of the penalty's double backward.  Not with the collective outside
+            # the graph (gloo under graph replay): there the graph ends at the packed bucket.
+            def early(gpart):
+                handed[0] = t.early_reduce(gpart)
+        out, grads = t.d_grads(real, labels, fake=fake, early=early)
+        self._finish(t.d_opt, grads, lo=handed[0])
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
 
-    def _finish(self, opt, grads):
+    def _finish(self, opt, grads, lo=0):
         """End of a captured step body.  Adam inside the graph: bucket + update in one launch and the step end in another (single rank), or bucket,
         in-graph all-reduce, update + step end.  Adam outside (side-stream all-reduce): the graph ends at the packed bucket and at
         the Philox counter's own advance - Trainer.reduce_and_update must not advance it again, hence rng=None there."""
@@ -123,17 +132,20 @@ class GraphedTrainer:
         if self.adam_in_graph and not self.ar_in_graph:
             opt.update(grads, 1.0 / t.world, rng=t.rng)
             return
-        opt.gather_grads(grads)
-        self._reduce_in_graph(opt)
+        part = opt.gather_grads(grads, lo)
+        self._reduce_in_graph(part)
+        if lo and hasattr(t.allreduce, 'wait'):
+            t.allreduce.wait()              # join the forked collective of the bucket's prefix (Trainer.early_reduce)
         if self.adam_in_graph:
             opt.step(1.0 / t.world, rng=t.rng)
         else:
             t.rng.end_step()
 
-    def _reduce_in_graph(self, opt):
-        """The flat gradient bucket summed over the ranks ON the capturing stream: the collective becomes a node of the step graph."""
+    def _reduce_in_graph(self, flat):
+        """The flat gradient bucket (or its remaining part) summed over the ranks ON the capturing stream: the collective becomes a node of
+        the step graph."""
         if self.ar_in_graph:
-            self.t.allreduce.inline(opt.grad)
+            self.t.allreduce.inline(flat)
 
     def _it_body(self):
         """A whole iteration of the loop body (TF/CT_gan_cifar_resnet.py:393-404) with it > 0: generator step, the fake batches

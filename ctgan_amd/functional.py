@@ -104,6 +104,32 @@ def deferred_wgrads():
                 fn()
 
 
+def flush_partial(keys):
+    """Inside deferred_wgrads(): flush NOW the queued weight gradients of the filters `keys` (the (filter address, geometry) keys of
+    _wgrad) - one grouped launch for them - and fold the spread-filter gradients that belong to them; the rest of the queue stays for
+    the flush at the end of the block.  For a step that hands part of its gradient bucket to the all-reduce early
+    (critic_schedule.critic_step(early=...): blocks 1-2 of the critic are complete while the penalty's double backward is still in blocks
+    3-4).  Every use of those filters must have been queued already: a later request would open a second result buffer."""
+    assert _DEFER['on']
+    groups = _DEFER['groups']
+    part = [groups.pop(k) for k in keys if k in groups]
+    if not part:
+        return
+    _flush_groups(part)
+    bufs = {id(g.dw) for g in part}
+    post, keep = _DEFER['post'], []
+    folds = []
+    for e in post:
+        if isinstance(e, tuple) and e[0] == 'fold' and id(e[1]) in bufs:
+            folds.append(e[1:])
+        else:
+            keep.append(e)
+    post[:] = keep
+    if folds:
+        K.filter_fold_batch(folds)
+    _DEFER['imm'].update(keys)          # a stray later use of one of these filters is launched at once instead of re-opening its queue
+
+
 def _seg_bias(grp):
     return any(sg[3] for sg in grp.segs)
 

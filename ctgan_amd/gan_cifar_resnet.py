@@ -312,6 +312,10 @@ HEADS_FOLD = _os.environ.get('CTGAN_HEADS_FOLD', '1') != '0'
 PREP_FUSION = _os.environ.get('CTGAN_PREP_FUSION', '1') != '0'
 
 
+# Batch-sharded steps: the critic's gradient bucket in two parts, the first one all-reduced under the rest of the backward (Trainer.split_flush)
+SPLIT_FLUSH = _os.environ.get('CTGAN_SPLIT_FLUSH', '0') == '1'
+
+
 # Draw the fake batches of all N_CRITIC critic steps of an iteration in one generator forward (Trainer.generate_fakes)
 BATCH_FAKES = _os.environ.get('CTGAN_BATCH_FAKES', '1') != '0'
 
@@ -401,6 +405,15 @@ class Trainer:
         self.d_params = [p for _, p in self.d_named]
         self.g_params = [p for _, p in self.g_named]
         self._one = None
+        # Batch-sharded steps: hand the critic's gradient bucket to the all-reduce in two parts - blocks 1-2 (a prefix of the flat bucket)
+        # as soon as the hand-scheduled step has completed them, under the rest of the penalty's double backward (north star: "all-reduce
+        # overlapped with backward").  A switch, off by default: a second grouped weight-gradient launch and a second collective against
+        # ~0.15 ms of overlap on a 4 MB bucket; bench.py --split-flush reports the exposed time of both forms.
+        self.split_flush = SPLIT_FLUSH
+        names = [n for n, _ in self.d_named]
+        self._n_early = 0
+        while self._n_early < len(names) and names[self._n_early].startswith(('Discriminator.1.', 'Discriminator.2.')):
+            self._n_early += 1
 
     def cost_seed(self, cost):
         """grad_outputs of a step's backward: a cached tensor of ones (autograd otherwise launches a fill kernel per step)."""
@@ -513,7 +526,15 @@ class Trainer:
                    real=real, d_real=d_all[:B], d_fake=d_all[B:2 * B], gp_grads=grads)
         return out
 
-    def d_grads(self, real_int, labels, rnd=None, fake=None):
+    def early_reduce(self, gpart):
+        """`early` hook of critic_schedule.critic_step: the finished gradients of blocks 1-2 -> the prefix of the flat bucket -> their
+        all-reduce, asynchronous on the side stream (ddp.FlatAllReduce).  Returns the number of parameters handed over."""
+        opt, n = self.d_opt, self._n_early
+        part = opt.gather_grads([gpart.get(name) for name in opt.names[:n]] + [None] * (len(opt.names) - n), 0, n)
+        self.allreduce(part)
+        return n
+
+    def d_grads(self, real_int, labels, rnd=None, fake=None, early=None):
         """Losses and parameter gradients of one critic step -> (out, grads aligned with self.d_params): compute_gradients(disc_cost) of
         :335-336.  Default: the hand-scheduled step (critic_schedule.py - one backward chain over the rows of the dropout passes and of the
         gradient-penalty pass); the autograd path (d_losses + torch.autograd.grad) wherever that schedule does not apply - injected draws
@@ -524,7 +545,7 @@ class Trainer:
                 fake = Generator(cfg.BATCH_SIZE, labels, groups=2, rng=self.rng)
         if CS.usable(_this_module(), rnd, self.rng, real_int, fake):
             with torch.no_grad(), F.deferred_wgrads():
-                return CS.critic_step(self, _this_module(), real_int, labels, fake)
+                return CS.critic_step(self, _this_module(), real_int, labels, fake, early=early)
         out = self.d_losses(real_int, labels, rnd, fake=fake)
         with F.deferred_wgrads():
             grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed(out['cost']), allow_unused=True)
@@ -591,8 +612,13 @@ class Trainer:
         """session.run([..., disc_train_op]) :402"""
         F.prepare_filters()
         self.rng.begin_step()
-        out, grads = self.d_grads(real_int, labels, rnd, fake=fake)
-        self._apply(self.d_opt, grads, iteration, set_lr)
+        handed = [0]
+        early = None
+        if self.split_flush and self.world > 1 and self.allreduce is not None and self._n_early:
+            def early(gpart):
+                handed[0] = self.early_reduce(gpart)
+        out, grads = self.d_grads(real_int, labels, rnd, fake=fake, early=early)
+        self._apply(self.d_opt, grads, iteration, set_lr, lo=handed[0])
         out['grads'] = dict(zip([n for n, _ in self.d_named], grads))
         return out
 
@@ -607,14 +633,15 @@ class Trainer:
         out['grads'] = dict(zip([n for n, _ in self.g_named], grads))
         return out
 
-    def _apply(self, opt, grads, iteration, set_lr):
+    def _apply(self, opt, grads, iteration, set_lr, lo=0):
+        """lo: the first `lo` parameters' gradients are already in the bucket and on their way through the all-reduce (early_reduce)."""
         if set_lr:
             opt.set_lr(self.lr(iteration))
         if self.allreduce is None or self.world <= 1:
             # single rank: gradient bucket + Adam in one launch, the end of the step (beta powers, Philox step counter) in another
             opt.update(grads, 1.0 / self.world, rng=self.rng)
             return
-        flat = opt.gather_grads(grads)
+        flat = opt.gather_grads(grads, lo)
         self.reduce_and_update(opt, flat)
 
     def reduce_and_update(self, opt, flat, between=None, end_rng=True):

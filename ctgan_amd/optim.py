@@ -66,22 +66,27 @@ class FlatAdam:
         Reads device memory: call it outside captured regions, at logging cadence."""
         return int(self.state[3].item())
 
-    def gather_grads(self, grads):
+    def gather_grads(self, grads, lo=0, hi=None):
         """Pack per-parameter gradients (None = zero) into the flat bucket with ONE kernel (the pointer table rides
-        in the kernel arguments: no per-variable copy, hipGraph-capture safe)."""
+        in the kernel arguments: no per-variable copy, hipGraph-capture safe).  lo / hi: only parameters [lo, hi) - `grads` still
+        lists all of them - for a step that hands its bucket to the all-reduce in two parts; returns that part of the bucket."""
+        hi = len(self.sizes) if hi is None else hi
+        end = self.offsets[hi] if hi < len(self.sizes) else self.grad.numel()
+        part = self.grad[self.offsets[lo]:end] if lo < hi else self.grad[0:0]
+        if lo >= hi:
+            return part
         if self.grad.device.type != 'cuda':
-            off = 0
-            for g, n in zip(grads, self.sizes):
+            for i in range(lo, hi):
+                g, off, n = grads[i], self.offsets[i], self.sizes[i]
                 if g is None:
                     self.grad[off:off + n].zero_()
                 else:
                     self.grad[off:off + n].copy_(g.reshape(-1))
-                off += n
-            return self.grad
-        srcs = [g.contiguous() if g is not None else None for g in grads]
-        K.pack(srcs, self.offsets, self.sizes, self.grad)
-        self._keepalive = srcs          # sources stay allocated until the next gather
-        return self.grad
+            return part
+        srcs = [g.contiguous() if g is not None else None for g in grads[lo:hi]]
+        K.pack(srcs, self.offsets[lo:hi], self.sizes[lo:hi], self.grad)
+        self._keepalive = (self._keepalive if lo else []) + srcs          # sources stay allocated until the next step's first gather
+        return part
 
     def step(self, grad_scale=1.0, rng=None):
         """theta <- Adam(theta, grad); then ONE launch advances the beta-power accumulators and, with `rng`, that stream's step

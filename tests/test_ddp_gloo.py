@@ -124,3 +124,68 @@ def test_two_rank_step_equals_average_of_rank_gradients(tmp_path):
         assert torch.allclose(tr.g_opt.theta[~live], res[0]['g'][~live], rtol=0, atol=5e-4)
     finally:
         lib.delete_all_params(); lib.set_device(None); R.configure()
+
+
+def _split_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    lib = _patch_cpu()
+    import ctgan_amd.critic_schedule as CS
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    from ctgan_amd import ddp
+    from ctgan_amd.engine import GraphedTrainer
+    ddp.init_from_env(backend='gloo')
+    res = {}
+    for split in (False, True):
+        lib.delete_all_params(); lib.set_device('cpu'); lib.set_seed(7)
+        R.configure(DIM_G=8, DIM_D=64, BATCH_SIZE=2)                  # DIM_D = 64: the width from which the hand-scheduled step applies
+        R.build_params('cpu')
+        tr = R.Trainer(seed=1, rank=rank, world_size=world, allreduce=ddp.FlatAllReduce())
+        tr.split_flush = split
+        ddp.broadcast_params([tr.d_opt.theta, tr.g_opt.theta])
+        calls, early_calls = [], []
+        orig, orig_early = CS.critic_step, tr.early_reduce
+        CS.critic_step = lambda *a, **k: (calls.append(k.get('early') is not None), orig(*a, **k))[1]
+        tr.early_reduce = lambda gp: (early_calls.append(sorted(gp)), orig_early(gp))[1]
+        try:
+            g = torch.Generator().manual_seed(100 + rank)
+            real = torch.randint(0, 256, (2, 3072), generator=g, dtype=torch.int32)
+            labels = torch.randint(0, 10, (2,), generator=g, dtype=torch.int32)
+            F.prepare_filters()
+            fake = tr.generate_fakes(labels)[0]
+            out = tr.d_step(real, labels, iteration=0, fake=fake)
+            grads = tr.d_opt.grad.clone()                              # the reduced bucket
+            eng = GraphedTrainer(tr, use_graphs=False)                 # and through the engine's eager loop
+            o2 = eng.train_iteration(1, lambda: (real, labels))
+        finally:
+            CS.critic_step = orig
+        assert calls and all(c == split for c in calls), calls
+        assert (len(early_calls) == len(calls)) if split else not early_calls
+        if split:
+            assert all(n.startswith(('Discriminator.1.', 'Discriminator.2.')) for n in early_calls[0]) and len(early_calls[0]) == 12
+        res[split] = {'grad': grads, 'theta': tr.d_opt.theta.clone(), 'g': tr.g_opt.theta.clone(), 'cost': out['cost'].detach().clone(),
+                      'cost2': o2['cost'].detach().clone()}
+    torch.save(res, os.path.join(out_dir, 'split_rank%d.pt' % rank))
+    ddp.barrier()
+    torch.distributed.destroy_process_group()
+    R.configure()
+
+
+def test_split_flush_hands_blocks_1_2_over_early_and_changes_no_bit(tmp_path):
+    """Trainer.split_flush (the all-reduce overlapped with backward the north star asks for, behind a switch): the
+    hand-scheduled critic step flushes the weight gradients of blocks 1-2 when the penalty's double backward has left them and hands that
+    prefix of the flat bucket to its own all-reduce; the rest follows at the end of the step.  World 2 over gloo: the reduced bucket, the
+    weights after the step and after a further loop iteration are BIT-identical to the one-bucket form on every rank (the stand-in
+    kernels are row-order independent; on the GPU the two grouped launches plan their split-K chunks separately - same values to fp32
+    rounding), and the replicas stay in sync."""
+    world = 2
+    mp.spawn(_split_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), 'split_rank%d.pt' % r)) for r in range(world)]
+    for r in range(world):
+        a, b = res[r][False], res[r][True]
+        for k in a:
+            assert torch.equal(a[k], b[k]), (r, k)
+    assert torch.equal(res[0][True]['theta'], res[1][True]['theta']) and torch.equal(res[0][True]['g'], res[1][True]['g'])
+    assert not torch.equal(res[0][True]['cost'], res[1][True]['cost'])

@@ -331,10 +331,18 @@ def test_all_reduce_captured_in_the_step_graphs():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    r = subprocess.run([sys.executable, os.path.join(here, 'ar_in_graph_check.py'), '32', '8', '3'], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, os.path.join(here, 'ar_in_graph_check.py'), '32', '8', '3', '64', '8'], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert rec['backend'] == 'nccl' and rec['d_equal'] and rec['g_equal'], rec
     assert math.isfinite(rec['cost_in_graph']) and rec['cost_plain'] == rec['cost_in_graph'], rec
     # grad_scale = 1 / world != 1 through the in-graph path (gather, all-reduce, Adam with the average folded in)
     assert rec['scaled_d_equal'] and rec['scaled_g_equal'] and rec['scaled_differs_from_unscaled'], rec
+    # Trainer.split_flush under capture (round 5): the critic bucket's prefix on its own collective, forked onto a side stream inside the
+    # graph and joined before Adam.  Two iterations against the one-bucket form: the two grouped weight-gradient launches plan their
+    # split-K chunks separately (another fp32 summation order), and Adam's first steps are sign-like, so single near-zero-gradient
+    # entries may move by a step in the other direction - the weights agree to 2e-5 but for a small fraction of entries, never by more
+    # than a few learning rates; the generator (whose gradients do not pass through the split) agrees to rounding through the critic.
+    sp = rec['split_flush']
+    assert sp is not None and math.isfinite(sp['cost_split']) and abs(sp['cost_split'] - sp['cost_one_bucket']) <= 1e-3 * max(1.0, abs(sp['cost_one_bucket'])), sp
+    assert sp['theta_max_abs_diff'] <= 2e-3 and sp['theta_frac_above_2e-5'] <= 0.02, sp
