@@ -289,10 +289,42 @@ def main():
             K.X3_HYBRID = True
             K.clear_pack16_cache()
 
+    # the same loop with the critic step on the autograd path (Trainer.d_losses + two autograd calls: the penalty's first backward as a 64-row
+    # chain of its own) instead of the hand-scheduled step: what merging the penalty rows into the main backward is worth in the step
+    critic_ab = None
+    import ctgan_amd.critic_schedule as CS
+    if CS.MERGED_BWD and rank == 0 and world == 1 and not args.no_roofline:
+        CS.MERGED_BWD = False
+        try:
+            eng3 = GraphedTrainer(trainer, use_graphs=not args.no_graph)
+            k3 = max(10, args.steps // 2)
+            for _ in range(5):
+                eng3.train_iteration(it, next_batch); it += 1
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k3):
+                eng3.train_iteration(it, next_batch); it += 1
+            torch.cuda.synchronize()
+            ms_auto = 1e3 * (time.perf_counter() - t1) / k3
+            critic_ab = {'autograd_path_ms_per_step': round(ms_auto, 3), 'hand_scheduled_ms_per_step': round(ms_per_step, 3), 'steps': k3,
+                         'saved_ms_per_critic_step': round((ms_auto - ms_per_step) / R.cfg.N_CRITIC, 4)}
+            del eng3
+        finally:
+            CS.MERGED_BWD = True
+
     gp_unit = None
     step_exec = None
     if not args.no_roofline and rank == 0:
         gp_unit = measure_gp_unit(trainer, batches[0], torch)
+        if critic_ab is not None and isinstance(gp_unit, dict) and 'ms' in gp_unit:
+            # the unit above is the penalty ALONE (forward + its own 64-row backward chain + double backward, as the autograd path runs it).
+            # In the training step its first backward rides the launches of the main backward: the unit's cost inside the step = its
+            # stand-alone time minus what the merged schedule saves per critic step (measured, same box, same run).
+            ms_in = gp_unit['ms'] - critic_ab['saved_ms_per_critic_step']
+            gf_by_pipe = gp_unit['gflop_executed_by_pipe']
+            gp_unit['in_step'] = {'ms': round(ms_in, 4),
+                                  'frac_executed': round(sum(gf / PIPE_PEAK[pp] for pp, gf in gf_by_pipe.items()) / ms_in, 4),
+                                  'note': 'stand-alone ms - critic_step_ab.saved_ms_per_critic_step; same executed FLOPs'}
         if roofline is not None:
             gf = roofline['all_conv_kernels']['gflop_executed']
             ideal_ms = sum(v['gflop_executed'] / v['peak'] for v in roofline['by_pipe'].values())
@@ -308,7 +340,6 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(lib, torch)
 
-    import ctgan_amd.critic_schedule as CS
     critic_scheduled = bool(CS.usable(R, None, trainer.rng, batches[0][0], torch.zeros(B, R.cfg.OUTPUT_DIM, device=dev)))
     # a finite-gradient guard fired during the timed loops = the run overflowed or diverged: not a valid measurement
     sane = sane and trainer.d_opt.skipped() == 0 and trainer.g_opt.skipped() == 0
@@ -334,6 +365,7 @@ def main():
             'host_feed': host_feed, 'fp32_mfma_only': fp32_only,
             'adam_skipped_elements': {'critic': trainer.d_opt.skipped(), 'generator': trainer.g_opt.skipped()},
             'critic_step': 'hand-scheduled (critic_schedule.py: one backward chain over dropout-pass rows + penalty rows)' if critic_scheduled else 'autograd',
+            'critic_step_ab': critic_ab,
             'step': step_exec,
             'step_effective_frac': round(ITER_GFLOP * 1e9 / (ms_per_step * 1e-3) / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
             'step_effective_frac_note': 'EFFECTIVE rate, not a roofline fraction: FLOPs of the REFERENCE formulation (SURVEY 8(d), 2990.5 GFLOP / iteration) / time / fp32 MFMA peak; the executed count is lower (resampled convs run as stride-2 convs with the spread filter): see step.frac_executed',
@@ -623,18 +655,18 @@ def load_pmc_traffic():
     """profiles/r03_pmc_traffic_x3.json (tools/pmc_x3.sh: separate rocprofv3 --pmc passes, gfx950 corrections of the guide) + the
     round-1 files of the fp32 tiles, keyed by device symbol."""
     out = {}
-    for fn in ('r03_pmc_traffic_x3.json', 'r04_pmc_traffic_x3.json', 'r04_pmc_wgrad_col.json'):      # (later files override earlier ones per symbol; the last: tools/pmc_wgrad_col.sh)
+    for fn in ('r03_pmc_traffic_x3.json', 'r04_pmc_traffic_x3.json', 'r04_pmc_wgrad_col.json', 'r05_pmc_traffic_x3.json', 'r05_pmc_wgrad_col.json'):      # (later files override earlier ones per symbol; *_wgrad_col: tools/pmc_wgrad_col.sh)
         try:
             for sym, rec in json.load(open(os.path.join(ROOT, 'profiles', fn))).items():
                 if isinstance(rec, dict) and 'hbm_bytes_per_launch' in rec and 'flops_per_launch' in rec:
-                    out[sym] = dict(rec, file='profiles/' + fn)
+                    out[sym] = dict(rec, file='profiles/' + fn, measured_in_round=int(fn[1:3]))
         except Exception:
             pass
     for fn, sym in (('r01_pmc_traffic_64x128.json', 'igemm_fwd_pipe_kernel<1, 4, 1, 2, 1, 1, false, 1>'),
                     ('r01_pmc_traffic.json', 'igemm_fwd_pipe_kernel<2, 2, 1, 2, 2, 1, false, 1>')):
         try:
             rec = json.load(open(os.path.join(ROOT, 'profiles', fn)))
-            out.setdefault(sym, dict(rec, file='profiles/' + fn))
+            out.setdefault(sym, dict(rec, file='profiles/' + fn, measured_in_round=1))
         except Exception:
             pass
     return out
@@ -689,6 +721,7 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
         k = flops_per_launch / rec['flops_per_launch']
         out = {'hbm_bytes_per_launch': round(rec['hbm_bytes_per_launch'] * k), 'algorithmic_bytes_per_launch': round(rec['algorithmic_bytes_per_launch'] * k),
                'traffic_over_algorithmic': round(rec['hbm_bytes_per_launch'] / rec['algorithmic_bytes_per_launch'], 2),
+               'measured_in_round': rec.get('measured_in_round'),      # the round whose kernel code / routing the counters were taken on
                'source': '%s (%s; FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes, scaled by FLOPs to this launch mix)'
                          % (rec['file'], rec.get('geometry', 'geometry in the file'))}
         for key in ('mfma_busy_frac', 'valu_active_frac', 'lds_wait_frac', 'l2_hit_rate'):

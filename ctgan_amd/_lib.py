@@ -164,9 +164,13 @@ SIGNATURES = {
                                              c_float, c_float, c_float, _p, _p, _p, _p, _p, _p, _p, _p]),
     'ctgan_tail_heads_bwd': (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float,
                                      _p, _p, _p, _p, _p, _p, _p, _p]),
+    'ctgan_tail_heads_bwd_gp': (c_int, [_p, _p, _p, _p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float,
+                                        _p, _p, _p, _p, _p, _p, _p, _p, c_int32, _p, _p]),
     'ctgan_gen_heads_fwd': (c_int, [_p, c_int32, c_int32, c_int32, _p, _p, _p, _p, c_int32, _p, c_float, _p, _p, _p, _p, _p, _p]),
     'ctgan_gen_heads_bwd': (c_int, [_p, _p, _p, _p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, _p, _p, _p, _p]),
     'ctgan_gp_head_grad': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p, _p]),
+    'ctgan_gp_head_wgrad_acc': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p, _p, _p]),
+    'ctgan_gp_finish': (c_int, [_p, _p, POINTER(c_int64), c_int32, c_int32, c_int32, c_int32, c_float, _p, _p]),
     'ctgan_gp_head_wgrad': (c_int, [_p, _p, c_int32, c_int32, c_int32, c_float, _p, _p, _p]),
     'ctgan_accuracy2': (c_int, [_p, _p, c_int32, c_int32, _p, _p]),
     'ctgan_adam_step': (c_int, [_p, _p, _p, _p, c_int64, _p, c_float, c_float, c_float, c_float, _p]),

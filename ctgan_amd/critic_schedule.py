@@ -124,9 +124,10 @@ def critic_step(tr, R, real_int, labels, fake, early=None):
     one = tr.cost_seed(out5[0]).reshape(1)
     g3 = ConvGeom(D, 8, 8, D, 3, 3, 1)
     gy = K.empty_cl(T, D, 8, 8, y.device)
+    # both seeds in one launch: the loss heads' gradient on the dropout-pass rows, dD/dz = (y > 0) w_out / hw / keep on the penalty rows
     _, gw_out, gb_out, gw_ac, gb_ac = K.tail_heads_bwd(y[:3 * B], d_all, f_all, probs, labels, ct_i, one, B, cfg.LAMBDA_2, cfg.Factor_M,
-                                                       cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, w_out, w_ac, out=gy[:3 * B])
-    K.gp_head_grad(y[3 * B:T], w_out, 1.0 / 0.5, out=gy[3 * B:T])
+                                                       cfg.ACGAN_SCALE if use_ac else 0.0, 1.0 / 0.5, w_out, w_ac, out=gy[:3 * B],
+                                                       y_gp=y[3 * B:T], out_gp=gy[3 * B:T])
 
     def rdrop(i):         # the dropout in front of block 3 (i = 0) / block 4 (i = 1): each range with the mask of its own forward draw
         return {'ranges': [(3 * B, main_specs[i]), (T, gp_specs[i])]}
@@ -171,10 +172,8 @@ def critic_step(tr, R, real_int, labels, fake, early=None):
     G.wgrad('Discriminator.1.Conv1', x4[:m], g_y1[:m], W11, g11, False, True)
     # the chain's end on the penalty rows: dD/dx_hat through the first conv and through the pooled shortcut (:146-153)
     gx = _dgrad(g_y1[m:], W11, g11, B, out_strides=(3072, 1024, 32, 1))
-    gx_s = K.upsample2(_dgrad(g_h1[m:], Wsc1, gsc1, B), 0.25)
-    gx.add_(gx_s)
+    slopes = K.gp_finish(gx, _dgrad(g_h1[m:], Wsc1, gsc1, B), 0.25)      # += the shortcut's gradient through the 2x2 mean pool; per-sample norms
     grads_x = gx.reshape(B, cfg.OUTPUT_DIM)
-    _, slopes = K.gp_fwd(grads_x, cfg.GP_LAMBDA, True)
 
     # ------------------------------------------------------------------ phase C: the penalty's double backward, x_hat rows only
     # cotangent of dD/dx_hat (and the penalty's value into the sums that contain it)
@@ -213,7 +212,7 @@ def critic_step(tr, R, real_int, labels, fake, early=None):
     u_gz = K.conv_fwd(u_a41, W42, None, g3, resid=r4)
     G.wgrad('Discriminator.4.Conv2', u_a41, gy[3 * B:T], W42, g3, False, False)
     # the seed dD/dz = (y > 0) w_out / hw / keep depends on w_out
-    K.axpby(gw_out, K.gp_head_wgrad(u_gz, y[3 * B:T], 1.0 / 0.5, w_out), 1.0, 1.0, out=gw_out)
+    K.gp_head_wgrad(u_gz, y[3 * B:T], 1.0 / 0.5, w_out, add_to=gw_out)
 
     by = G.by_name
     by['Discriminator.Output.W'], by['Discriminator.Output.b'] = gw_out, gb_out

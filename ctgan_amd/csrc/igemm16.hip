@@ -137,6 +137,46 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
     const long long stride = (long long)gridDim.x * blockDim.x, t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (jb.op == CTGAN_CONV_FWD) {
         const long long per = (long long)pp.R * pp.S * pp.C / 2, total = per * pp.K;
+        if (per % 32 == 0 && pp.K % 32 == 0) {
+            // The packed image is the TRANSPOSE of the HWIO filter ([kout][pairs along (r,s,c)] from [(r,s,c)][kout]): read straight,
+            // every lane of a wave touched its own cache line (stride 2 K floats) - 21 us per launch for 15 MB, eight launches per
+            // iteration.  32 x 32 (pair, kout) tiles through LDS: reads coalesced along kout, writes coalesced along the pairs.
+            __shared__ unsigned tl[planes<MMA>()][32][33];
+            const int tiles_p = (int)(per / 32), ntiles = tiles_p * (pp.K / 32);
+            for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+                const int n0 = (tile / tiles_p) * 32;
+                const long long p0 = (long long)(tile % tiles_p) * 32;
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = threadIdx.x + 256 * it, n_l = idx & 31, p_l = idx >> 5;
+                    const long long e = (p0 + p_l) * 2;
+                    unsigned o[planes<MMA>()];
+                    split_pk<MMA>(jb.w[e * pp.K + n0 + n_l], jb.w[(e + 1) * pp.K + n0 + n_l], o);
+#pragma unroll
+                    for (int q = 0; q < planes<MMA>(); ++q) tl[q][p_l][n_l] = o[q];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = threadIdx.x + 256 * it, p_l = idx & 31, n_l = idx >> 5;
+                    const int n = n0 + n_l;
+                    const long long i = (long long)n * per + p0 + p_l;
+#pragma unroll
+                    for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane)[i] = tl[q][p_l][n_l];
+                    if constexpr (planes<MMA>() == 3) {
+                        if (pp.frag) {
+                            const long long e = (p0 + p_l) * 2;
+                            const int tap = (int)(e / pp.C), c = (int)(e - (long long)tap * pp.C);
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane)[frag_u32_index(n, tap, c, pp.R * pp.S, pp.C >> 5, q)] = tl[q][p_l][n_l];
+                        }
+                    }
+                }
+            }
+            return;
+        }
         for (long long i = t0; i < total; i += stride) {
             const int n = (int)(i / per);
             const long long e = (i - (long long)n * per) * 2;

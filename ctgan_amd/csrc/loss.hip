@@ -456,10 +456,28 @@ __global__ __launch_bounds__(256) void tail_heads_bwd_kernel(const float* __rest
                                                              float l2, float M, float scale, float mask_scale,
                                                              const float* __restrict__ w_out, const float* __restrict__ w_ac,
                                                              float* __restrict__ gy, float* __restrict__ gw_out, float* __restrict__ gb_out,
-                                                             float* __restrict__ gw_ac, float* __restrict__ gb_ac) {
+                                                             float* __restrict__ gw_ac, float* __restrict__ gb_ac,
+                                                             const float* __restrict__ y_gp, int n_gp, float* __restrict__ gz_gp) {
     extern __shared__ float sm[];
     const int tid = threadIdx.x;
     const HeadCoef c = head_coef(gout, n_gout, B, scale);
+    if ((int)blockIdx.x >= 3 * B && (int)blockIdx.x < 3 * B + n_gp) {
+        // rows of the gradient-penalty pass (gp_head_grad_kernel's formula): gz = y > 0 ? w_out / hw * mask_scale : 0 - the seed of their
+        // backward, written by the launch that seeds the dropout passes' (the hand-scheduled step runs both chains as one)
+        const long long base = (long long)((int)blockIdx.x - 3 * B) * hw * nf;
+        const int n4 = (hw * nf) >> 2;
+        const float sc = mask_scale / (float)hw;
+        for (int q = tid; q < n4; q += 256) {
+            const int j = (q * 4) % nf;
+            const float4 yv = *reinterpret_cast<const float4*>(y_gp + base + (long long)q * 4);
+            const float4 wv = *reinterpret_cast<const float4*>(w_out + j);
+            float4 o;
+            o.x = yv.x > 0.f ? wv.x * sc : 0.f; o.y = yv.y > 0.f ? wv.y * sc : 0.f;
+            o.z = yv.z > 0.f ? wv.z * sc : 0.f; o.w = yv.w > 0.f ? wv.w * sc : 0.f;
+            *reinterpret_cast<float4*>(gz_gp + base + (long long)q * 4) = o;
+        }
+        return;
+    }
     if ((int)blockIdx.x < 3 * B) {
         const int row = blockIdx.x;
         const float gd = head_gd(d, ct_i, row, B, l2, M, c);
@@ -499,7 +517,7 @@ __global__ __launch_bounds__(256) void tail_heads_bwd_kernel(const float* __rest
     const int nac = w_ac ? ncls : 0;
     const int n_w = nf * (1 + nac), n_all = n_w + 1 + nac;
     const int lane = tid & 63;
-    const int idx = ((int)blockIdx.x - 3 * B) * 4 + (tid >> 6);          // one wave per output, lanes over rows (fixed order)
+    const int idx = ((int)blockIdx.x - 3 * B - n_gp) * 4 + (tid >> 6);   // one wave per output, lanes over rows (fixed order)
     if (idx >= n_all) return;
     float acc = 0.f;
     if (idx < nf) {
@@ -620,7 +638,8 @@ __global__ __launch_bounds__(256) void gp_head_wgrad_stage1_kernel(const float* 
         *reinterpret_cast<float4*>(part + (long long)blockIdx.x * nf + c4 * 4) = t;
     }
 }
-__global__ __launch_bounds__(256) void gp_head_wgrad_stage2_kernel(const float* __restrict__ part, int nf, float s, float* __restrict__ gw) {
+__global__ __launch_bounds__(256) void gp_head_wgrad_stage2_kernel(const float* __restrict__ part, int nf, float s, float* __restrict__ gw,
+                                                                   int accumulate) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nf) return;
     float acc = 0.f;
@@ -631,7 +650,28 @@ __global__ __launch_bounds__(256) void gp_head_wgrad_stage2_kernel(const float* 
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    gw[j] = acc * s;
+    gw[j] = accumulate ? gw[j] + acc * s : acc * s;
+}
+
+// End of the penalty's first backward (hand-scheduled critic step): dD/dx_hat = ga + scale * upsample2(gs) - the gradient through the first
+// conv plus the gradient through the pooled 1x1 shortcut (TF/CT_gan_cifar_resnet.py:146-153) - written over ga, and slopes[b] = ||.||_2 of
+// the sample: one workgroup per sample instead of an upsample, an add and the slopes launch.
+__global__ __launch_bounds__(256) void gp_finish_kernel(float* __restrict__ ga, const float* __restrict__ gs, long long ss_n, long long ss_c,
+                                                        long long ss_h, long long ss_w, int C, int H, int W, float scale,
+                                                        float* __restrict__ slopes) {
+    __shared__ float sh[4];
+    const int d = C * H * W;
+    float* row = ga + (long long)blockIdx.x * d;
+    const float* srow = gs + (long long)blockIdx.x * ss_n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < d; i += 256) {
+        const int c = i / (H * W), rem = i - c * H * W, h = rem / W, w = rem - h * W;
+        const float v = row[i] + scale * srow[c * ss_c + (h >> 1) * ss_h + (w >> 1) * ss_w];
+        row[i] = v;
+        s += v * v;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) slopes[blockIdx.x] = sqrtf(s);
 }
 
 }  // namespace
@@ -758,20 +798,30 @@ int ctgan_tail_critic_heads_fwd2(const float* y, int32_t B, int32_t hw, int32_t 
                        acgan_scale, out, slopes, gp_lambda, y_clean ? a_clean : (const float*)nullptr, labels, ncls, acc);
     return ctgan_check_launch("critic_heads_final");
 }
+int ctgan_tail_heads_bwd_gp(const float* y, const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
+                            const float* gout, int32_t n_gout, int32_t B, int32_t hw, int32_t nf, int32_t ncls, float lambda2, float M,
+                            float acgan_scale, float mask_scale, const float* w_out, const float* w_ac, float* gy, float* gw_out,
+                            float* gb_out, float* gw_ac, float* gb_ac, const float* y_gp, int32_t n_gp, float* gz_gp, ctgan_stream_t s) {
+    if (!y || !d || !f || !ct_i || !gout || (n_gout != 1 && n_gout != 4) || !w_out || !gy || !gw_out || !gb_out || B <= 0 || hw <= 0 ||
+        nf <= 0 || (nf & 3) || (w_ac && (!probs || !labels || !gw_ac || !gb_ac || ncls <= 0)) || n_gp < 0 || (n_gp > 0 && (!y_gp || !gz_gp)))
+        return ctgan_fail(CTGAN_E_BADARG, "tail_heads_bwd: bad argument");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y_gp) | reinterpret_cast<uintptr_t>(gz_gp) |
+         (n_gp > 0 ? reinterpret_cast<uintptr_t>(w_out) : 0)) & 15)
+        return ctgan_fail(CTGAN_E_BADARG, "tail_heads_bwd: unaligned");
+    const int nac = w_ac ? ncls : 0;
+    const int wblocks = (nf * (1 + nac) + 1 + nac + 3) / 4;               // one wave per output
+    const size_t sh = (size_t)(nf > 3 * B ? nf : 3 * B) * sizeof(float);
+    hipLaunchKernelGGL(tail_heads_bwd_kernel, dim3(3 * B + n_gp + wblocks), dim3(256), sh, static_cast<hipStream_t>(s), y, d, f, probs, labels, ct_i,
+                       gout, n_gout, B, hw, nf, ncls, lambda2, M, acgan_scale, mask_scale, w_out, w_ac, gy, gw_out, gb_out, gw_ac, gb_ac,
+                       y_gp, n_gp, gz_gp);
+    return ctgan_check_launch("tail_heads_bwd");
+}
 int ctgan_tail_heads_bwd(const float* y, const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
                          const float* gout, int32_t n_gout, int32_t B, int32_t hw, int32_t nf, int32_t ncls, float lambda2, float M,
                          float acgan_scale, float mask_scale, const float* w_out, const float* w_ac, float* gy, float* gw_out,
                          float* gb_out, float* gw_ac, float* gb_ac, ctgan_stream_t s) {
-    if (!y || !d || !f || !ct_i || !gout || (n_gout != 1 && n_gout != 4) || !w_out || !gy || !gw_out || !gb_out || B <= 0 || hw <= 0 ||
-        nf <= 0 || (nf & 3) || (w_ac && (!probs || !labels || !gw_ac || !gb_ac || ncls <= 0)))
-        return ctgan_fail(CTGAN_E_BADARG, "tail_heads_bwd: bad argument");
-    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gy)) & 15) return ctgan_fail(CTGAN_E_BADARG, "tail_heads_bwd: unaligned");
-    const int nac = w_ac ? ncls : 0;
-    const int wblocks = (nf * (1 + nac) + 1 + nac + 3) / 4;               // one wave per output
-    const size_t sh = (size_t)(nf > 3 * B ? nf : 3 * B) * sizeof(float);
-    hipLaunchKernelGGL(tail_heads_bwd_kernel, dim3(3 * B + wblocks), dim3(256), sh, static_cast<hipStream_t>(s), y, d, f, probs, labels, ct_i,
-                       gout, n_gout, B, hw, nf, ncls, lambda2, M, acgan_scale, mask_scale, w_out, w_ac, gy, gw_out, gb_out, gw_ac, gb_ac);
-    return ctgan_check_launch("tail_heads_bwd");
+    return ctgan_tail_heads_bwd_gp(y, d, f, probs, labels, ct_i, gout, n_gout, B, hw, nf, ncls, lambda2, M, acgan_scale, mask_scale, w_out, w_ac, gy,
+                                   gw_out, gb_out, gw_ac, gb_ac, nullptr, 0, nullptr, s);
 }
 int ctgan_gen_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, const float* w_out, const float* b_out, const float* w_ac,
                         const float* b_ac, int32_t ncls, const int32_t* labels, float ac_scale, float* f, float* d, float* a, float* probs,
@@ -818,8 +868,30 @@ int ctgan_gp_head_wgrad(const float* gg, const float* y, int32_t n, int32_t hw, 
     hipLaunchKernelGGL(gp_head_wgrad_stage1_kernel, dim3(GPW_SLICES), dim3(256), 0, st, gg, y, (long long)n * hw, nf, ws);
     int rc = ctgan_check_launch("gp_head_wgrad_stage1");
     if (rc) return rc;
-    hipLaunchKernelGGL(gp_head_wgrad_stage2_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, ws, nf, mask_scale / (float)hw, gw);
+    hipLaunchKernelGGL(gp_head_wgrad_stage2_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, ws, nf, mask_scale / (float)hw, gw, 0);
     return ctgan_check_launch("gp_head_wgrad_stage2");
+}
+int ctgan_gp_head_wgrad_acc(const float* gg, const float* y, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gw, float* ws,
+                            ctgan_stream_t s) {
+    const int c4n = nf >> 2;
+    if (!gg || !y || !gw || !ws || n <= 0 || hw <= 0 || nf <= 0 || (nf & 3) || c4n > 256 || (256 % c4n))
+        return ctgan_fail(CTGAN_E_BADARG, "gp_head_wgrad_acc: bad argument");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gg) | reinterpret_cast<uintptr_t>(ws)) & 15)
+        return ctgan_fail(CTGAN_E_BADARG, "gp_head_wgrad_acc: unaligned");
+    hipStream_t st = static_cast<hipStream_t>(s);
+    hipLaunchKernelGGL(gp_head_wgrad_stage1_kernel, dim3(GPW_SLICES), dim3(256), 0, st, gg, y, (long long)n * hw, nf, ws);
+    int rc = ctgan_check_launch("gp_head_wgrad_stage1");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gp_head_wgrad_stage2_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, ws, nf, mask_scale / (float)hw, gw, 1);
+    return ctgan_check_launch("gp_head_wgrad_stage2");
+}
+int ctgan_gp_finish(float* ga, const float* gs, const int64_t* gs_strides, int32_t b, int32_t c, int32_t h, int32_t w, float scale, float* slopes,
+                    ctgan_stream_t s) {
+    if (!ga || !gs || !gs_strides || !slopes || b <= 0 || c <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1))
+        return ctgan_fail(CTGAN_E_BADARG, "gp_finish: bad argument");
+    hipLaunchKernelGGL(gp_finish_kernel, dim3(b), dim3(256), 0, static_cast<hipStream_t>(s), ga, gs, (long long)gs_strides[0], (long long)gs_strides[1],
+                       (long long)gs_strides[2], (long long)gs_strides[3], c, h, w, scale, slopes);
+    return ctgan_check_launch("gp_finish");
 }
 int ctgan_accuracy2(const float* logits, const int32_t* labels, int32_t B, int32_t ncls, float* acc, ctgan_stream_t s) {
     if (!logits || !labels || !acc || B <= 0 || ncls <= 0) return ctgan_fail(CTGAN_E_BADARG, "accuracy2: bad argument");

@@ -1465,10 +1465,11 @@ def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, s
     return out, f, d, a, ct_i, probs, None
 
 
-def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac, out=None):
+def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac, out=None, y_gp=None, out_gp=None):
     """-> (gy like y: gradient w.r.t. the last block's pre-activation; gw_out, gb_out, gw_ac, gb_ac) - one launch.
-    out: buffer for gy (y's shape, dense channels-last - e.g. the leading rows of a larger batch)."""
-    _need_dev(y, d, f, probs, labels, ct_i, gout, w_out, w_ac, out)
+    out: buffer for gy (y's shape, dense channels-last - e.g. the leading rows of a larger batch).
+    y_gp, out_gp: rows of the gradient-penalty pass - the same launch also writes out_gp = gp_head_grad(y_gp, w_out, mask_scale)."""
+    _need_dev(y, d, f, probs, labels, ct_i, gout, w_out, w_ac, out, y_gp, out_gp)
     n, hw, nf = _cl_rows(y)
     assert n == 3 * B and gout.is_contiguous() and gout.numel() in (1, 4)
     if out is not None:
@@ -1480,9 +1481,14 @@ def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_s
     ncls = w_ac.shape[1] if w_ac is not None else 0
     gw_ac = torch.empty_like(w_ac) if w_ac is not None else None
     gb_ac = torch.empty(ncls, dtype=torch.float32, device=y.device) if w_ac is not None else None
-    check(lib.ctgan_tail_heads_bwd(_ptr(y), _ptr(d), _ptr(f), _ptr(probs), _ptr(labels), _ptr(ct_i), _ptr(gout), gout.numel(), B, hw, nf, ncls,
-                                   lam2, M, scale, mask_scale, _ptr(w_out), _ptr(w_ac), _ptr(gy), _ptr(gw_out), _ptr(gb_out), _ptr(gw_ac),
-                                   _ptr(gb_ac), _stream()), 'tail_heads_bwd')
+    n_gp = 0
+    if y_gp is not None:
+        n_gp = y_gp.shape[0]
+        assert out_gp is not None and tuple(out_gp.shape) == tuple(y_gp.shape) and _cl_rows(y_gp) == (n_gp, hw, nf) and _cl_rows(out_gp) == (n_gp, hw, nf)
+        assert w_out.is_contiguous()
+    check(lib.ctgan_tail_heads_bwd_gp(_ptr(y), _ptr(d), _ptr(f), _ptr(probs), _ptr(labels), _ptr(ct_i), _ptr(gout), gout.numel(), B, hw, nf, ncls,
+                                      lam2, M, scale, mask_scale, _ptr(w_out), _ptr(w_ac), _ptr(gy), _ptr(gw_out), _ptr(gb_out), _ptr(gw_ac),
+                                      _ptr(gb_ac), _ptr(y_gp), n_gp, _ptr(out_gp), _stream()), 'tail_heads_bwd')
     return gy, gw_out, gb_out, gw_ac, gb_ac
 
 
@@ -1526,15 +1532,31 @@ def gp_head_grad(y, w_out, mask_scale, out=None):
     return gz
 
 
-def gp_head_wgrad(gg, y, mask_scale, like):
-    """gw_out = mask_scale / hw * sum over (row, hw) with y > 0 of gg  (adjoint of gp_head_grad w.r.t. w_out)."""
-    _need_dev(gg, y)
+def gp_head_wgrad(gg, y, mask_scale, like, add_to=None):
+    """gw_out = mask_scale / hw * sum over (row, hw) with y > 0 of gg  (adjoint of gp_head_grad w.r.t. w_out).
+    add_to: a finished gradient of the same weight - the result is ADDED onto it in place (and it is returned)."""
+    _need_dev(gg, y, add_to)
     n, hw, nf = _cl_rows(y)
     assert tuple(gg.shape) == tuple(y.shape) and gg.permute(0, 2, 3, 1).is_contiguous()
-    gw = torch.empty_like(like)
     ws = torch.empty(64 * nf, dtype=torch.float32, device=y.device)
+    if add_to is not None:
+        assert add_to.is_contiguous() and add_to.numel() == nf
+        check(lib.ctgan_gp_head_wgrad_acc(_ptr(gg), _ptr(y), n, hw, nf, mask_scale, _ptr(add_to), _ptr(ws), _stream()), 'gp_head_wgrad_acc')
+        return add_to
+    gw = torch.empty_like(like)
     check(lib.ctgan_gp_head_wgrad(_ptr(gg), _ptr(y), n, hw, nf, mask_scale, _ptr(gw), _ptr(ws), _stream()), 'gp_head_wgrad')
     return gw
+
+
+def gp_finish(ga, gs, scale):
+    """ga [B,C,H,W] (plain NCHW, contiguous) += scale * upsample2(gs [B,C,H/2,W/2], any strides), in place; -> slopes [B] = per-sample L2
+    norm of the result.  The end of the penalty's first backward: gradient through the first conv + through the pooled shortcut."""
+    _need_dev(ga, gs)
+    B, C, H, W = ga.shape
+    assert ga.is_contiguous() and tuple(gs.shape) == (B, C, H // 2, W // 2) and H % 2 == 0 and W % 2 == 0
+    slopes = torch.empty(B, dtype=torch.float32, device=ga.device)
+    check(lib.ctgan_gp_finish(_ptr(ga), _ptr(gs), I64x4(*gs.stride()), B, C, H, W, scale, _ptr(slopes), _stream()), 'gp_finish')
+    return slopes
 
 
 def accuracy2(logits, labels, B):

@@ -496,6 +496,21 @@ int ctgan_gen_heads_fwd(const float* y, int32_t n, int32_t hw, int32_t nf, const
 int ctgan_gen_heads_bwd(const float* y, const float* probs, const int32_t* labels, const float* gout, int32_t n, int32_t hw,
                         int32_t nf, int32_t ncls, float ac_scale, float mask_scale, const float* w_out, const float* w_ac,
                         float* gy, ctgan_stream_t stream);
+/* Round 5 (the hand-scheduled critic step, critic_schedule.py): three launches folded into their neighbours.
+ *   ctgan_tail_heads_bwd_gp  = ctgan_tail_heads_bwd that also writes gz_gp = ctgan_gp_head_grad(y_gp) for the n_gp rows of the penalty pass
+ *                              (the seeds of BOTH backward chains in one launch - the step runs them as one chain);
+ *   ctgan_gp_head_wgrad_acc  = ctgan_gp_head_wgrad that ADDS onto gw (the head weight's gradient from the dropout passes);
+ *   ctgan_gp_finish          : ga [b, c*h*w] (NCHW, in place) += scale * upsample2(gs [b,c,h/2,w/2], element strides gs_strides[4]) and
+ *                              slopes[b] = ||ga[b,:]||_2 - dD/dx_hat = gradient through the first conv + gradient through the pooled 1x1
+ *                              shortcut (:146-153, :284-285) in one launch instead of upsample + add + ctgan_gp_fwd.                      */
+int ctgan_tail_heads_bwd_gp(const float* y, const float* d, const float* f, const float* probs, const int32_t* labels, const float* ct_i,
+                            const float* gout, int32_t n_gout, int32_t B, int32_t hw, int32_t nf, int32_t ncls, float lambda2, float M,
+                            float acgan_scale, float mask_scale, const float* w_out, const float* w_ac, float* gy, float* gw_out,
+                            float* gb_out, float* gw_ac, float* gb_ac, const float* y_gp, int32_t n_gp, float* gz_gp, ctgan_stream_t stream);
+int ctgan_gp_head_wgrad_acc(const float* gg, const float* y, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gw,
+                            float* ws /* 64 * nf floats */, ctgan_stream_t stream);
+int ctgan_gp_finish(float* ga, const float* gs, const int64_t* gs_strides, int32_t b, int32_t c, int32_t h, int32_t w, float scale, float* slopes,
+                    ctgan_stream_t stream);
 int ctgan_gp_head_grad(const float* y, const float* w_out, int32_t n, int32_t hw, int32_t nf, float mask_scale,
                        float* gz, ctgan_stream_t stream);
 int ctgan_gp_head_wgrad(const float* gg, const float* y, int32_t n, int32_t hw, int32_t nf, float mask_scale, float* gw,

@@ -645,7 +645,9 @@ def tail_critic_heads_fwd(y, B, w_out, b_out, w_ac, b_ac, labels, gp, lam2, M, s
 
 
 @_export
-def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac, out=None):
+def tail_heads_bwd(y, d, f, probs, labels, ct_i, gout, B, lam2, M, scale, mask_scale, w_out, w_ac, out=None, y_gp=None, out_gp=None):
+    if y_gp is not None:
+        gp_head_grad(y_gp, w_out, mask_scale, out=out_gp)
     gd, gf, ga = critic_heads_bwd(d, f, probs if w_ac is not None else None, labels, ct_i, gout, B, lam2, M, scale)
     t = gf + gd[:, None] * w_out.reshape(1, -1)
     if w_ac is not None:
@@ -695,9 +697,19 @@ def gp_head_grad(y, w_out, mask_scale, out=None):
 
 
 @_export
-def gp_head_wgrad(gg, y, mask_scale, like):
+def gp_head_wgrad(gg, y, mask_scale, like, add_to=None):
     hw = y.shape[2] * y.shape[3]
-    return ((gg * (y > 0).to(y.dtype)).sum(dim=(0, 2, 3)) * (mask_scale / hw)).reshape(like.shape)
+    gw = ((gg * (y > 0).to(y.dtype)).sum(dim=(0, 2, 3)) * (mask_scale / hw)).reshape(like.shape)
+    if add_to is not None:
+        add_to += gw.reshape(add_to.shape)
+        return add_to
+    return gw
+
+
+@_export
+def gp_finish(ga, gs, scale):
+    ga += scale * gs.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    return torch.sqrt((ga.reshape(ga.shape[0], -1) ** 2).sum(dim=1))
 
 
 @_export

@@ -1028,3 +1028,37 @@ def test_many_to_few_one_pixel_per_lane_kernel(K, N, C, dgrad):
     finally:
         K.debug_m2f_px(True)
     assert relerr(y, y_ring) < 2e-6
+
+
+def test_launches_folded_into_their_neighbours_for_the_hand_scheduled_critic_step(K):
+    """Round 5 (critic_schedule.py): (i) ctgan_tail_heads_bwd_gp = tail_heads_bwd + gp_head_grad for the penalty rows in one launch, bit for bit;
+    (ii) ctgan_gp_head_wgrad_acc adds onto a finished gradient; (iii) ctgan_gp_finish = upsample2 + add + per-sample norms."""
+    g = torch.Generator().manual_seed(9)
+    B, nf, hw = 8, 128, 64
+    y = cl(torch.randn(4 * B, nf, 8, 8, generator=g))
+    w_out = dev(torch.randn(nf, 1, generator=g) * 0.1); b_out = dev(torch.zeros(1))
+    w_ac = dev(torch.randn(nf, 10, generator=g) * 0.1); b_ac = dev(torch.zeros(10))
+    labels = torch.randint(0, 10, (B,), generator=g, dtype=torch.int32).cuda()
+    out5, f, d, a, ct_i, probs, _ = K.tail_critic_heads_fwd(y[:3 * B], B, w_out, b_out, w_ac, b_ac, labels, None, 2.0, 0.0, 1.0)
+    one = torch.ones(1, device='cuda')
+    ref = K.tail_heads_bwd(y[:3 * B], d, f, probs, labels, ct_i, one, B, 2.0, 0.0, 1.0, 2.0, w_out, w_ac)
+    gz_ref = K.gp_head_grad(y[3 * B:], w_out, 2.0)
+    gy = K.empty_cl(4 * B, nf, 8, 8, 'cuda')
+    got = K.tail_heads_bwd(y[:3 * B], d, f, probs, labels, ct_i, one, B, 2.0, 0.0, 1.0, 2.0, w_out, w_ac, out=gy[:3 * B], y_gp=y[3 * B:], out_gp=gy[3 * B:])
+    assert torch.equal(gy[:3 * B], ref[0]) and torch.equal(gy[3 * B:], gz_ref)
+    for a_, b_ in zip(got[1:], ref[1:]):
+        assert torch.equal(a_, b_)
+    # (ii)
+    gg = cl(torch.randn(B, nf, 8, 8, generator=g))
+    gw0 = dev(torch.randn(nf, 1, generator=g))
+    part = K.gp_head_wgrad(gg, y[3 * B:], 2.0, w_out)
+    acc = K.gp_head_wgrad(gg, y[3 * B:], 2.0, w_out, add_to=gw0.clone())
+    assert torch.allclose(acc, gw0 + part, rtol=1e-6, atol=1e-7)
+    # (iii)
+    ga = torch.randn(B, 3, 32, 32, generator=g).cuda()
+    gs = cl(torch.randn(B, 3, 16, 16, generator=g))
+    want = ga + K.upsample2(gs, 0.25)
+    _, s_ref = K.gp_fwd(want.reshape(B, -1).contiguous(), 10.0, True)
+    ga2 = ga.clone()
+    slopes = K.gp_finish(ga2, gs, 0.25)
+    assert torch.allclose(ga2, want, rtol=1e-6, atol=1e-7) and torch.allclose(slopes, s_ref, rtol=1e-6)

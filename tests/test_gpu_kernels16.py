@@ -565,3 +565,48 @@ def test_dcgan_cifar_step_in_16bit_mode_matches_oracle(K, dt):
                 assert v[0] <= gtol and v[1] >= ctol, (n, report)
     finally:
         lib.delete_all_params(); M.configure()
+
+
+@pytest.mark.parametrize('mode', ['f32x3', 'bf16'])
+def test_batched_filter_pack_equals_the_per_filter_pack_bitwise(K, mode):
+    """ctgan_conv2d16_pack_batch (every packed image of a weight version in one launch; its forward images go through 32 x 32 LDS tiles
+    since round 5: the image is the transpose of the HWIO filter) against ctgan_conv2d16_pack_filter (one launch per filter and
+    operator, element by element): forward and data-gradient images, 3x3 / 4x4 stride-2 / 1x1 filters, channel counts with and
+    without whole tiles - bit for bit, the fragment-order copy of the split mode included."""
+    import ctgan_amd.tflib as lib
+    lib.delete_all_params(); lib.set_device(None)
+    try:
+        g = torch.Generator().manual_seed(3)
+        shapes = [('A', 3, 128, 128, 1, 8), ('B', 4, 128, 128, 2, 16), ('C', 1, 64, 64, 1, 8), ('D', 3, 96, 160, 1, 8), ('E', 3, 32, 32, 1, 8)]
+        ws, ents = {}, {}
+        with K.mma_dtype(mode):
+            for name, k, C, Ko, st, H in shapes:
+                w = lib.param(name + '.Filters', (torch.randn(k, k, C, Ko, generator=g) * 0.05).numpy())
+                ws[name] = w
+                geom = K.ConvGeom(C, H, H, Ko, k, k, st, False)
+                x = cl(torch.randn(2, C, H, H, generator=g)); gy = cl(torch.randn(2, Ko, geom.P, geom.Q, generator=g))
+                K.conv_fwd(x, w, None, geom); K.conv_dgrad(gy, w, geom, 2)          # lazily packed, one pack_filter launch per image
+            torch.cuda.synchronize()
+            single = {key: ent[0].clone() for key, ent in K._pack16.items()}
+            assert len(single) >= 2 * len(shapes) - 2, len(single)
+            with torch.no_grad():
+                for w in ws.values():
+                    w.mul_(-0.75)
+            lib.bump_epoch()
+            for key, ent in K._pack16.items():                                          # per-filter packs of the NEW values: the reference
+                d = ent[3].desc(1, (0, 0, 0, 0), (0, 0, 0, 0))
+                from ctgan_amd._lib import I64x4, check, lib as clib
+                import ctypes
+                d.xs = I64x4(4, 1, 4, 4); d.ys = I64x4(4, 1, 4, 4)
+                ref = torch.empty_like(ent[0])
+                check(clib.ctgan_conv2d16_pack_filter(ctypes.byref(d), ent[4], K._MMA_CODE[mode], ctypes.c_void_p(ent[2].data_ptr()),
+                                                      ctypes.c_void_p(ref.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'pack')
+                ents[key] = ref
+            K.prepare_packs()                                                           # ... and the batched launch
+            torch.cuda.synchronize()
+            for key, ent in K._pack16.items():
+                assert not torch.equal(ent[0], single[key]), key
+                assert torch.equal(ent[0], ents[key]), key
+    finally:
+        K.set_mma_dtype(None)
+        lib.delete_all_params()
