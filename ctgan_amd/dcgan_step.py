@@ -92,6 +92,23 @@ class DCGANTrainer:
         cost, wgan, ct, _, _ = F.critic_heads(d, f, None, None, B, cfg.LAMBDA_2, cfg.Factor_M, 0.0, gp)
         return {'cost': cost, 'wgan_only': wgan, 'ct': ct, 'gp': gp, 'fake': fake, 'slopes': slopes, 'gp_grads': grads}
 
+    def d_grads(self, real_in, rnd=None, fake=None):
+        """Losses and parameter gradients of one critic step -> (out, grads aligned with self.d_params; scaled by the loss scale).  The
+        DCGAN scripts' piecewise-linear critic runs the hand-scheduled step (dcgan_schedule.py: one forward and one backward chain over
+        [real, fake, real | x_hat], the penalty's double backward on its own rows); everything else - injected draws, the layer-normalised
+        ResNet critics - the autograd form."""
+        from . import dcgan_schedule as DS
+        if fake is None and rnd is None:
+            with torch.no_grad():
+                fake = self._gen(self.mod.cfg.BATCH_SIZE, None)
+        if DS.usable(self, rnd, fake, real_in):
+            with torch.no_grad(), F.deferred_wgrads():
+                return DS.critic_step(self, real_in, fake)
+        out = self.d_losses(real_in, rnd, fake=fake)
+        with F.deferred_wgrads():       # the queued weight gradients of the step: one grouped launch (functional._flush_groups)
+            grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        return out, grads
+
     def _gen(self, n, z, groups=1):
         g = self.towers * groups
         if g > 1:
@@ -135,9 +152,7 @@ class DCGANTrainer:
 
     def d_step(self, real_in, rnd=None, fake=None):
         self.rng.begin_step()
-        out = self.d_losses(real_in, rnd, fake=fake)
-        with F.deferred_wgrads():       # the queued weight gradients of the step: one grouped launch (functional._flush_groups)
-            grads = torch.autograd.grad(out['cost'], self.d_params, grad_outputs=self.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+        out, grads = self.d_grads(real_in, rnd, fake=fake)
         self._apply(self.d_opt, grads)
         out['grads'] = dict(zip([n for n, _ in self.d_named], self._unscaled(grads)))
         return out

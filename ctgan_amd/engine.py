@@ -406,13 +406,13 @@ class GraphedDCGANTrainer:
         F.prepare_filters()
         t.rng.begin_step()
         if which == 'd':
-            out = t.d_losses(self.real if real is None else real, fake=self.fake if fake is None else fake)
-            params, opt = t.d_params, t.d_opt
+            out, grads = t.d_grads(self.real if real is None else real, fake=self.fake if fake is None else fake)
+            opt = t.d_opt
         else:
             out = t.g_losses()
             params, opt = t.g_params, t.g_opt
-        with F.deferred_wgrads():       # the step's queued weight gradients in one grouped launch, as the ResNet step
-            grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
+            with F.deferred_wgrads():       # the step's queued weight gradients in one grouped launch, as the ResNet step
+                grads = torch.autograd.grad(out['cost'], params, grad_outputs=t.cost_seed().reshape(out['cost'].shape), allow_unused=True)
         if self.adam_in_graph:
             opt.update(grads, 1.0 / t.loss_scale, rng=t.rng)
         else:

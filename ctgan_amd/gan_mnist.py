@@ -35,6 +35,10 @@ def configure(**kw):
     return cfg
 
 
+# the critic's shape for the hand-scheduled step (dcgan_schedule.py): three 5x5 stride-2 convs DIM / 2 DIM / 4 DIM from this input, then Linear
+SCHEDULED_CRITIC = {'channels': 1, 'size': 28}
+
+
 def LeakyReLU(x, alpha=0.2):
     return F.leaky_relu(x, alpha)
 

@@ -847,13 +847,17 @@ def dropout_rng(x, keep, seed, stream_id, ctr):
     return y
 
 
-def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr):
+def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr, out=None):
     """x * (ref > 0 ? 1 : alpha) / keep * floor(keep + u) in one launch: dropout(LeakyReLU(x)) for ref = x; the backward of that pair for
-    x = the gradient, ref = the forward result.  ref in x's physical layout; draws as dropout_rng."""
-    _need_dev(x, ref)
+    x = the gradient, ref = the forward result.  ref in x's physical layout; draws as dropout_rng.  out: result buffer in x's layout."""
+    _need_dev(x, ref, out)
     assert ctr.is_cuda and ctr.dtype == torch.int64
     assert tuple(ref.shape) == tuple(x.shape) and ref.stride() == x.stride()
-    y = _ew_out(x)
+    if out is not None:
+        assert is_dense(x) and tuple(out.shape) == tuple(x.shape) and out.stride() == x.stride()
+        y = out
+    else:
+        y = _ew_out(x)
     check(lib.ctgan_lrelu_dropout_rng(_ptr(x), _ptr(ref), _ptr(y), x.numel(), alpha, keep, seed, stream_id, _ptr(ctr), _stream()),
           'lrelu_dropout_rng')
     return y

@@ -253,8 +253,12 @@ def dropout_rng(x, keep, seed, stream_id, ctr):
 
 
 @_export
-def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr):
-    return dropout_rng(lrelu_bwd(x, ref, alpha), keep, seed, stream_id, ctr)
+def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr, out=None):
+    y = dropout_rng(lrelu_bwd(x, ref, alpha), keep, seed, stream_id, ctr)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 @_export

@@ -233,3 +233,30 @@ def test_cifar_dcgan_bf16_batch64_d_step_vs_fp64_fixture():
         json.dump(res, open('gpurun_out/cifar_dcgan_B64_vs_fixture.json', 'w'), indent=1)
     finally:
         M.configure(); lib.delete_all_params()
+
+
+@pytest.mark.parametrize('which,dim,B,dtype,S', [('cifar', 128, 64, None, 1.0), ('cifar', 128, 64, 'bf16', 1.0), ('mnist', 64, 50, None, 1.0),
+                                                 ('cifar', 64, 8, 'f16', 1024.0)])
+def test_hand_scheduled_dcgan_critic_step_equals_the_autograd_form_on_gpu(which, dim, B, dtype, S):
+    """dcgan_schedule.critic_step against DCGANTrainer.d_losses + autograd at the benchmarked sizes (config[1]: DIM 128, B 64, fp32 and bf16;
+    config[0]: MNIST DIM 64, B 50) and with the fp16 mode's loss scale.  The merged launches run other row counts and tile shapes than the
+    separate 3B / B-row chains: fp32 agrees to summation-order rounding; in the 16-bit modes both forms round the same operands (rounding is
+    per element, row-independent), so they agree as closely."""
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from tests.test_host_logic_dcgan import _dcgan_scheduled_vs_autograd
+    lib.delete_all_params(); lib.set_device(None)
+    try:
+        with K.mma_dtype(dtype):
+            a, b = _dcgan_scheduled_vs_autograd(lib, which, dim, B, S, None)
+        for k in ('cost', 'wgan_only', 'ct', 'gp'):
+            _cmp(b[0][k], a[0][k], 1e-5, 'scheduled.' + k, atol=1e-6)
+        _l2(b[0]['slopes'], a[0]['slopes'], 1e-5, 'slopes'); _l2(b[0]['gp_grads'], a[0]['gp_grads'], 1e-5, 'dD/dx_hat')
+        assert a[2] == b[2]
+        for n, x, y in zip(a[2], a[1], b[1]):
+            assert (x is None) == (y is None), n
+            if x is not None and x.abs().max() > 0:
+                _l2(y, x, 3e-5, 'scheduled grad ' + n, atol=1e-7 * S)
+    finally:
+        K.set_mma_dtype(None)
+        lib.delete_all_params()

@@ -247,3 +247,58 @@ def test_train_iteration_runs_for_every_module_of_the_shared_step(cpu_kernels, n
                 _cmp(both[k * B:(k + 1) * B], one, 2e-5, '%s group %d' % (net, k), atol=1e-6)
     finally:
         M.configure()
+
+
+def _dcgan_scheduled_vs_autograd(lib, which, dim, B, S, dev):
+    """One critic step of a DCGAN script through dcgan_schedule.critic_step and through d_losses + autograd: same weights, inputs, Philox streams."""
+    import ctgan_amd.dcgan_schedule as DS
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    if which == 'cifar':
+        import ctgan_amd.gan_cifar as M
+    else:
+        import ctgan_amd.gan_mnist as M
+    res = {}
+    for merged in (False, True):
+        lib.delete_all_params(); lib.set_device(dev); lib.set_seed(1)
+        M.configure(DIM=dim, BATCH_SIZE=B)
+        try:
+            d = lib._dev()
+            with torch.no_grad():
+                M.Discriminator(M.Generator(2, noise=torch.zeros(2, 128, device=d)), u=[torch.full((2,) + s, 0.9, device=d) for s in M.feat_shapes()])
+            g = torch.Generator().manual_seed(5)
+            with torch.no_grad():
+                for n, p in lib._params.items():
+                    if n.endswith(('.Biases', '.b')):
+                        p.add_((0.1 * torch.randn(p.shape, generator=g)).to(p.device))
+            tr = DCGANTrainer(M, seed=3)
+            tr.loss_scale = S
+            real = (torch.randint(0, 256, (B, 3072), dtype=torch.int32, generator=g) if which == 'cifar' else torch.rand(B, 784, generator=g)).to(d)
+            old, DS.MERGED_BWD = DS.MERGED_BWD, merged
+            try:
+                fake = tr.generate_fakes(1)[0]
+                assert DS.usable(tr, None, fake, real) == merged
+                tr.rng.begin_step()
+                out, grads = tr.d_grads(real, fake=fake)
+            finally:
+                DS.MERGED_BWD = old
+            res[merged] = (out, grads, [n for n, _ in tr.d_named])
+        finally:
+            M.configure()
+    return res[False], res[True]
+
+
+@pytest.mark.parametrize('which,dim,S', [('cifar', 32, 1.0), ('mnist', 32, 1024.0), ('mnist', 64, 1.0)])
+def test_hand_scheduled_dcgan_critic_step_equals_the_autograd_form(cpu_kernels, which, dim, S):
+    """dcgan_schedule.critic_step (round 5: ONE forward and ONE backward chain over [real, fake, real | x_hat], weight gradients from the
+    first 3B rows, the penalty's double backward on the x_hat rows only) against DCGANTrainer.d_losses + autograd: loss terms, slopes,
+    dD/dx_hat and every parameter gradient - first conv through im2col + GEMM (CIFAR; MNIST at DIM 32) and on the direct few-channel
+    kernels (MNIST at DIM 64), with and without a loss scale."""
+    import ctgan_amd.tflib as lib
+    a, b = _dcgan_scheduled_vs_autograd(lib, which, dim, 2, S, 'cpu')
+    for k in ('cost', 'wgan_only', 'ct', 'gp', 'slopes', 'gp_grads'):
+        _cmp(b[0][k], a[0][k], 2e-6, 'scheduled.' + k, atol=1e-7)
+    assert a[2] == b[2]
+    for n, x, y in zip(a[2], a[1], b[1]):
+        assert (x is None) == (y is None) and (x is None or x.shape == y.shape), n
+        if x is not None:
+            _cmp(y, x, 5e-6, 'scheduled grad ' + n, atol=1e-8 * S)
