@@ -182,6 +182,7 @@ SIGNATURES = {
     'ctgan_dropout_rng': (c_int, [_p, _p, c_int64, c_float, c_uint64, c_uint64, _p, _p]),
     'ctgan_dropout_rng_mask': (c_int, [_p, _p, _p, _p, c_int64, c_float, c_uint64, c_uint64, _p, _p]),
     'ctgan_lrelu_dropout_rng': (c_int, [_p, _p, _p, c_int64, c_float, c_float, c_uint64, c_uint64, _p, _p]),
+    'ctgan_lrelu_dropout_rng2': (c_int, [_p, _p, _p, c_int64, c_int64, c_float, c_float, c_uint64, c_uint64, c_uint64, _p, _p]),
     'ctgan_rng_uniform': (c_int, [_p, c_int64, c_uint64, c_uint64, _p, c_float, c_float, _p]),
     'ctgan_rng_normal': (c_int, [_p, c_int64, c_uint64, c_uint64, _p, _p]),
     'ctgan_rng_labels': (c_int, [_p, c_int64, c_int32, c_uint64, c_uint64, _p, _p]),

@@ -150,15 +150,19 @@ __global__ void dropout_rng_kernel(const float* __restrict__ x, float* __restric
 // LeakyReLU and dropout in ONE pass (the DCGAN critics' `dropout(LeakyReLU(conv))`, TF/CT_gan_cifar.py:84-98): y = x * slope(ref) / keep *
 // floor(keep + u), slope(r) = r > 0 ? 1 : alpha.  Forward: ref = x (y = dropout(lrelu(x))).  Backward and double backward: x = the arriving
 // gradient, ref = the forward RESULT - where the mask kept the value its sign is the pre-activation's, where it dropped it the product is 0.
+// (n1, sid2: elements [n1, n) draw stream sid2, indexed from n1 - two tensors' dropouts in one launch, each with the draws a launch of
+// its own would make: the hand-scheduled DCGAN critic step keeps the dropout-pass rows and the penalty rows in one tensor.  n1 % 4 == 0.)
 __global__ void lrelu_dropout_rng_kernel(const float* __restrict__ x, const float* __restrict__ ref, float* __restrict__ y, long long n,
-                                         float alpha, float keep, float inv, uint64_t seed, uint32_t sid, const uint64_t* __restrict__ ctr) {
+                                         float alpha, float keep, float inv, uint64_t seed, uint32_t sid, const uint64_t* __restrict__ ctr,
+                                         long long n1, uint32_t sid2) {
     const uint64_t step = ctr ? ctr[0] : 0;
-    const long long nblk = (n + 3) >> 2;
+    const long long nblk = (n + 3) >> 2, blk1 = n1 >> 2;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ref)) & 15) == 0;
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += stride) {
         uint32_t c[4];
-        draw4(seed, sid, step, (uint32_t)b, c);
+        if (b < blk1) draw4(seed, sid, step, (uint32_t)b, c);
+        else draw4(seed, sid2, step, (uint32_t)(b - blk1), c);
         const long long i = b * 4;
         if (vec && i + 3 < n) {
             const float4 v = *reinterpret_cast<const float4*>(x + i);
@@ -440,8 +444,17 @@ int ctgan_lrelu_dropout_rng(const float* x, const float* ref, float* y, int64_t 
     if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "lrelu_dropout_rng: keep=%g not in (0,1]", keep);
     if (n == 0) return CTGAN_OK;
     hipLaunchKernelGGL(lrelu_dropout_rng_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, ref, y,
-                       (long long)n, alpha, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr);
+                       (long long)n, alpha, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr, (long long)n, 0u);
     return ctgan_check_launch("lrelu_dropout_rng");
+}
+int ctgan_lrelu_dropout_rng2(const float* x, const float* ref, float* y, int64_t n, int64_t n1, float alpha, float keep, uint64_t seed,
+                             uint64_t stream_id, uint64_t stream_id2, const uint64_t* ctr, ctgan_stream_t s) {
+    if (!x || !ref || !y || n < 0 || n >= (1LL << 34) || n1 < 0 || n1 > n || (n1 & 3)) return ctgan_fail(CTGAN_E_BADARG, "lrelu_dropout_rng2: bad argument");
+    if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "lrelu_dropout_rng2: keep=%g not in (0,1]", keep);
+    if (n == 0) return CTGAN_OK;
+    hipLaunchKernelGGL(lrelu_dropout_rng_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, ref, y,
+                       (long long)n, alpha, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr, (long long)n1, (uint32_t)stream_id2);
+    return ctgan_check_launch("lrelu_dropout_rng2");
 }
 int ctgan_dropout_rng_mask(const float* x, const float* ref, float* y, float* y_masked, int64_t n, float keep, uint64_t seed,
                            uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t s) {

@@ -80,18 +80,14 @@ def critic_step(tr, real_in, fake):
         x1 = K.im2col(img, g1, cpad)
 
     def act(c, i):
-        """dropout(LeakyReLU(c)): the main rows on their stream, the penalty rows on theirs (each indexed from its own first row)."""
-        y = K.empty_like_dense(c)
-        for r0, r1, sp in ((0, M3, main_specs[i]), (M3, T, gp_specs[i])):
-            K.lrelu_dropout_rng(c[r0:r1], c[r0:r1], alpha_l, sp[0], sp[1], sp[2], sp[3], out=y[r0:r1])
-        return y
+        """dropout(LeakyReLU(c)): the main rows on their stream, the penalty rows on theirs (each indexed from its own first row) - one launch"""
+        ms, gs = main_specs[i], gp_specs[i]
+        return K.lrelu_dropout_rng2(c, c, M3, alpha_l, ms[0], ms[1], ms[2], gs[2], ms[3])
 
     def act_bwd(g, y, i):
         """the pair's backward on all 4B rows: g * slope(y) * mask / keep with the forward result y as sign reference (functional.LReluDropBwdFn)"""
-        out = K.empty_like_dense(g)
-        for r0, r1, sp in ((0, M3, main_specs[i]), (M3, T, gp_specs[i])):
-            K.lrelu_dropout_rng(g[r0:r1], y[r0:r1], alpha_l, sp[0], sp[1], sp[2], sp[3], out=out[r0:r1])
-        return out
+        ms, gs = main_specs[i], gp_specs[i]
+        return K.lrelu_dropout_rng2(g, y, M3, alpha_l, ms[0], ms[1], ms[2], gs[2], ms[3])
 
     def act_gp(u, y, i):
         """the same diagonal factor applied to a cotangent on the penalty rows only (the double backward: the map is its own adjoint)"""

@@ -863,6 +863,19 @@ def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr, out=None):
     return y
 
 
+def lrelu_dropout_rng2(x, ref, n1_rows, alpha, keep, seed, stream_id, stream_id2, ctr):
+    """lrelu_dropout_rng over a tensor whose leading n1_rows rows draw stream_id and whose remaining rows draw stream_id2 (each part indexed
+    from its own first element: the draws of two separate launches) - one launch."""
+    _need_dev(x, ref)
+    assert ctr.is_cuda and ctr.dtype == torch.int64 and is_dense(x)
+    assert tuple(ref.shape) == tuple(x.shape) and ref.stride() == x.stride() and x.stride(0) == x[0].numel()
+    y = _ew_out(x)
+    n1 = n1_rows * x[0].numel()
+    check(lib.ctgan_lrelu_dropout_rng2(_ptr(x), _ptr(ref), _ptr(y), x.numel(), n1, alpha, keep, seed, stream_id, stream_id2, _ptr(ctr), _stream()),
+          'lrelu_dropout_rng2')
+    return y
+
+
 def dropout_rng_mask(x, ref, keep, seed, stream_id, ctr, want_dropped=True):
     """-> (dropout_rng(x, ...) or None, lrelu_bwd(dropout_rng(x, ...), ref, 0)) in one launch; ref in x's physical layout."""
     _need_dev(x, ref)

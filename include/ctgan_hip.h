@@ -561,6 +561,10 @@ int ctgan_dropout_rng_mask(const float* x, const float* ref, float* y, float* y_
  * ref = the forward result (kept values carry the pre-activation's sign, dropped ones are multiplied by 0).  One physical layout.     */
 int ctgan_lrelu_dropout_rng(const float* x, const float* ref, float* y, int64_t n, float alpha, float keep, uint64_t seed,
                             uint64_t stream_id, const uint64_t* ctr, ctgan_stream_t stream);
+/* The same over TWO tensors laid end to end: elements [0, n1) draw stream_id, elements [n1, n) draw stream_id2 indexed from n1 (n1 % 4 == 0) -
+ * each part gets the draws a launch of its own would make (TF/CT_gan_cifar.py:84-98 evaluated once on [real, fake, real | x_hat]).        */
+int ctgan_lrelu_dropout_rng2(const float* x, const float* ref, float* y, int64_t n, int64_t n1, float alpha, float keep, uint64_t seed,
+                             uint64_t stream_id, uint64_t stream_id2, const uint64_t* ctr, ctgan_stream_t stream);
 int ctgan_rng_uniform(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,
                       float lo, float hi, ctgan_stream_t stream);
 int ctgan_rng_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, const uint64_t* ctr,

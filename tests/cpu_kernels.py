@@ -262,6 +262,14 @@ def lrelu_dropout_rng(x, ref, alpha, keep, seed, stream_id, ctr, out=None):
 
 
 @_export
+def lrelu_dropout_rng2(x, ref, n1_rows, alpha, keep, seed, stream_id, stream_id2, ctr):
+    y = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype)
+    y[:n1_rows] = lrelu_dropout_rng(x[:n1_rows], ref[:n1_rows], alpha, keep, seed, stream_id, ctr)
+    y[n1_rows:] = lrelu_dropout_rng(x[n1_rows:], ref[n1_rows:], alpha, keep, seed, stream_id2, ctr)
+    return y
+
+
+@_export
 def dropout_rng_mask(x, ref, keep, seed, stream_id, ctr, want_dropped=True):
     y = dropout_rng(x, keep, seed, stream_id, ctr)
     return (y if want_dropped else None), lrelu_bwd(y, ref, 0.0)

@@ -260,3 +260,18 @@ def test_hand_scheduled_dcgan_critic_step_equals_the_autograd_form_on_gpu(which,
     finally:
         K.set_mma_dtype(None)
         lib.delete_all_params()
+
+
+def test_two_range_lrelu_dropout_launch_equals_two_launches_bitwise():
+    """ctgan_lrelu_dropout_rng2: the leading rows on one Philox stream, the remaining rows on another, each indexed from its own first element -
+    the draws (and bits) of one ctgan_lrelu_dropout_rng launch per part."""
+    import ctgan_amd.kernels as K
+    g = torch.Generator().manual_seed(2)
+    x = K.empty_cl(16, 64, 8, 8, 'cuda').copy_(torch.randn(16, 64, 8, 8, generator=g).cuda())
+    ref = K.empty_cl(16, 64, 8, 8, 'cuda').copy_(torch.randn(16, 64, 8, 8, generator=g).cuda())
+    ctr = torch.full((1,), 5, dtype=torch.int64, device='cuda')
+    y = K.lrelu_dropout_rng2(x, ref, 12, 0.2, 0.5, 99, 3, 7, ctr)
+    a = K.lrelu_dropout_rng(x[:12], ref[:12], 0.2, 0.5, 99, 3, ctr)
+    b = K.lrelu_dropout_rng(x[12:], ref[12:], 0.2, 0.5, 99, 7, ctr)
+    assert torch.equal(y[:12], a) and torch.equal(y[12:], b)
+    assert 0.3 < (y == 0).float().mean().item() < 0.7
