@@ -75,11 +75,17 @@ class _Grads:
                 else:
                     K.filter_fold(gw.contiguous(), spread, False, out=out)
                 gw = out
-            assert name + '.Filters' not in self.by_name
-            self.by_name[name + '.Filters'] = gw
+            self._put(name + '.Filters', gw)
         if gb is not None:
-            assert name + '.Biases' not in self.by_name
-            self.by_name[name + '.Biases'] = gb
+            self._put(name + '.Biases', gb)
+
+    def _put(self, key, val):
+        """A queued filter hands its buffer over once; a filter whose uses are launched at once (the 16-bit modes' per-filter policy for
+        large layers, functional._wgrad: never mixed with queued uses) returns one finished gradient per use - summed here, as autograd would."""
+        if key in self.by_name:
+            K.axpby(self.by_name[key], val, 1.0, 1.0, out=self.by_name[key])
+        else:
+            self.by_name[key] = val
 
 
 EARLY_CONVS = ('Discriminator.1.Conv1', 'Discriminator.1.Conv2', 'Discriminator.1.Shortcut', 'Discriminator.2.Conv1', 'Discriminator.2.Conv2',

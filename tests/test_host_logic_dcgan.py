@@ -287,14 +287,18 @@ def _dcgan_scheduled_vs_autograd(lib, which, dim, B, S, dev):
     return res[False], res[True]
 
 
-@pytest.mark.parametrize('which,dim,S', [('cifar', 32, 1.0), ('mnist', 32, 1024.0), ('mnist', 64, 1.0)])
-def test_hand_scheduled_dcgan_critic_step_equals_the_autograd_form(cpu_kernels, which, dim, S):
+@pytest.mark.parametrize('which,dim,S,mode', [('cifar', 32, 1.0, None), ('mnist', 32, 1024.0, None), ('mnist', 64, 1.0, None), ('cifar', 32, 1.0, 'bf16')])
+def test_hand_scheduled_dcgan_critic_step_equals_the_autograd_form(cpu_kernels, which, dim, S, mode):
     """dcgan_schedule.critic_step (round 5: ONE forward and ONE backward chain over [real, fake, real | x_hat], weight gradients from the
     first 3B rows, the penalty's double backward on the x_hat rows only) against DCGANTrainer.d_losses + autograd: loss terms, slopes,
     dD/dx_hat and every parameter gradient - first conv through im2col + GEMM (CIFAR; MNIST at DIM 32) and on the direct few-channel
     kernels (MNIST at DIM 64), with and without a loss scale."""
+    import ctgan_amd.kernels as K
     import ctgan_amd.tflib as lib
-    a, b = _dcgan_scheduled_vs_autograd(lib, which, dim, 2, S, 'cpu')
+    # mode 'bf16' (the stand-ins still multiply in fp32): the 16-bit modes' per-filter policy applies - on a CPU tensor no filter is queued, every
+    # use's weight gradient arrives at once and the schedule has to sum a filter's two uses itself (on the GPU: the large layers of config[1])
+    with K.mma_dtype(mode):
+        a, b = _dcgan_scheduled_vs_autograd(lib, which, dim, 2, S, 'cpu')
     for k in ('cost', 'wgan_only', 'ct', 'gp', 'slopes', 'gp_grads'):
         _cmp(b[0][k], a[0][k], 2e-6, 'scheduled.' + k, atol=1e-7)
     assert a[2] == b[2]
