@@ -444,7 +444,7 @@ int ctgan_lrelu_dropout_rng(const float* x, const float* ref, float* y, int64_t 
     if (!(keep > 0.f) || keep > 1.f) return ctgan_fail(CTGAN_E_BADARG, "lrelu_dropout_rng: keep=%g not in (0,1]", keep);
     if (n == 0) return CTGAN_OK;
     hipLaunchKernelGGL(lrelu_dropout_rng_kernel, dim3(ctgan_blocks((n + 3) / 4, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(s), x, ref, y,
-                       (long long)n, alpha, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr, (long long)n, 0u);
+                       (long long)n, alpha, keep, 1.f / keep, seed, (uint32_t)stream_id, ctr, ((long long)n + 3) & ~3LL, 0u);      // one stream: every block
     return ctgan_check_launch("lrelu_dropout_rng");
 }
 int ctgan_lrelu_dropout_rng2(const float* x, const float* ref, float* y, int64_t n, int64_t n1, float alpha, float keep, uint64_t seed,
