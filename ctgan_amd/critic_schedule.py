@@ -51,7 +51,7 @@ def usable(R, rnd, rng, real_int, fake):
 
 def _dgrad(gy, w, g, N, mask=None, resid=None, drop=None, out_strides=None):
     """conv^T(gy, w) [kept where mask > 0] [+ resid] [x dropout mask]: what ConvDgradFn.forward launches."""
-    return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=None, wt=F._repacked(w, g), mask=mask, resid=resid, drop=drop)
+    return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=None, wt=F._repacked(w, g, drop is None), mask=mask, resid=resid, drop=drop)
 
 
 class _Grads:

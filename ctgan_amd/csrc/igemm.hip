@@ -1643,6 +1643,7 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
     const bool want_drop = ext_wants_drop(ext);
     if (rc) return rc;
     if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
+    if (ext && ext->act) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_fwd_ex: the fused LeakyReLU + dropout epilogue exists in the 16-bit slice kernels only");
     const float* out_mask = ext ? ext->out_mask : nullptr;
     if (ctgan_is_small_linear(d) && !resid && !out_mask && !(flags & CTGAN_IN_RELU) && !g_force_generic && !want_drop) {
         ctgan_set_last_kernel("linear_small_fwd");
@@ -1700,6 +1701,7 @@ int ctgan_conv2d_dgrad_ex(const ctgan_conv_desc* d, const float* dy, const float
     const bool want_drop = ext_wants_drop(ext);
     if (rc) return rc;
     if (!dy || !w || !dx) return ctgan_fail(CTGAN_E_BADARG, "conv2d_dgrad: null pointer");
+    if (ext && ext->act) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad_ex: the fused LeakyReLU + dropout epilogue exists in the 16-bit slice kernels only");
     if (d->x_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_dgrad: x_up (pool the result instead)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ctgan_is_small_linear(d) && !mask && !resid && !g_force_generic && !want_drop) {

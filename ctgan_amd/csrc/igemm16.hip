@@ -239,6 +239,11 @@ struct P16 {
     int drop; float drop_keep; unsigned long long drop_seed; unsigned drop_sid; const unsigned long long* drop_ctr;
     int drop_nr; int drop_mend[CTGAN_DROP_RANGES]; float drop_rkeep[CTGAN_DROP_RANGES]; unsigned drop_rsid[CTGAN_DROP_RANGES];
     long long drop_roff[CTGAN_DROP_RANGES];
+    // slice kernels only (conv16_kernel, conv16_splitk_epilogue_kernel): the LeakyReLU + dropout pair of the DCGAN critics on the result
+    // (ctgan_epilogue_ext::act) - D = r * (ref > 0 ? 1 : act_alpha) * floor(keep + u) / keep, ref = act_ref ? act_ref[offset] : r; keep /
+    // stream from drop_keep / drop_sid or the sample range of the row (drop_nend: first sample past the range; any boundary, the choice
+    // is per lane), draws indexed as above.  D is dense channels-last.
+    int act; float act_alpha; const float* act_ref; int drop_nend[CTGAN_DROP_RANGES];
     unsigned x_bytes, w_bytes;      // w_bytes covers every plane
     const unsigned short* Wf;       // FRAG image of the filter (fragment order, see frag_u32_index) or null; wf_bytes its size
     unsigned wf_bytes;
@@ -251,6 +256,28 @@ struct P16 {
     float* slab; size_t slab_bytes;
     int dbg;                        // perf-diagnosis bits (env CTGAN_DBG16): 1 no LDS store, 2 no global load, 4 no barrier (a branch around the MFMAs would move the accumulators out of the AGPRs)
 };
+
+// the fused LeakyReLU + dropout pair (P16::act) on four consecutive channels at physical offset `off` of sample n: the arithmetic and the
+// draws of lrelu_dropout_rng_kernel (optim_rng.hip), so the fused and the separate launches agree bit for bit
+__device__ __forceinline__ void conv16_act(const P16& p, float4& v, long long off, int n, unsigned long long step) {
+    float keep = p.drop_keep;
+    unsigned sid = p.drop_sid, off4 = 0;
+    if (p.drop_nr) {
+        const bool r1 = p.drop_nr > 1 && n >= p.drop_nend[0], r2 = p.drop_nr > 2 && n >= p.drop_nend[1];
+        keep = r2 ? p.drop_rkeep[2] : (r1 ? p.drop_rkeep[1] : p.drop_rkeep[0]);
+        sid = r2 ? p.drop_rsid[2] : (r1 ? p.drop_rsid[1] : p.drop_rsid[0]);
+        off4 = (unsigned)((r2 ? p.drop_roff[2] : (r1 ? p.drop_roff[1] : p.drop_roff[0])) >> 2);
+    }
+    float4 r = v;
+    if (p.act_ref) r = *reinterpret_cast<const float4*>(p.act_ref + off);
+    const float a = p.act_alpha, inv = 1.f / keep;
+    uint32_t c[4];
+    ctgan_philox::draw4(p.drop_seed, sid, step, (uint32_t)(off >> 2) - off4, c);
+    v.x = v.x * (r.x > 0.f ? 1.f : a) * inv * floorf(keep + ctgan_philox::u01(c[0]));
+    v.y = v.y * (r.y > 0.f ? 1.f : a) * inv * floorf(keep + ctgan_philox::u01(c[1]));
+    v.z = v.z * (r.z > 0.f ? 1.f : a) * inv * floorf(keep + ctgan_philox::u01(c[2]));
+    v.w = v.w * (r.w > 0.f ? 1.f : a) * inv * floorf(keep + ctgan_philox::u01(c[3]));
+}
 
 // one workgroup per CU (the staging must be woven between the MFMAs): the 8-accumulator tiles
 template <int MMA, int TM, int TN> constexpr bool conv16_one_wave() { return TM * TN >= 8; }
@@ -528,6 +555,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
             }
             if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.act) conv16_act(p, v, off, n, p.drop_ctr ? p.drop_ctr[0] : 0);
             *reinterpret_cast<float4*>(p.D + off) = v;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1385,6 +1413,7 @@ __global__ __launch_bounds__(256) void conv16_splitk_epilogue_kernel(const P16 p
     }
     if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
     if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.act) conv16_act(p, v, off, n, p.drop_ctr ? p.drop_ctr[0] : 0);
     *reinterpret_cast<float4*>(p.D + off) = v;
 }
 
@@ -1859,6 +1888,33 @@ size_t ctgan_conv2d16_workspace_bytes(const ctgan_conv_desc* d, int op) {
     return (size_t)8 * rows * cols * sizeof(float);
 }
 
+// ctgan_epilogue_ext::act on the slice kernels: fills the act / dropout fields of p for a dense channels-last result of `sample_elems`
+// elements per sample.  Only the bf16 / fp16 modes (the split mode routes launches to the halo-patch kernels, which have no such epilogue).
+static int conv16_set_act(P16& p, const ctgan_epilogue_ext* ext, int mma, bool dense, long long sample_elems, const char* who) {
+    if (mma == CTGAN_MMA_F32X3 || !dense || ext->out_mask)
+        return ctgan_fail(CTGAN_E_UNSUPPORTED, "%s: fused LeakyReLU + dropout needs a 16-bit mode and a dense channels-last result", who);
+    if (ext->n_ranges < 0 || ext->n_ranges > CTGAN_DROP_RANGES) return ctgan_fail(CTGAN_E_UNSUPPORTED, "%s: more than %d sample ranges", who, CTGAN_DROP_RANGES);
+    if (ext->act_ref && (reinterpret_cast<uintptr_t>(ext->act_ref) & 15)) return ctgan_fail(CTGAN_E_BADARG, "%s: act_ref must be 16-byte aligned", who);
+    p.act = 1; p.act_alpha = ext->act_alpha; p.act_ref = ext->act_ref;
+    p.drop_seed = ext->drop_seed; p.drop_ctr = reinterpret_cast<const unsigned long long*>(ext->drop_ctr);
+    p.drop_keep = 1.f; p.drop_sid = 0; p.drop_nr = ext->n_ranges;
+    for (int i = 0; i < CTGAN_DROP_RANGES; ++i) { p.drop_nend[i] = 0x7fffffff; p.drop_rkeep[i] = 1.f; p.drop_rsid[i] = 0; p.drop_roff[i] = 0; }
+    if (ext->n_ranges > 0) {
+        long long start = 0;
+        for (int i = 0; i < ext->n_ranges; ++i) {
+            if (ext->range_end[i] < start) return ctgan_fail(CTGAN_E_BADARG, "%s: sample ranges must ascend", who);
+            p.drop_nend[i] = ext->range_end[i];
+            p.drop_rkeep[i] = (ext->range_keep[i] > 0.f && ext->range_keep[i] < 1.f) ? ext->range_keep[i] : 1.f;
+            p.drop_rsid[i] = (unsigned)ext->range_stream_id[i];
+            p.drop_roff[i] = start * sample_elems;
+            start = ext->range_end[i];
+        }
+    } else if (ext->drop_keep > 0.f && ext->drop_keep < 1.f) {
+        p.drop_keep = ext->drop_keep; p.drop_sid = (unsigned)ext->drop_stream_id;
+    }
+    return CTGAN_OK;
+}
+
 static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, const void* wp, const float* bias, const float* resid,
                              float* y, int flags, const ctgan_epilogue_ext* ext, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     if (!d || !x || !wp || !y || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_fwd: bad argument");
@@ -1882,6 +1938,12 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
     p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
     p.ph_T[1] = d->R; p.ph_U[1] = d->S; p.ph_pad_t[1] = d->pad_t; p.ph_pad_l[1] = d->pad_l;
     hipStream_t st = (hipStream_t)stream;
+    if (ext && ext->act) {                                   // the LeakyReLU + dropout pair in the slice kernels' epilogue
+        const bool dense = d->ys[1] == 1 && d->ys[3] == d->K && d->ys[2] == (int64_t)d->Q * d->K && d->ys[0] == (int64_t)d->P * d->Q * d->K;
+        if (resid || p.resid_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: fused LeakyReLU + dropout with a residual");
+        if (const int rc = conv16_set_act(p, ext, mma, dense, (long long)d->P * d->Q * d->K, "conv2d16_fwd_ex")) return rc;
+        return run_conv16(mma, p, st);
+    }
     const bool ranged = ext && ext->n_ranges > 0;
     const bool want_drop = ext && (ranged || (ext->drop_keep > 0.f && ext->drop_keep < 1.f));
     if (want_drop) {                                         // only the halo-patch kernel has the dropout epilogue
@@ -1964,6 +2026,11 @@ int ctgan_conv2d16_dgrad_ex(const ctgan_conv_desc* d, int mma, const float* dy, 
     }
     p.M = d->N * p.P * p.Q;
     hipStream_t st = (hipStream_t)stream;
+    if (ext && ext->act) {                                   // the pair's backward (act_ref = the forward result) in the slice kernels' epilogue
+        const bool dense = d->xs[1] == 1 && d->xs[3] == d->C && d->xs[2] == (int64_t)d->W * d->C && d->xs[0] == (int64_t)d->H * d->W * d->C;
+        if (const int rc = conv16_set_act(p, ext, mma, dense, (long long)d->H * d->W * d->C, "conv2d16_dgrad_ex")) return rc;
+        return run_conv16(mma, p, st);
+    }
     const bool ranged = ext && ext->n_ranges > 0;
     bool range_drop = false;
     if (ranged)

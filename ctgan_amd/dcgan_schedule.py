@@ -79,32 +79,32 @@ def critic_step(tr, real_in, fake):
         g1k = ConvGeom(cpad, g1.P, g1.Q, D, 1, 1, 1)
         x1 = K.im2col(img, g1, cpad)
 
-    def act(c, i):
-        """dropout(LeakyReLU(c)): the main rows on their stream, the penalty rows on theirs (each indexed from its own first row) - one launch"""
-        ms, gs = main_specs[i], gp_specs[i]
-        return K.lrelu_dropout_rng2(c, c, M3, alpha_l, ms[0], ms[1], ms[2], gs[2], ms[3])
+    # The LeakyReLU + dropout pair after every conv rides the conv's epilogue where the 16-bit slice kernels run it (kernels._conv_act;
+    # its own launch otherwise - the same draws either way):
+    def act(i, ref=None):
+        """dropout(LeakyReLU(.)) on all 4B rows: the main rows on their stream, the penalty rows on theirs (each indexed from its own first
+        row).  ref = the forward result: the pair's backward, g * slope(y) * mask / keep (functional.LReluDropBwdFn)"""
+        return {'alpha': alpha_l, 'ref': ref, 'drop': {'ranges': [(M3, main_specs[i]), (T, gp_specs[i])]}}
 
     def act_bwd(g, y, i):
-        """the pair's backward on all 4B rows: g * slope(y) * mask / keep with the forward result y as sign reference (functional.LReluDropBwdFn)"""
         ms, gs = main_specs[i], gp_specs[i]
         return K.lrelu_dropout_rng2(g, y, M3, alpha_l, ms[0], ms[1], ms[2], gs[2], ms[3])
 
-    def act_gp(u, y, i):
+    def act_gp(y, i):
         """the same diagonal factor applied to a cotangent on the penalty rows only (the double backward: the map is its own adjoint)"""
-        sp = gp_specs[i]
-        return K.lrelu_dropout_rng(u, y[M3:T], alpha_l, sp[0], sp[1], sp[2], sp[3])
+        return {'alpha': alpha_l, 'ref': y[M3:T], 'drop': gp_specs[i]}
 
-    c1 = K.conv_fwd(x1, w1k, b1, g1k)
-    a1 = act(c1, 0)
-    c2 = K.conv_fwd(a1, W2, b2, g2)
-    a2 = act(c2, 1)
-    c3 = K.conv_fwd(a2, W3, b3, g3)
-    a3 = act(c3, 2)
+    a1 = K.conv_fwd(x1, w1k, b1, g1k, act=act(0))
+    a2 = K.conv_fwd(a1, W2, b2, g2, act=act(1))
+    a3 = K.conv_fwd(a2, W3, b3, g3, act=act(2))
     nf = 4 * D * g3.P * g3.Q
-    f4 = K.to_nchw(a3)                                             # [T, 4D, p, q] contiguous = the reference's reshape [-1, 4*4*4*DIM]
-    f = f4.reshape(T, nf)
+    # The reference flattens NCHW (reshape [-1, 4*4*4*DIM]); here the features stay in the convs' channels-last order and W_out is permuted
+    # to it instead (8 K elements against three passes over the activations): d = <f, W> and the consistency term's ||f - f'||^2 do not
+    # depend on the order of the features.
+    f = a3.permute(0, 2, 3, 1).reshape(T, nf)                      # a view: a3 is dense channels-last
+    Wp = Wo.reshape(4 * D, g3.P, g3.Q).permute(1, 2, 0).reshape(nf, 1).contiguous()
     gL = ConvGeom(nf, 1, 1, 1, 1, 1, 1)
-    Wv = Wo.view(1, 1, nf, 1)
+    Wv = Wp.view(1, 1, nf, 1)
     f_main = f[:M3]
     d = K.conv_fwd(f_main.reshape(M3, nf, 1, 1), Wv, bo, gL).reshape(M3)
     out5, ct_i, _ = K.critic_heads_fwd(d, f_main, None, None, B, cfg.LAMBDA_2, cfg.Factor_M, 0.0, None)
@@ -115,17 +115,15 @@ def critic_step(tr, real_in, fake):
     gd, gf, _ = K.critic_heads_bwd(d, f_main, None, None, ct_i, seed, B, cfg.LAMBDA_2, cfg.Factor_M, 0.0)
     gd4 = gd.reshape(M3, 1, 1, 1)
     gWo, gbo = K.conv_wgrad(f_main.reshape(M3, nf, 1, 1), gd4, gL, with_bias=True)
-    g_f = torch.empty(T, nf, dtype=torch.float32, device=dev)
+    g_a3 = K.empty_cl(T, 4 * D, g3.P, g3.Q, dev)
+    g_f = g_a3.permute(0, 2, 3, 1).reshape(T, nf)                                            # the same storage in feature order
     K.axpby(K.conv_dgrad(gd4, Wv, gL, M3).reshape(M3, nf), gf, 1.0, 1.0, out=g_f[:M3])     # through the Linear layer + the CT term's direct part
-    g_f[M3:].copy_(Wo.reshape(1, nf).expand(B, nf))                                          # penalty rows: dD/dfeatures = W_out
-    g_a3 = K.to_channels_last(g_f.reshape(T, 4 * D, g3.P, g3.Q))
+    g_f[M3:].copy_(Wp.reshape(1, nf).expand(B, nf))                                          # penalty rows: dD/dfeatures = W_out
     g_c3 = act_bwd(g_a3, a3, 2)
     G.wgrad('Discriminator.3', a2[:M3], g_c3[:M3], W3, g3, False, True)
-    g_a2 = _dgrad(g_c3, W3, g3, T)
-    g_c2 = act_bwd(g_a2, a2, 1)
+    g_c2 = K.conv_dgrad(g_c3, W3, g3, T, wt=F._repacked(W3, g3), act=act(1, a2))
     G.wgrad('Discriminator.2', a1[:M3], g_c2[:M3], W2, g2, False, True)
-    g_a1 = _dgrad(g_c2, W2, g2, T)
-    g_c1 = act_bwd(g_a1, a1, 0)
+    g_c1 = K.conv_dgrad(g_c2, W2, g2, T, wt=F._repacked(W2, g2), act=act(0, a1))
     G.wgrad('Discriminator.1', x1[:M3], g_c1[:M3], w1k, g1k, False, True)
     nchw = (c0 * H * H, H * H, H, 1)
     if few:
@@ -139,18 +137,16 @@ def critic_step(tr, real_in, fake):
     ggx, gp = K.gp_bwd_mean(grads_x, slopes, seed, float(cfg.LAMBDA), out5)
     ggx4 = ggx.reshape(B, c0, H, H)
     u_x1 = ggx4 if few else K.im2col(ggx4, g1, g1k.C)
-    u_c1 = K.conv_fwd(u_x1, w1k, None, g1k)
+    u_a1 = K.conv_fwd(u_x1, w1k, None, g1k, act=act_gp(a1, 0))
     G.wgrad('Discriminator.1', u_x1, g_c1[M3:], w1k, g1k, False, False)
-    u_a1 = act_gp(u_c1, a1, 0)
-    u_c2 = K.conv_fwd(u_a1, W2, None, g2)
+    u_a2 = K.conv_fwd(u_a1, W2, None, g2, act=act_gp(a2, 1))
     G.wgrad('Discriminator.2', u_a1, g_c2[M3:], W2, g2, False, False)
-    u_a2 = act_gp(u_c2, a2, 1)
-    u_c3 = K.conv_fwd(u_a2, W3, None, g3)
+    u_a3 = K.conv_fwd(u_a2, W3, None, g3, act=act_gp(a3, 2))
     G.wgrad('Discriminator.3', u_a2, g_c3[M3:], W3, g3, False, False)
-    u_a3 = act_gp(u_c3, a3, 2)
-    u_f = K.to_nchw(u_a3).reshape(B, nf)
+    u_f = u_a3.permute(0, 2, 3, 1).reshape(B, nf)
     # the penalty rows' seed was W_out itself: its cotangent sums over the rows
     K.axpby(gWo.reshape(-1), K.colsum_channels(u_f.reshape(B, nf, 1, 1)), 1.0, 1.0, out=gWo.reshape(-1))
+    gWo = gWo.reshape(g3.P, g3.Q, 4 * D).permute(2, 0, 1)                                    # back to the parameter's (c, h, w) order
 
     by = G.by_name
     if not few:        # the gradient of the padded GEMM filter maps back onto the parameter by a view (functional.GemmFilterFn.backward)

@@ -459,7 +459,7 @@ class ConvDgradFn(Function):
         ctx.pre = ctx.own = None
         if PREMASK_FUSION and not fork:                 # is gy a masked data gradient whose only processing there is the mask?
             ctx.pre = getattr(gy, '_ctgan_premask', None)
-        dx = K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g), mask=mask, resid=resid, drop=drop)
+        dx = K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=b, wt=_repacked(w, g, drop is None), mask=mask, resid=resid, drop=drop)
         if PREMASK_FUSION and mask is not None and resid is None and drop is None and b is None:
             tok = _PreMask()
             tok.mask, tok.fused_done = mask, False      # (the token does not reference dx: no cycle dx -> grad_fn -> ctx -> token -> dx)
@@ -599,8 +599,10 @@ def prepare_filters():
         K.prepare_packs()                 # the 16-bit / split-mode images of the parameters and of the filters just rebuilt: one launch
 
 
-def _repacked(w, g):
-    if not K.dgrad_wants_repack(g):
+def _repacked(w, g, plain=True):
+    """The fp32 family's data-gradient layout of w (cached per weight version), or None where conv_dgrad does not read one.  plain: no
+    epilogue dropout (the launches the 16-bit family takes in the bf16 / fp16 modes - from its own packed image)."""
+    if not K.dgrad_wants_repack(g) or (plain and K.dgrad_runs_16bit(g)):
         return None
     kind = K.dgrad_filter_kind(g)
     return _cached_filter(w, kind, (g.pad_t, g.pad_l) if kind == K.FILTER_PHASES else (0, 0))

@@ -344,13 +344,43 @@ def _ext(drop, out_mask=None):
     """drop = (keep, seed, stream_id, ctr) -> ctgan_epilogue_ext*, or None.  Ranged form (forward launches shared by several
     passes): {'ranges': [(end_sample, spec or None), ...]} - consecutive sample ranges with their own dropout.
     out_mask (forward convs): tensor with the result's strides, the result is kept where it is > 0."""
+    e = _ext_struct(drop, out_mask)
+    return None if e is None else ctypes.byref(e)
+
+
+def _act_ext(act):
+    """act = {'alpha': a, 'drop': spec or ranged dict, 'ref': tensor or None} -> ctgan_epilogue_ext* with the fused LeakyReLU + dropout
+    pair switched on (csrc/igemm16.hip conv16_act)."""
+    e = _ext_struct(act['drop'])
+    e.act, e.act_alpha = 1, float(act['alpha'])
+    ref = act.get('ref')
+    e.act_ref = ref.data_ptr() if ref is not None else None
+    return ctypes.byref(e)
+
+
+def _act_apply(y, act):
+    """The LeakyReLU + dropout pair of `act` as its own launch on the dense result y (the fallback of the fused epilogue: the same draws)."""
+    ref = act.get('ref')
+    ref = y if ref is None else ref
+    drop = act['drop']
+    if not isinstance(drop, dict):
+        return lrelu_dropout_rng(y, ref, act['alpha'], *drop)
+    rs = drop['ranges']
+    if len(rs) == 1:
+        return lrelu_dropout_rng(y, ref, act['alpha'], *rs[0][1])
+    assert len(rs) == 2 and rs[1][0] == y.shape[0] and rs[0][1][0] == rs[1][1][0]
+    a, b = rs[0][1], rs[1][1]
+    return lrelu_dropout_rng2(y, ref, rs[0][0], act['alpha'], a[0], a[1], a[2], b[2], a[3])
+
+
+def _ext_struct(drop, out_mask=None):
     if drop is None and out_mask is None:
         return None
     from ._lib import EpilogueExt
     if drop is None:
         e = EpilogueExt(0.0, 0, 0, None)               # keep outside (0,1): no dropout
         e.out_mask = out_mask.data_ptr()
-        return ctypes.byref(e)
+        return e
     assert out_mask is None
     if isinstance(drop, dict):
         rs = drop['ranges']
@@ -363,10 +393,10 @@ def _ext(drop, out_mask=None):
             e.range_end[i] = int(end)
             e.range_keep[i] = float(sp[0]) if sp is not None else 1.0
             e.range_stream_id[i] = int(sp[2]) if sp is not None else 0
-        return ctypes.byref(e)
+        return e
     keep, seed, sid, ctr = drop
     assert ctr.is_cuda and ctr.dtype == torch.int64
-    return ctypes.byref(EpilogueExt(keep, seed, sid, ctr.data_ptr()))
+    return EpilogueExt(keep, seed, sid, ctr.data_ptr())
 
 
 def _dropout_ranges(y, drop):
@@ -379,11 +409,55 @@ def _dropout_ranges(y, drop):
     return y
 
 
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False, mask=None):
+# A/B switch: the LeakyReLU + dropout pair inside the 16-bit slice kernels' epilogue (default) / as its own launch
+ACT_EPILOGUE = os.environ.get('CTGAN_ACT_EPILOGUE', '1') != '0'
+
+
+def _conv_act(op, a, w, bias, g, N, relu_in, act, wt=None):
+    """conv_fwd (op 0) / conv_dgrad (op 1) followed by the LeakyReLU + dropout pair `act`: one launch where the 16-bit slice kernels take
+    the conv (ctgan_epilogue_ext.act), otherwise the plain conv and lrelu_dropout_rng(2) - the same result bit for bit."""
+    ref = act.get('ref')
+    _need_dev(ref)
+    if op == 0:
+        assert tuple(a.shape) == _x_phys_shape(g, N) and tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
+        y = empty_cl(N, g.K, g.P, g.Q, a.device)
+        d = g.desc(N, a.stride(), y.stride())
+    else:
+        assert tuple(a.shape) == (N, g.K, g.P, g.Q) and tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
+        y = empty_cl(N, g.C, g.H, g.W, a.device)
+        d = g.desc(N, y.stride(), a.stride())
+    if ref is not None:
+        assert tuple(ref.shape) == tuple(y.shape) and ref.stride() == y.stride()
+    mode = _conv_mode(d, op, ACT_EPILOGUE and MMA_DTYPE in ('bf16', 'f16') and not fewch_handles(g) and not g.x_up)
+    if mode is not None:
+        wp = _packed16(w, d, op, g, mode)
+        code = _MMA_CODE[mode]
+        nb = lib.ctgan_conv2d16_workspace_bytes(ctypes.byref(d), op)
+        ws = workspace(nb, a.device) if nb else None
+        try:
+            if op == 0:
+                _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd_ex(ctypes.byref(d), code, _ptr(a), _ptr(wp), _ptr(bias), None, _ptr(y), 2 if relu_in else 0,
+                                                                       _act_ext(act), _ptr(ws), nb, _stream()), 'conv2d16_fwd_ex'))
+            else:
+                _timed(g, N, lambda: check(lib.ctgan_conv2d16_dgrad_ex(ctypes.byref(d), code, _ptr(a), _ptr(wp), None, None, None, _ptr(y), 0,
+                                                                         _act_ext(act), _ptr(ws), nb, _stream()), 'conv2d16_dgrad_ex'))
+            return y
+        except NotImplementedError:
+            pass
+    y = conv_fwd(a, w, bias, g, relu_in=relu_in) if op == 0 else conv_dgrad(a, w, g, N, wt=wt)
+    return _act_apply(y, act)
+
+
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False, mask=None, act=None):
     """y = conv(x,w) [+bias] [kept where mask > 0] [+resid] [relu] [dropout]; relu_in: conv(relu(x)).  x logical [N,C,H(/2),W(/2)],
     w HWIO.  drop = (keep, seed, stream_id, ctr): tf.nn.dropout of the result inside the epilogue (== dropout_rng(y, ...)).
-    mask (same shape and strides as the result; only without resid / relu / drop): == lrelu_bwd(conv(x,w)+bias, mask, 0)."""
+    mask (same shape and strides as the result; only without resid / relu / drop): == lrelu_bwd(conv(x,w)+bias, mask, 0).
+    act = {'alpha', 'drop', 'ref'} (only with bias): the LeakyReLU + dropout pair on the result (== lrelu_dropout_rng(y, ref or y, ...));
+    inside the epilogue of the 16-bit slice kernels, its own launch elsewhere."""
     _need_dev(x, w, bias, resid, mask)
+    if act is not None:
+        assert resid is None and not relu and drop is None and mask is None and out_strides is None
+        return _conv_act(0, x, w, bias, g, x.shape[0], relu_in, act)
     if mask is not None:
         assert resid is None and not relu and drop is None
         return _conv_fwd_masked(x, w, bias, g, out_strides, relu_in, mask)
@@ -481,18 +555,39 @@ def repack_filter(w, g):
     return wt
 
 
+_DGRAD16 = {}
+
+
+def dgrad_runs_16bit(g):
+    """bf16 / fp16 modes: does the plain data gradient of geometry g (dense channels-last operands) run on the 16-bit family?  It then
+    reads its own packed image of the filter and never the fp32 family's repacked one - callers skip building that (functional._repacked)."""
+    if MMA_DTYPE not in ('bf16', 'f16') or g.x_up or fewch_handles(g):
+        return False
+    key = (MMA_DTYPE, g.C, g.H, g.W, g.K, g.R, g.S, g.stride, g.pad_t, g.pad_l)
+    r = _DGRAD16.get(key)
+    if r is None:
+        d = g.desc(1, (g.C * g.H * g.W, 1, g.W * g.C, g.C), (g.K * g.P * g.Q, 1, g.Q * g.K, g.K))
+        r = _DGRAD16[key] = bool(lib.ctgan_conv2d16_supported(ctypes.byref(d), 1, _MMA_CODE[MMA_DTYPE]))
+    return r
+
+
 def dgrad_wants_repack(g):
     """True when conv_dgrad can run the vector kernels on a pre-repacked filter."""
     small_linear = g.R == 1 and g.S == 1 and g.H == 1 and g.W == 1 and g.K <= 16
     return g.C % 4 == 0 and g.K % 32 == 0 and not small_linear
 
 
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None, drop=None):
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None, drop=None, act=None):
     """dx = conv^T(gy, w) [+ bias] [kept where mask > 0] [+ resid] [dropout]; dx logical [N,C,H,W] (channels-last
     unless out_strides given).  `wt` = repack_filter(w, g) computed earlier (skips the per-call repack).
-    drop = (keep, seed, stream_id, ctr): the result is multiplied by that dropout's mask (== dropout_rng(dx, ...))."""
+    drop = (keep, seed, stream_id, ctr): the result is multiplied by that dropout's mask (== dropout_rng(dx, ...)).
+    act = {'alpha', 'drop', 'ref'}: the backward of a LeakyReLU + dropout pair on the result (== lrelu_dropout_rng(dx, ref, ...), ref =
+    the pair's forward result) - conv_fwd's act."""
     _need_dev(gy, w, bias, wt, mask, resid)
     assert not g.x_up
+    if act is not None:
+        assert bias is None and mask is None and resid is None and drop is None and out_strides is None
+        return _conv_act(1, gy, w, None, g, N, False, act, wt=wt)
     assert tuple(gy.shape) == (N, g.K, g.P, g.Q)
     assert tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous()
     if out_strides is None:

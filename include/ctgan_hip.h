@@ -108,6 +108,16 @@ typedef struct ctgan_epilogue_ext {
      * bias, before resid - the order of the dgrad epilogue's mask).  Used by the double backward of the gradient penalty, where the
      * conv that follows multiplies its input with a constant ReLU mask (TF/CT_gan_cifar_resnet.py:284-286 through :109-141).  NULL = none. */
     const float* out_mask;
+    /* 16-bit slice kernels only (ctgan_conv2d16_fwd_ex / ctgan_conv2d16_dgrad_ex, mma = CTGAN_MMA_BF16 / CTGAN_MMA_F16, dense channels-last
+     * result): act = 1 applies the LeakyReLU + dropout pair of the DCGAN critics (TF/CT_gan_cifar.py:86-98, TF/CT_gan_mnist.py:94-106:
+     * tf.nn.dropout(LeakyReLU(conv))) to the result r after bias / mask / resid / relu:
+     *     out = r * (ref > 0 ? 1 : act_alpha) * floor(keep + u) / keep,   ref = act_ref ? act_ref[same offset] : r
+     * with keep / Philox stream from drop_keep / drop_stream_id or, with n_ranges > 0, from the sample range of the row (draws indexed
+     * from the range's first element) - bit for bit ctgan_lrelu_dropout_rng(2) run on the plain result.  act_ref = the forward result
+     * gives the pair's backward (the data gradient's epilogue) and its application to a cotangent (the penalty's double backward).      */
+    int32_t act;
+    float act_alpha;
+    const float* act_ref;
 } ctgan_epilogue_ext;
 int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                         float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream);

@@ -46,7 +46,25 @@ def _xin(x, g):
 
 
 @_export
-def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False, mask=None):
+def _act_apply(y, act):
+    ref = act.get('ref')
+    ref = y if ref is None else ref
+    drop = act['drop']
+    if not isinstance(drop, dict):
+        return lrelu_dropout_rng(y, ref, act['alpha'], *drop)
+    out, r0 = torch.empty_strided(y.shape, y.stride(), dtype=y.dtype), 0
+    for end, sp in drop['ranges']:
+        out[r0:end] = lrelu_dropout_rng(y[r0:end], ref[r0:end], act['alpha'], *sp)
+        r0 = end
+    assert r0 == y.shape[0]
+    return out
+
+
+@_export
+def conv_fwd(x, w, bias, g, resid=None, relu=False, out_strides=None, relu_in=False, drop=None, resid_up=False, mask=None, act=None):
+    if act is not None:
+        assert resid is None and not relu and drop is None and mask is None and out_strides is None
+        return _act_apply(conv_fwd(x, w, bias, g, relu_in=relu_in), act)
     if mask is not None:
         assert resid is None and not relu and drop is None
         y = conv_fwd(x, w, bias, g, None, False, out_strides, relu_in)
@@ -87,12 +105,21 @@ def repack_filter(w, g):
 
 
 @_export
+def dgrad_runs_16bit(g):
+    import ctgan_amd.kernels as _K
+    return _K.MMA_DTYPE in ('bf16', 'f16') and not g.x_up and g.C % 32 == 0 and g.K % 32 == 0
+
+
+@_export
 def dgrad_wants_repack(g):
     return g.C % 4 == 0 and g.K % 32 == 0
 
 
 @_export
-def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None, drop=None):
+def conv_dgrad(gy, w, g, N, out_strides=None, bias=None, wt=None, mask=None, resid=None, drop=None, act=None):
+    if act is not None:
+        assert bias is None and mask is None and resid is None and drop is None and out_strides is None
+        return _act_apply(conv_dgrad(gy, w, g, N, wt=wt), act)
     if isinstance(drop, dict):             # sample ranges, each with the mask of its own dropout (indices relative to the range)
         dx = conv_dgrad(gy, w, g, N, out_strides, bias, wt, mask, resid)
         r0 = 0

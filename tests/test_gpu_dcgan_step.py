@@ -240,8 +240,10 @@ def test_cifar_dcgan_bf16_batch64_d_step_vs_fp64_fixture():
 def test_hand_scheduled_dcgan_critic_step_equals_the_autograd_form_on_gpu(which, dim, B, dtype, S):
     """dcgan_schedule.critic_step against DCGANTrainer.d_losses + autograd at the benchmarked sizes (config[1]: DIM 128, B 64, fp32 and bf16;
     config[0]: MNIST DIM 64, B 50) and with the fp16 mode's loss scale.  The merged launches run other row counts and tile shapes than the
-    separate 3B / B-row chains: fp32 agrees to summation-order rounding; in the 16-bit modes both forms round the same operands (rounding is
-    per element, row-independent), so they agree as closely."""
+    separate 3B / B-row chains, and the schedule keeps the features in channels-last order (another summation order in the Linear layer and
+    the consistency term): fp32 agrees to summation-order rounding.  In the 16-bit modes both forms round the same operands up to those
+    last-bit fp32 differences, which flip the 16-bit rounding of a few operand elements in 10^5 (one such flip is 2^-9 of the element):
+    the gradients agree to 5e-4 in L2 - an order below the mode's own rounding error against the oracle (5e-3 .. 5e-2, test_gpu_kernels16)."""
     import ctgan_amd.kernels as K
     import ctgan_amd.tflib as lib
     from tests.test_host_logic_dcgan import _dcgan_scheduled_vs_autograd
@@ -250,13 +252,14 @@ def test_hand_scheduled_dcgan_critic_step_equals_the_autograd_form_on_gpu(which,
         with K.mma_dtype(dtype):
             a, b = _dcgan_scheduled_vs_autograd(lib, which, dim, B, S, None)
         for k in ('cost', 'wgan_only', 'ct', 'gp'):
-            _cmp(b[0][k], a[0][k], 1e-5, 'scheduled.' + k, atol=1e-6)
-        _l2(b[0]['slopes'], a[0]['slopes'], 1e-5, 'slopes'); _l2(b[0]['gp_grads'], a[0]['gp_grads'], 1e-5, 'dD/dx_hat')
+            _cmp(b[0][k], a[0][k], 1e-5 if dtype is None else 1e-4, 'scheduled.' + k, atol=1e-6)
+        tl = 1e-5 if dtype is None else 2e-4
+        _l2(b[0]['slopes'], a[0]['slopes'], tl, 'slopes'); _l2(b[0]['gp_grads'], a[0]['gp_grads'], tl, 'dD/dx_hat')
         assert a[2] == b[2]
         for n, x, y in zip(a[2], a[1], b[1]):
             assert (x is None) == (y is None), n
             if x is not None and x.abs().max() > 0:
-                _l2(y, x, 3e-5, 'scheduled grad ' + n, atol=1e-7 * S)
+                _l2(y, x, 3e-5 if dtype is None else 5e-4, 'scheduled grad ' + n, atol=1e-7 * S)
     finally:
         K.set_mma_dtype(None)
         lib.delete_all_params()

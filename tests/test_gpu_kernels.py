@@ -347,6 +347,29 @@ def test_few_channel_conv_via_im2col(K, N, C, H, Ko, k, st, layout):
     assert relerr(gw2, gw2r) < 3e-5
 
 
+@pytest.mark.parametrize('N,C,H,W,k,st,cpad,layout', [(256, 3, 32, 32, 5, 2, 96, 'nchw'), (64, 3, 32, 32, 5, 2, 96, 'cl'), (4, 1, 28, 28, 5, 2, 32, 'nchw'),
+                                                          (2, 3, 7, 9, 3, 1, 32, 'cl'), (3, 4, 9, 6, 3, 2, 36, 'nchw'), (5, 2, 8, 8, 1, 1, 4, 'nchw')])
+def test_im2col_band_kernel_and_col2im_pixel_kernel(K, N, C, H, W, k, st, cpad, layout):
+    """ctgan_im2col (band kernel: LDS rows, 16-byte stores) is pure data movement - exact against the slicing definition - and ctgan_col2im
+    (one thread per pixel over the taps that exist) is its adjoint: against the scatter-add definition to fp32 summation error, and
+    <im2col(x), c> = <x, col2im(c)>.  The first critic conv of TF/CT_gan_cifar.py:84 / TF/CT_gan_mnist.py:92 (5x5, stride 2) and odd shapes."""
+    from tests import cpu_kernels as M
+    geom = K.ConvGeom(C, H, W, 8, k, k, st, False)
+    g = torch.Generator().manual_seed(N * 7 + C + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    xd = cl(x) if layout == 'cl' else dev(x)
+    cols = K.im2col(xd, geom, cpad)
+    assert torch.equal(cols.cpu(), M.im2col(x, geom, cpad))
+    c = torch.randn(N, cpad, geom.P, geom.Q, generator=g)
+    ref = M.col2im(c.double(), geom, N)
+    for strides in (None, (C * H * W, H * W, W, 1)):
+        dx = K.col2im(cl(c), geom, N, strides)
+        assert relerr(dx, ref) < 2e-6
+    lhs = (cols.double().cpu() * c.double()).sum().item()
+    rhs = (x.double() * K.col2im(cl(c), geom, N).double().cpu()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+
+
 @pytest.mark.parametrize('N,C,H,Ko,k', [(64, 128, 32, 128, 3), (16, 128, 8, 128, 3), (3, 40, 6, 24, 3), (8, 128, 16, 128, 1)])
 def test_fused_relu_in_and_mask_epilogue(K, N, C, H, Ko, k):
     """conv(relu(x)) with the ReLU applied while staging the tile; its data gradient with the ReLU mask

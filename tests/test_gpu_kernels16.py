@@ -610,3 +610,68 @@ def test_batched_filter_pack_equals_the_per_filter_pack_bitwise(K, mode):
     finally:
         K.set_mma_dtype(None)
         lib.delete_all_params()
+
+
+# (N, C, H, W, K, k, stride): the DCGAN critics' layers at the hand-scheduled step's 4B = 256 rows (128x64 tiles; 64x64 tiles + K split),
+# the im2col'd first conv as a 1x1 (96-channel slices), a partial kout tile, and a small batch with an odd range boundary
+ACT_CASES = [
+    (256, 128, 16, 16, 256, 5, 2),
+    (256, 256, 8, 8, 512, 5, 2),
+    (64, 96, 16, 16, 128, 1, 1),
+    (12, 64, 16, 16, 96, 3, 1),
+    (20, 64, 16, 16, 128, 5, 2),
+]
+
+
+@pytest.mark.parametrize('dt', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', ACT_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_fused_lrelu_dropout_epilogue_equals_conv_then_its_own_launch_bitwise(K, case, dt):
+    """ctgan_epilogue_ext.act (csrc/igemm16.hip conv16_act): dropout(LeakyReLU(conv + bias)) of TF/CT_gan_cifar.py:86-98 inside the slice
+    kernels' epilogue - forward (ref = the result itself; one stream and two sample ranges) and, with ref = a forward result, on the data
+    gradient (the pair's backward) - against the plain conv followed by ctgan_lrelu_dropout_rng(2): same bits, same draws."""
+    from ctgan_amd.kernels import ConvGeom
+    N, C, H, W, Kc, k, st = case
+    K.set_mma_dtype(dt)
+    try:
+        gen = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
+        g = ConvGeom(C, H, W, Kc, k, k, st)
+        x = cl(torch.randn(N, C, H, W, generator=gen))
+        w = (torch.randn(k, k, C, Kc, generator=gen) / (k * (C ** 0.5))).cuda()
+        b = (0.1 * torch.randn(Kc, generator=gen)).cuda()
+        ctr = torch.full((1,), 11, dtype=torch.int64, device='cuda')
+        n1 = (3 * N) // 4
+        one = (0.5, 1234, 5, ctr)
+        two = {'ranges': [(n1, (0.5, 1234, 5, ctr)), (N, (0.5, 1234, 9, ctr))]}
+        assert K.ACT_EPILOGUE
+        for drop in (one, two):
+            act = {'alpha': 0.2, 'ref': None, 'drop': drop}
+            y = K.conv_fwd(x, w, b, g, act=act)
+            fused_kernel = K.last_kernel()
+            K.ACT_EPILOGUE = False
+            try:
+                y0 = K.conv_fwd(x, w, b, g, act=act)
+            finally:
+                K.ACT_EPILOGUE = True
+            assert 'conv16' in fused_kernel, fused_kernel
+            assert torch.equal(y, y0), (fused_kernel, (y != y0).float().mean().item())
+            assert 0.3 < (y == 0).float().mean().item() < 0.7
+            if drop is two:      # each range indexed from its own first element: the rows of the second range are a launch of their own on stream 9
+                c = K.conv_fwd(x, w, b, g)
+                assert torch.equal(y[n1:], K.lrelu_dropout_rng(c[n1:], c[n1:], 0.2, 0.5, 1234, 9, ctr))
+            # data gradient of the same layer with the pair's backward: ref = a tensor of dx's shape
+            gy = cl(torch.randn(N, Kc, g.P, g.Q, generator=gen))
+            ref = cl(torch.randn(N, C, H, W, generator=gen))
+            actb = {'alpha': 0.2, 'ref': ref, 'drop': drop}
+            dx = K.conv_dgrad(gy, w, g, N, act=actb)
+            K.ACT_EPILOGUE = False
+            try:
+                dx0 = K.conv_dgrad(gy, w, g, N, act=actb)
+            finally:
+                K.ACT_EPILOGUE = True
+            assert torch.equal(dx, dx0), (dx != dx0).float().mean().item()
+            plain = K.conv_dgrad(gy, w, g, N)
+            kept = dx != 0
+            slope = torch.where(ref > 0, torch.ones_like(ref), torch.full_like(ref, 0.2))
+            assert torch.equal(dx[kept], (plain * slope * 2.0)[kept])
+    finally:
+        K.set_mma_dtype(None)
