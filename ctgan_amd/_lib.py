@@ -98,6 +98,7 @@ SIGNATURES = {
     'ctgan_conv2d_wgrad': (c_int, [_D, _p, _p, _p, _p, _p, c_size_t, c_int, _p]),
     'ctgan_conv2d16_supported': (c_int, [_D, c_int, c_int]),
     'ctgan_conv2d16_x3_prefers': (c_int, [_D, c_int]),
+    'ctgan_conv2d16_wgrad_col_takes': (c_int, [_D, c_int, c_int32]),
     'ctgan_conv2d16_filter_elems': (c_size_t, [_D, c_int, c_int]),
     'ctgan_conv2d16_pack_filter': (c_int, [_D, c_int, c_int, _p, _p, _p]),
     'ctgan_conv2d16_pack_batch': (c_int, [POINTER(ConvDesc), POINTER(c_int32), c_int32, c_int, POINTER(c_void_p), POINTER(c_void_p), _p]),

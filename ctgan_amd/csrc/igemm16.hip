@@ -1739,6 +1739,10 @@ int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma) {
     return (shape_ok_wgrad(d) && (mma != CTGAN_MMA_F32X3 || shape_ok_wgrad_x3(d))) ? 1 : 0;
 }
 
+int ctgan_conv2d16_wgrad_col_takes(const ctgan_conv_desc* d, int mma, int32_t rows) {
+    return (d && rows > 0 && mma_ok(mma) && ctgan_wgrad16c_takes(d, mma, rows)) ? 1 : 0;
+}
+
 static long long x3_wgrad_min_pixels() { return 32768LL; }      // routing threshold of weight gradients launched at request time
 
 int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {

@@ -55,6 +55,12 @@ __device__ __forceinline__ void split_pk(float a, float b, unsigned (&o)[planes<
         asm("" : "+s"(klo));
         asm("" : "+s"(khi));
         const bf2 lo = __builtin_bit_cast(bf2, klo), hi = __builtin_bit_cast(bf2, khi);
+#ifdef CTGAN_SPLIT_NONE
+        // diagnosis build (tools/nosplit_probe.sh; results are wrong by design): the three terms cost ONE pack - what a consumer would pay if
+        // its producer had stored the split planes (an upper bound of that change's gain, before the extra operand bytes)
+        o[0] = o[1] = o[2] = Cvt<MMA>::pk(a, b);
+        return;
+#endif
 #ifdef CTGAN_SPLIT_SUB
         const unsigned h0 = Cvt<MMA>::pk(a, b);
         const float ra0 = a - __builtin_bit_cast(float, h0 << 16), rb0 = b - __builtin_bit_cast(float, h0 & 0xFFFF0000u);

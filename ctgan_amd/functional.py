@@ -241,7 +241,7 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
         elif key in _DEFER['imm']:
             can = False
         else:
-            can = DEFER_16BIT and x.is_cuda and K.grouped16_takes(g, x.shape[0])
+            can = DEFER_16BIT and x.is_cuda and K.grouped16_takes(g, x.shape[0], x.stride())
             if not can:
                 _DEFER['imm'].add(key)
     defer = can

@@ -96,16 +96,19 @@ def grouped16_mode():
     return 'f32x3' if X3_HYBRID else None
 
 
-def grouped16_takes(g, rows):
-    """Mixed-precision modes: is this weight gradient (geometry g over `rows` samples) queued for the grouped 16-bit launch?  Every
-    problem the filter-column kernel takes (csrc/wgrad16c.hip: 128-multiples of channels, rows of 8-64 pixels, stride 1 / 2) - one grouped
-    launch per step balances them over the CUs - and otherwise the SMALL problems only (<= 16 K pixels, <= 512 channels): large ones
-    outside the column kernel run faster on the wide tiles of their own launch."""
+def grouped16_takes(g, rows, xs=None):
+    """Mixed-precision modes: is this weight gradient (geometry g over `rows` samples, x with strides xs - dense channels-last when None)
+    queued for the grouped 16-bit launch?  Every problem the filter-column kernel takes (the library is asked: ctgan_conv2d16_wgrad_col_takes -
+    128-multiples of channels, rows of 8-64 pixels, stride 1 / 2, images dense in memory) - one grouped launch per step balances them over the
+    CUs - and otherwise the SMALL problems only (<= 16 K pixels, <= 512 channels): large ones outside the column kernel run faster on the
+    wide tiles of their own launch."""
     if not (X3_WGRAD_GROUP and MMA_DTYPE in ('bf16', 'f16') and g.C % 128 == 0 and g.K % 128 == 0 and g.Q % 4 == 0 and not g.x_up
             and not fewch_handles(g)):
         return False
     if g.Q in (8, 16, 32, 64) and g.stride in (1, 2) and g.H == g.stride * g.P and g.W == g.stride * g.Q and g.P * g.Q >= 64 and not (g.P * g.Q & (g.P * g.Q - 1)):
-        return True
+        d = g.desc(rows, xs if xs is not None else (g.C * g.H * g.W, 1, g.W * g.C, g.C), (g.K * g.P * g.Q, 1, g.Q * g.K, g.K))
+        if lib.ctgan_conv2d16_wgrad_col_takes(ctypes.byref(d), _MMA_CODE[MMA_DTYPE], rows):
+            return True
     return g.C <= 512 and g.K <= 512 and rows * g.P * g.Q <= 16384
 
 

@@ -71,7 +71,7 @@ const char* ctgan_last_symbol(void);
 /* tests only: 1 = route every conv through the table-driven generic kernels                   */
 void ctgan_debug_force_generic(int on);
 /* tests only: which halo-patch kernel of the split mode takes the launches that qualify - 1: filter through an LDS stage
-   (conv16x3h_kernel), 2: filter fragments streamed from L2 (conv16x3hf_kernel), 0: back to the default (env CTGAN_X3_HALO_V, else 2) */
+   (conv16x3h_kernel), 2: filter fragments streamed from L2 (conv16x3hf_kernel), 0: back to the default (2) */
 void ctgan_debug_x3_halo_version(int version);
 /* tests / A-B: 0 = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel (conv16x3p_kernel) */
 void ctgan_debug_x3_s2halo(int on);
@@ -244,6 +244,10 @@ int ctgan_conv2d16_supported(const ctgan_conv_desc* d, int op, int mma);        
  * on the fp32 MFMA entry points - the results carry fp32 accuracy either way.  A forward launch with prefers = 1 and stride 1 also
  * accepts CTGAN_RESID_UP.                                                                                                    */
 int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op);
+/* 1 when the filter-column weight-gradient kernel (csrc/wgrad16c.hip) takes this problem over `rows` samples in mode mma - geometry, the
+ * strides of x in d->xs (images dense in memory) and the 32-bit offset limits; callers that queue weight gradients for
+ * ctgan_conv2d16_wgrad_group use it to tell the problems the grouped launch runs on that kernel from those it would run on the slice tiles. */
+int ctgan_conv2d16_wgrad_col_takes(const ctgan_conv_desc* d, int mma, int32_t rows);
 size_t ctgan_conv2d16_filter_elems(const ctgan_conv_desc* d, int op, int mma);  /* 16-bit elements of the packed filter     */
 int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const float* w, void* wp, ctgan_stream_t stream);
 /* n packs in one launch (all images of one weight version): descs[i] / ops[i] (CTGAN_CONV_FWD | CTGAN_CONV_DGRAD) / ws[i] -> wps[i] */
