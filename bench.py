@@ -759,7 +759,7 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
                                       'note': 'HBM-bound kernel: bytes of the wide (128-channel) tensor / time; the MFMA fraction above does not bound it'}}
                              if k in wide else {})}
                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
-        'note': 'by_kernel keys are device symbols: look them up in profiles/r04_kernel_stats_resnet_*.txt / r04_steady_state_resnet_*.txt '
+        'note': 'by_kernel keys are device symbols: look them up in profiles/r05_kernel_stats_resnet.txt / r05_steady_state_resnet.txt '
                 '(tools/roofline_crosscheck.py prints both side by side)',
     }
 
