@@ -75,6 +75,7 @@ SIGNATURES = {
     'ctgan_last_kernel': (c_char_p, []),
     'ctgan_last_symbol': (c_char_p, []),
     'ctgan_debug_force_generic': (None, [c_int]),
+    'ctgan_debug_reduce_lanes': (None, [c_int]),
     'ctgan_debug_x3_halo_version': (None, [c_int]),
     'ctgan_debug_x3_s2halo': (None, [c_int]),
     'ctgan_debug_m2f_px': (None, [c_int]),

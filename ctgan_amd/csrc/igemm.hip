@@ -1187,6 +1187,58 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
     }
 }
 
+// The same sums for SMALL outputs with many slabs (the 1x1 weight gradient of the im2col'd first critic conv: 12 K outputs x 85 slabs - one
+// thread per float4 is 13 workgroups, each walking the slabs as a chain of dependent load batches: 15 us).  Four lanes per float4: lane j
+// owns accumulator a_j of the kernel above - slabs j, j + 4, ... in ascending order, four loads in flight - and lane 0 combines
+// (a0 + a1) + (a2 + a3): the same bits, a quarter of the chain.  n and n_main multiples of 4; blockDim 256 = 64 float4 x 4 lanes.
+__global__ __launch_bounds__(256) void splitk_reduce_lanes_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2,
+                                                                  long long n, long long n_main, int splits) {
+    __shared__ float4 acc[4][64];
+    const int g = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x * 64 + g) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        const int full = splits & ~3;                        // the kernel above feeds a_j from the slabs of its unrolled loop only ...
+        int k = j;
+        for (; k + 12 < full; k += 16) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)(k + 0) * n + i);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (long long)(k + 4) * n + i);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (long long)(k + 8) * n + i);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (long long)(k + 12) * n + i);
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        }
+        for (; k < full; k += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        }
+        if (j == 0)                                          // ... and the remaining splits % 4 slabs all go to a0
+            for (k = full; k < splits; ++k) {
+                const float4 v0 = *reinterpret_cast<const float4*>(part + (long long)k * n + i);
+                a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            }
+    }
+    acc[j][g] = a;
+    __syncthreads();
+    if (j != 0 || i >= n) return;
+    const float4 a0 = acc[0][g], a1 = acc[1][g], a2 = acc[2][g], a3 = acc[3][g];
+    float4 r;
+    r.x = (a0.x + a1.x) + (a2.x + a3.x); r.y = (a0.y + a1.y) + (a2.y + a3.y);
+    r.z = (a0.z + a1.z) + (a2.z + a3.z); r.w = (a0.w + a1.w) + (a2.w + a3.w);
+    if (i < n_main) *reinterpret_cast<float4*>(out + i) = r;
+    else *reinterpret_cast<float4*>(out2 + (i - n_main)) = r;
+}
+// launches the reduction: the lane form where the float4-per-thread form would leave the chip empty in front of a long slab chain
+static int g_reduce_lanes = 1;      // tests: ctgan_debug_reduce_lanes(0) = the float4-per-thread form everywhere
+static void launch_splitk_reduce(const float* part, float* out, float* out2, long long n, long long n_main, int splits, hipStream_t st) {
+    if (g_reduce_lanes && ((n | n_main) & 3) == 0 && splits >= 16 && n / 4 < 256 * 256)
+        hipLaunchKernelGGL(splitk_reduce_lanes_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, st, part, out, out2, n, n_main, splits);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, part, out, out2, n, n_main, splits);
+}
+
 // wT[r',s',k,c] = w[R-1-r', S-1-s', c, k]   (dgrad filter: rotate 180 degrees, swap I/O)
 __global__ void repack_dgrad_filter_kernel(const float* __restrict__ w, float* __restrict__ wt, int R, int S, int C, int K) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1447,7 +1499,7 @@ int launch_wgrad(WgradParams p, const WPlan& w, float* dw, void* ws, hipStream_t
     if (rc) return rc;
     if (w.splits > 1) {
         const long long n = (long long)p.Mtot * p.Ng;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, p.OUT, dw, dw, n, n, w.splits);
+        launch_splitk_reduce(p.OUT, dw, dw, n, n, w.splits, st);
         rc = ctgan_check_launch("splitk_reduce");
     }
     return rc;
@@ -1487,7 +1539,7 @@ int launch_wgrad_pipe(WgradParams p, const WPlan& w, float* dw, float* db, void*
     int rc = ctgan_check_launch("igemm_wgrad_pipe");
     if (rc || direct) return rc;
     const long long n_main = (long long)p.Mtot * p.Ng, n = n_main + (db ? p.Ng : 0);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, p.OUT, dw, db, n, n_main, w.splits);
+    launch_splitk_reduce(p.OUT, dw, db, n, n_main, w.splits, st);
     return ctgan_check_launch("splitk_reduce");
 }
 
@@ -1586,6 +1638,7 @@ extern "C" {
 const char* ctgan_last_kernel(void) { return g_last_kernel; }
 const char* ctgan_last_symbol(void) { return g_last_symbol[0] ? g_last_symbol : g_last_kernel; }
 void ctgan_debug_force_generic(int on) { g_force_generic = on != 0; }
+void ctgan_debug_reduce_lanes(int on) { g_reduce_lanes = on ? 1 : 0; }
 
 size_t ctgan_conv2d_workspace_bytes(const ctgan_conv_desc* d, int op) {
     if (!d) return 0;

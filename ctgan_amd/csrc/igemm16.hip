@@ -1810,6 +1810,19 @@ int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const 
         if (d->C % 2) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_pack_filter: odd channel count");
         const long long total = (long long)d->R * d->S * d->C / 2 * d->K;
         const int frag = frag_image(d, op, mma) ? 1 : 0;
+        if (((long long)d->R * d->S * d->C / 2) % 32 == 0 && d->K % 32 == 0) {
+            // the transposing pack through 32 x 32 LDS tiles (pack_batch_kernel's forward branch) as a batch of one: the straight kernel below
+            // reads one cache line per lane - 19.5 us for config[1]'s 5x5x256x512 filter (13 MB in, 6.5 MB out), once per weight version
+            PackJobs jobs{};
+            PackJob& jb = jobs.j[0];
+            jb.w = w; jb.wp = out; jb.op = CTGAN_CONV_FWD; jb.plane = plane;
+            jb.pp.R = d->R; jb.pp.S = d->S; jb.pp.C = d->C; jb.pp.K = d->K; jb.pp.nph = 1; jb.pp.frag = frag;
+            const dim3 grid(ctgan_blocks(total / 4, 256, 2048), 1);
+            if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_batch_kernel<CTGAN_MMA_BF16>, grid, dim3(256), 0, st, jobs);
+            else if (mma == CTGAN_MMA_F16) hipLaunchKernelGGL(pack_batch_kernel<CTGAN_MMA_F16>, grid, dim3(256), 0, st, jobs);
+            else hipLaunchKernelGGL(pack_batch_kernel<CTGAN_MMA_F32X3>, grid, dim3(256), 0, st, jobs);
+            return ctgan_check_launch("pack16_fwd");
+        }
         if (mma == CTGAN_MMA_BF16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_BF16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane, 0);
         else if (mma == CTGAN_MMA_F16) hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F16>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane, 0);
         else hipLaunchKernelGGL(pack_fwd_kernel<CTGAN_MMA_F32X3>, dim3(ctgan_blocks(total, 256)), dim3(256), 0, st, w, out, d->R * d->S, d->C, d->K, plane, frag);

@@ -70,6 +70,9 @@ const char* ctgan_last_kernel(void);
 const char* ctgan_last_symbol(void);
 /* tests only: 1 = route every conv through the table-driven generic kernels                   */
 void ctgan_debug_force_generic(int on);
+/* tests only: 0 = the split-K reduction of the fp32 weight gradients as one thread per float4 everywhere (the form before the four-lanes-per-float4
+   kernel for small outputs with many slabs; both give the same bits) */
+void ctgan_debug_reduce_lanes(int on);
 /* tests only: which halo-patch kernel of the split mode takes the launches that qualify - 1: filter through an LDS stage
    (conv16x3h_kernel), 2: filter fragments streamed from L2 (conv16x3hf_kernel), 0: back to the default (2) */
 void ctgan_debug_x3_halo_version(int version);

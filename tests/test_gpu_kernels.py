@@ -347,6 +347,23 @@ def test_few_channel_conv_via_im2col(K, N, C, H, Ko, k, st, layout):
     assert relerr(gw2, gw2r) < 3e-5
 
 
+@pytest.mark.parametrize('N,C,H,Ko,k', [(192, 96, 16, 128, 1), (64, 96, 16, 128, 1), (256, 32, 8, 64, 3)])
+def test_split_k_reduction_with_four_lanes_per_float4_gives_the_same_bits(K, N, C, H, Ko, k):
+    """splitk_reduce_lanes_kernel (small filter, many slabs: the 1x1 weight gradient of the im2col'd first critic conv, TF/CT_gan_cifar.py:84) sums the
+    slabs in the order of splitk_reduce_kernel - lane j = that kernel's accumulator j - so the weight and bias gradients are bit-identical."""
+    g = torch.Generator().manual_seed(N + C)
+    geom = K.ConvGeom(C, H, H, Ko, k, k, 1, False)
+    x = cl(torch.randn(N, C, H, H, generator=g)); gy = cl(torch.randn(N, Ko, H, H, generator=g))
+    dw, db = K.conv_wgrad(x, gy, geom, with_bias=True)
+    K.lib.ctgan_debug_reduce_lanes(0)
+    try:
+        dw0, db0 = K.conv_wgrad(x, gy, geom, with_bias=True)
+    finally:
+        K.lib.ctgan_debug_reduce_lanes(1)
+    assert torch.equal(dw, dw0) and torch.equal(db, db0), K.last_kernel()
+    assert relerr(db, gy.double().sum(dim=(0, 2, 3))) < 2e-5
+
+
 @pytest.mark.parametrize('N,C,H,W,k,st,cpad,layout', [(256, 3, 32, 32, 5, 2, 96, 'nchw'), (64, 3, 32, 32, 5, 2, 96, 'cl'), (4, 1, 28, 28, 5, 2, 32, 'nchw'),
                                                           (2, 3, 7, 9, 3, 1, 32, 'cl'), (3, 4, 9, 6, 3, 2, 36, 'nchw'), (5, 2, 8, 8, 1, 1, 4, 'nchw')])
 def test_im2col_band_kernel_and_col2im_pixel_kernel(K, N, C, H, W, k, st, cpad, layout):
