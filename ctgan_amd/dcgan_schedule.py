@@ -124,7 +124,12 @@ def critic_step(tr, real_in, fake):
     g_c2 = K.conv_dgrad(g_c3, W3, g3, T, wt=F._repacked(W3, g3), act=act(1, a2))
     G.wgrad('Discriminator.2', a1[:M3], g_c2[:M3], W2, g2, False, True)
     g_c1 = K.conv_dgrad(g_c2, W2, g2, T, wt=F._repacked(W2, g2), act=act(0, a1))
-    G.wgrad('Discriminator.1', x1[:M3], g_c1[:M3], w1k, g1k, False, True)
+    # the first conv's two uses (dropout-pass rows; below, the penalty's double backward): queued like every filter in the fp32 mode and on
+    # the direct few-channel kernels; in the 16-bit modes its im2col'd GEMM filter (96 input columns) is outside the grouped 16-bit launch and
+    # each use would be a weight gradient + reduction of its own - there the two uses go to ONE multi-segment launch of the fp32 family
+    multi1 = (not few) and K.MMA_DTYPE is not None
+    if not multi1:
+        G.wgrad('Discriminator.1', x1[:M3], g_c1[:M3], w1k, g1k, False, True)
     nchw = (c0 * H * H, H * H, H, 1)
     if few:
         gx = _dgrad(g_c1[M3:], W1, g1, B, out_strides=nchw)
@@ -138,7 +143,17 @@ def critic_step(tr, real_in, fake):
     ggx4 = ggx.reshape(B, c0, H, H)
     u_x1 = ggx4 if few else K.im2col(ggx4, g1, g1k.C)
     u_a1 = K.conv_fwd(u_x1, w1k, None, g1k, act=act_gp(a1, 0))
-    G.wgrad('Discriminator.1', u_x1, g_c1[M3:], w1k, g1k, False, False)
+    if multi1:
+        dw1 = torch.empty(w1k.shape, dtype=torch.float32, device=dev)
+        db1 = torch.empty(D, dtype=torch.float32, device=dev)
+        try:
+            K.conv_wgrad_multi([(x1[:M3], g_c1[:M3], False, True), (u_x1, g_c1[M3:], False, False)], g1k, dw1, db1)
+            G._put('Discriminator.1.Filters', dw1); G._put('Discriminator.1.Biases', db1)
+        except NotImplementedError:
+            G.wgrad('Discriminator.1', x1[:M3], g_c1[:M3], w1k, g1k, False, True)
+            G.wgrad('Discriminator.1', u_x1, g_c1[M3:], w1k, g1k, False, False)
+    else:
+        G.wgrad('Discriminator.1', u_x1, g_c1[M3:], w1k, g1k, False, False)
     u_a2 = K.conv_fwd(u_a1, W2, None, g2, act=act_gp(a2, 1))
     G.wgrad('Discriminator.2', u_a1, g_c2[M3:], W2, g2, False, False)
     u_a3 = K.conv_fwd(u_a2, W3, None, g3, act=act_gp(a3, 2))
