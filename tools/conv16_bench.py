@@ -23,6 +23,8 @@ if len(sys.argv) > 2 and sys.argv[2] == 'resnet':
     SHAPES = RESNET
 if len(sys.argv) > 2 and sys.argv[2] == 's2':
     SHAPES = S2
+if len(sys.argv) > 2 and sys.argv[2] == 'dcgan':      # the DCGAN critic's layers at the hand-scheduled step's row counts (4B = 256, B = 64)
+    SHAPES = [(256, 128, 16, 16, 256, 5, 2), (256, 256, 8, 8, 512, 5, 2), (64, 128, 16, 16, 256, 5, 2), (64, 256, 8, 8, 512, 5, 2), (320, 256, 8, 8, 512, 5, 2), (320, 128, 16, 16, 256, 5, 2)]
 if dt == 'f32':
     dt = None
 
