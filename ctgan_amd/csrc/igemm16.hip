@@ -375,8 +375,15 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
 #pragma unroll
         for (int i = 0; i < X_PER; ++i) {
             const bool ok = x_valid[i] & ((unsigned)(x_ih0[i] + ld_t) < (unsigned)p.H) & ((unsigned)(x_iw0[i] + ld_u) < (unsigned)p.W);
+#if defined(C16_DBG) && (C16_DBG & 2)      // diagnosis build: no pixel-operand loads (results wrong by design)
+            rx[i] = make_float4((float)ok, 0.f, 0.f, 0.f);
+#elif defined(C16_DBG) && (C16_DBG & 8)    // diagnosis build: half the pixel-operand bytes (what 16-bit storage would fetch)
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, ok ? (x_voff[i] + xs) / 2 : 0xFFFFFFFFu, 0, 0);
+            rx[i] = make_float4(__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), 0.f, 0.f);
+#else
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? x_voff[i] + xs : 0xFFFFFFFFu, 0, 0);
             rx[i] = __builtin_bit_cast(float4, v);
+#endif
         }
         const unsigned ws = (unsigned)((long long)ld_k * BK * 2);
 #pragma unroll
