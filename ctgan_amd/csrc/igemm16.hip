@@ -420,11 +420,13 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
                 *reinterpret_cast<u32x2*>(&Xs[q * XPLANE + (x_row0 + i * (NT / XC)) * LDS_K + x_chunk * 4]) = o;
             }
         }
+#if !(defined(C16_DBG) && (C16_DBG & 16))      // diagnosis build 16: the filter operand never touches LDS (no stores, no fragment reads)
 #pragma unroll
         for (int q = 0; q < NP; ++q)
 #pragma unroll
             for (int i = 0; i < W_PER; ++i)
                 *reinterpret_cast<u32x4*>(&Ws[q * WPLANE + (w_row0 + i * (NT / WC)) * LDS_K + w_chunk * 8]) = rw[q][i];
+#endif
     };
 
     // split mode, one accumulator per wave: its six products alternate between two accumulators (no back-to-back dependent MFMAs)
@@ -449,7 +451,11 @@ __global__ __launch_bounds__(256) void conv16_kernel(const P16 p) {
             for (int q = 0; q < NP; ++q) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
+#if defined(C16_DBG) && (C16_DBG & 16)
+                    fw[q][i] = u32x4{(unsigned)(size_t)Ws, (unsigned)lane, (unsigned)(q + ks), (unsigned)i};
+#else
                     fw[q][i] = *reinterpret_cast<const u32x4*>(&Ws[q * WPLANE + (wm * TM * 32 + i * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#endif
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     fx[q][j] = *reinterpret_cast<const u32x4*>(&Xs[q * XPLANE + (wn * TN * 32 + j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
@@ -987,6 +993,181 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
     }
 }
 
+// ---------------------------------------------------------------------------------------------- slice staging, filter from L2
+// conv16x3sf (round 5): the split-mode forward of the launches the halo-patch kernels do not take - the folded ConvMeanPool / MeanPoolConv
+// filters (4x4 / 2x2, stride 2; TF/CT_gan_cifar_resnet.py:89-98) - with the filter operand streamed from L2 in fragment order, as
+// conv16x3hf does.  The slice kernel (conv16_kernel<3,...>) stages pixels AND filter through LDS and every wave reads three filter
+// fragments per two accumulators: per 12 MFMAs (384 cycles) a wave moves 9 KB of fragments out of LDS and its workgroup 18 KB of operands
+// into it - at three workgroups per CU more LDS cycles than MFMA cycles (0.37 of 2500/6; a diagnosis build with the filter operand out of
+// LDS ran 193 -> 135 us on the 192-row 32x32 -> 16x16 layer).  Here LDS holds the pixel operand only:
+//   * a workgroup = TN*32 output positions x 128 output channels; wave w owns channels 32w .. 32w+31 of ALL positions (1 x TN accumulators),
+//     so every filter fragment is loaded by exactly one wave - 6 KB per (32-channel chunk, tap) step, one step ahead of its MFMAs (two
+//     register sets) - and fragment reads from LDS are 0.5 ds_read_b128 per MFMA;
+//   * the pixel operand of a step (TN*32 positions x 32 channels, gathered with the conv's stride, split into its three bf16 terms) goes
+//     through TWO LDS stages: the loads of step s+2 are issued and step s+1 is stored while step s is multiplied, one barrier per step;
+//   * steps run chunk-major, taps inside - the order of the FRAG image (frag_u32_index), so the filter stream is linear.
+// Epilogue as conv16x3hf's (bias, mask, residual, relu).  Another summation order than the slice kernel: results agree to fp32 rounding.
+template <bool RELU_IN, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3 : 2))) void conv16x3sf_kernel(const P16 p) {
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, BMP = TN * 32;
+    constexpr int LDS_K = BK + 8, XPLANE = BMP * LDS_K, STAGE = NP * XPLANE;
+    constexpr int X_PER = BMP * 8 / NT;                   // float4 items (4 channels of a position) per thread and step
+    constexpr int LDE = 32 + 4;
+    static_assert(X_PER >= 1, "tile / thread mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short* const S0 = smem;
+    unsigned short* const S1 = smem + STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
+    const int tiles_n = p.Ng / 128;
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // neighbouring position tiles (shared input rows) on one XCD
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BMP, n0 = tile_n * 128;
+    const int nch = p.C / BK;
+    const int PQ = p.P * p.Q;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
+    // ---- filter fragment stream of this wave (conv16x3hf_kernel): 6 KB per step, steps contiguous
+    const unsigned a_voff = (unsigned)lane * 16u;
+    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((long long)((n0 >> 5) + wave) * nch * RS * 6144));
+    u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
+    auto loadA = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                fa[SET][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, a_soff + (unsigned)((ks * NP + q) * 1024), 0));
+        a_soff += 6144u;
+    };
+    // ---- pixel-operand loader: item -> (position, 4-channel group); the position's byte offset at tap (0,0), chunk 0 is fixed
+    unsigned x_voff[X_PER];
+    int x_ih0[X_PER], x_iw0[X_PER];
+#pragma unroll
+    for (int i = 0; i < X_PER; ++i) {
+        const int item = i * NT + tid, px = item >> 3;
+        const int m = m0 + px;
+        const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+        x_ih0[i] = pp * p.stride - p.ph_pad_t[0];
+        x_iw0[i] = qq * p.stride - p.ph_pad_l[0];
+        const long long o = (long long)n * p.s_n + (long long)x_ih0[i] * p.s_h + (long long)x_iw0[i] * p.s_w + (item & 7) * 4;
+        x_voff[i] = (unsigned)(o * 4);                    // may be "negative": wraps consistently mod 2^32
+    }
+    float4 rx[X_PER];
+    int ld_c = 0, ld_t = 0, ld_u = 0;                     // chunk / tap of the NEXT step to load (taps inside a chunk)
+    auto load_x = [&]() __attribute__((always_inline)) {
+        const unsigned xs = (unsigned)(((long long)ld_t * p.s_h + (long long)ld_u * p.s_w + ld_c * BK) * 4);
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i) {
+            const bool ok = ((unsigned)(x_ih0[i] + ld_t) < (unsigned)p.H) & ((unsigned)(x_iw0[i] + ld_u) < (unsigned)p.W);
+            rx[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? x_voff[i] + xs : 0xFFFFFFFFu, 0, 0));
+        }
+        ++ld_u;                                           // branch-free advance (a branch would split the step's basic block)
+        const bool wu = ld_u == S;
+        ld_u = wu ? 0 : ld_u;
+        ld_t += wu ? 1 : 0;
+        const bool wt = ld_t == R;
+        ld_t = wt ? 0 : ld_t;
+        ld_c += wt ? 1 : 0;
+    };
+    auto store_x = [&](unsigned short* Xs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < X_PER; ++i) {
+            const int item = i * NT + tid, px = item >> 3;
+            float4 v = rx[i];
+            if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            unsigned o0[NP], o1[NP];
+            split_pk<MMA>(v.x, v.y, o0);
+            split_pk<MMA>(v.z, v.w, o1);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const u32x2 o = {o0[q], o1[q]};
+                *reinterpret_cast<u32x2*>(&Xs[q * XPLANE + px * LDS_K + (item & 7) * 4]) = o;
+            }
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int h = lane >> 5, l31 = lane & 31;
+    constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
+
+    const int T = nch * RS;
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    load_x();
+    loadA(set0{});
+    store_x(S0);
+    __syncthreads();
+    if (T > 1) load_x();
+    auto step = [&](auto curc, auto nxtc, const unsigned short* rd, unsigned short* wr, int st) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(curc)::value;
+        if (st + 1 < T) loadA(nxtc);                       // the next step's filter fragments, one step ahead
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fx[NP][TN];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fx[q][j] = *reinterpret_cast<const u32x4*>(&rd[q * XPLANE + (j * 32 + l31) * LDS_K + ks * 16 + h * 8]);
+#pragma unroll
+            for (int cl = 0; cl < 6; ++cl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[j] = Cvt<MMA>::mma(fa[CUR][ks][QW[cl]], fx[QX[cl]][j], acc[j]);
+        }
+        if (st + 1 < T) {
+            store_x(wr);                                   // step st+1 (its readers of two steps ago passed the last barrier)
+            if (st + 2 < T) load_x();
+        }
+        __syncthreads();
+    };
+    int st = 0;
+    for (; st + 1 < T; st += 2) { step(set0{}, set1{}, S0, S1, st); step(set1{}, set0{}, S1, S0, st + 1); }
+    if (st < T) step(set0{}, set1{}, S0, S1, st);
+
+    // epilogue through LDS (conv16x3hf_kernel): a wave's 32 kout x 32 positions per pass
+    float* es = reinterpret_cast<float*>(smem) + wave * (32 * LDE);
+    constexpr int C4 = 8, ROWS_PER = 64 / C4;
+#pragma unroll
+    for (int jh = 0; jh < TN; ++jh) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = {acc[jh][4 * q], acc[jh][4 * q + 1], acc[jh][4 * q + 2], acc[jh][4 * q + 3]};
+            *reinterpret_cast<float4*>(&es[l31 * LDE + 8 * q + 4 * h]) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 / ROWS_PER; ++it) {
+            const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
+            const int m = m0 + jh * 32 + row, col = n0 + wave * 32 + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+            const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+            const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+            if (p.mask) {
+                const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+                v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+            }
+            if (p.resid) { const float4 r = *reinterpret_cast<const float4*>(p.resid + off); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(p.D + off) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- WGRAD kernel
 struct W16 {
     const float* X; const float* DY;
@@ -1376,7 +1557,8 @@ bool frag_image_shape(const ctgan_conv_desc* d, int op) {
     const int nout = op == CTGAN_CONV_FWD ? d->K : d->C, cred = op == CTGAN_CONV_FWD ? d->C : d->K;
     if (!(op == CTGAN_CONV_FWD || op == CTGAN_CONV_DGRAD) || nout % 128 != 0 || cred % 32 != 0) return false;
     if (d->stride == 1) return d->R * d->S >= 2;
-    return op == CTGAN_CONV_DGRAD && s2_halo_shape(d);
+    if (op == CTGAN_CONV_FWD) return d->stride == 2 && d->R * d->S >= 2 && !d->x_up;      // conv16x3sf_kernel (the folded 4x4 / 2x2 stride-2 filters)
+    return s2_halo_shape(d);
 }
 int mma_planes(int mma) { return mma == CTGAN_MMA_F32X3 ? 3 : 1; }
 int dbg16() { static const int v = [] { const char* e = getenv("CTGAN_DBG16"); return e ? atoi(e) : 0; }(); return v; }
@@ -1547,6 +1729,41 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
     return ctgan_check_launch("conv16x3hf");
 }
 
+// conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 otherwise, 32 when 64 leave
+// fewer than 256 workgroups.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
+int g_s2fwd = 1;                      // tests / A-B: ctgan_debug_x3_s2fwd(0) puts the strided forward launches back on the slice kernel
+int conv16x3sf_tile(const P16& p) {
+    if (!g_s2fwd || p.nph != 1 || p.stride != 2 || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.M % 32) return 0;
+    // one accumulator per output element and no K split: reductions up to 2,304 terms (4x4x128, 3x3x256: 864 accumulation steps) - the chain of the
+    // halo-patch kernels at 2x their length; longer ones (the DCGAN 5x5x128 layers in the fp32 mode) keep the slice kernel's two accumulators / K split
+    if ((long long)p.ph_T[0] * p.ph_U[0] * p.C > 2304) return 0;
+    const long long kt = p.Ng / 128;
+    if (p.M % 128 == 0 && (p.M / 128) * kt >= 512) return 128;
+    if (p.M % 64 == 0 && (p.M / 64) * kt >= 256) return 64;
+    return (p.M / 32) * kt >= 192 ? 32 : 0;
+}
+template <bool RELU_IN, int TN>
+int launch_conv16x3sf_t(const P16& p, hipStream_t st) {
+    const size_t epi = (size_t)4 * 32 * 36 * 4, stages = (size_t)2 * 3 * (TN * 32) * 40 * 2;
+    const size_t lds = stages > epi ? stages : epi;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv16x3sf_kernel<RELU_IN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3sf: cannot reserve %zu B of LDS", lds);
+        attr = true;
+    }
+    P16 q = p;
+    q.ksplit = 1; q.slab = nullptr;
+    hipLaunchKernelGGL((conv16x3sf_kernel<RELU_IN, TN>), dim3((unsigned)((p.M / (TN * 32)) * (p.Ng / 128))), dim3(256), lds, st, q);
+    ctgan_set_last_kernel(TN == 4 ? "conv16x3sf<128x128,k32>" : (TN == 2 ? "conv16x3sf<64x128,k32>" : "conv16x3sf<32x128,k32>"));
+    ctgan_set_last_symbol("conv16x3sf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
+    return ctgan_check_launch("conv16x3sf");
+}
+int launch_conv16x3sf(const P16& p, int bmp, hipStream_t st) {
+    if (p.relu_in) return bmp == 128 ? launch_conv16x3sf_t<true, 4>(p, st) : (bmp == 64 ? launch_conv16x3sf_t<true, 2>(p, st) : launch_conv16x3sf_t<true, 1>(p, st));
+    return bmp == 128 ? launch_conv16x3sf_t<false, 4>(p, st) : (bmp == 64 ? launch_conv16x3sf_t<false, 2>(p, st) : launch_conv16x3sf_t<false, 1>(p, st));
+}
+
 int launch_conv16x3h(const P16& p, hipStream_t st) {
     // whole small images per 128-pixel tile (8x8): the LDS-staged kernel is the faster one when it applies
     const bool prefer_v1 = !g_halo_version_override && x3_8x8_mode() == 0 && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
@@ -1595,6 +1812,7 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
     const bool small = big_tiles < 192 || p.Ng % 128 != 0;
     if constexpr (planes<MMA>() == 3) {
         if (p.nph == 4 && x3_s2halo() && conv16x3p_tile(p) && big_tiles >= 96) return launch_conv16x3p(p, st);
+        if (const int bmp = conv16x3sf_tile(p)) return launch_conv16x3sf(p, bmp, st);
     }
     P16 q = p;
     q.ksplit = 1;
@@ -1732,6 +1950,7 @@ extern "C" {
 
 void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = version; }
 void ctgan_debug_x3_s2halo(int on) { g_s2halo = on ? 1 : 0; }
+void ctgan_debug_x3_s2fwd(int on) { g_s2fwd = on ? 1 : 0; }
 static thread_local int g_last_group_kinds = 0;
 static thread_local unsigned g_last_group_col_mask = 0;
 int ctgan_debug_last_wgrad_group_kinds(void) { return g_last_group_kinds; }

@@ -868,6 +868,11 @@ def debug_x3_halo_version(v):
     lib.ctgan_debug_x3_halo_version(int(v))
 
 
+def debug_x3_s2fwd(on):
+    """Tests / A-B: False = the stride-2 forward launches of the split mode on the slice kernel instead of conv16x3sf_kernel."""
+    lib.ctgan_debug_x3_s2fwd(1 if on else 0)
+
+
 def debug_x3_s2halo(on):
     """Tests / A-B: False = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel."""
     lib.ctgan_debug_x3_s2halo(1 if on else 0)
@@ -882,6 +887,8 @@ if os.environ.get('CTGAN_M2F_PX') == '0':
     debug_m2f_px(False)
 if os.environ.get('CTGAN_X3_S2HALO') == '0':      # (bench A/B; the routing query ctgan_conv2d16_x3_prefers follows the switch)
     debug_x3_s2halo(False)
+if os.environ.get('CTGAN_X3_S2FWD') == '0':       # (bench A/B: the strided forward launches of the split mode on the slice kernel)
+    debug_x3_s2fwd(False)
 
 
 def debug_last_wgrad_group_kinds():

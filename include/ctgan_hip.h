@@ -78,6 +78,8 @@ void ctgan_debug_reduce_lanes(int on);
 void ctgan_debug_x3_halo_version(int version);
 /* tests / A-B: 0 = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel (conv16x3p_kernel) */
 void ctgan_debug_x3_s2halo(int on);
+/* tests / A-B: 0 = the stride-2 forward launches of the split mode on the slice kernel instead of conv16x3sf_kernel (filter fragments from L2) */
+void ctgan_debug_x3_s2fwd(int on);
 /* Tests / A-B: 0 = the 3x3 many -> few convs (generator output conv, data gradient of the first critic conv) on the row-ring kernel
  * instead of the one-pixel-per-lane kernel with the filter as scalar operands (csrc/fewch.hip, round 5).                          */
 void ctgan_debug_m2f_px(int on);

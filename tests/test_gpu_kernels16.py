@@ -134,7 +134,9 @@ X3_CASES = CASES + [
     (40, 256, 32, 32, 128, 4, 2),     # two channel tiles on the output side of the data gradient, 4 chunks on its reduction side
 ]
 X3_S2_DGRAD = {(128, 128, 32, 32, 128, 4, 2): 'conv16x3p<4x64x128', (128, 128, 16, 16, 128, 4, 2): 'conv16x3p<4x32x128', (40, 256, 32, 32, 128, 4, 2): 'conv16x3p<4x64x128'}
-X3_S2_FWD = {(40, 256, 32, 32, 128, 4, 2): 'conv16x3<', (128, 128, 16, 16, 128, 4, 2): 'conv16x3<'}      # (the forward stays on the slice kernels; 80 tiles: the 64x64 one)
+# the stride-2 forward: conv16x3sf_kernel (filter fragments from L2, round 5) at 64- / 32-position tiles; reductions beyond 2,304 terms keep the slice kernel
+X3_S2_FWD = {(96, 64, 32, 32, 128, 4, 2): 'conv16x3sf<64x128', (128, 128, 32, 32, 128, 4, 2): 'conv16x3sf<64x128', (128, 128, 16, 16, 128, 4, 2): 'conv16x3sf<32x128',
+             (40, 256, 32, 32, 128, 4, 2): 'conv16x3<'}
 X3_SMALL_TILE = {(64, 32, 16, 16, 128, 3, 1): '64x128', (12, 64, 32, 32, 128, 3, 1): '64x128', (48, 32, 8, 8, 128, 3, 1): '32x128',
                  (160, 32, 8, 8, 256, 3, 1): '32x128', (192, 128, 8, 8, 128, 3, 1): '32x128', (384, 32, 8, 8, 128, 3, 1): '32x128'}
 
@@ -193,7 +195,7 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
         e3, e1 = rel_l2(got3[what], want[what]), rel_l2(got1[what], want[what])
         assert e3 <= max(2.0 * e1, 3e-7), (what, e3, e1)
         m3, m1 = relerr(got3[what], want[what]), relerr(got1[what], want[what])
-        assert m3 <= max(3.0 * m1, 1e-6), (what, m3, m1)
+        assert m3 <= max(3.0 * m1, 2e-6), (what, m3, m1)      # (floor: 2e-6 of the largest element - a 3,200-term fp32 chain in any order)
 
 
 @pytest.mark.parametrize('case', [(128, 128, 32, 32, 128), (192, 128, 16, 16, 256), (40, 256, 32, 32, 64), (48, 128, 16, 16, 128)],
@@ -226,6 +228,42 @@ def test_f32x3_stride2_halo_data_gradient_equals_the_slice_kernel(K, case):
     xr = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
     gx, = torch.autograd.grad(tf_ops.conv2d_same(xr, w.cpu().double(), 2), [xr], gy.cpu().double())
     assert relerr(a1, gx) <= 3e-6
+
+
+@pytest.mark.parametrize('case', [(192, 128, 32, 32, 128, 4), (320, 128, 32, 32, 128, 4), (64, 128, 32, 32, 128, 4), (192, 128, 16, 16, 128, 4), (96, 128, 16, 16, 256, 2),
+                                  (24, 64, 32, 32, 128, 4), (96, 256, 16, 16, 128, 3)], ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d' % c)
+def test_f32x3_strided_forward_with_filter_fragments_from_l2_equals_the_slice_kernel(K, case):
+    """conv16x3sf_kernel (round 5): the stride-2 forward of the split mode - the folded ConvMeanPool / MeanPoolConv filters of
+    TF/CT_gan_cifar_resnet.py:89-98 (4x4 / 2x2, stride 2) and a 3x3 stride-2 conv (LS/wgan_LSUN_Bedrooms128.py:113) - with the filter operand
+    streamed from L2 in fragment order and the pixel operand alone in LDS, at 128- / 64- / 32-position tiles.  Same products as the slice kernel
+    in another fp32 summation order: the two agree to 2e-6 of the largest element, plain and with relu-on-load + bias + residual and with the
+    out-mask epilogue, and the plain result matches the fp64 oracle."""
+    N, C, H, W, Ko, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    geom = K.ConvGeom(C, H, W, Ko, k, k, 2, False)
+    w = (torch.randn(k, k, C, Ko, generator=g) / np.sqrt(k * k * C)).cuda()
+    x = cl(torch.randn(N, C, H, W, generator=g))
+    b = torch.randn(Ko, generator=g).cuda(); rr = cl(torch.randn(N, Ko, geom.P, geom.Q, generator=g)); mk = cl(torch.randn(N, Ko, geom.P, geom.Q, generator=g))
+
+    def run():
+        a = K.conv_fwd(x, w, None, geom); ka = K.last_kernel()
+        c = K.conv_fwd(x, w, b, geom, resid=rr, relu_in=True); kc = K.last_kernel()
+        d = K.conv_fwd(x, w, b, geom, mask=mk)
+        e = K.conv_fwd(x, w, b, geom, relu=True)
+        return (a, c, d, e), ka, kc
+    with K.mma_dtype('f32x3'):
+        r1, k1, k1c = run()
+        K.debug_x3_s2fwd(False)
+        try:
+            r0, k0, _ = run()
+        finally:
+            K.debug_x3_s2fwd(True)
+    assert k1.startswith('conv16x3sf<') and k1c.startswith('conv16x3sf<') and k0.startswith('conv16x3<'), (k1, k1c, k0)
+    for x1, x0 in zip(r1, r0):
+        assert float((x1 - x0).abs().max()) <= 2e-6 * float(x0.abs().max()), k1
+    assert float((r1[3] < 0).sum()) == 0
+    ref = tf_ops.conv2d_same(x.cpu().double(), w.cpu().double(), 2)
+    assert relerr(r1[0], ref) <= 3e-6, k1
 
 
 @pytest.mark.parametrize('case', [(24, 128, 32, 32, 128, 3, 1), (96, 128, 16, 16, 256, 3, 1), (384, 128, 8, 8, 128, 3, 1)],
