@@ -1729,8 +1729,7 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
     return ctgan_check_launch("conv16x3hf");
 }
 
-// conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 otherwise, 32 when 64 leave
-// fewer than 256 workgroups.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
+// conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 from 384, 32 from 192.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
 int g_s2fwd = 1;                      // tests / A-B: ctgan_debug_x3_s2fwd(0) puts the strided forward launches back on the slice kernel
 int conv16x3sf_tile(const P16& p) {
     if (!g_s2fwd || p.nph != 1 || p.stride != 2 || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.M % 32) return 0;
@@ -1738,9 +1737,16 @@ int conv16x3sf_tile(const P16& p) {
     // halo-patch kernels at 2x their length; longer ones (the DCGAN 5x5x128 layers in the fp32 mode) keep the slice kernel's two accumulators / K split
     if ((long long)p.ph_T[0] * p.ph_U[0] * p.C > 2304) return 0;
     const long long kt = p.Ng / 128;
-    if (p.M % 128 == 0 && (p.M / 128) * kt >= 512) return 128;
-    if (p.M % 64 == 0 && (p.M / 64) * kt >= 256) return 64;
-    return (p.M / 32) * kt >= 192 ? 32 : 0;
+#ifdef SF_TUNE      // (A/B builds: thresholds from the environment)
+    static const int t128 = [] { const char* e = getenv("CTGAN_SF_T128"); return e ? atoi(e) : 512; }();
+    static const int t64 = [] { const char* e = getenv("CTGAN_SF_T64"); return e ? atoi(e) : 384; }();
+    static const int t32 = [] { const char* e = getenv("CTGAN_SF_T32"); return e ? atoi(e) : 192; }();
+#else
+    constexpr int t128 = 512, t64 = 384, t32 = 192;      // sweep (tools/conv16_bench.py f32x3 s2, one box): 64 rows of 32x32 -> 16x16 65 us at 256 tiles of 64, 59 at 512 of 32
+#endif
+    if (p.M % 128 == 0 && (p.M / 128) * kt >= t128) return 128;
+    if (p.M % 64 == 0 && (p.M / 64) * kt >= t64) return 64;
+    return (p.M / 32) * kt >= t32 ? 32 : 0;
 }
 template <bool RELU_IN, int TN>
 int launch_conv16x3sf_t(const P16& p, hipStream_t st) {
