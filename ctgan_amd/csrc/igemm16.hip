@@ -1729,7 +1729,7 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
     return ctgan_check_launch("conv16x3hf");
 }
 
-// conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 from 256, 32 (2x2 filters) from 192.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
+// conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 from 384, 32 (2x2 filters) from 192.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
 int g_s2fwd = 1;                      // tests / A-B: ctgan_debug_x3_s2fwd(0) puts the strided forward launches back on the slice kernel
 int conv16x3sf_tile(const P16& p) {
     if (!g_s2fwd || p.nph != 1 || p.stride != 2 || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.M % 32) return 0;
@@ -1739,10 +1739,10 @@ int conv16x3sf_tile(const P16& p) {
     const long long kt = p.Ng / 128;
 #ifdef SF_TUNE      // (A/B builds: thresholds from the environment)
     static const int t128 = [] { const char* e = getenv("CTGAN_SF_T128"); return e ? atoi(e) : 512; }();
-    static const int t64 = [] { const char* e = getenv("CTGAN_SF_T64"); return e ? atoi(e) : 256; }();
+    static const int t64 = [] { const char* e = getenv("CTGAN_SF_T64"); return e ? atoi(e) : 384; }();
     static const int t32 = [] { const char* e = getenv("CTGAN_SF_T32"); return e ? atoi(e) : 192; }();
 #else
-    constexpr int t128 = 512, t64 = 256, t32 = 192;
+    constexpr int t128 = 512, t64 = 384, t32 = 192;      // (64 rows of 32x32 -> 16x16 = 256 tiles of 64: 74.4 us in the step against the slice kernel's 63.8)
 #endif
     if (p.M % 128 == 0 && (p.M / 128) * kt >= t128) return 128;
     if (p.M % 64 == 0 && (p.M / 64) * kt >= t64) return 64;

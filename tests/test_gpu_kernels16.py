@@ -230,8 +230,8 @@ def test_f32x3_stride2_halo_data_gradient_equals_the_slice_kernel(K, case):
     assert relerr(a1, gx) <= 3e-6
 
 
-@pytest.mark.parametrize('case', [(192, 128, 32, 32, 128, 4), (320, 128, 32, 32, 128, 4), (64, 128, 32, 32, 128, 4), (320, 128, 16, 16, 128, 4), (96, 128, 16, 16, 256, 2),
-                                  (64, 64, 32, 32, 128, 4), (256, 256, 16, 16, 128, 3)], ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d' % c)
+@pytest.mark.parametrize('case', [(192, 128, 32, 32, 128, 4), (320, 128, 32, 32, 128, 4), (96, 128, 32, 32, 128, 4), (384, 128, 16, 16, 128, 4), (96, 128, 16, 16, 256, 2),
+                                  (96, 64, 32, 32, 128, 4), (384, 256, 16, 16, 128, 3)], ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d' % c)
 def test_f32x3_strided_forward_with_filter_fragments_from_l2_equals_the_slice_kernel(K, case):
     """conv16x3sf_kernel (round 5): the stride-2 forward of the split mode - the folded ConvMeanPool / MeanPoolConv filters of
     TF/CT_gan_cifar_resnet.py:89-98 (4x4 / 2x2, stride 2) and a 3x3 stride-2 conv (LS/wgan_LSUN_Bedrooms128.py:113) - with the filter operand
