@@ -79,6 +79,7 @@ SIGNATURES = {
     'ctgan_debug_x3_halo_version': (None, [c_int]),
     'ctgan_debug_x3_s2halo': (None, [c_int]),
     'ctgan_debug_x3_s2fwd': (None, [c_int]),
+    'ctgan_debug_x3_s2dgrad_sf': (None, [c_int]),
     'ctgan_debug_m2f_px': (None, [c_int]),
     'ctgan_debug_last_wgrad_group_kinds': (c_int, []),
     'ctgan_debug_last_wgrad_group_col_mask': (ctypes.c_uint, []),

@@ -1020,21 +1020,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
     const int tiles_n = p.Ng / 128;
     int bid = blockIdx.x;
     const int nb = gridDim.x;
     if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // neighbouring position tiles (shared input rows) on one XCD
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m = bid / tiles_n;
+    const int tile_n = bid - tile_m * tiles_n;
+    // four-phase data gradient of a stride-2 conv (nph == 4; the folded 4x4 filters: every phase 2 x 2 taps): the workgroup's phase, its
+    // taps / pads, its offset in the result and - the FRAG image of these filters is in (chunk, phase, tap) order - in the filter stream
+    int ph = 0;
+    if (p.nph > 1) { ph = tile_m / p.ph_tiles_m; tile_m -= ph * p.ph_tiles_m; }
+    const int pa = ph >> 1, pb = ph & 1;
+    const int R = p.ph_T[pa], S = p.ph_U[pb], RS = R * S;
+    const int RS_all = p.nph > 1 ? p.nph * RS : RS;
+    const int pad_t = p.ph_pad_t[pa], pad_l = p.ph_pad_l[pb];
+    const long long d_off = pa * p.ph_d_h + pb * p.ph_d_w;
     const int m0 = tile_m * BMP, n0 = tile_n * 128;
     const int nch = p.C / BK;
     const int PQ = p.P * p.Q;
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
-    // ---- filter fragment stream of this wave (conv16x3hf_kernel): 6 KB per step, steps contiguous
+    // ---- filter fragment stream of this wave (conv16x3hf_kernel): 6 KB per step; the steps of a chunk contiguous, chunks RS_all steps apart
     const unsigned a_voff = (unsigned)lane * 16u;
-    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((long long)((n0 >> 5) + wave) * nch * RS * 6144));
+    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(((long long)((n0 >> 5) + wave) * nch * RS_all + ph * RS) * 6144));
+    const unsigned a_skip = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((RS_all - RS) * 6144));
+    int a_tap = 0;
     u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
     auto loadA = [&](auto setc) __attribute__((always_inline)) {
         constexpr int SET = decltype(setc)::value;
@@ -1043,7 +1054,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
 #pragma unroll
             for (int q = 0; q < NP; ++q)
                 fa[SET][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, a_soff + (unsigned)((ks * NP + q) * 1024), 0));
-        a_soff += 6144u;
+        ++a_tap;
+        const bool wrap = a_tap == RS;
+        a_tap = wrap ? 0 : a_tap;
+        a_soff += 6144u + (wrap ? a_skip : 0u);
     };
     // ---- pixel-operand loader: item -> (position, 4-channel group); the position's byte offset at tap (0,0), chunk 0 is fixed
     unsigned x_voff[X_PER];
@@ -1053,8 +1067,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
         const int item = i * NT + tid, px = item >> 3;
         const int m = m0 + px;
         const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
-        x_ih0[i] = pp * p.stride - p.ph_pad_t[0];
-        x_iw0[i] = qq * p.stride - p.ph_pad_l[0];
+        x_ih0[i] = pp * p.stride - pad_t;
+        x_iw0[i] = qq * p.stride - pad_l;
         const long long o = (long long)n * p.s_n + (long long)x_ih0[i] * p.s_h + (long long)x_iw0[i] * p.s_w + (item & 7) * 4;
         x_voff[i] = (unsigned)(o * 4);                    // may be "negative": wraps consistently mod 2^32
     }
@@ -1153,7 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
             const int m = m0 + jh * 32 + row, col = n0 + wave * 32 + c4 * 4;
             float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
             const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
-            const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+            const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
             if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
             if (p.mask) {
                 const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
@@ -1731,7 +1745,18 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
 
 // conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 from 384, 32 (2x2 filters) from 192.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
 int g_s2fwd = 1;                      // tests / A-B: ctgan_debug_x3_s2fwd(0) puts the strided forward launches back on the slice kernel
+// The four-phase data gradients of the folded 4x4 filters: one phase per workgroup on conv16x3sf_kernel where conv16x3p_kernel would run its
+// 32-position tiles (8x8 dy grids: tools/sf_dgrad_check.py 84.3 -> 71.5 us at 320 rows, 88.3 -> 79.4 at 192 rows x 256 channels; bit-identical
+// results - the same accumulation order); on 16x16 dy grids the four-phases-per-patch kernel stays ahead (153 against 163 us at 192 rows).
+int g_s2dgrad_sf = 0;                 // tests / A-B: ctgan_debug_x3_s2dgrad_sf(1) = every such data gradient, (-1) = none
 int conv16x3sf_tile(const P16& p) {
+    if (p.nph == 4) {
+        // (the FRAG image of these filters exists for the 4x4 / stride-2 / pad-1 shape only: every phase 2 x 2 taps)
+        if (g_s2dgrad_sf < 0 || (g_s2dgrad_sf == 0 && p.P * p.Q > 64) || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.relu_in || p.ph_T[0] != 2 || p.ph_T[1] != 2 || p.ph_U[0] != 2 || p.ph_U[1] != 2) return 0;
+        const long long kt = 4LL * (p.Ng / 128);
+        if (p.M % 128 == 0 && (p.M / 128) * kt >= 1536) return 128;
+        return (p.M % 64 == 0 && (p.M / 64) * kt >= 768) ? 64 : 0;
+    }
     if (!g_s2fwd || p.nph != 1 || p.stride != 2 || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.M % 32) return 0;
     // one accumulator per output element and no K split: reductions up to 2,304 terms (4x4x128, 3x3x256: 864 accumulation steps) - the chain of the
     // halo-patch kernels at 2x their length; longer ones (the DCGAN 5x5x128 layers in the fp32 mode) keep the slice kernel's two accumulators / K split
@@ -1762,7 +1787,8 @@ int launch_conv16x3sf_t(const P16& p, hipStream_t st) {
     }
     P16 q = p;
     q.ksplit = 1; q.slab = nullptr;
-    hipLaunchKernelGGL((conv16x3sf_kernel<RELU_IN, TN>), dim3((unsigned)((p.M / (TN * 32)) * (p.Ng / 128))), dim3(256), lds, st, q);
+    q.ph_tiles_m = p.M / (TN * 32);
+    hipLaunchKernelGGL((conv16x3sf_kernel<RELU_IN, TN>), dim3((unsigned)(p.nph * q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q);
     ctgan_set_last_kernel(TN == 4 ? "conv16x3sf<128x128,k32>" : (TN == 2 ? "conv16x3sf<64x128,k32>" : "conv16x3sf<32x128,k32>"));
     ctgan_set_last_symbol("conv16x3sf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
     return ctgan_check_launch("conv16x3sf");
@@ -1819,8 +1845,12 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
     const long long big_tiles = (long long)p.nph * ((p.M + 127) / 128) * ((p.Ng + 127) / 128);
     const bool small = big_tiles < 192 || p.Ng % 128 != 0;
     if constexpr (planes<MMA>() == 3) {
-        if (p.nph == 4 && x3_s2halo() && conv16x3p_tile(p) && big_tiles >= 96) return launch_conv16x3p(p, st);
-        if (const int bmp = conv16x3sf_tile(p)) return launch_conv16x3sf(p, bmp, st);
+        if (p.nph == 4 && x3_s2halo() && conv16x3p_tile(p) && big_tiles >= 96) {
+            if (const int bmp = conv16x3sf_tile(p)) return launch_conv16x3sf(p, bmp, st);
+            return launch_conv16x3p(p, st);
+        }
+        if (p.nph == 1)
+            if (const int bmp = conv16x3sf_tile(p)) return launch_conv16x3sf(p, bmp, st);
     }
     P16 q = p;
     q.ksplit = 1;
@@ -1959,6 +1989,7 @@ extern "C" {
 void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = version; }
 void ctgan_debug_x3_s2halo(int on) { g_s2halo = on ? 1 : 0; }
 void ctgan_debug_x3_s2fwd(int on) { g_s2fwd = on ? 1 : 0; }
+void ctgan_debug_x3_s2dgrad_sf(int on) { g_s2dgrad_sf = on; }
 static thread_local int g_last_group_kinds = 0;
 static thread_local unsigned g_last_group_col_mask = 0;
 int ctgan_debug_last_wgrad_group_kinds(void) { return g_last_group_kinds; }

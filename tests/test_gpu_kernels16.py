@@ -222,7 +222,7 @@ def test_f32x3_stride2_halo_data_gradient_equals_the_slice_kernel(K, case):
             a0, b0, k0 = run()
         finally:
             K.debug_x3_s2halo(True)
-    assert k1.startswith('conv16x3p<') and k0.startswith('conv16x3<'), (k1, k0)
+    assert k1.startswith(('conv16x3p<', 'conv16x3sf<')) and k0.startswith('conv16x3<'), (k1, k0)      # (8x8 dy grids from 768 workgroups: one phase per workgroup on conv16x3sf)
     for x1, x0 in ((a1, a0), (b1, b0)):
         assert float((x1 - x0).abs().max()) <= 2e-6 * float(x0.abs().max())
     xr = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
@@ -264,6 +264,30 @@ def test_f32x3_strided_forward_with_filter_fragments_from_l2_equals_the_slice_ke
     assert float((r1[3] < 0).sum()) == 0
     ref = tf_ops.conv2d_same(x.cpu().double(), w.cpu().double(), 2)
     assert relerr(r1[0], ref) <= 3e-6, k1
+
+
+@pytest.mark.parametrize('case', [(192, 128, 32, 32, 128), (192, 128, 16, 16, 256), (320, 128, 16, 16, 128)], ids=lambda c: 'N%d_C%d_H%dx%d_K%d' % c)
+def test_f32x3_four_phase_data_gradient_one_phase_per_workgroup_equals_the_four_phase_kernel_bitwise(K, case):
+    """The data gradient of the folded 4x4 / stride-2 filters on conv16x3sf_kernel (one output-parity phase per workgroup, its 2x2 taps staged
+    slice by slice, filter fragments from L2 in the FRAG image's (chunk, phase, tap) order) against conv16x3p_kernel (four phases from one dy
+    patch): the same products accumulated in the same order - identical bits, plain and with bias + mask + residual."""
+    N, C, H, W, Ko = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    geom = K.ConvGeom(C, H, W, Ko, 4, 4, 2, False)
+    w = (torch.randn(4, 4, C, Ko, generator=g) / np.sqrt(16 * Ko)).cuda()
+    gy = cl(torch.randn(N, Ko, geom.P, geom.Q, generator=g))
+    bc = torch.randn(C, generator=g).cuda(); m = cl(torch.randn(N, C, H, W, generator=g)); rr = cl(torch.randn(N, C, H, W, generator=g))
+    out = {}
+    with K.mma_dtype('f32x3'):
+        try:
+            for code in (-1, 1):
+                K.lib.ctgan_debug_x3_s2dgrad_sf(code)
+                a = K.conv_dgrad(gy, w, geom, N); ka = K.last_kernel()
+                out[code] = (a, K.conv_dgrad(gy, w, geom, N, bias=bc, mask=m, resid=rr), ka)
+        finally:
+            K.lib.ctgan_debug_x3_s2dgrad_sf(0)
+    assert out[-1][2].startswith('conv16x3p<') and out[1][2].startswith('conv16x3sf<'), (out[-1][2], out[1][2])
+    assert torch.equal(out[-1][0], out[1][0]) and torch.equal(out[-1][1], out[1][1])
 
 
 @pytest.mark.parametrize('case', [(24, 128, 32, 32, 128, 3, 1), (96, 128, 16, 16, 256, 3, 1), (384, 128, 8, 8, 128, 3, 1)],
