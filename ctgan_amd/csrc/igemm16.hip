@@ -1037,13 +1037,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
     const long long d_off = pa * p.ph_d_h + pb * p.ph_d_w;
     const int m0 = tile_m * BMP, n0 = tile_n * 128;
     const int nch = p.C / BK;
+    // K split (launches whose tiles cannot fill the chip): blockIdx.y handles the chunks [c0, c1) and leaves raw sums in its slab
+    const int c0 = p.ksplit > 1 ? (int)((long long)nch * blockIdx.y / p.ksplit) : 0;
+    const int c1 = p.ksplit > 1 ? (int)((long long)nch * (blockIdx.y + 1) / p.ksplit) : nch;
     const int PQ = p.P * p.Q;
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
     // ---- filter fragment stream of this wave (conv16x3hf_kernel): 6 KB per step; the steps of a chunk contiguous, chunks RS_all steps apart
     const unsigned a_voff = (unsigned)lane * 16u;
-    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(((long long)((n0 >> 5) + wave) * nch * RS_all + ph * RS) * 6144));
+    unsigned a_soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)((n0 >> 5) + wave) * nch + c0) * RS_all + ph * RS) * 6144));
     const unsigned a_skip = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((RS_all - RS) * 6144));
     int a_tap = 0;
     u32x4 fa[2][2][NP];                                   // [register set][k step][plane]
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
         x_voff[i] = (unsigned)(o * 4);                    // may be "negative": wraps consistently mod 2^32
     }
     float4 rx[X_PER];
-    int ld_c = 0, ld_t = 0, ld_u = 0;                     // chunk / tap of the NEXT step to load (taps inside a chunk)
+    int ld_c = c0, ld_t = 0, ld_u = 0;                    // chunk / tap of the NEXT step to load (taps inside a chunk)
     auto load_x = [&]() __attribute__((always_inline)) {
         const unsigned xs = (unsigned)(((long long)ld_t * p.s_h + (long long)ld_u * p.s_w + ld_c * BK) * 4);
 #pragma unroll
@@ -1114,7 +1117,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
     const int h = lane >> 5, l31 = lane & 31;
     constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
 
-    const int T = nch * RS;
+    const int T = (c1 - c0) * RS;
     using set0 = std::integral_constant<int, 0>;
     using set1 = std::integral_constant<int, 1>;
     load_x();
@@ -1166,6 +1169,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
             const int row = it * ROWS_PER + lane / C4, c4 = lane % C4;
             const int m = m0 + jh * 32 + row, col = n0 + wave * 32 + c4 * 4;
             float4 v = *reinterpret_cast<const float4*>(&es[row * LDE + c4 * 4]);
+            if (p.ksplit > 1) {               // partial sums: conv16_splitk_epilogue_kernel applies the epilogue
+                *reinterpret_cast<float4*>(p.slab + (((long long)blockIdx.y * p.nph + ph) * p.M + m) * p.Ng + col) = v;
+                continue;
+            }
             const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
             const long long off = d_off + n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
             if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
@@ -1748,6 +1755,13 @@ int g_s2fwd = 1;                      // tests / A-B: ctgan_debug_x3_s2fwd(0) pu
 // The four-phase data gradients of the folded 4x4 filters: one phase per workgroup on conv16x3sf_kernel where conv16x3p_kernel would run its
 // 32-position tiles (8x8 dy grids: tools/sf_dgrad_check.py 84.3 -> 71.5 us at 320 rows, 88.3 -> 79.4 at 192 rows x 256 channels; bit-identical
 // results - the same accumulation order); on 16x16 dy grids the four-phases-per-patch kernel stays ahead (153 against 163 us at 192 rows).
+int g_sf_ksplit = 1;                  // A/B: ctgan_debug_x3_s2fwd(2) = no K split on conv16x3sf_kernel
+int conv16x3sf_ksplit(const P16& p) {
+    if (!g_sf_ksplit || p.nph != 1 || p.M % 64 || p.C < 64 || !p.slab || p.ph_T[0] * p.ph_U[0] <= 4) return 1;
+    const long long tiles = (long long)(p.M / 64) * (p.Ng / 128);
+    if (tiles < 160 || tiles >= 384) return 1;      // (tools/conv16_bench.py f32x3 s2: 128 tiles 37 -> 39 us, 192 tiles 57 -> 50, 256 tiles 64 -> 56, 320 tiles 81 -> 78)
+    return (size_t)2 * p.M * p.Ng * sizeof(float) <= p.slab_bytes ? 2 : 1;
+}
 int g_s2dgrad_sf = 0;                 // tests / A-B: ctgan_debug_x3_s2dgrad_sf(1) = every such data gradient, (-1) = none
 int conv16x3sf_tile(const P16& p) {
     if (p.nph == 4) {
@@ -1771,6 +1785,9 @@ int conv16x3sf_tile(const P16& p) {
 #endif
     if (p.M % 128 == 0 && (p.M / 128) * kt >= t128) return 128;
     if (p.M % 64 == 0 && (p.M / 64) * kt >= t64) return 64;
+    // 160 .. 383 tiles of 64 positions (4x4 layers at 192 rows of 16x16 / 64 rows of 32x32): two workgroups per tile, each half the chunks,
+    // raw sums to slabs + conv16_splitk_epilogue_kernel (conv16x3sf_ksplit)
+    if (conv16x3sf_ksplit(p) > 1) return 64;
     // 32-position tiles (a wave streams 6 KB of filter per 12 MFMAs): only the short reductions of the 2x2 shortcut filters gain (in the step:
     // 22.2 -> 18.8 us); the 4x4 layers at 192 rows of 16x16 / 64 rows of 32x32 measured 61.0 / 64.1 us against the slice kernel's 57.1 / 63.8
     return (p.ph_T[0] * p.ph_U[0] <= 4 && (p.M / 32) * kt >= t32) ? 32 : 0;
@@ -1786,12 +1803,17 @@ int launch_conv16x3sf_t(const P16& p, hipStream_t st) {
         attr = true;
     }
     P16 q = p;
-    q.ksplit = 1; q.slab = nullptr;
+    q.ksplit = (TN == 2 && (long long)(p.M / 64) * (p.Ng / 128) < 384) ? conv16x3sf_ksplit(p) : 1;
+    if (q.ksplit == 1) q.slab = nullptr;
     q.ph_tiles_m = p.M / (TN * 32);
-    hipLaunchKernelGGL((conv16x3sf_kernel<RELU_IN, TN>), dim3((unsigned)(p.nph * q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q);
-    ctgan_set_last_kernel(TN == 4 ? "conv16x3sf<128x128,k32>" : (TN == 2 ? "conv16x3sf<64x128,k32>" : "conv16x3sf<32x128,k32>"));
+    hipLaunchKernelGGL((conv16x3sf_kernel<RELU_IN, TN>), dim3((unsigned)(p.nph * q.ph_tiles_m * (p.Ng / 128)), (unsigned)q.ksplit), dim3(256), lds, st, q);
+    ctgan_set_last_kernel(q.ksplit > 1 ? "conv16x3sf<64x128,k32,ksplit>" : (TN == 4 ? "conv16x3sf<128x128,k32>" : (TN == 2 ? "conv16x3sf<64x128,k32>" : "conv16x3sf<32x128,k32>")));
     ctgan_set_last_symbol("conv16x3sf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
-    return ctgan_check_launch("conv16x3sf");
+    int rc = ctgan_check_launch("conv16x3sf");
+    if (rc || q.ksplit == 1) return rc;
+    const long long n = (long long)q.nph * q.M * (q.Ng / 4);
+    hipLaunchKernelGGL(conv16_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q);
+    return ctgan_check_launch("conv16_splitk_epilogue");
 }
 int launch_conv16x3sf(const P16& p, int bmp, hipStream_t st) {
     if (p.relu_in) return bmp == 128 ? launch_conv16x3sf_t<true, 4>(p, st) : (bmp == 64 ? launch_conv16x3sf_t<true, 2>(p, st) : launch_conv16x3sf_t<true, 1>(p, st));
@@ -1988,7 +2010,7 @@ extern "C" {
 
 void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = version; }
 void ctgan_debug_x3_s2halo(int on) { g_s2halo = on ? 1 : 0; }
-void ctgan_debug_x3_s2fwd(int on) { g_s2fwd = on ? 1 : 0; }
+void ctgan_debug_x3_s2fwd(int on) { g_s2fwd = on ? 1 : 0; g_sf_ksplit = on == 2 ? 0 : 1; }
 void ctgan_debug_x3_s2dgrad_sf(int on) { g_s2dgrad_sf = on; }
 static thread_local int g_last_group_kinds = 0;
 static thread_local unsigned g_last_group_col_mask = 0;

@@ -869,8 +869,9 @@ def debug_x3_halo_version(v):
 
 
 def debug_x3_s2fwd(on):
-    """Tests / A-B: False = the stride-2 forward launches of the split mode on the slice kernel instead of conv16x3sf_kernel."""
-    lib.ctgan_debug_x3_s2fwd(1 if on else 0)
+    """Tests / A-B: False = the stride-2 forward launches of the split mode on the slice kernel instead of conv16x3sf_kernel; 2 = on that
+    kernel, without its K split for launches of 128 .. 383 tiles."""
+    lib.ctgan_debug_x3_s2fwd(2 if on == 2 else (1 if on else 0))
 
 
 def debug_x3_s2halo(on):
@@ -889,8 +890,8 @@ if os.environ.get('CTGAN_X3_S2HALO') == '0':      # (bench A/B; the routing quer
     debug_x3_s2halo(False)
 if os.environ.get('CTGAN_X3_S2DGRAD_SF') == '1':  # (bench A/B: the four-phase data gradients on the slice-staging kernel with the filter from L2)
     lib.ctgan_debug_x3_s2dgrad_sf(1)
-if os.environ.get('CTGAN_X3_S2FWD') == '0':       # (bench A/B: the strided forward launches of the split mode on the slice kernel)
-    debug_x3_s2fwd(False)
+if os.environ.get('CTGAN_X3_S2FWD') in ('0', '2'):   # (bench A/B: the strided forward launches of the split mode on the slice kernel / without the K split)
+    debug_x3_s2fwd(int(os.environ['CTGAN_X3_S2FWD']))
 
 
 def debug_last_wgrad_group_kinds():

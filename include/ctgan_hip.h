@@ -78,7 +78,8 @@ void ctgan_debug_reduce_lanes(int on);
 void ctgan_debug_x3_halo_version(int version);
 /* tests / A-B: 0 = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel (conv16x3p_kernel) */
 void ctgan_debug_x3_s2halo(int on);
-/* tests / A-B: 0 = the stride-2 forward launches of the split mode on the slice kernel instead of conv16x3sf_kernel (filter fragments from L2) */
+/* tests / A-B: 0 = the stride-2 forward launches of the split mode on the slice kernel instead of conv16x3sf_kernel (filter fragments from L2);
+   2 = on that kernel but without its K split (launches of 128 .. 383 tiles of 64 positions) */
 void ctgan_debug_x3_s2fwd(int on);
 /* tests / A-B: which four-phase data gradients of the folded 4x4 / stride-2 filters run on conv16x3sf_kernel (one phase per workgroup, slice staging)
    instead of conv16x3p_kernel (four phases from one dy patch): 0 (default) those on 8x8 dy grids, 1 all, -1 none */

@@ -231,11 +231,12 @@ def test_f32x3_stride2_halo_data_gradient_equals_the_slice_kernel(K, case):
 
 
 @pytest.mark.parametrize('case', [(192, 128, 32, 32, 128, 4), (320, 128, 32, 32, 128, 4), (96, 128, 32, 32, 128, 4), (384, 128, 16, 16, 128, 4), (96, 128, 16, 16, 256, 2),
-                                  (96, 64, 32, 32, 128, 4), (384, 256, 16, 16, 128, 3)], ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d' % c)
+                                  (96, 64, 32, 32, 128, 4), (384, 256, 16, 16, 128, 3), (192, 128, 16, 16, 128, 4), (64, 128, 32, 32, 128, 4)], ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d' % c)
 def test_f32x3_strided_forward_with_filter_fragments_from_l2_equals_the_slice_kernel(K, case):
     """conv16x3sf_kernel (round 5): the stride-2 forward of the split mode - the folded ConvMeanPool / MeanPoolConv filters of
     TF/CT_gan_cifar_resnet.py:89-98 (4x4 / 2x2, stride 2) and a 3x3 stride-2 conv (LS/wgan_LSUN_Bedrooms128.py:113) - with the filter operand
-    streamed from L2 in fragment order and the pixel operand alone in LDS, at 128- / 64- / 32-position tiles.  Same products as the slice kernel
+    streamed from L2 in fragment order and the pixel operand alone in LDS, at 128- / 64- / 32-position tiles and (the last two cases: 192 / 256 tiles)
+    with the chunks split over two workgroups per tile + the slab epilogue.  Same products as the slice kernel
     in another fp32 summation order: the two agree to 3e-6 of the largest element, plain and with relu-on-load + bias + residual and with the
     out-mask epilogue, and the plain result matches the fp64 oracle."""
     N, C, H, W, Ko, k = case
