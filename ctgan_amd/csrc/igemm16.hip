@@ -1752,9 +1752,6 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
 
 // conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 from 384, 32 (2x2 filters) from 192.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
 int g_s2fwd = 1;                      // tests / A-B: ctgan_debug_x3_s2fwd(0) puts the strided forward launches back on the slice kernel
-// The four-phase data gradients of the folded 4x4 filters: one phase per workgroup on conv16x3sf_kernel where conv16x3p_kernel would run its
-// 32-position tiles (8x8 dy grids: tools/sf_dgrad_check.py 84.3 -> 71.5 us at 320 rows, 88.3 -> 79.4 at 192 rows x 256 channels; bit-identical
-// results - the same accumulation order); on 16x16 dy grids the four-phases-per-patch kernel stays ahead (153 against 163 us at 192 rows).
 int g_sf_ksplit = 1;                  // A/B: ctgan_debug_x3_s2fwd(2) = no K split on conv16x3sf_kernel
 int conv16x3sf_ksplit(const P16& p) {
     if (!g_sf_ksplit || p.nph != 1 || p.M % 64 || p.C < 64 || !p.slab || p.ph_T[0] * p.ph_U[0] <= 4) return 1;
@@ -1762,13 +1759,16 @@ int conv16x3sf_ksplit(const P16& p) {
     if (tiles < 160 || tiles >= 384) return 1;      // (tools/conv16_bench.py f32x3 s2: 128 tiles 37 -> 39 us, 192 tiles 57 -> 50, 256 tiles 64 -> 56, 320 tiles 81 -> 78)
     return (size_t)2 * p.M * p.Ng * sizeof(float) <= p.slab_bytes ? 2 : 1;
 }
-int g_s2dgrad_sf = 0;                 // tests / A-B: ctgan_debug_x3_s2dgrad_sf(1) = every such data gradient, (-1) = none
+// The four-phase data gradients of the folded 4x4 filters: one phase per workgroup on conv16x3sf_kernel at 64-position tiles (three workgroups
+// of four waves per CU instead of conv16x3p_kernel's one of eight; bit-identical results - the same accumulation order).  tools/sf_dgrad_check.py:
+// 8x8 dy grids 84.3 -> 71.5 us at 320 rows, 88.3 -> 79.4 at 192 rows x 256 channels; 16x16 dy grids level in the micro-benchmark (155 / 157 us at
+// 192 rows) and ahead in the step: iteration 13.01 -> 12.93 ms with every such launch here (128-position tiles: 13.07).
+int g_s2dgrad_sf = 0;                 // tests / A-B: ctgan_debug_x3_s2dgrad_sf(-1) = none of them (conv16x3p_kernel)
 int conv16x3sf_tile(const P16& p) {
     if (p.nph == 4) {
         // (the FRAG image of these filters exists for the 4x4 / stride-2 / pad-1 shape only: every phase 2 x 2 taps)
-        if (g_s2dgrad_sf < 0 || (g_s2dgrad_sf == 0 && p.P * p.Q > 64) || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.relu_in || p.ph_T[0] != 2 || p.ph_T[1] != 2 || p.ph_U[0] != 2 || p.ph_U[1] != 2) return 0;
+        if (g_s2dgrad_sf < 0 || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.relu_in || p.ph_T[0] != 2 || p.ph_T[1] != 2 || p.ph_U[0] != 2 || p.ph_U[1] != 2) return 0;
         const long long kt = 4LL * (p.Ng / 128);
-        if (p.M % 128 == 0 && (p.M / 128) * kt >= 1536) return 128;
         return (p.M % 64 == 0 && (p.M / 64) * kt >= 768) ? 64 : 0;
     }
     if (!g_s2fwd || p.nph != 1 || p.stride != 2 || !p.Wf || p.Ng % 128 || p.C % 32 || p.drop || p.act || p.resid_up || p.M % 32) return 0;

@@ -888,8 +888,8 @@ if os.environ.get('CTGAN_M2F_PX') == '0':
     debug_m2f_px(False)
 if os.environ.get('CTGAN_X3_S2HALO') == '0':      # (bench A/B; the routing query ctgan_conv2d16_x3_prefers follows the switch)
     debug_x3_s2halo(False)
-if os.environ.get('CTGAN_X3_S2DGRAD_SF') == '1':  # (bench A/B: the four-phase data gradients on the slice-staging kernel with the filter from L2)
-    lib.ctgan_debug_x3_s2dgrad_sf(1)
+if os.environ.get('CTGAN_X3_S2DGRAD_SF') == '-1':  # (bench A/B: the four-phase data gradients back on conv16x3p_kernel)
+    lib.ctgan_debug_x3_s2dgrad_sf(-1)
 if os.environ.get('CTGAN_X3_S2FWD') in ('0', '2'):   # (bench A/B: the strided forward launches of the split mode on the slice kernel / without the K split)
     debug_x3_s2fwd(int(os.environ['CTGAN_X3_S2FWD']))
 

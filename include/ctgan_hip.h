@@ -82,7 +82,7 @@ void ctgan_debug_x3_s2halo(int on);
    2 = on that kernel but without its K split (launches of 128 .. 383 tiles of 64 positions) */
 void ctgan_debug_x3_s2fwd(int on);
 /* tests / A-B: which four-phase data gradients of the folded 4x4 / stride-2 filters run on conv16x3sf_kernel (one phase per workgroup, slice staging)
-   instead of conv16x3p_kernel (four phases from one dy patch): 0 (default) those on 8x8 dy grids, 1 all, -1 none */
+   instead of conv16x3p_kernel (four phases from one dy patch): 0 (default) every launch of >= 768 workgroups, -1 none */
 void ctgan_debug_x3_s2dgrad_sf(int on);
 /* Tests / A-B: 0 = the 3x3 many -> few convs (generator output conv, data gradient of the first critic conv) on the row-ring kernel
  * instead of the one-pixel-per-lane kernel with the filter as scalar operands (csrc/fewch.hip, round 5).                          */

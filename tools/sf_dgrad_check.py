@@ -28,7 +28,7 @@ for (N, C, H, Ko) in [(192, 128, 32, 128), (128, 128, 32, 128), (320, 128, 32, 1
     m = K.empty_cl(N, C, H, H, 'cuda').normal_(); rr = K.empty_cl(N, C, H, H, 'cuda').normal_()
     out = {}
     with K.mma_dtype('f32x3'):
-        for sw, code in ((0, -1), (1, 1)):
+        for sw, code in ((0, -1), (1, 0)):
             K.lib.ctgan_debug_x3_s2dgrad_sf(code)
             a = K.conv_dgrad(gy, w, geom, N); ka = K.last_kernel()
             b = K.conv_dgrad(gy, w, geom, N, bias=bc, mask=m, resid=rr)
