@@ -164,13 +164,19 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
                     const long long i = (long long)n * per + p0 + p_l;
 #pragma unroll
                     for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane)[i] = tl[q][p_l][n_l];
-                    if constexpr (planes<MMA>() == 3) {
-                        if (pp.frag) {
-                            const long long e = (p0 + p_l) * 2;
-                            const int tap = (int)(e / pp.C), c = (int)(e - (long long)tap * pp.C);
+                }
+                if constexpr (planes<MMA>() == 3) {
+                    if (pp.frag) {
+                        // FRAG image: a lane's unit = the four pairs (8 consecutive reduction channels) of one output channel - 16 bytes, and the 32
+                        // output channels of the tile are 32 consecutive units of a fragment block: one 512-byte run per (wave half, plane) instead of
+                        // a 4-byte store per pair.  (A group of four pairs never straddles a tap: C is a multiple of 32 where the image exists.)
+                        const int n_l = threadIdx.x & 31, g4 = threadIdx.x >> 5;         // 32 output channels x 8 groups of four pairs
+                        const long long e = (p0 + g4 * 4) * 2;
+                        const int tap = (int)(e / pp.C), c = (int)(e - (long long)tap * pp.C);
 #pragma unroll
-                            for (int q = 0; q < 3; ++q)
-                                reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane)[frag_u32_index(n, tap, c, pp.R * pp.S, pp.C >> 5, q)] = tl[q][p_l][n_l];
+                        for (int q = 0; q < 3; ++q) {
+                            const u32x4 v = {tl[q][g4 * 4][n_l], tl[q][g4 * 4 + 1][n_l], tl[q][g4 * 4 + 2][n_l], tl[q][g4 * 4 + 3][n_l]};
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned*>(jb.wp + 3 * jb.plane) + frag_u32_index(n0 + n_l, tap, c, pp.R * pp.S, pp.C >> 5, q)) = v;
                         }
                     }
                 }
