@@ -852,7 +852,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int q = 0; q < NP; ++q)
+#if defined(HF_DBG) && (HF_DBG & 1)      // diagnosis build: the filter stream reads the same 6 KB again and again (L1 hits: what a free L2 stream would give)
+                fa[SET][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, (unsigned)((ks * NP + q) * 1024), 0));
+#else
                 fa[SET][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, a_soff + (unsigned)((ks * NP + q) * 1024), 0));
+#endif
         a_soff += 6144u;
     };
     // ---- patch loader (as conv16x3h_kernel)
@@ -918,6 +922,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
     auto step = [&](auto curc, auto nxtc, bool has_next) __attribute__((always_inline)) {
         constexpr int CUR = decltype(curc)::value;
         if (tp == 0) {                                     // chunk prologue (uniform): every wave is past the previous chunk's reads
+#if defined(HF_DBG) && (HF_DBG & 2)          // diagnosis build: the patch is staged for the first chunk only (results wrong by design)
+            if (c == 0)
+#endif
             store_patch();
             if (c + 1 < nch) load_patch(c + 1);            // in flight during this chunk's taps
             __syncthreads();
