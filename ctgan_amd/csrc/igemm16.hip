@@ -1069,7 +1069,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int q = 0; q < NP; ++q)
+#if defined(SF_DBG) && (SF_DBG & 1)      // diagnosis build: the filter stream re-reads one 6 KB block (results wrong by design)
+                fa[SET][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, (unsigned)((ks * NP + q) * 1024), 0));
+#else
                 fa[SET][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, a_soff + (unsigned)((ks * NP + q) * 1024), 0));
+#endif
         ++a_tap;
         const bool wrap = a_tap == RS;
         a_tap = wrap ? 0 : a_tap;
@@ -1156,10 +1160,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
                     acc[j] = Cvt<MMA>::mma(fa[CUR][ks][QW[cl]], fx[QX[cl]][j], acc[j]);
         }
         if (st + 1 < T) {
+#if defined(SF_DBG) && (SF_DBG & 2)          // diagnosis build: no split / LDS stores after the first two steps
+            if (st < 1)
+#endif
             store_x(wr);                                   // step st+1 (its readers of two steps ago passed the last barrier)
+#if defined(SF_DBG) && (SF_DBG & 4)          // diagnosis build: no pixel-operand loads after the first steps
+            if (st < 1)
+#endif
             if (st + 2 < T) load_x();
         }
+#if !(defined(SF_DBG) && (SF_DBG & 8))       // diagnosis build 8: no barrier per step
         __syncthreads();
+#endif
     };
     int st = 0;
     for (; st + 1 < T; st += 2) { step(set0{}, set1{}, S0, S1, st); step(set1{}, set0{}, S1, S0, st + 1); }
