@@ -62,6 +62,10 @@ def main():
     ap.add_argument('--ar-in-graph', action='store_true',
                     help='N > 1: capture the gradient all-reduces (RCCL) and Adam inside the step graphs - one graph per iteration as at N = 1 '
                          '(engine.AR_IN_GRAPH; default: eager all-reduce on a side stream between per-step graphs)')
+    ap.add_argument('--split-flush-ab', action='store_true',
+                    help='N > 1: also time the loop with the split flush (blocks 1-2 of the critic bucket all-reduced on the side stream under the rest of\n'
+                         'the backward).  Off by default with the RCCL backend: that engine forks collectives into the capture and has never run on more\n'
+                         'than one device - a hang there must not cost the main record; on by default with gloo (tests)')
     ap.add_argument('--feed', default='both', choices=['device', 'both'],
                     help='device: the timed loop cycles 16 device-resident batches (the headline `value`); both: also re-time the loop with the\n'
                          'real input path - tflib.cifar10.EpochFeed over synthetic uint8 images -> pinned host buffers -> H2D on a copy stream ->\n'
@@ -207,6 +211,8 @@ def main():
                       'bucket_bytes': {'critic': 4 * trainer.d_opt.theta.numel(), 'generator': 4 * trainer.g_opt.theta.numel()},
                       'critic_bucket_prefix_bytes_split_flush': 4 * trainer.d_opt.offsets[trainer._n_early] if trainer._n_early < len(trainer.d_opt.offsets) else None}
         try:
+            if not (args.split_flush_ab or (args.backend or 'nccl') == 'gloo'):
+                raise RuntimeError('not run (python bench.py --gpus N --split-flush-ab times it)')
             trainer.split_flush = True
             eng_s = GraphedTrainer(trainer, use_graphs=not args.no_graph, ar_in_graph=eng.ar_in_graph)
             ms_split = timed_loop(eng_s, k2)
