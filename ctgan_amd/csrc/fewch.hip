@@ -635,13 +635,21 @@ __global__ __launch_bounds__(NT) void fw_wgrad_mfma_kernel(const FWParams p) {
             const float* arow = tile_f + (hr * p.fst * TW + h * p.fst) * 4 + a_off;
             const int npair = p.MW >> 1;                                 // MW even (checked by the host)
             constexpr int UQ = 8;                                        // pixel pairs per batch: 8 float4 loads in flight per lane
+            // the loads of batch q0 + UQ are issued before the MFMAs of batch q0 (two register sets): a wave's load round trip no longer
+            // sits between its own MFMA bursts (round 5; one batch in flight per wave before)
+            float4 gn[UQ];
+#pragma unroll
+            for (int u = 0; u < UQ; ++u)
+                gn[u] = u < npair ? *reinterpret_cast<const float4*>(mrow + (long long)(2 * u) * p.ms_w) : make_float4(0.f, 0.f, 0.f, 0.f);
             for (int q0 = 0; q0 < npair; q0 += UQ) {
                 float4 gv[UQ];
                 float av[UQ];
 #pragma unroll
+                for (int u = 0; u < UQ; ++u) gv[u] = gn[u];
+#pragma unroll
                 for (int u = 0; u < UQ; ++u) {
-                    const int q = q0 + u;
-                    gv[u] = q < npair ? *reinterpret_cast<const float4*>(mrow + (long long)(2 * q) * p.ms_w) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int q = q0 + UQ + u;
+                    gn[u] = q < npair ? *reinterpret_cast<const float4*>(mrow + (long long)(2 * q) * p.ms_w) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < UQ; ++u) {
@@ -662,26 +670,29 @@ __global__ __launch_bounds__(NT) void fw_wgrad_mfma_kernel(const FWParams p) {
             }
         }
     }
-    // combine the four waves through LDS in a fixed order, then one wave writes the slab
-    __syncthreads();
-    float* red = smem;                                                   // [3][64 regs][64 lanes]
-    if (wave > 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) red[((wave - 1) * 64 + t * 16 + e) * 64 + lane] = acc[t][e];
-        red[3 * 64 * 64 + (wave - 1) * 64 + lane] = bsum;
-    }
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
+    // combine the four waves through LDS in a fixed order (wave 1, 2, 3 onto wave 0), one wave at a time through ONE 16 KB buffer - the
+    // three-wave buffer (49 KB) was what limited the kernel to three workgroups per CU - then wave 0 writes the slab
+    float* red = smem;                                                   // [64 regs + 1][64 lanes]
+#pragma unroll 1
     for (int w = 1; w < 4; ++w) {
+        __syncthreads();                                                 // the tile / the previous wave's values are consumed
+        if (wave == w) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] += red[((w - 1) * 64 + t * 16 + e) * 64 + lane];
-        bsum += red[3 * 64 * 64 + (w - 1) * 64 + lane];
+                for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 64 + lane] = acc[t][e];
+            red[64 * 64 + lane] = bsum;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][e] += red[(t * 16 + e) * 64 + lane];
+            bsum += red[64 * 64 + lane];
+        }
     }
+    if (wave != 0) return;
     float* out = p.slab + (long long)blockIdx.x * p.n_out;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -764,11 +775,14 @@ int tap_case(int R, int S, int few) {
     return 0;
 }
 
-int pick_band(int N, int rows, int unit) {         // rows per workgroup: >= ~512 workgroups when the batch allows it
+int pick_band(int N, int rows, int unit, int min_tasks = 512) {         // rows per workgroup: >= ~512 workgroups when the batch allows it
     int band = unit;
-    while (band * 2 <= rows && (long long)N * ((rows + band * 2 - 1) / (band * 2)) >= 512) band *= 2;
+    while (band * 2 <= rows && (long long)N * ((rows + band * 2 - 1) / (band * 2)) >= min_tasks) band *= 2;
     return band;
 }
+#ifndef FW_TASKS
+#define FW_TASKS 512      // (A/B builds) tasks / workgroups of the MFMA weight-gradient kernel
+#endif
 
 }  // namespace
 
@@ -935,7 +949,7 @@ static void fw_plan(const ctgan_conv_desc* d, int* band, int* bands, int* n_main
     const int rows = d->C <= 4 ? d->P : d->H;              // rows of the many-channel operand
     const int cm = d->C <= 4 ? d->K : d->C;
     const int unit = NT / (cm / 4);                        // one row per lane group
-    *band = pick_band(d->N, rows, unit);
+    *band = pick_band(d->N, rows, unit, FW_TASKS);
     *bands = (rows + *band - 1) / *band;
     *n_main = d->R * d->S * d->C * d->K;
     *n_out = *n_main + ((d->C <= 4 ? d->K : d->K) + 3) / 4 * 4;
@@ -1002,12 +1016,12 @@ int ctgan_fewch_wgrad2(const ctgan_conv_desc* d0, const float* x, const float* d
     int rc = 0;
     const dim3 grid(blocks), blk(NT);
     const int use_mfma = 1;
-    const size_t red_mfma = (size_t)(3 * 64 * 64 + 3 * 64) * sizeof(float);
+    const size_t red_mfma = (size_t)(64 * 64 + 64) * sizeof(float);
     const size_t smem_m = tile_b > red_mfma ? tile_b : red_mfma;
     if (use_mfma && p.CM == 128 && (p.MW & 1) == 0 && smem_m <= 150 * 1024) {
         bool done = true;
         // two workgroups per CU: the loop is a latency-bound stream (one float4 per lane per two pixels), registers are few
-        const int cap = 512;
+        const int cap = FW_TASKS;
         int blocks_m = p.total < cap ? p.total : cap;
         if ((size_t)blocks_m * p.n_out * sizeof(float) > ws_bytes) blocks_m = blocks;
         const dim3 grid(blocks_m);
