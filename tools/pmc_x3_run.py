@@ -49,10 +49,9 @@ def case(op, N, C, H, Ko, R, st, relu=False, mode='f32x3', wide_only=False):
 case('fwd', 192, 128, 32, 128, 3, 1, relu=False)      # conv16x3hf_kernel<false, 4>
 case('fwd', 192, 128, 16, 128, 3, 1, relu=True)       # conv16x3hf_kernel<true, 2>: 16x16 images on 64-pixel tiles (the critic's relu-on-load convs)
 case('fwd', 384, 128, 8, 128, 3, 1, relu=True)        # conv16x3hf_kernel<true, 1>: the 384-row shared tail forward on 32-pixel tiles
-case('dgrad', 128, 128, 32, 128, 4, 2)                # conv16x3p_kernel<2> (round 4): four-phase data gradient of the folded ConvMeanPool, 512 workgroups of eight waves
+case('dgrad', 128, 128, 32, 128, 4, 2)                # conv16x3sf_kernel<false, 2> (round 5; round 4: conv16x3p_kernel<2>): four-phase data gradient of the folded ConvMeanPool, one phase per workgroup
 case('dgrad', 128, 128, 16, 128, 4, 2)                # conv16x3p_kernel<1>: the same on an 8x8 dy grid, 32-position tiles
 case('fwd', 192, 128, 32, 128, 4, 2, relu=True)       # conv16x3sf_kernel<true, 2> (round 5): its forward at 192 rows, filter fragments from L2, 64-position tiles
-case('fwd', 192, 128, 16, 128, 4, 2, relu=True)       # conv16_kernel<3, 1, 1, 32, true, false>: the 16x16 -> 8x8 forward that stays on the slice kernel (64x64 tiles)
 # round 5: the merged backward's 8x8 data gradients (4B = 256 rows: dropout-pass rows + penalty rows), the 16x16 data gradients at 3B rows,
 # the penalty's double-backward convs that stay on the fp32 family (64 rows of 8x8), the one-pixel-per-lane many -> few kernel
 case('dgrad', 256, 128, 8, 128, 3, 1)                 # conv16x3hf_kernel<false, 1> at the merged backward's row count (overrides the 192-row entry)
