@@ -100,12 +100,20 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, unsigned short* __r
         }
     }
 }
-struct PackPhases { int T[2], U[2], r0[2], s0[2]; int nph, step, R, S, C, K; long long off[4]; int frag; int pad; };
+struct PackPhases { int T[2], U[2], r0[2], s0[2]; int nph, step, R, S, C, K; int frag; int pad; };
+// 16-bit elements of the packed data-gradient image before phase `ph` (phase_off of the host side; computed here so that a job is 88 bytes
+// and 32 of them fit the kernel arguments: one pack launch per weight version instead of two on the headline's critic)
+__host__ __device__ inline long long pack_phase_off(const PackPhases& pp, int ph) {
+    long long o = 0;
+    for (int q = 0; q < ph; ++q) o += (long long)pp.C * pp.T[q >> 1] * pp.U[q & 1] * pp.K;
+    return o;
+}
 template <int MMA>
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, const PackPhases pp, long long plane) {
     const int ph = blockIdx.y, a = ph >> 1, b = ph & 1;
     const int T = pp.T[a], U = pp.U[b];
     const long long kph = (long long)T * U * pp.K, per = kph / 2, total = per * pp.C;
+    const long long ph_off = pack_phase_off(pp, ph);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i / per);
         const long long e = (i - (long long)n * per) * 2;                      // (t*U + u)*K + k, k even
@@ -115,7 +123,7 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* _
         unsigned o[planes<MMA>()];
         split_pk<MMA>(src[0], src[1], o);
 #pragma unroll
-        for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane + pp.off[ph])[i] = o[q];
+        for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(wp + q * plane + ph_off)[i] = o[q];
         if constexpr (planes<MMA>() == 3) {
             if (pp.frag) {                                   // (the reduction channel is k, the output channel n = c; stride 2: step = 4 * phase + tap)
 #pragma unroll
@@ -128,8 +136,9 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, unsigned short* _
 // all packed images of one weight version in ONE launch (a pack per filter and operator is ~5 us of launch floor each, 57 per
 // iteration on the headline): blockIdx.y = job, grid-stride over the job's pairs; a data-gradient job walks its phases in turn
 struct PackJob { const float* w; unsigned short* wp; PackPhases pp; long long plane; int op; int pad; };
-#define CTGAN_PACK_BATCH 20
+#define CTGAN_PACK_BATCH 32
 struct PackJobs { PackJob j[CTGAN_PACK_BATCH]; };
+static_assert(sizeof(PackJobs) <= 3584, "kernel arguments");
 template <int MMA>
 __global__ void pack_batch_kernel(const PackJobs jobs) {
     const PackJob& jb = jobs.j[blockIdx.y];
@@ -204,6 +213,7 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
         const int a = ph >> 1, b = ph & 1;
         const int T = pp.T[a], U = pp.U[b];
         const long long kph = (long long)T * U * pp.K, per = kph / 2, total = per * pp.C;
+        const long long ph_off = pack_phase_off(pp, ph);
         for (long long i = t0; i < total; i += stride) {
             const int n = (int)(i / per);
             const long long e = (i - (long long)n * per) * 2;
@@ -213,7 +223,7 @@ __global__ void pack_batch_kernel(const PackJobs jobs) {
             unsigned o[planes<MMA>()];
             split_pk<MMA>(src[0], src[1], o);
 #pragma unroll
-            for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane + pp.off[ph])[i] = o[q];
+            for (int q = 0; q < planes<MMA>(); ++q) reinterpret_cast<unsigned*>(jb.wp + q * jb.plane + ph_off)[i] = o[q];
             if constexpr (planes<MMA>() == 3) {
                 if (pp.frag) {
 #pragma unroll
@@ -2149,7 +2159,6 @@ int ctgan_conv2d16_pack_filter(const ctgan_conv_desc* d, int op, int mma, const 
         pp.frag = frag_image(d, op, mma) ? 1 : 0;
         long long most = 0;
         for (int ph = 0; ph < g.nph; ++ph) {
-            pp.off[ph] = phase_off(g, d, ph);
             const long long n = (long long)d->C * g.T[ph >> 1] * g.U[ph & 1] * d->K / 2;
             if (n > most) most = n;
         }
@@ -2189,7 +2198,6 @@ int ctgan_conv2d16_pack_batch(const ctgan_conv_desc* descs, const int32_t* ops, 
                 pp.nph = g.nph; pp.step = g.step;
                 work = 0;
                 for (int ph = 0; ph < g.nph; ++ph) {
-                    pp.off[ph] = phase_off(g, d, ph);
                     const long long m = (long long)d->C * g.T[ph >> 1] * g.U[ph & 1] * d->K / 2;
                     if (m > work) work = m;
                 }
