@@ -60,7 +60,9 @@ class EpilogueExt(ctypes.Structure):
     _fields_ = [('drop_keep', ctypes.c_float), ('drop_seed', ctypes.c_uint64), ('drop_stream_id', ctypes.c_uint64),
                 ('drop_ctr', ctypes.c_void_p), ('n_ranges', c_int32), ('range_end', c_int32 * 3), ('range_keep', ctypes.c_float * 3),
                 ('range_stream_id', ctypes.c_uint64 * 3), ('out_mask', ctypes.c_void_p),
-                ('act', c_int32), ('act_alpha', ctypes.c_float), ('act_ref', ctypes.c_void_p)]
+                ('act', c_int32), ('act_alpha', ctypes.c_float), ('act_ref', ctypes.c_void_p),
+                ('in_bn_mean', ctypes.c_void_p), ('in_bn_rstd', ctypes.c_void_p), ('in_bn_scale', ctypes.c_void_p), ('in_bn_offset', ctypes.c_void_p),
+                ('in_bn_groups', c_int32), ('out_tanh', c_int32)]
 
 
 I64x4 = c_int64 * 4

@@ -38,6 +38,8 @@ void ctgan_set_last_symbol(const char* fmt, ...);
 bool ctgan_fewch_handles(const ctgan_conv_desc* d);
 int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* mask, const float* resid,
                     float* y, int relu, int relu_in, hipStream_t st);
+int ctgan_fewch_fwd_bn(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu_in, const float* mean,
+                       const float* rstd, const float* scale, const float* offset, int groups, int tanh_out, hipStream_t st);
 int ctgan_fewch_dgrad(const ctgan_conv_desc* d, const float* dy, const float* w, const float* bias, float* dx, hipStream_t st);
 size_t ctgan_fewch_wgrad_workspace(const ctgan_conv_desc* d);
 int ctgan_fewch_wgrad(const ctgan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,

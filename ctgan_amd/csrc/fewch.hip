@@ -136,6 +136,9 @@ struct M2FParams {
     const float* bias;
     int N, pad_t, pad_l, band, total, relu_in;                          // total = N * bands workgroup tasks
     int dbg;                                                            // perf diagnosis (env CTGAN_M2F_DBG): 1 no row loads, 2 no compute
+    // m2f_px_kernel only (PXParams): batch norm of the input while it is staged, tanh of the result
+    const float* bn_mean = nullptr; const float* bn_rstd = nullptr; const float* bn_scale = nullptr; const float* bn_offset = nullptr;
+    int bn_per = 1, tanh_out = 0;
 };
 
 template <int R, int S, int JS>
@@ -349,6 +352,10 @@ struct PXParams {
     const float* w; long long w_off, ws_r, ws_s, ws_c, ws_j;
     const float* bias;
     int relu_in, tiles;
+    // round 5: training-mode batch norm of the INPUT applied while it is staged (the generator's output stage under no_grad:
+    // tanh(conv(relu(bn(h)))), TF/CT_gan_cifar_resnet.py:164-166) - x' = (x - mean[g]) * rstd[g] * scale + offset per channel, sample n in group
+    // n / bn_per; the zero padding stays zero.  bn_mean == NULL: off.  tanh_out: tanh of the result in the epilogue.
+    const float* bn_mean; const float* bn_rstd; const float* bn_scale; const float* bn_offset; int bn_per, tanh_out;
 };
 constexpr int PX_TH = 8, PX_W = 32, PX_CC = 32, PX_PS = 36, PX_NT = 256;
 constexpr int PX_PIX = (PX_TH + 2) * (PX_W + 2);            // 340 staged pixels per chunk
@@ -368,6 +375,13 @@ __global__ __launch_bounds__(PX_NT) void m2f_px_kernel(const PXParams p) {
     const float* img = p.x + (long long)n * p.xs_n;
     float4 pf[PX_PF], wpf = make_float4(0.f, 0.f, 0.f, 0.f);
     auto fetch = [&](int chunk) {
+        // (a thread's channel quad is the same for all its items: PX_NT % 8 == 0 - one set of BN coefficients per chunk)
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, ga = mu, be = mu;
+        if (p.bn_mean) {
+            const int c = chunk * PX_CC + (tid & 7) * 4, g = n / p.bn_per;
+            mu = *reinterpret_cast<const float4*>(p.bn_mean + (long long)g * p.CM + c); rs = *reinterpret_cast<const float4*>(p.bn_rstd + (long long)g * p.CM + c);
+            ga = *reinterpret_cast<const float4*>(p.bn_scale + c); be = *reinterpret_cast<const float4*>(p.bn_offset + c);
+        }
 #pragma unroll
         for (int k = 0; k < PX_PF; ++k) {
             const int i = tid + k * PX_NT;
@@ -375,8 +389,13 @@ __global__ __launch_bounds__(PX_NT) void m2f_px_kernel(const PXParams p) {
             const int tr = pix / (PX_W + 2), tw = pix - tr * (PX_W + 2);
             const int ih = p0 - 1 + tr, iw = tw - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < PX_F4 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)PX_W)
+            if (i < PX_F4 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)PX_W) {
                 v = *reinterpret_cast<const float4*>(img + (long long)ih * p.xs_h + (long long)iw * p.xs_w + chunk * PX_CC + c4 * 4);
+                if (p.bn_mean) {      // bn_apply_vec_kernel's operation order: ((x - mean) * rstd) * scale + offset
+                    v.x = (v.x - mu.x) * rs.x * ga.x + be.x; v.y = (v.y - mu.y) * rs.y * ga.y + be.y;
+                    v.z = (v.z - mu.z) * rs.z * ga.z + be.z; v.w = (v.w - mu.w) * rs.w * ga.w + be.w;
+                }
+            }
             pf[k] = v;
         }
         if (tid < WF4) {                                               // wl[(t * 8 + c4) * JS + j] = w(t, channels c .. c+3, j)
@@ -428,7 +447,8 @@ __global__ __launch_bounds__(PX_NT) void m2f_px_kernel(const PXParams p) {
 #pragma unroll
         for (int j = 0; j < JS; ++j) {
             const f32x2 a = acc[j][0] + acc[j][1];
-            p.y[off + j * p.ys_c] = (a.x + a.y) + (p.bias ? p.bias[j] : 0.f);
+            const float r = (a.x + a.y) + (p.bias ? p.bias[j] : 0.f);
+            p.y[off + j * p.ys_c] = p.tanh_out ? tanhf(r) : r;
         }
     }
 }
@@ -846,6 +866,7 @@ static int launch_m2f_px(const M2FParams& m, hipStream_t st) {
     p.y = m.y; p.ys_n = m.ys_n; p.ys_c = m.ys_c; p.ys_p = m.ys_p; p.ys_q = m.ys_q;
     p.w = m.w; p.w_off = m.w_off; p.ws_r = m.ws_r; p.ws_s = m.ws_s; p.ws_c = m.ws_c; p.ws_j = m.ws_j;
     p.bias = m.bias; p.relu_in = m.relu_in;
+    p.bn_mean = m.bn_mean; p.bn_rstd = m.bn_rstd; p.bn_scale = m.bn_scale; p.bn_offset = m.bn_offset; p.bn_per = m.bn_per; p.tanh_out = m.tanh_out;
     p.tiles = (m.H + PX_TH - 1) / PX_TH;
     const size_t smem = (size_t)PX_PIX * PX_PS * sizeof(float) + (size_t)9 * (PX_CC / 4) * 3 * sizeof(float4);
     int rc = set_smem(&m2f_px_kernel<3>, smem);
@@ -907,6 +928,26 @@ int ctgan_fewch_fwd(const ctgan_conv_desc* d, const float* x, const float* w, co
     p.total = d->N * ((d->P + p.band - 1) / p.band);
     ctgan_set_last_kernel("fewch_m2f");
     const int rc = launch_m2f(p, d->R, d->S, d->K, st);
+    return rc ? rc : 1;
+}
+
+// forward of a many -> few conv with training-mode batch norm (+ ReLU) of the input applied on load and an optional tanh of the result:
+// only the one-pixel-per-lane kernel has that staging.  Returns 1 when handled, 0 when not (the caller reports UNSUPPORTED), < 0 on error.
+int ctgan_fewch_fwd_bn(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu_in, const float* mean,
+                       const float* rstd, const float* scale, const float* offset, int groups, int tanh_out, hipStream_t st) {
+    if (!ctgan_fewch_handles(d) || d->C <= 4 || groups <= 0 || d->N % groups) return 0;
+    if (d->xs[1] != 1 || (d->xs[0] | d->xs[2] | d->xs[3]) % 4 || !al16(x) || !al16(mean) || !al16(rstd) || !al16(scale) || !al16(offset)) return 0;
+    M2FParams p; p.dbg = 0;
+    p.x = x; p.xs_n = d->xs[0]; p.xs_h = d->xs[2]; p.xs_w = d->xs[3]; p.H = d->H; p.W = d->W; p.CM = d->C;
+    p.y = y; p.ys_n = d->ys[0]; p.ys_c = d->ys[1]; p.ys_p = d->ys[2]; p.ys_q = d->ys[3]; p.P = d->P; p.Q = d->Q;
+    p.w = w; p.w_off = 0; p.ws_r = (long long)d->S * d->C * d->K; p.ws_s = (long long)d->C * d->K; p.ws_c = d->K; p.ws_j = 1;
+    p.bias = bias;
+    p.N = d->N; p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.relu_in = relu_in;
+    p.band = 2; p.total = d->N * ((d->P + 1) / 2);
+    p.bn_mean = mean; p.bn_rstd = rstd; p.bn_scale = scale; p.bn_offset = offset; p.bn_per = d->N / groups; p.tanh_out = tanh_out;
+    if (!m2f_px_ok(p, d->R, d->S, d->K)) return 0;
+    ctgan_set_last_kernel("fewch_m2f(bn)");
+    const int rc = launch_m2f_px(p, st);
     return rc ? rc : 1;
 }
 

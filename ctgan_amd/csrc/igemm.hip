@@ -1698,6 +1698,16 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
     if (!x || !w || !y) return ctgan_fail(CTGAN_E_BADARG, "conv2d_fwd: null pointer");
     if (ext && ext->act) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_fwd_ex: the fused LeakyReLU + dropout epilogue exists in the 16-bit slice kernels only");
     const float* out_mask = ext ? ext->out_mask : nullptr;
+    if (ext && (ext->in_bn_mean || ext->out_tanh)) {
+        // batch norm of the input on load (+ tanh of the result): the one-pixel-per-lane many -> few kernel only
+        if (!ext->in_bn_mean || !ext->in_bn_rstd || !ext->in_bn_scale || !ext->in_bn_offset || resid || out_mask || want_drop ||
+            (flags & (CTGAN_EPI_RELU | CTGAN_RESID_UP)))
+            return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_fwd_ex: input batch norm / tanh epilogue with other epilogue operands");
+        rc = ctgan_fewch_fwd_bn(d, x, w, bias, y, (flags & CTGAN_IN_RELU) ? 1 : 0, ext->in_bn_mean, ext->in_bn_rstd, ext->in_bn_scale, ext->in_bn_offset,
+                                ext->in_bn_groups, ext->out_tanh, static_cast<hipStream_t>(stream));
+        if (rc == 0) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_fwd_ex: input batch norm on load exists in the many -> few pixel kernel only (3x3, <= 4 output channels, 32-pixel rows)");
+        return rc < 0 ? rc : CTGAN_OK;
+    }
     if (ctgan_is_small_linear(d) && !resid && !out_mask && !(flags & CTGAN_IN_RELU) && !g_force_generic && !want_drop) {
         ctgan_set_last_kernel("linear_small_fwd");
         return ctgan_small_linear_fwd(d, x, w, bias, y, (flags & CTGAN_EPI_RELU) ? 1 : 0, static_cast<hipStream_t>(stream));

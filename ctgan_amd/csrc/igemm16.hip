@@ -2256,6 +2256,7 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
                              float* y, int flags, const ctgan_epilogue_ext* ext, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     if (!d || !x || !wp || !y || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_fwd: bad argument");
     if (!shape_ok_fwd(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: shape outside the 16-bit family");
+    if (ext && (ext->in_bn_mean || ext->out_tanh)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: input batch norm / tanh epilogue exist in the many -> few pixel kernel only");
     const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
     const long long w_plane = (long long)d->R * d->S * d->C * d->K * 2;
     if (x_extent * 4 >= (1LL << 32) || w_plane * mma_planes(mma) >= (1LL << 32))

@@ -204,10 +204,35 @@ def Generator(n_samples, labels, noise=None, groups=1, rng=None):
     out = ResidualBlock('Generator.1', G, G, 3, out, resample='up', labels=labels, groups=groups)
     out = ResidualBlock('Generator.2', G, G, 3, out, resample='up', labels=labels, groups=groups)
     out = ResidualBlock('Generator.3', G, G, 3, out, resample='up', labels=labels, groups=groups)
+    fused = _fused_output_stage(out, G, groups)
+    if fused is not None:
+        return fused.reshape(-1, cfg.OUTPUT_DIM)
     out = Normalize('Generator.OutputN', out, groups=groups, relu=True)
     out = _conv2d.Conv2D('Generator.Output', G, 3, 3, out, he_init=False, out_nchw=True)
     out = F.tanh(out)
     return out.reshape(-1, cfg.OUTPUT_DIM)
+
+
+# A/B switch: under no_grad (the fake batches of the critic steps) the output stage tanh(Conv2D(relu(Batchnorm(h)))) (:164-166) as the
+# moments + ONE conv launch - the batch norm applied while the many -> few kernel stages its input, tanh in its epilogue
+OUTPUT_STAGE_FUSION = _os.environ.get('CTGAN_OUTPUT_STAGE_FUSION', '1') != '0'
+
+
+def _fused_output_stage(h, G, groups):
+    if not OUTPUT_STAGE_FUSION or torch.is_grad_enabled() or not cfg.NORMALIZATION_G or not h.is_cuda:
+        return None
+    names = ('Generator.OutputN.scale', 'Generator.OutputN.offset', 'Generator.Output.Filters', 'Generator.Output.Biases')
+    if any(nm not in lib._params for nm in names):
+        return None                   # first call: the operators create their parameters
+    scale, offset, w, b = (lib.param(nm) for nm in names)
+    g = K.ConvGeom(G, h.shape[2], h.shape[3], 3, 3, 3, 1)
+    try:
+        mean, rstd = K.bn_stats(h, groups)
+        N = h.shape[0]
+        return K.conv_fwd_bn_in(h, w, b, g, mean, rstd, scale, offset, groups, relu_in=True, tanh=True,
+                                out_strides=(3 * g.P * g.Q, g.P * g.Q, g.Q, 1))
+    except NotImplementedError:
+        return None
 
 
 def DiscriminatorTrunk(inputs):

@@ -1319,6 +1319,41 @@ def interpolate(real, fake, alpha):
 
 
 # ------------------------------------------------------------------------------- batch norm
+def bn_stats(x4, groups, eps=1e-5):
+    """Training-mode moments of a channels-last [N,C,H,W] tensor over (n,h,w) per statistic group -> mean[groups,C], rstd[groups,C]
+    (the first two launches of bn_fwd)."""
+    _need_dev(x4)
+    N, C, H, W = x4.shape
+    assert x4.permute(0, 2, 3, 1).is_contiguous()
+    mean = torch.empty((groups, C), dtype=torch.float32, device=x4.device)
+    rstd = torch.empty((groups, C), dtype=torch.float32, device=x4.device)
+    nb = lib.ctgan_bn_workspace_bytes(N, H * W, C, groups, 1)
+    ws = workspace(nb, x4.device)
+    check(lib.ctgan_bn_stats(_ptr(x4), N, H * W, C, groups, eps, _ptr(mean), _ptr(rstd), _ptr(ws), ws.numel(), _stream()), 'bn_stats')
+    return mean, rstd
+
+
+def conv_fwd_bn_in(x, w, bias, g, mean, rstd, scale, offset, groups, relu_in=True, tanh=False, out_strides=None):
+    """conv(relu?(bn(x))) [+ bias] [tanh] with the batch norm applied while the input is staged (ctgan_epilogue_ext.in_bn_*): the many -> few
+    pixel kernel only (3x3, <= 4 output channels, 32-pixel rows) - NotImplementedError elsewhere.  mean / rstd [groups, C] from bn_stats,
+    scale / offset [C] (no labels)."""
+    from ._lib import EpilogueExt
+    _need_dev(x, w, bias, mean, rstd, scale, offset)
+    N = x.shape[0]
+    assert tuple(x.shape) == (N, g.C, g.H, g.W) and tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous() and not g.x_up
+    assert tuple(mean.shape) == (groups, g.C) and tuple(rstd.shape) == (groups, g.C) and scale.numel() == g.C and offset.numel() == g.C
+    if out_strides is None:
+        y = empty_cl(N, g.K, g.P, g.Q, x.device)
+    else:
+        y = torch.empty_strided((N, g.K, g.P, g.Q), out_strides, dtype=torch.float32, device=x.device)
+    d = g.desc(N, x.stride(), y.stride())
+    e = EpilogueExt(0.0, 0, 0, None)
+    e.in_bn_mean, e.in_bn_rstd, e.in_bn_scale, e.in_bn_offset = mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), offset.data_ptr()
+    e.in_bn_groups, e.out_tanh = int(groups), 1 if tanh else 0
+    _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), None, _ptr(y), 2 if relu_in else 0, ctypes.byref(e), _stream()), 'conv2d_fwd'))
+    return y
+
+
 def bn_fwd(x, scale, offset, labels, groups, relu, eps=1e-5):
     """x channels-last [N,C,H,W] (or [N,C]); returns y, mean[groups,C], rstd[groups,C]."""
     _need_dev(x, scale, offset, labels)

@@ -127,6 +127,17 @@ typedef struct ctgan_epilogue_ext {
     int32_t act;
     float act_alpha;
     const float* act_ref;
+    /* ctgan_conv2d_fwd_ex, many -> few convs on the one-pixel-per-lane kernel only (3x3, <= 4 output channels, 32-pixel rows; the generator's
+     * output stage tanh(Conv2D(relu(Batchnorm(h)))), TF/CT_gan_cifar_resnet.py:164-166, evaluated without a tape): training-mode batch norm of
+     * the INPUT applied while it is staged - x' = (x - in_bn_mean[g][c]) * in_bn_rstd[g][c] * in_bn_scale[c] + in_bn_offset[c], g = sample /
+     * (N / in_bn_groups), then CTGAN_IN_RELU if set; the SAME zero padding stays zero - and out_tanh: tanh of the result.  The arithmetic of
+     * ctgan_bn_apply followed by the conv and ctgan_tanh_fwd.  in_bn_mean == NULL and out_tanh == 0: off.                                   */
+    const float* in_bn_mean;
+    const float* in_bn_rstd;
+    const float* in_bn_scale;
+    const float* in_bn_offset;
+    int32_t in_bn_groups;
+    int32_t out_tanh;
 } ctgan_epilogue_ext;
 int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                         float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream);

@@ -438,3 +438,39 @@ def test_data_gradient_with_per_range_dropout_masks_equals_one_dropout_per_range
         assert 0.4 < z[:192].mean().item() < 0.6 and 0.1 < z[192:].mean().item() < 0.3
     finally:
         K.X3_HYBRID = old
+
+
+def test_generator_output_stage_with_batchnorm_on_load_equals_the_separate_launches():
+    """Under no_grad the output stage tanh(Conv2D(relu(Batchnorm(h)))) of TF/CT_gan_cifar_resnet.py:164-166 runs as the moments + ONE launch of the
+    many -> few pixel kernel (batch norm while the input is staged, tanh in the epilogue; ctgan_epilogue_ext.in_bn_*): the same arithmetic as
+    ctgan_bn_apply + the conv + ctgan_tanh_fwd - compared bit for bit (and to 1e-6 should the compiler contract the two kernels differently),
+    for one tower and for the five towers of an iteration's fake batches."""
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    lib.delete_all_params(); lib.set_device(None); lib.set_seed(3)
+    R.configure(DIM_G=128, DIM_D=128, BATCH_SIZE=64)
+    try:
+        dev = lib._dev()
+        g = torch.Generator().manual_seed(4)
+        for n, groups in ((64, 1), (320, 5)):
+            z = torch.randn(n, 128, generator=g).to(dev)
+            labels = torch.randint(0, 10, (n,), generator=g, dtype=torch.int32).to(dev)
+            with torch.no_grad():
+                R.Generator(n, labels, noise=z, groups=groups)                 # creates the parameters
+                with torch.no_grad():
+                    for nm in ('Generator.OutputN.scale', 'Generator.OutputN.offset', 'Generator.Output.Biases'):
+                        p = lib.param(nm); p.add_((0.2 * torch.randn(p.shape, generator=g)).to(dev))
+                lib.bump_epoch()
+                assert R.OUTPUT_STAGE_FUSION
+                a = R.Generator(n, labels, noise=z, groups=groups); ka = K.last_kernel()
+                R.OUTPUT_STAGE_FUSION = False
+                try:
+                    b = R.Generator(n, labels, noise=z, groups=groups)
+                finally:
+                    R.OUTPUT_STAGE_FUSION = True
+            assert ka == 'fewch_m2f(bn)', ka
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-6
+            assert torch.equal(a, b), float((a - b).abs().max())
+    finally:
+        R.configure(); lib.delete_all_params()
