@@ -62,7 +62,7 @@ class EpilogueExt(ctypes.Structure):
                 ('range_stream_id', ctypes.c_uint64 * 3), ('out_mask', ctypes.c_void_p),
                 ('act', c_int32), ('act_alpha', ctypes.c_float), ('act_ref', ctypes.c_void_p),
                 ('in_bn_mean', ctypes.c_void_p), ('in_bn_rstd', ctypes.c_void_p), ('in_bn_scale', ctypes.c_void_p), ('in_bn_offset', ctypes.c_void_p),
-                ('in_bn_groups', c_int32), ('out_tanh', c_int32)]
+                ('in_bn_groups', c_int32), ('out_tanh', c_int32), ('in_bn_labels', ctypes.c_void_p)]
 
 
 I64x4 = c_int64 * 4

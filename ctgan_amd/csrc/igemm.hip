@@ -1700,7 +1700,7 @@ int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w
     const float* out_mask = ext ? ext->out_mask : nullptr;
     if (ext && (ext->in_bn_mean || ext->out_tanh)) {
         // batch norm of the input on load (+ tanh of the result): the one-pixel-per-lane many -> few kernel only
-        if (!ext->in_bn_mean || !ext->in_bn_rstd || !ext->in_bn_scale || !ext->in_bn_offset || resid || out_mask || want_drop ||
+        if (!ext->in_bn_mean || !ext->in_bn_rstd || !ext->in_bn_scale || !ext->in_bn_offset || ext->in_bn_labels || resid || out_mask || want_drop ||
             (flags & (CTGAN_EPI_RELU | CTGAN_RESID_UP)))
             return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d_fwd_ex: input batch norm / tanh epilogue with other epilogue operands");
         rc = ctgan_fewch_fwd_bn(d, x, w, bias, y, (flags & CTGAN_IN_RELU) ? 1 : 0, ext->in_bn_mean, ext->in_bn_rstd, ext->in_bn_scale, ext->in_bn_offset,

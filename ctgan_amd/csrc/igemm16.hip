@@ -260,6 +260,8 @@ struct P16 {
     // stream from drop_keep / drop_sid or the sample range of the row (drop_nend: first sample past the range; any boundary, the choice
     // is per lane), draws indexed as above.  D is dense channels-last.
     int act; float act_alpha; const float* act_ref; int drop_nend[CTGAN_DROP_RANGES];
+    // conv16x3hf_kernel<.., BN = true> only: batch norm of the pixel operand on load (ctgan_epilogue_ext::in_bn_*); bn_per = samples per statistic group
+    const float* bn_mean; const float* bn_rstd; const float* bn_scale; const float* bn_offset; const int* bn_labels; int bn_per;
     unsigned x_bytes, w_bytes;      // w_bytes covers every plane
     const unsigned short* Wf;       // FRAG image of the filter (fragment order, see frag_u32_index) or null; wf_bytes its size
     unsigned wf_bytes;
@@ -827,7 +829,10 @@ __global__ __launch_bounds__(256) void conv16x3h_kernel(const P16 p, const Patch
 // TN = 32-pixel sub-tiles per workgroup tile (4: 128 pixels; 2 / 1: the 64- / 32-pixel tiles of launches whose 128-pixel tiles
 // could not fill the chip - the 16x16 / 8x8 layers at 64-192 rows; the filter stream per workgroup is the same, so they trade L2
 // bytes per MFMA for workgroups).
-template <bool RELU_IN, int TN>
+// BN (round 5): training-mode batch norm of the INPUT applied while the patch is staged - x' = (x - mean[g][c]) * rstd[g][c] * scale[lab][c] +
+// offset[lab][c] for the pixels inside the image (the SAME zero padding stays zero), then RELU_IN: the generator's Conv2 layers under no_grad
+// (P16::bn_*; tiles inside one image: the coefficients of a thread's channel quad are four float4 per chunk).
+template <bool RELU_IN, int TN, bool BN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3 : 2))) void conv16x3hf_kernel(const P16 p, const PatchGeom pg) {
     // (MAXIT = float4 patch items per thread the registers hold: conv16x3hf_maxit on the host side)
     constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, NT = 256, MAXIT = TN == 4 ? 8 : (TN == 2 ? 6 : 4), BMP = TN * 32;
@@ -890,12 +895,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
             if (it < pg.n_it)
                 rp[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, p_voff[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : p_voff[it] + chunk * (BK * 4), 0, 0));
     };
-    auto store_patch = [&]() __attribute__((always_inline)) {
+    auto store_patch = [&](int chunk) __attribute__((always_inline)) {
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, ga = mu, be = mu;
+        if constexpr (BN) {                                // (a thread's channel quad is the same for all its items: NT % 8 == 0)
+            const int cc = chunk * BK + (tid & 7) * 4, gq = img / p.bn_per, lab = p.bn_labels ? p.bn_labels[img] : 0;
+            mu = *reinterpret_cast<const float4*>(p.bn_mean + (long long)gq * p.C + cc); rs = *reinterpret_cast<const float4*>(p.bn_rstd + (long long)gq * p.C + cc);
+            ga = *reinterpret_cast<const float4*>(p.bn_scale + (long long)lab * p.C + cc); be = *reinterpret_cast<const float4*>(p.bn_offset + (long long)lab * p.C + cc);
+        }
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int item = it * NT + tid, px = item >> 3;
             if (it < pg.n_it && px < pg.NPX) {
                 float4 v = rp[it];
+                if constexpr (BN) {
+                    if (p_voff[it] != 0xFFFFFFFFu) {      // bn_apply_vec_kernel's operation order: ((x - mean) * rstd) * scale + offset
+                        v.x = (v.x - mu.x) * rs.x * ga.x + be.x; v.y = (v.y - mu.y) * rs.y * ga.y + be.y;
+                        v.z = (v.z - mu.z) * rs.z * ga.z + be.z; v.w = (v.w - mu.w) * rs.w * ga.w + be.w;
+                    }
+                }
                 if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 unsigned o0[NP], o1[NP];
                 split_pk<MMA>(v.x, v.y, o0);
@@ -935,7 +952,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
 #if defined(HF_DBG) && (HF_DBG & 2)          // diagnosis build: the patch is staged for the first chunk only (results wrong by design)
             if (c == 0)
 #endif
-            store_patch();
+            store_patch(c);
             if (c + 1 < nch) load_patch(c + 1);            // in flight during this chunk's taps
             __syncthreads();
             tap_off = 0; s_cnt = 0;
@@ -1765,13 +1782,13 @@ int halo_version() {
 }
 bool conv16x3hf_usable(const P16& p) { return halo_version() != 1 && p.Wf != nullptr && conv16x3hf_tile(p) > 0; }
 
-template <bool RELU_IN, int TN>
+template <bool RELU_IN, int TN, bool BN = false>
 int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
     const size_t epi = (size_t)4 * 32 * 36 * 4, stage = (size_t)3 * pg.NPX * 40 * 2;
     const size_t lds = stage > epi ? stage : epi;
     static size_t have = 0;
     if (have < lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv16x3hf_kernel<RELU_IN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv16x3hf_kernel<RELU_IN, TN, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3hf: cannot reserve %zu B of LDS", lds);
         have = lds;
     }
@@ -1779,9 +1796,10 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
     q.ph_tiles_m = p.M / (TN * 32);
     q.dbg = dbg16();
     q.ksplit = 1; q.slab = nullptr;
-    hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
-    ctgan_set_last_kernel(TN == 4 ? "conv16x3hf<128x128,k32>" : (TN == 2 ? "conv16x3hf<64x128,k32>" : "conv16x3hf<32x128,k32>"));
-    ctgan_set_last_symbol("conv16x3hf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
+    hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN, BN>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
+    ctgan_set_last_kernel(BN ? (TN == 4 ? "conv16x3hf<128x128,k32,bn>" : (TN == 2 ? "conv16x3hf<64x128,k32,bn>" : "conv16x3hf<32x128,k32,bn>"))
+                             : (TN == 4 ? "conv16x3hf<128x128,k32>" : (TN == 2 ? "conv16x3hf<64x128,k32>" : "conv16x3hf<32x128,k32>")));
+    ctgan_set_last_symbol(BN ? "conv16x3hf_kernel<%s, %d, true>" : "conv16x3hf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
     return ctgan_check_launch("conv16x3hf");
 }
 
@@ -1858,6 +1876,15 @@ int launch_conv16x3sf(const P16& p, int bmp, hipStream_t st) {
 int launch_conv16x3h(const P16& p, hipStream_t st) {
     // whole small images per 128-pixel tile (8x8): the LDS-staged kernel is the faster one when it applies
     const bool prefer_v1 = !g_halo_version_override && x3_8x8_mode() == 0 && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
+    if (p.bn_mean) {                  // batch norm of the input on load: the fragment-streaming kernel, tiles inside one image, ReLU behind the norm
+        PatchGeom pg;
+        const int bmp = conv16x3hf_usable(p) ? conv16x3hf_tile(p) : 0;
+        if (!bmp || !conv16x3h_ok(p, &pg, bmp) || pg.IMGS != 1 || !p.relu_in)
+            return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv16x3hf: input batch norm needs the fragment-streaming halo kernel, tiles inside one image and relu_in");
+        if (bmp == 128) return launch_conv16x3hf_t<true, 4, true>(p, pg, st);
+        if (bmp == 64) return launch_conv16x3hf_t<true, 2, true>(p, pg, st);
+        return launch_conv16x3hf_t<true, 1, true>(p, pg, st);
+    }
     if (conv16x3hf_usable(p) && !prefer_v1) {
         const int bmp = conv16x3hf_tile(p);
         PatchGeom pg;
@@ -2256,7 +2283,7 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
                              float* y, int flags, const ctgan_epilogue_ext* ext, void* ws, size_t ws_bytes, ctgan_stream_t stream) {
     if (!d || !x || !wp || !y || !mma_ok(mma)) return ctgan_fail(CTGAN_E_BADARG, "conv2d16_fwd: bad argument");
     if (!shape_ok_fwd(d)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd: shape outside the 16-bit family");
-    if (ext && (ext->in_bn_mean || ext->out_tanh)) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: input batch norm / tanh epilogue exist in the many -> few pixel kernel only");
+    if (ext && ext->out_tanh) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: the tanh epilogue exists in the many -> few pixel kernel only");
     const long long x_extent = (long long)(d->N - 1) * d->xs[0] + (long long)(d->H - 1) * d->xs[2] + (long long)(d->W - 1) * d->xs[3] + d->C;
     const long long w_plane = (long long)d->R * d->S * d->C * d->K * 2;
     if (x_extent * 4 >= (1LL << 32) || w_plane * mma_planes(mma) >= (1LL << 32))
@@ -2276,6 +2303,16 @@ static int conv2d16_fwd_impl(const ctgan_conv_desc* d, int mma, const float* x, 
     p.ph_T[0] = d->R; p.ph_U[0] = d->S; p.ph_pad_t[0] = d->pad_t; p.ph_pad_l[0] = d->pad_l;
     p.ph_T[1] = d->R; p.ph_U[1] = d->S; p.ph_pad_t[1] = d->pad_t; p.ph_pad_l[1] = d->pad_l;
     hipStream_t st = (hipStream_t)stream;
+    if (ext && ext->in_bn_mean) {                            // batch norm of the input while the halo patch is staged (split mode, stride 1)
+        if (mma != CTGAN_MMA_F32X3 || d->stride != 1 || !ext->in_bn_rstd || !ext->in_bn_scale || !ext->in_bn_offset || ext->in_bn_groups <= 0 ||
+            d->N % ext->in_bn_groups || ext->act || ext->out_mask || ext->n_ranges > 0 || (ext->drop_keep > 0.f && ext->drop_keep < 1.f) ||
+            ((reinterpret_cast<uintptr_t>(ext->in_bn_mean) | reinterpret_cast<uintptr_t>(ext->in_bn_rstd) | reinterpret_cast<uintptr_t>(ext->in_bn_scale) |
+              reinterpret_cast<uintptr_t>(ext->in_bn_offset)) & 15))
+            return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: input batch norm on load: split mode, stride 1, no other epilogue extension");
+        p.bn_mean = ext->in_bn_mean; p.bn_rstd = ext->in_bn_rstd; p.bn_scale = ext->in_bn_scale; p.bn_offset = ext->in_bn_offset;
+        p.bn_labels = ext->in_bn_labels; p.bn_per = d->N / ext->in_bn_groups;
+        return launch_conv16x3h(p, st);
+    }
     if (ext && ext->act) {                                   // the LeakyReLU + dropout pair in the slice kernels' epilogue
         const bool dense = d->ys[1] == 1 && d->ys[3] == d->K && d->ys[2] == (int64_t)d->Q * d->K && d->ys[0] == (int64_t)d->P * d->Q * d->K;
         if (resid || p.resid_up) return ctgan_fail(CTGAN_E_UNSUPPORTED, "conv2d16_fwd_ex: fused LeakyReLU + dropout with a residual");

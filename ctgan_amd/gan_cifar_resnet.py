@@ -164,6 +164,9 @@ def ResidualBlock(name, input_dim, output_dim, filter_size, inputs, resample=Non
             shortcut = UpsampleConv(name + '.Shortcut', input_dim, output_dim, 1, inputs, he_init=False, biases=True)
             epi = None
         out = UpsampleConv(name + '.Conv1', input_dim, output_dim, filter_size, out, relu_in=r1)
+        fused = _fused_norm_conv(name, out, output_dim, filter_size, shortcut, epi is not None, labels, groups)
+        if fused is not None:
+            return fused
         out, r2 = _norm_relu(name + '.N2', out, labels=labels, groups=groups)
         return _conv2d.Conv2D(name + '.Conv2', output_dim, output_dim, filter_size, out, resid=shortcut, relu_in=r2, epi=epi)
     # resample None.  in_drop: `inputs` is the result of that dropout - its mask is applied to the block's input gradient
@@ -216,6 +219,27 @@ def Generator(n_samples, labels, noise=None, groups=1, rng=None):
 # A/B switch: under no_grad (the fake batches of the critic steps) the output stage tanh(Conv2D(relu(Batchnorm(h)))) (:164-166) as the
 # moments + ONE conv launch - the batch norm applied while the many -> few kernel stages its input, tanh in its epilogue
 OUTPUT_STAGE_FUSION = _os.environ.get('CTGAN_OUTPUT_STAGE_FUSION', '1') != '0'
+
+
+def _fused_norm_conv(name, x, dim, filter_size, shortcut, resid_up, labels, groups):
+    """Conv2(relu(N2(x))) + shortcut of an 'up' block (:134-141) under no_grad: the moments, then ONE conv launch with the (conditional) batch norm
+    and the ReLU applied while the halo patch is staged (kernels.conv_fwd_bn_in); None where that form does not apply."""
+    if (not OUTPUT_STAGE_FUSION or torch.is_grad_enabled() or not cfg.NORMALIZATION_G or 'Generator' not in name or not x.is_cuda
+            or (not resid_up and shortcut is not None and tuple(shortcut.shape) != tuple(x.shape))):
+        return None
+    names = (name + '.N2.scale', name + '.N2.offset', name + '.Conv2.Filters', name + '.Conv2.Biases')
+    if any(nm not in lib._params for nm in names):
+        return None                   # first call: the operators create their parameters
+    scale, offset, w, b = (lib.param(nm) for nm in names)
+    lab = labels if (cfg.CONDITIONAL and labels is not None and scale.dim() == 2 and scale.shape[0] > 1) else None
+    if lab is None and scale.numel() != dim:
+        return None
+    g = K.ConvGeom(dim, x.shape[2], x.shape[3], dim, filter_size, filter_size, 1)
+    try:
+        mean, rstd = K.bn_stats(x, groups)
+        return K.conv_fwd_bn_in(x, w, b, g, mean, rstd, scale, offset, groups, relu_in=True, labels=lab, resid=shortcut, resid_up=resid_up)
+    except NotImplementedError:
+        return None
 
 
 def _fused_output_stage(h, G, groups):

@@ -1333,15 +1333,18 @@ def bn_stats(x4, groups, eps=1e-5):
     return mean, rstd
 
 
-def conv_fwd_bn_in(x, w, bias, g, mean, rstd, scale, offset, groups, relu_in=True, tanh=False, out_strides=None):
-    """conv(relu?(bn(x))) [+ bias] [tanh] with the batch norm applied while the input is staged (ctgan_epilogue_ext.in_bn_*): the many -> few
-    pixel kernel only (3x3, <= 4 output channels, 32-pixel rows) - NotImplementedError elsewhere.  mean / rstd [groups, C] from bn_stats,
-    scale / offset [C] (no labels)."""
+def conv_fwd_bn_in(x, w, bias, g, mean, rstd, scale, offset, groups, relu_in=True, tanh=False, out_strides=None, labels=None, resid=None,
+                   resid_up=False):
+    """conv(relu?(bn(x))) [+ bias] [+ resid (through a nearest-2x upsample: resid_up)] [tanh] with the training-mode batch norm applied while
+    the conv stages its input (ctgan_epilogue_ext.in_bn_*): the many -> few pixel kernel (3x3, <= 4 output channels, 32-pixel rows; no labels,
+    no resid) or, in the split mode, the fragment-streaming halo kernel (stride 1, tiles inside one image, relu_in) - NotImplementedError
+    elsewhere.  mean / rstd [groups, C] from bn_stats; scale / offset [C], or [n_labels, C] tables with labels (int32 per sample)."""
     from ._lib import EpilogueExt
-    _need_dev(x, w, bias, mean, rstd, scale, offset)
+    _need_dev(x, w, bias, mean, rstd, scale, offset, labels, resid)
     N = x.shape[0]
     assert tuple(x.shape) == (N, g.C, g.H, g.W) and tuple(w.shape) == (g.R, g.S, g.C, g.K) and w.is_contiguous() and not g.x_up
-    assert tuple(mean.shape) == (groups, g.C) and tuple(rstd.shape) == (groups, g.C) and scale.numel() == g.C and offset.numel() == g.C
+    assert tuple(mean.shape) == (groups, g.C) and tuple(rstd.shape) == (groups, g.C) and scale.shape[-1] == g.C and offset.shape[-1] == g.C
+    assert labels is not None or scale.numel() == g.C
     if out_strides is None:
         y = empty_cl(N, g.K, g.P, g.Q, x.device)
     else:
@@ -1350,7 +1353,22 @@ def conv_fwd_bn_in(x, w, bias, g, mean, rstd, scale, offset, groups, relu_in=Tru
     e = EpilogueExt(0.0, 0, 0, None)
     e.in_bn_mean, e.in_bn_rstd, e.in_bn_scale, e.in_bn_offset = mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), offset.data_ptr()
     e.in_bn_groups, e.out_tanh = int(groups), 1 if tanh else 0
-    _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), None, _ptr(y), 2 if relu_in else 0, ctypes.byref(e), _stream()), 'conv2d_fwd'))
+    e.in_bn_labels = labels.data_ptr() if labels is not None else None
+    if fewch_handles(g):
+        if labels is not None or resid is not None:
+            raise NotImplementedError('conv_fwd_bn_in: the many -> few kernel takes neither labels nor a residual')
+        _timed(g, N, lambda: check(lib.ctgan_conv2d_fwd_ex(ctypes.byref(d), _ptr(x), _ptr(w), _ptr(bias), None, _ptr(y), 2 if relu_in else 0, ctypes.byref(e), _stream()), 'conv2d_fwd'))
+        return y
+    if tanh or not (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID and lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 0))):
+        raise NotImplementedError('conv_fwd_bn_in: batch norm on load exists in the split mode\'s halo kernel and in the many -> few pixel kernel')
+    if resid is not None and resid_up:
+        assert tuple(resid.shape) == (N, g.K, g.P // 2, g.Q // 2) and resid.permute(0, 2, 3, 1).is_contiguous()
+    elif resid is not None:
+        assert is_dense_like(resid, y)
+    wp = _packed16(w, d, 0, g, 'f32x3')
+    fl = (2 if relu_in else 0) | (8 if (resid_up and resid is not None) else 0)
+    _timed(g, N, lambda: check(lib.ctgan_conv2d16_fwd_ex(ctypes.byref(d), 3, _ptr(x), _ptr(wp), _ptr(bias), _ptr(resid), _ptr(y), fl, ctypes.byref(e), None, 0, _stream()),
+                               'conv2d16_fwd_ex'))
     return y
 
 

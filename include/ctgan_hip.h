@@ -138,6 +138,10 @@ typedef struct ctgan_epilogue_ext {
     const float* in_bn_offset;
     int32_t in_bn_groups;
     int32_t out_tanh;
+    /* ... and on ctgan_conv2d16_fwd_ex (mma = CTGAN_MMA_F32X3, stride 1, launches the fragment-streaming halo kernel takes with tiles inside one image,
+     * CTGAN_IN_RELU set): the same batch norm while the halo patch is staged - the generator's Conv2 layers (TF/CT_gan_cifar_resnet.py:134-141) without
+     * a tape.  in_bn_labels (int32 per sample, or NULL): conditional batch norm - in_bn_scale / in_bn_offset are [n_labels][C] tables.  */
+    const int32_t* in_bn_labels;
 } ctgan_epilogue_ext;
 int ctgan_conv2d_fwd_ex(const ctgan_conv_desc* d, const float* x, const float* w, const float* bias, const float* resid,
                         float* y, int flags, const ctgan_epilogue_ext* ext, ctgan_stream_t stream);
