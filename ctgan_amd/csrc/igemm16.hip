@@ -1799,7 +1799,7 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
     hipLaunchKernelGGL((conv16x3hf_kernel<RELU_IN, TN, BN>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / 128))), dim3(256), lds, st, q, pg);
     ctgan_set_last_kernel(BN ? (TN == 4 ? "conv16x3hf<128x128,k32,bn>" : (TN == 2 ? "conv16x3hf<64x128,k32,bn>" : "conv16x3hf<32x128,k32,bn>"))
                              : (TN == 4 ? "conv16x3hf<128x128,k32>" : (TN == 2 ? "conv16x3hf<64x128,k32>" : "conv16x3hf<32x128,k32>")));
-    ctgan_set_last_symbol(BN ? "conv16x3hf_kernel<%s, %d, true>" : "conv16x3hf_kernel<%s, %d>", RELU_IN ? "true" : "false", TN);
+    ctgan_set_last_symbol("conv16x3hf_kernel<%s, %d, %s>", RELU_IN ? "true" : "false", TN, BN ? "true" : "false");      // (as rocprofv3 prints it: every template argument)
     return ctgan_check_launch("conv16x3hf");
 }
 
