@@ -889,19 +889,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
                 p_voff[it] = (unsigned)(((long long)(img + pi) * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + (item & 7) * 4) * 4);
         }
     }
+    // BN: the chunk's coefficients of this thread's channel quad travel with its patch loads (a thread's quad is the same for all its items:
+    // NT % 8 == 0) - in flight during the previous chunk's taps like the patch itself
+    float4 bn_mu = make_float4(0.f, 0.f, 0.f, 0.f), bn_rs = bn_mu, bn_ga = bn_mu, bn_be = bn_mu;
     auto load_patch = [&](int chunk) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it)
             if (it < pg.n_it)
                 rp[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, p_voff[it] == 0xFFFFFFFFu ? 0xFFFFFFFFu : p_voff[it] + chunk * (BK * 4), 0, 0));
-    };
-    auto store_patch = [&](int chunk) __attribute__((always_inline)) {
-        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, ga = mu, be = mu;
-        if constexpr (BN) {                                // (a thread's channel quad is the same for all its items: NT % 8 == 0)
+        if constexpr (BN) {
             const int cc = chunk * BK + (tid & 7) * 4, gq = img / p.bn_per, lab = p.bn_labels ? p.bn_labels[img] : 0;
-            mu = *reinterpret_cast<const float4*>(p.bn_mean + (long long)gq * p.C + cc); rs = *reinterpret_cast<const float4*>(p.bn_rstd + (long long)gq * p.C + cc);
-            ga = *reinterpret_cast<const float4*>(p.bn_scale + (long long)lab * p.C + cc); be = *reinterpret_cast<const float4*>(p.bn_offset + (long long)lab * p.C + cc);
+            bn_mu = *reinterpret_cast<const float4*>(p.bn_mean + (long long)gq * p.C + cc); bn_rs = *reinterpret_cast<const float4*>(p.bn_rstd + (long long)gq * p.C + cc);
+            bn_ga = *reinterpret_cast<const float4*>(p.bn_scale + (long long)lab * p.C + cc); bn_be = *reinterpret_cast<const float4*>(p.bn_offset + (long long)lab * p.C + cc);
         }
+    };
+    auto store_patch = [&](int) __attribute__((always_inline)) {
+        const float4 mu = bn_mu, rs = bn_rs, ga = bn_ga, be = bn_be;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int item = it * NT + tid, px = item >> 3;
