@@ -70,7 +70,10 @@ class _Grads:
                 # w is the cached spread filter of parameter `name`: its gradient is folded back after the flush (FilterSpreadFn.backward)
                 R_, S_ = gw.shape[0] - 1, gw.shape[1] - 1
                 out = torch.empty((R_, S_, gw.shape[2], gw.shape[3]), dtype=torch.float32, device=gw.device)
-                if F._DEFER['on']:
+                # queued use: gw is the filter's ONE result buffer, filled by the flush - fold it after that, once.  A use launched at
+                # once (16-bit modes' per-filter policy, f32x3, shapes the column kernel rejects) returns a FINISHED gradient per use:
+                # fold it now - a deferred fold per use would have _put sum buffers nothing has written yet
+                if F._DEFER['on'] and self.keys[name] in F._DEFER['groups']:
                     F._DEFER['post'].append(('fold', gw, spread, False, out))
                 else:
                     K.filter_fold(gw.contiguous(), spread, False, out=out)

@@ -82,7 +82,6 @@ class GraphedTrainer:
         self.adam_in_graph = trainer.world == 1 or self.ar_in_graph
         self.d_graph = self.g_graph = None
         self.d_out = self.g_out = None
-        self.graphed_capture = bool(use_graphs)      # the step bodies run under capture / replay (as opposed to eager launches)
         self.graph_error = None
         self.it_graph_error = None    # only the whole-iteration graph failed to capture: the per-step graphs are in use (still `graphed`)
         if use_graphs:
@@ -114,7 +113,7 @@ class GraphedTrainer:
         t.rng.begin_step()
         handed = [0]
         early = None
-        if t.split_flush and t.world > 1 and t.allreduce is not None and t._n_early and (self.ar_in_graph or not self.graphed_capture):
+        if t.split_flush and t.world > 1 and t.allreduce is not None and t._n_early and self.ar_in_graph:
             # the bucket's prefix (blocks 1-2) goes to its all-reduce from inside the step: on the side stream - forked into the capture
             # when the collectives are graph nodes (RCCL) - under the rest of the penalty's double backward.  Not with the collective outside
             # the graph (gloo under graph replay): there the graph ends at the packed bucket.

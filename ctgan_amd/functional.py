@@ -233,13 +233,13 @@ def _wgrad(x, gy, w, g, relu_x, with_bias):
     key = (w.data_ptr(), gk)       # (w: a registry parameter or a cached derived filter - persistent tensors, their addresses are stable)
     can = (_DEFER['on'] and stable and not torch.is_grad_enabled() and x.is_cuda == gy.is_cuda and not g.x_up
            and ((g.C % 32 == 0 and g.K % 4 == 0) or (fewch and FEWCH_DEFER)) and not (g.R == 1 and g.H == 1 and g.W == 1))
+    if can and key in _DEFER['imm'] and key not in _DEFER['groups']:
+        can = False                # launched at once earlier in this step (or flushed early, flush_partial): never re-open its queue
     if can and K.MMA_DTYPE is not None:
         # mixed-precision modes: the small problems the grouped 16-bit launch takes (kernels.grouped16_takes), everything else at once on
         # its own tile - decided by the filter's FIRST use of the step and kept for its later uses
         if key in _DEFER['groups']:
             can = x.is_cuda and K.grouped16_member(g)
-        elif key in _DEFER['imm']:
-            can = False
         else:
             can = DEFER_16BIT and x.is_cuda and K.grouped16_takes(g, x.shape[0], x.stride())
             if not can:
@@ -910,8 +910,10 @@ class FilterSpreadFn(Function):
     def backward(ctx, g):
         if g is None:
             return None, None, None
-        if _DEFER['on'] and not torch.is_grad_enabled():
-            # g may be a queued weight gradient that is only filled when the queue is flushed: fold after that
+        if _DEFER['on'] and not torch.is_grad_enabled() and any(grp.dw.data_ptr() == g.data_ptr() for grp in _DEFER['groups'].values()):
+            # g is a queued weight gradient that is only filled when the queue is flushed: fold after that.  (A FINISHED gradient - a use
+            # launched at once, as the 16-bit modes and f32x3 do - is folded now: each use's node would otherwise return its own unfilled
+            # buffer and the engine would sum them before any fold has run)
             g = g.contiguous()
             R, S = g.shape[0] - 1, g.shape[1] - 1
             C, Ko = (g.shape[3], g.shape[2]) if ctx.flip else (g.shape[2], g.shape[3])

@@ -235,6 +235,8 @@ def _fused_norm_conv(name, x, dim, filter_size, shortcut, resid_up, labels, grou
     if lab is None and scale.numel() != dim:
         return None
     g = K.ConvGeom(dim, x.shape[2], x.shape[3], dim, filter_size, filter_size, 1)
+    if not K.conv_fwd_bn_in_supported(x, g, labels=lab, resid=shortcut):
+        return None                   # (asked before the moments: the fallback computes its own)
     try:
         mean, rstd = K.bn_stats(x, groups)
         return K.conv_fwd_bn_in(x, w, b, g, mean, rstd, scale, offset, groups, relu_in=True, labels=lab, resid=shortcut, resid_up=resid_up)
@@ -250,6 +252,8 @@ def _fused_output_stage(h, G, groups):
         return None                   # first call: the operators create their parameters
     scale, offset, w, b = (lib.param(nm) for nm in names)
     g = K.ConvGeom(G, h.shape[2], h.shape[3], 3, 3, 3, 1)
+    if not K.conv_fwd_bn_in_supported(h, g, tanh=True):
+        return None
     try:
         mean, rstd = K.bn_stats(h, groups)
         N = h.shape[0]

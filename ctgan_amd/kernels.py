@@ -1333,6 +1333,22 @@ def bn_stats(x4, groups, eps=1e-5):
     return mean, rstd
 
 
+def conv_fwd_bn_in_supported(x, g, tanh=False, labels=None, resid=None):
+    """Does conv_fwd_bn_in have a kernel for this launch?  Asked BEFORE the moments are computed, so that a caller who falls back to the
+    separate batch norm does not pay a bn_stats launch it then repeats."""
+    if fewch_handles(g):
+        return labels is None and resid is None
+    if tanh:
+        return False
+    if MMA_DTYPE == 'f32x3':
+        return True
+    if MMA_DTYPE is None and X3_HYBRID:
+        y_strides = (g.K * g.P * g.Q, 1, g.Q * g.K, g.K)          # channels-last result (empty_cl)
+        d = g.desc(x.shape[0], x.stride(), y_strides)
+        return bool(lib.ctgan_conv2d16_x3_prefers(ctypes.byref(d), 0))
+    return False
+
+
 def conv_fwd_bn_in(x, w, bias, g, mean, rstd, scale, offset, groups, relu_in=True, tanh=False, out_strides=None, labels=None, resid=None,
                    resid_up=False):
     """conv(relu?(bn(x))) [+ bias] [+ resid (through a nearest-2x upsample: resid_up)] [tanh] with the training-mode batch norm applied while

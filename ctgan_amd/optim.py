@@ -127,4 +127,5 @@ class FlatAdam:
 
     def load_state_dict(self, sd):
         self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.state.copy_(sd['state']); self.t = int(sd['t'])
+        self.state[3:4].zero_()            # skipped() counts THIS session's skips: a resumed run does not inherit the saved run's
         self._lr_last = None

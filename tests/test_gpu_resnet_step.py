@@ -384,8 +384,9 @@ def test_layernorm_critic_d_step_on_gpu(setup):
         lib0.delete_all_params(); R0.configure()
 
 
-@pytest.mark.parametrize('dim,B,ac', [(64, 8, True), (128, 64, True), (128, 64, False)])
-def test_hand_scheduled_critic_step_equals_the_autograd_path_on_gpu(setup, dim, B, ac):
+@pytest.mark.parametrize('dim,B,ac,mode', [(64, 8, True, None), (128, 64, True, None), (128, 64, False, None), (64, 8, False, 'f32x3'),
+                                           (64, 8, False, 'bf16'), (128, 16, False, 'bf16')])
+def test_hand_scheduled_critic_step_equals_the_autograd_path_on_gpu(setup, dim, B, ac, mode):
     """critic_schedule.critic_step (one backward chain over the rows of the dropout passes and of the gradient-penalty
     pass; weight gradients restricted to the dropout-pass rows; the penalty's double backward on the x_hat rows only) against the path it
     replaces (Trainer.d_losses + two autograd calls), at the benchmarked size: same weights, inputs and Philox streams.  The merged
@@ -393,18 +394,24 @@ def test_hand_scheduled_critic_step_equals_the_autograd_path_on_gpu(setup, dim, 
     masks are taken from the same forward tensors, so the gradients agree to fp32 rounding - not bit for bit."""
     import ctgan_amd.functional as F
     from tests.test_host_logic_resnet import _scheduled_vs_autograd
+    import ctgan_amd.kernels as K
     R, lib = setup(dim, B)
-    a, b = _scheduled_vs_autograd(R, lib, F, B, dim, ac, None)
+    # modes 'f32x3' / 'bf16' (ADVICE r5, high): filters whose uses are launched at once instead of queued - the schedule (and the autograd
+    # path's FilterSpreadFn) must fold each finished spread-filter gradient itself.  bf16: the two paths round different partial sums to
+    # 16 bits (other row counts per launch), so they agree to bf16 rounding of the operands, not to fp32 rounding
+    with K.mma_dtype(mode):
+        a, b = _scheduled_vs_autograd(R, lib, F, B, dim, ac, None)
+    t = 2e-2 if mode == 'bf16' else 0.0
     for k in ('cost', 'wgan', 'acgan', 'wgan_only', 'ct', 'gp', 'acc_real', 'acc_fake', 'd_real', 'd_fake', 'real'):
         assert (a[0].get(k) is None) == (b[0].get(k) is None), k
         if a[0].get(k) is not None:
-            _cmp(b[0][k], a[0][k], 1e-5, 'scheduled.' + k, atol=1e-6)
-    assert _rel_l2(b[0]['slopes'], a[0]['slopes']) < 1e-5 and _rel_l2(b[0]['gp_grads'], a[0]['gp_grads']) < 1e-5
+            _cmp(b[0][k], a[0][k], max(1e-5, t * 1e-2), 'scheduled.' + k, atol=1e-6)
+    assert _rel_l2(b[0]['slopes'], a[0]['slopes']) < max(1e-5, t * 1e-2) and _rel_l2(b[0]['gp_grads'], a[0]['gp_grads']) < max(1e-5, t)
     assert a[2] == b[2]
     for n, x, y in zip(a[2], a[1], b[1]):
         assert (x is None) == (y is None), n
         if x is not None and x.abs().max() > 0:
-            assert _rel_l2(y, x) < 2e-5, (n, _rel_l2(y, x))
+            assert _rel_l2(y, x) < max(2e-5, t), (n, _rel_l2(y, x))
 
 
 @pytest.mark.parametrize('split_mode', [True, False])

@@ -644,8 +644,8 @@ def _scheduled_vs_autograd(R, lib, F, B, D, ac, dev, seed=1):
     return res[False], res[True]
 
 
-@pytest.mark.parametrize('ac', [True, False])
-def test_hand_scheduled_critic_step_equals_the_autograd_path(cpu_kernels, ac):
+@pytest.mark.parametrize('ac,mode', [(True, None), (False, None), (False, 'bf16'), (False, 'f32x3')])
+def test_hand_scheduled_critic_step_equals_the_autograd_path(cpu_kernels, ac, mode):
     """critic_schedule.critic_step - ONE backward chain over the rows of the two dropout passes and the rows of the gradient-penalty
     pass, weight gradients from the dropout-pass rows only, the penalty's double backward on the x_hat rows only -
     against the path it replaces (Trainer.d_losses + two torch.autograd.grad calls): every loss term, the slopes, dD/dx_hat and every
@@ -653,8 +653,12 @@ def test_hand_scheduled_critic_step_equals_the_autograd_path(cpu_kernels, ac):
     import ctgan_amd.functional as F
     import ctgan_amd.gan_cifar_resnet as R
     import ctgan_amd.tflib as lib
+    import ctgan_amd.kernels as K
     try:
-        a, b = _scheduled_vs_autograd(R, lib, F, 2, 64, ac, 'cpu')
+        # modes 'bf16' / 'f32x3' (the stand-ins still multiply in fp32): no filter is queued there - every use returns a finished weight
+        # gradient, and the schedule has to fold each spread-filter gradient itself before summing the uses
+        with K.mma_dtype(mode):
+            a, b = _scheduled_vs_autograd(R, lib, F, 2, 64, ac, 'cpu')
         for k in ('cost', 'wgan', 'acgan', 'wgan_only', 'ct', 'gp', 'acc_real', 'acc_fake', 'slopes', 'gp_grads', 'd_real', 'd_fake', 'real'):
             assert (a[0].get(k) is None) == (b[0].get(k) is None), k
             if a[0].get(k) is not None:
