@@ -70,12 +70,8 @@ I32x4 = c_int32 * 4
 _p = c_void_p          # device pointers and the stream travel as void*
 _D = POINTER(ConvDesc)
 
-# name -> (restype, argtypes); the single source the symbol-export test checks against the header
-SIGNATURES = {
-    'ctgan_version': (c_int, []),
-    'ctgan_last_error': (c_char_p, []),
-    'ctgan_last_kernel': (c_char_p, []),
-    'ctgan_last_symbol': (c_char_p, []),
+# test / A-B switches and launch introspection (include/ctgan_hip_debug.h): exported by the same library, NOT part of the drop-in ABI
+DEBUG_SIGNATURES = {
     'ctgan_debug_force_generic': (None, [c_int]),
     'ctgan_debug_reduce_lanes': (None, [c_int]),
     'ctgan_debug_x3_halo_version': (None, [c_int]),
@@ -85,6 +81,14 @@ SIGNATURES = {
     'ctgan_debug_m2f_px': (None, [c_int]),
     'ctgan_debug_last_wgrad_group_kinds': (c_int, []),
     'ctgan_debug_last_wgrad_group_col_mask': (ctypes.c_uint, []),
+}
+
+# name -> (restype, argtypes); the single source the symbol-export test checks against include/ctgan_hip.h
+SIGNATURES = {
+    'ctgan_version': (c_int, []),
+    'ctgan_last_error': (c_char_p, []),
+    'ctgan_last_kernel': (c_char_p, []),
+    'ctgan_last_symbol': (c_char_p, []),
     'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     'ctgan_conv2d_wgrad_multi': (c_int, [POINTER(ConvDesc), c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), _p, _p, _p,
                                          c_size_t, _p]),
@@ -213,7 +217,7 @@ def _load():
             'ctgan_amd: %s is missing - build the HIP extension first (python __graft_entry__.py, or '
             'make -C ctgan_amd/csrc).  There is no CPU fallback.' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:

@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/ctgan_hip.h"
+#include "../../include/ctgan_hip_debug.h"
 
 // thread-local last-error message (no exception crosses the C ABI)
 int ctgan_fail(int code, const char* fmt, ...);

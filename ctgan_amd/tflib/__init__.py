@@ -126,9 +126,45 @@ def state_dict():
     return collections.OrderedDict((n, p.detach().cpu().clone()) for n, p in _params.items())
 
 
-def load_state_dict(sd, strict=True):
+def from_ls_names(sd):
+    """A name -> array mapping under the parameter names of the LSUN tree's operator library - conv / deconv biases `name.b`
+    (LS/tflib/ops/conv2d.py:117, deconv2d.py:108), Layernorm / Batchnorm offsets `name.b` (LS/tflib/ops/layernorm.py:15,22,
+    batchnorm.py:24) - renamed to the names this library (and the TF tree: TF/tflib/ops/conv2d.py:116, layernorm.py:14) registers:
+    `name.Biases` next to a `name.Filters`, `name.offset` next to a `name.scale`.  A Linear's `name.b` is the same in both trees."""
+    out = collections.OrderedDict()
+    for n, v in sd.items():
+        if n.endswith('.b'):
+            base = n[:-2]
+            if base + '.Filters' in sd:
+                n = base + '.Biases'
+            elif base + '.scale' in sd:
+                n = base + '.offset'
+        if n in out:
+            raise KeyError('from_ls_names: %s appears under both naming schemes' % n)
+        out[n] = v
+    return out
+
+
+def to_ls_names(sd):
+    """Inverse of from_ls_names: this registry's names -> the LSUN tree's (for a checkpoint the LS scripts' Saver / lib.param read)."""
+    out = collections.OrderedDict()
+    for n, v in sd.items():
+        if n.endswith('.Biases') and n[:-7] + '.Filters' in sd:
+            n = n[:-7] + '.b'
+        elif n.endswith('.offset') and n[:-7] + '.scale' in sd:
+            n = n[:-7] + '.b'
+        out[n] = v
+    return out
+
+
+def load_state_dict(sd, strict=True, names='tf'):
     """Create / overwrite parameters from a name -> array mapping (explicit weight injection:
-    the reference's numpy-seed replay is not reproducible)."""
+    the reference's numpy-seed replay is not reproducible).  names='ls': `sd` carries the LSUN tree's parameter
+    names (config[4]'s script, LS/wgan_LSUN_Bedrooms128.py) - translated by from_ls_names first."""
+    if names == 'ls':
+        sd = from_ls_names(sd)
+    elif names != 'tf':
+        raise ValueError("load_state_dict: names must be 'tf' or 'ls'")
     for n, v in sd.items():
         v = torch.as_tensor(np.asarray(v, dtype=np.float32)) if not torch.is_tensor(v) else v
         if n in _params:

@@ -68,30 +68,7 @@ const char* ctgan_last_kernel(void);
 /* ... and its device symbol as rocprofv3 prints it (e.g. "conv16_kernel<3, 2, 2, 32, false, false>"); the variant name when the
    launcher does not record one.  bench.py keys its per-kernel roofline table by it (cross-checked against profiles/).            */
 const char* ctgan_last_symbol(void);
-/* tests only: 1 = route every conv through the table-driven generic kernels                   */
-void ctgan_debug_force_generic(int on);
-/* tests only: 0 = the split-K reduction of the fp32 weight gradients as one thread per float4 everywhere (the form before the four-lanes-per-float4
-   kernel for small outputs with many slabs; both give the same bits) */
-void ctgan_debug_reduce_lanes(int on);
-/* tests only: which halo-patch kernel of the split mode takes the launches that qualify - 1: filter through an LDS stage
-   (conv16x3h_kernel), 2: filter fragments streamed from L2 (conv16x3hf_kernel), 0: back to the default (2) */
-void ctgan_debug_x3_halo_version(int version);
-/* tests / A-B: 0 = the stride-2 data gradients of the split mode on the slice kernel instead of the four-phase halo kernel (conv16x3p_kernel) */
-void ctgan_debug_x3_s2halo(int on);
-/* tests / A-B: 0 = the stride-2 forward launches of the split mode on the slice kernel instead of conv16x3sf_kernel (filter fragments from L2);
-   2 = on that kernel but without its K split (launches of 128 .. 383 tiles of 64 positions) */
-void ctgan_debug_x3_s2fwd(int on);
-/* tests / A-B: which four-phase data gradients of the folded 4x4 / stride-2 filters run on conv16x3sf_kernel (one phase per workgroup, slice staging)
-   instead of conv16x3p_kernel (four phases from one dy patch): 0 (default) every launch of >= 768 workgroups, -1 none */
-void ctgan_debug_x3_s2dgrad_sf(int on);
-/* Tests / A-B: 0 = the 3x3 many -> few convs (generator output conv, data gradient of the first critic conv) on the row-ring kernel
- * instead of the one-pixel-per-lane kernel with the filter as scalar operands (csrc/fewch.hip, round 5).                          */
-void ctgan_debug_m2f_px(int on);
-/* tests only: which weight-gradient kernels the last ctgan_conv2d16_wgrad_group call on this thread launched - bit 0: the filter-column
-   kernel (wgrad16c_group_kernel), bit 1: the slice kernel (wgrad16_group_kernel)                                                     */
-int ctgan_debug_last_wgrad_group_kinds(void);
-/* ... and which members (bit i = groups[i]) rode the filter-column kernel                                                             */
-unsigned ctgan_debug_last_wgrad_group_col_mask(void);
+/* (test / A-B switches and launch introspection live in ctgan_hip_debug.h - not part of this ABI)                              */
 
 /* Optional epilogue extension of ctgan_conv2d_fwd / ctgan_conv2d_dgrad: tf.nn.dropout (:173-177) applied to the
  * RESULT inside the kernel, y *= floor(keep + u)/keep, where u is what ctgan_rng_uniform(.., seed, stream_id, ctr)

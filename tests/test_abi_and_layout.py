@@ -8,8 +8,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, 'include', 'ctgan_hip.h')).read()
+def _header_functions(header='ctgan_hip.h'):
+    src = open(os.path.join(ROOT, 'include', header)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(ctgan_[a-z0-9_]+)\s*\(', src)))
 
@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     names = _header_functions()
     assert len(names) >= 40
-    missing = [n for n in names if not hasattr(lib, n)]
+    missing = [n for n in names + _header_functions('ctgan_hip_debug.h') if not hasattr(lib, n)]
     assert not missing, missing
     assert lib.ctgan_version() == 1
 
@@ -28,6 +28,13 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     from ctgan_amd import _lib
     assert sorted(_lib.SIGNATURES) == _header_functions()
+    assert sorted(_lib.DEBUG_SIGNATURES) == _header_functions('ctgan_hip_debug.h')
+
+
+def test_product_header_carries_no_debug_switches():
+    """The drop-in ABI (include/ctgan_hip.h) declares operators only; the test / A-B switches live in ctgan_hip_debug.h."""
+    assert not [n for n in _header_functions() if 'debug' in n]
+    assert all(n.startswith('ctgan_debug_') for n in _header_functions('ctgan_hip_debug.h'))
 
 
 def test_conv_desc_layout_matches_header():

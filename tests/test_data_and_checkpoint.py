@@ -59,6 +59,74 @@ def test_cifar10_epoch_order_is_the_in_place_shuffle_order(tmp_path):
     assert np.array_equal(state_after, np.random.get_state()[1])
 
 
+def _fake_mnist(path, n_train=120, n_dev=40, n_test=40):
+    rng = np.random.default_rng(1)
+
+    def split(n, base):
+        x = rng.random((n, 784), dtype=np.float32)
+        x[:, 0] = np.arange(base, base + n)                                # row id in column 0
+        return x, (np.arange(base, base + n) % 10).astype(np.int64)
+    with gzip.open(path, 'wb') as f:
+        pickle.dump((split(n_train, 0), split(n_dev, 1000), split(n_test, 2000)), f, protocol=2)
+
+
+def test_mnist_generator_contract(tmp_path):
+    """TF/tflib/mnist.py:48-104: first-n_examples truncation, (images [B,784] float32, targets [B]) batches, images and targets
+    permuted together, a fresh order every epoch, whole dev / test splits, reshape error when B does not divide the set, no download."""
+    from ctgan_amd.tflib import mnist
+    path = str(tmp_path / 'mnist.pkl.gz')
+    with pytest.raises(IOError, match="Couldn't find MNIST dataset"):
+        mnist.load(10, 10, filepath=path)
+    _fake_mnist(path)
+    np.random.seed(5)
+    train_gen, dev_gen, test_gen = mnist.load(10, 20, n_examples=50, filepath=path)
+    batches = list(train_gen())
+    assert len(batches) == 5 and batches[0][0].shape == (10, 784) and batches[0][0].dtype == np.float32 and batches[0][1].shape == (10,)
+    ids = np.concatenate([b[0][:, 0] for b in batches]).astype(int); labs = np.concatenate([b[1] for b in batches])
+    assert sorted(ids.tolist()) == list(range(50))                         # FIRST n_examples only (:50-51), each once per epoch
+    assert np.array_equal(ids % 10, labs)                                  # same permutation for images and targets (:52-55, :64-67)
+    ids2 = np.concatenate([b[0][:, 0] for b in train_gen()]).astype(int)
+    assert sorted(ids2.tolist()) == list(range(50)) and not np.array_equal(ids, ids2)
+    assert sorted(np.concatenate([b[0][:, 0] for b in dev_gen()]).astype(int).tolist()) == list(range(1000, 1040))
+    assert sorted(np.concatenate([b[0][:, 0] for b in test_gen()]).astype(int).tolist()) == list(range(2000, 2040))
+    b0 = next(iter(train_gen())); b0[0][:] = -1                            # batches are copies (:85): the set is not written through them
+    assert train_gen.images.min() >= 0
+    bad, _, _ = mnist.load(16, 20, n_examples=50, filepath=path)           # 50 rows, batches of 16: numpy's reshape error (:73)
+    with pytest.raises(ValueError):
+        next(iter(bad()))
+    lab_gen, _, _ = mnist.load(10, 20, n_examples=50, n_labelled=7, filepath=path)
+    x, t, lab = next(iter(lab_gen()))
+    assert lab.shape == (50,) and lab.sum() == 7 and lab.dtype == np.int32  # the whole labelled vector rides every batch (:80)
+
+
+def test_mnist_order_is_the_reference_in_place_shuffle_order(tmp_path):
+    """One shuffle when the factory is built, one per epoch, each under a saved / restored global generator state
+    (TF/tflib/mnist.py:52-55, :64-71): the rows MnistEpochs yields against literal in-place shuffles of the same arrays, and the
+    global generator's state afterwards."""
+    from ctgan_amd.tflib import mnist
+    path = str(tmp_path / 'mnist.pkl.gz')
+    _fake_mnist(path)
+    train, _, _ = mnist.read_splits(path)
+    np.random.seed(21)
+    gen = mnist.mnist_generator2(train, 10, None, 60)
+    got = [np.concatenate([b[0][:, 0] for b in gen()]) for _ in range(3)]
+    got_t = np.concatenate([b[1] for b in gen()])
+    state_after = np.random.get_state()[1].copy()
+    # literal restatement on copies
+    np.random.seed(21)
+    images, targets = train[0][0:60, :].copy(), train[1][0:60].copy()
+
+    def both():
+        st = np.random.get_state(); np.random.shuffle(images); np.random.set_state(st); np.random.shuffle(targets)
+    both()
+    for e in range(3):
+        both()
+        assert np.array_equal(got[e], images[:, 0])
+    both()
+    assert np.array_equal(got_t, targets)
+    assert np.array_equal(state_after, np.random.get_state()[1])
+
+
 def test_save_images_grid(tmp_path):
     from ctgan_amd.tflib import save_images
     X = np.zeros((6, 3, 4, 4), dtype=np.int32); X[3] = 200

@@ -95,6 +95,36 @@ def test_lsun128_nets_and_steps_match_oracle(cpu_kernels):
     _run(lib, 'cpu', DIMS_G, DIMS_D, 2, 2e-5)
 
 
+def test_lsun128_checkpoint_under_the_ls_tree_names_loads_by_name(cpu_kernels):
+    """config[4]'s script is built on the LSUN tree's operator library, whose conv / deconv biases and Layernorm / Batchnorm offsets are
+    registered as `name.b` (LS/tflib/ops/conv2d.py:117, deconv2d.py:108, layernorm.py:15, batchnorm.py:24); this registry keeps the TF
+    tree's `.Biases` / `.offset`.  lib.to_ls_names / load_state_dict(names='ls') translate both ways: every parameter of both nets
+    round-trips, a Linear's `.b` stays, nothing is left unmatched (strict)."""
+    import ctgan_amd.gan_lsun128 as M
+    import ctgan_amd.tflib as lib
+    M.configure(BATCH_SIZE=2, **DIMS_G, **DIMS_D)
+    try:
+        lib.set_seed(2)
+        M.build_params('cpu')
+        sd = lib.state_dict()
+        ls = lib.to_ls_names(sd)
+        assert len(ls) == len(sd) and not any(n.endswith(('.Biases', '.offset')) for n in ls)
+        assert 'Discriminator.Input.b' in ls and 'Discriminator.64_3.Conv1.b' in ls and 'Generator.Input.b' in ls and 'Discriminator.Output.b' in ls
+        assert any(n.endswith('.LN1.b') or n.endswith('.N1.b') or '.BN' in n for n in ls), sorted(ls)[:8]
+        assert list(lib.from_ls_names(ls)) == list(sd)
+        ls = {n: (v + 1.0) for n, v in ls.items()}
+        with pytest.raises(KeyError):
+            lib.load_state_dict(ls, strict=True)                  # LS names without the map: every `.Biases` / `.offset` is missing
+        for n in [n for n in lib._params if n not in sd]:
+            del lib._params[n]
+        lib.load_state_dict(ls, strict=True, names='ls')
+        for n, v in sd.items():
+            assert torch.equal(lib._params[n].detach().cpu(), v + 1.0), n
+        assert set(lib._params) == set(sd)
+    finally:
+        lib.delete_all_params(); M.configure()
+
+
 def test_lsun128_full_width_parameter_counts(cpu_kernels):
     """D 47.7 M parameters, G 8.5 M at the reference widths (shapes only: parameters are created lazily)."""
     import ctgan_amd.gan_lsun128 as M
