@@ -62,10 +62,12 @@ def main():
     ap.add_argument('--ar-in-graph', action='store_true',
                     help='N > 1: capture the gradient all-reduces (RCCL) and Adam inside the step graphs - one graph per iteration as at N = 1 '
                          '(engine.AR_IN_GRAPH; default: eager all-reduce on a side stream between per-step graphs)')
-    ap.add_argument('--split-flush-ab', action='store_true',
-                    help='N > 1: also time the loop with the split flush (blocks 1-2 of the critic bucket all-reduced on the side stream under the rest of\n'
-                         'the backward).  Off by default with the RCCL backend: that engine forks collectives into the capture and has never run on more\n'
-                         'than one device - a hang there must not cost the main record; on by default with gloo (tests)')
+    ap.add_argument('--no-ab-legs', action='store_true',
+                    help='N > 1: do not start the A/B legs (in-graph RCCL collectives, split flush) after the record has been printed')
+    ap.add_argument('--leg-timeout', type=float, default=240.0, help='N > 1: seconds an A/B leg (a fresh group of rank processes) may take before it is killed')
+    ap.add_argument('--leg', default=None, choices=sorted(LEGS),
+                    help='(internal) this process is one rank of an A/B leg started by a rank of the main run AFTER it printed its record: '
+                         'prints a short record of its own, never starts legs')
     ap.add_argument('--feed', default='both', choices=['device', 'both'],
                     help='device: the timed loop cycles 16 device-resident batches (the headline `value`); both: also re-time the loop with the\n'
                          'real input path - tflib.cifar10.EpochFeed over synthetic uint8 images -> pinned host buffers -> H2D on a copy stream ->\n'
@@ -77,10 +79,14 @@ def main():
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.spawn_check:
         return spawn_check(args)
-    if args.ar_in_graph:
-        os.environ['CTGAN_AR_IN_GRAPH'] = '1'
-    if args.no_ar_in_graph:
-        os.environ['CTGAN_AR_IN_GRAPH'] = '0'          # read when ctgan_amd.engine is imported (below)
+    if args.leg is not None:
+        args.no_roofline = args.no_cpu_baseline = args.no_ab_legs = True
+        args.feed = 'device'
+        args.ar_in_graph, args.no_graph = LEGS[args.leg]['ar_in_graph'], LEGS[args.leg]['no_graph']
+    # N > 1: the RECORD leg runs the eager side-stream collective (ddp.FlatAllReduce between per-step graphs: the path the 2-rank gloo tests
+    # cover) unless --ar-in-graph asks for the captured one; the captured RCCL collectives and the split flush are A/B legs, run as fresh
+    # rank groups after the record is out (run_ab_legs): a hang or a watchdog abort there cannot cost the record
+    ar_in_graph = bool(args.ar_in_graph) and not args.no_ar_in_graph
 
     import numpy as np
     import torch
@@ -127,7 +133,9 @@ def main():
     if args.gp_unit_only:
         print(json.dumps(measure_gp_unit(trainer, batches[0], torch)))
         return
-    eng = GraphedTrainer(trainer, use_graphs=not args.no_graph)
+    if args.leg is not None:
+        trainer.split_flush = LEGS[args.leg]['split_flush']
+    eng = GraphedTrainer(trainer, use_graphs=not args.no_graph, ar_in_graph=ar_in_graph)
     if world > 1:
         # every rank must run the same path: if any rank could not capture the in-graph collective, all fall back to the side-stream one.
         # (Only a failed capture of the STEP graphs counts: the whole-iteration graph is optional - off by design with CTGAN_ITERATION_GRAPH=0
@@ -210,20 +218,6 @@ def main():
         collective = {'all_reduces_per_step': R.cfg.N_CRITIC + 1, 'in_graph': bool(eng.ar_in_graph), 'steps': k2,
                       'bucket_bytes': {'critic': 4 * trainer.d_opt.theta.numel(), 'generator': 4 * trainer.g_opt.theta.numel()},
                       'critic_bucket_prefix_bytes_split_flush': 4 * trainer.d_opt.offsets[trainer._n_early] if trainer._n_early < len(trainer.d_opt.offsets) else None}
-        try:
-            if not (args.split_flush_ab or (args.backend or 'nccl') == 'gloo'):
-                raise RuntimeError('not run (python bench.py --gpus N --split-flush-ab times it)')
-            trainer.split_flush = True
-            eng_s = GraphedTrainer(trainer, use_graphs=not args.no_graph, ar_in_graph=eng.ar_in_graph)
-            ms_split = timed_loop(eng_s, k2)
-            collective['split_flush'] = {'ms_per_step': round(ms_split, 3), 'graph_error': eng_s.graph_error,
-                                         'what': 'critic steps hand blocks 1-2 of the bucket (a prefix) to their own all-reduce on the side stream as soon '
-                                                 'as the hand-scheduled step has completed them; the rest follows at the end of the step'}
-            del eng_s
-        except Exception as e:          # noqa: BLE001   (report, never fail the record over the comparison)
-            collective['split_flush'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        finally:
-            trainer.split_flush = False
         saved_ar = trainer.allreduce
         try:
             trainer.allreduce = _NoComm()
@@ -232,14 +226,19 @@ def main():
             del eng_n
             collective['ms_per_step_without_all_reduce'] = round(ms_local, 3)
             collective['exposed_ms_per_step'] = round(ms_per_step - ms_local, 3)
-            if 'ms_per_step' in collective.get('split_flush', {}):
-                collective['split_flush']['exposed_ms_per_step'] = round(collective['split_flush']['ms_per_step'] - ms_local, 3)
+            # the arithmetic behind the >= 0.85 scaling target: the per-GPU work is fixed (weak scaling), so whole-job efficiency at N ranks
+            # = ms_per_step(1 GPU) / ms_per_step(N) ~ 1 - exposed / ms_per_step as long as the launches themselves take what they take alone
+            collective['exposed_frac_of_step'] = round((ms_per_step - ms_local) / ms_per_step, 4)
+            collective['scaling_efficiency_bound'] = round(ms_local / ms_per_step, 4)
         except Exception as e:          # noqa: BLE001
             collective['without_all_reduce_error'] = '%s: %s' % (type(e).__name__, e)
         finally:
             trainer.allreduce = saved_ar
-        collective['note'] = ('in_graph: the all-reduces are nodes of the iteration graph (RCCL under stream capture); otherwise eager collectives on a '
-                              'side stream between per-step graphs, the next step\'s input staging enqueued while the bucket is in flight (DESIGN 5)')
+        collective['note'] = ('in_graph: the all-reduces are nodes of the iteration graph (RCCL under stream capture); otherwise (the record leg\'s '
+                              'default) eager collectives on a side stream between per-step graphs, the next step\'s input staging enqueued while the '
+                              'bucket is in flight (DESIGN 5).  exposed = this loop - the same loop with the collective replaced by nothing; '
+                              'scaling_efficiency_bound = that loop / this loop.  The captured-collective and split-flush engines are timed by A/B legs '
+                              'started after this record is printed (stderr lines "bench: leg ...")')
 
     # The same loop fed the way the reference's loop is (TF/CT_gan_cifar_resnet.py:394-412 times the feed too; TF/tflib/cifar10.py:40-63 is
     # the contract): uint8 epochs shuffled on the host, pinned prefetch two batches deep, H2D on a copy stream, the iteration's staging
@@ -377,13 +376,85 @@ def main():
             'step_effective_frac_note': 'EFFECTIVE rate, not a roofline fraction: FLOPs of the REFERENCE formulation (SURVEY 8(d), 2990.5 GFLOP / iteration) / time / fp32 MFMA peak; the executed count is lower (resampled convs run as stride-2 convs with the spread filter): see step.frac_executed',
             'roofline': roofline, 'gp_unit': gp_unit, 'cpu_baseline': cpu, 'build': build_provenance(),
         }
+        if args.leg is not None:
+            rec = {'leg': args.leg, 'n_gpus': world, 'ms_per_step': rec['ms_per_step'], 'value': rec['value'], 'steps': args.steps, 'in_graph': bool(eng.ar_in_graph),
+                   'split_flush': bool(trainer.split_flush), 'hipgraph': bool(eng.graphed), 'graph_error': eng.graph_error, 'it_graph_error': eng.it_graph_error,
+                   'backend': dist_info(world)[0], 'replicas_identical': replicas_identical, 'loss_sane': sane,
+                   'exposed_ms_per_step': (collective or {}).get('exposed_ms_per_step')}
         print(json.dumps(rec))
+        sys.stdout.flush()               # the record is OUT before any A/B leg starts
     if world > 1:
+        legs = [] if (args.no_ab_legs or not sane) else [n for n, l in sorted(LEGS.items()) if (dist_info(world)[0] or 'nccl') in l['backends']]
+        ports = pick_ports(len(legs), rank, dev)
         dist.barrier()
         dist.destroy_process_group()
+        if legs:
+            run_ab_legs(args, rank, world, legs, ports, max(5, min(20, args.steps)))
     if not sane:
         print('bench: critic loss terms out of band %r (replicas identical: %r) - the timed loop is not computing the reference step' % (last, replicas_identical), file=sys.stderr)
         sys.exit(3)
+
+
+# A/B legs of an N > 1 run: each a FRESH group of N rank processes, started by the ranks of the main run after the record is printed and
+# their own process group is gone, killed after --leg-timeout.  in_graph*: the gradient all-reduces captured as nodes of the step graphs
+# (engine.GraphedTrainer(ar_in_graph=True)) - RCCL only, never run on more than one device so far; *split_flush: blocks 1-2 of the critic
+# bucket on their own all-reduce under the rest of the backward (Trainer.split_flush; with eager collectives only the eager engine overlaps).
+LEGS = {
+    'in_graph': {'ar_in_graph': True, 'split_flush': False, 'no_graph': False, 'backends': ('nccl',)},
+    'in_graph_split_flush': {'ar_in_graph': True, 'split_flush': True, 'no_graph': False, 'backends': ('nccl',)},
+    'eager_split_flush': {'ar_in_graph': False, 'split_flush': True, 'no_graph': True, 'backends': ('gloo',)},
+    'spawn': {'ar_in_graph': False, 'split_flush': False, 'no_graph': False, 'backends': ()},        # --spawn-check's leg (launcher tests, no GPU)
+}
+
+
+def pick_ports(n, rank, dev=None):
+    """n free TCP ports chosen by rank 0 and broadcast (the legs' rendezvous ports); needs the process group still alive."""
+    import socket
+    import torch.distributed as dist
+    ports = [0] * n
+    if rank == 0:
+        socks = []
+        for i in range(n):
+            sk = socket.socket(); sk.bind(('127.0.0.1', 0)); socks.append(sk)
+            ports[i] = sk.getsockname()[1]
+        for sk in socks:
+            sk.close()
+    if n:
+        box = [ports]
+        dist.broadcast_object_list(box, src=0, device=dev)
+        ports = box[0]
+    return ports
+
+
+def run_ab_legs(args, rank, world, legs, ports, steps, extra=()):
+    """Every rank of the finished main run starts ITS rank of each leg as a child process (same RANK / LOCAL_RANK / WORLD_SIZE, the leg's
+    own MASTER_PORT), waits at most --leg-timeout and kills exactly that child on expiry.  Works the same under torch.distributed.run
+    (the driver's launch) and under this script's own launcher.  Rank 0 relays each leg's short record to STDERR: stdout carries the one
+    record line only, and that line is already out."""
+    import subprocess
+    for name, port in zip(legs, ports):
+        env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC_')}     # (the agent's store is not the leg's store)
+        env.update(MASTER_PORT=str(port), MASTER_ADDR='127.0.0.1')
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--steps', str(steps), '--warmup', '3', '--leg', name,
+               '--launcher', 'never'] + (['--backend', args.backend] if args.backend else []) + list(extra)
+        t0 = time.time()
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=sys.stderr)
+        try:
+            out, _ = pr.communicate(timeout=args.leg_timeout)
+            res = None
+            for ln in (out or b'').decode(errors='replace').splitlines():
+                if ln.startswith('{'):
+                    res = json.loads(ln)
+            if res is None:
+                res = {'leg': name, 'error': 'rank 0 of the leg exited with status %s and no record' % pr.returncode}
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.communicate()
+            res = {'leg': name, 'error': 'killed after --leg-timeout %.0f s' % args.leg_timeout}
+        if rank == 0:
+            res['wall_s'] = round(time.time() - t0, 1)
+            print('bench: leg %s: %s' % (name, json.dumps(res)), file=sys.stderr)
+            sys.stderr.flush()
 
 
 def launch_ranks(args, argv):
@@ -433,7 +504,15 @@ def launch_ranks(args, argv):
                                                   stdout=subprocess.PIPE if r == 0 else sys.stderr))
                 # rank 0's stdout is drained by a thread (a full pipe would block it); the launcher polls ALL ranks: the first rank that
                 # dies with a non-zero status ends the run - the others would otherwise sit in a collective until the RCCL timeout
-                reader = threading.Thread(target=lambda c=chunks, pr=procs[0]: c.append(pr.stdout.read()), daemon=True)
+                def relay(pr=procs[0]):
+                    # rank 0's lines go out as they arrive: the record must be on the launcher's stdout BEFORE the A/B legs start (a hang there
+                    # ends in a kill by the driver; the record is out by then).  stdout carries records only; library chatter
+                    # (gloo / RCCL print banners to stdout) -> stderr
+                    for raw in iter(pr.stdout.readline, b''):
+                        line = raw.decode(errors='replace').rstrip('\n')
+                        print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
+                        (sys.stdout if line.startswith('{') else sys.stderr).flush()
+                reader = threading.Thread(target=relay, daemon=True)
                 reader.start()
                 status = 0
                 while True:
@@ -459,9 +538,6 @@ def launch_ranks(args, argv):
     finally:
         for sg, h in old_handlers.items():
             signal.signal(sg, h)
-    for line in b''.join(c for c in chunks if c).decode(errors='replace').splitlines():
-        # stdout carries the record only; library chatter (gloo / RCCL print banners to stdout) -> stderr
-        print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
     sys.stdout.flush()
     return status
 
@@ -502,6 +578,9 @@ def spawn_check(args):
         import time
         open(os.environ['CTGAN_TEST_PID_FILE'] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))
         time.sleep(600)
+    if args.leg is not None and os.environ.get('CTGAN_TEST_HANG_LEG') == os.environ.get('RANK'):   # launcher test: this rank of the LEG never joins
+        import time
+        time.sleep(600)
     rank, world, local = init_ranks(args.backend or 'gloo')
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
@@ -510,11 +589,22 @@ def spawn_check(args):
         dist.all_reduce(t)
     backend, rccl = dist_info(world)
     if rank == 0:
-        print(json.dumps({'spawn_check': True, 'n_gpus': world, 'rank_sum': t.item(), 'backend': backend, 'rccl_world': rccl,
-                          'local_rank': local, 'master_port': os.environ.get('MASTER_PORT')}))
+        rec = {'spawn_check': True, 'n_gpus': world, 'rank_sum': t.item(), 'backend': backend, 'rccl_world': rccl,
+               'local_rank': local, 'master_port': os.environ.get('MASTER_PORT')}
+        if args.leg is not None:
+            rec['leg'] = args.leg
+        print(json.dumps(rec))
+        sys.stdout.flush()
     if world > 1:
+        # the A/B-leg mechanism of the training bench, exercised without a GPU (tests/test_bench_launcher.py): fresh rank groups AFTER the record
+        legs = ['spawn'] if (args.leg is None and not args.no_ab_legs and os.environ.get('CTGAN_TEST_SPAWN_LEG')) else []
+        ports = pick_ports(len(legs), rank)
         dist.barrier()
         dist.destroy_process_group()
+        if legs:
+            if not args.backend:
+                args.backend = 'gloo'
+            run_ab_legs(args, rank, world, legs, ports, 1, extra=['--spawn-check'])
 
 
 def run_unconditional(args):

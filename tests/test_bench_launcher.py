@@ -99,3 +99,34 @@ def test_sigterm_to_the_launcher_ends_its_ranks(tmp_path):
         if p.poll() is None:
             p.kill()
             p.wait()
+
+
+def test_ab_legs_start_after_the_record_and_a_hanging_leg_cannot_cost_it():
+    """N > 1: the record is printed - and relayed by the launcher - BEFORE any A/B leg starts; a leg is a fresh group of rank
+    processes started by the ranks of the finished main run, and one that hangs is killed after --leg-timeout while the run still exits 0
+    with its one record line.  (--spawn-check: the same run_ab_legs / pick_ports code as the training bench, without a GPU.)"""
+    import time
+    r = _run('--gpus', '2', '--backend', 'gloo', '--spawn-check', env={'CTGAN_TEST_SPAWN_LEG': '1'})
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['rank_sum'] == 3.0, r.stdout
+    legs = [ln for ln in r.stderr.splitlines() if ln.startswith('bench: leg spawn: ')]
+    assert len(legs) == 1, r.stderr[-2000:]
+    leg = json.loads(legs[0][len('bench: leg spawn: '):])
+    assert leg['leg'] == 'spawn' and leg['rank_sum'] == 3.0 and leg['master_port'] != json.loads(lines[0])['master_port']     # its own rendezvous
+    # rank 1 of the leg never joins: both leg processes are killed at the timeout, the main record is untouched, exit status 0
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    e.update(CTGAN_TEST_SPAWN_LEG='1', CTGAN_TEST_HANG_LEG='1')
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--spawn-check', '--leg-timeout', '8'],
+                         env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    first = p.stdout.readline()                       # arrives while the leg is still hanging
+    t_rec = time.time() - t0
+    out, err = p.communicate(timeout=120)
+    t_all = time.time() - t0
+    assert json.loads(first)['rank_sum'] == 3.0
+    assert p.returncode == 0, err[-2000:]
+    assert t_all - t_rec > 6.0, (t_rec, t_all)        # the record was out (at least) the leg's timeout before the run ended
+    legs = [ln for ln in err.splitlines() if ln.startswith('bench: leg spawn: ')]
+    assert len(legs) == 1 and 'killed after --leg-timeout' in legs[0], err[-2000:]
+    assert [ln for ln in out.splitlines() if ln.startswith('{')] == []
