@@ -269,8 +269,33 @@ def main():
                      'path': 'tflib.cifar10.EpochFeed (synthetic uint8, %d images) -> int32 pinned ring -> H2D copy stream, two iterations deep -> staging kernel' % n_img}
 
     roofline = None
+    step_clock = None
     if not args.no_roofline and rank == 0:
+        if eng.graphed and world == 1:
+            step_clock, it = measure_step_clock(eng, it, next_batch, K, torch)
         roofline = measure_roofline(trainer, next_batch, K, torch, ms_per_step)
+        if roofline is not None and world == 1:
+            try:
+                # the critic-step launch of the dominant kernel: its five launches of the iteration are the largest same-FLOPs group
+                fl_c = roofline.pop('_critic_launch_flops', None)
+                ins = measure_in_situ(trainer, eng, batches, K, torch, roofline['kernel'], fl_c, it) if fl_c else None
+            except Exception as e:          # noqa: BLE001  (report, never fail the record over the cross-check)
+                ins = {'error': '%s: %s' % (type(e).__name__, e)}
+            if ins is not None and ins.get('us_per_launch'):
+                br = roofline.pop('_critic_launch_bracket_us', None)
+                ins['frac'] = round(ins['tflops'] / roofline['peak'], 4)
+                ins['bracket_us_same_launch'] = round(br, 2) if br else None
+                if br:
+                    ins['bracket_vs_in_situ_pct'] = round(100.0 * (br - ins['us_per_launch']) / ins['us_per_launch'], 1)
+                    ins['crosscheck'] = 'ok' if abs(ins['bracket_vs_in_situ_pct']) <= 10.0 else 'FAIL: the event bracket and the in-graph difference disagree by more than 10 %'
+                if step_clock and step_clock.get('sclk_mhz'):
+                    ins['frac_at_loop_clock'] = round(ins['tflops'] / (roofline['peak'] * step_clock['sclk_mhz'] / NOMINAL_MHZ), 4)
+            roofline['in_situ'] = ins
+            if ins and str(ins.get('crosscheck', '')).startswith('FAIL'):
+                print('bench: roofline cross-check: %r' % (ins,), file=sys.stderr)
+        if roofline is not None:
+            roofline.pop('_critic_launch_flops', None); roofline.pop('_critic_launch_bracket_us', None)
+            roofline['loop_clock'] = step_clock
     # the same loop with every layer on the fp32 MFMA family (no split-mode routing), for comparison: a second engine, same warm-up and
     # step counts, same clock (the comparison used to be 10 / 50 steps on wall clock against 20 / 100 with a p50)
     fp32_only = None
@@ -745,6 +770,66 @@ def pipe_of(variant):
 
 
 PIPE_PEAK = {'bf16x6': PEAK_16BIT_MFMA_TFLOPS / 6.0, '16bit': PEAK_16BIT_MFMA_TFLOPS, 'f32': PEAK_F32_MFMA_TFLOPS}
+NOMINAL_MHZ = 2400.0                  # the clock the guide's peaks are quoted at
+
+
+def measure_in_situ(trainer, eng, batches, K, torch, sym, flops_critic, it):
+    """The dominant kernel's time WHERE IT RUNS - inside the replayed critic-step graph, behind the step's own launches, at the clock the
+    loop sustains: a second capture of the same step with the filter-column weight-gradient kernel launched twice (K.WGRAD_GROUP_EXTRA;
+    same operands, same result), replayed in alternation with the step's own graph; the difference of the two replay times is one launch.
+    Cross-checks the HIP-event bracket of the instrumented eager iteration (0.427 on the driver's line vs 0.540 in
+    profiles/ with nothing in the record to tell a slow box from a mis-timed bracket)."""
+    import ctgan_amd.engine as E
+    from ctgan_amd.engine import GraphedTrainer
+    if not sym.startswith('wgrad16c_group_kernel') or not eng.graphed or eng.d_graph is None:
+        return None
+    old_it = E.ITERATION_GRAPH
+    try:
+        E.ITERATION_GRAPH = False
+        K.WGRAD_GROUP_EXTRA = 1
+        eng2 = GraphedTrainer(trainer, use_graphs=True, ar_in_graph=False)
+    finally:
+        K.WGRAD_GROUP_EXTRA = 0
+        E.ITERATION_GRAPH = old_it
+    if not eng2.graphed:
+        return {'error': eng2.graph_error}
+    real, labels = batches[0]
+    fake = trainer.generate_fakes(labels)[0]
+    n, rounds = 10, 7
+    times = {0: [], 1: []}
+    for r in range(rounds + 1):
+        for which, e in ((0, eng), (1, eng2)):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e._stage_d_inputs(real, labels, fake)
+            e0.record()
+            for _ in range(n):
+                e.d_graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            if r:                                   # (round 0: warm-up of both graphs)
+                times[which].append(e0.elapsed_time(e1) * 1e3 / n)
+    trainer.d_opt.t += 2 * n * (rounds + 1)
+    eng._weights_moved('Discriminator')
+    del eng2
+    m0 = sorted(times[0])[rounds // 2]; m1 = sorted(times[1])[rounds // 2]
+    us = m1 - m0
+    return {'us_per_launch': round(us, 2), 'critic_step_graph_us': round(m0, 2), 'with_second_launch_us': round(m1, 2), 'replays': n * rounds,
+            'tflops': round(flops_critic / us / 1e6, 2) if us > 0 else None,
+            'what': 'median replay time of the critic-step graph captured with the kernel launched twice - median of the step\'s own graph (alternating, 7 x 10 replays each)'}
+
+
+def measure_step_clock(eng, it, next_batch, K, torch, iters=8):
+    """Average shader clock over `iters` replayed iterations (one K.ClockProbe wave on a side stream around the loop)."""
+    eng.train_iteration(it, next_batch); it += 1
+    torch.cuda.synchronize()
+    with K.ClockProbe(cap_ms=1500.0) as pr:
+        for _ in range(iters):
+            eng.train_iteration(it, next_batch); it += 1
+    torch.cuda.synchronize()
+    mhz, us, seen = pr.result()
+    return ({'sclk_mhz': round(mhz, 1), 'iterations': iters, 'probe_ms': round(us / 1e3, 2), 'nominal_mhz': NOMINAL_MHZ,
+             'note': 's_memtime cycles / s_memrealtime (100 MHz) of a one-wave probe spanning the replayed iterations: the average shader clock of the loop'}
+            if seen else {'error': 'probe gave up before the loop ended'}), it
 
 
 def load_pmc_traffic():
@@ -780,26 +865,42 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
         trainer.train_iteration(1, next_batch)         # eager warm-up (lazy allocations)
         torch.cuda.synchronize()
         K.PROFILE = []
+        K.PROFILE_CLOCKS = []
         K.PROFILE_REPS = 4          # each (idempotent) conv launch runs 4x inside its event bracket: amortises the event overhead
         try:
             trainer.train_iteration(1, next_batch)
             torch.cuda.synchronize()
             prof = K.PROFILE
+            clocks = [(sym_, fl_) + pr.result() for sym_, fl_, pr in K.PROFILE_CLOCKS]
         finally:
             K.PROFILE = None
+            K.PROFILE_CLOCKS = []
             K.PROFILE_REPS = 1
     finally:
         trainer.world = saved_world
     agg = {}
     wide = {}          # few-channel kernels (csrc/fewch.hip) stream the wide tensor once: they are rated against HBM, not against a matrix pipe
+    # launches of one symbol on one problem (same shape, same FLOPs) are repeats of the same measurement - the five critic steps of the
+    # iteration: each such group enters with its MEDIAN bracket (one slow bracket must not move the line)
+    same = {}
+    for name, flops, e0, e1, reps, _shape, sym in prof:
+        same.setdefault((sym, round(flops), tuple(_shape)), []).append(e0.elapsed_time(e1) * 1e-3 / reps)
+    med = {k: sorted(v)[len(v) // 2] for k, v in same.items()}
     for name, flops, e0, e1, reps, _shape, sym in prof:
         a = agg.setdefault(sym, [0, 0.0, 0.0, set()])
-        a[0] += 1; a[1] += flops; a[2] += e0.elapsed_time(e1) * 1e-3 / reps
+        a[0] += 1; a[1] += flops; a[2] += med[(sym, round(flops), tuple(_shape))]
         a[3].add(name.replace(',ph4', '').split(',split')[0].rstrip('>') + ('>' if '<' in name else ''))
         if name.startswith('fewch') and len(_shape) == 8:
             n_, c_, h_, w_, k_, _r, st_, _up = _shape
             px = (h_ // st_) * (w_ // st_) if k_ > c_ else h_ * w_          # pixels of the wide side (output grid when it is the output)
             wide[sym] = wide.get(sym, 0.0) + 4.0 * n_ * px * max(c_, k_)
+    # shader clock per symbol: the probe's cycles / its wall time, summed over the symbol's brackets whose probe ended on the flag
+    clk = {}
+    for sym_, fl_, mhz, us, seen in clocks:
+        if seen and us > 0:
+            c = clk.setdefault(sym_, [0.0, 0.0])
+            c[0] += mhz * us; c[1] += us
+    clk = {k: v[0] / v[1] for k, v in clk.items() if v[1] > 0}
     if not agg:
         return None
     total_t = sum(a[2] for a in agg.values())
@@ -835,11 +936,22 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
                    'share_of_conv_time': round(v[1] / total_t, 3),
                    'share_of_step_time': round(v[1] * 1e3 / ms_per_step, 3) if ms_per_step else None}
                for k, v in sorted(pipes.items(), key=lambda kv: -kv[1][1])}
+    # the dominant symbol's most frequent problem = its critic-step launch (five per iteration)
+    grp = max(((k_, ts) for k_, ts in same.items() if k_[0] == sym), key=lambda kv: (len(kv[1]), kv[0][1]))
+    sclk = clk.get(sym)
+    brackets = sorted(1e6 * t for (s_, f_, sh_), ts in same.items() if s_ == sym for t in ts)
     return {
         'bound': 'mfma', 'kernel': sym, 'variant': sorted(variants), 'pipe': pipe, 'launches': cnt,
         'flops_per_launch': round(fl / cnt / 1e9, 3), 'avg_launch_us': round(tt / cnt * 1e6, 2),
         'achieved': round(achieved, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
         'frac': round(achieved / peak, 4), 'traffic': traffic_of(sym, fl / cnt),
+        # the shader clock this kernel ran at inside its brackets (K.ClockProbe: s_memtime cycles / s_memrealtime) and the fraction against
+        # the peak AT that clock: peak is quoted at 2.4 GHz, the chip clocks to its power budget (MI355X_MICROARCH.md, "DVFS give-back")
+        'sclk_mhz': round(sclk, 1) if sclk else None,
+        'frac_at_measured_clock': round(achieved / (peak * sclk / NOMINAL_MHZ), 4) if sclk else None,
+        '_critic_launch_flops': float(grp[0][1]), '_critic_launch_bracket_us': 1e6 * med[grp[0]],
+        'bracket_us': {'n': len(brackets), 'min': round(brackets[0], 2), 'median': round(brackets[len(brackets) // 2], 2), 'max': round(brackets[-1], 2),
+                       'note': 'every HIP-event bracket of this symbol in the instrumented iteration; launches on the same problem enter avg_launch_us with their median'},
         'peak_note': ('dense bf16 MFMA peak / 6: a split-mode kernel issues six bf16 MFMAs per fp32 product' if pipe == 'bf16x6' else
                       ('dense 16-bit MFMA peak' if pipe == '16bit' else 'fp32 MFMA peak')),
         'kernel_share_of_conv_time': round(tt / total_t, 3),
@@ -849,6 +961,7 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
                              'note': 'mixed pipes: see by_pipe for the roofline fractions'},
         'by_kernel': {k: {'launches': v[0], 'avg_launch_us': round(v[2] / v[0] * 1e6, 2), 'tflops': round(v[1] / v[2] / 1e12, 2), 'ms': round(v[2] * 1e3, 3),
                           'frac': round(v[1] / v[2] / 1e12 / PIPE_PEAK[pipe_of(sorted(v[3])[0])], 4), 'pipe': pipe_of(sorted(v[3])[0]),
+                          'sclk_mhz': round(clk[k], 1) if k in clk else None,
                           'variant': sorted(v[3]), 'traffic': traffic_of(k, v[1] / v[0]),
                           **({'hbm': {'wide_tensor_bytes_per_launch': round(wide[k] / v[0]), 'achieved_GBps': round(wide[k] / v[2] / 1e9, 1),
                                       'peak_GBps': 8000.0, 'frac': round(wide[k] / v[2] / 8e12, 4),

@@ -29,6 +29,8 @@ def _conv_flops(g, N):
 
 
 PROFILE_REPS = 1          # bench.py's roofline pass repeats each (idempotent) conv launch inside its event bracket
+PROFILE_CLOCKS = []       # (device symbol, flops, ClockProbe) of the brackets that carry a shader-clock probe (the grouped weight gradient)
+WGRAD_GROUP_EXTRA = 0     # bench.py: extra launches of the filter-column weight-gradient kernel per grouped call (in-situ timing by difference)
 
 
 def _timed(g, N, launch):
@@ -41,11 +43,13 @@ def _timed(g, N, launch):
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     st = torch.cuda.current_stream()
-    e0.record(st)
-    for _ in range(PROFILE_REPS):
-        launch()
-    e1.record(st)
+    with ClockProbe() as probe:           # (the shader clock over the bracket: a one-wave kernel on a side stream)
+        e0.record(st)
+        for _ in range(PROFILE_REPS):
+            launch()
+        e1.record(st)
     PROFILE.append((last_kernel(), _conv_flops(g, N), e0, e1, PROFILE_REPS, (N, g.C, g.H, g.W, g.K, g.R, g.stride, int(g.x_up)), last_symbol()))
+    PROFILE_CLOCKS.append((last_symbol(), _conv_flops(g, N), probe))
 
 
 def _stream():
@@ -775,6 +779,10 @@ def conv_wgrad_group(groups):
             raise NotImplementedError('conv2d16_wgrad_group: unsupported group')
         ws3 = workspace(nb3, dev)
         if PROFILE is None:
+            for _ in range(WGRAD_GROUP_EXTRA):
+                # bench.py's in-situ timing: the filter-column kernel launched once more (same operands, same result) - the replay time of a
+                # step graph captured with this switch minus that of the step's own graph = the kernel's time where it runs
+                check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1 | 16, _stream()), 'conv2d16_wgrad_group')
             check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 3, _stream()), 'conv2d16_wgrad_group')
         else:
             st = torch.cuda.current_stream()
@@ -787,13 +795,15 @@ def conv_wgrad_group(groups):
                 # (a spin of ~0.1 ms in front of the bracket: the host has recorded e0 and submitted the launch before the device gets there -
                 # on an idle queue the bracket would include the host's submission time)
                 torch.cuda._sleep(200000)
-                e0.record(st)
-                check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1 | (16 << which), _stream()), 'conv2d16_wgrad_group')
-                e1.record(st)
+                with ClockProbe() as probe:
+                    e0.record(st)
+                    check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 1 | (16 << which), _stream()), 'conv2d16_wgrad_group')
+                    e1.record(st)
                 mask = int(lib.ctgan_debug_last_wgrad_group_col_mask())
                 flops = sum(f for k, f in enumerate(fl) if bool((mask >> k) & 1) == (which == 0))
                 if flops:
                     PROFILE.append((last_kernel(), flops, e0, e1, 1, ('group', len(x3)), last_symbol()))
+                    PROFILE_CLOCKS.append((last_symbol(), flops, probe))
             check(lib.ctgan_conv2d16_wgrad_group(arr3, len(x3), code, _ptr(ws3), ws3.numel(), 2, _stream()), 'conv2d16_wgrad_group')
         if not rest:
             return
@@ -897,6 +907,47 @@ if os.environ.get('CTGAN_X3_S2FWD') in ('0', '2'):   # (bench A/B: the strided f
 def debug_last_wgrad_group_kinds():
     """Tests only: bit 0 = the last grouped 16-bit weight-gradient call launched the filter-column kernel, bit 1 = the slice kernel."""
     return int(lib.ctgan_debug_last_wgrad_group_kinds())
+
+
+class ClockProbe:
+    """bench.py's roofline leg: the shader clock the chip sustains while the launches inside the `with` block run.
+
+        with K.ClockProbe() as p:
+            <launches on the current stream>
+        torch.cuda.synchronize(); p.mhz()
+
+    A one-wave kernel (ctgan_debug_clock_probe) on a side stream reads s_memrealtime (constant 100 MHz) and s_memtime (shader cycles) when
+    the block is entered - the side stream waits for an event recorded there - and again when the current stream reaches the end of the
+    block (a flag it sets), at the latest after `cap_ms`: it cannot outlive that even if both streams share a hardware queue."""
+    _side = None
+
+    def __init__(self, cap_ms=50.0):
+        self.cap_ticks = int(cap_ms * 1e5)
+
+    def __enter__(self):
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if ClockProbe._side is None:
+            ClockProbe._side = torch.cuda.Stream()
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.out = torch.zeros(5, dtype=torch.int64, device=dev)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ClockProbe._side.wait_event(ev)
+        check(lib.ctgan_debug_clock_probe(_ptr(self.flag), self.cap_ticks, _ptr(self.out), ctypes.c_void_p(ClockProbe._side.cuda_stream)), 'clock_probe')
+        return self
+
+    def __exit__(self, *exc):
+        self.flag.fill_(1)                 # on the current stream, after the block's launches
+        return False
+
+    def result(self):
+        """(shader MHz, region microseconds, flag_seen) - call after a synchronize."""
+        r0, s0, r1, s1, seen = [int(v) for v in self.out.cpu().tolist()]
+        dr = max(r1 - r0, 1)
+        return 100.0 * (s1 - s0) / dr, dr / 100.0, bool(seen)
+
+    def mhz(self):
+        return self.result()[0]
 
 
 def colsum_channels(gy):

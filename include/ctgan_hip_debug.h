@@ -8,6 +8,8 @@
 #ifndef CTGAN_HIP_DEBUG_H
 #define CTGAN_HIP_DEBUG_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -36,6 +38,11 @@ void ctgan_debug_m2f_px(int on);
 int ctgan_debug_last_wgrad_group_kinds(void);
 /* ... and which members (bit i = groups[i]) rode the filter-column kernel                                                             */
 unsigned ctgan_debug_last_wgrad_group_col_mask(void);
+/* bench.py's roofline leg: a one-wave kernel that reads s_memrealtime (constant 100 MHz) and s_memtime (shader cycles) when it starts, polls
+   `*flag` (device int32; may be NULL) and reads both again when the flag is non-zero or after max_real_ticks (100 MHz ticks, <= 2 s): launched on a
+   SIDE stream next to a measured launch, out[0..3] = real0, shader0, real1, shader1 give the shader clock sustained over that launch
+   (d shader / d real x 100 MHz); out[4] = 1 when the flag ended the wait.  `out`: five uint64 in device memory. */
+int ctgan_debug_clock_probe(const int* flag, uint64_t max_real_ticks, uint64_t* out, void* stream);
 
 #ifdef __cplusplus
 }

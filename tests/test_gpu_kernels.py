@@ -1102,3 +1102,31 @@ def test_launches_folded_into_their_neighbours_for_the_hand_scheduled_critic_ste
     ga2 = ga.clone()
     slopes = K.gp_finish(ga2, gs, 0.25)
     assert torch.allclose(ga2, want, rtol=1e-6, atol=1e-7) and torch.allclose(slopes, s_ref, rtol=1e-6)
+
+
+def test_clock_probe_reports_a_plausible_shader_clock_and_never_outlives_its_cap():
+    """K.ClockProbe (bench.py's roofline leg): s_memtime cycles / s_memrealtime over a bracketed region on a side stream.  Around real
+    launches the clock is a shader clock of this part (0.1 .. 2.5 GHz) and the probe ends on the region's flag; a probe whose region never
+    ends (the flag is not set) gives up at its cap instead of hanging."""
+    import time
+    import ctgan_amd.kernels as K
+    from ctgan_amd.kernels import ConvGeom
+    g = ConvGeom(128, 16, 16, 128, 3, 3, 1)
+    x = K.empty_cl(192, 128, 16, 16, 'cuda').normal_()
+    w = torch.randn(3, 3, 128, 128, device='cuda') * 0.05
+    K.conv_fwd(x, w, None, g)
+    torch.cuda.synchronize()
+    with K.ClockProbe() as p:
+        for _ in range(8):
+            K.conv_fwd(x, w, None, g)
+    torch.cuda.synchronize()
+    mhz, us, seen = p.result()
+    assert seen and 100.0 < mhz < 2500.0 and 20.0 < us < 50000.0, (mhz, us, seen)
+    # a region that never signals: the probe returns after its cap (5 ms here), not at the flag
+    pr = K.ClockProbe(cap_ms=5.0)
+    pr.__enter__()
+    t0 = time.time()
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 2.0
+    mhz, us, seen = pr.result()
+    assert not seen and 4000.0 < us < 50000.0
