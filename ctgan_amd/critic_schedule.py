@@ -179,6 +179,9 @@ def critic_step(tr, R, real_int, labels, fake, early=None):
     G.wgrad('Discriminator.1.Shortcut', pool_x[:m], g_h1[:m], Wsc1, gsc1, False, True)
     x4 = both.reshape(N3, 3, 32, 32)
     G.wgrad('Discriminator.1.Conv1', x4[:m], g_y1[:m], W11, g11, False, True)
+    # every (x, dy) pair of the dropout-pass rows exists: their weight gradients go to a side stream now, under the penalty's double backward
+    # (phase C: a dependent chain of 64-row launches that leaves most of the chip idle); phase C's own segments join them at the final flush
+    F.flush_async()
     # the chain's end on the penalty rows: dD/dx_hat through the first conv and through the pooled shortcut (:146-153)
     gx = _dgrad(g_y1[m:], W11, g11, B, out_strides=(3072, 1024, 32, 1))
     slopes = K.gp_finish(gx, _dgrad(g_h1[m:], Wsc1, gsc1, B), 0.25)      # += the shortcut's gradient through the 2x2 mean pool; per-sample norms

@@ -61,7 +61,11 @@ def weight_grads(enabled):
 # returns the (still empty) result buffer, later requests of the same filter return None, and on exit every filter
 # gets ONE multi-segment launch (K.conv_wgrad_multi) that sums its uses - the dropout passes and the gradient-penalty
 # double backward - instead of one wgrad + reduction per use and an autograd `add` per extra use.
-_DEFER = {'on': False, 'groups': None, 'post': None, 'imm': None}      # imm: filters whose first use of the step was launched at once
+_DEFER = {'on': False, 'groups': None, 'post': None, 'imm': None, 'join': None}      # imm: filters whose first use of the step was launched at once
+# A/B switch: the hand-scheduled critic step launches the weight gradients of the dropout-pass rows on a SIDE stream as soon as its backward
+# chain has produced them, under the (latency-bound, 64-row) launches of the penalty's double backward (flush_async)
+WGRAD_OVERLAP = _os.environ.get('CTGAN_WGRAD_OVERLAP', '1') != '0'
+_SIDE = {}
 DEFER_WGRADS = _os.environ.get('CTGAN_DEFER_WGRADS', '1') != '0'
 # A/B switch: the few-channel weight gradients (first critic conv / shortcut) are queued too: both uses of a filter in one launch
 FEWCH_DEFER = _os.environ.get('CTGAN_FEWCH_DEFER', '1') != '0'
@@ -89,13 +93,16 @@ def deferred_wgrads():
     if not DEFER_WGRADS or _DEFER['on']:
         yield
         return
-    _DEFER.update(on=True, groups={}, post=[], imm=set())
+    _DEFER.update(on=True, groups={}, post=[], imm=set(), join=None)
     try:
         yield
     finally:
-        groups, post = _DEFER['groups'], _DEFER['post']
-        _DEFER.update(on=False, groups=None, post=None, imm=None)
+        groups, post, join = _DEFER['groups'], _DEFER['post'], _DEFER['join']
+        _DEFER.update(on=False, groups=None, post=None, imm=None, join=None)
+        if join is not None and join[0] is not None:       # the early launch on the side stream (flush_async) wrote the buffers the flush below accumulates onto
+            torch.cuda.current_stream().wait_event(join[0])
         _flush_groups(list(groups.values()))
+        join = None                             # (the early launch's operands were kept alive until here)
         folds = [e[1:] for e in post if isinstance(e, tuple) and e[0] == 'fold']
         if folds:
             K.filter_fold_batch(folds)               # every spread-filter gradient of the step folded in one launch
@@ -115,6 +122,8 @@ def flush_partial(keys):
     part = [groups.pop(k) for k in keys if k in groups]
     if not part:
         return
+    if _DEFER['join'] is not None and _DEFER['join'][0] is not None:
+        torch.cuda.current_stream().wait_event(_DEFER['join'][0])         # (flush_async's launch wrote what this one accumulates onto)
     _flush_groups(part)
     bufs = {id(g.dw) for g in part}
     post, keep = _DEFER['post'], []
@@ -128,6 +137,46 @@ def flush_partial(keys):
     if folds:
         K.filter_fold_batch(folds)
     _DEFER['imm'].update(keys)          # a stray later use of one of these filters is launched at once instead of re-opening its queue
+
+
+def flush_async():
+    """Inside deferred_wgrads(): launch NOW, on a side stream, every weight gradient queued so far (the filters of the grouped MFMA launch;
+    the few-channel filters stay queued), and keep their queues open: segments requested later are accumulated onto these results by the
+    flush at the end of the block (the in-place form of the grouped launch, as for a first use the split-mode kernel took at request time).
+
+    For a step whose remaining launches do not fill the chip: the hand-scheduled critic step calls it when its backward chain has produced
+    the (x, dy) pairs of the dropout-pass rows - 3B / 2B rows per filter, ~0.24 ms of matrix work - and the penalty's double backward, a
+    dependent chain of ~20 launches on the B x_hat rows (0.3 ms, none of them wider than 256 workgroups), is still to come: the two
+    run side by side instead of one after the other.  Under hipGraph capture the side stream is forked into the capture (event wait) and
+    joined by the final flush.  No-op outside CUDA / with the switch off."""
+    if not (_DEFER['on'] and WGRAD_OVERLAP) or _DEFER['join'] is not None:
+        return False
+    grps = [g for g in _DEFER['groups'].values() if g.segs and not g.pre and not K.fewch_handles(g.g)]
+    if len(grps) < 2:
+        return False
+    dev = grps[0].segs[0][0].device
+    if dev.type != 'cuda':
+        _flush_groups(grps)                      # (the CPU stand-ins of the test suite: same two-part flush, no streams)
+        done = None
+    else:
+        side = _SIDE.get(dev.index)
+        if side is None:
+            side = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            _flush_groups(grps)
+            done.record(side)
+    keep = []
+    for g in grps:
+        keep.append(g.segs)                      # operands stay referenced until the join: the allocator must not hand their memory to a
+        g.inplace_b = g.inplace_b or _seg_bias(g)        # launch of the main stream while the side stream still reads it
+        g.segs = []
+        g.inplace = True
+    _DEFER['join'] = (done, keep)
+    return True
 
 
 def _seg_bias(grp):
