@@ -109,7 +109,7 @@ class GraphedTrainer:
         # the critic's weights change between replays (its Adam step): its derived filter layouts must be rebuilt INSIDE
         # this graph - all of them in one or two launches.  The generator's are not used here (fake batches are inputs).
         lib.bump_epoch('Discriminator' if self.batch_fakes else None)
-        F.prepare_filters()
+        prep_done = F.prepare_filters_async()        # on a side stream, under the step's input staging and first (few-channel) conv
         t.rng.begin_step()
         handed = [0]
         early = None
@@ -120,6 +120,8 @@ class GraphedTrainer:
             def early(gpart):
                 handed[0] = t.early_reduce(gpart)
         out, grads = t.d_grads(real, labels, fake=fake, early=early)
+        if prep_done is not None:
+            torch.cuda.current_stream().wait_event(prep_done)       # (every consumer has waited already; the fork is joined whatever the step routed)
         self._finish(t.d_opt, grads, lo=handed[0])
         return {k: out[k].detach() for k in ('cost', 'wgan', 'acgan', 'acc_real', 'acc_fake', 'ct', 'gp') if out.get(k) is not None}
 

@@ -64,7 +64,7 @@ def weight_grads(enabled):
 _DEFER = {'on': False, 'groups': None, 'post': None, 'imm': None, 'join': None}      # imm: filters whose first use of the step was launched at once
 # A/B switch: the hand-scheduled critic step launches the weight gradients of the dropout-pass rows on a SIDE stream as soon as its backward
 # chain has produced them, under the (latency-bound, 64-row) launches of the penalty's double backward (flush_async)
-WGRAD_OVERLAP = _os.environ.get('CTGAN_WGRAD_OVERLAP', '1') != '0'
+WGRAD_OVERLAP = _os.environ.get('CTGAN_WGRAD_OVERLAP', '0') == '1'
 _SIDE = {}
 DEFER_WGRADS = _os.environ.get('CTGAN_DEFER_WGRADS', '1') != '0'
 # A/B switch: the few-channel weight gradients (first critic conv / shortcut) are queued too: both uses of a filter in one launch
@@ -646,6 +646,37 @@ def prepare_filters():
         _refresh_gemm_filter(key, e)
     if (todo or K._pack16) and (K.MMA_DTYPE is not None or K.X3_HYBRID):       # no 16-bit / split-mode launch can be routed otherwise
         K.prepare_packs()                 # the 16-bit / split-mode images of the parameters and of the filters just rebuilt: one launch
+
+
+# A/B switch: the graphed critic step rebuilds its derived / packed filters on a side stream, under the step's first launches
+PREP_ASYNC = _os.environ.get('CTGAN_PREP_ASYNC', '1') != '0'
+_PREP_SIDE = {}
+
+
+def prepare_filters_async():
+    """prepare_filters() on a SIDE stream forked from the current one; returns the event the caller must make its stream wait for before
+    the step ends (every consumer of a derived filter / packed image waits for it by itself: _cached_filter, kernels._packed16).
+
+    A critic step opens with ~35 us of filter work (the spread / rotated layouts and the split-mode fragment images of the weights its Adam
+    step just changed: filter_batch + pack_batch, 256 workgroups each) while its first launches - input staging and the first conv, a
+    few-channel kernel that reads the fp32 parameter itself - do not need any of it: the two run side by side.  The side stream starts
+    behind everything already on the caller's stream (the previous step's readers of the old images are done)."""
+    if not PREP_ASYNC or not torch.cuda.is_available() or _GEMM_FILTERS:      # (the GEMM-route buffers are refreshed by plain copies: no event of their own)
+        prepare_filters()
+        return None
+    cur = torch.cuda.current_stream()
+    dev = cur.device_index if hasattr(cur, 'device_index') else torch.cuda.current_device()
+    side = _PREP_SIDE.get(dev)
+    if side is None:
+        side = _PREP_SIDE[dev] = torch.cuda.Stream()
+    start = torch.cuda.Event()
+    start.record(cur)
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        side.wait_event(start)
+        prepare_filters()
+        done.record(side)
+    return done
 
 
 def _repacked(w, g, plain=True):

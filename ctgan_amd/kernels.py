@@ -187,6 +187,8 @@ def _packed16(w, d, op, g, mode):
         group = (tflib.group_of(w) if isinstance(w, torch.nn.Parameter) else _STABLE_GROUP.get(w.data_ptr())) if stable else None
     ver = tflib.epoch(group)              # only updates of the filter's own network make its image stale
     if ent is not None and ent[1] == ver:
+        if len(ent) > 7 and ent[7] is not None and w.is_cuda and torch.cuda.current_stream() != ent[7][1]:
+            torch.cuda.current_stream().wait_event(ent[7][0])       # refreshed on another stream (prepare_packs under functional.prepare_filters_async)
         return ent[0]
     if ent is None:
         if not _pack16:
@@ -200,6 +202,8 @@ def _packed16(w, d, op, g, mode):
         print('x3-log pack op%d %s stable=%d cached=%d type=%s shape=%s' % (op, mode, stable, key in _pack16, type(w).__name__, tuple(w.shape)), flush=True)
     check(lib.ctgan_conv2d16_pack_filter(ctypes.byref(d), op, _MMA_CODE[mode], _ptr(w), _ptr(ent[0]), _stream()), 'conv2d16_pack_filter')
     ent[1] = ver
+    if len(ent) > 7:
+        ent[7] = None                     # packed on the consumer's own stream just now
     return ent[0]
 
 
@@ -233,8 +237,18 @@ def prepare_packs():
             ws[i] = w.data_ptr()
             wps[i] = ent[0].data_ptr()
         check(lib.ctgan_conv2d16_pack_batch(descs, ops, n, _MMA_CODE[mode], ws, wps, _stream()), 'conv2d16_pack_batch')
+        mark = None
+        if items[0][0][0].is_cuda:                # (stream, event) of this refresh: a consumer on another stream waits for it (_packed16)
+            st = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(st)
+            mark = (ev, st)
         for ent, _ in items:
             ent[1] = tflib.epoch(ent[6])
+            if len(ent) > 7:
+                ent[7] = mark
+            else:
+                ent.append(mark)
 
 
 def _need_dev(*ts):
