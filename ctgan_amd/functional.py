@@ -649,7 +649,7 @@ def prepare_filters():
 
 
 # A/B switch: the graphed critic step rebuilds its derived / packed filters on a side stream, under the step's first launches
-PREP_ASYNC = _os.environ.get('CTGAN_PREP_ASYNC', '1') != '0'
+PREP_ASYNC = _os.environ.get('CTGAN_PREP_ASYNC', '0') == '1'      # measured: 12.16 -> 12.40 ms per iteration (cross-queue edges in the replayed graph cost more than the 35 us they hide)
 _PREP_SIDE = {}
 
 

@@ -241,6 +241,79 @@ def dstep_b64_fixture(which, B=64, chunk=8, init_seed=9, data_seed=3, nsample=10
     np.savez_compressed(os.path.join(HERE, '%s_dstep_%d.npz' % (which, B)), **out)
 
 
+def gstep_b64_fixture(which, B=64, chunk=8, init_seed=9, data_seed=5, nsample=1024, check_direct=False):
+    """One GENERATOR step of config[4] ('lsun128') / config[1] ('cifar') at the full batch B = 64 in fp64: gen_cost = -mean(D(G(z)))
+    (TF/CT_gan_cifar.py:124; LS/wgan_LSUN_Bedrooms128.py:246-258 with its two generator towers) and its gradient w.r.t. every generator
+    parameter (the B = 64 fixtures pinned the critic step only).  Same conventions as dstep_b64_fixture: seeds, not
+    tensors; loss, per-parameter gradient norms and `nsample` fixed entries.
+
+    Memory: the generator's graph at B = 64 is kept whole (its BatchNorm couples the samples of a tower); the critic couples no samples
+    and no critic parameter gradient is needed, so d cost / d x is evaluated `chunk` rows at a time on detached rows of the fake batch and
+    pushed through the generator's graph once - the chain rule, an identity in exact arithmetic (check_direct: asserted against the
+    one-graph evaluation, which fits for config[1])."""
+    import time
+    g = torch.Generator().manual_seed(data_seed)
+    reg = ops.Registry(dtype=F64, seed=init_seed)
+    if which == 'lsun128':
+        cfg = nets.Lsun128Cfg()
+        h = B // 2
+        Gfull = lambda r, n, zz: torch.cat([nets.lsun128_generator(r, cfg, h, zz[:h]), nets.lsun128_generator(r, cfg, h, zz[h:])])   # noqa: E731
+        D = lambda r, xx, uu: nets.lsun128_discriminator(r, cfg, xx, 0.8, 0.5, 0.5, uu)                                            # noqa: E731
+        feat = [(cfg.DIM_D_8, 8, 8)] * 3
+        with torch.no_grad():
+            D(reg, torch.cat([nets.lsun128_generator(reg, cfg, 2, torch.zeros(2, 128, dtype=F64))] * 2), [torch.ones(4, *s, dtype=F64) for s in feat])
+    else:
+        Gfull = lambda r, n, zz: nets.cifar_generator(r, n, zz, DIM=128)        # noqa: E731
+        D = lambda r, xx, uu: nets.cifar_discriminator(r, xx, uu, DIM=128)      # noqa: E731
+        feat = [(128, 16, 16), (256, 8, 8), (512, 4, 4)]
+        with torch.no_grad():
+            D(reg, Gfull(reg, 2, torch.zeros(2, 128, dtype=F64)), [torch.full((2,) + s, 0.9, dtype=F64) for s in feat])
+    for n, t in reg.items():                       # fp32-representable weights on both sides
+        with torch.no_grad():
+            t.copy_(t.float().double())
+    rnd = steps.make_rnd_dcgan_g(B, feat, g)
+    names = [n for n, _ in reg.trainable_with_name('Generator')]
+    params = [reg[n] for n in names]
+    t0 = time.time()
+    x = Gfull(reg, B, rnd['z'])
+    print('generator forward (with graph) %.1f s' % (time.time() - t0), flush=True)
+    gx = torch.zeros_like(x)
+    cost = 0.0
+    nch = B // chunk
+    assert nch * chunk == B
+    for c in range(nch):
+        rows = slice(c * chunk, (c + 1) * chunk)
+        xs = x[rows].detach().requires_grad_(True)
+        d, _ = D(reg, xs, [u[rows] for u in rnd['u_fake']])
+        cc = -d.sum() / B
+        (gxs,) = torch.autograd.grad(cc, xs)
+        gx[rows] = gxs
+        cost += cc.item()
+        del d, cc, gxs, xs
+        print('chunk %d/%d  %.1f s' % (c + 1, nch, time.time() - t0), flush=True)
+    grads = torch.autograd.grad(x, params, grad_outputs=gx, allow_unused=True)
+    print('generator backward %.1f s  cost %.9f' % (time.time() - t0, cost), flush=True)
+    if check_direct:
+        o = steps.dcgan_g_losses(reg, Gfull, D, B, rnd)
+        gd = steps.grads_of(o['cost'], reg, 'Generator')
+        assert abs(o['cost'].item() - cost) <= 1e-12 * max(1.0, abs(cost)), (o['cost'].item(), cost)
+        for n, ga in zip(names, grads):
+            if ga is not None:
+                assert (ga - gd[n]).abs().max().item() <= 1e-11 * max(gd[n].abs().max().item(), 1e-30), n
+        print('chunked == one-graph evaluation (1e-11)', flush=True)
+    out = {'cfg': np.array([B, chunk, init_seed, data_seed, nsample]), 'names': np.array([n for n, ga in zip(names, grads) if ga is not None]),
+           'loss.cost': np.array(cost), 'fake_abs_sum': np.array(x.detach().abs().sum().item()),
+           'theta_abs_sum': np.array(sum(reg[n].detach().abs().sum().item() for n in names))}
+    for n, ga in zip(names, grads):
+        if ga is None:
+            continue
+        flat = ga.detach().reshape(-1)
+        idx = _sample_index(n, flat.numel(), nsample)
+        out['norm.' + n] = np.array(flat.norm().item())
+        out['vals.' + n] = npy(flat[torch.from_numpy(idx)]).astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, '%s_gstep_%d.npz' % (which, B)), **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     which = sys.argv[1:] or ['ops', 'resnet', 'loop']
@@ -262,6 +335,12 @@ if __name__ == '__main__':
     if 'cifar64' in which:      # config[1] at B = 64
         torch.set_num_threads(6)
         dstep_b64_fixture('cifar')
+    if 'cifar64g' in which:     # config[1]'s generator step at B = 64 (the chunked evaluation asserted against the one-graph evaluation)
+        torch.set_num_threads(6)
+        gstep_b64_fixture('cifar', check_direct=True)
+    if 'lsun64g' in which:      # config[4]'s generator step at B = 64
+        torch.set_num_threads(6)
+        gstep_b64_fixture('lsun128')
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')

@@ -397,3 +397,52 @@ def test_lsun128_full_width_f16_batch64_d_step_vs_fp64_fixture():
         assert tr.d_opt.skipped() == 0          # no gradient element overflowed fp16 under the loss scale
     finally:
         lib.delete_all_params(); M.configure()
+
+
+@pytest.mark.gpu
+def test_lsun128_full_width_f16_batch64_g_step_vs_fp64_fixture():
+    """configs[4]'s GENERATOR step at its full single-GPU size - reference widths, B = 64 as two towers of 32 (each with its own batch-norm
+    statistics, LS/wgan_LSUN_Bedrooms128.py:215-218), convs on the fp16 matrix cores, loss scale 1024 - against the fp64 oracle's committed
+    fixture tests/golden/lsun128_gstep_64.npz (`make_golden.py lsun64g`: gen_cost and every generator parameter's gradient, 1024 sampled
+    entries each; the oracle pushes d cost / d x through the critic eight rows at a time and through the generator's graph once - the
+    chain rule).  VERDICT r5 weak 1(a).  Bounds: cost 1e-2 of max(1, |cost|); per parameter the gradient norm within 5 %, relative L2 over
+    the sampled entries <= 10 %, cosine >= 0.994 (the critic-step fixture's bounds plus the nine batch norms the gradient crosses)."""
+    import json
+    import os
+    import numpy as np
+    import ctgan_amd.gan_lsun128 as M
+    import ctgan_amd.kernels as K
+    import ctgan_amd.tflib as lib
+    from ctgan_amd.dcgan_step import DCGANTrainer
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lsun128_gstep_64.npz')))
+    B, _chunk, init_seed, data_seed, _ns = [int(v) for v in fx['cfg']]
+    lib.delete_all_params(); lib.set_device(None)
+    M.configure(BATCH_SIZE=B)
+    try:
+        lib.set_seed(init_seed)
+        M.build_params('cuda')
+        tr = DCGANTrainer(M, seed=1)
+        tr.loss_scale = 1024.0
+        assert tr.towers == 2
+        names = [str(n) for n in fx['names']]
+        gnames = [n for n, _ in tr.g_named]
+        assert set(names) <= set(gnames)
+        th = sum(p.detach().double().abs().sum().item() for _, p in tr.g_named)
+        assert abs(th - float(fx['theta_abs_sum'])) <= 1e-9 * th, 'the product drew other initial weights than the fixture'
+        g = torch.Generator().manual_seed(data_seed)
+        rnd = osteps.make_rnd_dcgan_g(B, M.feat_shapes(), g)
+        with K.mma_dtype('f16'):
+            out = tr.g_step({k: _to(v, 'cuda') for k, v in rnd.items()})
+        a, b = out['cost'].item(), float(fx['loss.cost'])
+        assert abs(a - b) <= 1e-2 * max(1.0, abs(b)), (a, b)
+        rows = _fixture_grad_errors(fx, out['grads'], names)
+        worst = max(rows, key=lambda r: r[2])
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/lsun128_f16_B64_gstep_vs_fixture.json', 'w') as f:
+            json.dump({'B': B, 'loss_scale': tr.loss_scale, 'cost': (a, b), 'worst_param': worst[0], 'worst_sample_rel_l2': worst[2],
+                       'its_cosine': worst[3], 'worst_norm_dev': max(r[1] for r in rows), 'adam_skipped': tr.g_opt.skipped(), 'rows': rows}, f, indent=1)
+        for n, dn, e, c in rows:
+            assert dn <= 0.05 and e <= 0.10 and c >= 0.994, (n, dn, e, c)
+        assert tr.g_opt.skipped() == 0
+    finally:
+        lib.delete_all_params(); M.configure()
