@@ -727,11 +727,11 @@ def run_unconditional(args):
         name, (cnt, fl, tt) = max(mm.items(), key=lambda kv: kv[1][2])
         traffic = None
         try:        # HBM-side bytes of this kernel from the committed PMC passes (tools/pmc_run16.sh), scaled by FLOPs to this launch mix
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic_conv16.json'))).get(name)
+            pmc = json.load(open(_profile_path('r02_pmc_traffic_conv16.json'))).get(name)
             if pmc:
                 k = (fl / cnt) / pmc['flops_per_launch']
                 traffic = {'hbm_bytes_per_launch': round(pmc['hbm_bytes_per_launch'] * k), 'algorithmic_bytes_per_launch': round(pmc['algorithmic_bytes_per_launch'] * k),
-                           'source': 'profiles/r02_pmc_traffic_conv16.json (%s; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, scaled to this launch mix)' % pmc['geometry']}
+                           'source': 'profiles/history/r02_pmc_traffic_conv16.json (%s; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, scaled to this launch mix)' % pmc['geometry']}
         except Exception:
             pass
         roofline = {'bound': 'mfma', 'kernel': name, 'launches': cnt, 'flops_per_launch': round(fl / cnt / 1e9, 3),
@@ -832,22 +832,30 @@ def measure_step_clock(eng, it, next_batch, K, torch, iters=8):
             if seen else {'error': 'probe gave up before the loop ended'}), it
 
 
+def _profile_path(fn):
+    """profiles/<fn>, or profiles/history/<fn> (rounds 1-4 were moved there in round 6)."""
+    p = os.path.join(ROOT, 'profiles', fn)
+    return p if os.path.exists(p) else os.path.join(ROOT, 'profiles', 'history', fn)
+
+
 def load_pmc_traffic():
     """profiles/r03_pmc_traffic_x3.json (tools/pmc_x3.sh: separate rocprofv3 --pmc passes, gfx950 corrections of the guide) + the
     round-1 files of the fp32 tiles, keyed by device symbol."""
     out = {}
-    for fn in ('r03_pmc_traffic_x3.json', 'r04_pmc_traffic_x3.json', 'r04_pmc_wgrad_col.json', 'r05_pmc_traffic_x3.json', 'r05_pmc_wgrad_col.json'):      # (later files override earlier ones per symbol; *_wgrad_col: tools/pmc_wgrad_col.sh)
+    for fn in ('r03_pmc_traffic_x3.json', 'r04_pmc_traffic_x3.json', 'r04_pmc_wgrad_col.json', 'r05_pmc_traffic_x3.json', 'r05_pmc_wgrad_col.json',
+               'r06_pmc_traffic_x3.json', 'r06_pmc_wgrad_col.json'):      # (later files override earlier ones per symbol; *_wgrad_col: tools/pmc_wgrad_col.sh)
         try:
-            for sym, rec in json.load(open(os.path.join(ROOT, 'profiles', fn))).items():
+            path = _profile_path(fn)
+            for sym, rec in json.load(open(path)).items():
                 if isinstance(rec, dict) and 'hbm_bytes_per_launch' in rec and 'flops_per_launch' in rec:
-                    out[sym] = dict(rec, file='profiles/' + fn, measured_in_round=int(fn[1:3]))
+                    out[sym] = dict(rec, file=os.path.relpath(path, ROOT), measured_in_round=int(fn[1:3]))
         except Exception:
             pass
     for fn, sym in (('r01_pmc_traffic_64x128.json', 'igemm_fwd_pipe_kernel<1, 4, 1, 2, 1, 1, false, 1>'),
                     ('r01_pmc_traffic.json', 'igemm_fwd_pipe_kernel<2, 2, 1, 2, 2, 1, false, 1>')):
         try:
-            rec = json.load(open(os.path.join(ROOT, 'profiles', fn)))
-            out.setdefault(sym, dict(rec, file='profiles/' + fn, measured_in_round=1))
+            rec = json.load(open(_profile_path(fn)))
+            out.setdefault(sym, dict(rec, file=os.path.relpath(_profile_path(fn), ROOT), measured_in_round=1))
         except Exception:
             pass
     return out
@@ -968,7 +976,7 @@ def measure_roofline(trainer, next_batch, K, torch, ms_per_step=None):
                                       'note': 'HBM-bound kernel: bytes of the wide (128-channel) tensor / time; the MFMA fraction above does not bound it'}}
                              if k in wide else {})}
                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])},
-        'note': 'by_kernel keys are device symbols: look them up in profiles/r05_kernel_stats_resnet.txt / r05_steady_state_resnet.txt '
+        'note': 'by_kernel keys are device symbols: look them up in profiles/r06_kernel_stats_resnet.txt / r06_steady_state_resnet.txt '
                 '(tools/roofline_crosscheck.py prints both side by side)',
     }
 

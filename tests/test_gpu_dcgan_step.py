@@ -191,7 +191,7 @@ def test_cifar_dcgan_bf16_batch64_d_step_vs_fp64_fixture():
     tests/golden/cifar_dstep_64.npz (seeds, loss terms, gradient norms, 1024 sampled entries per parameter; `make_golden.py cifar64`).
     bf16 keeps 8 significant bits per operand (2^-9 relative rounding, 8x fp16's): stated bounds = loss terms 2e-2 of max(1, |term|);
     per parameter the gradient norm within 5 %, relative L2 over the sampled entries <= 10 %, cosine >= 0.994 (measured in round 2 at
-    B = 64 against the fp32 kernels: 4.3-5.8 % / 0.9983, profiles/r02_dcgan16_bf16_errors.json)."""
+    B = 64 against the fp32 kernels: 4.3-5.8 % / 0.9983, profiles/history/r02_dcgan16_bf16_errors.json)."""
     import json
     import os
     import numpy as np

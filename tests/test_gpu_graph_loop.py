@@ -270,7 +270,7 @@ def test_thousand_iteration_curves_track_the_fp64_oracle_as_closely_as_its_own_f
                             'windowed_mean_rel_err_max': {n: float(twin_w[:, j].max()) for j, n in enumerate(names)}}
         with open('gpurun_out/loop_drift.json', 'w') as f:
             json.dump(out, f, indent=1)
-    # Measured (profiles/r02_loop_drift.json): every term within 1e-3 for the first 10 critic steps (2 iterations), 1e-1 ..
+    # Measured (profiles/history/r02_loop_drift.json): every term within 1e-3 for the first 10 critic steps (2 iterations), 1e-1 ..
     # 3e-1 after 100 steps, O(1) pointwise after 1,000 iterations (different trajectory of the same chaotic system); the
     # CURVES agree: 50-iteration window means of cost / wgan within 7 % / 11 %, acgan 0.3 %, ct 3 %, gp 2 %.
     assert rel[:8].max() <= 1e-3, out['max_rel_by_step_decade']

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Copy the summaries of one tools/round_end_call.sh run (gpurun_out/<tag>, gpurun_out/prof_<tag>*, gpurun_out/phase_<tag>, gpurun_out/pmc_*) into
-# profiles/r05_* (the tracked, judged copies).  usage: tools/collect_profiles.sh <tag>
+# profiles/r06_* (the tracked, judged copies).  usage: tools/collect_profiles.sh <tag>
 set -e
-tag=${1:?tag}; o=gpurun_out/$tag; p=profiles; r=r05
+tag=${1:?tag}; o=gpurun_out/$tag; p=profiles; r=r06
 cp $o/tests_all.log $p/${r}_gpu_tests.log
 cp $o/bench.json $p/${r}_bench_resnet.json
 cp $o/bench_defaults.json $p/${r}_bench_resnet_defaults.json
+cp $o/bench_driver_args.json $p/${r}_bench_resnet_driver_args.json
+for v in WGRAD_OVERLAP PREP_ASYNC; do cp $o/bench_$v.json $p/${r}_bench_resnet_$v.json; done
 cp $o/bench_autograd_critic.json $p/${r}_bench_resnet_autograd_critic_step.json
-cp $o/bench_m2f_ring.json $p/${r}_bench_resnet_m2f_ring.json
 cp $o/bench_2rank_gloo.json $p/${r}_bench_resnet_2rank_gloo_one_gpu.json
 cp $o/gp_unit.json $p/${r}_gp_unit.json
 cp $o/phase_times.txt $p/${r}_phase_times.txt
@@ -27,7 +28,8 @@ cp $o/bench_lsun128_f16.json $p/${r}_bench_lsun128_f16.json
 cp $o/bench_lsun128_f32.json $p/${r}_bench_lsun128_f32.json
 cp $o/wgrad_group_bench_col.txt $p/${r}_wgrad_group_bench_col.txt
 cp gpurun_out/fewch_prof.txt $p/${r}_fewch_kernel_times.txt
-cp gpurun_out/pmc_x3/r05_pmc_traffic_x3.json $p/${r}_pmc_traffic_x3.json
+cp gpurun_out/pmc_x3/r06_pmc_traffic_x3.json $p/${r}_pmc_traffic_x3.json
 cp gpurun_out/pmc_wcol/col_summary.json $p/${r}_pmc_wgrad_col.json
-for f in lsun128_f16_B64_vs_fixture.json cifar_dcgan_B64_vs_fixture.json; do [ -f gpurun_out/$f ] && cp gpurun_out/$f $p/${r}_$f; done
+cp $o/bench_2rank_gloo.err $p/${r}_bench_resnet_2rank_gloo_one_gpu_legs.txt 2>/dev/null || true
+for f in lsun128_f16_B64_vs_fixture.json cifar_dcgan_B64_vs_fixture.json lsun128_f16_B64_gstep_vs_fixture.json cifar_dcgan_B64_gstep_vs_fixture.json; do [ -f gpurun_out/$f ] && cp gpurun_out/$f $p/${r}_$f; done
 ls $p | grep -c "^${r}_"

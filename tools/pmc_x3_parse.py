@@ -40,7 +40,7 @@ for sym, rec in info.items():
         o['l2_hit_rate'] = round(hit / (hit + miss), 4)
     busy, mf, wave = mean('SQ_BUSY_CYCLES'), mean('SQ_VALU_MFMA_BUSY_CYCLES'), mean('SQ_WAVE_CYCLES')
     # SQ_BUSY_CYCLES is summed over the 32 SQ instances (shader engines), SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs (checked in
-    # round 1 against a kernel of known MFMA count: profiles/r01_pmc_sq_fwd_n128_h32.json): busy fraction of the matrix pipes =
+    # round 1 against a kernel of known MFMA count: profiles/history/r01_pmc_sq_fwd_n128_h32.json): busy fraction of the matrix pipes =
     # MFMA_BUSY / (1024 * BUSY / 32)
     if busy:
         busy = 1024.0 * busy / 32.0

@@ -7,7 +7,8 @@ timeout 2400 python -m pytest tests -m gpu -q --durations=15 > $o/tests_all.log 
 python bench.py --steps 30 --warmup 5 > $o/bench.json 2> $o/bench.err; echo "bench rc=$?"; head -c 300 $o/bench.json; echo
 python bench.py > $o/bench_defaults.json 2> $o/bench_defaults.err; echo "bench (default 100/20) rc=$?"; head -c 300 $o/bench_defaults.json; echo
 CTGAN_MERGED_BWD=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $o/bench_autograd_critic.json 2> /dev/null; head -c 200 $o/bench_autograd_critic.json; echo
-CTGAN_M2F_PX=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --feed device > $o/bench_m2f_ring.json 2> /dev/null
+python bench.py --steps 20 --warmup 5 > $o/bench_driver_args.json 2> /dev/null; echo "bench (driver's 20/5) rc=$?"
+for v in WGRAD_OVERLAP PREP_ASYNC; do env CTGAN_$v=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --feed device > $o/bench_$v.json 2> /dev/null; done
 python bench.py --gp-unit-only > $o/gp_unit.json 2> $o/gp_unit.err
 python tools/phase_times.py 2>/dev/null | grep -v amdgpu.ids > $o/phase_times.txt; cat $o/phase_times.txt
 bash tools/prof_run.sh $tag --steps 20 --warmup 5 > $o/prof_run.log 2>&1
@@ -17,7 +18,7 @@ bash tools/pmc_x3.sh > $o/pmc_x3.log 2>&1
 bash tools/pmc_wgrad_col.sh col d > $o/pmc_wgrad_col.log 2>&1
 timeout 120 python tools/wgrad_group_bench.py both 40 > $o/wgrad_group_bench_col.txt 2>&1
 bash tools/fewch_prof.sh > $o/fewch_prof.log 2>&1
-python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-roofline --no-cpu-baseline --feed device > $o/bench_2rank_gloo.json 2> $o/bench_2rank_gloo.err; echo "2rank rc=$?"
+python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-roofline --no-cpu-baseline --feed device > $o/bench_2rank_gloo.json 2> $o/bench_2rank_gloo.err; grep '^bench: leg' $o/bench_2rank_gloo.err; echo "2rank rc=$?"
 python bench.py --config lsun128_f16 --steps 8 --warmup 2 > $o/bench_lsun128_f16.json 2> $o/bench_lsun128_f16.err; echo "lsun rc=$?"; head -c 200 $o/bench_lsun128_f16.json; echo
 python bench.py --config cifar_dcgan_bf16 --steps 20 --warmup 5 > $o/bench_dcgan_bf16.json 2> $o/bench_dcgan_bf16.err; echo "dcgan rc=$?"; head -c 200 $o/bench_dcgan_bf16.json; echo
 python bench.py --config cifar_dcgan_f32 --steps 20 --warmup 5 --no-roofline > $o/bench_dcgan_f32.json 2> /dev/null
