@@ -81,6 +81,7 @@ DEBUG_SIGNATURES = {
     'ctgan_debug_m2f_px': (None, [c_int]),
     'ctgan_debug_last_wgrad_group_kinds': (c_int, []),
     'ctgan_debug_last_wgrad_group_col_mask': (ctypes.c_uint, []),
+    'ctgan_debug_x3_hk': (None, [c_int, c_int]),
     'ctgan_debug_clock_probe': (c_int, [c_void_p, ctypes.c_uint64, c_void_p, c_void_p]),
 }
 

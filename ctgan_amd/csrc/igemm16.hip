@@ -1036,6 +1036,203 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN <= 2 ? 3
     }
 }
 
+// ---------------------------------------------------------------------------------------------- halo patch, one channel chunk per wave
+// conv16x3hk (round 6): the halo-patch form for launches that CANNOT fill the chip with pixel tiles - the 8x8 layers of the critic at
+// 64-384 rows and the 16x16 layers at 64 rows (the penalty's double backward): 16 K pixels x 128 output channels is 512 tiles of
+// conv16x3hf_kernel<.,1> (32 pixels x 128 kout), every one of which streams the WHOLE filter (885 KB of fragments) out of L2 - 453 MB
+// per launch, 14.6 TB/s at the measured 31 us: those launches are bound by the L2 -> CU filter stream (0.33 of 2500/6, the worst of the
+// family; profiles/r05_steady_state_resnet.txt), and the 64-row ones fall back to the fp32 pipe (igemm_fwd_pipe<32x64,k4>, 18 us for
+// 1.2 GFLOP).  Bigger pixel tiles halve the stream but leave 128-256 workgroups of 72 dependent (tap, chunk) steps each.
+// Here the K axis is split INSIDE the workgroup instead:
+//   * workgroup = 64 pixels (whole rows of one image: an 8x8 image, 4 rows of a 16-wide one) x 64 output channels; wave w owns CHANNEL
+//     CHUNK w (C = 128 = 4 chunks of 32): it stages ITS chunk of the halo patch into its own LDS region (no workgroup barrier: only
+//     wave-local ordering), streams the filter fragments of (2 kout blocks, chunk w, taps 0..8) from L2 - 12 KB per tap, one tap ahead -
+//     and runs 9 taps x 2 k-steps x (2 x 2 accumulators) x 6 MFMAs: a dependent chain of 18 steps instead of 72;
+//   * the four partial sums meet in LDS (each wave parks its 64 x 64 block in its own region), ONE barrier, then every thread sums the
+//     four partials of its four float4 in the fixed order chunk 0..3 (deterministic) and applies conv16x3hf's epilogue.
+// Per launch the filter stream is (M / 64) x (Ng / 64) x 442 KB = 226 MB at 16 K pixels - half of TN = 1's - from twice as many
+// independent waves per pixel.  LDS: 4 x 3 planes x NPX x 80 B <= 104 KB: one workgroup (one wave per SIMD) per CU.
+template <bool RELU_IN>
+__global__ __launch_bounds__(256) void conv16x3hk_kernel(const P16 p, const PatchGeom pg) {
+    constexpr int MMA = CTGAN_MMA_F32X3, NP = 3, BK = 32, BMP = 64, BNK = 64, MAXIT = 14;
+    constexpr int LDS_K = BK + 8;
+    constexpr int LDE = BNK + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    const int PPLANE = pg.NPX * LDS_K;
+    const int WREG = NP * PPLANE;                           // 16-bit elements per wave region (>= 64 * LDE * 2: the partial sums fit)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = this wave's channel chunk
+    unsigned short* const Xs = smem + wave * WREG;
+    const int R = p.ph_T[0], S = p.ph_U[0], RS = R * S;
+    const int tiles_n = p.Ng / BNK;
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);       // the kout halves of a pixel tile (same patch) on one XCD
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BMP, n0 = tile_n * BNK;
+    const int nch = p.C / BK;                               // == 4 (the launcher checks)
+    const int PQ = p.P * p.Q;
+    const int img = m0 / PQ, row0 = (m0 - img * PQ) / p.Q;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Wf), 0, p.wf_bytes, 0x00020000);
+    // ---- filter fragment streams of this wave: kout blocks (n0 / 32) and (n0 / 32 + 1), chunk `wave`, taps contiguous (6 KB each)
+    const unsigned a_voff = (unsigned)lane * 16u;
+    unsigned a_soff0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)(n0 >> 5) * nch + wave) * RS) * 6144));
+    unsigned a_soff1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((((long long)((n0 >> 5) + 1) * nch + wave) * RS) * 6144));
+    u32x4 fa[2][2][2][NP];                                // [register set][kout block][k step][plane]
+    auto loadA = [&](auto setc) __attribute__((always_inline)) {
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                fa[SET][0][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, a_soff0 + (unsigned)((ks * NP + q) * 1024), 0));
+                fa[SET][1][ks][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_rsrc, a_voff, a_soff1 + (unsigned)((ks * NP + q) * 1024), 0));
+            }
+        a_soff0 += 6144u; a_soff1 += 6144u;
+    };
+    using set0 = std::integral_constant<int, 0>;
+    using set1 = std::integral_constant<int, 1>;
+    loadA(set0{});                                        // tap 0's fragments fly while the patch is staged
+    // ---- this wave's chunk of the halo patch: NPX pixels x 8 channel quads over 64 lanes
+    {
+        float4 rp[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int item = it * 64 + lane, px = item >> 3;
+            unsigned voff = 0xFFFFFFFFu;
+            if (px < pg.NPX) {
+                const int prow = px / pg.PW, pcol = px - prow * pg.PW;
+                const int ih = row0 + prow - p.ph_pad_t[0], iw = pcol - p.ph_pad_l[0];
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                    voff = (unsigned)(((long long)img * p.s_n + (long long)ih * p.s_h + (long long)iw * p.s_w + wave * BK + (item & 7) * 4) * 4);
+            }
+            rp[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, voff, 0, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int item = it * 64 + lane, px = item >> 3;
+            if (px < pg.NPX) {
+                float4 v = rp[it];
+                if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                unsigned o0[NP], o1[NP];
+                split_pk<MMA>(v.x, v.y, o0);
+                split_pk<MMA>(v.z, v.w, o1);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const u32x2 o = {o0[q], o1[q]};
+                    *reinterpret_cast<u32x2*>(&Xs[q * PPLANE + px * LDS_K + (item & 7) * 4]) = o;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): the wave reads what its own lanes wrote - no cross-wave traffic yet
+    __builtin_amdgcn_wave_barrier();
+
+    f32x16 acc[2][2];                                     // [kout block][pixel block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int h = lane >> 5, l31 = lane & 31;
+    int pix[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tp = j * 32 + l31;
+        pix[j] = ((tp / p.Q) * pg.PW + (tp % p.Q)) * LDS_K + h * 8;
+    }
+    constexpr int QW[6] = {2, 0, 1, 1, 0, 0}, QX[6] = {0, 2, 1, 0, 1, 0};      // (filter piece, pixel piece): l*h, h*l, m*m, m*h, h*m, h*h
+    int tap_off = 0, s_cnt = 0;
+    auto step = [&](auto curc, auto nxtc, bool has_next) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(curc)::value;
+        if (has_next) loadA(nxtc);                         // the next tap's filter fragments, one tap ahead
+        u32x4 fx[2][NP][2];                                // [k step][plane][pixel block]: both k steps' pixel fragments read up front
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fx[ks][q][j] = *reinterpret_cast<const u32x4*>(&Xs[q * PPLANE + pix[j] + tap_off * LDS_K + ks * 16]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int cl = 0; cl < 6; ++cl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = Cvt<MMA>::mma(fa[CUR][i][ks][QW[cl]], fx[ks][QX[cl]][j], acc[i][j]);
+        if (++s_cnt == S) { s_cnt = 0; tap_off += pg.PW - (S - 1); } else ++tap_off;
+    };
+    int st = 0;
+    for (; st + 1 < RS; st += 2) { step(set0{}, set1{}, true); step(set1{}, set0{}, st + 2 < RS); }
+    if (st < RS) step(set0{}, set1{}, false);
+
+    // ---- the four chunks' partial sums meet in LDS: each wave parks its 64 pixels x 64 kout (fp32) in its OWN region (it alone read it)
+    float* const part = reinterpret_cast<float*>(smem);
+    const int PREG = WREG / 2;                             // floats per wave region
+    {
+        float* es = part + wave * PREG;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *reinterpret_cast<float4*>(&es[(j * 32 + l31) * LDE + i * 32 + 8 * q + 4 * h]) = v;
+                }
+    }
+    __syncthreads();
+    const unsigned long long drop_step = p.drop ? (p.drop_ctr ? p.drop_ctr[0] : 0) : 0;
+    float dkeep = p.drop_keep;
+    unsigned dsid = p.drop_sid, doff4 = 0;
+    if (p.drop_nr) {
+        const bool r1 = p.drop_nr > 1 && m0 >= p.drop_mend[0], r2 = p.drop_nr > 2 && m0 >= p.drop_mend[1];
+        dkeep = r2 ? p.drop_rkeep[2] : (r1 ? p.drop_rkeep[1] : p.drop_rkeep[0]);
+        dsid = r2 ? p.drop_rsid[2] : (r1 ? p.drop_rsid[1] : p.drop_rsid[0]);
+        doff4 = (unsigned)((r2 ? p.drop_roff[2] : (r1 ? p.drop_roff[1] : p.drop_roff[0])) >> 2);
+    }
+    const bool do_drop = p.drop && dkeep < 1.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 16 + (tid >> 4), c4 = tid & 15;
+        const int m = m0 + row, col = n0 + c4 * 4;
+        float4 v = *reinterpret_cast<const float4*>(&part[row * LDE + c4 * 4]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {                      // chunk order 0, 1, 2, 3: the same sum whatever the waves' timing
+            const float4 a = *reinterpret_cast<const float4*>(&part[w * PREG + row * LDE + c4 * 4]);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        const int n = m / PQ, rem = m - n * PQ, pp = rem / p.Q, qq = rem - pp * p.Q;
+        const long long off = n * p.ds_n + pp * p.ds_p + qq * p.ds_q + col;
+        if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (p.mask) {
+            const float4 k = *reinterpret_cast<const float4*>(p.mask + off);
+            v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+        }
+        if (p.resid) {
+            const long long ro = p.resid_up ? ((((long long)n * (p.P >> 1) + (pp >> 1)) * (p.Q >> 1) + (qq >> 1)) * p.Ng + col) : off;
+            const float4 r = *reinterpret_cast<const float4*>(p.resid + ro);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (do_drop) {
+            uint32_t cc[4];
+            ctgan_philox::draw4(p.drop_seed, dsid, drop_step, (uint32_t)(off >> 2) - doff4, cc);
+            const float inv = 1.f / dkeep;
+            v.x *= inv * floorf(dkeep + ctgan_philox::u01(cc[0])); v.y *= inv * floorf(dkeep + ctgan_philox::u01(cc[1]));
+            v.z *= inv * floorf(dkeep + ctgan_philox::u01(cc[2])); v.w *= inv * floorf(dkeep + ctgan_philox::u01(cc[3]));
+        }
+        *reinterpret_cast<float4*>(p.D + off) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- slice staging, filter from L2
 // conv16x3sf (round 5): the split-mode forward of the launches the halo-patch kernels do not take - the folded ConvMeanPool / MeanPoolConv
 // filters (4x4 / 2x2, stride 2; TF/CT_gan_cifar_resnet.py:89-98) - with the filter operand streamed from L2 in fragment order, as
@@ -1806,6 +2003,43 @@ int launch_conv16x3hf_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
     return ctgan_check_launch("conv16x3hf");
 }
 
+// conv16x3hk_kernel (one channel chunk per wave, 64-pixel x 64-kout tiles): which launches it takes.  The halo-patch shapes with C = 128 whose
+// 64-pixel tiles lie inside one image, without the input batch norm, when the launch is ONE round of one workgroup per CU (<= 256
+// workgroups: 8x8 images up to 128 rows - the penalty's double backward and the generator step's critic pass - 16x16 up to 32).  Measured
+// kernel-only (tools/hk_prof.sh, profiles/r06_hk_prof.txt): 8x8 at 64 rows 17.5 us against 20.6 (conv16x3hf<.,1>) and 18.8 (fp32 pipe, where
+// these launches ran), 128 rows 18.9 against 22.2 / 29.5; from 192 rows on the pixel-tiled kernels are level or ahead (30.1 / 28.2, 44.8 / 41.2 at
+// 384 rows; 16x16 at 128 rows 57.4 / 49.1): a workgroup's 432 MFMAs per wave are 6 us of a 17 us round - the rest is launch ramp, patch staging
+// and the reduction, which more rounds do not amortise.  g_hk: 0 = never (tests / A-B: ctgan_debug_x3_hk), 1 = by the rule, 2 = every launch
+// that qualifies whatever its size.
+int g_hk = 1;
+int g_hk_max_wgs = 256;      // one round of one workgroup per CU: beyond it the pixel-tiled kernels are level or ahead (profiles/r06_hk_prof.txt)
+bool conv16x3hk_takes(const P16& p, PatchGeom* out) {
+    if (!g_hk || p.nph != 1 || p.stride != 1 || !p.Wf || p.bn_mean || p.act || p.C != 128 || p.Ng % 128 || p.M % 64) return false;
+    PatchGeom g;
+    if (!conv16x3h_ok(p, &g, 64) || g.IMGS != 1 || g.NPX > 14 * 8 || g.NPX * 60 < 64 * 68) return false;      // (14 patch items per lane; a wave region holds its 64 x 68 partial sums)
+    const long long wgs = (long long)(p.M / 64) * (p.Ng / 64);
+    if (g_hk == 1 && wgs > g_hk_max_wgs) return false;
+    if (out) *out = g;
+    return true;
+}
+template <bool RELU_IN>
+int launch_conv16x3hk_t(const P16& p, const PatchGeom& pg, hipStream_t st) {
+    const size_t bytes = (size_t)4 * 3 * pg.NPX * 40 * 2;    // four wave regions of three planes (each >= the 64 x 68 floats of its partial sums: conv16x3hk_takes)
+    static size_t have = 0;
+    if (have < bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv16x3hk_kernel<RELU_IN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+            return ctgan_fail(CTGAN_E_LAUNCH, "conv16x3hk: cannot reserve %zu B of LDS", bytes);
+        have = bytes;
+    }
+    P16 q = p;
+    q.ph_tiles_m = p.M / 64;
+    q.ksplit = 1; q.slab = nullptr;
+    hipLaunchKernelGGL((conv16x3hk_kernel<RELU_IN>), dim3((unsigned)(q.ph_tiles_m * (p.Ng / 64))), dim3(256), bytes, st, q, pg);
+    ctgan_set_last_kernel("conv16x3hk<64x64,chunk/wave>");
+    ctgan_set_last_symbol("conv16x3hk_kernel<%s>", RELU_IN ? "true" : "false");
+    return ctgan_check_launch("conv16x3hk");
+}
+
 // conv16x3sf_kernel: strided forward launches with a FRAG image; tile = 128 positions from 512 tiles up, 64 from 384, 32 (2x2 filters) from 192.  0: the launch stays on the slice kernel (no image, ragged tiles, too few workgroups for a kernel without K split)
 int g_s2fwd = 1;                      // tests / A-B: ctgan_debug_x3_s2fwd(0) puts the strided forward launches back on the slice kernel
 int g_sf_ksplit = 1;                  // A/B: ctgan_debug_x3_s2fwd(2) = no K split on conv16x3sf_kernel
@@ -1877,6 +2111,10 @@ int launch_conv16x3sf(const P16& p, int bmp, hipStream_t st) {
 }
 
 int launch_conv16x3h(const P16& p, hipStream_t st) {
+    {
+        PatchGeom pk;                 // launches that cannot fill the chip with pixel tiles: one channel chunk per wave (conv16x3hk_kernel)
+        if (conv16x3hk_takes(p, &pk)) return p.relu_in ? launch_conv16x3hk_t<true>(p, pk, st) : launch_conv16x3hk_t<false>(p, pk, st);
+    }
     // whole small images per 128-pixel tile (8x8): the LDS-staged kernel is the faster one when it applies
     const bool prefer_v1 = !g_halo_version_override && x3_8x8_mode() == 0 && p.P * p.Q < 128 && conv16x3h_ok(p, nullptr) && (long long)(p.M / 128) * (p.Ng / 128) >= 192;
     if (p.bn_mean) {                  // batch norm of the input on load: the fragment-streaming kernel, tiles inside one image, ReLU behind the norm
@@ -1932,6 +2170,7 @@ int dispatch_conv16(const P16& p, hipStream_t st) {
     const long long big_tiles = (long long)p.nph * ((p.M + 127) / 128) * ((p.Ng + 127) / 128);
     const bool small = big_tiles < 192 || p.Ng % 128 != 0;
     if constexpr (planes<MMA>() == 3) {
+        if (conv16x3hk_takes(p, nullptr)) return launch_conv16x3h(p, st);
         if (p.nph == 4 && x3_s2halo() && conv16x3p_tile(p) && big_tiles >= 96) {
             if (const int bmp = conv16x3sf_tile(p)) return launch_conv16x3sf(p, bmp, st);
             return launch_conv16x3p(p, st);
@@ -2077,6 +2316,7 @@ void ctgan_debug_x3_halo_version(int version) { g_halo_version_override = versio
 void ctgan_debug_x3_s2halo(int on) { g_s2halo = on ? 1 : 0; }
 void ctgan_debug_x3_s2fwd(int on) { g_s2fwd = on ? 1 : 0; g_sf_ksplit = on == 2 ? 0 : 1; }
 void ctgan_debug_x3_s2dgrad_sf(int on) { g_s2dgrad_sf = on; }
+void ctgan_debug_x3_hk(int mode, int max_wgs) { g_hk = mode; if (max_wgs > 0) g_hk_max_wgs = max_wgs; }
 static thread_local int g_last_group_kinds = 0;
 static thread_local unsigned g_last_group_col_mask = 0;
 int ctgan_debug_last_wgrad_group_kinds(void) { return g_last_group_kinds; }
@@ -2139,6 +2379,7 @@ int ctgan_conv2d16_x3_prefers(const ctgan_conv_desc* d, int op) {
         // the fragment-streaming halo kernel has 64- and 32-pixel tiles: the 16x16 / 8x8 layers at 64-192 rows qualify too
         P16 q = p;
         q.Wf = reinterpret_cast<const unsigned short*>(d);      // (any non-null value: only the shape matters here)
+        if (conv16x3hk_takes(q, nullptr)) return 1;          // (incl. the 64-row launches of the penalty's double backward, which the pixel-tiled kernels leave to the fp32 pipe)
         if (conv16x3hf_wins(q)) return 1;
     }
     if (!conv16x3h_ok(p, nullptr)) return 0;

@@ -908,6 +908,14 @@ def debug_m2f_px(on):
     lib.ctgan_debug_m2f_px(1 if on else 0)
 
 
+def debug_x3_hk(mode, max_wgs=0):
+    """Tests / A-B: 0 = no launch on conv16x3hk_kernel (one channel chunk per wave), 1 = launches of <= max_wgs workgroups (default 768), 2 = all that qualify."""
+    lib.ctgan_debug_x3_hk(int(mode), int(max_wgs))
+
+
+if os.environ.get('CTGAN_X3_HK') is not None:      # (bench A/B: "0", "2", or "1:<max workgroups>")
+    _hk = os.environ['CTGAN_X3_HK'].split(':')
+    debug_x3_hk(int(_hk[0]), int(_hk[1]) if len(_hk) > 1 else 0)
 if os.environ.get('CTGAN_M2F_PX') == '0':
     debug_m2f_px(False)
 if os.environ.get('CTGAN_X3_S2HALO') == '0':      # (bench A/B; the routing query ctgan_conv2d16_x3_prefers follows the switch)

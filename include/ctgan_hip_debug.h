@@ -38,6 +38,10 @@ void ctgan_debug_m2f_px(int on);
 int ctgan_debug_last_wgrad_group_kinds(void);
 /* ... and which members (bit i = groups[i]) rode the filter-column kernel                                                             */
 unsigned ctgan_debug_last_wgrad_group_col_mask(void);
+/* tests / A-B: which stride-1 halo-patch launches of the split mode run on conv16x3hk_kernel (one channel chunk per wave, 64-pixel x 64-kout tiles,
+   round 6) instead of the pixel-tiled kernels (or, at 64 rows, the fp32 pipe): mode 0 none, 1 (default) launches of at most max_wgs workgroups (default
+   768; max_wgs <= 0 keeps the current value), 2 every launch that qualifies */
+void ctgan_debug_x3_hk(int mode, int max_wgs);
 /* bench.py's roofline leg: a one-wave kernel that reads s_memrealtime (constant 100 MHz) and s_memtime (shader cycles) when it starts, polls
    `*flag` (device int32; may be NULL) and reads both again when the flag is non-zero or after max_real_ticks (100 MHz ticks, <= 2 s): launched on a
    SIDE stream next to a measured launch, out[0..3] = real0, shader0, real1, shader1 give the shader clock sustained over that launch

@@ -138,7 +138,9 @@ X3_S2_DGRAD = {(128, 128, 32, 32, 128, 4, 2): 'conv16x3sf<64x128', (128, 128, 16
 X3_S2_FWD = {(96, 64, 32, 32, 128, 4, 2): 'conv16x3sf<64x128', (128, 128, 32, 32, 128, 4, 2): 'conv16x3sf<64x128', (128, 128, 16, 16, 128, 4, 2): 'conv16x3<',
              (40, 256, 32, 32, 128, 4, 2): 'conv16x3<'}
 X3_SMALL_TILE = {(64, 32, 16, 16, 128, 3, 1): '64x128', (12, 64, 32, 32, 128, 3, 1): '64x128', (48, 32, 8, 8, 128, 3, 1): '32x128',
-                 (160, 32, 8, 8, 256, 3, 1): '32x128', (192, 128, 8, 8, 128, 3, 1): '32x128', (384, 32, 8, 8, 128, 3, 1): '32x128'}
+                 (160, 32, 8, 8, 256, 3, 1): '32x128', (384, 32, 8, 8, 128, 3, 1): '32x128'}
+# round 6: 128-channel launches of at most 768 workgroups of 64 pixels x 64 kout run one channel chunk per wave (conv16x3hk_kernel)
+X3_CHUNK_PER_WAVE = {(192, 128, 8, 8, 128, 3, 1)}
 
 
 @pytest.mark.parametrize('case', X3_CASES, ids=lambda c: 'N%d_C%d_H%dx%d_K%d_k%d_s%d' % c)
@@ -187,6 +189,8 @@ def test_f32x3_split_mode_is_as_accurate_as_the_fp32_mfma_family(K, case):
         want_kernel = 'conv16x3h' if st == 1 else 'conv16x3<128x'       # (stride 2: the slice kernel, 128 kout x 128 or 64 pixels)
         if case in X3_SMALL_TILE:
             want_kernel = 'conv16x3hf<' + X3_SMALL_TILE[case]
+        if case in X3_CHUNK_PER_WAVE:
+            want_kernel = 'conv16x3hk<'
         assert kern3['fwd'].startswith(X3_S2_FWD.get(case, want_kernel)) and (C % 128 != 0 or kern3['dgrad'].startswith(X3_S2_DGRAD.get(case, want_kernel))), kern3
     pq = geom.P * geom.Q
     if C % 128 == 0 and Ko % 128 == 0 and geom.Q % 4 == 0 and not (pq & (pq - 1)) and not (geom.Q & (geom.Q - 1)):
@@ -306,6 +310,7 @@ def test_f32x3_halo_kernel_with_filter_fragments_from_l2_equals_the_lds_staged_o
 
     def run(v):
         K.debug_x3_halo_version(v)
+        K.debug_x3_hk(0)                  # (this test is about the two pixel-tiled kernels: the chunk-per-wave kernel stays out)
         try:
             with K.mma_dtype('f32x3'):
                 a = K.conv_fwd(x, w, b, geom, resid=r, relu=True, relu_in=True)
@@ -315,11 +320,86 @@ def test_f32x3_halo_kernel_with_filter_fragments_from_l2_equals_the_lds_staged_o
                 return a, c, d, name, K.last_kernel()
         finally:
             K.debug_x3_halo_version(0)
+            K.debug_x3_hk(1)
     a1, c1, d1, n1, nd1 = run(1)
     a2, c2, d2, n2, nd2 = run(2)
     assert n1.startswith('conv16x3h<128x128') and nd1.startswith('conv16x3h<128x128'), (n1, nd1)
     assert n2.startswith('conv16x3hf<') and nd2.startswith('conv16x3hf<'), (n2, nd2)       # (its preferred tile height for the image size)
     assert torch.equal(a1, a2) and torch.equal(c1, c2) and torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize('case', [(64, 8, 128), (192, 8, 128), (256, 8, 128), (384, 8, 128), (64, 16, 128), (128, 8, 256), (32, 16, 128)],
+                         ids=lambda c: 'N%d_H%d_K%d' % c)
+def test_f32x3_chunk_per_wave_halo_kernel_against_fp64_and_the_pixel_tiled_kernels(K, case):
+    """conv16x3hk_kernel (round 6): 64-pixel x 64-kout tiles, every wave one 32-channel chunk of C = 128, the four partial sums added in the
+    fixed order chunk 0..3 - the launches that cannot fill the chip with pixel tiles (the 8x8 layers at 64-384 rows, the 16x16 layers at 64
+    rows; TF/CT_gan_cifar_resnet.py:109-141,174-178 at the shapes of the critic's blocks 2-4 and of the penalty's double backward).  Forward
+    (bias, ReLU on load, residual, ReLU), data gradient (bias, mask, residual), the epilogue dropout with sample ranges and the residual
+    through the nearest-2x upsample: against fp64 (the split mode's bound: no worse than 2x the fp32 MFMA family, floor 3e-7 / 2e-6) and
+    against the kernels the same launches ran on before (another summation order inside fp32: 2e-6 of the largest element; the same
+    Philox draws: identical keep / drop pattern)."""
+    N, Hh, Ko = case
+    C = 128
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 1000 + 3)
+    geom = K.ConvGeom(C, Hh, Hh, Ko, 3, 3, 1, False)
+    x = torch.randn(N, C, Hh, Hh, generator=g)
+    w = torch.randn(3, 3, C, Ko, generator=g) / np.sqrt(9 * C)
+    b = torch.randn(Ko, generator=g)
+    r = torch.randn(N, Ko, Hh, Hh, generator=g)
+    xd, wd, bd, rd = cl(x), w.cuda(), b.cuda(), cl(r)
+    ref_f = tf_ops.bias_add_nchw(tf_ops.conv2d_same(x.double(), w.double(), 1), b.double())
+    ref_f2 = torch.relu(tf_ops.bias_add_nchw(tf_ops.conv2d_same(torch.relu(x.double()), w.double(), 1), b.double()) + r.double())
+    # the data gradient reduces over the conv's OUTPUT channels: a conv Ko -> 128, so that its reduction side has the 128 channels the kernel takes
+    wT = torch.randn(3, 3, Ko, C, generator=g) / np.sqrt(9 * C)          # a conv Ko -> C (C = 128 output channels): its dgrad reduces over C = 128 and yields Ko channels
+    geomD = K.ConvGeom(Ko, Hh, Hh, C, 3, 3, 1, False)
+    gyD = torch.randn(N, C, Hh, Hh, generator=g)
+    xr = torch.zeros(N, Ko, Hh, Hh, dtype=torch.float64, requires_grad=True)
+    (gx_ref,) = torch.autograd.grad(tf_ops.conv2d_same(xr, wT.double(), 1), [xr], gyD.double())
+    bc = torch.randn(Ko, generator=g); m = torch.randn(N, Ko, Hh, Hh, generator=g); rr = torch.randn(N, Ko, Hh, Hh, generator=g)
+    ref_g2 = torch.where(m.double() > 0, gx_ref + bc.double().view(1, -1, 1, 1), torch.zeros_like(gx_ref)) + rr.double()
+    ctr = torch.tensor([5], dtype=torch.int64, device='cuda')
+    drop = {'ranges': [(N // 2, (0.5, 99, 3, ctr)), (N, (0.8, 99, 4, ctr))]} if (N // 2 * Hh * Hh) % 128 == 0 else (0.5, 99, 3, ctr)
+    up = cl(torch.randn(N, Ko, Hh // 2, Hh // 2, generator=g))
+
+    def run():
+        out, names = {}, {}
+        out['fwd'] = K.conv_fwd(xd, wd, bd, geom); names['fwd'] = K.last_kernel()
+        out['fwd+epi'] = K.conv_fwd(xd, wd, bd, geom, resid=rd, relu=True, relu_in=True)
+        out['dgrad'] = K.conv_dgrad(cl(gyD), wT.cuda(), geomD, N); names['dgrad'] = K.last_kernel()
+        out['dgrad+epi'] = K.conv_dgrad(cl(gyD), wT.cuda(), geomD, N, bias=bc.cuda(), mask=cl(m), resid=cl(rr))
+        out['fwd+drop'] = K.conv_fwd(xd, wd, bd, geom, relu=True, relu_in=True, drop=drop); names['drop'] = K.last_kernel()
+        out['fwd+up'] = K.conv_fwd(xd, wd, bd, geom, resid=up, resid_up=True); names['up'] = K.last_kernel()
+        return out, names
+    with K.mma_dtype('f32x3'):
+        K.debug_x3_hk(2)
+        try:
+            got, names = run()
+        finally:
+            K.debug_x3_hk(1)
+        K.debug_x3_hk(0)
+        try:
+            old, names0 = run()
+        finally:
+            K.debug_x3_hk(1)
+    assert all(v.startswith('conv16x3hk<') for v in names.values()), names
+    assert not any(v.startswith('conv16x3hk<') for v in names0.values()), names0
+    hybrid, K.X3_HYBRID = K.X3_HYBRID, False
+    try:
+        f1 = {'fwd': K.conv_fwd(xd, wd, bd, geom), 'fwd+epi': K.conv_fwd(xd, wd, bd, geom, resid=rd, relu=True, relu_in=True),
+              'dgrad': K.conv_dgrad(cl(gyD), wT.cuda(), geomD, N),
+              'dgrad+epi': K.conv_dgrad(cl(gyD), wT.cuda(), geomD, N, bias=bc.cuda(), mask=cl(m), resid=cl(rr))}      # the fp32 MFMA family
+    finally:
+        K.X3_HYBRID = hybrid
+    want = {'fwd': ref_f, 'fwd+epi': ref_f2, 'dgrad': gx_ref, 'dgrad+epi': ref_g2}
+    for what in want:
+        e3, e1 = rel_l2(got[what], want[what]), rel_l2(f1[what], want[what])
+        assert e3 <= max(2.0 * e1, 3e-7), (what, e3, e1)
+        m3, m1 = relerr(got[what], want[what]), relerr(f1[what], want[what])
+        assert m3 <= max(3.0 * m1, 2e-6), (what, m3, m1)
+    for what in got:
+        assert relerr(got[what], old[what]) < 2e-6, (what, relerr(got[what], old[what]), names[what if what in names else 'fwd'], names0)
+    assert torch.equal(got['fwd+drop'] == 0, old['fwd+drop'] == 0) or ((got['fwd+drop'] == 0) != (old['fwd+drop'] == 0)).float().mean().item() < 1e-5
+    assert 0.2 < (got['fwd+drop'] == 0).float().mean().item() < 0.95
 
 
 def test_f32x3_halo_kernel_adds_the_upsampled_residual(K):

@@ -18,7 +18,12 @@ RESNET = [(192, 128, 32, 32, 128, 3, 1), (192, 128, 32, 32, 128, 4, 2), (192, 12
 S2 = [(192, 128, 32, 32, 128, 4, 2), (128, 128, 32, 32, 128, 4, 2), (64, 128, 32, 32, 128, 4, 2), (320, 128, 32, 32, 128, 4, 2),
       (192, 128, 16, 16, 128, 4, 2), (128, 128, 16, 16, 128, 4, 2), (64, 128, 16, 16, 128, 4, 2), (320, 128, 16, 16, 128, 4, 2),
       (128, 128, 8, 8, 128, 4, 2), (320, 128, 8, 8, 128, 4, 2)]
+# round 6: the stride-1 3x3 layers whose launches cannot fill the chip with pixel tiles (run with CTGAN_X3_HK=0 / 2 and with f32)
+HK = [(64, 128, 8, 8, 128, 3, 1), (128, 128, 8, 8, 128, 3, 1), (192, 128, 8, 8, 128, 3, 1), (256, 128, 8, 8, 128, 3, 1), (384, 128, 8, 8, 128, 3, 1),
+      (64, 128, 16, 16, 128, 3, 1), (128, 128, 16, 16, 128, 3, 1), (192, 128, 16, 16, 128, 3, 1)]
 dt = sys.argv[1] if len(sys.argv) > 1 else 'f16'
+if len(sys.argv) > 2 and sys.argv[2] == 'hk':
+    SHAPES = HK
 if len(sys.argv) > 2 and sys.argv[2] == 'resnet':
     SHAPES = RESNET
 if len(sys.argv) > 2 and sys.argv[2] == 's2':
@@ -51,6 +56,8 @@ for N, C, H, W, Ko, R, st in SHAPES:
     with K.mma_dtype(dt):
         tf = timed(lambda: K.conv_fwd(x, w, None, g)); kf = K.last_kernel()
         td = timed(lambda: K.conv_dgrad(gy, w, g, N)); kd = K.last_kernel()
-        tw = timed(lambda: K.conv_wgrad(x, gy, g)); kw = K.last_kernel()
+        tw, kw = 1.0, '-'
+        if not (len(sys.argv) > 2 and sys.argv[2] == 'hk'):
+            tw = timed(lambda: K.conv_wgrad(x, gy, g)); kw = K.last_kernel()
     print('%-36s %5.0f %4.0fus %5.0f %4.0fus %5.0f %4.0fus   %s | %s | %s' % (str((N, C, H, W, Ko, R, st)), fl / tf / 1e12, tf * 1e6, fl / td / 1e12, td * 1e6,
                                                                  fl / tw / 1e12, tw * 1e6, kf, kd, kw))
