@@ -18,7 +18,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, 'counters_*.csv')):
     for r in csv.DictReader(open(f)):
         k = r.get('Kernel_Name', '')
-        m = re.search(r'((conv16x3hf|conv16x3sf|conv16x3h|conv16x3p|conv16|wgrad16_group|wgrad16|igemm_wgrad_pipe_group|igemm_fwd_pipe|m2f_px|f2m)_kernel<[^>]*>)', k)
+        m = re.search(r'((conv16x3hf|conv16x3hk|conv16x3sf|conv16x3h|conv16x3p|conv16|wgrad16_group|wgrad16|igemm_wgrad_pipe_group|igemm_fwd_pipe|m2f_px|f2m)_kernel<[^>]*>)', k)
         if m:
             agg[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 out = {'_how': 'tools/pmc_x3.sh on one MI355X: separate rocprofv3 --kernel-trace --pmc passes per counter group; means over the launches '

@@ -38,7 +38,7 @@ def case(op, N, C, H, Ko, R, st, relu=False, mode='f32x3', wide_only=False):
         alg = xb + yb + 4 * R * R * C * Ko
     elif wide_only:
         alg = max(xb, yb) + min(xb, yb) + 4 * R * R * C * Ko      # few-channel kernels: the wide tensor once (+ the few-channel image, the filter)
-    elif mode is None:
+    elif mode is None and not sym.startswith('conv16x3'):
         alg = xb + yb + 4 * R * R * C * Ko             # fp32 family: the fp32 filter
     else:
         alg = xb + yb + 6 * R * R * C * Ko             # (dy or x) + (dx or y) + three bf16 planes of the packed filter
@@ -56,7 +56,8 @@ case('fwd', 192, 128, 32, 128, 4, 2, relu=True)       # conv16x3sf_kernel<true, 
 # the penalty's double-backward convs that stay on the fp32 family (64 rows of 8x8), the one-pixel-per-lane many -> few kernel
 case('dgrad', 256, 128, 8, 128, 3, 1)                 # conv16x3hf_kernel<false, 1> at the merged backward's row count (overrides the 192-row entry)
 case('dgrad', 192, 128, 16, 128, 3, 1)                # conv16x3hf_kernel<false, 2>
-case('fwd', 64, 128, 8, 128, 3, 1, mode=None)         # igemm_fwd_pipe_kernel<1, 2, 4, ...>: 32x64 tiles, in-block K split 4
+case('fwd', 64, 128, 8, 128, 3, 1, mode=None)         # round 6: conv16x3hk_kernel<false> (one channel chunk per wave) - until round 5 igemm_fwd_pipe_kernel<1, 2, 4, ...>
+case('fwd', 64, 128, 16, 128, 4, 2, mode=None)        # igemm_fwd_pipe_kernel<1, 2, 4, ...>: what the fp32 pipe keeps of the double backward (the folded 4x4 stride-2 conv, 16x16 -> 8x8, 64 rows)
 case('dgrad', 64, 3, 32, 128, 3, 1, mode=None, wide_only=True)      # m2f_px_kernel<3>: data gradient of the first critic conv on the penalty rows
 case('fwd', 192, 3, 32, 128, 3, 1, mode=None, wide_only=True)       # f2m_kernel<3, 3, 3>: the first critic conv on [real ; fake ; x_hat]
 # (weight gradients: tools/pmc_wgrad_col.sh on the step's grouped job table)
