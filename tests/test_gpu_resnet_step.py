@@ -414,6 +414,41 @@ def test_hand_scheduled_critic_step_equals_the_autograd_path_on_gpu(setup, dim, 
             assert _rel_l2(y, x) < max(2e-5, t), (n, _rel_l2(y, x))
 
 
+def test_hand_scheduled_critic_step_with_the_switched_off_overlap_forms_on_gpu(setup, monkeypatch):
+    """The two structural attempts of round 6 that stay behind switches (both measured slower): the dropout-pass rows' weight
+    gradients on a side stream under the penalty's double backward (functional.flush_async; another split of the same sums: fp32 rounding),
+    and - through the graphed engine - the filter images rebuilt on a side stream (functional.prepare_filters_async; the same launches in
+    another order: bit-identical step outputs and weights)."""
+    import ctgan_amd.functional as F
+    from tests.test_host_logic_resnet import _scheduled_vs_autograd
+    R, lib = setup(128, 64)
+    monkeypatch.setattr(F, 'WGRAD_OVERLAP', True)
+    a, b = _scheduled_vs_autograd(R, lib, F, 64, 128, True, None)
+    for n, x, y in zip(a[2], a[1], b[1]):
+        assert (x is None) == (y is None), n
+        if x is not None and x.abs().max() > 0:
+            assert _rel_l2(y, x) < 2e-5, (n, _rel_l2(y, x))
+    monkeypatch.setattr(F, 'WGRAD_OVERLAP', False)
+    from ctgan_amd.engine import GraphedTrainer
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(F, 'PREP_ASYNC', mode)
+        lib.delete_all_params(); lib.set_seed(4)
+        R.configure(DIM_G=64, DIM_D=64, BATCH_SIZE=8)
+        R.build_params()
+        tr = R.Trainer(seed=11)
+        eng = GraphedTrainer(tr, use_graphs=True)
+        assert eng.graphed, eng.graph_error
+        g = torch.Generator().manual_seed(2)
+        batches = [(torch.randint(0, 256, (8, 3072), dtype=torch.int32, generator=g).cuda(), torch.randint(0, 10, (8,), dtype=torch.int32, generator=g).cuda()) for _ in range(5)]
+        it = iter(batches * 3)
+        outs = [eng.train_iteration(k, lambda: next(it))['cost'].item() for k in range(1, 4)]
+        torch.cuda.synchronize()
+        res[mode] = (outs, tr.d_opt.theta.clone(), tr.g_opt.theta.clone())
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+
+
 @pytest.mark.parametrize('split_mode', [True, False])
 def test_data_gradient_with_per_range_dropout_masks_equals_one_dropout_per_range(split_mode):
     """ctgan_conv2d16_dgrad_ex / ctgan_conv2d_dgrad_ex with sample ranges (round 5: the merged backward carries the rows of the dropout

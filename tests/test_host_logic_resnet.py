@@ -673,6 +673,29 @@ def test_hand_scheduled_critic_step_equals_the_autograd_path(cpu_kernels, ac, mo
         R.configure()
 
 
+def test_hand_scheduled_critic_step_with_the_early_asynchronous_weight_gradient_flush(cpu_kernels, monkeypatch):
+    """functional.flush_async (CTGAN_WGRAD_OVERLAP=1; off by default - measured slower): the weight gradients of the dropout-pass rows are
+    launched when the backward chain has produced them, the penalty's double-backward segments are accumulated onto those results by the final flush
+    (the in-place form of the grouped launch).  Same gradients as the autograd path, incl. the folded spread filters and the bias gradients that
+    only the early launch computes."""
+    import ctgan_amd.functional as F
+    import ctgan_amd.gan_cifar_resnet as R
+    import ctgan_amd.tflib as lib
+    monkeypatch.setattr(F, 'WGRAD_OVERLAP', True)
+    fired = []
+    orig = F.flush_async
+    monkeypatch.setattr(F, 'flush_async', lambda: (fired.append(orig()), fired[-1])[1])
+    try:
+        a, b = _scheduled_vs_autograd(R, lib, F, 2, 64, True, 'cpu')
+        assert fired == [True]
+        for n, x, y in zip(a[2], a[1], b[1]):
+            assert (x is None) == (y is None), n
+            if x is not None:
+                _cmp(y, x, 5e-6, 'scheduled grad (early flush) ' + n, atol=1e-8)
+    finally:
+        R.configure()
+
+
 def test_hand_scheduled_critic_step_matches_oracle_on_identical_philox_streams(cpu_kernels):
     """The scheduled step (DIM_D = 64: the width from which the first critic convs run on the direct few-channel kernels, which the
     schedule requires) through Trainer.d_step against the fp64 oracle of the reference graph AS WRITTEN, fed the same Philox streams."""
