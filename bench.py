@@ -762,7 +762,7 @@ def pipe_of(variant):
     """'bf16x6' for the split-mode kernels (fp32 products as six bf16 MFMAs: peak = dense bf16 peak / 6), 'bf16' / 'f16' for the plain
     16-bit kernels, else 'f32' (v_mfma_f32_32x32x2_f32 or packed-fp32 FMA kernels: priced against the fp32 MFMA peak)."""
     family = variant.split('<')[0].split('(')[0]        # the kernel FAMILY, not a substring: 'igemm_fwd_pipe<32x32,k4>' contains "x3" (VERDICT r4)
-    if family.startswith(('conv16x3', 'wgrad16x3')):
+    if family.startswith(('conv16x3', 'wgrad16x3', 'chain8x8')):
         return 'bf16x6'
     if family.startswith(('conv16', 'wgrad16')):
         return '16bit'

@@ -44,6 +44,24 @@ class WgradGroup(ctypes.Structure):
                 ('add_dw', ctypes.c_void_p), ('add_db', ctypes.c_void_p)]
 
 
+class ChainStep(ctypes.Structure):
+    """struct ctgan_chain_step (include/ctgan_hip.h)."""
+    _fields_ = [('wp', ctypes.c_void_p), ('mask', ctypes.c_void_p), ('post_mask', ctypes.c_void_p), ('out', ctypes.c_void_p),
+                ('resid', c_int32), ('save', c_int32), ('drop', c_int32), ('reserved', c_int32)]
+
+
+class ChainDrop(ctypes.Structure):
+    """struct ctgan_chain_drop."""
+    _fields_ = [('keep', ctypes.c_float), ('n_split', c_int32), ('stream_id_lo', ctypes.c_uint64), ('stream_id_hi', ctypes.c_uint64)]
+
+
+class Chain8x8(ctypes.Structure):
+    """struct ctgan_chain8x8."""
+    _fields_ = [('x', ctypes.c_void_p), ('n_images', c_int32), ('channels', c_int32), ('height', c_int32), ('width', c_int32),
+                ('n_convs', c_int32), ('reserved', c_int32), ('step', ChainStep * 5), ('drop', ChainDrop * 2),
+                ('drop_seed', ctypes.c_uint64), ('drop_ctr', ctypes.c_void_p)]
+
+
 class RowSegment(ctypes.Structure):
     """struct ctgan_row_segment (include/ctgan_hip.h)."""
     _fields_ = [('src_row0', c_int64), ('rows', c_int64), ('keep', ctypes.c_float), ('stream_id', ctypes.c_uint64), ('index_row0', c_int64)]
@@ -91,6 +109,7 @@ SIGNATURES = {
     'ctgan_last_error': (c_char_p, []),
     'ctgan_last_kernel': (c_char_p, []),
     'ctgan_last_symbol': (c_char_p, []),
+    'ctgan_conv2d16_chain8x8': (c_int, [POINTER(Chain8x8), _p]),
     'ctgan_conv2d_wgrad_multi_workspace_bytes': (c_size_t, [POINTER(ConvDesc), c_int32, POINTER(c_int32)]),
     'ctgan_conv2d_wgrad_multi': (c_int, [POINTER(ConvDesc), c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), POINTER(c_int32), _p, _p, _p,
                                          c_size_t, _p]),

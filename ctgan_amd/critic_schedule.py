@@ -54,6 +54,18 @@ def _dgrad(gy, w, g, N, mask=None, resid=None, drop=None, out_strides=None):
     return K.conv_dgrad(gy, w, g, N, out_strides=out_strides, bias=None, wt=F._repacked(w, g, drop is None), mask=mask, resid=resid, drop=drop)
 
 
+def _chain_ok(x, D, main_specs, gp_specs):
+    """May blocks 3-4 of the backward passes run as one launch per chain (kernels.conv_chain8x8)?  8 x 8 x 128 images in a split-mode routing, and
+    both dropout sites drawn in the kernels with one keep / seed / counter for the two row ranges (always so on the default path)."""
+    if not (hasattr(K, 'chain8x8_usable') and K.chain8x8_usable(x, D, 8, 8)):
+        return False
+    specs = list(main_specs[:2]) + list(gp_specs[:2])
+    if any(sp is None or len(sp) != 4 for sp in specs):
+        return False
+    return all(main_specs[i][0] == gp_specs[i][0] and main_specs[i][1] == gp_specs[i][1] and main_specs[i][3] is gp_specs[i][3] for i in range(2)) \
+        and main_specs[0][1] == main_specs[1][1] and main_specs[0][3] is main_specs[1][3]
+
+
 class _Grads:
     """Collects the step's parameter gradients by name.  A filter's weight gradient is requested once per use (F._wgrad: queued per
     filter inside deferred_wgrads; the FIRST request of a filter returns the buffer the flush fills, later ones return None)."""
@@ -144,13 +156,26 @@ def critic_step(tr, R, real_int, labels, fake, early=None):
     W42, W41 = P('Discriminator.4.Conv2.Filters'), P('Discriminator.4.Conv1.Filters')
     W32, W31 = P('Discriminator.3.Conv2.Filters'), P('Discriminator.3.Conv1.Filters')
     m = 3 * B                                   # rows whose data gradients are loss gradients (weight gradients come from these)
-    g_a41 = _dgrad(gy, W42, g3, T, mask=a41[:T])
+    chain = _chain_ok(gy, D, main_specs, gp_specs)
+    if chain:
+        # blocks 4 and 3 of the backward in ONE launch, one image per workgroup (kernels.conv_chain8x8, csrc/chain8x8.hip): the four data
+        # gradients with their mask / residual / ranged-dropout epilogues; every intermediate goes to HBM once (the weight gradients read them)
+        g_a41, g_z3, g_a31, g_tin = K.conv_chain8x8(gy, [
+            {'save': 1},                                                                                      # slot 1 = gy
+            {'w': W42, 'op': 1, 'mask': a41[:T], 'out': True},
+            {'w': W41, 'op': 1, 'mask': b3[:T], 'resid': 1, 'drop': 1, 'save': 2, 'out': True},               # g_z3 (slot 2)
+            {'w': W32, 'op': 1, 'mask': a31[:T], 'out': True},
+            {'w': W31, 'op': 1, 'mask': tin[:T], 'resid': 2, 'drop': 2, 'out': True}],
+            drops=[(main_specs[1][0], main_specs[1][2], gp_specs[1][2], 3 * B), (main_specs[0][0], main_specs[0][2], gp_specs[0][2], 3 * B)],
+            seed=main_specs[0][1], ctr=main_specs[0][3])
+    else:
+        g_a41 = _dgrad(gy, W42, g3, T, mask=a41[:T])
+        g_z3 = _dgrad(g_a41, W41, g3, T, mask=b3[:T], resid=gy, drop=rdrop(1))
+        g_a31 = _dgrad(g_z3, W32, g3, T, mask=a31[:T])
+        g_tin = _dgrad(g_a31, W31, g3, T, mask=tin[:T], resid=g_z3, drop=rdrop(0))
     G.wgrad('Discriminator.4.Conv2', a41[:m], gy[:m], W42, g3, True, True)
-    g_z3 = _dgrad(g_a41, W41, g3, T, mask=b3[:T], resid=gy, drop=rdrop(1))
     G.wgrad('Discriminator.4.Conv1', b3[:m], g_a41[:m], W41, g3, True, True)
-    g_a31 = _dgrad(g_z3, W32, g3, T, mask=a31[:T])
     G.wgrad('Discriminator.3.Conv2', a31[:m], g_z3[:m], W32, g3, True, True)
-    g_tin = _dgrad(g_a31, W31, g3, T, mask=tin[:T], resid=g_z3, drop=rdrop(0))
     G.wgrad('Discriminator.3.Conv1', tin[:m], g_a31[:m], W31, g3, True, True)
     # rows [real, fake | real' | x_hat] -> rows [real, fake, x_hat] of the trunk (pass 2 shares the trunk rows of the real half)
     g_h2 = K.rows_cat_bwd(g_tin, 2 * B, B, B)
@@ -212,16 +237,27 @@ def critic_step(tr, R, real_int, labels, fake, early=None):
         early({n: G.by_name[n] for c in EARLY_CONVS for n in (c + '.Filters', c + '.Biases')})
     # block 3: dropout mask, then the ReLU mask (constants of the second pass); the dropped-only tensor goes on through the shortcut
     s1, s2 = gp_specs[0], gp_specs[1]
-    r3, u = K.dropout_rng_mask(u_h2, tin[3 * B:T], s1[0], s1[1], s1[2], s1[3], want_dropped=True)
-    u_a31 = K.conv_fwd(u, W31, None, g3, mask=a31[3 * B:T])
+    if chain and K.chain8x8_usable(u_h2, D, 8, 8):
+        # blocks 3 and 4 of the double backward in ONE launch: u = (u_h2 x dropout) masked; conv, mask; conv + residual, x dropout, masked; conv,
+        # mask; conv + residual - the residuals (the dropped-only tensors r3 / r4) never leave the kernel
+        u, u_a31, u4, u_a41, u_gz = K.conv_chain8x8(u_h2, [
+            {'drop': 1, 'save': 1, 'post_mask': tin[3 * B:T], 'out': True},
+            {'w': W31, 'op': 0, 'mask': a31[3 * B:T], 'out': True},
+            {'w': W32, 'op': 0, 'resid': 1, 'drop': 2, 'save': 2, 'post_mask': b3[3 * B:T], 'out': True},
+            {'w': W41, 'op': 0, 'mask': a41[3 * B:T], 'out': True},
+            {'w': W42, 'op': 0, 'resid': 2, 'out': True}],
+            drops=[(s1[0], s1[2], s1[2], 0), (s2[0], s2[2], s2[2], 0)], seed=s1[1], ctr=s1[3])
+    else:
+        r3, u = K.dropout_rng_mask(u_h2, tin[3 * B:T], s1[0], s1[1], s1[2], s1[3], want_dropped=True)
+        u_a31 = K.conv_fwd(u, W31, None, g3, mask=a31[3 * B:T])
+        u_z3 = K.conv_fwd(u_a31, W32, None, g3, resid=r3)
+        # block 4
+        r4, u4 = K.dropout_rng_mask(u_z3, b3[3 * B:T], s2[0], s2[1], s2[2], s2[3], want_dropped=True)
+        u_a41 = K.conv_fwd(u4, W41, None, g3, mask=a41[3 * B:T])
+        u_gz = K.conv_fwd(u_a41, W42, None, g3, resid=r4)
     G.wgrad('Discriminator.3.Conv1', u, g_a31[3 * B:T], W31, g3, False, False)
-    u_z3 = K.conv_fwd(u_a31, W32, None, g3, resid=r3)
     G.wgrad('Discriminator.3.Conv2', u_a31, g_z3[3 * B:T], W32, g3, False, False)
-    # block 4
-    r4, u = K.dropout_rng_mask(u_z3, b3[3 * B:T], s2[0], s2[1], s2[2], s2[3], want_dropped=True)
-    u_a41 = K.conv_fwd(u, W41, None, g3, mask=a41[3 * B:T])
-    G.wgrad('Discriminator.4.Conv1', u, g_a41[3 * B:T], W41, g3, False, False)
-    u_gz = K.conv_fwd(u_a41, W42, None, g3, resid=r4)
+    G.wgrad('Discriminator.4.Conv1', u4, g_a41[3 * B:T], W41, g3, False, False)
     G.wgrad('Discriminator.4.Conv2', u_a41, gy[3 * B:T], W42, g3, False, False)
     # the seed dD/dz = (y > 0) w_out / hw / keep depends on w_out
     K.gp_head_wgrad(u_gz, y[3 * B:T], 1.0 / 0.5, w_out, add_to=gw_out)

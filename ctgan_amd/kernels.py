@@ -931,6 +931,78 @@ def debug_last_wgrad_group_kinds():
     return int(lib.ctgan_debug_last_wgrad_group_kinds())
 
 
+def chain8x8_usable(x, C, H, W):
+    """Can conv_chain8x8 take chains on these images?  8 x 8 x 128, dense channels-last device tensors, and a mode in which the stride-1 3x3
+    layers run in the split mode anyway (the hybrid fp32 routing or 'f32x3')."""
+    return bool(CHAIN8X8 and x.is_cuda and C == 128 and H == 8 and W == 8 and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID))
+                and x.dtype == torch.float32 and x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous())
+
+
+# A/B switch: the 8x8 blocks of the critic's backward passes as one launch per chain (csrc/chain8x8.hip) instead of one launch per conv
+CHAIN8X8 = os.environ.get('CTGAN_CHAIN8X8', '1') != '0'
+
+
+def conv_chain8x8(x, steps, drops=(), seed=0, ctr=None):
+    """Up to four 3x3 SAME convs on 8 x 8 x 128 images, one image per workgroup (ctgan_conv2d16_chain8x8).
+
+    steps[0] is the pre step (no filter), steps[1:] the convs; each a dict with
+      'w', 'op'   (convs only) the 3x3x128x128 HWIO filter and 0 = conv(., w) / 1 = its data gradient conv^T(., w)
+      'mask'      keep the value where this tensor is > 0            'resid'  1 / 2: add the value saved in that slot
+      'drop'      1 / 2: multiply by the dropout mask drops[drop-1]  'save'   1 / 2: save the value (after the dropout) in that slot
+      'post_mask' keep where > 0 (after the save)                    'out'    True: return the step's result
+    drops: up to two (keep, stream_id_lo, stream_id_hi, n_split): images below n_split draw stream_id_lo indexed from image 0, the others
+    stream_id_hi indexed from image n_split (the two row ranges of a merged pass; n_split = 0: one stream).  seed / ctr: the Philox seed and the
+    device step counter.  Returns the list of the requested results (dense channels-last, in step order)."""
+    from ._lib import Chain8x8
+    N, C, H, W = x.shape
+    assert chain8x8_usable(x, C, H, W) and 2 <= len(steps) <= 5 and len(drops) <= 2
+    _need_dev(x)
+    c = Chain8x8()
+    c.x, c.n_images, c.channels, c.height, c.width, c.n_convs = x.data_ptr(), N, C, H, W, len(steps) - 1
+    g = ConvGeom(C, H, W, C, 3, 3, 1)
+    outs, keep = [], []
+    for i, st in enumerate(steps):
+        cs = c.step[i]
+        if i:
+            w = st['w']
+            assert tuple(w.shape) == (3, 3, C, C)
+            d = g.desc(N, x.stride(), x.stride())
+            wp = _packed16(w, d, int(st['op']), g, 'f32x3')
+            keep.append(wp)
+            cs.wp = wp.data_ptr()
+        for key in ('mask', 'post_mask'):
+            t = st.get(key)
+            if t is not None:
+                _need_dev(t)
+                assert tuple(t.shape) == (N, C, H, W) and t.stride() == x.stride(), key
+                setattr(cs, key, t.data_ptr())
+        cs.resid, cs.save, cs.drop = int(st.get('resid', 0)), int(st.get('save', 0)), int(st.get('drop', 0))
+        if st.get('out'):
+            o = empty_cl(N, C, H, W, x.device)
+            outs.append(o)
+            cs.out = o.data_ptr()
+    for i, (kp, lo, hi, split) in enumerate(drops):
+        c.drop[i].keep, c.drop[i].stream_id_lo, c.drop[i].stream_id_hi, c.drop[i].n_split = float(kp), int(lo), int(hi), int(split)
+    c.drop_seed = int(seed)
+    if ctr is not None:
+        assert ctr.is_cuda and ctr.dtype == torch.int64
+        c.drop_ctr = ctr.data_ptr()
+    flops = 2.0 * N * H * W * C * 9 * C * (len(steps) - 1)
+    if PROFILE is None:
+        check(lib.ctgan_conv2d16_chain8x8(ctypes.byref(c), _stream()), 'conv2d16_chain8x8')
+    else:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        stq = torch.cuda.current_stream()
+        with ClockProbe() as probe:
+            e0.record(stq)
+            for _ in range(PROFILE_REPS):
+                check(lib.ctgan_conv2d16_chain8x8(ctypes.byref(c), _stream()), 'conv2d16_chain8x8')
+            e1.record(stq)
+        PROFILE.append((last_kernel(), flops, e0, e1, PROFILE_REPS, (N, C, H, W, C, 3, 1, len(steps) - 1), last_symbol()))
+        PROFILE_CLOCKS.append((last_symbol(), flops, probe))
+    return outs
+
+
 class ClockProbe:
     """bench.py's roofline leg: the shader clock the chip sustains while the launches inside the `with` block run.
 

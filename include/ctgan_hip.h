@@ -621,6 +621,51 @@ typedef struct ctgan_row_segment {
 int ctgan_rows_gather_dropout(const float* src, const ctgan_row_segment* segs, int32_t nseg, int64_t row_elems, uint64_t seed,
                               const uint64_t* ctr, float* dst, ctgan_stream_t stream);
 
+/* ---- vertical fusion of the critic's 8x8 residual blocks (round 6) -------------------------------------------------------------------------
+ * Blocks 3 and 4 of the ResNet critic (ResidualBlock, TF/CT_gan_cifar_resnet.py:109-141; Discriminator :174-178: dropout - block - dropout -
+ * block) on 8 x 8 x 128 images, as the backward passes see them: a chain of up to four 3x3 SAME convs in which each conv's result is masked by a
+ * ReLU pattern of the forward pass, takes a residual, is multiplied by a tf.nn.dropout mask of the forward pass (redrawn from its Philox stream,
+ * :173-177) and feeds the next conv - the data-gradient chain of compute_gradients(disc_cost) through the two blocks (:335-336) and the forward-mode
+ * pass of the gradient penalty's double backward (tf.gradients inside the loss, :284).  One workgroup carries one image through the whole chain (the
+ * image stays in LDS between the convs); every intermediate that a weight gradient reads is written once.  Split mode (CTGAN_MMA_F32X3) only.
+ *
+ *   value = x[image]
+ *   for step s = 0 .. n_convs:        (step 0 has no filter: it only applies its epilogue to x)
+ *       if s > 0: value = conv3x3_same(value, filter of step s)
+ *       if mask:       value = mask[image] > 0 ? value : 0
+ *       if resid:      value += slot[resid]                    (slot 1 / 2: values saved by earlier steps)
+ *       if drop:       value *= floor(keep + u) / keep         u: element (offset / 4) of stream drop[drop-1], step drop_ctr[0]; images below n_split draw
+ *                                                              stream_id_lo indexed from image 0, the others stream_id_hi indexed from image n_split
+ *       if save:       slot[save] = value
+ *       if post_mask:  value = post_mask[image] > 0 ? value : 0
+ *       if out:        out[image] = value
+ * All tensors dense channels-last [n_images, 8, 8, 128] fp32, 16-byte aligned.  wp: the packed image of a 3x3x128x128 filter as
+ * ctgan_conv2d16_pack_filter(.., op, CTGAN_MMA_F32X3, ..) writes it (op CTGAN_CONV_FWD: the step is conv(., w); CTGAN_CONV_DGRAD: its transpose).
+ * Deterministic (fixed summation order).  CTGAN_E_UNSUPPORTED for other image sizes / channel counts.                                           */
+#define CTGAN_CHAIN_MAX_CONVS 4
+typedef struct {
+    const void* wp;                  /* step 0: NULL */
+    const float* mask;
+    const float* post_mask;
+    float* out;
+    int32_t resid, save, drop, reserved;
+} ctgan_chain_step;
+typedef struct {
+    float keep;
+    int32_t n_split;
+    uint64_t stream_id_lo, stream_id_hi;
+} ctgan_chain_drop;
+typedef struct {
+    const float* x;
+    int32_t n_images, channels, height, width;
+    int32_t n_convs, reserved;
+    ctgan_chain_step step[CTGAN_CHAIN_MAX_CONVS + 1];
+    ctgan_chain_drop drop[2];
+    uint64_t drop_seed;
+    const uint64_t* drop_ctr;
+} ctgan_chain8x8;
+int ctgan_conv2d16_chain8x8(const ctgan_chain8x8* chain, ctgan_stream_t stream);
+
 
 
 #ifdef __cplusplus

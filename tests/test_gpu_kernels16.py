@@ -403,6 +403,76 @@ def test_f32x3_chunk_per_wave_halo_kernel_against_fp64_and_the_pixel_tiled_kerne
     assert 0.2 < (got['fwd+drop'] == 0).float().mean().item() < 0.95
 
 
+@pytest.mark.parametrize('N,split', [(64, 0), (256, 192), (8, 8)])
+def test_chain8x8_equals_the_separate_launches_and_fp64(K, N, split):
+    """ctgan_conv2d16_chain8x8 (round 6: one image per workgroup through up to four 3x3 convs on 8 x 8 x 128 images, csrc/chain8x8.hip) with
+    both programs the critic step runs: (B) the data-gradient chain of blocks 4-3 - conv^T, mask; conv^T, mask, + residual, x ranged dropout;
+    twice - and (C) the penalty's double backward - x dropout, masked; conv, mask; conv + residual, x dropout, masked; conv, mask; conv +
+    residual.  Against the same chain as separate launches (conv_dgrad / conv_fwd with their epilogues, dropout_rng_mask: another summation
+    order inside fp32, the same Philox draws - identical zero patterns) and, without the dropouts, against fp64."""
+    C, H = 128, 8
+    g = torch.Generator().manual_seed(N + 3)
+    geom = K.ConvGeom(C, H, H, C, 3, 3, 1, False)
+    ws = [(torch.randn(3, 3, C, C, generator=g) / np.sqrt(9 * C)).cuda() for _ in range(4)]
+    for w in ws:
+        K._STABLE_PTRS.add(w.data_ptr())
+    x = cl(torch.randn(N, C, H, H, generator=g))
+    masks = [cl(torch.randn(N, C, H, H, generator=g)) for _ in range(4)]
+    ctr = torch.tensor([7], dtype=torch.int64, device='cuda')
+    seed, sA0, sA1, sB0, sB1 = 99, 3, 4, 5, 6
+    with K.mma_dtype('f32x3'):
+        # ---- (B) the backward chain
+        lo = split if split else N
+        dr = lambda a, b: {'ranges': [(lo, (0.5, seed, a, ctr)), (N, (0.5, seed, b, ctr))]} if split and split < N else (0.5, seed, a if split else b, ctr)
+        got = K.conv_chain8x8(x, [{'save': 1},
+                                  {'w': ws[0], 'op': 1, 'mask': masks[0], 'out': True},
+                                  {'w': ws[1], 'op': 1, 'mask': masks[1], 'resid': 1, 'drop': 1, 'save': 2, 'out': True},
+                                  {'w': ws[2], 'op': 1, 'mask': masks[2], 'out': True},
+                                  {'w': ws[3], 'op': 1, 'mask': masks[3], 'resid': 2, 'drop': 2, 'out': True}],
+                              drops=[(0.5, sA0, sA1, split if split < N else N), (0.5, sB0, sB1, split if split < N else N)], seed=seed, ctr=ctr)
+        assert K.last_kernel().startswith('chain8x8')
+        K.debug_x3_hk(0)
+        try:
+            a1 = K.conv_dgrad(x, ws[0], geom, N, mask=masks[0])
+            a2 = K.conv_dgrad(a1, ws[1], geom, N, mask=masks[1], resid=x, drop=dr(sA0, sA1))
+            a3 = K.conv_dgrad(a2, ws[2], geom, N, mask=masks[2])
+            a4 = K.conv_dgrad(a3, ws[3], geom, N, mask=masks[3], resid=a2, drop=dr(sB0, sB1))
+        finally:
+            K.debug_x3_hk(1)
+        for i, (u, v) in enumerate(zip(got, (a1, a2, a3, a4))):
+            assert torch.equal(u == 0, v == 0) or ((u == 0) != (v == 0)).float().mean().item() < 1e-5, i
+            assert relerr(u, v) < 4e-6 * (i + 1), (i, relerr(u, v))
+        # ---- (C) the double backward (one stream per dropout: n_split = 0)
+        gotc = K.conv_chain8x8(x, [{'drop': 1, 'save': 1, 'post_mask': masks[0], 'out': True},
+                                   {'w': ws[0], 'op': 0, 'mask': masks[1], 'out': True},
+                                   {'w': ws[1], 'op': 0, 'resid': 1, 'drop': 2, 'save': 2, 'post_mask': masks[2], 'out': True},
+                                   {'w': ws[2], 'op': 0, 'mask': masks[3], 'out': True},
+                                   {'w': ws[3], 'op': 0, 'resid': 2, 'out': True}],
+                               drops=[(0.8, sA0, sA0, 0), (0.5, sB0, sB0, 0)], seed=seed, ctr=ctr)
+        K.debug_x3_hk(0)
+        try:
+            r3, u = K.dropout_rng_mask(x, masks[0], 0.8, seed, sA0, ctr, want_dropped=True)
+            u1 = K.conv_fwd(u, ws[0], None, geom, mask=masks[1])
+            z = K.conv_fwd(u1, ws[1], None, geom, resid=r3)
+            r4, u2 = K.dropout_rng_mask(z, masks[2], 0.5, seed, sB0, ctr, want_dropped=True)
+            u3 = K.conv_fwd(u2, ws[2], None, geom, mask=masks[3])
+            u4 = K.conv_fwd(u3, ws[3], None, geom, resid=r4)
+        finally:
+            K.debug_x3_hk(1)
+        for i, (a, b) in enumerate(zip(gotc, (u, u1, u2, u3, u4))):
+            assert torch.equal(a == 0, b == 0) or ((a == 0) != (b == 0)).float().mean().item() < 1e-5, i
+            assert relerr(a, b) < 4e-6 * (i + 1), (i, relerr(a, b))
+        assert torch.equal(gotc[0], u)                        # the pre step is elementwise: bit for bit
+        # ---- fp64: two convs, masks and a residual, no dropout
+        got2 = K.conv_chain8x8(x, [{'save': 1}, {'w': ws[0], 'op': 0, 'mask': masks[0], 'out': True}, {'w': ws[1], 'op': 1, 'resid': 1, 'out': True}])
+    xd = x.cpu().double()
+    y1 = torch.where(masks[0].cpu().double() > 0, tf_ops.conv2d_same(xd, ws[0].cpu().double(), 1), torch.zeros_like(xd))
+    yr = y1.clone().requires_grad_(True)
+    zin = torch.zeros_like(xd, requires_grad=True)
+    (gx,) = torch.autograd.grad(tf_ops.conv2d_same(zin, ws[1].cpu().double(), 1), [zin], y1)       # conv^T(y1, w1)
+    assert rel_l2(got2[0], y1) < 3e-7 and rel_l2(got2[1], gx + xd) < 5e-7, (rel_l2(got2[0], y1), rel_l2(got2[1], gx + xd))
+
+
 def test_f32x3_halo_kernel_adds_the_upsampled_residual(K):
     """UpsampleConv shortcut (CTGAN_RESID_UP): the dense [N, K, P/2, Q/2] residual is added through a nearest-2x upsample inside the
     halo-patch kernel's epilogue - equal to the fp32 family's result on the same inputs to fp32 rounding."""
