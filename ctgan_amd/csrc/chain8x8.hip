@@ -28,8 +28,17 @@
 // back as the NEXT layer's patch (split into its three bf16 terms; the halo is zeroed again because the partial sums used that memory).
 // Residual slots and dropout draws are thread-local: the (pixel, channel quad) -> thread map is the same in every layer.
 // Deterministic: fixed summation order, no atomics.  One image per workgroup: 64-384 workgroups of 512 threads.
+//
+// MEASURED (round 6; profiles/r06_chain_probe.txt, a diagnosis build with parts of the conv phase compiled out): NOT faster than the
+// launches it replaces - 115-120 us per four-conv chain at 256 AND at 64 images against 4 x 32 us (256 rows) / 82 us (64 rows) - and therefore
+// OFF by default (kernels.CHAIN8X8, CTGAN_CHAIN8X8=1).  A layer costs ~29 us per workgroup: ~5 us of epilogue + restaging, and a conv phase of
+// ~23 us of which 14.5 us remain with the MFMAs compiled out, with the filter stream re-reading one tap (L1 hits) and without the LDS fragment
+// reads: the 864 KB of filter fragments a workgroup pulls per layer arrive at ~27 B per clock and CU through the vector-memory path, whatever
+// their source.  One image per workgroup means 256 B of filter per MFMA (conv16x3hf at 128-pixel tiles: 128 B; at 32-pixel tiles: 512 B and the
+// same bound); only more pixels per workgroup change that, and two images' patches do not fit LDS beside the partial sums.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -91,8 +100,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     using set0 = std::integral_constant<int, 0>;
     using set1 = std::integral_constant<int, 1>;
 
-    // one step of the chain; called with CONSTANT indices into the kernel arguments (a run-time index would move the table to scratch)
-    auto run_step = [&](const ChainStep& L, const bool last) __attribute__((always_inline)) {
+    // ONE copy of the step's code, looped (five inlined copies were 60 KB of straight-line code run once per workgroup: 128 us per launch, most of
+    // it instruction fetch); the step's record is picked with constant indices - a run-time index into the kernel arguments would move the
+    // table to scratch
+    const int ns = p.n_steps;
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
+        ChainStep L;
+        switch (s) {
+            case 0: L = p.s[0]; break;
+            case 1: L = p.s[1]; break;
+            case 2: L = p.s[2]; break;
+            case 3: L = p.s[3]; break;
+            default: L = p.s[4]; break;
+        }
+        const bool last = s + 1 == ns;
         if (L.Wf) {
             // ---- conv: this wave's chunk x kout half; the patch of `val` was staged at the end of the previous step
             const __amdgpu_buffer_rsrc_t f_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(L.Wf), 0, L.wf_bytes, 0x00020000);
@@ -142,9 +164,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (++s_cnt == 3) { s_cnt = 0; tap_off += CH_PW - 2; } else ++tap_off;
             };
             loadA(set0{});
-            tap(set0{}, set1{}, true); tap(set1{}, set0{}, true); tap(set0{}, set1{}, true); tap(set1{}, set0{}, true);
-            tap(set0{}, set1{}, true); tap(set1{}, set0{}, true); tap(set0{}, set1{}, true); tap(set1{}, set0{}, true);
+#pragma unroll 1
+            for (int t2 = 0; t2 < 4; ++t2) { tap(set0{}, set1{}, true); tap(set1{}, set0{}, true); }      // taps 0..7: a LOOP (the instruction cache keeps its body)
             tap(set0{}, set1{}, false);
+            // (a third register set - fragments two taps ahead - spills: 290 registers; and the stream is not latency- but rate-bound, see below)
             __syncthreads();                               // every wave has read the patch: its memory becomes the partial sums
             float* es = part + chunk * CH_PART;
 #pragma unroll
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 v.x += one ? ra.x : rb.x; v.y += one ? ra.y : rb.y; v.z += one ? ra.z : rb.z; v.w += one ? ra.w : rb.w;
             }
             if (L.drop) {
-                const ChainDropSpec D = L.drop == 1 ? p.d[0] : p.d[1];      // (constant indices: see run_step)
+                const ChainDropSpec D = L.drop == 1 ? p.d[0] : p.d[1];      // (constant indices)
                 const bool hi = img >= D.n_split;
                 const unsigned sid = hi ? D.sid_hi : D.sid_lo;
                 const long long rel = off - (hi ? (long long)D.n_split * (CH_PX * CH_C) : 0);
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (L.out) *reinterpret_cast<float4*>(L.out + off) = v;
             val[it] = v;
         }
-        if (last) return;
+        if (last) break;
         // ---- `val` becomes the next conv's halo patch: three bf16 planes per chunk, halo pixels zero
         for (int i = tid; i < 36 * 4 * CH_NP * 4; i += 512) {          // 36 halo pixels x 4 chunks x 3 planes x 4 x 16 B
             const int part16 = i & 3, r = i >> 2, pl = r % CH_NP, r2 = r / CH_NP, ck = r2 & 3, hp = r2 >> 2;
@@ -231,13 +254,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         __syncthreads();
-    };
-    const int ns = p.n_steps;
-    run_step(p.s[0], ns == 1);
-    if (ns > 1) run_step(p.s[1], ns == 2);
-    if (ns > 2) run_step(p.s[2], ns == 3);
-    if (ns > 3) run_step(p.s[3], ns == 4);
-    if (ns > 4) run_step(p.s[4], true);
+    }
 }
 
 }  // namespace

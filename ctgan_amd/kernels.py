@@ -931,15 +931,21 @@ def debug_last_wgrad_group_kinds():
     return int(lib.ctgan_debug_last_wgrad_group_kinds())
 
 
-def chain8x8_usable(x, C, H, W):
+def chain8x8_supported(x, C, H, W):
     """Can conv_chain8x8 take chains on these images?  8 x 8 x 128, dense channels-last device tensors, and a mode in which the stride-1 3x3
     layers run in the split mode anyway (the hybrid fp32 routing or 'f32x3')."""
-    return bool(CHAIN8X8 and x.is_cuda and C == 128 and H == 8 and W == 8 and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID))
+    return bool(x.is_cuda and C == 128 and H == 8 and W == 8 and (MMA_DTYPE == 'f32x3' or (MMA_DTYPE is None and X3_HYBRID))
                 and x.dtype == torch.float32 and x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous())
 
 
-# A/B switch: the 8x8 blocks of the critic's backward passes as one launch per chain (csrc/chain8x8.hip) instead of one launch per conv
-CHAIN8X8 = os.environ.get('CTGAN_CHAIN8X8', '1') != '0'
+def chain8x8_usable(x, C, H, W):
+    """... and does the step want them (the CHAIN8X8 switch)?"""
+    return bool(CHAIN8X8 and chain8x8_supported(x, C, H, W))
+
+
+# A/B switch (off: measured level-to-slower, 12.85 against 12.80 ms per iteration - the chain is bound by the rate at which one CU can pull a layer's
+# filter fragments, DESIGN 4.9): the 8x8 blocks of the critic's backward passes as one launch per chain (csrc/chain8x8.hip) instead of one per conv
+CHAIN8X8 = os.environ.get('CTGAN_CHAIN8X8', '0') == '1'
 
 
 def conv_chain8x8(x, steps, drops=(), seed=0, ctr=None):
@@ -955,7 +961,7 @@ def conv_chain8x8(x, steps, drops=(), seed=0, ctr=None):
     device step counter.  Returns the list of the requested results (dense channels-last, in step order)."""
     from ._lib import Chain8x8
     N, C, H, W = x.shape
-    assert chain8x8_usable(x, C, H, W) and 2 <= len(steps) <= 5 and len(drops) <= 2
+    assert chain8x8_supported(x, C, H, W) and 2 <= len(steps) <= 5 and len(drops) <= 2
     _need_dev(x)
     c = Chain8x8()
     c.x, c.n_images, c.channels, c.height, c.width, c.n_convs = x.data_ptr(), N, C, H, W, len(steps) - 1

@@ -415,7 +415,7 @@ def test_hand_scheduled_critic_step_equals_the_autograd_path_on_gpu(setup, dim, 
 
 
 def test_hand_scheduled_critic_step_with_the_switched_off_overlap_forms_on_gpu(setup, monkeypatch):
-    """The two structural attempts of round 6 that stay behind switches (both measured slower): the dropout-pass rows' weight
+    """The structural attempts of round 6 that stay behind switches (all measured level or slower): the dropout-pass rows' weight
     gradients on a side stream under the penalty's double backward (functional.flush_async; another split of the same sums: fp32 rounding),
     and - through the graphed engine - the filter images rebuilt on a side stream (functional.prepare_filters_async; the same launches in
     another order: bit-identical step outputs and weights)."""
@@ -429,6 +429,23 @@ def test_hand_scheduled_critic_step_with_the_switched_off_overlap_forms_on_gpu(s
         if x is not None and x.abs().max() > 0:
             assert _rel_l2(y, x) < 2e-5, (n, _rel_l2(y, x))
     monkeypatch.setattr(F, 'WGRAD_OVERLAP', False)
+    # ... and blocks 3-4 of the backward chain / of the penalty's double backward as ONE launch each (kernels.conv_chain8x8, csrc/chain8x8.hip;
+    # CTGAN_CHAIN8X8=1): the same sums in another order
+    import ctgan_amd.kernels as K
+    monkeypatch.setattr(K, 'CHAIN8X8', True)
+    seen = []
+    orig = K.conv_chain8x8
+    monkeypatch.setattr(K, 'conv_chain8x8', lambda *a, **k: (seen.append(len(a[1])), orig(*a, **k))[1])
+    a, b = _scheduled_vs_autograd(R, lib, F, 64, 128, True, None)
+    assert seen == [5, 5], seen
+    for k in ('cost', 'gp', 'ct'):
+        _cmp(b[0][k], a[0][k], 1e-5, 'scheduled (chains).' + k, atol=1e-6)
+    for n, x, y in zip(a[2], a[1], b[1]):
+        assert (x is None) == (y is None), n
+        if x is not None and x.abs().max() > 0:
+            assert _rel_l2(y, x) < 2e-5, (n, _rel_l2(y, x))
+    monkeypatch.setattr(K, 'CHAIN8X8', False)
+    monkeypatch.setattr(K, 'conv_chain8x8', orig)
     from ctgan_amd.engine import GraphedTrainer
     res = {}
     for mode in (False, True):
