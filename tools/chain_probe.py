@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Launch ctgan_conv2d16_chain8x8 (four convs, the backward program of critic_schedule) repeatedly on N images, for rocprofv3 kernel durations under
-the diagnosis bits of CTGAN_CHAIN_DBG (csrc/chain8x8.hip; results wrong by design).  usage: python tools/chain_probe.py [N]"""
+"""Launch ctgan_conv2d16_chain8x8 (four convs, the backward program of critic_schedule) repeatedly on N images, for rocprofv3 kernel durations
+(tools/chain_probe.sh).  usage: python tools/chain_probe.py [N]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
