@@ -7,7 +7,10 @@ cp $o/tests_all.log $p/${r}_gpu_tests.log
 cp $o/bench.json $p/${r}_bench_resnet.json
 cp $o/bench_defaults.json $p/${r}_bench_resnet_defaults.json
 cp $o/bench_driver_args.json $p/${r}_bench_resnet_driver_args.json
-for v in WGRAD_OVERLAP PREP_ASYNC; do cp $o/bench_$v.json $p/${r}_bench_resnet_$v.json; done
+for v in WGRAD_OVERLAP PREP_ASYNC CHAIN8X8 X3_HK0; do cp $o/bench_$v.json $p/${r}_bench_resnet_$v.json; done
+cp gpurun_out/hk_prof.txt $p/${r}_hk_prof.txt
+cp gpurun_out/chain_probe.txt $p/${r}_chain_kernel_times.txt
+cp gpurun_out/winograd_probe.txt $p/${r}_winograd_probe.txt; cp gpurun_out/mfma_loop_probe.txt $p/${r}_mfma_loop_probe.txt
 cp $o/bench_autograd_critic.json $p/${r}_bench_resnet_autograd_critic_step.json
 cp $o/bench_2rank_gloo.json $p/${r}_bench_resnet_2rank_gloo_one_gpu.json
 cp $o/gp_unit.json $p/${r}_gp_unit.json

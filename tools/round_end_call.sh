@@ -8,7 +8,11 @@ python bench.py --steps 30 --warmup 5 > $o/bench.json 2> $o/bench.err; echo "ben
 python bench.py > $o/bench_defaults.json 2> $o/bench_defaults.err; echo "bench (default 100/20) rc=$?"; head -c 300 $o/bench_defaults.json; echo
 CTGAN_MERGED_BWD=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $o/bench_autograd_critic.json 2> /dev/null; head -c 200 $o/bench_autograd_critic.json; echo
 python bench.py --steps 20 --warmup 5 > $o/bench_driver_args.json 2> /dev/null; echo "bench (driver's 20/5) rc=$?"
-for v in WGRAD_OVERLAP PREP_ASYNC; do env CTGAN_$v=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --feed device > $o/bench_$v.json 2> /dev/null; done
+for v in WGRAD_OVERLAP PREP_ASYNC CHAIN8X8; do env CTGAN_$v=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --feed device > $o/bench_$v.json 2> /dev/null; done
+CTGAN_X3_HK=0 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --feed device > $o/bench_X3_HK0.json 2> /dev/null
+bash tools/hk_prof.sh > $o/hk_prof.log 2>&1
+bash tools/chain_probe.sh > $o/chain_probe.log 2>&1
+(hipcc --offload-arch=gfx950 -O3 tools/winograd_probe.hip -o /tmp/wp 2>/dev/null && timeout 120 /tmp/wp > gpurun_out/winograd_probe.txt; hipcc --offload-arch=gfx950 -O3 tools/mfma_loop_probe.hip -o /tmp/mp 2>/dev/null && timeout 120 /tmp/mp > gpurun_out/mfma_loop_probe.txt)
 python bench.py --gp-unit-only > $o/gp_unit.json 2> $o/gp_unit.err
 python tools/phase_times.py 2>/dev/null | grep -v amdgpu.ids > $o/phase_times.txt; cat $o/phase_times.txt
 bash tools/prof_run.sh $tag --steps 20 --warmup 5 > $o/prof_run.log 2>&1
