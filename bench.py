@@ -64,7 +64,7 @@ def main():
                          '(engine.AR_IN_GRAPH; default: eager all-reduce on a side stream between per-step graphs)')
     ap.add_argument('--no-ab-legs', action='store_true',
                     help='N > 1: do not start the A/B legs (in-graph RCCL collectives, split flush) after the record has been printed')
-    ap.add_argument('--leg-timeout', type=float, default=240.0, help='N > 1: seconds an A/B leg (a fresh group of rank processes) may take before it is killed')
+    ap.add_argument('--leg-timeout', type=float, default=150.0, help='N > 1: seconds an A/B leg (a fresh group of rank processes) may take before it is killed')
     ap.add_argument('--leg', default=None, choices=sorted(LEGS),
                     help='(internal) this process is one rank of an A/B leg started by a rank of the main run AFTER it printed its record: '
                          'prints a short record of its own, never starts legs')
